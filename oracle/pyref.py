@@ -1,0 +1,405 @@
+"""CPU oracle (pure Python integers) for the Paillier-in-Halo2 hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product path (paillier_halo2_amd/, include/)
+may import this module; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg may.  It restates, with Python `int`/`pow`, the arithmetic that the reference computes
+with num-bigint and with its (un-vendored) halo2curves / halo2-axiom / biguint-halo2
+dependencies.
+
+PARITY STATUS: "parity unpinned" for proof / commitment / cell-layout bytes -- the reference
+(/root/reference, 548 lines of Rust) holds no golden vectors, KATs or fixtures
+ and cannot be built here (no cargo/rustc, un-vendored git
+deps).  What IS pinned, by mathematics: every function below has a unique correct output
+(modular products, the MSM group element in affine form, the DFT over Fr), so the oracle is
+cross-checked three independent ways in tests/test_oracle.py (Python int vs the C restatement
+in oracle/pz_oracle.c vs closed forms such as the discrete-log identity for walk bases).
+
+Reference anchors:
+  paillier_enc_native / paillier_add_native   -> /root/reference/src/paillier.rs:87-97
+  get_biguint (limb fold, little-endian limbs) -> /root/reference/src/paillier.rs:22-30
+  encrypt / add operation order                -> /root/reference/src/paillier.rs:32-60, 62-85
+  harness order (assign n,g,m,r -> encrypt ..) -> /root/reference/src/bench.rs:33-117
+  pow_mod_fixed_exp schedule (LSB->MSB, square every bit, multiply on set bits, acc=1)
+      -> dependency biguint-halo2 (git aerius-labs/biguint-halo2, unpinned; Cargo.toml:11),
+         call sites paillier.rs:51,55; restated from the halo2-rsa BigUintChip lineage.
+  best_multiexp / best_fft semantics -> dependency halo2curves (unpinned, via Cargo.toml:9-10).
+"""
+from __future__ import annotations
+
+import random
+from typing import Iterable, List, Sequence, Tuple
+
+# ----------------------------------------------------------------------------------------
+# BN254 constants (verified numerically there and again in tests/test_oracle.py)
+# ----------------------------------------------------------------------------------------
+FQ_P = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+FR_R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+FR_S = 28  # two-adicity of r-1
+FR_GENERATOR = 7
+FR_ROOT_OF_UNITY = pow(FR_GENERATOR, (FR_R - 1) >> FR_S, FR_R)
+MONT_R = 1 << 256
+G1_B = 3
+G1_GEN = (1, 2)
+MASK64 = (1 << 64) - 1
+
+
+# ----------------------------------------------------------------------------------------
+# limb / Montgomery helpers: the in-memory layout of halo2curves Fr/Fq is 4 x u64 little-endian
+# limbs of (a * 2^256 mod p)  
+# ----------------------------------------------------------------------------------------
+def to_limbs(x: int, n: int) -> List[int]:
+    assert 0 <= x < (1 << (64 * n)), "value does not fit"
+    return [(x >> (64 * i)) & MASK64 for i in range(n)]
+
+
+def from_limbs(limbs: Iterable[int]) -> int:
+    acc = 0
+    for i, l in enumerate(limbs):
+        acc |= int(l) << (64 * i)
+    return acc
+
+
+def to_mont(x: int, mod: int) -> int:
+    return (x * MONT_R) % mod
+
+
+def from_mont(x: int, mod: int) -> int:
+    return (x * pow(MONT_R, -1, mod)) % mod
+
+
+# ----------------------------------------------------------------------------------------
+# Paillier native formulas  (paillier.rs:87-97)
+# ----------------------------------------------------------------------------------------
+def paillier_enc_native(n: int, g: int, m: int, r: int) -> int:
+    """paillier.rs:87-92: n2 = n*n; (g.modpow(m,n2) * r.modpow(n,n2)) % n2"""
+    n2 = n * n
+    gm = pow(g, m, n2)
+    rn = pow(r, n, n2)
+    return (gm * rn) % n2
+
+
+def paillier_add_native(n: int, c1: int, c2: int) -> int:
+    """paillier.rs:94-97"""
+    n2 = n * n
+    return (c1 * c2) % n2
+
+
+def decompose_biguint(x: int, num_limbs: int, limb_bits: int) -> List[int]:
+    """assign_integer's limb split: little-endian limbs of width limb_bits."""
+    mask = (1 << limb_bits) - 1
+    out = [(x >> (limb_bits * i)) & mask for i in range(num_limbs)]
+    assert x >> (limb_bits * num_limbs) == 0, "integer does not fit in num_limbs"
+    return out
+
+
+def get_biguint(limbs: Sequence[int], max_limb_bits: int) -> int:
+    """paillier.rs:22-30: fold limbs MSB->LSB with shift max_limb_bits."""
+    acc = 0
+    for limb in reversed(list(limbs)):
+        acc = (acc << max_limb_bits) + int(limb)
+    return acc
+
+
+def exp_bits_lsb_first(e: int) -> List[int]:
+    """pow_mod_fixed_exp decomposes e into bits_size(e) bits, LSB first (e == 0 -> no bits)."""
+    return [(e >> i) & 1 for i in range(e.bit_length())]
+
+
+Step = Tuple[int, int, int, int]  # (a, b, q, r) with a*b == q*modulus + r, 0 <= r < modulus
+
+
+def mul_mod_step(a: int, b: int, modulus: int) -> Step:
+    """BigUintChip::mul_mod witness part: full = a*b; (q, r) = full.div_rem(modulus)."""
+    q, r = divmod(a * b, modulus)
+    return (a, b, q, r)
+
+
+def pow_mod_fixed_exp_trace(a: int, e: int, modulus: int) -> Tuple[int, List[Step]]:
+    """Step trace of BigUintChip::pow_mod_fixed_exp:
+
+        acc = 1; squared = a
+        for bit in bits(e) LSB->MSB:
+            cur = squared
+            squared = square_mod(cur)              # emitted for EVERY bit (the last one is unused)
+            if bit: acc = mul_mod(acc, cur)
+        return acc
+
+    Returns (acc, steps) with steps in emission order.
+    """
+    steps: List[Step] = []
+    acc = 1
+    squared = a
+    for bit in exp_bits_lsb_first(e):
+        cur = squared
+        st = mul_mod_step(cur, cur, modulus)
+        steps.append(st)
+        squared = st[3]
+        if bit:
+            st = mul_mod_step(acc, cur, modulus)
+            steps.append(st)
+            acc = st[3]
+    return acc, steps
+
+
+def encrypt_trace(n: int, g: int, m: int, r: int) -> Tuple[int, List[Step], List[Step], Step]:
+    """Operation order of PaillierChip::encrypt (paillier.rs:32-60):
+    n2 = n^2 (square + refresh), gm = pow_mod_fixed_exp(g_ext, m, n2),
+    rn = pow_mod_fixed_exp(r_ext, n, n2), c = mul_mod(gm, rn, n2)."""
+    n2 = n * n
+    gm, steps_g = pow_mod_fixed_exp_trace(g, m, n2)
+    rn, steps_r = pow_mod_fixed_exp_trace(r, n, n2)
+    final = mul_mod_step(gm, rn, n2)
+    return final[3], steps_g, steps_r, final
+
+
+def add_trace(n: int, c1: int, c2: int) -> Tuple[int, Step]:
+    """PaillierChip::add (paillier.rs:62-85): one mul_mod(c1_ext, c2_ext, n2)."""
+    st = mul_mod_step(c1, c2, n * n)
+    return st[3], st
+
+
+# ----------------------------------------------------------------------------------------
+# BN254 G1 (y^2 = x^3 + 3), affine identity encoded as (0, 0) like halo2curves G1Affine
+# ----------------------------------------------------------------------------------------
+Affine = Tuple[int, int]
+Jac = Tuple[int, int, int]
+AFF_INF: Affine = (0, 0)
+JAC_INF: Jac = (0, 1, 0)
+
+
+def g1_is_on_curve(pt: Affine) -> bool:
+    x, y = pt
+    if pt == AFF_INF:
+        return True
+    return (y * y - x * x * x - G1_B) % FQ_P == 0
+
+
+def jac_double(pt: Jac) -> Jac:
+    X, Y, Z = pt
+    if Z == 0 or Y == 0:
+        return JAC_INF
+    p = FQ_P
+    A = X * X % p
+    B = Y * Y % p
+    C = B * B % p
+    D = 2 * ((X + B) * (X + B) - A - C) % p
+    E = 3 * A % p
+    F = E * E % p
+    X3 = (F - 2 * D) % p
+    Y3 = (E * (D - X3) - 8 * C) % p
+    Z3 = 2 * Y * Z % p
+    return (X3, Y3, Z3)
+
+
+def jac_add(a: Jac, b: Jac) -> Jac:
+    if a[2] == 0:
+        return b
+    if b[2] == 0:
+        return a
+    p = FQ_P
+    X1, Y1, Z1 = a
+    X2, Y2, Z2 = b
+    Z1Z1 = Z1 * Z1 % p
+    Z2Z2 = Z2 * Z2 % p
+    U1 = X1 * Z2Z2 % p
+    U2 = X2 * Z1Z1 % p
+    S1 = Y1 * Z2 * Z2Z2 % p
+    S2 = Y2 * Z1 * Z1Z1 % p
+    if U1 == U2:
+        if S1 == S2:
+            return jac_double(a)
+        return JAC_INF
+    H = (U2 - U1) % p
+    R = (S2 - S1) % p
+    HH = H * H % p
+    HHH = H * HH % p
+    V = U1 * HH % p
+    X3 = (R * R - HHH - 2 * V) % p
+    Y3 = (R * (V - X3) - S1 * HHH) % p
+    Z3 = Z1 * Z2 * H % p
+    return (X3, Y3, Z3)
+
+
+def aff_to_jac(pt: Affine) -> Jac:
+    if pt == AFF_INF:
+        return JAC_INF
+    return (pt[0], pt[1], 1)
+
+
+def jac_to_aff(pt: Jac) -> Affine:
+    X, Y, Z = pt
+    if Z == 0:
+        return AFF_INF
+    zi = pow(Z, -1, FQ_P)
+    zi2 = zi * zi % FQ_P
+    return (X * zi2 % FQ_P, Y * zi2 * zi % FQ_P)
+
+
+def aff_neg(pt: Affine) -> Affine:
+    if pt == AFF_INF:
+        return pt
+    return (pt[0], (-pt[1]) % FQ_P)
+
+
+def g1_mul(pt: Affine, k: int) -> Affine:
+    k %= FR_R
+    acc = JAC_INF
+    base = aff_to_jac(pt)
+    for i in reversed(range(k.bit_length())):
+        acc = jac_double(acc)
+        if (k >> i) & 1:
+            acc = jac_add(acc, base)
+    return jac_to_aff(acc)
+
+
+def g1_add_aff(a: Affine, b: Affine) -> Affine:
+    return jac_to_aff(jac_add(aff_to_jac(a), aff_to_jac(b)))
+
+
+def msm_naive(scalars: Sequence[int], bases: Sequence[Affine]) -> Affine:
+    """Definition of best_multiexp's value: sum_i scalars[i] * bases[i] (double-and-add)."""
+    assert len(scalars) == len(bases)
+    acc = JAC_INF
+    for s, b in zip(scalars, bases):
+        acc = jac_add(acc, aff_to_jac(g1_mul(b, s)))
+    return jac_to_aff(acc)
+
+
+def msm_pippenger(scalars: Sequence[int], bases: Sequence[Affine], c: int | None = None) -> Affine:
+    """Bucket method, same value as msm_naive; used for the larger golden cases."""
+    n = len(scalars)
+    assert n == len(bases)
+    if n == 0:
+        return AFF_INF
+    if c is None:
+        c = 3 if n < 32 else max(3, n.bit_length() - 2)
+    nwin = (254 + c - 1) // c
+    total = JAC_INF
+    for w in reversed(range(nwin)):
+        for _ in range(c):
+            total = jac_double(total)
+        buckets = [JAC_INF] * ((1 << c) - 1)
+        for s, b in zip(scalars, bases):
+            d = ((s % FR_R) >> (w * c)) & ((1 << c) - 1)
+            if d:
+                buckets[d - 1] = jac_add(buckets[d - 1], aff_to_jac(b))
+        run = JAC_INF
+        acc = JAC_INF
+        for bkt in reversed(buckets):
+            run = jac_add(run, bkt)
+            acc = jac_add(acc, run)
+        total = jac_add(total, acc)
+    return jac_to_aff(total)
+
+
+def walk_bases(n: int, s: int, t: int) -> List[Affine]:
+    """P_i = [s + i*t] G for i < n  (the seeded walk of SURVEY.md section 8d, config c4).
+    Known discrete logs give the size-independent MSM check  sum k_i P_i = [sum k_i (s+i t)] G."""
+    out: List[Affine] = []
+    step = aff_to_jac(g1_mul(G1_GEN, t))
+    cur = aff_to_jac(g1_mul(G1_GEN, s))
+    for _ in range(n):
+        out.append(jac_to_aff(cur))
+        cur = jac_add(cur, step)
+    return out
+
+
+def msm_walk_expected(scalars: Sequence[int], s: int, t: int) -> Affine:
+    k = 0
+    for i, sc in enumerate(scalars):
+        k = (k + sc * (s + i * t)) % FR_R
+    return g1_mul(G1_GEN, k)
+
+
+# ----------------------------------------------------------------------------------------
+# NTT over Fr: value semantics of halo2curves best_fft(a, omega, log_n):
+#   out[k] = sum_j a[j] * omega^(j*k)   (in-place, natural order in and out)
+# ----------------------------------------------------------------------------------------
+def fr_omega(log_n: int) -> int:
+    """omega for a 2^log_n domain = ROOT_OF_UNITY^(2^(28-log_n))  (SURVEY.md section 8a row a8)."""
+    assert 0 <= log_n <= FR_S
+    return pow(FR_ROOT_OF_UNITY, 1 << (FR_S - log_n), FR_R)
+
+
+def ntt_naive(a: Sequence[int], omega: int) -> List[int]:
+    n = len(a)
+    return [sum(a[j] * pow(omega, j * k, FR_R) for j in range(n)) % FR_R for k in range(n)]
+
+
+def ntt(a: Sequence[int], omega: int) -> List[int]:
+    """Iterative radix-2 DIT following best_fft's structure: bit-reverse, then log_n butterfly
+    layers with twiddle omega^(n/(2m))."""
+    n = len(a)
+    log_n = n.bit_length() - 1
+    assert 1 << log_n == n
+    a = list(a)
+    for k in range(n):
+        rk = int(format(k, "0%db" % log_n)[::-1], 2) if log_n else 0
+        if k < rk:
+            a[k], a[rk] = a[rk], a[k]
+    m = 1
+    for _ in range(log_n):
+        w_m = pow(omega, n // (2 * m), FR_R)
+        for k in range(0, n, 2 * m):
+            w = 1
+            for j in range(m):
+                t = a[k + j + m] * w % FR_R
+                a[k + j + m] = (a[k + j] - t) % FR_R
+                a[k + j] = (a[k + j] + t) % FR_R
+                w = w * w_m % FR_R
+        m *= 2
+    return a
+
+
+def intt(a: Sequence[int], omega: int) -> List[int]:
+    """EvaluationDomain::ifft = best_fft with omega^-1 then scale by n^-1."""
+    n = len(a)
+    out = ntt(a, pow(omega, -1, FR_R))
+    ninv = pow(n, -1, FR_R)
+    return [x * ninv % FR_R for x in out]
+
+
+def coset_scale(a: Sequence[int], g: int) -> List[int]:
+    """distribute_powers: a[i] *= g^i (used by coeff_to_extended before the extended NTT)."""
+    out = []
+    cur = 1
+    for x in a:
+        out.append(x * cur % FR_R)
+        cur = cur * g % FR_R
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# seeded synthetic inputs
+# ----------------------------------------------------------------------------------------
+def synth_paillier_inputs(enc_bits: int, seed: int, standard_g: bool = True):
+    """n = p*q forced to exactly enc_bits bits (p, q random odd enc_bits/2-bit with top bit set;
+    primality NOT required -- the reference feeds a raw random n, paillier.rs:173), g = n+1 or
+    random < n, m uniform in [0,n), r uniform in [1,n)."""
+    rng = random.Random(seed)
+    half = enc_bits // 2
+    while True:
+        p = rng.getrandbits(half) | (1 << (half - 1)) | 1
+        q = rng.getrandbits(half) | (1 << (half - 1)) | 1
+        n = p * q
+        if n.bit_length() == enc_bits:
+            break
+    g = n + 1 if standard_g else rng.randrange(2, n)
+    m = rng.randrange(0, n)
+    r = rng.randrange(1, n)
+    return n, g, m, r
+
+
+def witness_like_scalars(n: int, seed: int) -> List[int]:
+    """c4 scalar mix (ii): 60 % < 2^16, 30 % < 2^64, 10 % < 2^135  (SURVEY.md section 8d)."""
+    rng = random.Random(seed)
+    out = []
+    for _ in range(n):
+        u = rng.random()
+        if u < 0.6:
+            out.append(rng.getrandbits(16))
+        elif u < 0.9:
+            out.append(rng.getrandbits(64))
+        else:
+            out.append(rng.getrandbits(135))
+    return out

@@ -1,0 +1,155 @@
+"""Pins the oracle: constants, Python-int restatement vs C restatement vs closed forms.
+The reference holds no golden vectors, so this three-way agreement plus the
+committed fixtures in tests/golden/ is what the oracle is anchored to ("parity unpinned" at
+proof-byte level, mathematically pinned at kernel level)."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import pyref as P
+
+
+def test_constants():
+    assert P.FQ_P.bit_length() == 254 and P.FR_R.bit_length() == 254
+    assert P.FQ_P % 4 == 3
+    assert (P.FR_R - 1) % (1 << 28) == 0 and ((P.FR_R - 1) >> 28) % 2 == 1
+    assert P.FR_ROOT_OF_UNITY == 0x03DDB9F5166D18B798865EA93DD31F743215CF6DD39329C8D34F1ED960C37C9C
+    assert pow(P.FR_ROOT_OF_UNITY, 1 << 28, P.FR_R) == 1
+    assert pow(P.FR_ROOT_OF_UNITY, 1 << 27, P.FR_R) != 1
+    # Montgomery constants quoted in SURVEY.md section 8c
+    assert (-pow(P.FQ_P, -1, 1 << 64)) % (1 << 64) == 0x87D20782E4866389
+    assert (-pow(P.FR_R, -1, 1 << 64)) % (1 << 64) == 0xC2E1F593EFFFFFFF
+    assert (1 << 256) % P.FQ_P == 0x0E0A77C19A07DF2F666EA36F7879462C0A78EB28F5C70B3DD35D438DC58F0D9D
+    assert (1 << 256) % P.FR_R == 0x0E0A77C19A07DF2F666EA36F7879462E36FC76959F60CD29AC96341C4FFFFFFB
+    assert P.g1_is_on_curve(P.G1_GEN)
+    assert P.g1_mul(P.G1_GEN, P.FR_R) == P.AFF_INF
+
+
+def test_paillier_native_small():
+    # the reference's own test shapes: 128-bit / 64-bit limbs and 264-bit / 88-bit limbs
+    rng = random.Random(1)
+    for bits in (128, 264):
+        n, g, m, r = (rng.getrandbits(bits) | 1 for _ in range(4))
+        c = P.paillier_enc_native(n, g, m, r)
+        res, sg, sr, fin = P.encrypt_trace(n, g, m, r)
+        assert res == c
+        for (a, b, q, rr) in sg + sr + [fin]:
+            assert a * b == q * n * n + rr and 0 <= rr < n * n
+        assert len(sg) == m.bit_length() + bin(m).count("1")
+        assert len(sr) == n.bit_length() + bin(n).count("1")
+        c1, c2 = rng.getrandbits(bits), rng.getrandbits(bits)
+        assert P.add_trace(n, c1, c2)[0] == P.paillier_add_native(n, c1, c2)
+
+
+def test_get_biguint_roundtrip():
+    rng = random.Random(2)
+    for bits, lb in ((128, 64), (264, 88), (2048, 64)):
+        x = rng.getrandbits(bits)
+        limbs = P.decompose_biguint(x, bits // lb, lb)
+        assert P.get_biguint(limbs, lb) == x
+
+
+def test_pow_mod_edge_cases():
+    assert P.pow_mod_fixed_exp_trace(5, 0, 77) == (1, [])
+    acc, steps = P.pow_mod_fixed_exp_trace(5, 1, 77)
+    assert acc == 5 and len(steps) == 2  # one (unused) squaring + one multiply
+    acc, steps = P.pow_mod_fixed_exp_trace(0, 6, 77)
+    assert acc == 0
+
+
+def test_c_bigint_vs_python(cref):
+    rng = random.Random(3)
+    for L, bits in ((4, 256), (6, 352), (64, 4096), (96, 6144)):
+        for _ in range(6):
+            mod = rng.getrandbits(bits) | (1 << (bits - 1))
+            a, b = rng.randrange(mod), rng.randrange(mod)
+            rc, q, r = cref.mul_mod_step(L, a, b, mod)
+            assert rc == 0 and (q, r) == divmod(a * b, mod)
+        # short / even / tiny moduli
+        for mod in (1, 2, 3, (1 << 64) - 1, 1 << 64, rng.getrandbits(bits // 2) | 1, rng.getrandbits(bits) & ~1 | 2):
+            a = rng.getrandbits(min(bits // 2, max(1, mod.bit_length())))
+            b = rng.getrandbits(min(bits // 2, max(1, mod.bit_length())))
+            rc, q, r = cref.mul_mod_step(L, a, b, mod)
+            if (a * b) // mod >= 1 << (64 * L):
+                assert rc == -2
+            else:
+                assert rc == 0 and (q, r) == divmod(a * b, mod), (L, mod)
+        assert cref.mul_mod_step(L, 1, 1, 0)[0] == -1
+
+
+def test_c_pow_trace_vs_python(cref):
+    rng = random.Random(4)
+    for L, bits in ((4, 128), (6, 176), (64, 2048)):
+        n = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+        n2 = n * n
+        base = rng.randrange(n)
+        e = rng.getrandbits(37 if L == 64 else bits)
+        rc, res, steps = cref.pow_mod_trace(L, n2, base, e, L // 2)
+        acc, psteps = P.pow_mod_fixed_exp_trace(base, e, n2)
+        assert rc == 0 and res == acc and len(steps) == len(psteps)
+        for st, (a, b, q, r) in zip(steps, psteps):
+            assert [cref.limbs_to_int(st[i]) for i in range(4)] == [a, b, q, r]
+    for bits, Ln in ((128, 2), (256, 4)):
+        n, g, m, r = P.synth_paillier_inputs(bits, 99)
+        assert cref.paillier_enc(Ln, n, g, m, r) == P.paillier_enc_native(n, g, m, r)
+
+
+def test_c_field_vs_python(cref):
+    rng = random.Random(5)
+    for which, mod in (("fr", P.FR_R), ("fq", P.FQ_P)):
+        xs = [0, 1, mod - 1] + [rng.randrange(mod) for _ in range(20)]
+        mont = cref.to_mont(cref.ints_to_array(xs, 4), which)
+        assert [cref.limbs_to_int(v) for v in mont] == [P.to_mont(x, mod) for x in xs]
+        assert [cref.limbs_to_int(v) for v in cref.from_mont(mont, which)] == xs
+
+
+def test_c_msm_vs_python(cref):
+    rng = random.Random(6)
+    for n in (0, 1, 2, 3, 5, 31, 33, 64, 200):
+        bases = P.walk_bases(n, 12345, 67891) if n else []
+        if n >= 3:
+            bases[2] = P.AFF_INF  # identity base
+        scalars = [rng.randrange(P.FR_R) for _ in range(n)]
+        for i, v in enumerate([0, 1, P.FR_R - 1, rng.getrandbits(64), rng.getrandbits(140)][:n]):
+            scalars[i] = v
+        want = P.msm_pippenger(scalars, bases) if n > 40 else P.msm_naive(scalars, bases)
+        got = cref.g1_normalize(cref.msm_g1(cref.fr_ints_to_mont(scalars).reshape(-1, 4),
+                                            cref.affine_ints_to_mont(bases).reshape(-1, 8), threads=3))
+        assert cref.affine_mont_to_ints(got)[0] == want, n
+
+
+def test_walk_bases_and_dlog_identity(cref):
+    s, t = 0x1234567, 0x89ABCDEF1
+    n = 300
+    wb = cref.walk_bases(n, s, t)
+    py = P.walk_bases(8, s, t)
+    assert cref.affine_mont_to_ints(wb[:8]) == py
+    assert all(cref.g1_on_curve(wb[i]) for i in (0, 1, 17, n - 1))
+    scalars = P.witness_like_scalars(n, 7)
+    got = cref.g1_normalize(cref.msm_g1(cref.fr_ints_to_mont(scalars), wb))
+    assert cref.affine_mont_to_ints(got)[0] == P.msm_walk_expected(scalars, s, t)
+    # adversarial walk: G, 2G, 3G ... forces doubling / cancellation cases inside buckets
+    wb = cref.walk_bases(64, 1, 1)
+    scalars = [1] * 32 + [P.FR_R - 1] * 32
+    got = cref.g1_normalize(cref.msm_g1(cref.fr_ints_to_mont(scalars), wb))
+    assert cref.affine_mont_to_ints(got)[0] == P.msm_walk_expected(scalars, 1, 1)
+
+
+def test_c_ntt_vs_python(cref):
+    rng = random.Random(8)
+    for log_n in range(0, 9):
+        n = 1 << log_n
+        a = [rng.randrange(P.FR_R) for _ in range(n)]
+        omega = P.fr_omega(log_n)
+        want = P.ntt(a, omega)
+        if log_n <= 5:
+            assert want == P.ntt_naive(a, omega)
+        got = cref.ntt_fr(cref.fr_ints_to_mont(a), cref.fr_ints_to_mont([omega])[0], log_n, threads=2)
+        assert cref.fr_mont_to_ints(got) == want
+        assert P.intt(want, omega) == a
+    # coset path: distribute_powers then NTT
+    a = [rng.randrange(P.FR_R) for _ in range(16)]
+    g = 7
+    got = cref.fr_distribute_powers(cref.fr_ints_to_mont(a), cref.fr_ints_to_mont([g])[0])
+    assert cref.fr_mont_to_ints(got) == P.coset_scale(a, g)
