@@ -1,0 +1,182 @@
+/* pz.h -- C ABI of the MI355X-native (gfx950, hand-written HIP) hot path of the
+ * Paillier-in-Halo2 prover.  This header is the whole drop-in boundary: plain pointers and sizes,
+ * no C++/torch types.  Library: paillier_halo2_amd/csrc/libpz_hip.so.
+ *
+ * The reference (aerius-labs/paillier-halo2) is a plain Rust library with no FFI seam of its own
+ * (src/lib.rs:1-2); every entry point below names the reference call site / dependency routine it
+ * replaces.  INTEGRATION.md shows the Rust `extern "C"` stub a maintainer adds for each.
+ *
+ * Conventions (all functions):
+ *   - return 0 (PZ_OK) on success, a negative pz_status on error; never throw, never abort, no
+ *     callbacks; there is NO CPU fallback -- without a usable gfx950 device pz_init fails.
+ *   - field elements: 4 x u64 little-endian limbs in MONTGOMERY form (R = 2^256), exactly the
+ *     in-memory layout of halo2curves Fr / Fq.  G1Affine = {x, y} (64 B), identity = all-zero.
+ *     G1 Jacobian = {x, y, z} (96 B), identity z = 0 (returned as (0, R, 0)).
+ *   - big integers: little-endian u64 limb arrays (limb 0 least significant), i.e. the limb order
+ *     of AssignedBigUint::limbs() at limb_bits = 64 (paillier.rs:22-30).
+ *   - "host" pointers are ordinary process memory; "_dev" entry points take device pointers
+ *     (hipMalloc / torch tensor data_ptr) valid on the context's device and run asynchronously on
+ *     the context's stream (pz_set_stream); host-pointer entry points synchronise before returning.
+ *   - a pz_ctx is bound to ONE device (one process per GPU, ranks joined by RCCL above this ABI);
+ *     distinct contexts may be used concurrently, one context is serialised by the caller.  Entry
+ *     points call hipSetDevice themselves, so they may be called from any thread (rayon workers).
+ */
+#ifndef PZ_H
+#define PZ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pz_ctx pz_ctx;
+typedef struct pz_bases pz_bases;
+
+enum pz_status {
+    PZ_OK = 0,
+    PZ_ERR_INVALID = -1,      /* null pointer, bad size, log_n out of range ...            */
+    PZ_ERR_HIP = -2,          /* a HIP runtime call failed (see pz_last_hip_error)          */
+    PZ_ERR_NO_DEVICE = -3,    /* no gfx950 device visible                                   */
+    PZ_ERR_OOM = -4,          /* device allocation failed                                   */
+    PZ_ERR_ZERO_MODULUS = -5, /* mul_mod / pow_mod with modulus 0 (reference: BigUint % 0 panics, paillier.rs:91) */
+    PZ_ERR_RANGE = -6,        /* quotient does not fit the limb count the circuit assigns it (unsatisfiable in the reference) */
+    PZ_ERR_UNSUPPORTED = -7,  /* n_devices != 1, limb count not a supported size ...         */
+    PZ_ERR_CAPACITY = -8      /* caller-provided output capacity too small                  */
+};
+
+/* ---------------------------------------------------------------------------------------------
+ * context
+ * ------------------------------------------------------------------------------------------- */
+/* n_devices must be 1; device_ids[0] is the HIP device ordinal (NULL -> device 0). */
+int pz_init(int n_devices, const int* device_ids, pz_ctx** out);
+int pz_free(pz_ctx* ctx);
+const char* pz_strerror(int status);
+/* last HIP error string recorded by this context (empty string if none) */
+const char* pz_last_hip_error(const pz_ctx* ctx);
+/* stream used by the _dev entry points (NULL = the context's own stream). */
+int pz_set_stream(pz_ctx* ctx, void* hip_stream);
+int pz_sync(pz_ctx* ctx);
+/* number of entry points exported; lets a binding check it was built against this header */
+int pz_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1 -- G1 multi-scalar multiplication.  Replaces halo2curves `best_multiexp(coeffs, bases)`
+ * reached from /root/reference/src/bench.rs:161-171 (bench_builder -> create_proof ->
+ * ParamsKZG::commit_lagrange / commit).  The VALUE (the group element) equals best_multiexp's;
+ * the Jacobian representative is not unique, compare after pz_g1_normalize (halo2 itself writes
+ * commitments to the transcript in affine form after batch_normalize).
+ * ------------------------------------------------------------------------------------------- */
+/* Upload 2^k affine bases (host) and build the device-resident window-shifted table
+ * T[w][i] = 2^(c*w) * P_i.  `lagrange` only labels the set (g vs g_lagrange of ParamsKZG).
+ * window_bits = 0 picks the default for k. */
+int pz_srs_load_g1(pz_ctx* ctx, uint32_t k, const uint64_t* bases_affine, int lagrange, pz_bases** out);
+/* general form: n_points need not be a power of two; bases may already be on the device. */
+int pz_bases_load_g1(pz_ctx* ctx, const uint64_t* bases_affine, size_t n_points, int on_device,
+                     uint32_t window_bits, pz_bases** out);
+int pz_bases_free(pz_ctx* ctx, pz_bases* bases);
+/* window parameters of a loaded set: c = window bits, n_windows = floor(253/c)+1 */
+int pz_bases_info(const pz_bases* bases, size_t* n_points, uint32_t* window_bits, uint32_t* n_windows);
+
+/* == best_multiexp(scalars[0..n], bases[0..n]);  n <= n_points.  Host pointers. */
+int pz_msm_g1(pz_ctx* ctx, const pz_bases* bases, const uint64_t* scalars, size_t n, uint64_t out_jac[12]);
+/* n_cols column commitments against the same bases (commit_lagrange per advice column). */
+int pz_msm_g1_batch(pz_ctx* ctx, const pz_bases* bases, const uint64_t* const* scalar_cols, size_t n_cols,
+                    size_t n, uint64_t* out_jac /* n_cols x 12 */);
+/* device-resident form: scalars = n_cols columns, column j at d_scalars + j*col_stride (in u64
+ * units, >= 4*n); result n_cols x 12 u64 on the device.  Only Pippenger windows
+ * [win_lo, win_hi) are accumulated (pass 0, n_windows for the full MSM) -- the multi-GPU split of
+ * one large MSM gives each rank a disjoint window range and sums the partial points. */
+int pz_msm_g1_dev(pz_ctx* ctx, const pz_bases* bases, const uint64_t* d_scalars, size_t n_cols, size_t n,
+                  size_t col_stride, uint32_t win_lo, uint32_t win_hi, uint64_t* d_out_jac);
+/* sum of n Jacobian points (host in/out): the fixed-order fold of per-rank partial MSMs. */
+int pz_g1_sum(pz_ctx* ctx, const uint64_t* jac /* n x 12 */, size_t n, uint64_t out_jac[12]);
+/* Jacobian -> affine for n points (host in/out): `batch_normalize`. */
+int pz_g1_normalize(pz_ctx* ctx, const uint64_t* jac /* n x 12 */, size_t n, uint64_t* aff /* n x 8 */);
+/* out[i] = [scalars[i]] * G1 generator, affine; scalars are Fr Montgomery (host in/out).  This is
+ * the fixed-base multiplication `ParamsKZG::setup` uses for g[i] = [s^i]G; also used to build
+ * synthetic base sets with known discrete logs. */
+int pz_g1_fixed_base_mul(pz_ctx* ctx, const uint64_t* scalars, size_t n, uint64_t* out_affine /* n x 8 */);
+/* device form of the same; out_affine is a device pointer */
+int pz_g1_fixed_base_mul_dev(pz_ctx* ctx, const uint64_t* d_scalars, size_t n, uint64_t* d_out_affine);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2 -- radix-2 NTT over Fr.  Replaces halo2curves `best_fft(a, omega, log_n)` reached from the
+ * same call site through halo2-axiom EvaluationDomain::{ifft, fft, coeff_to_extended,
+ * extended_to_coeff}:  a[k] <- sum_j a[j] * omega^(j k), natural order in and out, in place.
+ * ------------------------------------------------------------------------------------------- */
+int pz_ntt_fr(pz_ctx* ctx, uint64_t* a /* 2^log_n x 4 */, const uint64_t omega[4], uint32_t log_n);
+int pz_ntt_fr_batch(pz_ctx* ctx, uint64_t* const* cols, size_t n_cols, const uint64_t omega[4], uint32_t log_n);
+/* device-resident, n_cols columns at d_a + j*col_stride (u64 units).  Optional fused steps
+ * (either may be NULL):
+ *   pre_coset_g : a[i] *= g^i before the transform (distribute_powers of coeff_to_extended)
+ *   post_scale  : a[k] *= s   after  the transform (the 1/n `ifft_divisor`)            */
+int pz_ntt_fr_dev(pz_ctx* ctx, uint64_t* d_a, size_t n_cols, size_t col_stride, const uint64_t omega[4],
+                  uint32_t log_n, const uint64_t* pre_coset_g, const uint64_t* post_scale);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3 -- big-integer witness generation for g^m * r^n mod n^2.  Replaces the native
+ * (num-bigint) part of biguint-halo2's BigUintChip::{mul_mod, pow_mod_fixed_exp}
+ * (call sites /root/reference/src/paillier.rs:51,55,57,81) and paillier_enc_native /
+ * paillier_add_native (paillier.rs:87-97).
+ * A "step" is one mul_mod: (a, b, q, r) with a*b = q*modulus + r, 0 <= r < modulus, each `limbs`
+ * u64 limbs, laid out a|b|q|r (4*limbs u64 per step).
+ * ------------------------------------------------------------------------------------------- */
+/* one mul_mod witness (PaillierChip::add's single step, paillier.rs:81) */
+int pz_mul_mod(pz_ctx* ctx, uint32_t limbs, const uint64_t* a, const uint64_t* b, const uint64_t* modulus,
+               uint64_t* q, uint64_t* r);
+/* pow_mod_fixed_exp step trace: acc = 1, sq = base; for each bit of exp LSB->MSB: emit
+ * (sq,sq,q,sq') ; if bit: emit (acc,sq_old,q,acc').  steps_out has room for *n_steps steps on
+ * entry (needs bits(exp) + popcount(exp)); on return *n_steps = steps written. result = acc. */
+int pz_paillier_trace(pz_ctx* ctx, uint32_t limbs_n2, const uint64_t* n2, const uint64_t* base, const uint64_t* exp,
+                      uint32_t exp_limbs, uint64_t* steps_out, size_t* n_steps, uint64_t* result);
+/* whole PaillierChip::encrypt witness (paillier.rs:32-60) for `batch` independent instances:
+ * per instance n, g, m, r are limbs_n limbs (limbs_n2 = 2*limbs_n); n2 = n*n is formed on the
+ * device; the g^m and r^n chains of every instance run concurrently; then c = gm*rn mod n2.
+ * steps_out: per instance `steps_cap` steps (layout as above): first the g^m trace, then the r^n
+ * trace, then the final mul_mod.  n_steps_g / n_steps_r (per instance) receive the trace lengths.
+ * c_out: batch x 2*limbs_n limbs.  steps_out may be NULL (values only: the paillier_enc_native use). */
+int pz_paillier_encrypt(pz_ctx* ctx, uint32_t limbs_n, size_t batch, const uint64_t* n, const uint64_t* g,
+                        const uint64_t* m, const uint64_t* r, uint64_t* steps_out, size_t steps_cap,
+                        uint32_t* n_steps_g, uint32_t* n_steps_r, uint64_t* c_out);
+/* device-resident output form used by the prover pipeline (steps stay in HBM for K4) */
+int pz_paillier_encrypt_dev(pz_ctx* ctx, uint32_t limbs_n, size_t batch, const uint64_t* n, const uint64_t* g,
+                            const uint64_t* m, const uint64_t* r, uint64_t* d_steps_out, size_t steps_cap,
+                            uint32_t* n_steps_g, uint32_t* n_steps_r, uint64_t* c_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * K4 -- expansion of a step trace into advice-column cells (Fr Montgomery, 32 B each), i.e. the
+ * values halo2-lib's Context would hold after BigUintChip emitted the constraints of every
+ * mul_mod (limb convolutions, range-check digit splits, carry chains).  Replaces the cell pushes
+ * behind the dependency call sites paillier.rs:39-57, bench.rs:44-74.  Layout: DESIGN.md section 4.
+ * ------------------------------------------------------------------------------------------- */
+/* cells one mul_mod step expands to, for the given shape */
+int pz_witness_cells_per_step(uint32_t limbs, uint32_t limb_bits, uint32_t lookup_bits, size_t* advice_cells,
+                              size_t* lookup_cells);
+/* d_steps: n_steps steps on the device (a|b|q|r, `limbs` limbs each), d_modulus: `limbs` limbs on
+ * the device; writes n_steps*advice_cells Fr elements to d_advice and n_steps*lookup_cells to
+ * d_lookup (either may be NULL to skip). */
+int pz_witness_expand_dev(pz_ctx* ctx, uint32_t limbs, uint32_t limb_bits, uint32_t lookup_bits,
+                          const uint64_t* d_steps, size_t n_steps, const uint64_t* d_modulus, uint64_t* d_advice,
+                          uint64_t* d_lookup);
+
+/* ---------------------------------------------------------------------------------------------
+ * measurement helpers (used by bench.py; not part of the reference surface)
+ * ------------------------------------------------------------------------------------------- */
+/* HIP-event timing of the dominant kernel on the context's stream: accumulated since the last
+ * reset, for kernel class `which` (0 = MSM bucket accumulation, 1 = NTT passes, 2 = modexp trace,
+ * 3 = witness expand, 4 = MSM whole pipeline).  Enabled by pz_timing_enable(ctx, 1). */
+int pz_timing_enable(pz_ctx* ctx, int on);
+int pz_timing_reset(pz_ctx* ctx);
+int pz_timing_get(pz_ctx* ctx, int which, double* total_ms, uint64_t* launches);
+/* integer-multiply issue-rate microbenchmark: runs `iters` dependent-free v_mad_u64_u32 per lane
+ * on `blocks` x 256 threads, returns elapsed ms (device time) */
+int pz_ubench_mad(pz_ctx* ctx, uint32_t blocks, uint32_t iters, double* ms);
+/* Fq Montgomery multiplications per second microbenchmark (chains of `iters` per lane) */
+int pz_ubench_fqmul(pz_ctx* ctx, uint32_t blocks, uint32_t iters, double* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PZ_H */

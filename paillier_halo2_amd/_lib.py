@@ -1,0 +1,106 @@
+"""ctypes loader for paillier_halo2_amd/csrc/libpz_hip.so (the C ABI of include/pz.h).
+
+Plumbing only: no arithmetic lives here.  The library is hand-written HIP for gfx950; if it is
+missing or cannot be loaded the import fails loudly -- there is no CPU fallback and nothing in
+this package imports oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libpz_hip.so")
+
+U64P = C.POINTER(C.c_uint64)
+U32P = C.POINTER(C.c_uint32)
+VP = C.c_void_p
+
+# name -> (restype, argtypes): every entry point include/pz.h declares
+SIGNATURES = {
+    "pz_init": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(VP)]),
+    "pz_free": (C.c_int, [VP]),
+    "pz_strerror": (C.c_char_p, [C.c_int]),
+    "pz_last_hip_error": (C.c_char_p, [VP]),
+    "pz_set_stream": (C.c_int, [VP, VP]),
+    "pz_sync": (C.c_int, [VP]),
+    "pz_abi_version": (C.c_int, []),
+    "pz_srs_load_g1": (C.c_int, [VP, C.c_uint32, VP, C.c_int, C.POINTER(VP)]),
+    "pz_bases_load_g1": (C.c_int, [VP, VP, C.c_size_t, C.c_int, C.c_uint32, C.POINTER(VP)]),
+    "pz_bases_free": (C.c_int, [VP, VP]),
+    "pz_bases_info": (C.c_int, [VP, C.POINTER(C.c_size_t), U32P, U32P]),
+    "pz_msm_g1": (C.c_int, [VP, VP, VP, C.c_size_t, VP]),
+    "pz_msm_g1_batch": (C.c_int, [VP, VP, C.POINTER(VP), C.c_size_t, C.c_size_t, VP]),
+    "pz_msm_g1_dev": (C.c_int, [VP, VP, VP, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, VP]),
+    "pz_g1_sum": (C.c_int, [VP, VP, C.c_size_t, VP]),
+    "pz_g1_normalize": (C.c_int, [VP, VP, C.c_size_t, VP]),
+    "pz_g1_fixed_base_mul": (C.c_int, [VP, VP, C.c_size_t, VP]),
+    "pz_g1_fixed_base_mul_dev": (C.c_int, [VP, VP, C.c_size_t, VP]),
+    "pz_ntt_fr": (C.c_int, [VP, VP, VP, C.c_uint32]),
+    "pz_ntt_fr_batch": (C.c_int, [VP, C.POINTER(VP), C.c_size_t, VP, C.c_uint32]),
+    "pz_ntt_fr_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, VP, C.c_uint32, VP, VP]),
+    "pz_mul_mod": (C.c_int, [VP, C.c_uint32, VP, VP, VP, VP, VP]),
+    "pz_paillier_trace": (C.c_int, [VP, C.c_uint32, VP, VP, VP, C.c_uint32, VP, C.POINTER(C.c_size_t), VP]),
+    "pz_paillier_encrypt": (C.c_int, [VP, C.c_uint32, C.c_size_t, VP, VP, VP, VP, VP, C.c_size_t, VP, VP, VP]),
+    "pz_paillier_encrypt_dev": (C.c_int, [VP, C.c_uint32, C.c_size_t, VP, VP, VP, VP, VP, C.c_size_t, VP, VP, VP]),
+    "pz_witness_cells_per_step": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t),
+                                            C.POINTER(C.c_size_t)]),
+    "pz_witness_expand_dev": (C.c_int, [VP, C.c_uint32, C.c_uint32, C.c_uint32, VP, C.c_size_t, VP, VP, VP]),
+    "pz_timing_enable": (C.c_int, [VP, C.c_int]),
+    "pz_timing_reset": (C.c_int, [VP]),
+    "pz_timing_get": (C.c_int, [VP, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "pz_ubench_mad": (C.c_int, [VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
+    "pz_ubench_fqmul": (C.c_int, [VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError("libpz_hip.so was not produced by the build")
+    return SO_PATH
+
+
+def lib():
+    """Load the HIP library; raises if it is absent (no fallback of any kind)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+            )
+        l = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError here == ABI symbol missing: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+class PzError(RuntimeError):
+    def __init__(self, status: int, where: str, detail: str = ""):
+        self.status = status
+        msg = lib().pz_strerror(status).decode()
+        super().__init__(f"{where}: pz_status {status} ({msg}){(' -- ' + detail) if detail else ''}")
+
+
+# status codes mirrored from include/pz.h
+PZ_OK = 0
+PZ_ERR_INVALID = -1
+PZ_ERR_HIP = -2
+PZ_ERR_NO_DEVICE = -3
+PZ_ERR_OOM = -4
+PZ_ERR_ZERO_MODULUS = -5
+PZ_ERR_RANGE = -6
+PZ_ERR_UNSUPPORTED = -7
+PZ_ERR_CAPACITY = -8

@@ -1,0 +1,240 @@
+// fp.cuh -- BN254 base field Fq and scalar field Fr on gfx950, 8 x 32-bit limbs, Montgomery form
+// with R = 2^256 (bit-identical to the 4 x u64 little-endian layout of halo2curves Fr/Fq that the
+// C ABI in include/pz.h takes verbatim).
+//
+// Integer modular arithmetic: no MFMA.  The multiplier primitive of CDNA4's VALU is
+// v_mad_u64_u32 (32x32+64 -> 64); everything here is written so hipcc lowers the inner products
+// to that instruction with the carries kept in 64-bit accumulators.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+struct FqTag {};
+struct FrTag {};
+
+template <class Tag> struct FieldParams;
+
+template <> struct FieldParams<FqTag> {
+    static constexpr u32 INV = 0xe4866389u;  // -p^-1 mod 2^32
+    __device__ __forceinline__ static constexpr u32 P(int i) {
+        constexpr u32 p[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
+                              0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+        return p[i];
+    }
+    __device__ __forceinline__ static constexpr u32 R1(int i) {  // R mod p
+        constexpr u32 r[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
+                              0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+        return r[i];
+    }
+    __device__ __forceinline__ static constexpr u32 R2(int i) {  // R^2 mod p
+        constexpr u32 r[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
+                              0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+        return r[i];
+    }
+};
+
+template <> struct FieldParams<FrTag> {
+    static constexpr u32 INV = 0xefffffffu;
+    __device__ __forceinline__ static constexpr u32 P(int i) {
+        constexpr u32 p[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
+                              0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+        return p[i];
+    }
+    __device__ __forceinline__ static constexpr u32 R1(int i) {
+        constexpr u32 r[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
+                              0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+        return r[i];
+    }
+    __device__ __forceinline__ static constexpr u32 R2(int i) {
+        constexpr u32 r[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
+                              0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+        return r[i];
+    }
+};
+
+template <class Tag> struct alignas(16) Fp {
+    u32 v[8];
+};
+typedef Fp<FqTag> Fq;
+typedef Fp<FrTag> Fr;
+
+template <class T> __device__ __forceinline__ Fp<T> fp_zero() {
+    Fp<T> r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = 0;
+    return r;
+}
+template <class T> __device__ __forceinline__ Fp<T> fp_one() {  // Montgomery one
+    Fp<T> r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = FieldParams<T>::R1(i);
+    return r;
+}
+template <class T> __device__ __forceinline__ bool fp_is_zero(const Fp<T>& a) {
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o |= a.v[i];
+    return o == 0;
+}
+template <class T> __device__ __forceinline__ bool fp_eq(const Fp<T>& a, const Fp<T>& b) {
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o |= a.v[i] ^ b.v[i];
+    return o == 0;
+}
+
+// r = a - p if a >= p (a < 2p assumed)
+template <class T> __device__ __forceinline__ void fp_reduce_once(Fp<T>& a) {
+    u32 t[8];
+    u64 br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u64 d = (u64)a.v[i] - FieldParams<T>::P(i) - br;
+        t[i] = (u32)d;
+        br = (d >> 32) & 1;
+    }
+    if (!br) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a.v[i] = t[i];
+    }
+}
+
+template <class T> __device__ __forceinline__ Fp<T> fp_add(const Fp<T>& a, const Fp<T>& b) {
+    Fp<T> r;
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        c += (u64)a.v[i] + b.v[i];
+        r.v[i] = (u32)c;
+        c >>= 32;
+    }
+    // p < 2^254 so a + b < 2^255: no carry out of limb 7
+    fp_reduce_once(r);
+    return r;
+}
+
+template <class T> __device__ __forceinline__ Fp<T> fp_sub(const Fp<T>& a, const Fp<T>& b) {
+    Fp<T> r;
+    u64 br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u64 d = (u64)a.v[i] - b.v[i] - br;
+        r.v[i] = (u32)d;
+        br = (d >> 32) & 1;
+    }
+    u32 mask = (u32)0 - (u32)br;
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        c += (u64)r.v[i] + (FieldParams<T>::P(i) & mask);
+        r.v[i] = (u32)c;
+        c >>= 32;
+    }
+    return r;
+}
+
+template <class T> __device__ __forceinline__ Fp<T> fp_neg(const Fp<T>& a) {
+    if (fp_is_zero(a)) return a;
+    Fp<T> r;
+    u64 br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u64 d = (u64)FieldParams<T>::P(i) - a.v[i] - br;
+        r.v[i] = (u32)d;
+        br = (d >> 32) & 1;
+    }
+    return r;
+}
+
+template <class T> __device__ __forceinline__ Fp<T> fp_dbl(const Fp<T>& a) { return fp_add(a, a); }
+
+// Montgomery product a*b*R^-1 mod p, CIOS over 32-bit limbs: per outer limb one multiply row and
+// one reduction row, each 8 x v_mad_u64_u32 with a 64-bit running carry.
+template <class T> __device__ __forceinline__ Fp<T> fp_mul(const Fp<T>& a, const Fp<T>& b) {
+    u32 t[8];
+    u32 t8 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u64 c = 0;
+        const u32 bi = b.v[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            c = (u64)a.v[j] * bi + t[j] + c;
+            t[j] = (u32)c;
+            c >>= 32;
+        }
+        c += t8;
+        t8 = (u32)c;
+        u32 t9 = (u32)(c >> 32);
+        const u32 m = t[0] * FieldParams<T>::INV;
+        c = (u64)m * FieldParams<T>::P(0) + t[0];
+        c >>= 32;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            c = (u64)m * FieldParams<T>::P(j) + t[j] + c;
+            t[j - 1] = (u32)c;
+            c >>= 32;
+        }
+        c += t8;
+        t[7] = (u32)c;
+        t8 = t9 + (u32)(c >> 32);
+    }
+    Fp<T> r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = t[i];
+    // result < 2p and p < 2^254, so t8 == 0 here
+    fp_reduce_once(r);
+    return r;
+}
+
+template <class T> __device__ __forceinline__ Fp<T> fp_sqr(const Fp<T>& a) { return fp_mul(a, a); }
+
+template <class T> __device__ __forceinline__ Fp<T> fp_from_mont(const Fp<T>& a) {
+    Fp<T> one = fp_zero<T>();
+    one.v[0] = 1;
+    return fp_mul(a, one);
+}
+template <class T> __device__ __forceinline__ Fp<T> fp_to_mont(const Fp<T>& a) {
+    Fp<T> r2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r2.v[i] = FieldParams<T>::R2(i);
+    return fp_mul(a, r2);
+}
+
+// a^(p-2): not unrolled (a loop of 254 squarings), used once per output point / table entry
+template <class T> __device__ __noinline__ Fp<T> fp_inv(const Fp<T>& a) {
+    Fp<T> acc = fp_one<T>();
+    u32 e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = FieldParams<T>::P(i);
+    e[0] -= 2;  // p is odd and p[0] >= 2 for both fields
+    for (int i = 253; i >= 0; --i) {
+        acc = fp_sqr(acc);
+        u32 w = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k == (i >> 5)) w = e[k];
+        if ((w >> (i & 31)) & 1) acc = fp_mul(acc, a);
+    }
+    return acc;
+}
+
+// 32-byte global/LDS accessors (two 16-byte transactions per element)
+template <class T> __device__ __forceinline__ Fp<T> fp_load(const void* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 lo = q[0], hi = q[1];
+    Fp<T> r;
+    r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+    r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    return r;
+}
+template <class T> __device__ __forceinline__ void fp_store(void* p, const Fp<T>& a) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+}

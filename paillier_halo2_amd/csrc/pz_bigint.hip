@@ -1,0 +1,766 @@
+// pz_bigint.hip -- K3: big-integer witness generation for c = g^m * r^n mod n^2.
+// Replaces the num-bigint arithmetic inside biguint-halo2's BigUintChip::{mul_mod,
+// pow_mod_fixed_exp} (call sites /root/reference/src/paillier.rs:51,55,57,81) and
+// paillier_enc_native / paillier_add_native (paillier.rs:87-97): every step yields the exact
+// quotient and remainder (q, r) of a*b by the modulus, because the circuit assigns both.
+//
+// Mapping to CDNA4: one 64-lane wavefront owns one big integer, lane j holds limbs [j*E, j*E+E)
+// (E = 1: up to 64 x 64-bit limbs = 4096 bits, the 2048-bit-n case; E = 2: up to 128 limbs, the
+// 3072-bit-n case).  A product is a lane-systolic schoolbook: per outer limb A_i (broadcast with
+// v_readlane) every lane multiplies its limbs (v_mad_u64_u32), adds into its column sums and the
+// column array shifts one lane down; carries are kept as per-column counters and resolved once
+// per product with a ballot-based carry look-ahead (64-bit scalar add of generate/propagate
+// masks).  Reduction is Barrett with a normalised modulus, so the exact quotient falls out; the
+// reciprocal is computed on the device once per modulus by restoring division.  A workgroup is
+// two waves: wave 0 runs the squaring chain, wave 1 the multiply chain (needed only on set
+// exponent bits), synchronised once per exponent bit.
+// Latency-bound by construction (serial dependency between steps); see DESIGN.md section 5.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pz_internal.h"
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+template <int E> struct LD {
+    u64 v[E];
+};
+
+__device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ u64 bcast64(u64 x, unsigned src) {
+    u32 lo = __builtin_amdgcn_readlane((u32)x, src);
+    u32 hi = __builtin_amdgcn_readlane((u32)(x >> 32), src);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 shfl_down1(u64 x) {  // lane j <- lane j+1, lane 63 <- 0
+    u64 y = __shfl_down(x, 1, 64);
+    return lane_id() == 63 ? 0 : y;
+}
+__device__ __forceinline__ u32 shfl_down1_32(u32 x) {
+    u32 y = __shfl_down(x, 1, 64);
+    return lane_id() == 63 ? 0 : y;
+}
+__device__ __forceinline__ u64 shfl_up1(u64 x) {  // lane j <- lane j-1, lane 0 <- 0
+    u64 y = __shfl_up(x, 1, 64);
+    return lane_id() == 0 ? 0 : y;
+}
+
+template <int E> __device__ __forceinline__ LD<E> ld_zero() {
+    LD<E> r;
+#pragma unroll
+    for (int e = 0; e < E; ++e) r.v[e] = 0;
+    return r;
+}
+template <int E> __device__ __forceinline__ LD<E> ld_small(u64 x) {  // the integer x
+    LD<E> r = ld_zero<E>();
+    if (lane_id() == 0) r.v[0] = x;
+    return r;
+}
+template <int E> __device__ __forceinline__ bool ld_is_zero(const LD<E>& a) {
+    u64 o = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) o |= a.v[e];
+    return __ballot(o != 0) == 0;
+}
+// load `limbs` u64 limbs from memory (zero extended to the 64*E capacity)
+template <int E> __device__ __forceinline__ LD<E> ld_load(const u64* p, unsigned limbs) {
+    LD<E> r;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        unsigned idx = lane_id() * E + e;
+        r.v[e] = idx < limbs ? p[idx] : 0;
+    }
+    return r;
+}
+template <int E> __device__ __forceinline__ void ld_store(u64* p, const LD<E>& a, unsigned limbs) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        unsigned idx = lane_id() * E + e;
+        if (idx < limbs) p[idx] = a.v[e];
+    }
+}
+// true if any limb with index >= limbs is non-zero
+template <int E> __device__ __forceinline__ bool ld_exceeds(const LD<E>& a, unsigned limbs) {
+    bool bad = false;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        unsigned idx = lane_id() * E + e;
+        bad |= (idx >= limbs) && (a.v[e] != 0);
+    }
+    return __ballot(bad) != 0;
+}
+
+// s = a + b + cin ; returns carry out.  Local ripple, then a wave-wide carry look-ahead: with
+// per-lane generate g and (exclusive) propagate p, the carries of the 64-"bit" addition
+// (G|P) + G + cin are exactly the inter-lane carries.
+template <int E> __device__ __forceinline__ bool ld_add(LD<E>& s, const LD<E>& a, const LD<E>& b, bool cin) {
+    u64 c = 0;
+    bool allones = true;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        u64 t = a.v[e] + b.v[e];
+        u64 c1 = t < a.v[e];
+        u64 t2 = t + c;
+        u64 c2 = t2 < t;
+        s.v[e] = t2;
+        c = c1 | c2;
+        allones = allones && (t2 == ~0ull);
+    }
+    const bool g = c != 0;
+    const bool p = allones && !g;
+    const u64 G = __ballot(g), P = __ballot(p);
+    const u64 X = G | P, Y = G;
+    const u64 t = X + Y;
+    const u64 o1 = t < X;
+    const u64 t2 = t + (cin ? 1ull : 0ull);
+    const u64 o2 = t2 < t;
+    const u64 cmask = t2 ^ P;  // bit j = carry into lane j
+    u64 ci = (cmask >> lane_id()) & 1ull;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        u64 t3 = s.v[e] + ci;
+        ci = t3 < s.v[e];
+        s.v[e] = t3;
+    }
+    return (o1 | o2) != 0;
+}
+// d = a - b ; returns borrow out (true if a < b)
+template <int E> __device__ __forceinline__ bool ld_sub(LD<E>& d, const LD<E>& a, const LD<E>& b) {
+    LD<E> nb;
+#pragma unroll
+    for (int e = 0; e < E; ++e) nb.v[e] = ~b.v[e];
+    return !ld_add(d, a, nb, true);
+}
+
+__device__ __forceinline__ void mul64(u64 a, u64 b, u64& hi, u64& lo) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p00 = (u64)a0 * b0;
+    const u64 t = (u64)a0 * b1 + (p00 >> 32);
+    const u64 u = (u64)a1 * b0 + (u32)t;
+    lo = (u << 32) | (u32)p00;
+    hi = (u64)a1 * b1 + (t >> 32) + (u >> 32);
+}
+
+// full product of two capacity-sized integers: lo = low 64*E limbs, hi = high 64*E limbs
+template <int E> __device__ __noinline__ void ld_mul(LD<E>& lo, LD<E>& hi, const LD<E> a, const LD<E> b) {
+    u64 col[E];
+    u32 cc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        col[e] = 0;
+        cc[e] = 0;
+        lo.v[e] = 0;
+    }
+    const unsigned lane = lane_id();
+    for (unsigned jj = 0; jj < 64; ++jj) {
+#pragma unroll
+        for (int ee = 0; ee < E; ++ee) {
+            const u64 A = bcast64(a.v[ee], jj);
+            u64 pend = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                u64 ph, pl;
+                mul64(A, b.v[e], ph, pl);
+                u64 t = col[e] + pl;
+                cc[e] += t < pl;
+                col[e] = t;
+                if (e + 1 < E) {
+                    u64 t2 = col[e + 1] + ph;
+                    cc[e + 1] += t2 < ph;
+                    col[e + 1] = t2;
+                } else {
+                    pend = ph;
+                }
+            }
+            const u64 emit = bcast64(col[0], 0);
+            if (lane == jj) lo.v[ee] = emit;
+            // shift the column array one limb down
+            const u64 n0 = shfl_down1(col[0]);
+            const u32 ncc0 = shfl_down1_32(cc[0]);
+            u64 ncol[E];
+            u32 ncc[E];
+#pragma unroll
+            for (int e = 0; e + 1 < E; ++e) {
+                u64 t = col[e + 1] + cc[e];
+                ncc[e] = cc[e + 1] + (t < col[e + 1]);
+                ncol[e] = t;
+            }
+            {
+                u64 t = n0 + pend;
+                u32 k = ncc0 + (t < pend);
+                u64 t2 = t + cc[E - 1];
+                k += t2 < t;
+                ncol[E - 1] = t2;
+                ncc[E - 1] = k;
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                col[e] = ncol[e];
+                cc[e] = ncc[e];
+            }
+        }
+    }
+    // resolve: hi = col + (cc shifted up by one limb)
+    LD<E> cv, sh;
+#pragma unroll
+    for (int e = 0; e < E; ++e) cv.v[e] = col[e];
+    sh.v[0] = shfl_up1((u64)cc[E - 1]);
+#pragma unroll
+    for (int e = 1; e < E; ++e) sh.v[e] = cc[e - 1];
+    (void)ld_add(hi, cv, sh, false);
+}
+
+// per-wave LDS scratch: 4*64*E u64 (a 2C-limb value twice)
+template <int E> struct BarrettCtx {
+    LD<E> M;      // modulus << s (top bit of the capacity set)
+    LD<E> mu;     // floor(2^(2N)/M') - 2^N, N = 64*64*E
+    unsigned s;   // normalisation shift in bits
+    unsigned limbs;  // real limb count L of operands / results
+    volatile u64* sm;  // this wave's LDS scratch, 2*64*E limbs
+};
+
+// y = (x_hi:x_lo) << s, as two halves; returns true if non-zero bits were shifted out
+template <int E>
+__device__ __forceinline__ bool shl_2c(const BarrettCtx<E>& B, LD<E>& ylo, LD<E>& yhi, const LD<E>& xlo, const LD<E>& xhi) {
+    constexpr unsigned C = 64 * E;
+    const unsigned ls = B.s >> 6, bs = B.s & 63;
+    const unsigned lane = lane_id();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        B.sm[lane * E + e] = xlo.v[e];
+        B.sm[C + lane * E + e] = xhi.v[e];
+    }
+    __builtin_amdgcn_wave_barrier();
+    bool lost = false;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const unsigned t = h * C + lane * E + e;
+            u64 cur = t >= ls ? B.sm[t - ls] : 0;
+            u64 prv = t >= ls + 1 ? B.sm[t - ls - 1] : 0;
+            u64 v = bs ? (cur << bs) | (prv >> (64 - bs)) : cur;
+            if (h == 0) ylo.v[e] = v; else yhi.v[e] = v;
+            // source limb t is shifted (partly) out if t + ls >= 2C, or its top bs bits if t + ls == 2C-1
+            const u64 src = B.sm[t];
+            if (t + ls >= 2 * C) lost |= src != 0;
+            else if (t + ls == 2 * C - 1 && bs) lost |= (src >> (64 - bs)) != 0;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return __ballot(lost) != 0;
+}
+// y = x >> s (single capacity-sized value)
+template <int E> __device__ __forceinline__ LD<E> shr_c(const BarrettCtx<E>& B, const LD<E>& x) {
+    constexpr unsigned C = 64 * E;
+    const unsigned ls = B.s >> 6, bs = B.s & 63;
+    const unsigned lane = lane_id();
+#pragma unroll
+    for (int e = 0; e < E; ++e) B.sm[lane * E + e] = x.v[e];
+    __builtin_amdgcn_wave_barrier();
+    LD<E> y;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const unsigned t = lane * E + e;
+        u64 cur = t + ls < C ? B.sm[t + ls] : 0;
+        u64 nxt = t + ls + 1 < C ? B.sm[t + ls + 1] : 0;
+        y.v[e] = bs ? (cur >> bs) | (nxt << (64 - bs)) : cur;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return y;
+}
+// y = x << s within the capacity (bits shifted out are dropped; used for the modulus only)
+template <int E> __device__ __forceinline__ LD<E> shl_c(const BarrettCtx<E>& B, const LD<E>& x) {
+    const unsigned ls = B.s >> 6, bs = B.s & 63;
+    const unsigned lane = lane_id();
+#pragma unroll
+    for (int e = 0; e < E; ++e) B.sm[lane * E + e] = x.v[e];
+    __builtin_amdgcn_wave_barrier();
+    LD<E> y;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const unsigned t = lane * E + e;
+        u64 cur = t >= ls ? B.sm[t - ls] : 0;
+        u64 prv = t >= ls + 1 ? B.sm[t - ls - 1] : 0;
+        y.v[e] = bs ? (cur << bs) | (prv >> (64 - bs)) : cur;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return y;
+}
+
+// bit length of a capacity-sized integer (0 for zero)
+template <int E> __device__ __forceinline__ unsigned ld_bitlen(const LD<E>& a) {
+    unsigned best = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (a.v[e]) best = (lane_id() * E + e) * 64 + (64 - __clzll(a.v[e]));
+    }
+    // max over lanes
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned o = __shfl_xor(best, off, 64);
+        best = o > best ? o : best;
+    }
+    return best;
+}
+
+// Barrett constants for modulus m (must be non-zero): returns false if m == 0
+template <int E> __device__ __noinline__ bool barrett_setup(BarrettCtx<E>& B, const LD<E> m) {
+    constexpr unsigned N = 64 * 64 * E;
+    const unsigned bl = ld_bitlen(m);
+    if (bl == 0) return false;
+    B.s = N - bl;
+    B.M = shl_c(B, m);
+    // R0 = 2^N - M' ; mu' = floor(2^N * R0 / M') by N steps of restoring division
+    LD<E> R, zero = ld_zero<E>();
+    (void)ld_sub(R, zero, B.M);  // wraps to 2^N - M'
+    LD<E> mu = ld_zero<E>();
+    LD<E> d;
+    if (!ld_sub(d, R, B.M)) {
+        // R0 >= M' only when M' == 2^(N-1): reciprocal would be 2^N, clamp to 2^N - 1
+#pragma unroll
+        for (int e = 0; e < E; ++e) mu.v[e] = ~0ull;
+        B.mu = mu;
+        return true;
+    }
+    for (unsigned i = 0; i < N; ++i) {
+        // R <<= 1 (top bit out in `top`)
+        u64 carry_in = shfl_up1(R.v[E - 1] >> 63);
+        const bool top = (bcast64(R.v[E - 1], 63) >> 63) != 0;
+#pragma unroll
+        for (int e = E - 1; e >= 1; --e) R.v[e] = (R.v[e] << 1) | (R.v[e - 1] >> 63);
+        R.v[0] = (R.v[0] << 1) | carry_in;
+        const bool borrow = ld_sub(d, R, B.M);
+        const bool bit = top || !borrow;
+        if (bit) R = d;
+        // mu = (mu << 1) | bit
+        u64 mc = shfl_up1(mu.v[E - 1] >> 63);
+#pragma unroll
+        for (int e = E - 1; e >= 1; --e) mu.v[e] = (mu.v[e] << 1) | (mu.v[e - 1] >> 63);
+        mu.v[0] = (mu.v[0] << 1) | mc;
+        if (bit && lane_id() == 0) mu.v[0] |= 1ull;
+    }
+    B.mu = mu;
+    return true;
+}
+
+enum { ST_OK = 0, ST_RANGE = 1, ST_ZERO_MOD = 2, ST_INTERNAL = 4 };
+
+// (q, r) = divmod(a*b, modulus).  Returns status bits.
+template <int E>
+__device__ __noinline__ unsigned mul_mod(const BarrettCtx<E>& B, LD<E>& q, LD<E>& r, const LD<E> a, const LD<E> b) {
+    unsigned st = ST_OK;
+    LD<E> xlo, xhi;
+    ld_mul(xlo, xhi, a, b);
+    LD<E> ylo, yhi;
+    if (shl_2c(B, ylo, yhi, xlo, xhi)) st |= ST_RANGE;  // quotient cannot fit the capacity
+    // qhat = yhi + hi(yhi * mu)
+    LD<E> plo, phi;
+    ld_mul(plo, phi, yhi, B.mu);
+    LD<E> qh;
+    if (ld_add(qh, yhi, phi, false)) st |= ST_RANGE;
+    // r' = y - qhat*M'  (low capacity limbs + one limb above)
+    LD<E> zlo, zhi;
+    ld_mul(zlo, zhi, qh, B.M);
+    LD<E> rr;
+    const bool b0 = ld_sub(rr, ylo, zlo);
+    u64 top = bcast64(yhi.v[0], 0) - bcast64(zhi.v[0], 0) - (b0 ? 1ull : 0ull);
+    for (int it = 0; it < 8; ++it) {
+        LD<E> d;
+        const bool borrow = ld_sub(d, rr, B.M);
+        if (top == 0 && borrow) break;  // 0 <= r' < M'
+        if (it == 7) { st |= ST_INTERNAL; break; }
+        rr = d;
+        top -= borrow ? 1ull : 0ull;
+        LD<E> z = ld_zero<E>();
+        if (ld_add(qh, qh, z, true)) st |= ST_RANGE;
+    }
+    r = shr_c(B, rr);
+    q = qh;
+    if (ld_exceeds(q, B.limbs)) st |= ST_RANGE;
+    return st;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+struct ChainDesc {
+    const u64* modulus;  // limbs_mod limbs; if square_modulus: n (limbs_mod = Ln) and the modulus is n*n
+    const u64* base;     // limbs_base limbs
+    const u64* exp;      // exp_limbs limbs
+    u64* steps;          // optional trace output (a|b|q|r per step, L limbs each)
+    u64* result;         // L limbs
+    u32* n_steps;        // optional
+    u32* status;         // status bits (atomicOr)
+    u32 limbs_mod, limbs_base, exp_limbs;
+    u32 L;               // operand/result limb count (limbs of the modulus n^2)
+    u32 square_modulus;
+    u32 steps_cap;
+};
+
+template <int E> __global__ __launch_bounds__(128) void k_pow_mod_chain(const ChainDesc* __restrict__ descs) {
+    constexpr unsigned C = 64 * E;
+    __shared__ u64 s_scratch[2][2 * C];   // per-wave shift scratch
+    __shared__ u64 s_cur[2][C];           // squaring chain hand-off, double buffered
+    const ChainDesc D = descs[blockIdx.x];
+    const unsigned wave = threadIdx.x >> 6;
+    BarrettCtx<E> B;
+    B.sm = s_scratch[wave];
+    B.limbs = D.L;
+    B.s = 0;
+    unsigned st = ST_OK;
+    LD<E> m = ld_load<E>(D.modulus, D.limbs_mod);
+    if (D.square_modulus) {
+        LD<E> lo, hi;
+        ld_mul(lo, hi, m, m);
+        m = lo;
+    }
+    const bool mod_ok = barrett_setup(B, m);
+    if (!mod_ok) st |= ST_ZERO_MOD;
+    // exponent bit length (uniform)
+    unsigned nbits = 0;
+    for (int i = (int)D.exp_limbs - 1; i >= 0; --i) {
+        u64 w = D.exp[i];
+        if (w) {
+            nbits = (unsigned)i * 64 + (64 - __clzll(w));
+            break;
+        }
+    }
+    LD<E> sq = ld_load<E>(D.base, D.limbs_base);
+    LD<E> acc = ld_small<E>(1);
+    unsigned step_idx = 0;  // index of this bit's squaring step
+    if (mod_ok) {
+        for (unsigned i = 0; i < nbits; ++i) {
+            const bool bit = (D.exp[i >> 6] >> (i & 63)) & 1;
+            if (wave == 0) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) s_cur[i & 1][lane_id() * E + e] = sq.v[e];
+            }
+            __syncthreads();
+            if (wave == 0) {
+                LD<E> q, r;
+                st |= mul_mod(B, q, r, sq, sq);
+                if (D.steps && step_idx < D.steps_cap) {
+                    u64* o = D.steps + (size_t)step_idx * 4 * D.L;
+                    ld_store(o, sq, D.L);
+                    ld_store(o + D.L, sq, D.L);
+                    ld_store(o + 2 * D.L, q, D.L);
+                    ld_store(o + 3 * D.L, r, D.L);
+                }
+                sq = r;
+            } else if (bit) {
+                LD<E> cur;
+#pragma unroll
+                for (int e = 0; e < E; ++e) cur.v[e] = s_cur[i & 1][lane_id() * E + e];
+                LD<E> q, r;
+                st |= mul_mod(B, q, r, acc, cur);
+                if (D.steps && step_idx + 1 < D.steps_cap) {
+                    u64* o = D.steps + (size_t)(step_idx + 1) * 4 * D.L;
+                    ld_store(o, acc, D.L);
+                    ld_store(o + D.L, cur, D.L);
+                    ld_store(o + 2 * D.L, q, D.L);
+                    ld_store(o + 3 * D.L, r, D.L);
+                }
+                acc = r;
+            }
+            step_idx += bit ? 2 : 1;
+        }
+    }
+    if (D.steps && step_idx > D.steps_cap) st |= ST_INTERNAL;
+    if (wave == 1) {
+        ld_store(D.result, acc, D.L);
+        if (D.n_steps && lane_id() == 0) *D.n_steps = step_idx;
+    }
+    if (st && lane_id() == 0) atomicOr(D.status, st);
+}
+
+struct MulDesc {
+    const u64 *a, *b, *modulus;
+    u64 *q, *r;
+    u64* step;  // optional a|b|q|r record
+    u32* status;
+    u32 limbs_a, limbs_b, limbs_mod, L, square_modulus;
+};
+
+template <int E> __global__ __launch_bounds__(64) void k_mul_mod(const MulDesc* __restrict__ descs) {
+    constexpr unsigned C = 64 * E;
+    __shared__ u64 s_scratch[2 * C];
+    const MulDesc D = descs[blockIdx.x];
+    BarrettCtx<E> B;
+    B.sm = s_scratch;
+    B.limbs = D.L;
+    B.s = 0;
+    unsigned st = ST_OK;
+    LD<E> m = ld_load<E>(D.modulus, D.limbs_mod);
+    if (D.square_modulus) {
+        LD<E> lo, hi;
+        ld_mul(lo, hi, m, m);
+        m = lo;
+    }
+    if (!barrett_setup(B, m)) {
+        if (lane_id() == 0) atomicOr(D.status, (u32)ST_ZERO_MOD);
+        return;
+    }
+    LD<E> a = ld_load<E>(D.a, D.limbs_a), b = ld_load<E>(D.b, D.limbs_b);
+    LD<E> q, r;
+    st |= mul_mod(B, q, r, a, b);
+    if (D.q) ld_store(D.q, q, D.L);
+    if (D.r) ld_store(D.r, r, D.L);
+    if (D.step) {
+        ld_store(D.step, a, D.L);
+        ld_store(D.step + D.L, b, D.L);
+        ld_store(D.step + 2 * D.L, q, D.L);
+        ld_store(D.step + 3 * D.L, r, D.L);
+    }
+    if (st && lane_id() == 0) atomicOr(D.status, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host
+// ------------------------------------------------------------------------------------------------
+static int status_to_rc(u32 st) {
+    if (st & ST_ZERO_MOD) return PZ_ERR_ZERO_MODULUS;
+    if (st & ST_RANGE) return PZ_ERR_RANGE;
+    if (st & ST_INTERNAL) return PZ_ERR_HIP;
+    return PZ_OK;
+}
+
+static int launch_chains(pz_ctx* ctx, const ChainDesc* d_descs, size_t n, unsigned L) {
+    if (L <= 64) hipLaunchKernelGGL(k_pow_mod_chain<1>, dim3((unsigned)n), dim3(128), 0, ctx->stream, d_descs);
+    else hipLaunchKernelGGL(k_pow_mod_chain<2>, dim3((unsigned)n), dim3(128), 0, ctx->stream, d_descs);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}
+static int launch_muls(pz_ctx* ctx, const MulDesc* d_descs, size_t n, unsigned L) {
+    if (L <= 64) hipLaunchKernelGGL(k_mul_mod<1>, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_descs);
+    else hipLaunchKernelGGL(k_mul_mod<2>, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_descs);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}
+
+extern "C" int pz_mul_mod(pz_ctx* ctx, uint32_t limbs, const uint64_t* a, const uint64_t* b, const uint64_t* modulus,
+                          uint64_t* q, uint64_t* r) {
+    if (!ctx || !a || !b || !modulus || !q || !r || limbs == 0) return PZ_ERR_INVALID;
+    if (limbs > 128) return PZ_ERR_UNSUPPORTED;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t lb = (size_t)limbs * 8;
+    void* d;
+    PZCHK(pz_ws_get(ctx, WS_BIG_A, 5 * lb + 256, &d));
+    char* base = (char*)d;
+    u32* d_status = (u32*)(base + 5 * lb);
+    MulDesc* d_desc = (MulDesc*)(base + 5 * lb + 64);
+    HIPCHK(ctx, hipMemcpyAsync(base, a, lb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(base + lb, b, lb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(base + 2 * lb, modulus, lb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(d_status, 0, 4, ctx->stream));
+    MulDesc h{};
+    h.a = (const u64*)base;
+    h.b = (const u64*)(base + lb);
+    h.modulus = (const u64*)(base + 2 * lb);
+    h.q = (u64*)(base + 3 * lb);
+    h.r = (u64*)(base + 4 * lb);
+    h.step = nullptr;
+    h.status = d_status;
+    h.limbs_a = h.limbs_b = h.limbs_mod = h.L = limbs;
+    h.square_modulus = 0;
+    HIPCHK(ctx, hipMemcpyAsync(d_desc, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+    PZCHK(launch_muls(ctx, d_desc, 1, limbs));
+    u32 st = 0;
+    HIPCHK(ctx, hipMemcpyAsync(q, base + 3 * lb, lb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(r, base + 4 * lb, lb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&st, d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return status_to_rc(st);
+}
+
+extern "C" int pz_paillier_trace(pz_ctx* ctx, uint32_t limbs_n2, const uint64_t* n2, const uint64_t* base,
+                                 const uint64_t* exp, uint32_t exp_limbs, uint64_t* steps_out, size_t* n_steps,
+                                 uint64_t* result) {
+    if (!ctx || !n2 || !base || !exp || !result || limbs_n2 == 0 || exp_limbs == 0) return PZ_ERR_INVALID;
+    if (steps_out && !n_steps) return PZ_ERR_INVALID;
+    if (limbs_n2 > 128) return PZ_ERR_UNSUPPORTED;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const unsigned L = limbs_n2;
+    const size_t lb = (size_t)L * 8, eb = (size_t)exp_limbs * 8;
+    // steps needed = bits(exp) + popcount(exp)
+    size_t need = 0;
+    {
+        int top = (int)exp_limbs - 1;
+        while (top >= 0 && exp[top] == 0) --top;
+        if (top >= 0) need = (size_t)top * 64 + (64 - __builtin_clzll(exp[top]));
+        for (uint32_t i = 0; i < exp_limbs; ++i) need += (size_t)__builtin_popcountll(exp[i]);
+    }
+    const size_t cap = steps_out ? *n_steps : 0;
+    if (steps_out && cap < need) return PZ_ERR_CAPACITY;
+    void *d_in, *d_steps = nullptr;
+    PZCHK(pz_ws_get(ctx, WS_BIG_A, 3 * lb + eb + 512, &d_in));
+    if (steps_out && need) PZCHK(pz_ws_get(ctx, WS_BIG_B, need * 4 * lb, &d_steps));
+    char* p = (char*)d_in;
+    HIPCHK(ctx, hipMemcpyAsync(p, n2, lb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(p + lb, base, lb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(p + 2 * lb, exp, eb, hipMemcpyHostToDevice, ctx->stream));
+    u32* d_status = (u32*)(p + 3 * lb + eb);
+    u32* d_nsteps = d_status + 1;
+    ChainDesc* d_desc = (ChainDesc*)(p + 3 * lb + eb + 64);
+    HIPCHK(ctx, hipMemsetAsync(d_status, 0, 8, ctx->stream));
+    ChainDesc h{};
+    h.modulus = (const u64*)p;
+    h.base = (const u64*)(p + lb);
+    h.exp = (const u64*)(p + 2 * lb);
+    h.steps = (u64*)d_steps;
+    h.result = (u64*)(p + 2 * lb + eb);
+    h.n_steps = d_nsteps;
+    h.status = d_status;
+    h.limbs_mod = L;
+    h.limbs_base = L;
+    h.exp_limbs = exp_limbs;
+    h.L = L;
+    h.square_modulus = 0;
+    h.steps_cap = (u32)need;
+    HIPCHK(ctx, hipMemcpyAsync(d_desc, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+    {
+        pz_timer tm(ctx, PZ_T_TRACE);
+        PZCHK(launch_chains(ctx, d_desc, 1, L));
+    }
+    u32 st[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(result, p + 2 * lb + eb, lb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(st, d_status, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (steps_out && need)
+        HIPCHK(ctx, hipMemcpyAsync(steps_out, d_steps, need * 4 * lb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_steps) *n_steps = st[1];
+    return status_to_rc(st[0]);
+}
+
+static int encrypt_impl(pz_ctx* ctx, uint32_t Ln, size_t batch, const uint64_t* n, const uint64_t* g,
+                        const uint64_t* m, const uint64_t* r, uint64_t* steps_out, int steps_on_device,
+                        size_t steps_cap, uint32_t* n_steps_g, uint32_t* n_steps_r, uint64_t* c_out) {
+    if (!ctx || !n || !g || !m || !r || !c_out || Ln == 0 || batch == 0) return PZ_ERR_INVALID;
+    const unsigned L = 2 * Ln;
+    if (L > 128) return PZ_ERR_UNSUPPORTED;
+    if (steps_cap > 0x7fffffffu) return PZ_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t nb = (size_t)Ln * 8, lb = (size_t)L * 8;
+    // exact per-instance step counts from the exponents (host side: they are public structure of the
+    // circuit, paillier.rs:50,54)
+    std::vector<uint32_t> ng(batch), nr(batch);
+    for (size_t i = 0; i < batch; ++i) {
+        auto count = [&](const uint64_t* e) {
+            size_t need = 0;
+            int top = (int)Ln - 1;
+            while (top >= 0 && e[top] == 0) --top;
+            if (top >= 0) need = (size_t)top * 64 + (64 - __builtin_clzll(e[top]));
+            for (uint32_t k = 0; k < Ln; ++k) need += (size_t)__builtin_popcountll(e[k]);
+            return (uint32_t)need;
+        };
+        ng[i] = count(m + i * Ln);
+        nr[i] = count(n + i * Ln);
+        if (steps_out && (size_t)ng[i] + nr[i] + 1 > steps_cap) return PZ_ERR_CAPACITY;
+    }
+    // device staging: inputs n,g,m,r (batch x Ln each), results gm, rn, c (batch x L), status, descs
+    const size_t in_bytes = 4 * batch * nb;
+    const size_t res_bytes = 3 * batch * lb;
+    const size_t desc_bytes = batch * (2 * sizeof(ChainDesc) + sizeof(MulDesc));
+    void* d;
+    PZCHK(pz_ws_get(ctx, WS_BIG_A, in_bytes + res_bytes + desc_bytes + 1024, &d));
+    char* p = (char*)d;
+    u64* d_n = (u64*)p;
+    u64* d_g = (u64*)(p + batch * nb);
+    u64* d_m = (u64*)(p + 2 * batch * nb);
+    u64* d_r = (u64*)(p + 3 * batch * nb);
+    u64* d_gm = (u64*)(p + in_bytes);
+    u64* d_rn = (u64*)(p + in_bytes + batch * lb);
+    u64* d_c = (u64*)(p + in_bytes + 2 * batch * lb);
+    u32* d_status = (u32*)(p + in_bytes + res_bytes);
+    char* d_descs = p + in_bytes + res_bytes + 256;
+    u64* d_steps = nullptr;
+    if (steps_out) {
+        if (steps_on_device) d_steps = steps_out;
+        else {
+            void* t;
+            PZCHK(pz_ws_get(ctx, WS_BIG_B, batch * steps_cap * 4 * lb, &t));
+            d_steps = (u64*)t;
+        }
+    }
+    HIPCHK(ctx, hipMemcpyAsync(d_n, n, batch * nb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_g, g, batch * nb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_m, m, batch * nb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_r, r, batch * nb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(d_status, 0, 4, ctx->stream));
+    std::vector<ChainDesc> ch(2 * batch);
+    std::vector<MulDesc> mu(batch);
+    for (size_t i = 0; i < batch; ++i) {
+        u64* st_i = d_steps ? d_steps + i * steps_cap * 4 * L : nullptr;
+        ChainDesc& a = ch[2 * i];
+        a = ChainDesc{};
+        a.modulus = d_n + i * Ln;
+        a.base = d_g + i * Ln;
+        a.exp = d_m + i * Ln;
+        a.steps = st_i;
+        a.result = d_gm + i * L;
+        a.n_steps = nullptr;
+        a.status = d_status;
+        a.limbs_mod = Ln;
+        a.limbs_base = Ln;
+        a.exp_limbs = Ln;
+        a.L = L;
+        a.square_modulus = 1;
+        a.steps_cap = ng[i];
+        ChainDesc& b = ch[2 * i + 1];
+        b = a;
+        b.base = d_r + i * Ln;
+        b.exp = d_n + i * Ln;
+        b.steps = st_i ? st_i + (size_t)ng[i] * 4 * L : nullptr;
+        b.result = d_rn + i * L;
+        b.steps_cap = nr[i];
+        MulDesc& f = mu[i];
+        f = MulDesc{};
+        f.a = d_gm + i * L;
+        f.b = d_rn + i * L;
+        f.modulus = d_n + i * Ln;
+        f.q = nullptr;
+        f.r = d_c + i * L;
+        f.step = st_i ? st_i + (size_t)(ng[i] + nr[i]) * 4 * L : nullptr;
+        f.status = d_status;
+        f.limbs_a = f.limbs_b = L;
+        f.limbs_mod = Ln;
+        f.L = L;
+        f.square_modulus = 1;
+    }
+    ChainDesc* d_ch = (ChainDesc*)d_descs;
+    MulDesc* d_mu = (MulDesc*)(d_descs + 2 * batch * sizeof(ChainDesc));
+    HIPCHK(ctx, hipMemcpyAsync(d_ch, ch.data(), ch.size() * sizeof(ChainDesc), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_mu, mu.data(), mu.size() * sizeof(MulDesc), hipMemcpyHostToDevice, ctx->stream));
+    {
+        pz_timer tm(ctx, PZ_T_TRACE);
+        PZCHK(launch_chains(ctx, d_ch, 2 * batch, L));
+        PZCHK(launch_muls(ctx, d_mu, batch, L));
+    }
+    u32 st = 0;
+    HIPCHK(ctx, hipMemcpyAsync(c_out, d_c, batch * lb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&st, d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (steps_out && !steps_on_device)
+        for (size_t i = 0; i < batch; ++i) {
+            size_t cnt = (size_t)ng[i] + nr[i] + 1;
+            HIPCHK(ctx, hipMemcpyAsync(steps_out + i * steps_cap * 4 * L, d_steps + i * steps_cap * 4 * L,
+                                       cnt * 4 * lb, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < batch; ++i) {
+        if (n_steps_g) n_steps_g[i] = ng[i];
+        if (n_steps_r) n_steps_r[i] = nr[i];
+    }
+    return status_to_rc(st);
+}
+
+extern "C" int pz_paillier_encrypt(pz_ctx* ctx, uint32_t limbs_n, size_t batch, const uint64_t* n, const uint64_t* g,
+                                   const uint64_t* m, const uint64_t* r, uint64_t* steps_out, size_t steps_cap,
+                                   uint32_t* n_steps_g, uint32_t* n_steps_r, uint64_t* c_out) {
+    return encrypt_impl(ctx, limbs_n, batch, n, g, m, r, steps_out, 0, steps_cap, n_steps_g, n_steps_r, c_out);
+}
+extern "C" int pz_paillier_encrypt_dev(pz_ctx* ctx, uint32_t limbs_n, size_t batch, const uint64_t* n,
+                                       const uint64_t* g, const uint64_t* m, const uint64_t* r, uint64_t* d_steps_out,
+                                       size_t steps_cap, uint32_t* n_steps_g, uint32_t* n_steps_r, uint64_t* c_out) {
+    return encrypt_impl(ctx, limbs_n, batch, n, g, m, r, d_steps_out, 1, steps_cap, n_steps_g, n_steps_r, c_out);
+}

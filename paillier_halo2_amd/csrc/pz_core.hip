@@ -1,0 +1,261 @@
+// pz_core.hip -- context, workspaces, cached power tables, timing and the two issue-rate
+// microbenchmarks of libpz_hip.so.  gfx950 only.
+#include "fp.cuh"
+#include "pz_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+// table[i] = base^i (Montgomery).  Thread t fills entries [t*CH, (t+1)*CH): start by
+// square-and-multiply over the bits of t*CH, then CH-1 successive products.
+__global__ void k_pow_table(Fr base, Fr* table, size_t n, unsigned ch) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t lo = t * ch;
+    if (lo >= n) return;
+    Fr acc = fp_one<FrTag>();
+    Fr sq = base;
+    size_t e = lo;
+    while (e) {
+        if (e & 1) acc = fp_mul(acc, sq);
+        sq = fp_sqr(sq);
+        e >>= 1;
+    }
+    size_t hi = lo + ch < n ? lo + ch : n;
+    for (size_t i = lo; i < hi; ++i) {
+        fp_store(table + i, acc);
+        acc = fp_mul(acc, base);
+    }
+}
+
+// issue-rate probes --------------------------------------------------------------------------
+__global__ void k_ubench_mad(u64* out, unsigned iters) {
+    u32 a = threadIdx.x * 2654435761u + 12345u, b = blockIdx.x * 40503u + 7u;
+    u64 x0 = a, x1 = b, x2 = a ^ b, x3 = a + b, x4 = a * 3, x5 = b * 5, x6 = a - b, x7 = ~a;
+    for (unsigned i = 0; i < iters; ++i) {
+        // 8 independent accumulators: measures issue throughput, not dependent latency
+        x0 = (u64)a * (u32)x0 + x0;
+        x1 = (u64)b * (u32)x1 + x1;
+        x2 = (u64)a * (u32)x2 + x2;
+        x3 = (u64)b * (u32)x3 + x3;
+        x4 = (u64)a * (u32)x4 + x4;
+        x5 = (u64)b * (u32)x5 + x5;
+        x6 = (u64)a * (u32)x6 + x6;
+        x7 = (u64)b * (u32)x7 + x7;
+    }
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7;
+}
+
+__global__ void k_ubench_fqmul(Fq* out, unsigned iters) {
+    Fq x = fp_one<FqTag>(), y = fp_one<FqTag>();
+    x.v[0] ^= threadIdx.x;
+    y.v[1] ^= blockIdx.x;
+    for (unsigned i = 0; i < iters; ++i) {
+        x = fp_mul(x, y);
+        y = fp_mul(y, x);
+    }
+    fp_store(out + (size_t)blockIdx.x * blockDim.x + threadIdx.x, fp_add(x, y));
+}
+
+// ------------------------------------------------------------------------------------------------
+// host
+// ------------------------------------------------------------------------------------------------
+extern "C" int pz_abi_version(void) { return 1; }
+
+extern "C" const char* pz_strerror(int s) {
+    switch (s) {
+        case PZ_OK: return "ok";
+        case PZ_ERR_INVALID: return "invalid argument";
+        case PZ_ERR_HIP: return "HIP runtime error";
+        case PZ_ERR_NO_DEVICE: return "no gfx950 device";
+        case PZ_ERR_OOM: return "device out of memory";
+        case PZ_ERR_ZERO_MODULUS: return "modulus is zero";
+        case PZ_ERR_RANGE: return "quotient does not fit the assigned limb count";
+        case PZ_ERR_UNSUPPORTED: return "unsupported configuration";
+        case PZ_ERR_CAPACITY: return "output capacity too small";
+        default: return "unknown pz_status";
+    }
+}
+
+extern "C" const char* pz_last_hip_error(const pz_ctx* ctx) { return ctx ? ctx->hip_err : ""; }
+
+extern "C" int pz_init(int n_devices, const int* device_ids, pz_ctx** out) {
+    if (!out) return PZ_ERR_INVALID;
+    *out = nullptr;
+    if (n_devices != 1) return PZ_ERR_UNSUPPORTED;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return PZ_ERR_NO_DEVICE;
+    int dev = device_ids ? device_ids[0] : 0;
+    if (dev < 0 || dev >= count) return PZ_ERR_INVALID;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return PZ_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return PZ_ERR_NO_DEVICE;  // code objects are gfx950 only
+    pz_ctx* ctx = new pz_ctx();
+    ctx->device = dev;
+    ctx->cu_count = prop.multiProcessorCount;
+    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return PZ_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return PZ_OK;
+}
+
+extern "C" int pz_free(pz_ctx* ctx) {
+    if (!ctx) return PZ_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto& w : ctx->ws)
+        if (w.d) (void)hipFree(w.d);
+    for (auto& t : ctx->pow_tables)
+        if (t.d) (void)hipFree(t.d);
+    for (auto& v : ctx->ev)
+        for (auto& p : v) {
+            (void)hipEventDestroy(p.a);
+            (void)hipEventDestroy(p.b);
+        }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return PZ_OK;
+}
+
+extern "C" int pz_set_stream(pz_ctx* ctx, void* s) {
+    if (!ctx) return PZ_ERR_INVALID;
+    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    return PZ_OK;
+}
+
+extern "C" int pz_sync(pz_ctx* ctx) {
+    if (!ctx) return PZ_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PZ_OK;
+}
+
+int pz_ws_get(pz_ctx* ctx, int slot, size_t bytes, void** out) {
+    pz_wsbuf& w = ctx->ws[slot];
+    if (w.cap < bytes) {
+        // in-flight kernels may still use the old buffer
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (w.d) HIPCHK(ctx, hipFree(w.d));
+        w.d = nullptr;
+        w.cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        HIPCHK(ctx, hipMalloc(&w.d, want));
+        w.cap = want;
+    }
+    *out = w.d;
+    return PZ_OK;
+}
+
+int pz_get_pow_table(pz_ctx* ctx, const uint64_t base[4], size_t n, void** d_out) {
+    for (auto& t : ctx->pow_tables)
+        if (t.n >= n && memcmp(t.base, base, 32) == 0) {
+            *d_out = t.d;
+            return PZ_OK;
+        }
+    pz_pow_table t;
+    memcpy(t.base, base, 32);
+    t.n = n;
+    HIPCHK(ctx, hipMalloc(&t.d, n * 32));
+    Fr b;
+    memcpy(b.v, base, 32);
+    const unsigned ch = 64;
+    size_t threads = (n + ch - 1) / ch;
+    hipLaunchKernelGGL(k_pow_table, dim3(pz_div_up(threads, 128)), dim3(128), 0, ctx->stream, b, (Fr*)t.d, n, ch);
+    HIPCHK(ctx, hipGetLastError());
+    ctx->pow_tables.push_back(t);
+    *d_out = t.d;
+    return PZ_OK;
+}
+
+// ---- timing ------------------------------------------------------------------------------------
+pz_timer::pz_timer(pz_ctx* c, int cls_) : ctx(c), cls(cls_), on(c->timing), idx(0) {
+    if (!on) return;
+    auto& v = ctx->ev[cls];
+    if (ctx->ev_used[cls] == v.size()) {
+        pz_event_pair p;
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) {
+            on = false;
+            return;
+        }
+        v.push_back(p);
+    }
+    idx = ctx->ev_used[cls]++;
+    (void)hipEventRecord(v[idx].a, ctx->stream);
+}
+pz_timer::~pz_timer() {
+    if (on) (void)hipEventRecord(ctx->ev[cls][idx].b, ctx->stream);
+}
+
+static void pz_timing_collect(pz_ctx* ctx) {
+    for (int c = 0; c < PZ_T_COUNT; ++c) {
+        for (size_t i = 0; i < ctx->ev_used[c]; ++i) {
+            float ms = 0;
+            if (hipEventSynchronize(ctx->ev[c][i].b) == hipSuccess &&
+                hipEventElapsedTime(&ms, ctx->ev[c][i].a, ctx->ev[c][i].b) == hipSuccess) {
+                ctx->ev_ms[c] += ms;
+                ctx->ev_n[c] += 1;
+            }
+        }
+        ctx->ev_used[c] = 0;
+    }
+}
+
+extern "C" int pz_timing_enable(pz_ctx* ctx, int on) {
+    if (!ctx) return PZ_ERR_INVALID;
+    if (!on && ctx->timing) pz_timing_collect(ctx);
+    ctx->timing = on != 0;
+    return PZ_OK;
+}
+extern "C" int pz_timing_reset(pz_ctx* ctx) {
+    if (!ctx) return PZ_ERR_INVALID;
+    pz_timing_collect(ctx);
+    for (int c = 0; c < PZ_T_COUNT; ++c) {
+        ctx->ev_ms[c] = 0;
+        ctx->ev_n[c] = 0;
+    }
+    return PZ_OK;
+}
+extern "C" int pz_timing_get(pz_ctx* ctx, int which, double* total_ms, uint64_t* launches) {
+    if (!ctx || which < 0 || which >= PZ_T_COUNT) return PZ_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    pz_timing_collect(ctx);
+    if (total_ms) *total_ms = ctx->ev_ms[which];
+    if (launches) *launches = ctx->ev_n[which];
+    return PZ_OK;
+}
+
+// ---- microbenchmarks ---------------------------------------------------------------------------
+template <class K, class... A>
+static int timed_launch(pz_ctx* ctx, double* ms, K kern, dim3 g, dim3 b, A... args) {
+    hipEvent_t e0, e1;
+    HIPCHK(ctx, hipEventCreate(&e0));
+    HIPCHK(ctx, hipEventCreate(&e1));
+    hipLaunchKernelGGL(kern, g, b, 0, ctx->stream, args...);  // warm
+    HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+    hipLaunchKernelGGL(kern, g, b, 0, ctx->stream, args...);
+    HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(e1));
+    float f = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&f, e0, e1));
+    *ms = f;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return PZ_OK;
+}
+
+extern "C" int pz_ubench_mad(pz_ctx* ctx, uint32_t blocks, uint32_t iters, double* ms) {
+    if (!ctx || !ms || !blocks) return PZ_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    void* d;
+    PZCHK(pz_ws_get(ctx, WS_MISC, (size_t)blocks * 256 * 32, &d));
+    return timed_launch(ctx, ms, k_ubench_mad, dim3(blocks), dim3(256), (u64*)d, (unsigned)iters);
+}
+extern "C" int pz_ubench_fqmul(pz_ctx* ctx, uint32_t blocks, uint32_t iters, double* ms) {
+    if (!ctx || !ms || !blocks) return PZ_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    void* d;
+    PZCHK(pz_ws_get(ctx, WS_MISC, (size_t)blocks * 256 * 32, &d));
+    return timed_launch(ctx, ms, k_ubench_fqmul, dim3(blocks), dim3(256), (Fq*)d, (unsigned)iters);
+}

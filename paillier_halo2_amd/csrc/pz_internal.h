@@ -1,0 +1,87 @@
+// pz_internal.h -- shared host-side plumbing of libpz_hip.so (context, workspaces, error handling,
+// HIP-event timing).  Not part of the ABI; the ABI is include/pz.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/pz.h"
+
+enum { PZ_T_MSM_ACC = 0, PZ_T_NTT = 1, PZ_T_TRACE = 2, PZ_T_EXPAND = 3, PZ_T_MSM_ALL = 4, PZ_T_COUNT = 5 };
+
+struct pz_pow_table {   // cached table base^i, i < n  (twiddles omega^i, coset powers g^i)
+    uint64_t base[4];
+    size_t n;
+    void* d;            // n x 32 B
+};
+
+struct pz_wsbuf {
+    void* d = nullptr;
+    size_t cap = 0;
+};
+
+enum { WS_HIST = 0, WS_OFFS, WS_CURSOR, WS_ITEMS, WS_ENTRIES, WS_PARTIALS, WS_NODES_A, WS_NODES_B, WS_NTT_TMP,
+       WS_IO_A, WS_IO_B, WS_IO_C, WS_BIG_A, WS_BIG_B, WS_BIG_C, WS_MISC, WS_COUNT };
+
+struct pz_event_pair {
+    hipEvent_t a, b;
+};
+
+struct pz_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    char hip_err[256] = {0};
+    pz_wsbuf ws[WS_COUNT];
+    std::vector<pz_pow_table> pow_tables;
+    bool timing = false;
+    std::vector<pz_event_pair> ev[PZ_T_COUNT];
+    size_t ev_used[PZ_T_COUNT] = {0};
+    double ev_ms[PZ_T_COUNT] = {0};
+    uint64_t ev_n[PZ_T_COUNT] = {0};
+    int cu_count = 256;
+};
+
+struct pz_bases {
+    size_t n = 0;          // points
+    uint32_t c = 0;        // window bits
+    uint32_t nwin = 0;     // floor(253/c)+1
+    void* d_table = nullptr;  // nwin x n affine points (64 B), window-major
+    int lagrange = 0;
+    int device = 0;
+};
+
+static inline int pz_hip_fail(pz_ctx* ctx, hipError_t e, const char* what) {
+    if (ctx) snprintf(ctx->hip_err, sizeof ctx->hip_err, "%s: %s", what, hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? PZ_ERR_OOM : PZ_ERR_HIP;
+}
+#define HIPCHK(ctx, x)                                              \
+    do {                                                            \
+        hipError_t e_ = (x);                                        \
+        if (e_ != hipSuccess) return pz_hip_fail((ctx), e_, #x);    \
+    } while (0)
+#define PZCHK(x)                    \
+    do {                            \
+        int rc_ = (x);              \
+        if (rc_ != PZ_OK) return rc_; \
+    } while (0)
+
+// grow-only workspace slot; contents are NOT preserved across growth
+int pz_ws_get(pz_ctx* ctx, int slot, size_t bytes, void** out);
+// cached base^i table (device, Fr Montgomery)
+int pz_get_pow_table(pz_ctx* ctx, const uint64_t base[4], size_t n, void** d_out);
+
+// timing scopes: record an event pair around a kernel-class region on ctx->stream
+struct pz_timer {
+    pz_ctx* ctx;
+    int cls;
+    bool on;
+    size_t idx;
+    pz_timer(pz_ctx* c, int cls_);
+    ~pz_timer();
+};
+
+static inline unsigned pz_div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

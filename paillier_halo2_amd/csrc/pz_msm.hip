@@ -1,0 +1,594 @@
+// pz_msm.hip -- K1: BN254 G1 multi-scalar multiplication (== halo2curves best_multiexp, reached
+// from /root/reference/src/bench.rs:161-171 through create_proof -> commit_lagrange / commit).
+//
+// MI355X-first design (not a translation of the CPU bucket loop):
+//   * the base set is loaded ONCE into HBM as a window-shifted table T[w][i] = 2^(c*w) * P_i
+//     (288 GB of HBM makes nwin x the SRS affordable: 2^17 points x 16 windows = 134 MB), so all
+//     Pippenger windows of one MSM share ONE bucket set: no per-window running sums and no serial
+//     Horner fold of c*nwin doublings at the end;
+//   * scalars -> signed c-bit digits (sign folded into the point), zero digits dropped -- witness
+//     columns are mostly short scalars, their cost is proportional to the non-zero digits;
+//   * digits are counting-sorted by bucket in HBM (histogram -> scan -> scatter), then one lane
+//     owns one bucket chunk and accumulates in XYZZ coordinates with a gather of 64-byte table
+//     rows (the table stays Infinity-Cache resident across the columns of a batch); over-full
+//     buckets are split into chunks of MSM_CHUNK entries so skewed scalars cannot serialise;
+//   * sum_b b*B_b by a radix-16 tree of (weighted sum, plain sum) nodes.
+// Every kernel takes grid.y = column, so a batch of column commitments is one launch sequence.
+//
+// Roofline: bounded by 32-bit integer multiply issue (v_mad_u64_u32), NOT by HBM: algorithmic
+// traffic is 96 B per (scalar, base) pair; bench.py reports both fractions.
+#include "ec.cuh"
+#include "pz_internal.h"
+
+#define MSM_CHUNK 256u  // max entries one lane accumulates for one bucket chunk
+
+struct MsmP {
+    size_t n;          // scalars per column
+    size_t n_table;    // points per window row of the table
+    unsigned c;        // window bits
+    unsigned nwin;     // windows in the table
+    unsigned win_lo, win_hi;
+    unsigned B;        // buckets = 1 << (c-1)
+    size_t cap;        // entry capacity per column = n * (win_hi - win_lo)
+    size_t max_items;  // work items per column (upper bound) = B + cap / MSM_CHUNK
+};
+
+__device__ __forceinline__ u32 sel8(const u32 s[8], unsigned i) {
+    u32 r = s[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) r = (i == (unsigned)k) ? s[k] : r;
+    return r;
+}
+
+// canonical |k| with sign: k in [0, r) Montgomery -> s = min(k, r-k), neg = (r-k < k)
+__device__ __forceinline__ bool scalar_prepare(const Fr& mont, u32 s[8]) {
+    Fr k = fp_from_mont(mont);
+    Fr t;
+    u64 br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u64 d = (u64)FieldParams<FrTag>::P(i) - k.v[i] - br;
+        t.v[i] = (u32)d;
+        br = (d >> 32) & 1;
+    }
+    // lexicographic t < k ?
+    bool lt = false, decided = false;
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {
+        if (!decided && t.v[i] != k.v[i]) {
+            lt = t.v[i] < k.v[i];
+            decided = true;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = lt ? t.v[i] : k.v[i];
+    return lt;
+}
+
+// signed digit of window w given the running carry: d in (-2^(c-1), 2^(c-1)]
+__device__ __forceinline__ int next_digit(const u32 s[8], unsigned w, unsigned c, unsigned& carry) {
+    unsigned off = w * c;
+    unsigned wi = off >> 5, sh = off & 31;
+    u32 lo = wi < 8 ? sel8(s, wi) : 0;
+    u32 hi = wi + 1 < 8 ? sel8(s, wi + 1) : 0;
+    u64 both = ((u64)hi << 32) | lo;
+    unsigned raw = (unsigned)(both >> sh) & ((1u << c) - 1);
+    unsigned d = raw + carry;
+    if (d > (1u << (c - 1))) {
+        carry = 1;
+        return (int)d - (int)(1u << c);
+    }
+    carry = 0;
+    return (int)d;
+}
+
+// ------------------------------------------------------------------------------------------------
+// table build: T[w][i] = 2^(c*w) * P_i, affine
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_build_table(const G1Affine* __restrict__ bases, G1Affine* __restrict__ table,
+                                                     size_t n, unsigned c, unsigned nwin) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1Affine p = aff_load(bases + i);
+    aff_store(table + i, p);
+    G1X x = x_from_affine(p);
+    for (unsigned w = 1; w < nwin; ++w) {
+        for (unsigned k = 0; k < c; ++k) x = x_dbl(x);
+        G1Affine a = x_to_affine(x);
+        aff_store(table + (size_t)w * n + i, a);
+        x = x_from_affine(a);  // back to Z = 1: keeps the next conversion's operands small
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 1: histogram of non-zero digits per bucket
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_msm_hist(const Fr* __restrict__ scalars, size_t col_stride, MsmP p,
+                                                  u32* __restrict__ hist) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    const size_t col = blockIdx.y;
+    u32 s[8];
+    (void)scalar_prepare(fp_load<FrTag>(scalars + col * col_stride + i), s);
+    u32 any = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) any |= s[k];
+    if (!any) return;
+    unsigned carry = 0;
+    u32* h = hist + col * p.B;
+    for (unsigned w = 0; w < p.win_hi; ++w) {
+        int d = next_digit(s, w, p.c, carry);
+        if (w >= p.win_lo && d != 0) atomicAdd(h + ((d < 0 ? -d : d) - 1), 1u);
+    }
+}
+
+// per column: exclusive scans of the bucket counts (entry offsets) and of ceil(cnt/CHUNK) (item offsets)
+__global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, MsmP p, u32* __restrict__ offs,
+                                                  u32* __restrict__ items) {
+    __shared__ u32 s_cnt[256], s_itm[256];
+    const size_t col = blockIdx.x;
+    const u32* h = hist + col * p.B;
+    u32* o = offs + col * (p.B + 1);
+    u32* it = items + col * (p.B + 1);
+    const unsigned per = (p.B + 255) / 256;
+    const unsigned lo = threadIdx.x * per;
+    u32 c = 0, m = 0;
+    for (unsigned k = 0; k < per; ++k) {
+        unsigned b = lo + k;
+        if (b < p.B) {
+            u32 v = h[b];
+            c += v;
+            m += (v + MSM_CHUNK - 1) / MSM_CHUNK;
+        }
+    }
+    s_cnt[threadIdx.x] = c;
+    s_itm[threadIdx.x] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 a = 0, b2 = 0;
+        for (int k = 0; k < 256; ++k) {
+            u32 t = s_cnt[k];
+            s_cnt[k] = a;
+            a += t;
+            u32 t2 = s_itm[k];
+            s_itm[k] = b2;
+            b2 += t2;
+        }
+        o[p.B] = a;
+        it[p.B] = b2;
+    }
+    __syncthreads();
+    c = s_cnt[threadIdx.x];
+    m = s_itm[threadIdx.x];
+    for (unsigned k = 0; k < per; ++k) {
+        unsigned b = lo + k;
+        if (b < p.B) {
+            u32 v = h[b];
+            o[b] = c;
+            it[b] = m;
+            c += v;
+            m += (v + MSM_CHUNK - 1) / MSM_CHUNK;
+        }
+    }
+}
+
+// pass 2: scatter (table index | sign << 31) into bucket order
+__global__ __launch_bounds__(256) void k_msm_scatter(const Fr* __restrict__ scalars, size_t col_stride, MsmP p,
+                                                     const u32* __restrict__ offs, u32* __restrict__ cursor,
+                                                     u32* __restrict__ entries) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    const size_t col = blockIdx.y;
+    u32 s[8];
+    bool neg = scalar_prepare(fp_load<FrTag>(scalars + col * col_stride + i), s);
+    u32 any = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) any |= s[k];
+    if (!any) return;
+    unsigned carry = 0;
+    const u32* o = offs + col * (p.B + 1);
+    u32* cur = cursor + col * p.B;
+    u32* e = entries + col * p.cap;
+    for (unsigned w = 0; w < p.win_hi; ++w) {
+        int d = next_digit(s, w, p.c, carry);
+        if (w >= p.win_lo && d != 0) {
+            unsigned b = (d < 0 ? -d : d) - 1;
+            u32 pos = o[b] + atomicAdd(cur + b, 1u);
+            bool sgn = neg != (d < 0);
+            e[pos] = (u32)((size_t)w * p.n_table + i) | (sgn ? 0x80000000u : 0u);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bucket accumulation: one lane per (bucket, chunk) work item
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_msm_accumulate(const G1Affine* __restrict__ table, MsmP p,
+                                                        const u32* __restrict__ offs, const u32* __restrict__ items,
+                                                        const u32* __restrict__ entries, G1X* __restrict__ partials) {
+    const size_t col = blockIdx.y;
+    const u32* it = items + col * (p.B + 1);
+    const u32 total = it[p.B];
+    const u32 item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= total) return;
+    // bucket b with it[b] <= item < it[b+1]
+    unsigned lo = 0, hi = p.B;
+    while (hi - lo > 1) {
+        unsigned mid = (lo + hi) >> 1;
+        if (it[mid] <= item) lo = mid; else hi = mid;
+    }
+    const unsigned b = lo;
+    const u32* o = offs + col * (p.B + 1);
+    const u32 start = o[b] + (item - it[b]) * MSM_CHUNK;
+    u32 end = start + MSM_CHUNK;
+    if (end > o[b + 1]) end = o[b + 1];
+    const u32* e = entries + col * p.cap;
+    G1X acc = x_inf();
+    for (u32 k = start; k < end; ++k) {
+        u32 ent = e[k];
+        G1Affine q = aff_load(table + (ent & 0x7fffffffu));
+        if (ent & 0x80000000u) q.y = fp_neg(q.y);
+        x_add_affine(acc, q);
+    }
+    x_store(partials + col * p.max_items + item, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// sum_b (b+1) * B_b  as a tree of nodes {V = weighted sum with local weights 1.., S = plain sum}
+// ------------------------------------------------------------------------------------------------
+struct alignas(16) MsmNode {
+    G1X V, S;
+};
+
+// level 1: node t covers buckets [t*m, (t+1)*m)
+__global__ __launch_bounds__(128) void k_msm_reduce_l1(MsmP p, unsigned m, const u32* __restrict__ items,
+                                                       const G1X* __restrict__ partials, MsmNode* __restrict__ nodes) {
+    const size_t col = blockIdx.y;
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned nn = p.B / m;
+    if (t >= nn) return;
+    const u32* it = items + col * (p.B + 1);
+    const G1X* pc = partials + col * p.max_items;
+    G1X run = x_inf(), acc = x_inf();
+    for (unsigned j = m; j-- > 0;) {
+        unsigned b = t * m + j;
+        u32 a = it[b], z = it[b + 1];
+        for (u32 k = a; k < z; ++k) {
+            G1X v = x_load(pc + k);
+            x_add(run, v);
+        }
+        x_add(acc, run);
+    }
+    MsmNode* o = nodes + col * nn + t;
+    x_store(&o->V, acc);
+    x_store(&o->S, run);
+}
+
+// upper levels: m children of span w buckets each -> V = sum V_k + w * sum k*S_k, S = sum S_k
+__global__ __launch_bounds__(128) void k_msm_combine(unsigned n_in, unsigned m, unsigned log_w,
+                                                     const MsmNode* __restrict__ in, MsmNode* __restrict__ out) {
+    const size_t col = blockIdx.y;
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned n_out = n_in / m;
+    if (t >= n_out) return;
+    const MsmNode* c = in + col * n_in + (size_t)t * m;
+    G1X run = x_inf(), acc = x_inf();
+    for (unsigned k = m; k-- > 1;) {
+        G1X s = x_load(&c[k].S);
+        x_add(run, s);
+        x_add(acc, run);
+    }
+    for (unsigned k = 0; k < log_w; ++k) acc = x_dbl(acc);
+    G1X s0 = x_load(&c[0].S);
+    x_add(run, s0);
+    for (unsigned k = 0; k < m; ++k) {
+        G1X v = x_load(&c[k].V);
+        x_add(acc, v);
+    }
+    MsmNode* o = out + col * n_out + t;
+    x_store(&o->V, acc);
+    x_store(&o->S, run);
+}
+
+__global__ void k_msm_emit(const MsmNode* __restrict__ nodes, size_t n_cols, G1Jac* __restrict__ out) {
+    size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= n_cols) return;
+    G1X v = x_load(&nodes[col].V);
+    jac_store(out + col, x_to_jac(v));
+}
+
+// small utilities -------------------------------------------------------------------------------
+__global__ void k_g1_sum(const G1Jac* __restrict__ in, size_t n, G1Jac* __restrict__ out) {
+    if (blockIdx.x || threadIdx.x) return;
+    G1X acc = x_inf();
+    for (size_t i = 0; i < n; ++i) {
+        G1Jac j;
+        j.x = fp_load<FqTag>(&in[i].x);
+        j.y = fp_load<FqTag>(&in[i].y);
+        j.z = fp_load<FqTag>(&in[i].z);
+        G1X x = jac_to_x(j);
+        x_add(acc, x);
+    }
+    jac_store(out, x_to_jac(acc));
+}
+
+__global__ void k_g1_normalize(const G1Jac* __restrict__ in, size_t n, G1Affine* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1Jac j;
+    j.x = fp_load<FqTag>(&in[i].x);
+    j.y = fp_load<FqTag>(&in[i].y);
+    j.z = fp_load<FqTag>(&in[i].z);
+    aff_store(out + i, x_to_affine(jac_to_x(j)));
+}
+
+// out[i] = [k_i] G, G = (1, 2); plain double-and-add over the canonical scalar bits
+__global__ __launch_bounds__(128) void k_fixed_base_mul(const Fr* __restrict__ scalars, size_t n,
+                                                        G1Affine* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr k = fp_from_mont(fp_load<FrTag>(scalars + i));
+    G1Affine g;
+    g.x = fp_one<FqTag>();
+    g.y = fp_dbl(g.x);
+    G1X acc = x_inf();
+    for (int bit = 253; bit >= 0; --bit) {
+        acc = x_dbl(acc);
+        u32 w = sel8(k.v, (unsigned)bit >> 5);
+        if ((w >> (bit & 31)) & 1) x_add_affine(acc, g);
+    }
+    aff_store(out + i, x_to_affine(acc));
+}
+
+// ------------------------------------------------------------------------------------------------
+// host
+// ------------------------------------------------------------------------------------------------
+static unsigned default_window_bits(size_t n) {
+    if (n <= 1u << 8) return 9;
+    if (n <= 1u << 11) return 11;
+    if (n <= 1u << 14) return 13;
+    return 16;
+}
+
+extern "C" int pz_bases_load_g1(pz_ctx* ctx, const uint64_t* bases_affine, size_t n_points, int on_device,
+                                uint32_t window_bits, pz_bases** out) {
+    if (!ctx || !out || !bases_affine || n_points == 0) return PZ_ERR_INVALID;
+    *out = nullptr;
+    unsigned c = window_bits ? window_bits : default_window_bits(n_points);
+    if (c < 4 || c > 16) return PZ_ERR_INVALID;
+    unsigned nwin = 253 / c + 1;
+    if ((uint64_t)nwin * n_points >= (1ull << 31)) return PZ_ERR_UNSUPPORTED;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    pz_bases* b = new pz_bases();
+    b->n = n_points;
+    b->c = c;
+    b->nwin = nwin;
+    b->device = ctx->device;
+    hipError_t e = hipMalloc(&b->d_table, (size_t)nwin * n_points * 64);
+    if (e != hipSuccess) {
+        delete b;
+        return pz_hip_fail(ctx, e, "hipMalloc(table)");
+    }
+    const void* d_src = bases_affine;
+    if (!on_device) {
+        void* stage;
+        int rc = pz_ws_get(ctx, WS_IO_A, n_points * 64, &stage);
+        if (rc != PZ_OK) { (void)hipFree(b->d_table); delete b; return rc; }
+        e = hipMemcpyAsync(stage, bases_affine, n_points * 64, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) { (void)hipFree(b->d_table); delete b; return pz_hip_fail(ctx, e, "memcpy bases"); }
+        d_src = stage;
+    }
+    hipLaunchKernelGGL(k_build_table, dim3(pz_div_up(n_points, 128)), dim3(128), 0, ctx->stream,
+                       (const G1Affine*)d_src, (G1Affine*)b->d_table, n_points, c, nwin);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(b->d_table); delete b; return pz_hip_fail(ctx, e, "k_build_table"); }
+    *out = b;
+    return PZ_OK;
+}
+
+extern "C" int pz_srs_load_g1(pz_ctx* ctx, uint32_t k, const uint64_t* bases_affine, int lagrange, pz_bases** out) {
+    if (k > 26) return PZ_ERR_INVALID;
+    int rc = pz_bases_load_g1(ctx, bases_affine, (size_t)1 << k, 0, 0, out);
+    if (rc == PZ_OK) (*out)->lagrange = lagrange;
+    return rc;
+}
+
+extern "C" int pz_bases_free(pz_ctx* ctx, pz_bases* b) {
+    if (!b) return PZ_OK;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    if (b->d_table) (void)hipFree(b->d_table);
+    delete b;
+    return PZ_OK;
+}
+
+extern "C" int pz_bases_info(const pz_bases* b, size_t* n_points, uint32_t* window_bits, uint32_t* n_windows) {
+    if (!b) return PZ_ERR_INVALID;
+    if (n_points) *n_points = b->n;
+    if (window_bits) *window_bits = b->c;
+    if (n_windows) *n_windows = b->nwin;
+    return PZ_OK;
+}
+
+static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, size_t nc, size_t n, size_t cs,
+                     unsigned win_lo, unsigned win_hi, G1Jac* d_out) {
+    MsmP p;
+    p.n = n;
+    p.n_table = bases->n;
+    p.c = bases->c;
+    p.nwin = bases->nwin;
+    p.win_lo = win_lo;
+    p.win_hi = win_hi;
+    p.B = 1u << (bases->c - 1);
+    p.cap = n * (size_t)(win_hi - win_lo);
+    p.max_items = p.B + p.cap / MSM_CHUNK;
+    void *hist, *offs, *cursor, *items, *entries, *partials, *na, *nb;
+    PZCHK(pz_ws_get(ctx, WS_HIST, nc * p.B * 4, &hist));
+    PZCHK(pz_ws_get(ctx, WS_CURSOR, nc * p.B * 4, &cursor));
+    PZCHK(pz_ws_get(ctx, WS_OFFS, nc * (p.B + 1) * 4, &offs));
+    PZCHK(pz_ws_get(ctx, WS_ITEMS, nc * (p.B + 1) * 4, &items));
+    PZCHK(pz_ws_get(ctx, WS_ENTRIES, nc * p.cap * 4 + 16, &entries));
+    PZCHK(pz_ws_get(ctx, WS_PARTIALS, nc * p.max_items * sizeof(G1X), &partials));
+    // radix of the reduction tree
+    const unsigned m1 = p.B >= 16 ? 16 : p.B;
+    unsigned n_nodes = p.B / m1;
+    PZCHK(pz_ws_get(ctx, WS_NODES_A, nc * (size_t)n_nodes * sizeof(MsmNode), &na));
+    PZCHK(pz_ws_get(ctx, WS_NODES_B, nc * (size_t)(n_nodes / 2 + 1) * sizeof(MsmNode), &nb));
+    hipStream_t st = ctx->stream;
+    pz_timer tall(ctx, PZ_T_MSM_ALL);
+    HIPCHK(ctx, hipMemsetAsync(hist, 0, nc * p.B * 4, st));
+    HIPCHK(ctx, hipMemsetAsync(cursor, 0, nc * p.B * 4, st));
+    dim3 gs(pz_div_up(n, 256), (unsigned)nc);
+    hipLaunchKernelGGL(k_msm_hist, gs, dim3(256), 0, st, d_scalars, cs, p, (u32*)hist);
+    hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)nc), dim3(256), 0, st, (const u32*)hist, p, (u32*)offs, (u32*)items);
+    hipLaunchKernelGGL(k_msm_scatter, gs, dim3(256), 0, st, d_scalars, cs, p, (const u32*)offs, (u32*)cursor,
+                       (u32*)entries);
+    {
+        pz_timer tacc(ctx, PZ_T_MSM_ACC);
+        hipLaunchKernelGGL(k_msm_accumulate, dim3(pz_div_up(p.max_items, 256), (unsigned)nc), dim3(256), 0, st,
+                           (const G1Affine*)bases->d_table, p, (const u32*)offs, (const u32*)items,
+                           (const u32*)entries, (G1X*)partials);
+    }
+    hipLaunchKernelGGL(k_msm_reduce_l1, dim3(pz_div_up(n_nodes, 128), (unsigned)nc), dim3(128), 0, st, p, m1,
+                       (const u32*)items, (const G1X*)partials, (MsmNode*)na);
+    MsmNode* cur = (MsmNode*)na;
+    MsmNode* nxt = (MsmNode*)nb;
+    unsigned log_w = 0;
+    for (unsigned t = m1; t > 1; t >>= 1) ++log_w;
+    while (n_nodes > 1) {
+        unsigned m = n_nodes >= 16 ? 16 : n_nodes;
+        hipLaunchKernelGGL(k_msm_combine, dim3(pz_div_up(n_nodes / m, 128), (unsigned)nc), dim3(128), 0, st, n_nodes, m,
+                           log_w, (const MsmNode*)cur, nxt);
+        n_nodes /= m;
+        for (unsigned t = m; t > 1; t >>= 1) ++log_w;
+        MsmNode* tmp = cur;
+        cur = nxt;
+        nxt = tmp;
+    }
+    hipLaunchKernelGGL(k_msm_emit, dim3(pz_div_up(nc, 64)), dim3(64), 0, st, (const MsmNode*)cur, nc, d_out);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}
+
+extern "C" int pz_msm_g1_dev(pz_ctx* ctx, const pz_bases* bases, const uint64_t* d_scalars, size_t n_cols, size_t n,
+                             size_t col_stride, uint32_t win_lo, uint32_t win_hi, uint64_t* d_out_jac) {
+    if (!ctx || !bases || (n_cols && (!d_scalars || !d_out_jac))) return PZ_ERR_INVALID;
+    if (n > bases->n || win_lo > win_hi || win_hi > bases->nwin) return PZ_ERR_INVALID;
+    if (col_stride % 4 || (n_cols > 1 && col_stride < 4 * n)) return PZ_ERR_INVALID;
+    if (n_cols == 0) return PZ_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (n == 0 || win_lo == win_hi) {
+        // empty sum: identity for every column
+        size_t nn = n_cols;
+        void* z;
+        PZCHK(pz_ws_get(ctx, WS_NODES_A, nn * sizeof(MsmNode), &z));
+        HIPCHK(ctx, hipMemsetAsync(z, 0, nn * sizeof(MsmNode), ctx->stream));  // ZZ = 0 -> identity
+        hipLaunchKernelGGL(k_msm_emit, dim3(pz_div_up(nn, 64)), dim3(64), 0, ctx->stream, (const MsmNode*)z, nn,
+                           (G1Jac*)d_out_jac);
+        HIPCHK(ctx, hipGetLastError());
+        return PZ_OK;
+    }
+    const size_t cs = col_stride / 4;
+    // column groups: bound the sorted-entry workspace (4 B per digit) to ~1 GiB, grid.y to 65535
+    const size_t per_col = n * (size_t)(win_hi - win_lo) * 4 + (size_t)(1u << (bases->c - 1)) * 160;
+    size_t group = ((size_t)1 << 30) / per_col;
+    if (group == 0) group = 1;
+    if (group > n_cols) group = n_cols;
+    if (group > 4096) group = 4096;
+    for (size_t c0 = 0; c0 < n_cols; c0 += group) {
+        size_t nc = n_cols - c0 < group ? n_cols - c0 : group;
+        PZCHK(msm_group(ctx, bases, (const Fr*)d_scalars + c0 * cs, nc, n, cs, win_lo, win_hi,
+                        (G1Jac*)d_out_jac + c0));
+    }
+    return PZ_OK;
+}
+
+extern "C" int pz_msm_g1_batch(pz_ctx* ctx, const pz_bases* bases, const uint64_t* const* scalar_cols, size_t n_cols,
+                               size_t n, uint64_t* out_jac) {
+    if (!ctx || !bases || (n_cols && (!scalar_cols || !out_jac))) return PZ_ERR_INVALID;
+    if (n > bases->n) return PZ_ERR_INVALID;
+    if (n_cols == 0) return PZ_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = n * 32;
+    size_t group = bytes ? ((size_t)1 << 29) / bytes : n_cols;
+    if (group == 0) group = 1;
+    if (group > n_cols) group = n_cols;
+    void *d_s, *d_o;
+    PZCHK(pz_ws_get(ctx, WS_IO_B, group * bytes + 32, &d_s));
+    PZCHK(pz_ws_get(ctx, WS_IO_C, group * 96, &d_o));
+    for (size_t c0 = 0; c0 < n_cols; c0 += group) {
+        size_t nc = n_cols - c0 < group ? n_cols - c0 : group;
+        for (size_t j = 0; j < nc; ++j) {
+            if (!scalar_cols[c0 + j] && n) return PZ_ERR_INVALID;
+            if (bytes)
+                HIPCHK(ctx, hipMemcpyAsync((char*)d_s + j * bytes, scalar_cols[c0 + j], bytes, hipMemcpyHostToDevice,
+                                           ctx->stream));
+        }
+        PZCHK(pz_msm_g1_dev(ctx, bases, (const uint64_t*)d_s, nc, n, 4 * n, 0, bases->nwin, (uint64_t*)d_o));
+        HIPCHK(ctx, hipMemcpyAsync(out_jac + c0 * 12, d_o, nc * 96, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return PZ_OK;
+}
+
+extern "C" int pz_msm_g1(pz_ctx* ctx, const pz_bases* bases, const uint64_t* scalars, size_t n, uint64_t out_jac[12]) {
+    if (n && !scalars) return PZ_ERR_INVALID;
+    const uint64_t* cols[1] = {scalars};
+    return pz_msm_g1_batch(ctx, bases, cols, 1, n, out_jac);
+}
+
+extern "C" int pz_g1_sum(pz_ctx* ctx, const uint64_t* jac, size_t n, uint64_t out_jac[12]) {
+    if (!ctx || !out_jac || (n && !jac)) return PZ_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    void* d;
+    PZCHK(pz_ws_get(ctx, WS_IO_C, (n + 1) * 96, &d));
+    if (n) HIPCHK(ctx, hipMemcpyAsync((char*)d + 96, jac, n * 96, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_g1_sum, dim3(1), dim3(64), 0, ctx->stream, (const G1Jac*)((char*)d + 96), n, (G1Jac*)d);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out_jac, d, 96, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PZ_OK;
+}
+
+extern "C" int pz_g1_normalize(pz_ctx* ctx, const uint64_t* jac, size_t n, uint64_t* aff) {
+    if (!ctx || (n && (!jac || !aff))) return PZ_ERR_INVALID;
+    if (!n) return PZ_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    void *di, *dout;
+    PZCHK(pz_ws_get(ctx, WS_IO_B, n * 96, &di));
+    PZCHK(pz_ws_get(ctx, WS_IO_C, n * 64, &dout));
+    HIPCHK(ctx, hipMemcpyAsync(di, jac, n * 96, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_g1_normalize, dim3(pz_div_up(n, 64)), dim3(64), 0, ctx->stream, (const G1Jac*)di, n,
+                       (G1Affine*)dout);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(aff, dout, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PZ_OK;
+}
+
+extern "C" int pz_g1_fixed_base_mul_dev(pz_ctx* ctx, const uint64_t* d_scalars, size_t n, uint64_t* d_out_affine) {
+    if (!ctx || (n && (!d_scalars || !d_out_affine))) return PZ_ERR_INVALID;
+    if (!n) return PZ_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_fixed_base_mul, dim3(pz_div_up(n, 128)), dim3(128), 0, ctx->stream, (const Fr*)d_scalars, n,
+                       (G1Affine*)d_out_affine);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}
+
+extern "C" int pz_g1_fixed_base_mul(pz_ctx* ctx, const uint64_t* scalars, size_t n, uint64_t* out_affine) {
+    if (!ctx || (n && (!scalars || !out_affine))) return PZ_ERR_INVALID;
+    if (!n) return PZ_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    void *di, *dout;
+    PZCHK(pz_ws_get(ctx, WS_IO_B, n * 32, &di));
+    PZCHK(pz_ws_get(ctx, WS_IO_C, n * 64, &dout));
+    HIPCHK(ctx, hipMemcpyAsync(di, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    PZCHK(pz_g1_fixed_base_mul_dev(ctx, (const uint64_t*)di, n, (uint64_t*)dout));
+    HIPCHK(ctx, hipMemcpyAsync(out_affine, dout, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PZ_OK;
+}

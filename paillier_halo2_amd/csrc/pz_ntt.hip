@@ -1,0 +1,250 @@
+// pz_ntt.hip -- K2: radix-2 NTT over BN254 Fr, natural order in and out (== halo2curves best_fft,
+// the routine behind EvaluationDomain::{fft, ifft, coeff_to_extended, extended_to_coeff} that
+// /root/reference/src/bench.rs:161-171 reaches through create_proof).
+//
+// Decomposition (n = n1*n2 or n1*n2*n3, every factor <= 2^9): each pass does the small DFTs of
+// one factor entirely inside LDS (radix-2 DIT stages between __syncthreads), so a column crosses
+// HBM once per pass -- 2 passes up to 2^18, 3 up to 2^27:
+//   pass A/B ("strided"): view [hi][R][lo], DFT along R (stride lo), multiply by the inter-pass
+//                         twiddle omega^(tw_mul*l*k), write back in the same layout.  A block owns
+//                         T consecutive l, so every global access is a T*32-byte run.
+//   pass C  ("final")   : view [k1][k2][R], DFT along the contiguous R, write transposed to
+//                         k1 + n1*k2 + n1*n2*k so the result lands in natural order; a block
+//                         owns T consecutive k1 for one k2, so stores are T*32-byte runs.
+// Algorithmic HBM bytes: 64 B per element (one 32 B read + one 32 B write), see DESIGN.md.
+#include "fp.cuh"
+#include "pz_internal.h"
+
+struct NttPass {
+    unsigned logR;      // DFT size of this pass = 1 << logR
+    size_t lo;          // contiguous inner extent (1 for the final pass)
+    size_t hi;          // outer extent
+    size_t tw_mul;      // inter-pass twiddle exponent multiplier (strided passes)
+    size_t n;           // total transform size
+    unsigned T;         // tile width
+    size_t n1, n2;      // final pass: hi = n1*n2, output index = k1 + n1*k2 + hi*k
+};
+
+__device__ __forceinline__ unsigned bitrev32(unsigned x, unsigned bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
+
+// logR radix-2 DIT stages over an LDS tile holding T independent transforms.
+// element (j, t) lives at sm[j*sr + t*st].  Input must be stored bit-reversed in j.
+__device__ __forceinline__ void lds_dit(Fr* sm, unsigned logR, unsigned T, unsigned sr, unsigned st, bool t_fastest,
+                                        const Fr* __restrict__ tw, size_t n) {
+    const unsigned R = 1u << logR;
+    const unsigned nbf = (R >> 1) * T;
+    for (unsigned s = 0; s < logR; ++s) {
+        const unsigned half = 1u << s;
+        for (unsigned id = threadIdx.x; id < nbf; id += blockDim.x) {
+            unsigned t, bf;
+            if (t_fastest) {
+                t = id % T;
+                bf = id / T;
+            } else {
+                bf = id % (R >> 1);
+                t = id / (R >> 1);
+            }
+            const unsigned pos = bf & (half - 1);
+            const unsigned i0 = ((bf >> s) << (s + 1)) + pos;
+            const unsigned i1 = i0 + half;
+            Fr* p0 = sm + (size_t)i0 * sr + (size_t)t * st;
+            Fr* p1 = sm + (size_t)i1 * sr + (size_t)t * st;
+            Fr u = *p0;
+            Fr v = *p1;
+            if (pos) v = fp_mul(v, fp_load<FrTag>(tw + (size_t)pos * (n >> (s + 1))));
+            *p0 = fp_add(u, v);
+            *p1 = fp_sub(u, v);
+        }
+        __syncthreads();
+    }
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char pz_smem[];
+
+// strided pass.  grid.x = hi * (lo / T), grid.y = column
+__global__ __launch_bounds__(256) void k_ntt_strided(const Fr* in, Fr* out, size_t in_stride, size_t out_stride,
+                                                     NttPass p, const Fr* __restrict__ tw,
+                                                     const Fr* __restrict__ pre) {
+    Fr* sm = reinterpret_cast<Fr*>(pz_smem);
+    const unsigned R = 1u << p.logR, T = p.T;
+    const size_t tiles = p.lo / T;
+    const size_t h = blockIdx.x / tiles, lt = blockIdx.x % tiles;
+    const Fr* src = in + (size_t)blockIdx.y * in_stride;
+    Fr* dst = out + (size_t)blockIdx.y * out_stride;
+    const size_t base = h * R * p.lo + lt * T;
+    for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
+        unsigned j = idx / T, t = idx % T;
+        size_t g = base + (size_t)j * p.lo + t;
+        Fr x = fp_load<FrTag>(src + g);
+        if (pre) x = fp_mul(x, fp_load<FrTag>(pre + g));
+        sm[(size_t)bitrev32(j, p.logR) * T + t] = x;
+    }
+    __syncthreads();
+    lds_dit(sm, p.logR, T, T, 1, true, tw, p.n);
+    for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
+        unsigned k = idx / T, t = idx % T;
+        Fr x = sm[(size_t)k * T + t];
+        size_t e = p.tw_mul * (lt * T + t) * k;  // < n by construction
+        if (e) x = fp_mul(x, fp_load<FrTag>(tw + e));
+        fp_store(dst + base + (size_t)k * p.lo + t, x);
+    }
+}
+
+// final pass.  grid.x = n2 * (n1 / T), grid.y = column
+__global__ __launch_bounds__(256) void k_ntt_final(const Fr* in, Fr* out, size_t in_stride, size_t out_stride,
+                                                   NttPass p, const Fr* __restrict__ tw, const Fr* __restrict__ pre,
+                                                   Fr post, int has_post) {
+    Fr* sm = reinterpret_cast<Fr*>(pz_smem);
+    const unsigned R = 1u << p.logR, T = p.T;
+    const size_t tiles = p.n1 / T;
+    const size_t k2 = blockIdx.x / tiles, k1_0 = (blockIdx.x % tiles) * T;
+    const Fr* src = in + (size_t)blockIdx.y * in_stride;
+    Fr* dst = out + (size_t)blockIdx.y * out_stride;
+    for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
+        unsigned r = idx / R, j = idx % R;
+        size_t g = ((k1_0 + r) * p.n2 + k2) * R + j;
+        Fr x = fp_load<FrTag>(src + g);
+        if (pre) x = fp_mul(x, fp_load<FrTag>(pre + g));
+        sm[(size_t)r * R + bitrev32(j, p.logR)] = x;
+    }
+    __syncthreads();
+    lds_dit(sm, p.logR, T, 1, R, false, tw, p.n);
+    for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
+        unsigned k = idx / T, r = idx % T;
+        Fr x = sm[(size_t)r * R + k];
+        if (has_post) x = fp_mul(x, post);
+        fp_store(dst + (k1_0 + r) + p.n1 * k2 + p.hi * (size_t)k, x);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static unsigned pick_tile(size_t extent, unsigned logR) {
+    // LDS budget 64 KiB per block -> R*T*32 <= 65536; prefer 128-byte runs (T = 4) or more
+    unsigned T = 8;
+    while (T > 1 && (((size_t)32 << logR) * T > 65536 || T > extent)) T >>= 1;
+    return T;
+}
+
+static int launch_strided(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t os, size_t ncols, NttPass p,
+                          const Fr* tw, const Fr* pre) {
+    size_t blocks = p.hi * (p.lo / p.T);
+    size_t lds = ((size_t)32 << p.logR) * p.T;
+    hipLaunchKernelGGL(k_ntt_strided, dim3((unsigned)blocks, (unsigned)ncols), dim3(256), lds, ctx->stream, in, out, is, os,
+                       p, tw, pre);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}
+static int launch_final(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t os, size_t ncols, NttPass p,
+                        const Fr* tw, const Fr* pre, const uint64_t* post_scale) {
+    size_t blocks = p.n2 * (p.n1 / p.T);
+    size_t lds = ((size_t)32 << p.logR) * p.T;
+    Fr post;
+    memset(&post, 0, sizeof post);
+    if (post_scale) memcpy(post.v, post_scale, 32);
+    hipLaunchKernelGGL(k_ntt_final, dim3((unsigned)blocks, (unsigned)ncols), dim3(256), lds, ctx->stream, in, out, is, os, p,
+                       tw, pre, post, post_scale ? 1 : 0);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}
+
+extern "C" int pz_ntt_fr_dev(pz_ctx* ctx, uint64_t* d_a, size_t n_cols, size_t col_stride, const uint64_t omega[4],
+                             uint32_t log_n, const uint64_t* pre_coset_g, const uint64_t* post_scale) {
+    if (!ctx || !omega || (n_cols && !d_a) || log_n > 27) return PZ_ERR_INVALID;
+    if (n_cols == 0) return PZ_OK;
+    const size_t n = (size_t)1 << log_n;
+    if (col_stride % 4 || col_stride < 4 * n) return PZ_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t cs = col_stride / 4;  // column stride in elements
+    Fr* a = reinterpret_cast<Fr*>(d_a);
+    void* twv = nullptr;
+    PZCHK(pz_get_pow_table(ctx, omega, n, &twv));
+    const Fr* tw = (const Fr*)twv;
+    void* prev = nullptr;
+    if (pre_coset_g) PZCHK(pz_get_pow_table(ctx, pre_coset_g, n, &prev));
+    const Fr* pre = (const Fr*)prev;
+
+    const unsigned npass = log_n <= 9 ? 1 : (log_n <= 18 ? 2 : 3);
+    unsigned lg[3] = {0, 0, 0};
+    {
+        unsigned rem = log_n;
+        for (unsigned i = 0; i < npass; ++i) {
+            lg[i] = (rem + (npass - i) - 1) / (npass - i);
+            rem -= lg[i];
+        }
+    }
+    // column groups: bound the ping-pong workspace to ~1 GiB and grid.y to 65535
+    size_t group = n_cols;
+    const size_t max_ws = (size_t)1 << 30;
+    if (npass > 1 && group * n * 32 > max_ws) group = max_ws / (n * 32) ? max_ws / (n * 32) : 1;
+    if (group > 32768) group = 32768;
+    Fr* tmp = nullptr;
+    if (npass > 1) {
+        void* t;
+        PZCHK(pz_ws_get(ctx, WS_NTT_TMP, group * n * 32, &t));
+        tmp = (Fr*)t;
+    }
+    pz_timer tm(ctx, PZ_T_NTT);
+    for (size_t c0 = 0; c0 < n_cols; c0 += group) {
+        size_t nc = n_cols - c0 < group ? n_cols - c0 : group;
+        Fr* ac = a + c0 * cs;
+        if (npass == 1) {
+            NttPass p{};
+            p.logR = log_n; p.lo = 1; p.hi = 1; p.tw_mul = 0; p.n = n; p.T = 1; p.n1 = 1; p.n2 = 1;
+            PZCHK(launch_final(ctx, ac, ac, cs, cs, nc, p, tw, pre, post_scale));
+        } else if (npass == 2) {
+            size_t n1 = (size_t)1 << lg[0], n2 = (size_t)1 << lg[1];
+            NttPass pa{};
+            pa.logR = lg[0]; pa.lo = n2; pa.hi = 1; pa.tw_mul = 1; pa.n = n; pa.T = pick_tile(n2, lg[0]);
+            PZCHK(launch_strided(ctx, ac, tmp, cs, n, nc, pa, tw, pre));
+            // tmp columns are packed with stride n
+            NttPass pc{};
+            pc.logR = lg[1]; pc.lo = 1; pc.hi = n1; pc.n = n; pc.n1 = n1; pc.n2 = 1; pc.T = pick_tile(n1, lg[1]);
+            PZCHK(launch_final(ctx, tmp, ac, n, cs, nc, pc, tw, nullptr, post_scale));
+        } else {
+            size_t n1 = (size_t)1 << lg[0], n2 = (size_t)1 << lg[1], n3 = (size_t)1 << lg[2];
+            NttPass pa{};
+            pa.logR = lg[0]; pa.lo = n2 * n3; pa.hi = 1; pa.tw_mul = 1; pa.n = n; pa.T = pick_tile(n2 * n3, lg[0]);
+            PZCHK(launch_strided(ctx, ac, tmp, cs, n, nc, pa, tw, pre));
+            NttPass pb{};
+            pb.logR = lg[1]; pb.lo = n3; pb.hi = n1; pb.tw_mul = n1; pb.n = n; pb.T = pick_tile(n3, lg[1]);
+            PZCHK(launch_strided(ctx, tmp, tmp, n, n, nc, pb, tw, nullptr));
+            NttPass pc{};
+            pc.logR = lg[2]; pc.lo = 1; pc.hi = n1 * n2; pc.n = n; pc.n1 = n1; pc.n2 = n2; pc.T = pick_tile(n1, lg[2]);
+            PZCHK(launch_final(ctx, tmp, ac, n, cs, nc, pc, tw, nullptr, post_scale));
+        }
+    }
+    return PZ_OK;
+}
+
+// host-pointer forms: == best_fft(a, omega, log_n) on each column
+extern "C" int pz_ntt_fr_batch(pz_ctx* ctx, uint64_t* const* cols, size_t n_cols, const uint64_t omega[4],
+                               uint32_t log_n) {
+    if (!ctx || !omega || (n_cols && !cols) || log_n > 27) return PZ_ERR_INVALID;
+    if (n_cols == 0) return PZ_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)1 << log_n, bytes = n * 32;
+    // stage in groups of <= 1 GiB
+    size_t group = ((size_t)1 << 30) / bytes;
+    if (group == 0) group = 1;
+    if (group > n_cols) group = n_cols;
+    void* d;
+    PZCHK(pz_ws_get(ctx, WS_IO_A, group * bytes, &d));
+    for (size_t c0 = 0; c0 < n_cols; c0 += group) {
+        size_t nc = n_cols - c0 < group ? n_cols - c0 : group;
+        for (size_t j = 0; j < nc; ++j) {
+            if (!cols[c0 + j]) return PZ_ERR_INVALID;
+            HIPCHK(ctx, hipMemcpyAsync((char*)d + j * bytes, cols[c0 + j], bytes, hipMemcpyHostToDevice, ctx->stream));
+        }
+        PZCHK(pz_ntt_fr_dev(ctx, (uint64_t*)d, nc, 4 * n, omega, log_n, nullptr, nullptr));
+        for (size_t j = 0; j < nc; ++j)
+            HIPCHK(ctx, hipMemcpyAsync(cols[c0 + j], (char*)d + j * bytes, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return PZ_OK;
+}
+
+extern "C" int pz_ntt_fr(pz_ctx* ctx, uint64_t* a, const uint64_t omega[4], uint32_t log_n) {
+    if (!a) return PZ_ERR_INVALID;
+    uint64_t* cols[1] = {a};
+    return pz_ntt_fr_batch(ctx, cols, 1, omega, log_n);
+}

@@ -1,0 +1,248 @@
+"""Thin host-side handle over the C ABI (include/pz.h): owns a pz_ctx, marshals numpy arrays
+(host-pointer entry points) and torch CUDA tensors (device-pointer entry points).
+
+All arithmetic happens in libpz_hip.so on the MI355X.  Array conventions are the ABI's: uint64,
+field elements (…,4) Montgomery limbs, affine points (…,8), Jacobian points (…,12), big
+integers little-endian u64 limbs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import PzError, VP
+
+
+def _np(a, shape_last: Optional[int] = None) -> np.ndarray:
+    arr = np.ascontiguousarray(a, dtype=np.uint64)
+    if shape_last is not None and (arr.ndim == 0 or arr.shape[-1] != shape_last):
+        arr = arr.reshape(-1, shape_last)
+    return arr
+
+
+def _ptr(a: np.ndarray) -> VP:
+    return VP(a.ctypes.data)
+
+
+class Bases:
+    """A device-resident window-shifted base table (pz_bases)."""
+
+    def __init__(self, engine: "Engine", handle: VP):
+        self.engine = engine
+        self.handle = handle
+        n = C.c_size_t()
+        c = C.c_uint32()
+        w = C.c_uint32()
+        engine._chk(_lib.lib().pz_bases_info(handle, C.byref(n), C.byref(c), C.byref(w)), "pz_bases_info")
+        self.n_points = n.value
+        self.window_bits = c.value
+        self.n_windows = w.value
+
+    def free(self):
+        if self.handle is not None:
+            _lib.lib().pz_bases_free(self.engine.ctx, self.handle)
+            self.handle = None
+
+
+class Engine:
+    """One pz_ctx == one GPU (one process per GPU; ranks are joined by RCCL above this layer)."""
+
+    def __init__(self, device: int = 0):
+        self.L = _lib.lib()
+        self.ctx = VP()
+        dev = (C.c_int * 1)(device)
+        rc = self.L.pz_init(1, dev, C.byref(self.ctx))
+        if rc != 0:
+            raise PzError(rc, "pz_init")
+        self.device = device
+
+    # ------------------------------------------------------------------ plumbing
+    def _chk(self, rc: int, where: str):
+        if rc != 0:
+            detail = self.L.pz_last_hip_error(self.ctx).decode() if self.ctx else ""
+            raise PzError(rc, where, detail)
+
+    def close(self):
+        if self.ctx:
+            self.L.pz_free(self.ctx)
+            self.ctx = VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_handle: int = 0):
+        """stream_handle: a raw hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); 0 = own."""
+        self._chk(self.L.pz_set_stream(self.ctx, VP(stream_handle)), "pz_set_stream")
+
+    def sync(self):
+        self._chk(self.L.pz_sync(self.ctx), "pz_sync")
+
+    # ------------------------------------------------------------------ K1: MSM
+    def load_bases(self, bases_affine, window_bits: int = 0) -> Bases:
+        b = _np(bases_affine, 8)
+        h = VP()
+        self._chk(self.L.pz_bases_load_g1(self.ctx, _ptr(b), b.shape[0], 0, window_bits, C.byref(h)),
+                  "pz_bases_load_g1")
+        return Bases(self, h)
+
+    def load_bases_dev(self, d_ptr: int, n_points: int, window_bits: int = 0) -> Bases:
+        h = VP()
+        self._chk(self.L.pz_bases_load_g1(self.ctx, VP(d_ptr), n_points, 1, window_bits, C.byref(h)),
+                  "pz_bases_load_g1(dev)")
+        return Bases(self, h)
+
+    def srs_load_g1(self, k: int, bases_affine, lagrange: bool = False) -> Bases:
+        b = _np(bases_affine, 8)
+        assert b.shape[0] == 1 << k
+        h = VP()
+        self._chk(self.L.pz_srs_load_g1(self.ctx, k, _ptr(b), int(lagrange), C.byref(h)), "pz_srs_load_g1")
+        return Bases(self, h)
+
+    def msm(self, bases: Bases, scalars) -> np.ndarray:
+        s = _np(scalars, 4)
+        out = np.zeros(12, dtype=np.uint64)
+        self._chk(self.L.pz_msm_g1(self.ctx, bases.handle, _ptr(s) if s.size else VP(), s.shape[0] if s.size else 0,
+                                   _ptr(out)), "pz_msm_g1")
+        return out
+
+    def msm_batch(self, bases: Bases, cols: Sequence[np.ndarray]) -> np.ndarray:
+        cols = [_np(c, 4) for c in cols]
+        n = cols[0].shape[0] if cols else 0
+        assert all(c.shape[0] == n for c in cols)
+        arr = (VP * len(cols))(*[_ptr(c) for c in cols])
+        out = np.zeros((len(cols), 12), dtype=np.uint64)
+        self._chk(self.L.pz_msm_g1_batch(self.ctx, bases.handle, arr, len(cols), n, _ptr(out)), "pz_msm_g1_batch")
+        return out
+
+    def msm_dev(self, bases: Bases, d_scalars: int, n_cols: int, n: int, col_stride_u64: int, d_out: int,
+                win_lo: int = 0, win_hi: Optional[int] = None):
+        if win_hi is None:
+            win_hi = bases.n_windows
+        self._chk(self.L.pz_msm_g1_dev(self.ctx, bases.handle, VP(d_scalars), n_cols, n, col_stride_u64, win_lo,
+                                       win_hi, VP(d_out)), "pz_msm_g1_dev")
+
+    def g1_sum(self, jac) -> np.ndarray:
+        j = _np(jac, 12)
+        out = np.zeros(12, dtype=np.uint64)
+        self._chk(self.L.pz_g1_sum(self.ctx, _ptr(j), j.shape[0], _ptr(out)), "pz_g1_sum")
+        return out
+
+    def g1_normalize(self, jac) -> np.ndarray:
+        j = _np(jac, 12)
+        out = np.zeros((j.shape[0], 8), dtype=np.uint64)
+        self._chk(self.L.pz_g1_normalize(self.ctx, _ptr(j), j.shape[0], _ptr(out)), "pz_g1_normalize")
+        return out
+
+    def g1_fixed_base_mul(self, scalars) -> np.ndarray:
+        s = _np(scalars, 4)
+        out = np.zeros((s.shape[0], 8), dtype=np.uint64)
+        self._chk(self.L.pz_g1_fixed_base_mul(self.ctx, _ptr(s), s.shape[0], _ptr(out)), "pz_g1_fixed_base_mul")
+        return out
+
+    def g1_fixed_base_mul_dev(self, d_scalars: int, n: int, d_out: int):
+        self._chk(self.L.pz_g1_fixed_base_mul_dev(self.ctx, VP(d_scalars), n, VP(d_out)), "pz_g1_fixed_base_mul_dev")
+
+    # ------------------------------------------------------------------ K2: NTT
+    def ntt(self, a, omega, log_n: int) -> np.ndarray:
+        x = _np(a, 4).copy()
+        assert x.shape[0] == 1 << log_n
+        w = _np(omega).reshape(4)
+        self._chk(self.L.pz_ntt_fr(self.ctx, _ptr(x), _ptr(w), log_n), "pz_ntt_fr")
+        return x
+
+    def ntt_batch(self, cols: Sequence[np.ndarray], omega, log_n: int):
+        cols = [_np(c, 4).copy() for c in cols]
+        arr = (VP * len(cols))(*[_ptr(c) for c in cols])
+        w = _np(omega).reshape(4)
+        self._chk(self.L.pz_ntt_fr_batch(self.ctx, arr, len(cols), _ptr(w), log_n), "pz_ntt_fr_batch")
+        return cols
+
+    def ntt_dev(self, d_a: int, n_cols: int, col_stride_u64: int, omega, log_n: int, pre_coset_g=None,
+                post_scale=None):
+        w = _np(omega).reshape(4)
+        g = _np(pre_coset_g).reshape(4) if pre_coset_g is not None else None
+        s = _np(post_scale).reshape(4) if post_scale is not None else None
+        self._chk(self.L.pz_ntt_fr_dev(self.ctx, VP(d_a), n_cols, col_stride_u64, _ptr(w), log_n,
+                                       _ptr(g) if g is not None else VP(), _ptr(s) if s is not None else VP()),
+                  "pz_ntt_fr_dev")
+
+    # ------------------------------------------------------------------ K3: big integers
+    def mul_mod(self, limbs: int, a, b, modulus) -> Tuple[np.ndarray, np.ndarray]:
+        a, b, m = (_np(x).reshape(limbs) for x in (a, b, modulus))
+        q = np.zeros(limbs, dtype=np.uint64)
+        r = np.zeros(limbs, dtype=np.uint64)
+        self._chk(self.L.pz_mul_mod(self.ctx, limbs, _ptr(a), _ptr(b), _ptr(m), _ptr(q), _ptr(r)), "pz_mul_mod")
+        return q, r
+
+    def paillier_trace(self, limbs_n2: int, n2, base, exp, exp_limbs: int, want_steps: bool = True):
+        n2, base = (_np(x).reshape(limbs_n2) for x in (n2, base))
+        exp = _np(exp).reshape(exp_limbs)
+        e_int = 0
+        for i, l in enumerate(exp.tolist()):
+            e_int |= int(l) << (64 * i)
+        cap = e_int.bit_length() + bin(e_int).count("1")
+        steps = np.zeros((max(cap, 1), 4, limbs_n2), dtype=np.uint64) if want_steps else None
+        ns = C.c_size_t(cap)
+        res = np.zeros(limbs_n2, dtype=np.uint64)
+        self._chk(self.L.pz_paillier_trace(self.ctx, limbs_n2, _ptr(n2), _ptr(base), _ptr(exp), exp_limbs,
+                                           _ptr(steps) if want_steps else VP(), C.byref(ns), _ptr(res)),
+                  "pz_paillier_trace")
+        return res, (steps[: ns.value] if want_steps else None), ns.value
+
+    def paillier_encrypt(self, limbs_n: int, n, g, m, r, want_steps: bool = True):
+        """Batch form: n, g, m, r are (batch, limbs_n).  Returns (c (batch, 2*limbs_n), steps or None,
+        n_steps_g, n_steps_r)."""
+        n, g, m, r = (_np(x).reshape(-1, limbs_n) for x in (n, g, m, r))
+        batch = n.shape[0]
+        L = 2 * limbs_n
+        cap = 0
+        steps = None
+        if want_steps:
+            for i in range(batch):
+                bits = 0
+                for arr in (m[i], n[i]):
+                    e_int = 0
+                    for k, l in enumerate(arr.tolist()):
+                        e_int |= int(l) << (64 * k)
+                    bits += e_int.bit_length() + bin(e_int).count("1")
+                cap = max(cap, bits + 1)
+            steps = np.zeros((batch, cap, 4, L), dtype=np.uint64)
+        ng = np.zeros(batch, dtype=np.uint32)
+        nr = np.zeros(batch, dtype=np.uint32)
+        c = np.zeros((batch, L), dtype=np.uint64)
+        self._chk(self.L.pz_paillier_encrypt(self.ctx, limbs_n, batch, _ptr(n), _ptr(g), _ptr(m), _ptr(r),
+                                             _ptr(steps) if want_steps else VP(), cap, VP(ng.ctypes.data),
+                                             VP(nr.ctypes.data), _ptr(c)), "pz_paillier_encrypt")
+        return c, steps, ng, nr
+
+    # ------------------------------------------------------------------ measurement
+    def timing_enable(self, on: bool = True):
+        self._chk(self.L.pz_timing_enable(self.ctx, int(on)), "pz_timing_enable")
+
+    def timing_reset(self):
+        self._chk(self.L.pz_timing_reset(self.ctx), "pz_timing_reset")
+
+    def timing_get(self, which: int) -> Tuple[float, int]:
+        ms = C.c_double()
+        n = C.c_uint64()
+        self._chk(self.L.pz_timing_get(self.ctx, which, C.byref(ms), C.byref(n)), "pz_timing_get")
+        return ms.value, n.value
+
+    def ubench_mad(self, blocks: int, iters: int) -> float:
+        ms = C.c_double()
+        self._chk(self.L.pz_ubench_mad(self.ctx, blocks, iters, C.byref(ms)), "pz_ubench_mad")
+        return ms.value
+
+    def ubench_fqmul(self, blocks: int, iters: int) -> float:
+        ms = C.c_double()
+        self._chk(self.L.pz_ubench_fqmul(self.ctx, blocks, iters, C.byref(ms)), "pz_ubench_fqmul")
+        return ms.value
+
+
+T_MSM_ACC, T_NTT, T_TRACE, T_EXPAND, T_MSM_ALL = 0, 1, 2, 3, 4

@@ -1,0 +1,330 @@
+"""GPU parity tests proper: every HIP kernel, called through the C ABI (ctypes -> libpz_hip.so),
+against the oracle on the same seeded inputs and against the committed golden fixtures.
+Bit-exact everywhere (integer work).  MSM results are compared as group elements in affine form
+(the Jacobian representative of a point is not unique; halo2 itself normalises before hashing)."""
+import hashlib
+import random
+
+import numpy as np
+import pytest
+
+from oracle import pyref as P
+from tests.util import H, load_golden, steps_digest_arr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import paillier_halo2_amd as pz
+
+    e = pz.Engine(0)
+    yield e
+    e.close()
+
+
+def aff_ints(cref, arr):
+    return cref.affine_mont_to_ints(arr)
+
+
+# ------------------------------------------------------------------------------------------ K1
+def test_fixed_base_mul_and_normalize(eng, cref):
+    rng = random.Random(10)
+    ks = [0, 1, 2, P.FR_R - 1] + [rng.randrange(P.FR_R) for _ in range(28)]
+    got = eng.g1_fixed_base_mul(cref.fr_ints_to_mont(ks))
+    want = [P.g1_mul(P.G1_GEN, k) for k in ks]
+    assert aff_ints(cref, got) == want
+
+
+@pytest.mark.parametrize("c", [0, 4, 7, 13, 16])
+def test_msm_golden(eng, cref, c):
+    g = load_golden("msm.json")
+    for case in g["cases"]:
+        n = case["n"]
+        bases = cref.walk_bases(n, H(case["walk_s"]), H(case["walk_t"]))
+        for i in case["identity_at"]:
+            bases[i] = 0
+        tb = eng.load_bases(bases, window_bits=c)
+        scalars = cref.fr_ints_to_mont([H(x) for x in case["scalars"]])
+        got = eng.g1_normalize(eng.msm(tb, scalars))
+        assert aff_ints(cref, got)[0] == (H(case["result"][0]), H(case["result"][1])), (n, c)
+        tb.free()
+
+
+def test_msm_vs_oracle_sizes(eng, cref):
+    rng = random.Random(11)
+    nmax = 1 << 12
+    bases = cref.walk_bases(nmax, rng.randrange(1, P.FR_R), rng.randrange(1, P.FR_R))
+    tb = eng.load_bases(bases)
+    for n in (0, 1, 2, 3, 63, 64, 65, 255, 256, 257, 1000, nmax):
+        scalars = cref.fr_ints_to_mont([rng.randrange(P.FR_R) for _ in range(n)]).reshape(-1, 4)
+        got = eng.g1_normalize(eng.msm(tb, scalars))[0]
+        want = cref.g1_normalize(cref.msm_g1(scalars, bases[:n]))
+        assert np.array_equal(got, want), n
+    tb.free()
+
+
+def test_msm_scalar_classes_and_skew(eng, cref):
+    """edge scalars, witness-like short scalars, heavy repeats (one bucket gets most points)."""
+    rng = random.Random(12)
+    n = 1 << 11
+    s, t = rng.randrange(1, P.FR_R), rng.randrange(1, P.FR_R)
+    bases = cref.walk_bases(n, s, t)
+    tb = eng.load_bases(bases)
+    classes = {
+        "zeros": [0] * n,
+        "ones": [1] * n,
+        "minus_ones": [P.FR_R - 1] * n,
+        "witness_like": P.witness_like_scalars(n, 3),
+        "same_big": [rng.randrange(P.FR_R)] * n,
+        "half": [(P.FR_R - 1) // 2, (P.FR_R + 1) // 2] * (n // 2),
+        "bits": [rng.getrandbits(1) for _ in range(n)],
+    }
+    for name, sc in classes.items():
+        got = aff_ints(cref, eng.g1_normalize(eng.msm(tb, cref.fr_ints_to_mont(sc))))[0]
+        assert got == P.msm_walk_expected(sc, s, t), name
+    tb.free()
+
+
+def test_msm_adversarial_bases(eng, cref):
+    """bases G,2G,3G..: partial bucket sums collide with later points (doubling / cancellation)."""
+    n = 512
+    bases = cref.walk_bases(n, 1, 1)
+    for c in (5, 9):
+        tb = eng.load_bases(bases, window_bits=c)
+        for sc in ([1] * n, [3] * (n // 2) + [P.FR_R - 3] * (n // 2), list(range(n)), [2, P.FR_R - 1] * (n // 2)):
+            got = aff_ints(cref, eng.g1_normalize(eng.msm(tb, cref.fr_ints_to_mont(sc))))[0]
+            assert got == P.msm_walk_expected(sc, 1, 1)
+        tb.free()
+    # duplicate and opposite bases
+    b2 = bases.copy()
+    b2[1] = b2[0]
+    neg = cref.affine_ints_to_mont([P.aff_neg(cref.affine_mont_to_ints(b2[0:1])[0])])[0]
+    b2[2] = neg
+    tb = eng.load_bases(b2, window_bits=6)
+    sc = [5, 5, 5] + [0] * (n - 3)
+    got = aff_ints(cref, eng.g1_normalize(eng.msm(tb, cref.fr_ints_to_mont(sc))))[0]
+    assert got == P.g1_mul(P.G1_GEN, 5)
+    sc = [5, P.FR_R - 5, 0] + [0] * (n - 3)
+    got = aff_ints(cref, eng.g1_normalize(eng.msm(tb, cref.fr_ints_to_mont(sc))))[0]
+    assert got == P.AFF_INF
+    tb.free()
+
+
+def test_msm_batch_and_window_split(eng, cref):
+    """column batch == per-column MSMs; disjoint window ranges sum to the full MSM (the multi-GPU split)."""
+    import torch
+
+    rng = random.Random(13)
+    n = 1 << 10
+    bases = cref.walk_bases(n, rng.randrange(1, P.FR_R), rng.randrange(1, P.FR_R))
+    tb = eng.load_bases(bases, window_bits=11)
+    cols = [cref.fr_ints_to_mont([rng.randrange(P.FR_R) for _ in range(n)]) for _ in range(5)]
+    cols.append(cref.fr_ints_to_mont(P.witness_like_scalars(n, 9)))
+    out = eng.msm_batch(tb, cols)
+    for j, cten in enumerate(cols):
+        assert np.array_equal(eng.g1_normalize(out[j])[0], cref.g1_normalize(cref.msm_g1(cten, bases))), j
+    # device-resident entry point with window ranges
+    d_s = torch.from_numpy(np.stack(cols).astype(np.int64)).cuda()
+    d_o = torch.zeros((len(cols), 12), dtype=torch.int64, device="cuda")
+    parts = []
+    W = tb.n_windows
+    cuts = [0, W // 3, W // 2, W]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        eng.msm_dev(tb, d_s.data_ptr(), len(cols), n, 4 * n, d_o.data_ptr(), lo, hi)
+        eng.sync()
+        parts.append(d_o.cpu().numpy().astype(np.uint64))
+    for j in range(len(cols)):
+        total = eng.g1_sum(np.stack([p[j] for p in parts]))
+        assert np.array_equal(eng.g1_normalize(total)[0], eng.g1_normalize(out[j])[0])
+    tb.free()
+
+
+def test_msm_large_dlog_identity(eng, cref):
+    """2^17-point MSM (the k=17 column size): checked through the discrete-log identity of walk bases,
+    a size-independent property (bases generated ON the GPU by fixed-base multiplication)."""
+    import torch
+
+    n = 1 << 17
+    s, t = 0x1234567890ABCDEF1234567, 0xFEDCBA987654321
+    idx = np.arange(n, dtype=object)
+    ks = [(s + int(i) * t) % P.FR_R for i in range(n)]
+    d_k = torch.from_numpy(cref.fr_ints_to_mont(ks).astype(np.int64)).cuda()
+    d_b = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    eng.g1_fixed_base_mul_dev(d_k.data_ptr(), n, d_b.data_ptr())
+    eng.sync()
+    tb = eng.load_bases_dev(d_b.data_ptr(), n)
+    rng = random.Random(14)
+    for name, sc in (("uniform", [rng.randrange(P.FR_R) for _ in range(n)]), ("witness", P.witness_like_scalars(n, 5))):
+        got = aff_ints(cref, eng.g1_normalize(eng.msm(tb, cref.fr_ints_to_mont(sc))))[0]
+        assert got == P.msm_walk_expected(sc, s, t), name
+    tb.free()
+
+
+# ------------------------------------------------------------------------------------------ K2
+def test_ntt_golden(eng, cref):
+    g = load_golden("ntt.json")
+    for case in g["cases"]:
+        a = cref.fr_ints_to_mont([H(x) for x in case["a"]])
+        got = eng.ntt(a, cref.fr_ints_to_mont([H(case["omega"])])[0], case["log_n"])
+        assert cref.fr_mont_to_ints(got) == [H(x) for x in case["out"]], case["log_n"]
+    for case in g["digests"]:
+        a = cref.fr_ints_to_mont([H(x) for x in case["a"]])
+        omega = cref.fr_ints_to_mont([P.fr_omega(case["log_n"])])[0]
+        got = cref.fr_mont_to_ints(eng.ntt(a, omega, case["log_n"]))
+        assert hashlib.sha256(b"".join(x.to_bytes(32, "little") for x in got)).hexdigest() == case["out_sha256"]
+
+
+@pytest.mark.parametrize("log_n", [9, 10, 11, 13, 14, 17, 18, 19, 20])
+def test_ntt_vs_oracle(eng, cref, log_n):
+    rng = np.random.default_rng(100 + log_n)
+    n = 1 << log_n
+    a = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)  # < 2^254: valid Montgomery representatives? reduce:
+    a[:, 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
+    omega = cref.fr_ints_to_mont([P.fr_omega(log_n)])[0]
+    got = eng.ntt(a, omega, log_n)
+    want = cref.ntt_fr(a, omega, log_n)
+    assert np.array_equal(got, want)
+    # inverse: omega^-1 then scale by 1/n returns the input (round trip, size independent)
+    winv = cref.fr_ints_to_mont([pow(P.fr_omega(log_n), -1, P.FR_R)])[0]
+    ninv = cref.fr_ints_to_mont([pow(n, -1, P.FR_R)])[0]
+    import torch
+
+    d = torch.from_numpy(got.astype(np.int64)).cuda()
+    eng.ntt_dev(d.data_ptr(), 1, 4 * n, winv, log_n, None, ninv)
+    eng.sync()
+    assert np.array_equal(d.cpu().numpy().astype(np.uint64), a)
+
+
+def test_ntt_batch_coset_and_scale(eng, cref):
+    import torch
+
+    rng = random.Random(15)
+    log_n = 12
+    n = 1 << log_n
+    cols = [cref.fr_ints_to_mont([rng.randrange(P.FR_R) for _ in range(n)]) for _ in range(3)]
+    omega = cref.fr_ints_to_mont([P.fr_omega(log_n)])[0]
+    outs = eng.ntt_batch(cols, omega, log_n)
+    for c, o in zip(cols, outs):
+        assert np.array_equal(o, cref.ntt_fr(c, omega, log_n))
+    # fused coset pre-scale (distribute_powers) and post-scale, strided columns
+    g = cref.fr_ints_to_mont([7])[0]
+    sc = cref.fr_ints_to_mont([rng.randrange(P.FR_R)])[0]
+    stride = 4 * n + 8
+    buf = np.zeros((3, stride), dtype=np.uint64)
+    for j, c in enumerate(cols):
+        buf[j, : 4 * n] = c.reshape(-1)
+    d = torch.from_numpy(buf.astype(np.int64)).cuda()
+    eng.ntt_dev(d.data_ptr(), 3, stride, omega, log_n, g, sc)
+    eng.sync()
+    res = d.cpu().numpy().astype(np.uint64)
+    for j, c in enumerate(cols):
+        want = cref.fr_scale(cref.ntt_fr(cref.fr_distribute_powers(c, g), omega, log_n), sc)
+        assert np.array_equal(res[j, : 4 * n].reshape(-1, 4), want)
+        assert not res[j, 4 * n:].any()
+
+
+# ------------------------------------------------------------------------------------------ K3
+@pytest.mark.parametrize("L,bits", [(4, 256), (6, 352), (64, 4096), (96, 6144), (128, 8192)])
+def test_mul_mod_vs_oracle(eng, cref, L, bits):
+    rng = random.Random(16 + L)
+    to = lambda x: cref.int_to_limbs(x, L)
+    for it in range(6):
+        mod = rng.getrandbits(bits) | (1 << (bits - 1))
+        if it == 1:
+            mod &= ~1  # even modulus (the reference feeds raw random n, paillier.rs:173)
+        if it == 2:
+            mod = (1 << (bits - 1))  # power of two: reciprocal clamp path
+        if it == 3:
+            mod = (1 << bits) - 1
+        a, b = rng.randrange(mod), rng.randrange(mod)
+        q, r = eng.mul_mod(L, to(a), to(b), to(mod))
+        assert (cref.limbs_to_int(q), cref.limbs_to_int(r)) == divmod(a * b, mod), (L, it)
+    # short moduli (many leading zero limbs) and unreduced operands
+    for mod in (1, 2, 3, (1 << 64) - 1, 1 << 64, rng.getrandbits(bits // 2) | 1, rng.getrandbits(70) | (1 << 69)):
+        lim = min(bits // 2, max(1, mod.bit_length()))
+        a, b = rng.getrandbits(lim), rng.getrandbits(lim)
+        q, r = eng.mul_mod(L, to(a), to(b), to(mod))
+        assert (cref.limbs_to_int(q), cref.limbs_to_int(r)) == divmod(a * b, mod), (L, mod)
+
+
+def test_mul_mod_error_behaviour(eng, cref):
+    import paillier_halo2_amd as pz
+    from paillier_halo2_amd import _lib
+
+    L = 4
+    to = lambda x: cref.int_to_limbs(x, L)
+    with pytest.raises(pz.PzError) as ei:
+        eng.mul_mod(L, to(5), to(7), to(0))
+    assert ei.value.status == _lib.PZ_ERR_ZERO_MODULUS  # reference: BigUint % 0 panics (paillier.rs:91)
+    with pytest.raises(pz.PzError) as ei:
+        eng.mul_mod(L, to((1 << 255) + 9), to((1 << 254) + 1), to(3))  # quotient needs > L limbs
+    assert ei.value.status == _lib.PZ_ERR_RANGE
+    assert cref.mul_mod_step(L, (1 << 255) + 9, (1 << 254) + 1, 3)[0] == -2
+
+
+def test_pow_mod_trace_vs_oracle(eng, cref):
+    rng = random.Random(17)
+    for L, bits, ebits in ((4, 128, 128), (6, 176, 150), (64, 2048, 48), (96, 3072, 20)):
+        n = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+        n2 = n * n
+        base = rng.randrange(n)
+        for e in (rng.getrandbits(ebits) | (1 << (ebits - 1)), 0, 1, 2):
+            el = L // 2
+            res, steps, ns = eng.paillier_trace(L, cref.int_to_limbs(n2, L), cref.int_to_limbs(base, L),
+                                                cref.int_to_limbs(e, el), el)
+            acc, psteps = P.pow_mod_fixed_exp_trace(base, e, n2)
+            assert cref.limbs_to_int(res) == acc and ns == len(psteps)
+            for st, (a, b, q, r) in zip(steps, psteps):
+                assert [cref.limbs_to_int(st[i]) for i in range(4)] == [a, b, q, r]
+
+
+def test_encrypt_golden(eng, cref):
+    """PaillierChip::encrypt witness (paillier.rs:32-60): value == paillier_enc_native and the step
+    trace matches the fixture digest, for the reference's 128-bit shape and the 2048/3072-bit keys."""
+    g = load_golden("paillier.json")
+    for case in g["encrypt"]:
+        Ln = case["enc_bits"] // 64
+        L = 2 * Ln
+        arr = lambda k: cref.int_to_limbs(H(case[k]), Ln)
+        c, steps, ng, nr = eng.paillier_encrypt(Ln, arr("n"), arr("g"), arr("m"), arr("r"))
+        assert cref.limbs_to_int(c[0]) == H(case["c"])
+        assert (int(ng[0]), int(nr[0])) == (case["n_steps_g"], case["n_steps_r"])
+        tot = int(ng[0]) + int(nr[0]) + 1
+        assert steps_digest_arr(steps[0, :tot], L) == case["steps_sha256"], case["enc_bits"]
+    for case in g["add"]:
+        Ln = case["enc_bits"] // 64
+        L = 2 * Ln
+        n = H(case["n"])
+        q, r = eng.mul_mod(L, cref.int_to_limbs(H(case["c1"]), L), cref.int_to_limbs(H(case["c2"]), L),
+                           cref.int_to_limbs(n * n, L))
+        assert cref.limbs_to_int(r) == H(case["res"]) and cref.limbs_to_int(q) == H(case["q"])
+
+
+def test_encrypt_batch_full_2048(eng, cref):
+    """config c2 key size with FULL-length exponents, batch of 3; values == paillier_enc_native, and the
+    size-independent step property a*b == q*n^2 + r on a sample of steps."""
+    Ln = 32
+    L = 64
+    ins = [P.synth_paillier_inputs(2048, 0x5043 + i, standard_g=(i != 1)) for i in range(3)]
+    pack = lambda k: np.stack([cref.int_to_limbs(t[k], Ln) for t in ins])
+    c, steps, ng, nr = eng.paillier_encrypt(Ln, pack(0), pack(1), pack(2), pack(3))
+    for i, (n, g, m, r) in enumerate(ins):
+        assert cref.limbs_to_int(c[i]) == P.paillier_enc_native(n, g, m, r)
+        assert int(ng[i]) == m.bit_length() + bin(m).count("1")
+        assert int(nr[i]) == n.bit_length() + bin(n).count("1")
+        tot = int(ng[i]) + int(nr[i]) + 1
+        n2 = n * n
+        for k in list(range(0, tot, 97)) + [tot - 1]:
+            a, b, q, rr = (cref.limbs_to_int(steps[i, k, j]) for j in range(4))
+            assert a * b == q * n2 + rr and rr < n2
+
+
+def test_ubench_reports(eng):
+    ms = eng.ubench_mad(2048, 4096)
+    mads = 2048 * 256 * 4096 * 8
+    print("\n[ubench] v_mad_u64_u32: %.3f ms, %.2f Tmad/s" % (ms, mads / ms / 1e9))
+    ms = eng.ubench_fqmul(2048, 512)
+    muls = 2048 * 256 * 512 * 2
+    print("[ubench] Fq mont mul: %.3f ms, %.2f Gmul/s" % (ms, muls / ms / 1e6))
+    assert ms > 0
