@@ -78,6 +78,14 @@ def lib():
                 f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback."
             )
+        # torch bundles its own HIP runtime (same SONAME, libamdhip64.so.7).  Two HIP/HSA runtimes in one
+        # process cannot both open the GPU, so when torch is installed make sure ITS runtime is the one
+        # already mapped before libpz_hip.so's NEEDED entry is resolved.  Standalone (Rust/C++) users of
+        # the C ABI simply get the system ROCm runtime.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional for the C ABI itself
+            pass
         l = C.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError here == ABI symbol missing: fail loudly

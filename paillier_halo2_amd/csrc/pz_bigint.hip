@@ -37,10 +37,6 @@ __device__ __forceinline__ u64 shfl_down1(u64 x) {  // lane j <- lane j+1, lane 
     u64 y = __shfl_down(x, 1, 64);
     return lane_id() == 63 ? 0 : y;
 }
-__device__ __forceinline__ u32 shfl_down1_32(u32 x) {
-    u32 y = __shfl_down(x, 1, 64);
-    return lane_id() == 63 ? 0 : y;
-}
 __device__ __forceinline__ u64 shfl_up1(u64 x) {  // lane j <- lane j-1, lane 0 <- 0
     u64 y = __shfl_up(x, 1, 64);
     return lane_id() == 0 ? 0 : y;
@@ -176,19 +172,20 @@ template <int E> __device__ __noinline__ void ld_mul(LD<E>& lo, LD<E>& hi, const
             const u64 emit = bcast64(col[0], 0);
             if (lane == jj) lo.v[ee] = emit;
             // shift the column array one limb down
+            // (a column's overflow count is consumed here, by the lane that holds it, into the next
+            // column arriving in the same slot; it does not travel with the column)
             const u64 n0 = shfl_down1(col[0]);
-            const u32 ncc0 = shfl_down1_32(cc[0]);
             u64 ncol[E];
             u32 ncc[E];
 #pragma unroll
             for (int e = 0; e + 1 < E; ++e) {
                 u64 t = col[e + 1] + cc[e];
-                ncc[e] = cc[e + 1] + (t < col[e + 1]);
+                ncc[e] = (t < col[e + 1]);
                 ncol[e] = t;
             }
             {
                 u64 t = n0 + pend;
-                u32 k = ncc0 + (t < pend);
+                u32 k = (t < pend);
                 u64 t2 = t + cc[E - 1];
                 k += t2 < t;
                 ncol[E - 1] = t2;
@@ -519,10 +516,13 @@ template <int E> __global__ __launch_bounds__(64) void k_mul_mod(const MulDesc* 
 // ------------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------------
-static int status_to_rc(u32 st) {
+static int status_to_rc(pz_ctx* ctx, u32 st) {
     if (st & ST_ZERO_MOD) return PZ_ERR_ZERO_MODULUS;
     if (st & ST_RANGE) return PZ_ERR_RANGE;
-    if (st & ST_INTERNAL) return PZ_ERR_HIP;
+    if (st & ST_INTERNAL) {
+        snprintf(ctx->hip_err, sizeof ctx->hip_err, "big-integer kernel: internal consistency check failed (status %u)", st);
+        return PZ_ERR_HIP;
+    }
     return PZ_OK;
 }
 
@@ -571,7 +571,7 @@ extern "C" int pz_mul_mod(pz_ctx* ctx, uint32_t limbs, const uint64_t* a, const 
     HIPCHK(ctx, hipMemcpyAsync(r, base + 4 * lb, lb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(&st, d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return status_to_rc(st);
+    return status_to_rc(ctx, st);
 }
 
 extern "C" int pz_paillier_trace(pz_ctx* ctx, uint32_t limbs_n2, const uint64_t* n2, const uint64_t* base,
@@ -630,7 +630,7 @@ extern "C" int pz_paillier_trace(pz_ctx* ctx, uint32_t limbs_n2, const uint64_t*
         HIPCHK(ctx, hipMemcpyAsync(steps_out, d_steps, need * 4 * lb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (n_steps) *n_steps = st[1];
-    return status_to_rc(st[0]);
+    return status_to_rc(ctx, st[0]);
 }
 
 static int encrypt_impl(pz_ctx* ctx, uint32_t Ln, size_t batch, const uint64_t* n, const uint64_t* g,
@@ -751,7 +751,7 @@ static int encrypt_impl(pz_ctx* ctx, uint32_t Ln, size_t batch, const uint64_t* 
         if (n_steps_g) n_steps_g[i] = ng[i];
         if (n_steps_r) n_steps_r[i] = nr[i];
     }
-    return status_to_rc(st);
+    return status_to_rc(ctx, st);
 }
 
 extern "C" int pz_paillier_encrypt(pz_ctx* ctx, uint32_t limbs_n, size_t batch, const uint64_t* n, const uint64_t* g,
