@@ -1,0 +1,341 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native Paillier-in-Halo2 hot path.
+
+Metric (BASELINE.json): Paillier-encrypt proofs/s (2048-bit n, k=17); MSM achieved HBM GB/s vs peak.
+
+A "step" is ONE pass of the hot path of ONE encrypt proof at config c2 (2048-bit n, k=17,
+lookup_bits=16, limb_bits=64), inputs resident in HBM:
+    K3  witness trace   g^m * r^n mod n^2, ~6145 mul_mod steps (pz_paillier_encrypt_dev)
+    K1  commitments     A advice-column MSMs (short witness scalars) + Lk lookup-column MSMs
+                        + the full-width MSMs of the lookup / permutation / quotient / opening phases
+    K2  polynomials     every column: iNTT 2^k (Lagrange -> coeff) and coset NTT 2^(k+2)
+with the column / MSM / NTT counts of paillier_halo2_amd/layout.py.  Until the K4
+expansion kernel feeds real advice columns, column VALUES are synthetic with the witness' value
+mix; all arithmetic work of the listed kernels is performed every step, nothing
+is cached between steps.  What a full prover does OUTSIDE this hot path (transcript hashing,
+quotient evaluation, permutation/lookup product construction -- SURVEY.md section 8f "next") stays in the
+reference's Rust and is NOT in `value`; DESIGN.md section 6 says so next to the number.
+
+Contract: python bench.py --gpus N --steps K --warmup W ; for N>1 launched by torch.distributed.run,
+one rank per GPU, independent proofs per rank (weak scaling, no data-path collective).
+`--workload msm22` instead times config c4: one 2^22-point MSM with Pippenger windows sharded over
+the ranks and an RCCL all-gather + fixed-order fold of the partial points.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+
+
+def synth_inputs(enc_bits: int, seed: int):
+    """seeded (n, g, m, r): n = p*q exactly enc_bits bits (p, q random odd), g = n+1, m in [0,n), r in [1,n)
+    -- SURVEY.md section 8d; same recipe as oracle/pyref.synth_paillier_inputs, restated so the product path
+    never imports oracle/."""
+    import random
+
+    rng = random.Random(seed)
+    half = enc_bits // 2
+    while True:
+        p = rng.getrandbits(half) | (1 << (half - 1)) | 1
+        q = rng.getrandbits(half) | (1 << (half - 1)) | 1
+        n = p * q
+        if n.bit_length() == enc_bits:
+            break
+    return n, n + 1, rng.randrange(0, n), rng.randrange(1, n)
+
+
+class ProofWorkload:
+    """device-resident state of the c2 hot path on one GPU"""
+
+    def __init__(self, eng, torch, enc_bits: int, k: int, seed: int, scale: float, pool: int = 32):
+        from paillier_halo2_amd import consts, layout
+
+        self.eng, self.torch = eng, torch
+        self.enc_bits, self.k = enc_bits, k
+        self.n = 1 << k
+        self.Ln = enc_bits // 64
+        self.L = 2 * self.Ln
+        dev = "cuda"
+        nn, g, m, r = synth_inputs(enc_bits, seed)
+        self.inputs = tuple(consts.int_to_limbs(x, self.Ln) for x in (nn, g, m, r))
+        n_steps = m.bit_length() + bin(m).count("1") + nn.bit_length() + bin(nn).count("1") + 1
+        self.n_steps = n_steps
+        self.shape = layout.encrypt_proof_shape(enc_bits, k, n_steps)
+        sh = self.shape
+        sc = lambda x: max(1, int(round(x * scale)))
+        self.counts = dict(msm_witness=sc(sh.msm_witness), msm_lookup=sc(sh.msm_lookup), msm_full=sc(sh.msm_full),
+                           polys=sc(sh.polys))
+        self.scale = scale
+        # K3 output buffer (steps stay in HBM for K4)
+        self.d_steps = torch.zeros((n_steps, 4, self.L), dtype=torch.int64, device=dev)
+        # SRS stand-in: 2^k distinct points [s_i]G, generated on the GPU (fixed-base mul), window table built once
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+        self.gen = gen
+        ks = self._rand_fr(self.n)
+        d_b = torch.zeros((self.n, 8), dtype=torch.int64, device=dev)
+        eng.g1_fixed_base_mul_dev(ks.data_ptr(), self.n, d_b.data_ptr())
+        eng.sync()
+        self.bases = eng.load_bases_dev(d_b.data_ptr(), self.n)
+        del d_b, ks
+        # column pools (values synthetic, Montgomery form): witness-like / lookup digits / full width
+        self.pool = pool
+        self.col_w = self._witness_like(pool)
+        self.col_l = self._small(pool, sh.lookup_bits)
+        self.col_f = self._rand_fr(pool * self.n).view(pool, self.n, 4)
+        self.d_out = torch.zeros((pool, 12), dtype=torch.int64, device=dev)
+        # NTT buffers
+        self.ext_n = 1 << sh.ext_k
+        self.ntt_batch = min(pool, 16)
+        self.d_coeff = torch.zeros((self.ntt_batch, self.n, 4), dtype=torch.int64, device=dev)
+        self.d_ext = torch.zeros((self.ntt_batch, self.ext_n, 4), dtype=torch.int64, device=dev)
+        self.omega_inv = consts.fr_mont_limbs(pow(consts.fr_omega(k), -1, consts.FR_R))
+        self.n_inv = consts.fr_mont_limbs(pow(self.n, -1, consts.FR_R))
+        self.omega_ext = consts.fr_mont_limbs(consts.fr_omega(sh.ext_k))
+        self.coset_g = consts.fr_mont_limbs(consts.FR_GENERATOR)
+        torch.cuda.synchronize()
+
+    # ---- synthetic column values (generated on the GPU; converted to Montgomery by the library)
+    def _rand_fr(self, count):
+        t = self.torch
+        x = t.randint(-(1 << 63), (1 << 63) - 1, (count, 4), dtype=t.int64, device="cuda", generator=self.gen)
+        x[:, 3] &= 0x0FFFFFFFFFFFFFFF  # < 2^252 < r: a valid representative; uniform enough for digit statistics
+        return x
+
+    def _small(self, cols, bits):
+        t = self.torch
+        x = t.zeros((cols, self.n, 4), dtype=t.int64, device="cuda")
+        x[:, :, 0] = t.randint(0, 1 << bits, (cols, self.n), dtype=t.int64, device="cuda", generator=self.gen)
+        self.eng.fr_convert_dev(x.data_ptr(), cols * self.n, True)
+        return x
+
+    def _witness_like(self, cols):
+        """value mix of the mul_mod cell stream (layout.mul_mod_cells): ~76 % of the cells are the
+        (a_j, b_j, partial sum) triples of the two limb convolutions -- 1/3 of them 64-bit limbs of a,
+        1/3 limbs of b (half of each zero padding), 1/3 up-to-135-bit sums; the rest 64-bit limbs, 16-bit
+        digits, constants and booleans."""
+        t = self.torch
+        n = self.n
+        x = t.zeros((cols, n, 4), dtype=t.int64, device="cuda")
+        u = t.rand((cols, n), device="cuda", generator=self.gen)
+        r64 = lambda: t.randint(-(1 << 63), (1 << 63) - 1, (cols, n), dtype=t.int64, device="cuda", generator=self.gen)
+        lim = (u < 0.36)                      # 64-bit limbs (operands, remainders, quotients)
+        zero = (u >= 0.36) & (u < 0.60)       # zero padding of extended limbs / constant 0
+        sums = (u >= 0.60) & (u < 0.85)       # partial sums < 2^135
+        dig = (u >= 0.85) & (u < 0.95)        # 16-bit range-check digits
+        # remaining 5 %: booleans / ones
+        x[:, :, 0] = t.where(lim | sums, r64(), x[:, :, 0])
+        x[:, :, 1] = t.where(sums, r64(), x[:, :, 1])
+        x[:, :, 2] = t.where(sums, r64() & 0x7F, x[:, :, 2])
+        x[:, :, 0] = t.where(dig, r64() & 0xFFFF, x[:, :, 0])
+        x[:, :, 0] = t.where(~(lim | zero | sums | dig), t.ones_like(x[:, :, 0]), x[:, :, 0])
+        del zero
+        self.eng.fr_convert_dev(x.data_ptr(), cols * n, True)
+        return x
+
+    # ---- one pass of the hot path
+    def step(self):
+        eng, t = self.eng, self.torch
+        n, k, sh = self.n, self.k, self.shape
+        # K3: witness trace (steps stay in HBM)
+        nn, g, m, r = self.inputs
+        eng.paillier_encrypt_dev(self.Ln, nn, g, m, r, self.d_steps.data_ptr(), self.n_steps)
+        # K1: commitments
+        for cols, count in ((self.col_w, self.counts["msm_witness"]), (self.col_l, self.counts["msm_lookup"]),
+                            (self.col_f, self.counts["msm_full"])):
+            done = 0
+            while done < count:
+                nc = min(self.pool, count - done)
+                eng.msm_dev(self.bases, cols.data_ptr(), nc, n, 4 * n, self.d_out.data_ptr())
+                done += nc
+        # K2: Lagrange -> coeff (iNTT 2^k, 1/n fused) -> extended coset (zero-extend, g^i fused, NTT 2^(k+2))
+        done = 0
+        nb = self.ntt_batch
+        while done < self.counts["polys"]:
+            nc = min(nb, self.counts["polys"] - done)
+            self.d_coeff[:nc].copy_(self.col_f[:nc])
+            eng.ntt_dev(self.d_coeff.data_ptr(), nc, 4 * n, self.omega_inv, k, None, self.n_inv)
+            self.d_ext[:nc].zero_()
+            self.d_ext[:nc, :n].copy_(self.d_coeff[:nc])
+            eng.ntt_dev(self.d_ext.data_ptr(), nc, 4 * self.ext_n, self.omega_ext, sh.ext_k, self.coset_g, None)
+            done += nc
+
+
+def cpu_baseline(shape, n_steps, enc_bits, k, log):
+    """The C restatement (oracle/pz_oracle.c, kind 'port') timed on this host's cores on a bounded
+    sample of the same workload, extrapolated with the per-proof counts of `shape`."""
+    import random
+
+    from oracle import cref
+    from oracle import pyref as P
+
+    cref.build()
+    cores = cref.lib().ora_num_threads()
+    rng = random.Random(5)
+    n = 1 << k
+    t0 = time.time()
+    bases = cref.walk_bases(n, rng.randrange(1, P.FR_R), rng.randrange(1, P.FR_R))
+    full = np.random.default_rng(1).integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    wit = cref.fr_ints_to_mont(P.witness_like_scalars(n, 3))
+    log("cpu baseline setup %.1fs" % (time.time() - t0))
+
+    def timeit(fn, reps):
+        fn()
+        t = time.time()
+        for _ in range(reps):
+            fn()
+        return (time.time() - t) / reps
+
+    t_msm_full = timeit(lambda: cref.msm_g1(full, bases), 2)
+    t_msm_wit = timeit(lambda: cref.msm_g1(wit, bases), 2)
+    omega = cref.fr_ints_to_mont([P.fr_omega(k)])[0]
+    t_ntt = timeit(lambda: cref.ntt_fr(full, omega, k), 2)
+    ext = np.concatenate([full] * 4)
+    omega_e = cref.fr_ints_to_mont([P.fr_omega(k + 2)])[0]
+    t_ntt_ext = timeit(lambda: cref.ntt_fr(ext, omega_e, k + 2), 1)
+    nn, g, m, r = P.synth_paillier_inputs(enc_bits, 0x5043)
+    L = 2 * (enc_bits // 64)
+    e = m & ((1 << 96) - 1) | (1 << 95)
+    t = time.time()
+    rc, res, steps = cref.pow_mod_trace(L, nn * nn, g, e, L // 2)
+    t_step = (time.time() - t) / max(1, len(steps))
+    per_proof = (shape.msm_full * t_msm_full + (shape.msm_witness + shape.msm_lookup) * t_msm_wit
+                 + shape.polys * (t_ntt + t_ntt_ext) + n_steps * t_step)
+    return {
+        "value": 1.0 / per_proof, "unit": "proofs/s", "cores": int(cores), "kind": "port",
+        "sample": ("oracle/pz_oracle.c (C restatement of best_multiexp / best_fft / mul_mod, OpenMP): 2x MSM 2^%d full-width "
+                   "(%.3fs each), 2x MSM 2^%d witness-like (%.3fs), 2x NTT 2^%d (%.4fs), 1x NTT 2^%d (%.4fs), %d mul_mod "
+                   "steps single-thread (%.1f us each); extrapolated with the per-proof counts in config"
+                   % (k, t_msm_full, k, t_msm_wit, k, t_ntt, k + 2, t_ntt_ext, len(steps), t_step * 1e6)),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=["c2", "msm22"])
+    ap.add_argument("--k", type=int, default=17)
+    ap.add_argument("--enc-bits", type=int, default=2048)
+    ap.add_argument("--scale", type=float, default=1.0, help="fraction of the per-proof MSM/NTT counts (debug only; "
+                    "any value != 1 marks the line as not comparable)")
+    ap.add_argument("--log-n", type=int, default=22, help="msm22 workload: log2 of the MSM size")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import paillier_halo2_amd as pz
+    from paillier_halo2_amd import engine as E
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    log = (lambda s: print("[bench] " + s, file=sys.stderr, flush=True)) if rank == 0 else (lambda s: None)
+
+    eng = pz.Engine(local)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.workload == "msm22":
+        from paillier_halo2_amd import dist as pzd
+
+        res = pzd.bench_sharded_msm(eng, torch, dist if world > 1 else None, rank, world, args.log_n, args.steps,
+                                    args.warmup, barrier, log)
+        if rank == 0:
+            print(json.dumps(res))
+        return
+
+    t0 = time.time()
+    wl = ProofWorkload(eng, torch, args.enc_bits, args.k, seed=0x5043 + rank, scale=args.scale)
+    log("setup %.1fs: %s ; per-step counts %s" % (time.time() - t0, wl.shape, wl.counts))
+    for _ in range(args.warmup):
+        wl.step()
+    barrier()
+    eng.timing_enable(True)
+    eng.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    acc_ms, acc_n = eng.timing_get(E.T_MSM_ACC)
+    ntt_ms, ntt_n = eng.timing_get(E.T_NTT)
+    trace_ms, trace_n = eng.timing_get(E.T_TRACE)
+    msm_ms, msm_n = eng.timing_get(E.T_MSM_ALL)
+    eng.timing_enable(False)
+    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    sh, cnt = wl.shape, wl.counts
+    proofs = args.steps * world
+    value = proofs / dt
+    # roofline of the dominant kernel (k_msm_accumulate): algorithmic bytes per launch / avg launch time.
+    # one launch accumulates nc columns against the shared bases: 64 B per base + 32 B per scalar
+    n = 1 << args.k
+    total_cols = (cnt["msm_witness"] + cnt["msm_lookup"] + cnt["msm_full"]) * args.steps
+    alg_bytes_total = total_cols * n * 32.0 + acc_n * n * 64.0
+    ach = alg_bytes_total / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+    out = {
+        "metric": "Paillier-encrypt proofs/s (2048-bit n, k=17); MSM achieved HBM GB/s vs peak",
+        "value": value, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32 limbs (254-bit modular integers), u64 limbs (4096-bit integers)", "data": "synthetic",
+        "config": {
+            "workload": "c2: 2048-bit n encrypt, KZG prover hot path at k=17 (K3 trace + K1 commitments + K2 NTTs), 1 proof per GPU per step",
+            "enc_bits": args.enc_bits, "k": args.k, "lookup_bits": sh.lookup_bits, "limb_bits": 64,
+            "mul_mod_steps": wl.n_steps, "advice_cols": sh.advice_cols, "lookup_cols": sh.lookup_cols,
+            "perm_cols": sh.perm_cols, "msm_per_proof": cnt["msm_witness"] + cnt["msm_lookup"] + cnt["msm_full"],
+            "ntt_polys_per_proof": cnt["polys"], "scale": args.scale,
+            "scope": "hot path only (SURVEY section 8a): transcript, quotient evaluation and product construction stay on the reference's CPU side",
+            "parallelism": "proof replicas, one per GPU, no collective",
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "k_msm_accumulate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "launches": int(acc_n), "avg_launch_ms": acc_ms / max(1, acc_n),
+            "note": "integer-multiply-issue bound by construction (v_mad_u64_u32); HBM fraction is the metric's definition, see DESIGN.md section 5",
+        },
+        "breakdown_ms_per_proof": {"trace": trace_ms / args.steps, "msm_all": msm_ms / args.steps,
+                                   "msm_accumulate": acc_ms / args.steps, "ntt": ntt_ms / args.steps},
+    }
+    if not args.no_cpu_baseline and args.scale == 1.0:
+        try:
+            out["cpu_baseline"] = cpu_baseline(sh, wl.n_steps, args.enc_bits, args.k, log)
+        except Exception as ex:  # the checker must never take the bench line down
+            out["cpu_baseline"] = {"value": None, "error": repr(ex)}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -115,6 +115,10 @@ int pz_ntt_fr_batch(pz_ctx* ctx, uint64_t* const* cols, size_t n_cols, const uin
 int pz_ntt_fr_dev(pz_ctx* ctx, uint64_t* d_a, size_t n_cols, size_t col_stride, const uint64_t omega[4],
                   uint32_t log_n, const uint64_t* pre_coset_g, const uint64_t* post_scale);
 
+/* in-place representation change of n Fr elements on the device: to_mont != 0: canonical little-endian
+ * integers (must be < r) -> Montgomery form (Fr::from_raw); else Montgomery -> canonical (to_repr). */
+int pz_fr_convert_dev(pz_ctx* ctx, uint64_t* d_a, size_t n, int to_mont);
+
 /* ---------------------------------------------------------------------------------------------
  * K3 -- big-integer witness generation for g^m * r^n mod n^2.  Replaces the native
  * (num-bigint) part of biguint-halo2's BigUintChip::{mul_mod, pow_mod_fixed_exp}

@@ -248,3 +248,22 @@ extern "C" int pz_ntt_fr(pz_ctx* ctx, uint64_t* a, const uint64_t omega[4], uint
     uint64_t* cols[1] = {a};
     return pz_ntt_fr_batch(ctx, cols, 1, omega, log_n);
 }
+
+__global__ void k_fr_convert(Fr* a, size_t n, int to_mont) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        Fr x = fp_load<FrTag>(a + i);
+        fp_store(a + i, to_mont ? fp_to_mont(x) : fp_from_mont(x));
+    }
+}
+extern "C" int pz_fr_convert_dev(pz_ctx* ctx, uint64_t* d_a, size_t n, int to_mont) {
+    if (!ctx || (n && !d_a)) return PZ_ERR_INVALID;
+    if (!n) return PZ_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_fr_convert, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (Fr*)d_a, n, to_mont);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}

@@ -1,0 +1,104 @@
+"""Multi-GPU split of ONE large MSM (config c4): disjoint Pippenger windows per rank, one exchange.
+
+Each rank holds the whole base table and all scalars (402 MB at 2^22 -- nothing next to 288 GB),
+accumulates only its window range [lo, hi) (pz_msm_g1_dev's win_lo / win_hi) and produces one
+Jacobian point; the exchange is an all-gather of world x 96 bytes over RCCL (xGMI) followed by the
+same fixed-order elliptic-curve fold on every rank -- an all-reduce in effect (EC addition is not
+an ncclRedOp).  Latency-bound: per-link bandwidth is irrelevant at 96 B.
+
+The reference has no distributed path at all; this module is new.
+`partial_fn` / `fold_fn` are injection points so the sharding + collective logic can be tested on
+CPU with gloo (tests/test_dist_cpu.py); the defaults call the HIP library and nothing else.
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+
+
+def window_range(n_windows: int, rank: int, world: int) -> Tuple[int, int]:
+    """contiguous, disjoint, exhaustive split of [0, n_windows) -- rank r gets [lo, hi)"""
+    return (rank * n_windows) // world, ((rank + 1) * n_windows) // world
+
+
+def sharded_msm(torch, dist, rank: int, world: int, n_windows: int,
+                partial_fn: Callable[[int, int], "torch.Tensor"],
+                fold_fn: Callable[[np.ndarray], np.ndarray]) -> np.ndarray:
+    """partial_fn(lo, hi) -> int64 tensor (12,) holding this rank's partial point (on the device the
+    process group communicates from); fold_fn(parts (world,12) u64) -> (12,) u64.
+    Returns the full MSM as a Jacobian point, identical on every rank."""
+    lo, hi = window_range(n_windows, rank, world)
+    part = partial_fn(lo, hi).reshape(12).contiguous()
+    if world == 1 or dist is None:
+        return fold_fn(part.cpu().numpy().astype(np.uint64).reshape(1, 12))
+    parts = [torch.empty_like(part) for _ in range(world)]
+    dist.all_gather(parts, part)
+    stacked = torch.stack(parts).cpu().numpy().astype(np.uint64)  # rank order == fixed fold order
+    return fold_fn(stacked)
+
+
+def hip_partial_fn(eng, torch, bases, d_scalars, n: int):
+    d_out = torch.zeros((1, 12), dtype=torch.int64, device="cuda")
+
+    def fn(lo, hi):
+        eng.msm_dev(bases, d_scalars.data_ptr(), 1, n, 4 * n, d_out.data_ptr(), lo, hi)
+        return d_out
+
+    return fn
+
+
+def bench_sharded_msm(eng, torch, dist, rank, world, log_n, steps, warmup, barrier, log):
+    """config c4: one 2^log_n-point MSM, windows sharded over `world` ranks."""
+    n = 1 << log_n
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(0x5045)  # same on every rank: identical bases and scalars
+
+    def rand_fr(count):
+        x = torch.randint(-(1 << 63), (1 << 63) - 1, (count, 4), dtype=torch.int64, device="cuda", generator=gen)
+        x[:, 3] &= 0x0FFFFFFFFFFFFFFF
+        return x
+
+    t0 = time.time()
+    ks = rand_fr(n)
+    d_b = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    eng.g1_fixed_base_mul_dev(ks.data_ptr(), n, d_b.data_ptr())
+    eng.sync()
+    bases = eng.load_bases_dev(d_b.data_ptr(), n)
+    del d_b, ks
+    d_s = rand_fr(n)
+    log("msm22 setup %.1fs (n=2^%d, c=%d, %d windows)" % (time.time() - t0, log_n, bases.window_bits, bases.n_windows))
+    pfn = hip_partial_fn(eng, torch, bases, d_s, n)
+    fold = eng.g1_sum
+    res = None
+    for _ in range(warmup):
+        res = sharded_msm(torch, dist, rank, world, bases.n_windows, pfn, fold)
+    barrier()
+    eng.timing_enable(True)
+    eng.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = sharded_msm(torch, dist, rank, world, bases.n_windows, pfn, fold)
+    barrier()
+    dt = time.perf_counter() - t0
+    acc_ms, acc_n = eng.timing_get(0)
+    eng.timing_enable(False)
+    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if dist is not None and world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    aff = eng.g1_normalize(res)[0]
+    alg = n * 96.0
+    ach = alg * steps / dt / 1e9
+    return {
+        "metric": "MSM/s (one 2^%d-point BN254 G1 MSM, Pippenger windows sharded across GPUs)" % log_n,
+        "value": steps / dt, "unit": "MSM/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u32 limbs (254-bit modular integers)", "data": "synthetic",
+        "config": {"workload": "c4: single 2^%d-point MSM, uniform scalars" % log_n, "window_bits": bases.window_bits,
+                   "n_windows": bases.n_windows, "parallelism": "windows/%d + all_gather(96 B) + fold" % world},
+        "roofline": {"bound": "hbm", "kernel": "whole MSM", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
+                     "frac": ach / 8000.0, "traffic": None, "accumulate_ms_per_msm": acc_ms / max(1, steps)},
+        "result_affine_x_limb0": int(aff[0]),
+    }

@@ -172,6 +172,21 @@ class Engine:
                                        _ptr(g) if g is not None else VP(), _ptr(s) if s is not None else VP()),
                   "pz_ntt_fr_dev")
 
+    def fr_convert_dev(self, d_a: int, n: int, to_mont: bool = True):
+        self._chk(self.L.pz_fr_convert_dev(self.ctx, VP(d_a), n, int(to_mont)), "pz_fr_convert_dev")
+
+    def paillier_encrypt_dev(self, limbs_n: int, n, g, m, r, d_steps: int, steps_cap: int):
+        """steps stay on the device (d_steps: batch x steps_cap x 4 x 2*limbs_n u64). Returns (c, ng, nr)."""
+        n, g, m, r = (_np(x).reshape(-1, limbs_n) for x in (n, g, m, r))
+        batch = n.shape[0]
+        ng = np.zeros(batch, dtype=np.uint32)
+        nr = np.zeros(batch, dtype=np.uint32)
+        c = np.zeros((batch, 2 * limbs_n), dtype=np.uint64)
+        self._chk(self.L.pz_paillier_encrypt_dev(self.ctx, limbs_n, batch, _ptr(n), _ptr(g), _ptr(m), _ptr(r),
+                                                 VP(d_steps), steps_cap, VP(ng.ctypes.data), VP(nr.ctypes.data),
+                                                 _ptr(c)), "pz_paillier_encrypt_dev")
+        return c, ng, nr
+
     # ------------------------------------------------------------------ K3: big integers
     def mul_mod(self, limbs: int, a, b, modulus) -> Tuple[np.ndarray, np.ndarray]:
         a, b, m = (_np(x).reshape(limbs) for x in (a, b, modulus))

@@ -1,0 +1,116 @@
+"""Shape arithmetic of the Paillier-encrypt circuit: how many advice / lookup cells the
+BigUintChip operations behind PaillierChip::encrypt (paillier.rs:32-60) push into halo2-lib's
+Context, hence how many 2^k-row columns, MSMs and NTTs one proof needs.
+
+The cell-emitting code lives in un-vendored dependencies (biguint-halo2, halo2-base, halo2-ecc:
+Cargo.toml:9-11, no rev) -- SURVEY.md tags it [D].  The counts below restate the halo2-rsa
+BigUintChip lineage on halo2-lib v0.4 gate primitives and are the SPEC the K4 expansion kernel
+(csrc/pz_witness.hip) implements; DESIGN.md section 4 lists the per-primitive cell patterns.  Layout parity
+with the reference's dependency versions is unpinned (they float); the VALUES in the cells are
+determined by the step trace.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+
+def range_check_cells(bits: int, lookup_bits: int):
+    """halo2-lib RangeChip::range_check(a, bits): (advice cells, lookup cells)."""
+    k = -(-bits // lookup_bits)
+    rem = bits % lookup_bits
+    adv = 0 if k == 1 else 1 + 3 * (k - 1)
+    lk = k
+    if rem == 1:
+        adv += 4  # assert_bit gate
+    elif rem > 1:
+        adv += 4  # gate.mul(last_limb, 2^(lookup_bits-rem))
+        lk += 1
+    return adv, lk
+
+
+def mul_word_max_bits(limb_bits: int, min_n: int) -> int:
+    """bits_size(2 * (min_n*(2^limb_bits-1)^2 + (2^limb_bits-1)))  (is_equal_muled's carry bound)"""
+    m = (1 << limb_bits) - 1
+    return (2 * (min_n * m * m + m)).bit_length()
+
+
+@dataclass
+class StepCells:
+    advice: int
+    lookup: int
+    # offsets of the segments inside one step's advice block (the K4 kernel's layout)
+    seg: dict
+
+
+def mul_mod_cells(limbs: int, limb_bits: int, lookup_bits: int) -> StepCells:
+    """Cells one BigUintChip::mul_mod(a, b, n) emits, all operands `limbs` limbs."""
+    L = limbs
+    D = 2 * L - 1  # limbs of a product
+    seg = {}
+    off = 0
+    rc_adv, rc_lk = range_check_cells(limb_bits, lookup_bits)
+    # 1. assign_integer(q), assign_integer(n), assign_integer(r): L witness cells + L range checks each
+    seg["assign"] = off
+    off += 3 * (L + L * rc_adv)
+    lookups = 3 * L * rc_lk
+    # 2. mul(a, b) and mul(q, n): load_zero + truncated mul_no_carry over D limbs
+    per_mul = 1 + sum(1 + 3 * (i + 1) for i in range(D))
+    seg["mul_ab"] = off
+    off += per_mul
+    seg["mul_qn"] = off
+    off += per_mul
+    # 3. qn + r: L gate.add
+    seg["add_r"] = off
+    off += 4 * L
+    # 4. is_equal_muled over D limbs
+    cb = mul_word_max_bits(limb_bits, L) - limb_bits
+    cb_adv, cb_lk = range_check_cells(cb, lookup_bits)
+    per_limb = 4 + 7 + 22 + 4 + 22 + 12 + 4  # sub, sum3, div_mod, add, div_mod, is_equal, and
+    seg["eq"] = off
+    off += 2 + D * per_limb + (D - 1) * cb_adv + (12 + 4)  # load_zero/one + limbs + carry checks + final carry
+    lookups += (D - 1) * cb_lk
+    # 5. r < n : big_less_than over L limbs (sub with borrow, one range check per limb)
+    lt_adv, lt_lk = range_check_cells(limb_bits, lookup_bits)
+    seg["lt"] = off
+    off += L * (11 + lt_adv) + 1
+    lookups += L * lt_lk
+    seg["end"] = off
+    return StepCells(off, lookups, seg)
+
+
+@dataclass
+class ProofShape:
+    k: int
+    lookup_bits: int
+    limbs: int
+    n_steps: int
+    cells_per_step: int
+    lookups_per_step: int
+    advice_cols: int
+    lookup_cols: int
+    perm_cols: int
+    msm_witness: int      # commit_lagrange of advice columns (short scalars)
+    msm_lookup: int       # commit_lagrange of lookup-advice columns (lookup_bits-bit scalars)
+    msm_full: int         # permuted lookup columns, lookup/permutation products, h pieces, openings
+    polys: int            # polynomials taken Lagrange -> coeff -> extended coset
+    ext_k: int
+
+
+def encrypt_proof_shape(enc_bits: int, k: int, n_steps: int, limb_bits: int = 64, lookup_bits: int | None = None,
+                        blinding_rows: int = 10, max_degree: int = 4) -> ProofShape:
+    """Column / MSM / NTT counts of one encrypt proof (SURVEY.md section 3.4's table, made concrete)."""
+    if lookup_bits is None:
+        lookup_bits = k - 1  # the reference's pattern: paillier.rs:168-169, bench.rs:162-163
+    L = 2 * (enc_bits // limb_bits)
+    sc = mul_mod_cells(L, limb_bits, lookup_bits)
+    rows = (1 << k) - blinding_rows
+    # the four input assignments + n^2 square/refresh + the result assignment are < 1 step's worth
+    fixed_cells = sc.advice
+    A = math.ceil((n_steps * sc.advice + fixed_cells) / rows)
+    Lk = math.ceil((n_steps * sc.lookup + 8 * L) / rows)
+    P = math.ceil((A + Lk + 1) / (max_degree - 2))
+    return ProofShape(k=k, lookup_bits=lookup_bits, limbs=L, n_steps=n_steps, cells_per_step=sc.advice,
+                      lookups_per_step=sc.lookup, advice_cols=A, lookup_cols=Lk, perm_cols=P, msm_witness=A,
+                      msm_lookup=Lk, msm_full=3 * Lk + P + 1 + (max_degree - 1) + 2, polys=A + 4 * Lk + P,
+                      ext_k=k + 2)

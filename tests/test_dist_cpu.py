@@ -1,0 +1,84 @@
+"""CPU, world_size 2 over gloo: the window-sharded MSM's partition + all-gather + fixed-order fold
+(paillier_halo2_amd/dist.py).  The per-rank partial and the fold are injected from the oracle here
+(tests may use it); on a GPU the defaults call libpz_hip.so (tests/test_gpu_kernels.py covers the
+window-range entry point itself)."""
+import os
+import random
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import pyref as P
+from paillier_halo2_amd.dist import sharded_msm, window_range
+
+
+def test_window_range_partition():
+    for W in (1, 7, 16, 20, 24):
+        for world in (1, 2, 3, 4, 8):
+            cover = []
+            for r in range(world):
+                lo, hi = window_range(W, r, world)
+                assert 0 <= lo <= hi <= W
+                cover += list(range(lo, hi))
+            assert cover == list(range(W))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, c, seed, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import cref
+
+    rng = random.Random(seed)
+    s, t = rng.randrange(1, P.FR_R), rng.randrange(1, P.FR_R)
+    bases = P.walk_bases(n, s, t)
+    scalars = [rng.randrange(P.FR_R) for _ in range(n)]
+    nwin = 253 // c + 1
+
+    def partial(lo, hi):
+        # this rank's windows only: sum_i (digits of scalar_i in [lo,hi)) * P_i, unsigned c-bit digits
+        mask = (1 << c) - 1
+        sc = [sum(((k >> (w * c)) & mask) << (w * c) for w in range(lo, hi)) for k in scalars]
+        jac = cref.msm_g1(cref.fr_ints_to_mont(sc), cref.affine_ints_to_mont(bases))
+        return torch.from_numpy(jac.astype(np.int64))
+
+    def fold(parts):
+        acc = parts[0]
+        for p in parts[1:]:
+            acc = cref.g1_add(acc, p)
+        return acc
+
+    res = sharded_msm(torch, dist, rank, world, nwin, partial, fold)
+    got = cref.affine_mont_to_ints(cref.g1_normalize(res))[0]
+    q.put((rank, got, P.msm_walk_expected(scalars, s, t)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_sharded_msm_gloo(world, cref):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 96, 13, 0x5045, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, got, want in out:
+        assert got == want, rank
+    assert out[0][1] == out[1][1]
