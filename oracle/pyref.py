@@ -403,3 +403,147 @@ def witness_like_scalars(n: int, seed: int) -> List[int]:
         else:
             out.append(rng.getrandbits(135))
     return out
+
+
+# ----------------------------------------------------------------------------------------
+# K4 oracle: the advice / lookup cell stream of one BigUintChip::mul_mod step, as canonical
+# field integers, in the layout of paillier_halo2_amd/layout.py.  The cell
+# patterns restate halo2-lib v0.4 gate primitives [D]; layout parity with the reference's floating
+# dependency versions is unpinned, the VALUES follow from (a, b, q, r, n).
+# ----------------------------------------------------------------------------------------
+def _range_check_cells(x: int, bits: int, lb: int):
+    """RangeChip::range_check(x, bits) -> (advice cells, lookup cells)"""
+    k = -(-bits // lb)
+    rem = bits % lb
+    mask = (1 << lb) - 1
+    digs = [(x >> (lb * i)) & mask for i in range(k)]
+    adv = []
+    if k > 1:
+        adv.append(digs[0])
+        acc = digs[0]
+        for g in range(1, k):
+            acc += digs[g] << (lb * g)
+            adv += [digs[g], 1 << (lb * g), acc]
+    lk = list(digs)
+    last = digs[-1]
+    if rem == 1:
+        adv += [0, last, last, last]
+    elif rem > 1:
+        chk = last << (lb - rem)
+        adv += [0, last, 1 << (lb - rem), chk]
+        lk.append(chk)
+    return adv, lk
+
+
+def _is_zero_cells(d: int):
+    d %= FR_R
+    if d == 0:
+        return [1, 0, 1, 1, 0, 0, 1, 0], 1
+    return [0, d, pow(d, -1, FR_R), 1, 0, d, 0, 0], 0
+
+
+def _is_equal_cells(x: int, y: int):
+    d = (x - y) % FR_R
+    z, bit = _is_zero_cells(d)
+    return [d, y % FR_R, 1, x % FR_R] + z, bit
+
+
+def _div_mod_cells(v: int, limb_bits: int):
+    """BigUintChip::div_mod_unsafe(v, 2^limb_bits): 22 cells, returns (cells, quotient, remainder)"""
+    base = 1 << limb_bits
+    qd, rd = v >> limb_bits, v & (base - 1)
+    prod = qd * base
+    eq, _ = _is_equal_cells(rd, v - prod)
+    return [qd, rd, 0, qd, base, prod, v - prod, prod, 1, v] + eq, qd, rd
+
+
+def _mul_cells(x_limbs, y_limbs, D):
+    """load_zero + truncated mul_no_carry over D limbs; returns (cells, product limbs)"""
+    L = len(x_limbs)
+    xe = list(x_limbs) + [0] * (D - L)
+    ye = list(y_limbs) + [0] * (D - L)
+    cells = [0]
+    prod = []
+    for i in range(D):
+        cells.append(0)
+        s = 0
+        for j in range(i + 1):
+            s += xe[j] * ye[i - j]
+            cells += [xe[j], ye[i - j], s]
+        prod.append(s)
+    return cells, prod
+
+
+def expand_mul_mod_cells(a: int, b: int, q: int, r: int, n: int, L: int, lookup_bits: int, limb_bits: int = 64):
+    """-> (advice cells, lookup cells) as canonical integers mod FR_R"""
+    lb = lookup_bits
+    D = 2 * L - 1
+    base = 1 << limb_bits
+    lim = lambda x: decompose_biguint(x, L, limb_bits)
+    al, bl, ql, rl, nl = lim(a), lim(b), lim(q), lim(r), lim(n)
+    adv, lk = [], []
+    # 1. assign_integer q, n, r
+    for X in (ql, nl, rl):
+        adv += X
+        for x in X:
+            c, l = _range_check_cells(x, limb_bits, lb)
+            adv += c
+            lk += l
+    # 2. the two limb convolutions
+    c_ab, p_ab = _mul_cells(al, bl, D)
+    c_qn, p_qn = _mul_cells(ql, nl, D)
+    adv += c_ab + c_qn
+    # 3. qn + r
+    qnr = list(p_qn)
+    for i in range(L):
+        adv += [p_qn[i], 1, rl[i], p_qn[i] + rl[i]]
+        qnr[i] = p_qn[i] + rl[i]
+    # 4. is_equal_muled(ab, qn + r)
+    m = base - 1
+    MAX = L * m * m + m
+    cb = (2 * MAX).bit_length() - limb_bits
+    adv += [0, 1]
+    carry, accx, eq_bit = 0, 0, 1
+    for i in range(D):
+        diff = p_ab[i] - qnr[i]
+        adv += [diff, qnr[i], 1, p_ab[i]]
+        s = diff + carry + MAX
+        adv += [diff, carry, 1, diff + carry, MAX, 1, s]
+        assert s >= 0
+        dm, new_carry, c = _div_mod_cells(s, limb_bits)
+        adv += dm
+        t = accx + MAX
+        adv += [accx, 1, MAX, t]
+        dm2, q_acc, mod_acc = _div_mod_cells(t, limb_bits)
+        adv += dm2
+        eqc, e = _is_equal_cells(c, mod_acc)
+        adv += eqc
+        adv += [0, eq_bit, e, eq_bit & e]
+        eq_bit &= e
+        accx = q_acc
+        if i < D - 1:
+            cc, ll = _range_check_cells(new_carry, cb, lb)
+            adv += cc
+            lk += ll
+        else:
+            eqc, e = _is_equal_cells(new_carry, accx)
+            adv += eqc
+            adv += [0, eq_bit, e, eq_bit & e]
+            eq_bit &= e
+        carry = new_carry
+    # 5. r < n
+    borrow = 0
+    for i in range(L):
+        nb = nl[i] + borrow
+        adv += [nl[i], 1, borrow, nb]
+        shift = rl[i] - nb + base
+        lt = 1 if rl[i] < nb else 0
+        out = shift & (base - 1)
+        adv += [shift, lt, out]
+        adv += [rl[i], lt, base, rl[i] + lt * base]
+        cc, ll = _range_check_cells(out, limb_bits, lb)
+        adv += cc
+        lk += ll
+        borrow = lt
+    adv.append(borrow)
+    return [x % FR_R for x in adv], [x % FR_R for x in lk]

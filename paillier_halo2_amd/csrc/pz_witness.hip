@@ -1,9 +1,551 @@
-// pz_witness.hip -- K4: expansion of mul_mod steps into advice cells (placeholder until the
-// expansion kernels land; the entry points exist so the ABI is complete and fail loudly).
+// pz_witness.hip -- K4: expansion of a mul_mod step trace into the advice / lookup cell stream
+// (Fr Montgomery, 32 B per cell) that halo2-lib's Context holds after BigUintChip::mul_mod emitted
+// its constraints.  Replaces the per-cell CPU pushes behind the dependency call sites
+// /root/reference/src/paillier.rs:39-57 and src/bench.rs:44-74.
+//
+// Layout = paillier_halo2_amd/layout.py::mul_mod_cells (segments: assign q/n/r with range-check
+// digit splits | limb convolution a*b | limb convolution q*n | qn + r | carry chain of
+// is_equal_muled | r < n); the value semantics are restated in oracle/pyref.py::expand_mul_mod_cells.
+//
+// One workgroup (4 waves) per step.  The two convolutions are 76 % of the cells: a wave owns a
+// product limb (row), lanes own the terms, partial sums come from a 192-bit wave prefix scan, every
+// lane writes a contiguous 96/192-byte run -> fully coalesced streaming stores.  Operand limbs are
+// converted to Montgomery form once per step into LDS.  The short serial carry / borrow chains run
+// on one lane between two barriers.  Bound: HBM write bandwidth, 32 B per cell.
+#include "fp.cuh"
 #include "pz_internal.h"
 
-extern "C" int pz_witness_cells_per_step(uint32_t, uint32_t, uint32_t, size_t*, size_t*) { return PZ_ERR_UNSUPPORTED; }
-extern "C" int pz_witness_expand_dev(pz_ctx*, uint32_t, uint32_t, uint32_t, const uint64_t*, size_t, const uint64_t*,
-                                     uint64_t*, uint64_t*) {
-    return PZ_ERR_UNSUPPORTED;
+struct U192 {
+    u64 w[3];
+};
+__device__ __forceinline__ U192 u_make(u64 a, u64 b = 0, u64 c = 0) {
+    U192 r;
+    r.w[0] = a; r.w[1] = b; r.w[2] = c;
+    return r;
+}
+__device__ __forceinline__ U192 u_add(const U192& a, const U192& b) {
+    U192 r;
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        u64 t = a.w[i] + b.w[i];
+        u64 c1 = t < a.w[i];
+        u64 t2 = t + c;
+        c = c1 | (t2 < t);
+        r.w[i] = t2;
+    }
+    return r;
+}
+__device__ __forceinline__ U192 u_sub(const U192& a, const U192& b, bool& borrow) {
+    U192 r;
+    u64 br = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        u64 t = a.w[i] - b.w[i];
+        u64 b1 = a.w[i] < b.w[i];
+        u64 t2 = t - br;
+        br = b1 | (t < br);
+        r.w[i] = t2;
+    }
+    borrow = br != 0;
+    return r;
+}
+__device__ __forceinline__ bool u_eq(const U192& a, const U192& b) {
+    return a.w[0] == b.w[0] && a.w[1] == b.w[1] && a.w[2] == b.w[2];
+}
+__device__ __forceinline__ U192 u_shr(const U192& a, unsigned s) {  // s < 192
+    U192 r = a;
+    while (s >= 64) {
+        r.w[0] = r.w[1]; r.w[1] = r.w[2]; r.w[2] = 0;
+        s -= 64;
+    }
+    if (s) {
+        r.w[0] = (r.w[0] >> s) | (r.w[1] << (64 - s));
+        r.w[1] = (r.w[1] >> s) | (r.w[2] << (64 - s));
+        r.w[2] >>= s;
+    }
+    return r;
+}
+__device__ __forceinline__ U192 u_shl(const U192& a, unsigned s) {  // s < 192
+    U192 r = a;
+    while (s >= 64) {
+        r.w[2] = r.w[1]; r.w[1] = r.w[0]; r.w[0] = 0;
+        s -= 64;
+    }
+    if (s) {
+        r.w[2] = (r.w[2] << s) | (r.w[1] >> (64 - s));
+        r.w[1] = (r.w[1] << s) | (r.w[0] >> (64 - s));
+        r.w[0] <<= s;
+    }
+    return r;
+}
+__device__ __forceinline__ U192 u_lowbits(const U192& a, unsigned bits) {  // a mod 2^bits, bits <= 192
+    U192 r = a;
+    if (bits < 64) { r.w[0] &= (1ull << bits) - 1; r.w[1] = 0; r.w[2] = 0; }
+    else if (bits < 128) { if (bits > 64) r.w[1] &= (1ull << (bits - 64)) - 1; else r.w[1] = 0; r.w[2] = 0; }
+    else if (bits < 192) { if (bits > 128) r.w[2] &= (1ull << (bits - 128)) - 1; else r.w[2] = 0; }
+    return r;
+}
+struct S192 {
+    U192 m;
+    bool neg;
+};
+__device__ __forceinline__ S192 s_sub(const U192& a, const U192& b) {  // a - b
+    S192 r;
+    bool br;
+    r.m = u_sub(a, b, br);
+    r.neg = br;
+    if (br) {
+        bool d;
+        r.m = u_sub(b, a, d);
+    }
+    return r;
+}
+__device__ __forceinline__ S192 s_addu(const S192& a, const U192& b) {  // a + b, b >= 0
+    if (!a.neg) {
+        S192 r;
+        r.m = u_add(a.m, b);
+        r.neg = false;
+        return r;
+    }
+    return s_sub(b, a.m);
+}
+__device__ __forceinline__ Fr fr_from_u(const U192& v) {
+    Fr x;
+    x.v[0] = (u32)v.w[0]; x.v[1] = (u32)(v.w[0] >> 32);
+    x.v[2] = (u32)v.w[1]; x.v[3] = (u32)(v.w[1] >> 32);
+    x.v[4] = (u32)v.w[2]; x.v[5] = (u32)(v.w[2] >> 32);
+    x.v[6] = 0; x.v[7] = 0;
+    if ((v.w[0] | v.w[1] | v.w[2]) == 0) return x;
+    return fp_to_mont(x);
+}
+__device__ __forceinline__ Fr fr_from_s(const S192& v) {
+    Fr x = fr_from_u(v.m);
+    return v.neg ? fp_neg(x) : x;
+}
+__device__ __forceinline__ void mul64w(u64 a, u64 b, u64& hi, u64& lo) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p00 = (u64)a0 * b0;
+    const u64 t = (u64)a0 * b1 + (p00 >> 32);
+    const u64 u = (u64)a1 * b0 + (u32)t;
+    lo = (u << 32) | (u32)p00;
+    hi = (u64)a1 * b1 + (t >> 32) + (u >> 32);
+}
+
+struct ExpP {
+    unsigned L, D, lb;
+    unsigned k64, rem64, rc64_adv, rc64_lk;   // range_check(limb, 64)
+    unsigned cb, kcb, remcb, rccb_adv, rccb_lk;  // range_check(carry, cb)
+    size_t off_assign, off_ab, off_qn, off_add, off_eq, off_lt, cells;
+    size_t lk_assign, lk_eq, lk_lt, lookups;
+    u64 max_w[3];  // L*(2^64-1)^2 + (2^64-1)
+};
+
+// position p of RangeChip::range_check(x, bits): advice pattern
+__device__ __forceinline__ Fr rc_adv_cell(const U192& x, unsigned bits, unsigned lb, unsigned p) {
+    const unsigned k = (bits + lb - 1) / lb, rem = bits % lb;
+    const unsigned body = k > 1 ? 1 + 3 * (k - 1) : 0;
+    if (p < body) {
+        if (p == 0) return fr_from_u(u_lowbits(x, lb));
+        const unsigned g = (p - 1) / 3 + 1, w = (p - 1) % 3;
+        if (w == 0) return fr_from_u(u_lowbits(u_shr(x, lb * g), lb));
+        if (w == 1) return fr_from_u(u_shl(u_make(1), lb * g));
+        return fr_from_u(u_lowbits(x, lb * (g + 1)));
+    }
+    const unsigned t = p - body;  // tail gate
+    const U192 last = u_lowbits(u_shr(x, lb * (k - 1)), lb);
+    if (t == 0) return fp_zero<FrTag>();
+    if (rem == 1) return fr_from_u(last);
+    if (t == 1) return fr_from_u(last);
+    if (t == 2) return fr_from_u(u_make(1ull << (lb - rem)));
+    return fr_from_u(u_shl(last, lb - rem));
+}
+__device__ __forceinline__ Fr rc_lk_cell(const U192& x, unsigned bits, unsigned lb, unsigned p) {
+    const unsigned k = (bits + lb - 1) / lb, rem = bits % lb;
+    if (p < k) return fr_from_u(u_lowbits(u_shr(x, lb * p), lb));
+    return fr_from_u(u_shl(u_lowbits(u_shr(x, lb * (k - 1)), lb), lb - rem));
+}
+
+// 8-cell is_zero pattern on the (signed) difference d, then positions 0..11 of is_equal(x, y)
+__device__ __noinline__ Fr is_equal_cell(const U192& x, const U192& y, unsigned p) {
+    S192 d = s_sub(x, y);
+    const bool z = !d.neg && (d.m.w[0] | d.m.w[1] | d.m.w[2]) == 0;
+    switch (p) {
+        case 0: return fr_from_s(d);
+        case 1: return fr_from_u(y);
+        case 2: return fp_one<FrTag>();
+        case 3: return fr_from_u(x);
+        case 4: return z ? fp_one<FrTag>() : fp_zero<FrTag>();
+        case 5: return fr_from_s(d);
+        case 6: return z ? fp_one<FrTag>() : fp_inv(fr_from_s(d));
+        case 7: return fp_one<FrTag>();
+        case 8: return fp_zero<FrTag>();
+        case 9: return fr_from_s(d);
+        case 10: return z ? fp_one<FrTag>() : fp_zero<FrTag>();
+        default: return fp_zero<FrTag>();
+    }
+}
+// 22 cells of div_mod_unsafe(v, 2^64)
+__device__ __forceinline__ Fr div_mod_cell(const U192& v, unsigned p) {
+    const U192 qd = u_shr(v, 64);
+    const U192 rd = u_make(v.w[0]);
+    const U192 prod = u_shl(qd, 64);
+    switch (p) {
+        case 0: return fr_from_u(qd);
+        case 1: return fr_from_u(rd);
+        case 2: return fp_zero<FrTag>();
+        case 3: return fr_from_u(qd);
+        case 4: return fr_from_u(u_make(0, 1));
+        case 5: return fr_from_u(prod);
+        case 6: return fr_from_u(rd);  // v - prod
+        case 7: return fr_from_u(prod);
+        case 8: return fp_one<FrTag>();
+        case 9: return fr_from_u(v);
+        default: return is_equal_cell(rd, rd, p - 10);
+    }
+}
+
+#define EXP_THREADS 256
+#define EXP_MAXL 128
+
+__global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u64* __restrict__ steps,
+                                                                const u64* __restrict__ modulus,
+                                                                Fr* __restrict__ advice, Fr* __restrict__ lookup) {
+    __shared__ u64 s_a[EXP_MAXL], s_b[EXP_MAXL], s_q[EXP_MAXL], s_r[EXP_MAXL], s_n[EXP_MAXL];
+    __shared__ Fr s_am[EXP_MAXL], s_bm[EXP_MAXL], s_qm[EXP_MAXL], s_nm[EXP_MAXL];
+    __shared__ u64 s_pab[2 * EXP_MAXL][3], s_pqn[2 * EXP_MAXL][3];
+    __shared__ u64 s_carry[2 * EXP_MAXL + 1][2], s_accx[2 * EXP_MAXL + 1][2];
+    __shared__ unsigned char s_eqbit[2 * EXP_MAXL + 2], s_borrow[EXP_MAXL + 1];
+    const unsigned L = P.L, D = P.D, lb = P.lb;
+    const size_t step = blockIdx.x;
+    const u64* st = steps + step * 4 * (size_t)L;
+    Fr* adv = advice ? advice + step * P.cells : nullptr;
+    Fr* lk = lookup ? lookup + step * P.lookups : nullptr;
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const U192 MAXV = u_make(P.max_w[0], P.max_w[1], P.max_w[2]);
+
+    for (unsigned i = tid; i < L; i += EXP_THREADS) {
+        u64 a = st[i], b = st[L + i], q = st[2 * L + i], r = st[3 * L + i], n = modulus[i];
+        s_a[i] = a; s_b[i] = b; s_q[i] = q; s_r[i] = r; s_n[i] = n;
+        s_am[i] = fr_from_u(u_make(a));
+        s_bm[i] = fr_from_u(u_make(b));
+        s_qm[i] = fr_from_u(u_make(q));
+        s_nm[i] = fr_from_u(u_make(n));
+    }
+    __syncthreads();
+
+    // ---- the two limb convolutions: wave per product limb (row), lanes own terms
+    const unsigned PER = (D + 63) / 64;
+    for (int which = 0; which < 2; ++which) {
+        const u64* xs = which ? s_q : s_a;
+        const u64* ys = which ? s_n : s_b;
+        const Fr* xm = which ? s_qm : s_am;
+        const Fr* ym = which ? s_nm : s_bm;
+        u64(*pout)[3] = which ? s_pqn : s_pab;
+        Fr* seg = adv ? adv + (which ? P.off_qn : P.off_ab) : nullptr;
+        if (seg && tid == 0) fp_store(seg, fp_zero<FrTag>());  // load_zero
+        for (unsigned i = wave; i < D; i += EXP_THREADS / 64) {
+            const size_t row = 1 + (size_t)i + 3 * ((size_t)i * (i + 1) / 2);
+            // local inclusive prefix over this lane's PER terms
+            U192 pre[4];
+            U192 run = u_make(0);
+            for (unsigned t = 0; t < PER; ++t) {
+                const unsigned j = lane * PER + t;
+                U192 p = u_make(0);
+                if (j <= i) {
+                    const u64 x = j < L ? xs[j] : 0, y = (i - j) < L ? ys[i - j] : 0;
+                    u64 hi, lo;
+                    mul64w(x, y, hi, lo);
+                    p = u_make(lo, hi);
+                }
+                run = u_add(run, p);
+                pre[t] = run;
+            }
+            // wave inclusive scan of lane totals
+            U192 tot = run;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                U192 o;
+                o.w[0] = __shfl_up(tot.w[0], off, 64);
+                o.w[1] = __shfl_up(tot.w[1], off, 64);
+                o.w[2] = __shfl_up(tot.w[2], off, 64);
+                if (lane >= (unsigned)off) tot = u_add(tot, o);
+            }
+            bool dummy;
+            const U192 excl = u_sub(tot, run, dummy);
+            if (seg && lane == 0) fp_store(seg + row, fp_zero<FrTag>());
+            for (unsigned t = 0; t < PER; ++t) {
+                const unsigned j = lane * PER + t;
+                if (j <= i) {
+                    const U192 s = u_add(excl, pre[t]);
+                    if (seg) {
+                        Fr* c = seg + row + 1 + 3 * (size_t)j;
+                        fp_store(c, j < L ? xm[j] : fp_zero<FrTag>());
+                        fp_store(c + 1, (i - j) < L ? ym[i - j] : fp_zero<FrTag>());
+                        fp_store(c + 2, fr_from_u(s));
+                    }
+                    if (j == i) {
+                        pout[i][0] = s.w[0]; pout[i][1] = s.w[1]; pout[i][2] = s.w[2];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- serial chains (one lane): carries of is_equal_muled, borrows of r < n
+    if (tid == 0) {
+        U192 carry = u_make(0), accx = u_make(0);
+        unsigned eq = 1;
+        s_eqbit[0] = 1;
+        for (unsigned i = 0; i < D; ++i) {
+            s_carry[i][0] = carry.w[0]; s_carry[i][1] = carry.w[1];
+            s_accx[i][0] = accx.w[0]; s_accx[i][1] = accx.w[1];
+            const U192 A = u_make(s_pab[i][0], s_pab[i][1], s_pab[i][2]);
+            U192 Bq = u_make(s_pqn[i][0], s_pqn[i][1], s_pqn[i][2]);
+            if (i < L) Bq = u_add(Bq, u_make(s_r[i]));
+            S192 s = s_addu(s_addu(s_sub(A, Bq), carry), MAXV);  // >= 0 for a consistent step
+            const U192 t = u_add(accx, MAXV);
+            const unsigned e = (!s.neg && s.m.w[0] == t.w[0]) ? 1u : 0u;
+            eq &= e;
+            s_eqbit[i + 1] = (unsigned char)eq;
+            carry = u_shr(s.m, 64);
+            accx = u_shr(t, 64);
+        }
+        s_carry[D][0] = carry.w[0]; s_carry[D][1] = carry.w[1];
+        s_accx[D][0] = accx.w[0]; s_accx[D][1] = accx.w[1];
+        s_eqbit[D + 1] = (unsigned char)(eq & (u_eq(carry, accx) ? 1u : 0u));
+        unsigned borrow = 0;
+        for (unsigned i = 0; i < L; ++i) {
+            s_borrow[i] = (unsigned char)borrow;
+            // r_i < n_i + borrow  (n_i + borrow may be 2^64)
+            const u64 nb = s_n[i] + borrow;
+            const bool wrap = borrow && nb == 0;
+            borrow = (wrap || s_r[i] < nb) ? 1u : 0u;
+        }
+        s_borrow[L] = (unsigned char)borrow;
+    }
+    __syncthreads();
+
+    // ---- segment: assign_integer(q), (n), (r)
+    {
+        const unsigned per_int = L + L * P.rc64_adv;
+        for (unsigned t = tid; t < 3 * per_int; t += EXP_THREADS) {
+            const unsigned which = t / per_int, u = t % per_int;
+            const u64* X = which == 0 ? s_q : (which == 1 ? s_n : s_r);
+            Fr v;
+            if (u < L) v = fr_from_u(u_make(X[u]));
+            else {
+                const unsigned i = (u - L) / P.rc64_adv, p = (u - L) % P.rc64_adv;
+                v = rc_adv_cell(u_make(X[i]), 64, lb, p);
+            }
+            if (adv) fp_store(adv + P.off_assign + t, v);
+        }
+        if (lk)
+            for (unsigned t = tid; t < 3 * L * P.rc64_lk; t += EXP_THREADS) {
+                const unsigned which = t / (L * P.rc64_lk), u = t % (L * P.rc64_lk);
+                const u64* X = which == 0 ? s_q : (which == 1 ? s_n : s_r);
+                fp_store(lk + P.lk_assign + t, rc_lk_cell(u_make(X[u / P.rc64_lk]), 64, lb, u % P.rc64_lk));
+            }
+    }
+    // ---- segment: qn + r
+    if (adv)
+        for (unsigned t = tid; t < 4 * L; t += EXP_THREADS) {
+            const unsigned i = t / 4, p = t % 4;
+            const U192 qn = u_make(s_pqn[i][0], s_pqn[i][1], s_pqn[i][2]);
+            Fr v;
+            if (p == 0) v = fr_from_u(qn);
+            else if (p == 1) v = fp_one<FrTag>();
+            else if (p == 2) v = fr_from_u(u_make(s_r[i]));
+            else v = fr_from_u(u_add(qn, u_make(s_r[i])));
+            fp_store(adv + P.off_add + t, v);
+        }
+    // ---- segment: is_equal_muled
+    {
+        const unsigned per = 75 + P.rccb_adv;  // limbs 0..D-2; the last limb has 75 + 16
+        if (adv && tid == 0) {
+            fp_store(adv + P.off_eq, fp_zero<FrTag>());
+            fp_store(adv + P.off_eq + 1, fp_one<FrTag>());
+        }
+        const unsigned total = (D - 1) * per + 75 + 16;
+        for (unsigned t = tid; t < total; t += EXP_THREADS) {
+            unsigned i, p;
+            if (t < (D - 1) * per) { i = t / per; p = t % per; }
+            else { i = D - 1; p = t - (D - 1) * per; }
+            const U192 A = u_make(s_pab[i][0], s_pab[i][1], s_pab[i][2]);
+            U192 Bq = u_make(s_pqn[i][0], s_pqn[i][1], s_pqn[i][2]);
+            if (i < L) Bq = u_add(Bq, u_make(s_r[i]));
+            const U192 carry = u_make(s_carry[i][0], s_carry[i][1]);
+            const U192 accx = u_make(s_accx[i][0], s_accx[i][1]);
+            const S192 diff = s_sub(A, Bq);
+            const S192 dc = s_addu(diff, carry);
+            const S192 ssum = s_addu(dc, MAXV);
+            const U192 tt = u_add(accx, MAXV);
+            const U192 ncarry = u_make(s_carry[i + 1][0], s_carry[i + 1][1]);
+            Fr v;
+            if (p < 4) {
+                v = p == 0 ? fr_from_s(diff) : p == 1 ? fr_from_u(Bq) : p == 2 ? fp_one<FrTag>() : fr_from_u(A);
+            } else if (p < 11) {
+                switch (p - 4) {
+                    case 0: v = fr_from_s(diff); break;
+                    case 1: v = fr_from_u(carry); break;
+                    case 2: v = fp_one<FrTag>(); break;
+                    case 3: v = fr_from_s(dc); break;
+                    case 4: v = fr_from_u(MAXV); break;
+                    case 5: v = fp_one<FrTag>(); break;
+                    default: v = fr_from_s(ssum); break;
+                }
+            } else if (p < 33) {
+                v = div_mod_cell(ssum.m, p - 11);
+            } else if (p < 37) {
+                v = p == 33 ? fr_from_u(accx) : p == 34 ? fp_one<FrTag>() : p == 35 ? fr_from_u(MAXV) : fr_from_u(tt);
+            } else if (p < 59) {
+                v = div_mod_cell(tt, p - 37);
+            } else if (p < 71) {
+                v = is_equal_cell(u_make(ssum.m.w[0]), u_make(tt.w[0]), p - 59);
+            } else if (p < 75) {
+                const unsigned e = (ssum.m.w[0] == tt.w[0]) ? 1u : 0u;
+                const unsigned in = s_eqbit[i], out = s_eqbit[i + 1];
+                v = p == 71 ? fp_zero<FrTag>() : p == 72 ? (in ? fp_one<FrTag>() : fp_zero<FrTag>())
+                    : p == 73 ? (e ? fp_one<FrTag>() : fp_zero<FrTag>()) : (out ? fp_one<FrTag>() : fp_zero<FrTag>());
+            } else if (i < D - 1) {
+                v = rc_adv_cell(ncarry, P.cb, lb, p - 75);
+            } else {
+                const U192 qacc = u_make(s_accx[D][0], s_accx[D][1]);
+                if (p < 75 + 12) v = is_equal_cell(ncarry, qacc, p - 75);
+                else {
+                    const unsigned e = u_eq(ncarry, qacc) ? 1u : 0u;
+                    const unsigned in = s_eqbit[D], out = s_eqbit[D + 1];
+                    const unsigned pp = p - 87;
+                    v = pp == 0 ? fp_zero<FrTag>() : pp == 1 ? (in ? fp_one<FrTag>() : fp_zero<FrTag>())
+                        : pp == 2 ? (e ? fp_one<FrTag>() : fp_zero<FrTag>()) : (out ? fp_one<FrTag>() : fp_zero<FrTag>());
+                }
+            }
+            if (adv) fp_store(adv + P.off_eq + 2 + t, v);
+        }
+        if (lk)
+            for (unsigned t = tid; t < (D - 1) * P.rccb_lk; t += EXP_THREADS) {
+                const unsigned i = t / P.rccb_lk, p = t % P.rccb_lk;
+                fp_store(lk + P.lk_eq + t, rc_lk_cell(u_make(s_carry[i + 1][0], s_carry[i + 1][1]), P.cb, lb, p));
+            }
+    }
+    // ---- segment: r < n
+    {
+        const unsigned per = 11 + P.rc64_adv;
+        for (unsigned t = tid; t < L * per; t += EXP_THREADS) {
+            const unsigned i = t / per, p = t % per;
+            const unsigned borrow = s_borrow[i], lt = s_borrow[i + 1];
+            const U192 nb = u_add(u_make(s_n[i]), u_make(borrow));
+            bool br;
+            const U192 shift = u_sub(u_add(u_make(s_r[i]), u_make(0, 1)), nb, br);  // r_i - nb + 2^64
+            const U192 outv = u_make(shift.w[0]);
+            Fr v;
+            switch (p) {
+                case 0: v = fr_from_u(u_make(s_n[i])); break;
+                case 1: v = fp_one<FrTag>(); break;
+                case 2: v = borrow ? fp_one<FrTag>() : fp_zero<FrTag>(); break;
+                case 3: v = fr_from_u(nb); break;
+                case 4: v = fr_from_u(shift); break;
+                case 5: v = lt ? fp_one<FrTag>() : fp_zero<FrTag>(); break;
+                case 6: v = fr_from_u(outv); break;
+                case 7: v = fr_from_u(u_make(s_r[i])); break;
+                case 8: v = lt ? fp_one<FrTag>() : fp_zero<FrTag>(); break;
+                case 9: v = fr_from_u(u_make(0, 1)); break;
+                case 10: v = fr_from_u(u_add(u_make(s_r[i]), u_make(0, lt))); break;
+                default: v = rc_adv_cell(outv, 64, lb, p - 11); break;
+            }
+            if (adv) fp_store(adv + P.off_lt + t, v);
+        }
+        if (adv && tid == 0) fp_store(adv + P.off_lt + (size_t)L * per, s_borrow[L] ? fp_one<FrTag>() : fp_zero<FrTag>());
+        if (lk)
+            for (unsigned t = tid; t < L * P.rc64_lk; t += EXP_THREADS) {
+                const unsigned i = t / P.rc64_lk, p = t % P.rc64_lk;
+                const unsigned borrow = s_borrow[i];
+                const u64 nbw = s_n[i] + borrow;
+                fp_store(lk + P.lk_lt + t, rc_lk_cell(u_make(s_r[i] - nbw), 64, lb, p));
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host: layout arithmetic (mirrors paillier_halo2_amd/layout.py::mul_mod_cells)
+// ------------------------------------------------------------------------------------------------
+static void rc_counts(unsigned bits, unsigned lb, unsigned& k, unsigned& rem, unsigned& adv, unsigned& lk) {
+    k = (bits + lb - 1) / lb;
+    rem = bits % lb;
+    adv = k == 1 ? 0 : 1 + 3 * (k - 1);
+    lk = k;
+    if (rem == 1) adv += 4;
+    else if (rem > 1) { adv += 4; lk += 1; }
+}
+
+static int make_params(uint32_t L, uint32_t limb_bits, uint32_t lb, ExpP& P) {
+    if (limb_bits != 64) return PZ_ERR_UNSUPPORTED;  // K3 emits 64-bit limbs (the reference bench's choice, bench.rs:140)
+    if (L < 2 || L > EXP_MAXL) return PZ_ERR_UNSUPPORTED;
+    if (lb < 4 || lb > 32) return PZ_ERR_INVALID;
+    memset(&P, 0, sizeof P);
+    P.L = L;
+    P.D = 2 * L - 1;
+    P.lb = lb;
+    rc_counts(64, lb, P.k64, P.rem64, P.rc64_adv, P.rc64_lk);
+    if (P.k64 < 2) return PZ_ERR_INVALID;
+    // MAX = L*(2^64-1)^2 + (2^64-1) = L*2^128 - (2L-1)*2^64 + (L-1)
+    unsigned __int128 lo = (unsigned __int128)(L - 1);
+    // compute with 192-bit arithmetic: words w0,w1,w2
+    // L*2^128: w2 = L ; subtract (2L-1)*2^64: w1 -= (2L-1) with borrow from w2 ; add (L-1) to w0
+    uint64_t w0 = (uint64_t)lo, w1 = 0, w2 = L;
+    uint64_t sub = 2ull * L - 1;
+    w1 = (uint64_t)0 - sub;
+    w2 -= 1;  // borrow
+    P.max_w[0] = w0; P.max_w[1] = w1; P.max_w[2] = w2;
+    // bits of 2*MAX
+    unsigned bits = 0;
+    {
+        unsigned __int128 hi = ((unsigned __int128)w2 << 64) | w1;  // MAX >> 64
+        unsigned __int128 two_hi = hi << 1 | (w0 >> 63);
+        while (two_hi) { ++bits; two_hi >>= 1; }
+        bits += 64;
+    }
+    P.cb = bits - 64;
+    rc_counts(P.cb, lb, P.kcb, P.remcb, P.rccb_adv, P.rccb_lk);
+    size_t off = 0;
+    P.off_assign = off;
+    off += 3 * ((size_t)L + (size_t)L * P.rc64_adv);
+    size_t per_mul = 1;
+    for (unsigned i = 0; i < P.D; ++i) per_mul += 1 + 3 * ((size_t)i + 1);
+    P.off_ab = off; off += per_mul;
+    P.off_qn = off; off += per_mul;
+    P.off_add = off; off += 4 * (size_t)L;
+    P.off_eq = off; off += 2 + (size_t)P.D * 75 + (size_t)(P.D - 1) * P.rccb_adv + 16;
+    P.off_lt = off; off += (size_t)L * (11 + P.rc64_adv) + 1;
+    P.cells = off;
+    P.lk_assign = 0;
+    P.lk_eq = 3 * (size_t)L * P.rc64_lk;
+    P.lk_lt = P.lk_eq + (size_t)(P.D - 1) * P.rccb_lk;
+    P.lookups = P.lk_lt + (size_t)L * P.rc64_lk;
+    return PZ_OK;
+}
+
+extern "C" int pz_witness_cells_per_step(uint32_t limbs, uint32_t limb_bits, uint32_t lookup_bits,
+                                         size_t* advice_cells, size_t* lookup_cells) {
+    ExpP P;
+    PZCHK(make_params(limbs, limb_bits, lookup_bits, P));
+    if (advice_cells) *advice_cells = P.cells;
+    if (lookup_cells) *lookup_cells = P.lookups;
+    return PZ_OK;
+}
+
+extern "C" int pz_witness_expand_dev(pz_ctx* ctx, uint32_t limbs, uint32_t limb_bits, uint32_t lookup_bits,
+                                     const uint64_t* d_steps, size_t n_steps, const uint64_t* d_modulus,
+                                     uint64_t* d_advice, uint64_t* d_lookup) {
+    if (!ctx || (n_steps && (!d_steps || !d_modulus))) return PZ_ERR_INVALID;
+    ExpP P;
+    PZCHK(make_params(limbs, limb_bits, lookup_bits, P));
+    if (!n_steps || (!d_advice && !d_lookup)) return PZ_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    pz_timer tm(ctx, PZ_T_EXPAND);
+    hipLaunchKernelGGL(k_witness_expand, dim3((unsigned)n_steps), dim3(EXP_THREADS), 0, ctx->stream, P, d_steps,
+                       d_modulus, (Fr*)d_advice, (Fr*)d_lookup);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
 }

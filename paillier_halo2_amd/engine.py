@@ -236,6 +236,19 @@ class Engine:
                                              VP(nr.ctypes.data), _ptr(c)), "pz_paillier_encrypt")
         return c, steps, ng, nr
 
+    # ------------------------------------------------------------------ K4: witness expansion
+    def witness_cells_per_step(self, limbs: int, limb_bits: int, lookup_bits: int) -> Tuple[int, int]:
+        a = C.c_size_t()
+        l = C.c_size_t()
+        self._chk(self.L.pz_witness_cells_per_step(limbs, limb_bits, lookup_bits, C.byref(a), C.byref(l)),
+                  "pz_witness_cells_per_step")
+        return a.value, l.value
+
+    def witness_expand_dev(self, limbs: int, limb_bits: int, lookup_bits: int, d_steps: int, n_steps: int,
+                           d_modulus: int, d_advice: int, d_lookup: int = 0):
+        self._chk(self.L.pz_witness_expand_dev(self.ctx, limbs, limb_bits, lookup_bits, VP(d_steps), n_steps,
+                                               VP(d_modulus), VP(d_advice), VP(d_lookup)), "pz_witness_expand_dev")
+
     # ------------------------------------------------------------------ measurement
     def timing_enable(self, on: bool = True):
         self._chk(self.L.pz_timing_enable(self.ctx, int(on)), "pz_timing_enable")

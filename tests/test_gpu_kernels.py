@@ -328,3 +328,72 @@ def test_ubench_reports(eng):
     muls = 2048 * 256 * 512 * 2
     print("[ubench] Fq mont mul: %.3f ms, %.2f Gmul/s" % (ms, muls / ms / 1e6))
     assert ms > 0
+
+
+# ------------------------------------------------------------------------------------------ K4
+@pytest.mark.parametrize("L,lb", [(2, 15), (4, 16), (4, 14), (4, 8), (64, 16), (64, 14), (96, 18)])
+def test_witness_expand_vs_oracle(eng, cref, L, lb):
+    """cell stream of BigUintChip::mul_mod steps (layout.py / DESIGN.md section 4) vs the Python-int expansion"""
+    import torch
+
+    from paillier_halo2_amd import layout
+
+    rng = random.Random(1000 * L + lb)
+    bits = 64 * L
+    n = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+    steps_int = []
+    for it in range(3):
+        a, b = rng.randrange(n), rng.randrange(n)
+        if it == 1:
+            a = b = rng.randrange(n)  # a squaring step
+        if it == 2:
+            a, b = 1, rng.randrange(n)  # acc = 1 start of a chain (many zero limbs)
+        q, r = divmod(a * b, n)
+        steps_int.append((a, b, q, r))
+    steps = np.stack([np.stack([cref.int_to_limbs(v, L) for v in st]) for st in steps_int])
+    adv_n, lk_n = eng.witness_cells_per_step(L, 64, lb)
+    sc = layout.mul_mod_cells(L, 64, lb)
+    assert (adv_n, lk_n) == (sc.advice, sc.lookup)
+    d_steps = torch.from_numpy(steps.astype(np.int64)).cuda()
+    d_mod = torch.from_numpy(cref.int_to_limbs(n, L).astype(np.int64)).cuda()
+    d_adv = torch.zeros((len(steps_int), adv_n, 4), dtype=torch.int64, device="cuda")
+    d_lk = torch.zeros((len(steps_int), lk_n, 4), dtype=torch.int64, device="cuda")
+    eng.witness_expand_dev(L, 64, lb, d_steps.data_ptr(), len(steps_int), d_mod.data_ptr(), d_adv.data_ptr(),
+                           d_lk.data_ptr())
+    eng.sync()
+    adv = d_adv.cpu().numpy().astype(np.uint64)
+    lk = d_lk.cpu().numpy().astype(np.uint64)
+    for i, (a, b, q, r) in enumerate(steps_int):
+        want_adv, want_lk = P.expand_mul_mod_cells(a, b, q, r, n, L, lb)
+        got_adv = cref.fr_mont_to_ints(adv[i])
+        got_lk = cref.fr_mont_to_ints(lk[i])
+        if got_adv != want_adv:
+            bad = [k for k in range(len(want_adv)) if got_adv[k] != want_adv[k]]
+            raise AssertionError("step %d: %d advice cells differ, first at %d (segments %s)" % (i, len(bad), bad[0], sc.seg))
+        assert got_lk == want_lk, i
+
+
+def test_witness_expand_on_real_trace(eng, cref):
+    """K3 -> K4 on the device, 128-bit key (the reference's test shape): every step's cells == oracle;
+    properties at scale: lookup cells < 2^lookup_bits, eq bits all one."""
+    import torch
+
+    nn, g, m, r = P.synth_paillier_inputs(128, 0x5042, standard_g=False)
+    Ln, L, lb = 2, 4, 15
+    arr = lambda x: cref.int_to_limbs(x, Ln)
+    c, steps, ng, nr = eng.paillier_encrypt(Ln, arr(nn), arr(g), arr(m), arr(r))
+    tot = int(ng[0]) + int(nr[0]) + 1
+    adv_n, lk_n = eng.witness_cells_per_step(L, 64, lb)
+    d_steps = torch.from_numpy(steps[0, :tot].astype(np.int64)).cuda()
+    d_mod = torch.from_numpy(cref.int_to_limbs(nn * nn, L).astype(np.int64)).cuda()
+    d_adv = torch.zeros((tot, adv_n, 4), dtype=torch.int64, device="cuda")
+    d_lk = torch.zeros((tot, lk_n, 4), dtype=torch.int64, device="cuda")
+    eng.witness_expand_dev(L, 64, lb, d_steps.data_ptr(), tot, d_mod.data_ptr(), d_adv.data_ptr(), d_lk.data_ptr())
+    eng.sync()
+    adv = d_adv.cpu().numpy().astype(np.uint64)
+    lk = cref.fr_mont_to_ints(d_lk.cpu().numpy().astype(np.uint64).reshape(-1, 4))
+    assert max(lk) < (1 << lb)
+    for k in (0, 1, tot // 2, tot - 1):
+        a, b, q, rr = (cref.limbs_to_int(steps[0, k, j]) for j in range(4))
+        want_adv, _ = P.expand_mul_mod_cells(a, b, q, rr, nn * nn, L, lb)
+        assert cref.fr_mont_to_ints(adv[k]) == want_adv, k
