@@ -9,10 +9,12 @@ lookup_bits=16, limb_bits=64), inputs resident in HBM:
     K1  commitments     A advice-column MSMs (short witness scalars) + Lk lookup-column MSMs
                         + the full-width MSMs of the lookup / permutation / quotient / opening phases
     K2  polynomials     every column: iNTT 2^k (Lagrange -> coeff) and coset NTT 2^(k+2)
-with the column / MSM / NTT counts of paillier_halo2_amd/layout.py.  Until the K4
-expansion kernel feeds real advice columns, column VALUES are synthetic with the witness' value
-mix; all arithmetic work of the listed kernels is performed every step, nothing
-is cached between steps.  What a full prover does OUTSIDE this hot path (transcript hashing,
+    K4  cell expansion  trace -> ~4e8 advice cells (12.7 GB) + lookup cells, the circuit's columns
+with the column / MSM / NTT counts of paillier_halo2_amd/layout.py.  Advice and
+lookup columns committed in K1 are the REAL cells K4 wrote; the scalars of the later-phase MSMs and the
+NTT inputs are uniformly random field elements (what grand products / quotient pieces look like) from a
+resident pool.  All arithmetic work of the listed kernels is performed every step, nothing is cached
+between steps.  What a full prover does OUTSIDE this hot path (transcript hashing,
 quotient evaluation, permutation/lookup product construction -- SURVEY.md section 8f "next") stays in the
 reference's Rust and is NOT in `value`; DESIGN.md section 6 says so next to the number.
 
@@ -74,11 +76,19 @@ class ProofWorkload:
         self.shape = layout.encrypt_proof_shape(enc_bits, k, n_steps)
         sh = self.shape
         sc = lambda x: max(1, int(round(x * scale)))
-        self.counts = dict(msm_witness=sc(sh.msm_witness), msm_lookup=sc(sh.msm_lookup), msm_full=sc(sh.msm_full),
-                           polys=sc(sh.polys))
+        self.counts = dict(msm_full=sc(sh.msm_full), polys=sc(sh.polys))
         self.scale = scale
-        # K3 output buffer (steps stay in HBM for K4)
+        # K3 output buffer (steps stay in HBM for K4) and the K4 cell streams: the circuit's advice columns are
+        # consecutive runs of `rows` cells (2^k minus the blinding rows), lookup columns likewise
         self.d_steps = torch.zeros((n_steps, 4, self.L), dtype=torch.int64, device=dev)
+        self.d_mod = torch.from_numpy(consts.int_to_limbs(nn * nn, self.L).astype(np.int64)).to(dev)
+        self.cells, self.lookups = eng.witness_cells_per_step(self.L, 64, self.shape.lookup_bits)
+        self.rows = self.n - 10
+        self.adv_cols = -(-(n_steps * self.cells) // self.rows)
+        self.lk_cols = -(-(n_steps * self.lookups) // self.rows)
+        self.d_adv = torch.zeros((self.adv_cols * self.rows, 4), dtype=torch.int64, device=dev)
+        self.d_lk = torch.zeros((self.lk_cols * self.rows, 4), dtype=torch.int64, device=dev)
+        self.d_out_adv = torch.zeros((self.adv_cols, 12), dtype=torch.int64, device=dev)
         # SRS stand-in: 2^k distinct points [s_i]G, generated on the GPU (fixed-base mul), window table built once
         gen = torch.Generator(device=dev)
         gen.manual_seed(seed)
@@ -91,8 +101,6 @@ class ProofWorkload:
         del d_b, ks
         # column pools (values synthetic, Montgomery form): witness-like / lookup digits / full width
         self.pool = pool
-        self.col_w = self._witness_like(pool)
-        self.col_l = self._small(pool, sh.lookup_bits)
         self.col_f = self._rand_fr(pool * self.n).view(pool, self.n, 4)
         self.d_out = torch.zeros((pool, 12), dtype=torch.int64, device=dev)
         # NTT buffers
@@ -113,37 +121,6 @@ class ProofWorkload:
         x[:, 3] &= 0x0FFFFFFFFFFFFFFF  # < 2^252 < r: a valid representative; uniform enough for digit statistics
         return x
 
-    def _small(self, cols, bits):
-        t = self.torch
-        x = t.zeros((cols, self.n, 4), dtype=t.int64, device="cuda")
-        x[:, :, 0] = t.randint(0, 1 << bits, (cols, self.n), dtype=t.int64, device="cuda", generator=self.gen)
-        self.eng.fr_convert_dev(x.data_ptr(), cols * self.n, True)
-        return x
-
-    def _witness_like(self, cols):
-        """value mix of the mul_mod cell stream (layout.mul_mod_cells): ~76 % of the cells are the
-        (a_j, b_j, partial sum) triples of the two limb convolutions -- 1/3 of them 64-bit limbs of a,
-        1/3 limbs of b (half of each zero padding), 1/3 up-to-135-bit sums; the rest 64-bit limbs, 16-bit
-        digits, constants and booleans."""
-        t = self.torch
-        n = self.n
-        x = t.zeros((cols, n, 4), dtype=t.int64, device="cuda")
-        u = t.rand((cols, n), device="cuda", generator=self.gen)
-        r64 = lambda: t.randint(-(1 << 63), (1 << 63) - 1, (cols, n), dtype=t.int64, device="cuda", generator=self.gen)
-        lim = (u < 0.36)                      # 64-bit limbs (operands, remainders, quotients)
-        zero = (u >= 0.36) & (u < 0.60)       # zero padding of extended limbs / constant 0
-        sums = (u >= 0.60) & (u < 0.85)       # partial sums < 2^135
-        dig = (u >= 0.85) & (u < 0.95)        # 16-bit range-check digits
-        # remaining 5 %: booleans / ones
-        x[:, :, 0] = t.where(lim | sums, r64(), x[:, :, 0])
-        x[:, :, 1] = t.where(sums, r64(), x[:, :, 1])
-        x[:, :, 2] = t.where(sums, r64() & 0x7F, x[:, :, 2])
-        x[:, :, 0] = t.where(dig, r64() & 0xFFFF, x[:, :, 0])
-        x[:, :, 0] = t.where(~(lim | zero | sums | dig), t.ones_like(x[:, :, 0]), x[:, :, 0])
-        del zero
-        self.eng.fr_convert_dev(x.data_ptr(), cols * n, True)
-        return x
-
     # ---- one pass of the hot path
     def step(self):
         eng, t = self.eng, self.torch
@@ -151,14 +128,21 @@ class ProofWorkload:
         # K3: witness trace (steps stay in HBM)
         nn, g, m, r = self.inputs
         eng.paillier_encrypt_dev(self.Ln, nn, g, m, r, self.d_steps.data_ptr(), self.n_steps)
-        # K1: commitments
-        for cols, count in ((self.col_w, self.counts["msm_witness"]), (self.col_l, self.counts["msm_lookup"]),
-                            (self.col_f, self.counts["msm_full"])):
-            done = 0
-            while done < count:
-                nc = min(self.pool, count - done)
-                eng.msm_dev(self.bases, cols.data_ptr(), nc, n, 4 * n, self.d_out.data_ptr())
-                done += nc
+        # K4: expand the trace into the advice / lookup cell streams (the circuit's columns)
+        eng.witness_expand_dev(self.L, 64, sh.lookup_bits, self.d_steps.data_ptr(), self.n_steps, self.d_mod.data_ptr(),
+                               self.d_adv.data_ptr(), self.d_lk.data_ptr())
+        # K1: commitments -- every advice and lookup-advice column (real witness cells) ...
+        for buf, ncols in ((self.d_adv, self.adv_cols), (self.d_lk, self.lk_cols)):
+            if self.scale != 1.0:
+                ncols = max(1, int(round(ncols * self.scale)))
+            eng.msm_dev(self.bases, buf.data_ptr(), ncols, self.rows, 4 * self.rows, self.d_out_adv.data_ptr())
+        # ... and the full-width MSMs of the later prover phases (permuted lookup columns, grand products,
+        # quotient pieces, openings): uniformly random scalars
+        done = 0
+        while done < self.counts["msm_full"]:
+            nc = min(self.pool, self.counts["msm_full"] - done)
+            eng.msm_dev(self.bases, self.col_f.data_ptr(), nc, n, 4 * n, self.d_out.data_ptr())
+            done += nc
         # K2: Lagrange -> coeff (iNTT 2^k, 1/n fused) -> extended coset (zero-extend, g^i fused, NTT 2^(k+2))
         done = 0
         nb = self.ntt_batch
@@ -286,6 +270,7 @@ def main():
     ntt_ms, ntt_n = eng.timing_get(E.T_NTT)
     trace_ms, trace_n = eng.timing_get(E.T_TRACE)
     msm_ms, msm_n = eng.timing_get(E.T_MSM_ALL)
+    exp_ms, exp_n = eng.timing_get(E.T_EXPAND)
     eng.timing_enable(False)
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -301,7 +286,8 @@ def main():
     # roofline of the dominant kernel (k_msm_accumulate): algorithmic bytes per launch / avg launch time.
     # one launch accumulates nc columns against the shared bases: 64 B per base + 32 B per scalar
     n = 1 << args.k
-    total_cols = (cnt["msm_witness"] + cnt["msm_lookup"] + cnt["msm_full"]) * args.steps
+    n_adv = wl.adv_cols + wl.lk_cols if args.scale == 1.0 else max(1, int(round(wl.adv_cols * args.scale))) + max(1, int(round(wl.lk_cols * args.scale)))
+    total_cols = (n_adv + cnt["msm_full"]) * args.steps
     alg_bytes_total = total_cols * n * 32.0 + acc_n * n * 64.0
     ach = alg_bytes_total / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
     out = {
@@ -313,7 +299,8 @@ def main():
             "workload": "c2: 2048-bit n encrypt, KZG prover hot path at k=17 (K3 trace + K1 commitments + K2 NTTs), 1 proof per GPU per step",
             "enc_bits": args.enc_bits, "k": args.k, "lookup_bits": sh.lookup_bits, "limb_bits": 64,
             "mul_mod_steps": wl.n_steps, "advice_cols": sh.advice_cols, "lookup_cols": sh.lookup_cols,
-            "perm_cols": sh.perm_cols, "msm_per_proof": cnt["msm_witness"] + cnt["msm_lookup"] + cnt["msm_full"],
+            "perm_cols": sh.perm_cols, "advice_cols_committed": wl.adv_cols, "lookup_cols_committed": wl.lk_cols,
+            "cells_per_mul_mod": wl.cells, "advice_cells": wl.n_steps * wl.cells, "msm_per_proof": n_adv + cnt["msm_full"],
             "ntt_polys_per_proof": cnt["polys"], "scale": args.scale,
             "scope": "hot path only (SURVEY section 8a): transcript, quotient evaluation and product construction stay on the reference's CPU side",
             "parallelism": "proof replicas, one per GPU, no collective",
@@ -324,7 +311,7 @@ def main():
             "launches": int(acc_n), "avg_launch_ms": acc_ms / max(1, acc_n),
             "note": "integer-multiply-issue bound by construction (v_mad_u64_u32); HBM fraction is the metric's definition, see DESIGN.md section 5",
         },
-        "breakdown_ms_per_proof": {"trace": trace_ms / args.steps, "msm_all": msm_ms / args.steps,
+        "breakdown_ms_per_proof": {"trace": trace_ms / args.steps, "expand": exp_ms / args.steps, "msm_all": msm_ms / args.steps,
                                    "msm_accumulate": acc_ms / args.steps, "ntt": ntt_ms / args.steps},
     }
     if not args.no_cpu_baseline and args.scale == 1.0:

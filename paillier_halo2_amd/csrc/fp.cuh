@@ -151,8 +151,18 @@ template <class T> __device__ __forceinline__ Fp<T> fp_neg(const Fp<T>& a) {
 
 template <class T> __device__ __forceinline__ Fp<T> fp_dbl(const Fp<T>& a) { return fp_add(a, a); }
 
-// Montgomery product a*b*R^-1 mod p, CIOS over 32-bit limbs: per outer limb one multiply row and
-// one reduction row, each 8 x v_mad_u64_u32 with a 64-bit running carry.
+// Montgomery product a*b*R^-1 mod p: finely integrated product scanning over 32-bit limbs with one 96-bit
+// column accumulator.  Per term one v_mad_u64_u32 (the quarter-rate multiplier primitive; its carry-out
+// goes to VCC) and one v_addc folding the carry into the third accumulator word: 128 mads + 8 v_mul_lo
+// + 128 addc.  hipcc does not use the mad's carry-out from C (it re-derives carries with
+// v_cmp_lt_u64 + v_cndmask, or keeps 64-bit adds + zero-extension moves: 580 instructions), hence inline
+// asm, one statement per column (gen_fp_mul.py).  VALU->VALU dependencies inside a statement are
+// hardware-interlocked on gfx950; VCC written by the mad is read by the next instruction's carry-in,
+// which needs no wait state.  Cost model measured on MI355X: mad 8 cycles, other VALU 2.
+#ifndef PZ_FP_MUL_PLAIN
+#include "fp_mul_gen.cuh"
+#else
+// plain-C CIOS variant (what hipcc makes of it: 128 mads + ~450 moves / 64-bit adds); kept for A/B debugging
 template <class T> __device__ __forceinline__ Fp<T> fp_mul(const Fp<T>& a, const Fp<T>& b) {
     u32 t[8];
     u32 t8 = 0;
@@ -187,10 +197,10 @@ template <class T> __device__ __forceinline__ Fp<T> fp_mul(const Fp<T>& a, const
     Fp<T> r;
 #pragma unroll
     for (int i = 0; i < 8; ++i) r.v[i] = t[i];
-    // result < 2p and p < 2^254, so t8 == 0 here
     fp_reduce_once(r);
     return r;
 }
+#endif
 
 template <class T> __device__ __forceinline__ Fp<T> fp_sqr(const Fp<T>& a) { return fp_mul(a, a); }
 
