@@ -20,7 +20,9 @@
 #include "ec.cuh"
 #include "pz_internal.h"
 
-#define MSM_CHUNK 256u  // max entries one lane accumulates for one bucket chunk
+#ifndef MSM_CHUNK
+#define MSM_CHUNK 32u
+#endif  // max entries one lane accumulates for one bucket chunk
 
 struct MsmP {
     size_t n;          // scalars per column
@@ -124,8 +126,9 @@ __global__ __launch_bounds__(256) void k_msm_hist(const Fr* __restrict__ scalars
 
 // per column: exclusive scans of the bucket counts (entry offsets) and of ceil(cnt/CHUNK) (item offsets)
 __global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, MsmP p, u32* __restrict__ offs,
-                                                  u32* __restrict__ items) {
+                                                  u32* __restrict__ items, u32* __restrict__ max_chunks) {
     __shared__ u32 s_cnt[256], s_itm[256];
+    u32 mx = 0;
     const size_t col = blockIdx.x;
     const u32* h = hist + col * p.B;
     u32* o = offs + col * (p.B + 1);
@@ -138,9 +141,12 @@ __global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, 
         if (b < p.B) {
             u32 v = h[b];
             c += v;
-            m += (v + MSM_CHUNK - 1) / MSM_CHUNK;
+            const u32 ch = (v + MSM_CHUNK - 1) / MSM_CHUNK;
+            m += ch;
+            mx = ch > mx ? ch : mx;
         }
     }
+    if (mx > 1) atomicMax(max_chunks, mx);
     s_cnt[threadIdx.x] = c;
     s_itm[threadIdx.x] = m;
     __syncthreads();
@@ -205,7 +211,8 @@ __global__ __launch_bounds__(256) void k_msm_scatter(const Fr* __restrict__ scal
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_msm_accumulate(const G1Affine* __restrict__ table, MsmP p,
                                                         const u32* __restrict__ offs, const u32* __restrict__ items,
-                                                        const u32* __restrict__ entries, G1X* __restrict__ partials) {
+                                                        const u32* __restrict__ entries, G1X* __restrict__ partials,
+                                                        u32* __restrict__ item_bucket) {
     const size_t col = blockIdx.y;
     const u32* it = items + col * (p.B + 1);
     const u32 total = it[p.B];
@@ -231,6 +238,30 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const G1Affine* __restri
         x_add_affine(acc, q);
     }
     x_store(partials + col * p.max_items + item, acc);
+    item_bucket[col * p.max_items + item] = b;
+}
+
+// over-full buckets own several consecutive partials: fold them pairwise in place, stride 2^pass per
+// launch (partial j of a bucket absorbs partial j + 2^pass when j is a multiple of 2^(pass+1)); after
+// ceil(log2(chunks)) passes the bucket's first partial holds its sum.  Uniform early exit once
+// 2^pass reaches the largest chunk count of the group.
+__global__ __launch_bounds__(256) void k_msm_merge(MsmP p, unsigned pass, const u32* __restrict__ items,
+                                                   const u32* __restrict__ item_bucket, const u32* __restrict__ max_chunks,
+                                                   G1X* __restrict__ partials) {
+    if ((1u << pass) >= *max_chunks) return;
+    const size_t col = blockIdx.y;
+    const u32* it = items + col * (p.B + 1);
+    const u32 item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= it[p.B]) return;
+    const u32 b = item_bucket[col * p.max_items + item];
+    const u32 first = it[b], m = it[b + 1] - first;
+    const u32 j = item - first;
+    if ((j & ((2u << pass) - 1)) != 0 || j + (1u << pass) >= m) return;
+    G1X* pc = partials + col * p.max_items;
+    G1X a = x_load(pc + item);
+    G1X o = x_load(pc + item + (1u << pass));
+    x_add(a, o);
+    x_store(pc + item, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -253,8 +284,8 @@ __global__ __launch_bounds__(128) void k_msm_reduce_l1(MsmP p, unsigned m, const
     for (unsigned j = m; j-- > 0;) {
         unsigned b = t * m + j;
         u32 a = it[b], z = it[b + 1];
-        for (u32 k = a; k < z; ++k) {
-            G1X v = x_load(pc + k);
+        if (z > a) {  // merged: the bucket's sum sits in its first partial
+            G1X v = x_load(pc + a);
             x_add(run, v);
         }
         x_add(acc, run);
@@ -425,9 +456,11 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     p.B = 1u << (bases->c - 1);
     p.cap = n * (size_t)(win_hi - win_lo);
     p.max_items = p.B + p.cap / MSM_CHUNK;
-    void *hist, *offs, *cursor, *items, *entries, *partials, *na, *nb;
+    void *hist, *offs, *cursor, *items, *entries, *partials, *na, *nb, *ibk;
     PZCHK(pz_ws_get(ctx, WS_HIST, nc * p.B * 4, &hist));
-    PZCHK(pz_ws_get(ctx, WS_CURSOR, nc * p.B * 4, &cursor));
+    PZCHK(pz_ws_get(ctx, WS_CURSOR, nc * p.B * 4 + 64, &cursor));
+    PZCHK(pz_ws_get(ctx, WS_MISC, nc * p.max_items * 4, &ibk));
+    u32* max_chunks = (u32*)cursor + nc * p.B;
     PZCHK(pz_ws_get(ctx, WS_OFFS, nc * (p.B + 1) * 4, &offs));
     PZCHK(pz_ws_get(ctx, WS_ITEMS, nc * (p.B + 1) * 4, &items));
     PZCHK(pz_ws_get(ctx, WS_ENTRIES, nc * p.cap * 4 + 16, &entries));
@@ -440,17 +473,25 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     hipStream_t st = ctx->stream;
     pz_timer tall(ctx, PZ_T_MSM_ALL);
     HIPCHK(ctx, hipMemsetAsync(hist, 0, nc * p.B * 4, st));
-    HIPCHK(ctx, hipMemsetAsync(cursor, 0, nc * p.B * 4, st));
+    HIPCHK(ctx, hipMemsetAsync(cursor, 0, nc * p.B * 4 + 64, st));
     dim3 gs(pz_div_up(n, 256), (unsigned)nc);
     hipLaunchKernelGGL(k_msm_hist, gs, dim3(256), 0, st, d_scalars, cs, p, (u32*)hist);
-    hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)nc), dim3(256), 0, st, (const u32*)hist, p, (u32*)offs, (u32*)items);
+    hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)nc), dim3(256), 0, st, (const u32*)hist, p, (u32*)offs, (u32*)items,
+                       max_chunks);
     hipLaunchKernelGGL(k_msm_scatter, gs, dim3(256), 0, st, d_scalars, cs, p, (const u32*)offs, (u32*)cursor,
                        (u32*)entries);
     {
         pz_timer tacc(ctx, PZ_T_MSM_ACC);
         hipLaunchKernelGGL(k_msm_accumulate, dim3(pz_div_up(p.max_items, 256), (unsigned)nc), dim3(256), 0, st,
                            (const G1Affine*)bases->d_table, p, (const u32*)offs, (const u32*)items,
-                           (const u32*)entries, (G1X*)partials);
+                           (const u32*)entries, (G1X*)partials, (u32*)ibk);
+    }
+    {
+        unsigned passes = 0;
+        while (((size_t)1 << passes) < p.cap / MSM_CHUNK + 1) ++passes;
+        for (unsigned ps = 0; ps < passes; ++ps)
+            hipLaunchKernelGGL(k_msm_merge, dim3(pz_div_up(p.max_items, 256), (unsigned)nc), dim3(256), 0, st, p, ps,
+                               (const u32*)items, (const u32*)ibk, (const u32*)max_chunks, (G1X*)partials);
     }
     hipLaunchKernelGGL(k_msm_reduce_l1, dim3(pz_div_up(n_nodes, 128), (unsigned)nc), dim3(128), 0, st, p, m1,
                        (const u32*)items, (const G1X*)partials, (MsmNode*)na);
@@ -493,7 +534,8 @@ extern "C" int pz_msm_g1_dev(pz_ctx* ctx, const pz_bases* bases, const uint64_t*
     }
     const size_t cs = col_stride / 4;
     // column groups: bound the sorted-entry workspace (4 B per digit) to ~1 GiB, grid.y to 65535
-    const size_t per_col = n * (size_t)(win_hi - win_lo) * 4 + (size_t)(1u << (bases->c - 1)) * 160;
+    const size_t digits = n * (size_t)(win_hi - win_lo);
+    const size_t per_col = digits * 4 + (digits / MSM_CHUNK) * (sizeof(G1X) + 4) + (size_t)(1u << (bases->c - 1)) * 164;
     size_t group = ((size_t)1 << 30) / per_col;
     if (group == 0) group = 1;
     if (group > n_cols) group = n_cols;
