@@ -103,43 +103,67 @@ __global__ __launch_bounds__(128) void k_build_table(const G1Affine* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// pass 1: histogram of non-zero digits per bucket
+// counting sort of the digits by bucket, LDS-staged.  Scattered global atomics run at ~20 G/s on
+// MI355X (one 64-B memory-side request per lane), far below what 50 M digits per column group need,
+// so the bucket counters live in LDS: a 1024-thread workgroup owns a slice of SORT_SLICE scalars of
+// one column and a private 2^(c-1)-entry counter array (128 KiB at c = 16: one workgroup per CU).
+//   pass 1  k_msm_hist    : LDS histogram of the slice's non-zero digits -> slice_hist[col][slice][B]
+//   pass 2  k_msm_scan    : per column, bucket totals -> entry offsets, chunk (work item) offsets, and
+//                           slice_hist rewritten in place as each slice's start offset per bucket
+//   pass 3  k_msm_scatter : slice offsets back into LDS, returning LDS atomics give every digit its
+//                           slot; (table index | sign << 31) is written to the sorted entry list
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_msm_hist(const Fr* __restrict__ scalars, size_t col_stride, MsmP p,
-                                                  u32* __restrict__ hist) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.n) return;
+#define SORT_THREADS 1024u
+#define SORT_PER_THREAD 8u
+#define SORT_SLICE (SORT_THREADS * SORT_PER_THREAD)
+#define SORT_MAXB 32768u
+
+__global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(const Fr* __restrict__ scalars, size_t col_stride, MsmP p,
+                                                           u32* __restrict__ slice_hist, unsigned n_slices) {
+    __shared__ u32 h[SORT_MAXB];
     const size_t col = blockIdx.y;
-    u32 s[8];
-    (void)scalar_prepare(fp_load<FrTag>(scalars + col * col_stride + i), s);
-    u32 any = 0;
+    const unsigned slice = blockIdx.x;
+    for (unsigned b = threadIdx.x; b < p.B; b += SORT_THREADS) h[b] = 0;
+    __syncthreads();
+    const size_t base = (size_t)slice * SORT_SLICE;
+    for (unsigned t = 0; t < SORT_PER_THREAD; ++t) {
+        const size_t i = base + (size_t)t * SORT_THREADS + threadIdx.x;
+        if (i >= p.n) break;
+        u32 s[8];
+        (void)scalar_prepare(fp_load<FrTag>(scalars + col * col_stride + i), s);
+        u32 any = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) any |= s[k];
-    if (!any) return;
-    unsigned carry = 0;
-    u32* h = hist + col * p.B;
-    for (unsigned w = 0; w < p.win_hi; ++w) {
-        int d = next_digit(s, w, p.c, carry);
-        if (w >= p.win_lo && d != 0) atomicAdd(h + ((d < 0 ? -d : d) - 1), 1u);
+        for (int k = 0; k < 8; ++k) any |= s[k];
+        if (!any) continue;
+        unsigned carry = 0;
+        for (unsigned w = 0; w < p.win_hi; ++w) {
+            int d = next_digit(s, w, p.c, carry);
+            if (w >= p.win_lo && d != 0) atomicAdd(&h[(d < 0 ? -d : d) - 1], 1u);
+        }
     }
+    __syncthreads();
+    u32* out = slice_hist + (col * n_slices + slice) * (size_t)p.B;
+    for (unsigned b = threadIdx.x; b < p.B; b += SORT_THREADS) out[b] = h[b];
 }
 
-// per column: exclusive scans of the bucket counts (entry offsets) and of ceil(cnt/CHUNK) (item offsets)
-__global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, MsmP p, u32* __restrict__ offs,
-                                                  u32* __restrict__ items, u32* __restrict__ max_chunks) {
-    __shared__ u32 s_cnt[256], s_itm[256];
-    u32 mx = 0;
+// per column: bucket totals over the slices, exclusive scans (entry offsets, work-item offsets),
+// per-slice start offsets written back over slice_hist
+__global__ __launch_bounds__(1024) void k_msm_scan(u32* __restrict__ slice_hist, unsigned n_slices, MsmP p,
+                                                   u32* __restrict__ offs, u32* __restrict__ items,
+                                                   u32* __restrict__ max_chunks) {
+    __shared__ u32 s_cnt[1024], s_itm[1024];
     const size_t col = blockIdx.x;
-    const u32* h = hist + col * p.B;
+    u32* sh = slice_hist + col * n_slices * (size_t)p.B;
     u32* o = offs + col * (p.B + 1);
     u32* it = items + col * (p.B + 1);
-    const unsigned per = (p.B + 255) / 256;
+    const unsigned per = (p.B + 1023) / 1024;
     const unsigned lo = threadIdx.x * per;
-    u32 c = 0, m = 0;
+    u32 c = 0, m = 0, mx = 0;
     for (unsigned k = 0; k < per; ++k) {
-        unsigned b = lo + k;
+        const unsigned b = lo + k;
         if (b < p.B) {
-            u32 v = h[b];
+            u32 v = 0;
+            for (unsigned sl = 0; sl < n_slices; ++sl) v += sh[(size_t)sl * p.B + b];
             c += v;
             const u32 ch = (v + MSM_CHUNK - 1) / MSM_CHUNK;
             m += ch;
@@ -152,7 +176,7 @@ __global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, 
     __syncthreads();
     if (threadIdx.x == 0) {
         u32 a = 0, b2 = 0;
-        for (int k = 0; k < 256; ++k) {
+        for (int k = 0; k < 1024; ++k) {
             u32 t = s_cnt[k];
             s_cnt[k] = a;
             a += t;
@@ -167,41 +191,53 @@ __global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, 
     c = s_cnt[threadIdx.x];
     m = s_itm[threadIdx.x];
     for (unsigned k = 0; k < per; ++k) {
-        unsigned b = lo + k;
+        const unsigned b = lo + k;
         if (b < p.B) {
-            u32 v = h[b];
             o[b] = c;
             it[b] = m;
+            u32 run = c;
+            for (unsigned sl = 0; sl < n_slices; ++sl) {
+                u32* q = sh + (size_t)sl * p.B + b;
+                const u32 v = *q;
+                *q = run;
+                run += v;
+            }
+            const u32 v = run - c;
             c += v;
             m += (v + MSM_CHUNK - 1) / MSM_CHUNK;
         }
     }
 }
 
-// pass 2: scatter (table index | sign << 31) into bucket order
-__global__ __launch_bounds__(256) void k_msm_scatter(const Fr* __restrict__ scalars, size_t col_stride, MsmP p,
-                                                     const u32* __restrict__ offs, u32* __restrict__ cursor,
-                                                     u32* __restrict__ entries) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.n) return;
+__global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restrict__ scalars, size_t col_stride, MsmP p,
+                                                              const u32* __restrict__ slice_hist, unsigned n_slices,
+                                                              u32* __restrict__ entries) {
+    __shared__ u32 h[SORT_MAXB];
     const size_t col = blockIdx.y;
-    u32 s[8];
-    bool neg = scalar_prepare(fp_load<FrTag>(scalars + col * col_stride + i), s);
-    u32 any = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) any |= s[k];
-    if (!any) return;
-    unsigned carry = 0;
-    const u32* o = offs + col * (p.B + 1);
-    u32* cur = cursor + col * p.B;
+    const unsigned slice = blockIdx.x;
+    const u32* in = slice_hist + (col * n_slices + slice) * (size_t)p.B;
+    for (unsigned b = threadIdx.x; b < p.B; b += SORT_THREADS) h[b] = in[b];
+    __syncthreads();
     u32* e = entries + col * p.cap;
-    for (unsigned w = 0; w < p.win_hi; ++w) {
-        int d = next_digit(s, w, p.c, carry);
-        if (w >= p.win_lo && d != 0) {
-            unsigned b = (d < 0 ? -d : d) - 1;
-            u32 pos = o[b] + atomicAdd(cur + b, 1u);
-            bool sgn = neg != (d < 0);
-            e[pos] = (u32)((size_t)w * p.n_table + i) | (sgn ? 0x80000000u : 0u);
+    const size_t base = (size_t)slice * SORT_SLICE;
+    for (unsigned t = 0; t < SORT_PER_THREAD; ++t) {
+        const size_t i = base + (size_t)t * SORT_THREADS + threadIdx.x;
+        if (i >= p.n) break;
+        u32 s[8];
+        const bool neg = scalar_prepare(fp_load<FrTag>(scalars + col * col_stride + i), s);
+        u32 any = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) any |= s[k];
+        if (!any) continue;
+        unsigned carry = 0;
+        for (unsigned w = 0; w < p.win_hi; ++w) {
+            int d = next_digit(s, w, p.c, carry);
+            if (w >= p.win_lo && d != 0) {
+                const unsigned b = (d < 0 ? -d : d) - 1;
+                const u32 pos = atomicAdd(&h[b], 1u);
+                const bool sgn = neg != (d < 0);
+                e[pos] = (u32)((size_t)w * p.n_table + i) | (sgn ? 0x80000000u : 0u);
+            }
         }
     }
 }
@@ -457,10 +493,11 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     p.cap = n * (size_t)(win_hi - win_lo);
     p.max_items = p.B + p.cap / MSM_CHUNK;
     void *hist, *offs, *cursor, *items, *entries, *partials, *na, *nb, *ibk;
-    PZCHK(pz_ws_get(ctx, WS_HIST, nc * p.B * 4, &hist));
-    PZCHK(pz_ws_get(ctx, WS_CURSOR, nc * p.B * 4 + 64, &cursor));
+    const unsigned n_slices = pz_div_up(n, SORT_SLICE);
+    PZCHK(pz_ws_get(ctx, WS_HIST, nc * (size_t)n_slices * p.B * 4, &hist));
+    PZCHK(pz_ws_get(ctx, WS_CURSOR, 64, &cursor));
     PZCHK(pz_ws_get(ctx, WS_MISC, nc * p.max_items * 4, &ibk));
-    u32* max_chunks = (u32*)cursor + nc * p.B;
+    u32* max_chunks = (u32*)cursor;
     PZCHK(pz_ws_get(ctx, WS_OFFS, nc * (p.B + 1) * 4, &offs));
     PZCHK(pz_ws_get(ctx, WS_ITEMS, nc * (p.B + 1) * 4, &items));
     PZCHK(pz_ws_get(ctx, WS_ENTRIES, nc * p.cap * 4 + 16, &entries));
@@ -472,13 +509,12 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     PZCHK(pz_ws_get(ctx, WS_NODES_B, nc * (size_t)(n_nodes / 2 + 1) * sizeof(MsmNode), &nb));
     hipStream_t st = ctx->stream;
     pz_timer tall(ctx, PZ_T_MSM_ALL);
-    HIPCHK(ctx, hipMemsetAsync(hist, 0, nc * p.B * 4, st));
-    HIPCHK(ctx, hipMemsetAsync(cursor, 0, nc * p.B * 4 + 64, st));
-    dim3 gs(pz_div_up(n, 256), (unsigned)nc);
-    hipLaunchKernelGGL(k_msm_hist, gs, dim3(256), 0, st, d_scalars, cs, p, (u32*)hist);
-    hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)nc), dim3(256), 0, st, (const u32*)hist, p, (u32*)offs, (u32*)items,
-                       max_chunks);
-    hipLaunchKernelGGL(k_msm_scatter, gs, dim3(256), 0, st, d_scalars, cs, p, (const u32*)offs, (u32*)cursor,
+    HIPCHK(ctx, hipMemsetAsync(cursor, 0, 64, st));
+    dim3 gs(n_slices, (unsigned)nc);
+    hipLaunchKernelGGL(k_msm_hist, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (u32*)hist, n_slices);
+    hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)nc), dim3(1024), 0, st, (u32*)hist, n_slices, p, (u32*)offs,
+                       (u32*)items, max_chunks);
+    hipLaunchKernelGGL(k_msm_scatter, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (const u32*)hist, n_slices,
                        (u32*)entries);
     {
         pz_timer tacc(ctx, PZ_T_MSM_ACC);
@@ -535,8 +571,10 @@ extern "C" int pz_msm_g1_dev(pz_ctx* ctx, const pz_bases* bases, const uint64_t*
     const size_t cs = col_stride / 4;
     // column groups: bound the sorted-entry workspace (4 B per digit) to ~1 GiB, grid.y to 65535
     const size_t digits = n * (size_t)(win_hi - win_lo);
-    const size_t per_col = digits * 4 + (digits / MSM_CHUNK) * (sizeof(G1X) + 4) + (size_t)(1u << (bases->c - 1)) * 164;
-    size_t group = ((size_t)1 << 30) / per_col;
+    const size_t per_col = digits * 4 + (digits / MSM_CHUNK) * (sizeof(G1X) + 4) +
+                           (size_t)(1u << (bases->c - 1)) * (164 + 4 * (size_t)pz_div_up(n, SORT_SLICE));
+    // group size: sized for 288 GB of HBM -- up to 6 GiB of sort / partial-sum workspace per launch sequence
+    size_t group = ((size_t)6 << 30) / per_col;
     if (group == 0) group = 1;
     if (group > n_cols) group = n_cols;
     if (group > 4096) group = 4096;
