@@ -60,7 +60,7 @@ def synth_inputs(enc_bits: int, seed: int):
 class ProofWorkload:
     """device-resident state of the c2 hot path on one GPU"""
 
-    def __init__(self, eng, torch, enc_bits: int, k: int, seed: int, scale: float, pool: int = 32):
+    def __init__(self, eng, torch, enc_bits: int, k: int, seed: int, scale: float, pool: int = 256):
         from paillier_halo2_amd import consts, layout
 
         self.eng, self.torch = eng, torch

@@ -18,6 +18,8 @@
 // Roofline: bounded by 32-bit integer multiply issue (v_mad_u64_u32), NOT by HBM: algorithmic
 // traffic is 96 B per (scalar, base) pair; bench.py reports both fractions.
 #include "ec.cuh"
+#include <stdlib.h>
+
 #include "pz_internal.h"
 
 #ifndef MSM_CHUNK
@@ -146,24 +148,38 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(const Fr* __restrict_
     for (unsigned b = threadIdx.x; b < p.B; b += SORT_THREADS) out[b] = h[b];
 }
 
-// per column: bucket totals over the slices, exclusive scans (entry offsets, work-item offsets),
-// per-slice start offsets written back over slice_hist
-__global__ __launch_bounds__(1024) void k_msm_scan(u32* __restrict__ slice_hist, unsigned n_slices, MsmP p,
-                                                   u32* __restrict__ offs, u32* __restrict__ items,
-                                                   u32* __restrict__ max_chunks) {
-    __shared__ u32 s_cnt[1024], s_itm[1024];
+// pass 2a: per (column, bucket): total over the slices; slice_hist rewritten in place as the slice's
+// offset RELATIVE to the bucket start (exclusive prefix over slices).  One thread per bucket, coalesced.
+__global__ __launch_bounds__(256) void k_msm_totals(u32* __restrict__ slice_hist, unsigned n_slices, MsmP p,
+                                                    u32* __restrict__ totals) {
+    const size_t col = blockIdx.y;
+    const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= p.B) return;
+    u32* sh = slice_hist + col * n_slices * (size_t)p.B + b;
+    u32 run = 0;
+    for (unsigned sl = 0; sl < n_slices; ++sl) {
+        const u32 v = sh[(size_t)sl * p.B];
+        sh[(size_t)sl * p.B] = run;
+        run += v;
+    }
+    totals[col * p.B + b] = run;
+}
+
+// pass 2b: per column exclusive scans of the bucket totals (entry offsets) and of ceil(cnt/CHUNK) (item offsets)
+__global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, MsmP p, u32* __restrict__ offs,
+                                                  u32* __restrict__ items, u32* __restrict__ max_chunks) {
+    __shared__ u32 s_cnt[256], s_itm[256];
     const size_t col = blockIdx.x;
-    u32* sh = slice_hist + col * n_slices * (size_t)p.B;
+    const u32* h = hist + col * p.B;
     u32* o = offs + col * (p.B + 1);
     u32* it = items + col * (p.B + 1);
-    const unsigned per = (p.B + 1023) / 1024;
+    const unsigned per = (p.B + 255) / 256;
     const unsigned lo = threadIdx.x * per;
     u32 c = 0, m = 0, mx = 0;
     for (unsigned k = 0; k < per; ++k) {
-        const unsigned b = lo + k;
+        unsigned b = lo + k;
         if (b < p.B) {
-            u32 v = 0;
-            for (unsigned sl = 0; sl < n_slices; ++sl) v += sh[(size_t)sl * p.B + b];
+            u32 v = h[b];
             c += v;
             const u32 ch = (v + MSM_CHUNK - 1) / MSM_CHUNK;
             m += ch;
@@ -176,7 +192,7 @@ __global__ __launch_bounds__(1024) void k_msm_scan(u32* __restrict__ slice_hist,
     __syncthreads();
     if (threadIdx.x == 0) {
         u32 a = 0, b2 = 0;
-        for (int k = 0; k < 1024; ++k) {
+        for (int k = 0; k < 256; ++k) {
             u32 t = s_cnt[k];
             s_cnt[k] = a;
             a += t;
@@ -191,18 +207,11 @@ __global__ __launch_bounds__(1024) void k_msm_scan(u32* __restrict__ slice_hist,
     c = s_cnt[threadIdx.x];
     m = s_itm[threadIdx.x];
     for (unsigned k = 0; k < per; ++k) {
-        const unsigned b = lo + k;
+        unsigned b = lo + k;
         if (b < p.B) {
+            u32 v = h[b];
             o[b] = c;
             it[b] = m;
-            u32 run = c;
-            for (unsigned sl = 0; sl < n_slices; ++sl) {
-                u32* q = sh + (size_t)sl * p.B + b;
-                const u32 v = *q;
-                *q = run;
-                run += v;
-            }
-            const u32 v = run - c;
             c += v;
             m += (v + MSM_CHUNK - 1) / MSM_CHUNK;
         }
@@ -211,12 +220,13 @@ __global__ __launch_bounds__(1024) void k_msm_scan(u32* __restrict__ slice_hist,
 
 __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restrict__ scalars, size_t col_stride, MsmP p,
                                                               const u32* __restrict__ slice_hist, unsigned n_slices,
-                                                              u32* __restrict__ entries) {
+                                                              const u32* __restrict__ offs, u32* __restrict__ entries) {
     __shared__ u32 h[SORT_MAXB];
     const size_t col = blockIdx.y;
     const unsigned slice = blockIdx.x;
     const u32* in = slice_hist + (col * n_slices + slice) * (size_t)p.B;
-    for (unsigned b = threadIdx.x; b < p.B; b += SORT_THREADS) h[b] = in[b];
+    const u32* o = offs + col * (p.B + 1);
+    for (unsigned b = threadIdx.x; b < p.B; b += SORT_THREADS) h[b] = o[b] + in[b];
     __syncthreads();
     u32* e = entries + col * p.cap;
     const size_t base = (size_t)slice * SORT_SLICE;
@@ -281,23 +291,26 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const G1Affine* __restri
 // launch (partial j of a bucket absorbs partial j + 2^pass when j is a multiple of 2^(pass+1)); after
 // ceil(log2(chunks)) passes the bucket's first partial holds its sum.  Uniform early exit once
 // 2^pass reaches the largest chunk count of the group.
-__global__ __launch_bounds__(256) void k_msm_merge(MsmP p, unsigned pass, const u32* __restrict__ items,
-                                                   const u32* __restrict__ item_bucket, const u32* __restrict__ max_chunks,
-                                                   G1X* __restrict__ partials) {
-    if ((1u << pass) >= *max_chunks) return;
-    const size_t col = blockIdx.y;
-    const u32* it = items + col * (p.B + 1);
-    const u32 item = blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= it[p.B]) return;
-    const u32 b = item_bucket[col * p.max_items + item];
-    const u32 first = it[b], m = it[b + 1] - first;
-    const u32 j = item - first;
-    if ((j & ((2u << pass) - 1)) != 0 || j + (1u << pass) >= m) return;
-    G1X* pc = partials + col * p.max_items;
-    G1X a = x_load(pc + item);
-    G1X o = x_load(pc + item + (1u << pass));
-    x_add(a, o);
-    x_store(pc + item, a);
+__global__ __launch_bounds__(256) void k_msm_merge(MsmP p, unsigned pass, size_t n_cols,
+                                                   const u32* __restrict__ items, const u32* __restrict__ item_bucket,
+                                                   const u32* __restrict__ max_chunks, G1X* __restrict__ partials) {
+    if ((1u << pass) >= *max_chunks) return;  // uniform: an unneeded pass costs one small launch
+    const size_t total = n_cols * p.max_items;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        const size_t col = g / p.max_items;
+        const u32 item = (u32)(g % p.max_items);
+        const u32* it = items + col * (p.B + 1);
+        if (item >= it[p.B]) continue;
+        const u32 b = item_bucket[col * p.max_items + item];
+        const u32 first = it[b], m = it[b + 1] - first;
+        const u32 j = item - first;
+        if ((j & ((2u << pass) - 1)) != 0 || j + (1u << pass) >= m) continue;
+        G1X* pc = partials + col * p.max_items;
+        G1X a = x_load(pc + item);
+        G1X o = x_load(pc + item + (1u << pass));
+        x_add(a, o);
+        x_store(pc + item, a);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -410,6 +423,16 @@ __global__ __launch_bounds__(128) void k_fixed_base_mul(const Fr* __restrict__ s
 // ------------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------------
+static size_t pz_msm_ws_gib() {
+    static size_t v = 0;
+    if (!v) {
+        const char* e = getenv("PZ_MSM_WS_GIB");
+        long g = e ? atol(e) : 48;
+        v = g < 1 ? 1 : (size_t)g;
+    }
+    return v;
+}
+
 static unsigned default_window_bits(size_t n) {
     if (n <= 1u << 8) return 9;
     if (n <= 1u << 11) return 11;
@@ -492,10 +515,11 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     p.B = 1u << (bases->c - 1);
     p.cap = n * (size_t)(win_hi - win_lo);
     p.max_items = p.B + p.cap / MSM_CHUNK;
-    void *hist, *offs, *cursor, *items, *entries, *partials, *na, *nb, *ibk;
+    void *hist, *offs, *cursor, *items, *entries, *partials, *na, *nb, *ibk, *totals;
     const unsigned n_slices = pz_div_up(n, SORT_SLICE);
     PZCHK(pz_ws_get(ctx, WS_HIST, nc * (size_t)n_slices * p.B * 4, &hist));
     PZCHK(pz_ws_get(ctx, WS_CURSOR, 64, &cursor));
+    PZCHK(pz_ws_get(ctx, WS_TOTALS, nc * p.B * 4, &totals));
     PZCHK(pz_ws_get(ctx, WS_MISC, nc * p.max_items * 4, &ibk));
     u32* max_chunks = (u32*)cursor;
     PZCHK(pz_ws_get(ctx, WS_OFFS, nc * (p.B + 1) * 4, &offs));
@@ -512,10 +536,12 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     HIPCHK(ctx, hipMemsetAsync(cursor, 0, 64, st));
     dim3 gs(n_slices, (unsigned)nc);
     hipLaunchKernelGGL(k_msm_hist, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (u32*)hist, n_slices);
-    hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)nc), dim3(1024), 0, st, (u32*)hist, n_slices, p, (u32*)offs,
-                       (u32*)items, max_chunks);
+    hipLaunchKernelGGL(k_msm_totals, dim3(pz_div_up(p.B, 256), (unsigned)nc), dim3(256), 0, st, (u32*)hist, n_slices, p,
+                       (u32*)totals);
+    hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)nc), dim3(256), 0, st, (const u32*)totals, p, (u32*)offs, (u32*)items,
+                       max_chunks);
     hipLaunchKernelGGL(k_msm_scatter, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (const u32*)hist, n_slices,
-                       (u32*)entries);
+                       (const u32*)offs, (u32*)entries);
     {
         pz_timer tacc(ctx, PZ_T_MSM_ACC);
         hipLaunchKernelGGL(k_msm_accumulate, dim3(pz_div_up(p.max_items, 256), (unsigned)nc), dim3(256), 0, st,
@@ -526,8 +552,8 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
         unsigned passes = 0;
         while (((size_t)1 << passes) < p.cap / MSM_CHUNK + 1) ++passes;
         for (unsigned ps = 0; ps < passes; ++ps)
-            hipLaunchKernelGGL(k_msm_merge, dim3(pz_div_up(p.max_items, 256), (unsigned)nc), dim3(256), 0, st, p, ps,
-                               (const u32*)items, (const u32*)ibk, (const u32*)max_chunks, (G1X*)partials);
+            hipLaunchKernelGGL(k_msm_merge, dim3(4096), dim3(256), 0, st, p, ps, nc, (const u32*)items, (const u32*)ibk,
+                               (const u32*)max_chunks, (G1X*)partials);
     }
     hipLaunchKernelGGL(k_msm_reduce_l1, dim3(pz_div_up(n_nodes, 128), (unsigned)nc), dim3(128), 0, st, p, m1,
                        (const u32*)items, (const G1X*)partials, (MsmNode*)na);
@@ -573,8 +599,9 @@ extern "C" int pz_msm_g1_dev(pz_ctx* ctx, const pz_bases* bases, const uint64_t*
     const size_t digits = n * (size_t)(win_hi - win_lo);
     const size_t per_col = digits * 4 + (digits / MSM_CHUNK) * (sizeof(G1X) + 4) +
                            (size_t)(1u << (bases->c - 1)) * (164 + 4 * (size_t)pz_div_up(n, SORT_SLICE));
-    // group size: sized for 288 GB of HBM -- up to 6 GiB of sort / partial-sum workspace per launch sequence
-    size_t group = ((size_t)6 << 30) / per_col;
+    // group size: sized for 288 GB of HBM -- by default up to 48 GiB of sort / partial-sum workspace per launch
+    // sequence (PZ_MSM_WS_GIB overrides), so the latency-bound tree levels are paid once per ~2000 columns
+    size_t group = (pz_msm_ws_gib() << 30) / per_col;
     if (group == 0) group = 1;
     if (group > n_cols) group = n_cols;
     if (group > 4096) group = 4096;
