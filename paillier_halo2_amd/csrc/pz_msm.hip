@@ -272,9 +272,12 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const G1Affine* __restri
     }
     const unsigned b = lo;
     const u32* o = offs + col * (p.B + 1);
-    const u32 start = o[b] + (item - it[b]) * MSM_CHUNK;
-    u32 end = start + MSM_CHUNK;
-    if (end > o[b + 1]) end = o[b + 1];
+    // the bucket's entries are split EVENLY over its chunks (sizes differ by at most one), so the lanes of
+    // a wave run nearly equal trip counts
+    const u32 cnt = o[b + 1] - o[b], nch = it[b + 1] - it[b], j = item - it[b];
+    const u32 q = cnt / nch, rem = cnt % nch;
+    const u32 start = o[b] + j * q + (j < rem ? j : rem);
+    const u32 end = start + q + (j < rem ? 1u : 0u);
     const u32* e = entries + col * p.cap;
     G1X acc = x_inf();
     for (u32 k = start; k < end; ++k) {
