@@ -23,7 +23,7 @@
 #include "pz_internal.h"
 
 #ifndef MSM_CHUNK
-#define MSM_CHUNK 32u
+#define MSM_CHUNK 16u
 #endif  // max entries one lane accumulates for one bucket chunk
 
 struct MsmP {
@@ -298,21 +298,21 @@ __global__ __launch_bounds__(256) void k_msm_merge(MsmP p, unsigned pass, size_t
                                                    const u32* __restrict__ items, const u32* __restrict__ item_bucket,
                                                    const u32* __restrict__ max_chunks, G1X* __restrict__ partials) {
     if ((1u << pass) >= *max_chunks) return;  // uniform: an unneeded pass costs one small launch
-    const size_t total = n_cols * p.max_items;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-        const size_t col = g / p.max_items;
-        const u32 item = (u32)(g % p.max_items);
+    for (size_t col = blockIdx.y; col < n_cols; col += gridDim.y) {
         const u32* it = items + col * (p.B + 1);
-        if (item >= it[p.B]) continue;
-        const u32 b = item_bucket[col * p.max_items + item];
-        const u32 first = it[b], m = it[b + 1] - first;
-        const u32 j = item - first;
-        if ((j & ((2u << pass) - 1)) != 0 || j + (1u << pass) >= m) continue;
+        const u32 total = it[p.B];  // only the items this column really has
         G1X* pc = partials + col * p.max_items;
-        G1X a = x_load(pc + item);
-        G1X o = x_load(pc + item + (1u << pass));
-        x_add(a, o);
-        x_store(pc + item, a);
+        const u32* ib = item_bucket + col * p.max_items;
+        for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
+            const u32 b = ib[item];
+            const u32 first = it[b], m = it[b + 1] - first;
+            const u32 j = item - first;
+            if ((j & ((2u << pass) - 1)) != 0 || j + (1u << pass) >= m) continue;
+            G1X a = x_load(pc + item);
+            G1X o = x_load(pc + item + (1u << pass));
+            x_add(a, o);
+            x_store(pc + item, a);
+        }
     }
 }
 
@@ -555,7 +555,7 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
         unsigned passes = 0;
         while (((size_t)1 << passes) < p.cap / MSM_CHUNK + 1) ++passes;
         for (unsigned ps = 0; ps < passes; ++ps)
-            hipLaunchKernelGGL(k_msm_merge, dim3(4096), dim3(256), 0, st, p, ps, nc, (const u32*)items, (const u32*)ibk,
+            hipLaunchKernelGGL(k_msm_merge, dim3(32, (unsigned)(nc < 512 ? nc : 512)), dim3(256), 0, st, p, ps, nc, (const u32*)items, (const u32*)ibk,
                                (const u32*)max_chunks, (G1X*)partials);
     }
     hipLaunchKernelGGL(k_msm_reduce_l1, dim3(pz_div_up(n_nodes, 128), (unsigned)nc), dim3(128), 0, st, p, m1,
