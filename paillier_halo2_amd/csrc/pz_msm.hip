@@ -24,7 +24,8 @@
 
 #ifndef MSM_CHUNK
 #define MSM_CHUNK 16u
-#endif  // max entries one lane accumulates for one bucket chunk
+#endif
+#define MSM_HEAVY 32u  // buckets with more chunks than this are folded by a whole workgroup  // max entries one lane accumulates for one bucket chunk
 
 struct MsmP {
     size_t n;          // scalars per column
@@ -167,15 +168,19 @@ __global__ __launch_bounds__(256) void k_msm_totals(u32* __restrict__ slice_hist
 
 // pass 2b: per column exclusive scans of the bucket totals (entry offsets) and of ceil(cnt/CHUNK) (item offsets)
 __global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, MsmP p, u32* __restrict__ offs,
-                                                  u32* __restrict__ items, u32* __restrict__ max_chunks) {
+                                                  u32* __restrict__ items, u32* __restrict__ heavy,
+                                                  u32* __restrict__ heavy_cnt) {
     __shared__ u32 s_cnt[256], s_itm[256];
+    __shared__ u32 s_heavy;
+    if (threadIdx.x == 0) s_heavy = 0;
+    __syncthreads();
     const size_t col = blockIdx.x;
     const u32* h = hist + col * p.B;
     u32* o = offs + col * (p.B + 1);
     u32* it = items + col * (p.B + 1);
     const unsigned per = (p.B + 255) / 256;
     const unsigned lo = threadIdx.x * per;
-    u32 c = 0, m = 0, mx = 0;
+    u32 c = 0, m = 0;
     for (unsigned k = 0; k < per; ++k) {
         unsigned b = lo + k;
         if (b < p.B) {
@@ -183,10 +188,9 @@ __global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, 
             c += v;
             const u32 ch = (v + MSM_CHUNK - 1) / MSM_CHUNK;
             m += ch;
-            mx = ch > mx ? ch : mx;
+            if (ch > MSM_HEAVY) heavy[col * p.B + atomicAdd(&s_heavy, 1u)] = b;
         }
     }
-    if (mx > 1) atomicMax(max_chunks, mx);
     s_cnt[threadIdx.x] = c;
     s_itm[threadIdx.x] = m;
     __syncthreads();
@@ -202,6 +206,7 @@ __global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, 
         }
         o[p.B] = a;
         it[p.B] = b2;
+        heavy_cnt[col] = s_heavy;
     }
     __syncthreads();
     c = s_cnt[threadIdx.x];
@@ -257,8 +262,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restri
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_msm_accumulate(const G1Affine* __restrict__ table, MsmP p,
                                                         const u32* __restrict__ offs, const u32* __restrict__ items,
-                                                        const u32* __restrict__ entries, G1X* __restrict__ partials,
-                                                        u32* __restrict__ item_bucket) {
+                                                        const u32* __restrict__ entries, G1X* __restrict__ partials) {
     const size_t col = blockIdx.y;
     const u32* it = items + col * (p.B + 1);
     const u32 total = it[p.B];
@@ -287,32 +291,59 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const G1Affine* __restri
         x_add_affine(acc, q);
     }
     x_store(partials + col * p.max_items + item, acc);
-    item_bucket[col * p.max_items + item] = b;
 }
 
-// over-full buckets own several consecutive partials: fold them pairwise in place, stride 2^pass per
-// launch (partial j of a bucket absorbs partial j + 2^pass when j is a multiple of 2^(pass+1)); after
-// ceil(log2(chunks)) passes the bucket's first partial holds its sum.  Uniform early exit once
-// 2^pass reaches the largest chunk count of the group.
-__global__ __launch_bounds__(256) void k_msm_merge(MsmP p, unsigned pass, size_t n_cols,
-                                                   const u32* __restrict__ items, const u32* __restrict__ item_bucket,
-                                                   const u32* __restrict__ max_chunks, G1X* __restrict__ partials) {
-    if ((1u << pass) >= *max_chunks) return;  // uniform: an unneeded pass costs one small launch
-    for (size_t col = blockIdx.y; col < n_cols; col += gridDim.y) {
-        const u32* it = items + col * (p.B + 1);
-        const u32 total = it[p.B];  // only the items this column really has
-        G1X* pc = partials + col * p.max_items;
-        const u32* ib = item_bucket + col * p.max_items;
-        for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
-            const u32 b = ib[item];
-            const u32 first = it[b], m = it[b + 1] - first;
-            const u32 j = item - first;
-            if ((j & ((2u << pass) - 1)) != 0 || j + (1u << pass) >= m) continue;
-            G1X a = x_load(pc + item);
-            G1X o = x_load(pc + item + (1u << pass));
-            x_add(a, o);
-            x_store(pc + item, a);
+// A bucket with more than MSM_CHUNK entries owns several consecutive partials; its sum is left in the
+// first one.  Ordinary buckets (<= MSM_HEAVY chunks): one lane each, a short serial fold -- uniform
+// columns (every bucket ~4 chunks) keep a wave's lanes on the same trip count.  Heavy buckets (short
+// scalars put half of their signed-digit carries into the single bucket "digit 1", tens of thousands of
+// entries) are listed by the scan kernel and folded by a whole workgroup each: strided serial sums,
+// then an LDS tree.
+__global__ __launch_bounds__(256) void k_msm_bucket_sum(MsmP p, const u32* __restrict__ items, G1X* __restrict__ partials) {
+    const size_t col = blockIdx.y;
+    const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= p.B) return;
+    const u32* it = items + col * (p.B + 1);
+    const u32 first = it[b], m = it[b + 1] - first;
+    if (m <= 1 || m > MSM_HEAVY) return;
+    G1X* pc = partials + col * p.max_items + first;
+    G1X acc = x_load(pc);
+    for (u32 t = 1; t < m; ++t) {
+        G1X o = x_load(pc + t);
+        x_add(acc, o);
+    }
+    x_store(pc, acc);
+}
+
+__global__ __launch_bounds__(256) void k_msm_heavy_sum(MsmP p, const u32* __restrict__ items,
+                                                       const u32* __restrict__ heavy, const u32* __restrict__ heavy_cnt,
+                                                       G1X* __restrict__ partials) {
+    __shared__ G1X s_pt[256];
+    const size_t col = blockIdx.y;
+    const u32 nh = heavy_cnt[col];
+    const u32* it = items + col * (p.B + 1);
+    for (u32 k = blockIdx.x; k < nh; k += gridDim.x) {
+        const u32 b = heavy[col * p.B + k];
+        const u32 first = it[b], m = it[b + 1] - first;
+        G1X* pc = partials + col * p.max_items + first;
+        G1X acc = x_inf();
+        for (u32 t = threadIdx.x; t < m; t += blockDim.x) {
+            G1X o = x_load(pc + t);
+            x_add(acc, o);
         }
+        x_store(&s_pt[threadIdx.x], acc);
+        __syncthreads();
+        for (unsigned off = 128; off > 0; off >>= 1) {
+            if (threadIdx.x < off) {
+                G1X a = x_load(&s_pt[threadIdx.x]);
+                G1X o = x_load(&s_pt[threadIdx.x + off]);
+                x_add(a, o);
+                x_store(&s_pt[threadIdx.x], a);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) x_store(pc, x_load(&s_pt[0]));
+        __syncthreads();
     }
 }
 
@@ -518,13 +549,12 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     p.B = 1u << (bases->c - 1);
     p.cap = n * (size_t)(win_hi - win_lo);
     p.max_items = p.B + p.cap / MSM_CHUNK;
-    void *hist, *offs, *cursor, *items, *entries, *partials, *na, *nb, *ibk, *totals;
+    void *hist, *offs, *heavy, *items, *entries, *partials, *na, *nb, *totals;
     const unsigned n_slices = pz_div_up(n, SORT_SLICE);
     PZCHK(pz_ws_get(ctx, WS_HIST, nc * (size_t)n_slices * p.B * 4, &hist));
-    PZCHK(pz_ws_get(ctx, WS_CURSOR, 64, &cursor));
+    PZCHK(pz_ws_get(ctx, WS_CURSOR, nc * (size_t)(p.B + 1) * 4, &heavy));
     PZCHK(pz_ws_get(ctx, WS_TOTALS, nc * p.B * 4, &totals));
-    PZCHK(pz_ws_get(ctx, WS_MISC, nc * p.max_items * 4, &ibk));
-    u32* max_chunks = (u32*)cursor;
+    u32* heavy_cnt = (u32*)heavy + nc * (size_t)p.B;
     PZCHK(pz_ws_get(ctx, WS_OFFS, nc * (p.B + 1) * 4, &offs));
     PZCHK(pz_ws_get(ctx, WS_ITEMS, nc * (p.B + 1) * 4, &items));
     PZCHK(pz_ws_get(ctx, WS_ENTRIES, nc * p.cap * 4 + 16, &entries));
@@ -536,28 +566,24 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     PZCHK(pz_ws_get(ctx, WS_NODES_B, nc * (size_t)(n_nodes / 2 + 1) * sizeof(MsmNode), &nb));
     hipStream_t st = ctx->stream;
     pz_timer tall(ctx, PZ_T_MSM_ALL);
-    HIPCHK(ctx, hipMemsetAsync(cursor, 0, 64, st));
     dim3 gs(n_slices, (unsigned)nc);
     hipLaunchKernelGGL(k_msm_hist, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (u32*)hist, n_slices);
     hipLaunchKernelGGL(k_msm_totals, dim3(pz_div_up(p.B, 256), (unsigned)nc), dim3(256), 0, st, (u32*)hist, n_slices, p,
                        (u32*)totals);
     hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)nc), dim3(256), 0, st, (const u32*)totals, p, (u32*)offs, (u32*)items,
-                       max_chunks);
+                       (u32*)heavy, heavy_cnt);
     hipLaunchKernelGGL(k_msm_scatter, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (const u32*)hist, n_slices,
                        (const u32*)offs, (u32*)entries);
     {
         pz_timer tacc(ctx, PZ_T_MSM_ACC);
         hipLaunchKernelGGL(k_msm_accumulate, dim3(pz_div_up(p.max_items, 256), (unsigned)nc), dim3(256), 0, st,
                            (const G1Affine*)bases->d_table, p, (const u32*)offs, (const u32*)items,
-                           (const u32*)entries, (G1X*)partials, (u32*)ibk);
+                           (const u32*)entries, (G1X*)partials);
     }
-    {
-        unsigned passes = 0;
-        while (((size_t)1 << passes) < p.cap / MSM_CHUNK + 1) ++passes;
-        for (unsigned ps = 0; ps < passes; ++ps)
-            hipLaunchKernelGGL(k_msm_merge, dim3(32, (unsigned)(nc < 512 ? nc : 512)), dim3(256), 0, st, p, ps, nc, (const u32*)items, (const u32*)ibk,
-                               (const u32*)max_chunks, (G1X*)partials);
-    }
+    hipLaunchKernelGGL(k_msm_bucket_sum, dim3(pz_div_up(p.B, 256), (unsigned)nc), dim3(256), 0, st, p, (const u32*)items,
+                       (G1X*)partials);
+    hipLaunchKernelGGL(k_msm_heavy_sum, dim3(16, (unsigned)nc), dim3(256), 0, st, p, (const u32*)items, (const u32*)heavy,
+                       (const u32*)heavy_cnt, (G1X*)partials);
     hipLaunchKernelGGL(k_msm_reduce_l1, dim3(pz_div_up(n_nodes, 128), (unsigned)nc), dim3(128), 0, st, p, m1,
                        (const u32*)items, (const G1X*)partials, (MsmNode*)na);
     MsmNode* cur = (MsmNode*)na;
@@ -600,8 +626,8 @@ extern "C" int pz_msm_g1_dev(pz_ctx* ctx, const pz_bases* bases, const uint64_t*
     const size_t cs = col_stride / 4;
     // column groups: bound the sorted-entry workspace (4 B per digit) to ~1 GiB, grid.y to 65535
     const size_t digits = n * (size_t)(win_hi - win_lo);
-    const size_t per_col = digits * 4 + (digits / MSM_CHUNK) * (sizeof(G1X) + 4) +
-                           (size_t)(1u << (bases->c - 1)) * (164 + 4 * (size_t)pz_div_up(n, SORT_SLICE));
+    const size_t per_col = digits * 4 + (digits / MSM_CHUNK) * sizeof(G1X) +
+                           (size_t)(1u << (bases->c - 1)) * (168 + 4 * (size_t)pz_div_up(n, SORT_SLICE));
     // group size: sized for 288 GB of HBM -- by default up to 48 GiB of sort / partial-sum workspace per launch
     // sequence (PZ_MSM_WS_GIB overrides), so the latency-bound tree levels are paid once per ~2000 columns
     size_t group = (pz_msm_ws_gib() << 30) / per_col;
