@@ -25,7 +25,7 @@
 #ifndef MSM_CHUNK
 #define MSM_CHUNK 16u
 #endif
-#define MSM_HEAVY 32u  // buckets with more chunks than this are folded by a whole workgroup  // max entries one lane accumulates for one bucket chunk
+#define MSM_HEAVY 16u  // buckets with more chunks than this are folded by a whole workgroup  // max entries one lane accumulates for one bucket chunk
 
 struct MsmP {
     size_t n;          // scalars per column
@@ -582,7 +582,12 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     }
     hipLaunchKernelGGL(k_msm_bucket_sum, dim3(pz_div_up(p.B, 256), (unsigned)nc), dim3(256), 0, st, p, (const u32*)items,
                        (G1X*)partials);
-    hipLaunchKernelGGL(k_msm_heavy_sum, dim3(16, (unsigned)nc), dim3(256), 0, st, p, (const u32*)items, (const u32*)heavy,
+    // heavy buckets are few per column in a column batch, but a single large MSM makes every bucket heavy:
+    // size grid.x so the launch has ~8k workgroups either way (workgroups beyond the list exit at once)
+    unsigned hx = (unsigned)(8192 / nc);
+    if (hx < 16) hx = 16;
+    if (hx > p.B) hx = p.B;
+    hipLaunchKernelGGL(k_msm_heavy_sum, dim3(hx, (unsigned)nc), dim3(256), 0, st, p, (const u32*)items, (const u32*)heavy,
                        (const u32*)heavy_cnt, (G1X*)partials);
     hipLaunchKernelGGL(k_msm_reduce_l1, dim3(pz_div_up(n_nodes, 128), (unsigned)nc), dim3(128), 0, st, p, m1,
                        (const u32*)items, (const G1X*)partials, (MsmNode*)na);
