@@ -73,6 +73,12 @@ __device__ __noinline__ G1X x_dbl(const G1X& p) {
     return r;
 }
 
+// out = 2*q if same_y else identity: the acc == q / acc == -q cases of the mixed addition
+__device__ __noinline__ void x_add_affine_special(G1X* out, const G1Affine* q, bool same_y) {
+    if (same_y) *out = x_dbl_affine(*q);
+    else *out = x_inf();
+}
+
 // acc += q (affine), q possibly negated by the caller beforehand.   (madd-2008-s)
 __device__ __forceinline__ void x_add_affine(G1X& acc, const G1Affine& q) {
     if (aff_is_inf(q)) return;
@@ -88,8 +94,13 @@ __device__ __forceinline__ void x_add_affine(G1X& acc, const G1Affine& q) {
     Fq P = fp_sub(U2, acc.x);
     Fq R = fp_sub(S2, acc.y);
     if (fp_is_zero(P)) {
-        if (fp_is_zero(R)) acc = x_dbl_affine(q);
-        else acc = x_inf();
+        // rare (acc == +-q): handled out of line on COPIES, so the hot loop's accumulator never has its
+        // address taken and stays in registers (an sret call on `acc` itself put it in scratch: 256 B of
+        // scratch traffic per addition)
+        G1Affine qc = q;
+        G1X t;
+        x_add_affine_special(&t, &qc, fp_is_zero(R));
+        acc = t;
         return;
     }
     Fq PP = fp_sqr(P);
