@@ -169,10 +169,13 @@ __global__ __launch_bounds__(256) void k_msm_totals(u32* __restrict__ slice_hist
 // pass 2b: per column exclusive scans of the bucket totals (entry offsets) and of ceil(cnt/CHUNK) (item offsets)
 __global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, MsmP p, u32* __restrict__ offs,
                                                   u32* __restrict__ items, u32* __restrict__ heavy,
-                                                  u32* __restrict__ heavy_cnt) {
+                                                  u32* __restrict__ heavy_cnt, u32* __restrict__ fold_order,
+                                                  u32* __restrict__ fold_cnt) {
     __shared__ u32 s_cnt[256], s_itm[256];
     __shared__ u32 s_heavy;
+    __shared__ u32 s_bin[MSM_HEAVY + 1], s_base[MSM_HEAVY + 1];
     if (threadIdx.x == 0) s_heavy = 0;
+    if (threadIdx.x <= MSM_HEAVY) s_bin[threadIdx.x] = 0;
     __syncthreads();
     const size_t col = blockIdx.x;
     const u32* h = hist + col * p.B;
@@ -189,6 +192,7 @@ __global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, 
             const u32 ch = (v + MSM_CHUNK - 1) / MSM_CHUNK;
             m += ch;
             if (ch > MSM_HEAVY) heavy[col * p.B + atomicAdd(&s_heavy, 1u)] = b;
+            else if (ch > 1) atomicAdd(&s_bin[ch], 1u);
         }
     }
     s_cnt[threadIdx.x] = c;
@@ -207,6 +211,15 @@ __global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, 
         o[p.B] = a;
         it[p.B] = b2;
         heavy_cnt[col] = s_heavy;
+        // buckets with 2..MSM_HEAVY chunks, ordered by chunk count (largest first): the fold kernel's lanes
+        // then run equal trip counts within a wave
+        u32 run = 0;
+        for (int m2 = (int)MSM_HEAVY; m2 >= 2; --m2) {
+            s_base[m2] = run;
+            run += s_bin[m2];
+            s_bin[m2] = 0;
+        }
+        fold_cnt[col] = run;
     }
     __syncthreads();
     c = s_cnt[threadIdx.x];
@@ -218,7 +231,9 @@ __global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, 
             o[b] = c;
             it[b] = m;
             c += v;
-            m += (v + MSM_CHUNK - 1) / MSM_CHUNK;
+            const u32 ch = (v + MSM_CHUNK - 1) / MSM_CHUNK;
+            m += ch;
+            if (ch > 1 && ch <= MSM_HEAVY) fold_order[col * p.B + s_base[ch] + atomicAdd(&s_bin[ch], 1u)] = b;
         }
     }
 }
@@ -299,13 +314,15 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const G1Affine* __restri
 // scalars put half of their signed-digit carries into the single bucket "digit 1", tens of thousands of
 // entries) are listed by the scan kernel and folded by a whole workgroup each: strided serial sums,
 // then an LDS tree.
-__global__ __launch_bounds__(256) void k_msm_bucket_sum(MsmP p, const u32* __restrict__ items, G1X* __restrict__ partials) {
+__global__ __launch_bounds__(256) void k_msm_bucket_sum(MsmP p, const u32* __restrict__ items,
+                                                        const u32* __restrict__ fold_order,
+                                                        const u32* __restrict__ fold_cnt, G1X* __restrict__ partials) {
     const size_t col = blockIdx.y;
-    const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= p.B) return;
+    const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= fold_cnt[col]) return;
+    const unsigned b = fold_order[col * p.B + r];
     const u32* it = items + col * (p.B + 1);
     const u32 first = it[b], m = it[b + 1] - first;
-    if (m <= 1 || m > MSM_HEAVY) return;
     G1X* pc = partials + col * p.max_items + first;
     G1X acc = x_load(pc);
     for (u32 t = 1; t < m; ++t) {
@@ -549,12 +566,14 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     p.B = 1u << (bases->c - 1);
     p.cap = n * (size_t)(win_hi - win_lo);
     p.max_items = p.B + p.cap / MSM_CHUNK;
-    void *hist, *offs, *heavy, *items, *entries, *partials, *na, *nb, *totals;
+    void *hist, *offs, *heavy, *items, *entries, *partials, *na, *nb, *totals, *fold;
     const unsigned n_slices = pz_div_up(n, SORT_SLICE);
     PZCHK(pz_ws_get(ctx, WS_HIST, nc * (size_t)n_slices * p.B * 4, &hist));
     PZCHK(pz_ws_get(ctx, WS_CURSOR, nc * (size_t)(p.B + 1) * 4, &heavy));
     PZCHK(pz_ws_get(ctx, WS_TOTALS, nc * p.B * 4, &totals));
     u32* heavy_cnt = (u32*)heavy + nc * (size_t)p.B;
+    PZCHK(pz_ws_get(ctx, WS_MISC, nc * (size_t)(p.B + 1) * 4, &fold));
+    u32* fold_cnt = (u32*)fold + nc * (size_t)p.B;
     PZCHK(pz_ws_get(ctx, WS_OFFS, nc * (p.B + 1) * 4, &offs));
     PZCHK(pz_ws_get(ctx, WS_ITEMS, nc * (p.B + 1) * 4, &items));
     PZCHK(pz_ws_get(ctx, WS_ENTRIES, nc * p.cap * 4 + 16, &entries));
@@ -571,7 +590,7 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     hipLaunchKernelGGL(k_msm_totals, dim3(pz_div_up(p.B, 256), (unsigned)nc), dim3(256), 0, st, (u32*)hist, n_slices, p,
                        (u32*)totals);
     hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)nc), dim3(256), 0, st, (const u32*)totals, p, (u32*)offs, (u32*)items,
-                       (u32*)heavy, heavy_cnt);
+                       (u32*)heavy, heavy_cnt, (u32*)fold, fold_cnt);
     hipLaunchKernelGGL(k_msm_scatter, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (const u32*)hist, n_slices,
                        (const u32*)offs, (u32*)entries);
     {
@@ -581,7 +600,7 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
                            (const u32*)entries, (G1X*)partials);
     }
     hipLaunchKernelGGL(k_msm_bucket_sum, dim3(pz_div_up(p.B, 256), (unsigned)nc), dim3(256), 0, st, p, (const u32*)items,
-                       (G1X*)partials);
+                       (const u32*)fold, (const u32*)fold_cnt, (G1X*)partials);
     // heavy buckets are few per column in a column batch, but a single large MSM makes every bucket heavy:
     // size grid.x so the launch has ~8k workgroups either way (workgroups beyond the list exit at once)
     unsigned hx = (unsigned)(8192 / nc);
@@ -632,7 +651,7 @@ extern "C" int pz_msm_g1_dev(pz_ctx* ctx, const pz_bases* bases, const uint64_t*
     // column groups: bound the sorted-entry workspace (4 B per digit) to ~1 GiB, grid.y to 65535
     const size_t digits = n * (size_t)(win_hi - win_lo);
     const size_t per_col = digits * 4 + (digits / MSM_CHUNK) * sizeof(G1X) +
-                           (size_t)(1u << (bases->c - 1)) * (168 + 4 * (size_t)pz_div_up(n, SORT_SLICE));
+                           (size_t)(1u << (bases->c - 1)) * (172 + 4 * (size_t)pz_div_up(n, SORT_SLICE));
     // group size: sized for 288 GB of HBM -- by default up to 48 GiB of sort / partial-sum workspace per launch
     // sequence (PZ_MSM_WS_GIB overrides), so the latency-bound tree levels are paid once per ~2000 columns
     size_t group = (pz_msm_ws_gib() << 30) / per_col;
