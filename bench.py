@@ -230,7 +230,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)  # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     log = (lambda s: print("[bench] " + s, file=sys.stderr, flush=True)) if rank == 0 else (lambda s: None)
@@ -240,17 +241,19 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     if args.workload == "msm22":
         from paillier_halo2_amd import dist as pzd
 
-        res = pzd.bench_sharded_msm(eng, torch, dist if world > 1 else None, rank, world, args.log_n, args.steps,
+        res = pzd.bench_sharded_msm(eng, torch, dist if use_dist else None, rank, world, args.log_n, args.steps,
                                     args.warmup, barrier, log)
         if rank == 0:
             print(json.dumps(res))
+        if use_dist:
+            dist.destroy_process_group()
         return
 
     t0 = time.time()
@@ -273,11 +276,11 @@ def main():
     exp_ms, exp_n = eng.timing_get(E.T_EXPAND)
     eng.timing_enable(False)
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
     sh, cnt = wl.shape, wl.counts
@@ -296,7 +299,8 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32 limbs (254-bit modular integers), u64 limbs (4096-bit integers)", "data": "synthetic",
         "config": {
-            "workload": "c2: 2048-bit n encrypt, KZG prover hot path at k=17 (K3 trace + K1 commitments + K2 NTTs), 1 proof per GPU per step",
+            "workload": "%s: %d-bit n encrypt, KZG prover hot path at k=%d (K3 trace + K4 cell expansion + K1 commitments + K2 NTTs), 1 proof per GPU per step"
+                        % ("c2" if (args.enc_bits, args.k) == (2048, 17) else "c5-shape" if (args.enc_bits, args.k) == (3072, 19) else "custom", args.enc_bits, args.k),
             "enc_bits": args.enc_bits, "k": args.k, "lookup_bits": sh.lookup_bits, "limb_bits": 64,
             "mul_mod_steps": wl.n_steps, "advice_cols": sh.advice_cols, "lookup_cols": sh.lookup_cols,
             "perm_cols": sh.perm_cols, "advice_cols_committed": wl.adv_cols, "lookup_cols_committed": wl.lk_cols,
@@ -320,7 +324,7 @@ def main():
         except Exception as ex:  # the checker must never take the bench line down
             out["cpu_baseline"] = {"value": None, "error": repr(ex)}
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

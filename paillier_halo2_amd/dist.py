@@ -31,7 +31,7 @@ def sharded_msm(torch, dist, rank: int, world: int, n_windows: int,
     Returns the full MSM as a Jacobian point, identical on every rank."""
     lo, hi = window_range(n_windows, rank, world)
     part = partial_fn(lo, hi).reshape(12).contiguous()
-    if world == 1 or dist is None:
+    if dist is None:
         return fold_fn(part.cpu().numpy().astype(np.uint64).reshape(1, 12))
     parts = [torch.empty_like(part) for _ in range(world)]
     dist.all_gather(parts, part)
@@ -85,7 +85,7 @@ def bench_sharded_msm(eng, torch, dist, rank, world, log_n, steps, warmup, barri
     acc_ms, acc_n = eng.timing_get(0)
     eng.timing_enable(False)
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if dist is not None and world > 1:
+    if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     aff = eng.g1_normalize(res)[0]
