@@ -74,9 +74,10 @@ __device__ __noinline__ G1X x_dbl(const G1X& p) {
 }
 
 // out = 2*q if same_y else identity: the acc == q / acc == -q cases of the mixed addition
-__device__ __noinline__ void x_add_affine_special(G1X* out, const G1Affine* q, bool same_y) {
-    if (same_y) *out = x_dbl_affine(*q);
-    else *out = x_inf();
+// (arguments and result by VALUE: they travel in VGPRs, nothing in the caller's hot loop is address-taken)
+__device__ __noinline__ G1X x_add_affine_special(G1Affine q, bool same_y) {
+    if (same_y) return x_dbl_affine(q);
+    return x_inf();
 }
 
 // acc += q (affine), q possibly negated by the caller beforehand.   (madd-2008-s)
@@ -94,13 +95,10 @@ __device__ __forceinline__ void x_add_affine(G1X& acc, const G1Affine& q) {
     Fq P = fp_sub(U2, acc.x);
     Fq R = fp_sub(S2, acc.y);
     if (fp_is_zero(P)) {
-        // rare (acc == +-q): handled out of line on COPIES, so the hot loop's accumulator never has its
-        // address taken and stays in registers (an sret call on `acc` itself put it in scratch: 256 B of
-        // scratch traffic per addition)
-        G1Affine qc = q;
-        G1X t;
-        x_add_affine_special(&t, &qc, fp_is_zero(R));
-        acc = t;
+        // rare (acc == +-q): handled out of line with by-value arguments, so neither the accumulator nor the
+        // loaded point ever has its address taken in the hot loop (an sret call on `acc` put it in scratch:
+        // PMC showed 32 GB of scratch write-back per accumulate launch)
+        acc = x_add_affine_special(q, fp_is_zero(R));
         return;
     }
     Fq PP = fp_sqr(P);
@@ -114,8 +112,14 @@ __device__ __forceinline__ void x_add_affine(G1X& acc, const G1Affine& q) {
     acc.zzz = fp_mul(acc.zzz, PPP);
 }
 
+// rare case of the full addition (acc == +-q), by value for the same reason as above
+__device__ __noinline__ G1X x_add_special(G1X acc, bool same_y) {
+    if (same_y) return x_dbl(acc);
+    return x_inf();
+}
+
 // acc += q   (add-2008-s)
-__device__ __noinline__ void x_add(G1X& acc, const G1X& q) {
+__device__ __forceinline__ void x_add(G1X& acc, const G1X& q) {
     if (x_is_inf(q)) return;
     if (x_is_inf(acc)) {
         acc = q;
@@ -128,8 +132,7 @@ __device__ __noinline__ void x_add(G1X& acc, const G1X& q) {
     Fq P = fp_sub(U2, U1);
     Fq R = fp_sub(S2, S1);
     if (fp_is_zero(P)) {
-        if (fp_is_zero(R)) acc = x_dbl(acc);
-        else acc = x_inf();
+        acc = x_add_special(acc, fp_is_zero(R));
         return;
     }
     Fq PP = fp_sqr(P);
