@@ -115,6 +115,14 @@ int pz_ntt_fr_batch(pz_ctx* ctx, uint64_t* const* cols, size_t n_cols, const uin
 int pz_ntt_fr_dev(pz_ctx* ctx, uint64_t* d_a, size_t n_cols, size_t col_stride, const uint64_t omega[4],
                   uint32_t log_n, const uint64_t* pre_coset_g, const uint64_t* post_scale);
 
+/* coeff_to_extended in one call (n = 2^log_n coefficients per column -> 2^log_e * n evaluations on the coset):
+ *   d_ext[col][2^log_e * q + r] = sum_i d_coeff[col][i] * scale * coset_gens[r]^i * omega_n^(i q)
+ * coset_gens (host, 2^log_e x 4 limbs, Montgomery) = g * omega_ext^r; omega_n = omega_ext^(2^log_e) generates the
+ * 2^log_n domain; scale may be NULL (1) -- pass the 1/n ifft divisor here when d_coeff still carries it.
+ * log_n <= 18, log_e <= 3.  Equals zero-extending to 2^(log_n+log_e), distribute_powers(g) and best_fft(omega_ext). */
+int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t n_cols, size_t in_stride, uint64_t* d_ext,
+                         size_t out_stride, uint32_t log_n, uint32_t log_e, const uint64_t omega_n[4],
+                         const uint64_t* coset_gens, const uint64_t* scale);
 /* in-place representation change of n Fr elements on the device: to_mont != 0: canonical little-endian
  * integers (must be < r) -> Montgomery form (Fr::from_raw); else Montgomery -> canonical (to_repr). */
 int pz_fr_convert_dev(pz_ctx* ctx, uint64_t* d_a, size_t n, int to_mont);

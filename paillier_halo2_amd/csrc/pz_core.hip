@@ -8,11 +8,11 @@
 // ------------------------------------------------------------------------------------------------
 // table[i] = base^i (Montgomery).  Thread t fills entries [t*CH, (t+1)*CH): start by
 // square-and-multiply over the bits of t*CH, then CH-1 successive products.
-__global__ void k_pow_table(Fr base, Fr* table, size_t n, unsigned ch) {
+__global__ void k_pow_table(Fr base, Fr init, Fr* table, size_t n, unsigned ch) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t lo = t * ch;
     if (lo >= n) return;
-    Fr acc = fp_one<FrTag>();
+    Fr acc = init;
     Fr sq = base;
     size_t e = lo;
     while (e) {
@@ -109,6 +109,8 @@ extern "C" int pz_free(pz_ctx* ctx) {
         if (w.d) (void)hipFree(w.d);
     for (auto& t : ctx->pow_tables)
         if (t.d) (void)hipFree(t.d);
+    for (auto& t : ctx->ext_tables)
+        if (t.d) (void)hipFree(t.d);
     for (auto& v : ctx->ev)
         for (auto& p : v) {
             (void)hipEventDestroy(p.a);
@@ -148,21 +150,26 @@ int pz_ws_get(pz_ctx* ctx, int slot, size_t bytes, void** out) {
     return PZ_OK;
 }
 
-int pz_get_pow_table(pz_ctx* ctx, const uint64_t base[4], size_t n, void** d_out) {
+int pz_get_pow_table(pz_ctx* ctx, const uint64_t base[4], size_t n, void** d_out, const uint64_t* init) {
+    // Montgomery one (R mod r): the default first entry
+    static const uint64_t ONE[4] = {0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL};
+    if (!init) init = ONE;
     for (auto& t : ctx->pow_tables)
-        if (t.n >= n && memcmp(t.base, base, 32) == 0) {
+        if (t.n >= n && memcmp(t.base, base, 32) == 0 && memcmp(t.init, init, 32) == 0) {
             *d_out = t.d;
             return PZ_OK;
         }
     pz_pow_table t;
     memcpy(t.base, base, 32);
+    memcpy(t.init, init, 32);
     t.n = n;
     HIPCHK(ctx, hipMalloc(&t.d, n * 32));
-    Fr b;
+    Fr b, i0;
     memcpy(b.v, base, 32);
+    memcpy(i0.v, init, 32);
     const unsigned ch = 64;
     size_t threads = (n + ch - 1) / ch;
-    hipLaunchKernelGGL(k_pow_table, dim3(pz_div_up(threads, 128)), dim3(128), 0, ctx->stream, b, (Fr*)t.d, n, ch);
+    hipLaunchKernelGGL(k_pow_table, dim3(pz_div_up(threads, 128)), dim3(128), 0, ctx->stream, b, i0, (Fr*)t.d, n, ch);
     HIPCHK(ctx, hipGetLastError());
     ctx->pow_tables.push_back(t);
     *d_out = t.d;

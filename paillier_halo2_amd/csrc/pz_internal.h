@@ -12,10 +12,16 @@
 
 enum { PZ_T_MSM_ACC = 0, PZ_T_NTT = 1, PZ_T_TRACE = 2, PZ_T_EXPAND = 3, PZ_T_MSM_ALL = 4, PZ_T_COUNT = 5 };
 
-struct pz_pow_table {   // cached table base^i, i < n  (twiddles omega^i, coset powers g^i)
+struct pz_pow_table {   // cached table init * base^i, i < n  (twiddles omega^i, coset powers s*g^i)
     uint64_t base[4];
+    uint64_t init[4];
     size_t n;
     void* d;            // n x 32 B
+};
+
+struct pz_ext_table {   // packed [2^e][n] pre-scale tables of pz_ntt_fr_extend_dev, keyed by its parameters
+    std::vector<uint64_t> key;
+    void* d;
 };
 
 struct pz_wsbuf {
@@ -37,6 +43,7 @@ struct pz_ctx {
     char hip_err[256] = {0};
     pz_wsbuf ws[WS_COUNT];
     std::vector<pz_pow_table> pow_tables;
+    std::vector<pz_ext_table> ext_tables;
     bool timing = false;
     std::vector<pz_event_pair> ev[PZ_T_COUNT];
     size_t ev_used[PZ_T_COUNT] = {0};
@@ -72,7 +79,7 @@ static inline int pz_hip_fail(pz_ctx* ctx, hipError_t e, const char* what) {
 // grow-only workspace slot; contents are NOT preserved across growth
 int pz_ws_get(pz_ctx* ctx, int slot, size_t bytes, void** out);
 // cached base^i table (device, Fr Montgomery)
-int pz_get_pow_table(pz_ctx* ctx, const uint64_t base[4], size_t n, void** d_out);
+int pz_get_pow_table(pz_ctx* ctx, const uint64_t base[4], size_t n, void** d_out, const uint64_t* init = nullptr);
 
 // timing scopes: record an event pair around a kernel-class region on ctx->stream
 struct pz_timer {

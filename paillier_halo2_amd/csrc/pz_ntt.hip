@@ -12,6 +12,9 @@
 //                         k1 + n1*k2 + n1*n2*k so the result lands in natural order; a block
 //                         owns T consecutive k1 for one k2, so stores are T*32-byte runs.
 // Algorithmic HBM bytes: 64 B per element (one 32 B read + one 32 B write), see DESIGN.md.
+#include <utility>
+#include <vector>
+
 #include "fp.cuh"
 #include "pz_internal.h"
 
@@ -117,6 +120,36 @@ __global__ __launch_bounds__(256) void k_ntt_final(const Fr* in, Fr* out, size_t
     }
 }
 
+// final pass of the coset-EXTENDED transform (coeff_to_extended): the 2^e * n point NTT of a zero-extended
+// n-coefficient polynomial is 2^e independent n-point NTTs of a[i] * (g * w_ext^r)^i, r < 2^e, interleaved
+// as out[2^e * q + r].  The strided pass has already run per r (inputs at in + r * in_r_stride); this
+// block finishes T rows for ALL r at once so every store is a full T * 2^e * 32-byte run.
+__global__ __launch_bounds__(256) void k_ntt_final_ext(const Fr* in, Fr* out, size_t in_stride, size_t in_r_stride,
+                                                       size_t out_stride, NttPass p, unsigned log_e,
+                                                       const Fr* __restrict__ tw, const Fr* __restrict__ pre,
+                                                       size_t pre_r_stride) {
+    Fr* sm = reinterpret_cast<Fr*>(pz_smem);
+    const unsigned R = 1u << p.logR, T = p.T, E = 1u << log_e;
+    const size_t tiles = p.n1 / T;
+    const size_t k2 = blockIdx.x / tiles, k1_0 = (blockIdx.x % tiles) * T;
+    const Fr* src = in + (size_t)blockIdx.y * in_stride;
+    Fr* dst = out + (size_t)blockIdx.y * out_stride;
+    for (unsigned idx = threadIdx.x; idx < R * T * E; idx += blockDim.x) {
+        const unsigned j = idx % R, rr = (idx / R) % T, r = idx / (R * T);
+        const size_t g = ((k1_0 + rr) * p.n2 + k2) * R + j;
+        Fr x = fp_load<FrTag>(src + (size_t)r * in_r_stride + g);
+        if (pre) x = fp_mul(x, fp_load<FrTag>(pre + (size_t)r * pre_r_stride + g));
+        sm[((size_t)r * T + rr) * R + bitrev32(j, p.logR)] = x;
+    }
+    __syncthreads();
+    lds_dit(sm, p.logR, T * E, 1, R, false, tw, p.n);
+    for (unsigned idx = threadIdx.x; idx < R * T * E; idx += blockDim.x) {
+        const unsigned r = idx % E, rr = (idx / E) % T, k = idx / (E * T);
+        Fr x = sm[((size_t)r * T + rr) * R + k];
+        fp_store(dst + (((k1_0 + rr) + p.n1 * k2 + p.hi * (size_t)k) << log_e) + r, x);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 static unsigned pick_tile(size_t extent, unsigned logR) {
     // LDS budget 64 KiB per block -> R*T*32 <= 65536; prefer 128-byte runs (T = 4) or more
@@ -212,6 +245,84 @@ extern "C" int pz_ntt_fr_dev(pz_ctx* ctx, uint64_t* d_a, size_t n_cols, size_t c
             pc.logR = lg[2]; pc.lo = 1; pc.hi = n1 * n2; pc.n = n; pc.n1 = n1; pc.n2 = n2; pc.T = pick_tile(n1, lg[2]);
             PZCHK(launch_final(ctx, tmp, ac, n, cs, nc, pc, tw, nullptr, post_scale));
         }
+    }
+    return PZ_OK;
+}
+
+// coeff_to_extended in one call: d_ext[col][2^e * q + r] = sum_i d_coeff[col][i] * scale * (gens[r])^i * omega_n^(i q)
+// with gens[r] = g * omega_ext^r supplied by the caller (2^log_e x 4 limbs, host), omega_n = omega_ext^(2^log_e).
+// Saves the zero-fill, the copy and two butterfly layers of the generic zero-extended transform.
+extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t n_cols, size_t in_stride, uint64_t* d_ext,
+                                    size_t out_stride, uint32_t log_n, uint32_t log_e, const uint64_t omega_n[4],
+                                    const uint64_t* coset_gens, const uint64_t* scale) {
+    if (!ctx || !omega_n || !coset_gens || (n_cols && (!d_coeff || !d_ext)) || log_e > 3) return PZ_ERR_INVALID;
+    if (log_n > 18) return PZ_ERR_UNSUPPORTED;  // two LDS passes; larger n: zero-extend and use pz_ntt_fr_dev
+    if (n_cols == 0) return PZ_OK;
+    const size_t n = (size_t)1 << log_n, E = (size_t)1 << log_e;
+    if (in_stride % 4 || in_stride < 4 * n || out_stride % 4 || out_stride < 4 * n * E) return PZ_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t is = in_stride / 4, os = out_stride / 4;
+    void* twv = nullptr;
+    PZCHK(pz_get_pow_table(ctx, omega_n, n, &twv));
+    const Fr* tw = (const Fr*)twv;
+    // E pre-scale tables scale * gens[r]^i, packed [E][n], cached in the context
+    void* prev = nullptr;
+    {
+        std::vector<uint64_t> key(coset_gens, coset_gens + 4 * E);
+        key.push_back(log_n);
+        if (scale) key.insert(key.end(), scale, scale + 4);
+        for (auto& c : ctx->ext_tables)
+            if (c.key == key) prev = c.d;
+        if (!prev) {
+            HIPCHK(ctx, hipMalloc(&prev, E * n * 32));
+            for (size_t r = 0; r < E; ++r) {
+                void* t;
+                PZCHK(pz_get_pow_table(ctx, coset_gens + 4 * r, n, &t, scale));
+                HIPCHK(ctx, hipMemcpyAsync((char*)prev + r * n * 32, t, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+            ctx->ext_tables.push_back(pz_ext_table{key, prev});
+        }
+    }
+    const Fr* pre = (const Fr*)prev;
+    const Fr* cin = (const Fr*)d_coeff;
+    Fr* eout = (Fr*)d_ext;
+    const unsigned npass = log_n <= 9 ? 1 : 2;
+    size_t group = n_cols;
+    const size_t max_ws = (size_t)2 << 30;
+    if (npass > 1 && group * n * E * 32 > max_ws) group = max_ws / (n * E * 32) ? max_ws / (n * E * 32) : 1;
+    if (group > 32768) group = 32768;
+    Fr* tmp = nullptr;
+    if (npass > 1) {
+        void* t;
+        PZCHK(pz_ws_get(ctx, WS_NTT_TMP, group * n * E * 32, &t));
+        tmp = (Fr*)t;
+    }
+    pz_timer tm(ctx, PZ_T_NTT);
+    for (size_t c0 = 0; c0 < n_cols; c0 += group) {
+        const size_t nc = n_cols - c0 < group ? n_cols - c0 : group;
+        if (npass == 1) {
+            NttPass p{};
+            p.logR = log_n; p.lo = 1; p.hi = 1; p.n = n; p.T = 1; p.n1 = 1; p.n2 = 1;
+            const size_t lds = ((size_t)32 << p.logR) * p.T * E;
+            hipLaunchKernelGGL(k_ntt_final_ext, dim3(1, (unsigned)nc), dim3(256), lds, ctx->stream, cin + c0 * is,
+                               eout + c0 * os, is, (size_t)0, os, p, log_e, tw, pre, n);
+        } else {
+            unsigned lg0 = (log_n + 1) / 2, lg1 = log_n - lg0;
+            const size_t n1 = (size_t)1 << lg0, n2 = (size_t)1 << lg1;
+            NttPass pa{};
+            pa.logR = lg0; pa.lo = n2; pa.hi = 1; pa.tw_mul = 1; pa.n = n; pa.T = pick_tile(n2, lg0);
+            for (size_t r = 0; r < E; ++r)  // tmp layout [r][col][n]
+                PZCHK(launch_strided(ctx, cin + c0 * is, tmp + r * nc * n, is, n, nc, pa, tw, pre + r * n));
+            NttPass pc{};
+            pc.logR = lg1; pc.lo = 1; pc.hi = n1; pc.n = n; pc.n1 = n1; pc.n2 = 1;
+            unsigned T = 8;
+            while (T > 1 && (((size_t)32 << lg1) * T * E > 65536 || T > n1)) T >>= 1;
+            pc.T = T;
+            const size_t lds = ((size_t)32 << lg1) * T * E;
+            hipLaunchKernelGGL(k_ntt_final_ext, dim3((unsigned)(n1 / T), (unsigned)nc), dim3(256), lds, ctx->stream, tmp,
+                               eout + c0 * os, n, nc * n, os, pc, log_e, tw, (const Fr*)nullptr, (size_t)0);
+        }
+        HIPCHK(ctx, hipGetLastError());
     }
     return PZ_OK;
 }

@@ -172,6 +172,16 @@ class Engine:
                                        _ptr(g) if g is not None else VP(), _ptr(s) if s is not None else VP()),
                   "pz_ntt_fr_dev")
 
+    def ntt_extend_dev(self, d_coeff: int, n_cols: int, in_stride_u64: int, d_ext: int, out_stride_u64: int, log_n: int,
+                       log_e: int, omega_n, coset_gens, scale=None):
+        w = _np(omega_n).reshape(4)
+        g = _np(coset_gens).reshape(-1)
+        assert g.size == 4 << log_e
+        sc = _np(scale).reshape(4) if scale is not None else None
+        self._chk(self.L.pz_ntt_fr_extend_dev(self.ctx, VP(d_coeff), n_cols, in_stride_u64, VP(d_ext), out_stride_u64,
+                                              log_n, log_e, _ptr(w), _ptr(g), _ptr(sc) if sc is not None else VP()),
+                  "pz_ntt_fr_extend_dev")
+
     def fr_convert_dev(self, d_a: int, n: int, to_mont: bool = True):
         self._chk(self.L.pz_fr_convert_dev(self.ctx, VP(d_a), n, int(to_mont)), "pz_fr_convert_dev")
 

@@ -397,3 +397,33 @@ def test_witness_expand_on_real_trace(eng, cref):
         a, b, q, rr = (cref.limbs_to_int(steps[0, k, j]) for j in range(4))
         want_adv, _ = P.expand_mul_mod_cells(a, b, q, rr, nn * nn, L, lb)
         assert cref.fr_mont_to_ints(adv[k]) == want_adv, k
+
+
+@pytest.mark.parametrize("log_n,log_e", [(3, 2), (9, 2), (10, 2), (13, 1), (17, 2)])
+def test_ntt_extend_vs_oracle(eng, cref, log_n, log_e):
+    """coeff_to_extended in one call == zero-extend, distribute_powers(g), best_fft(omega_ext), with the ifft
+    divisor folded in as `scale`"""
+    import torch
+
+    rng = np.random.default_rng(200 + log_n)
+    n, E = 1 << log_n, 1 << log_e
+    ncols = 3
+    coeff = rng.integers(0, 1 << 62, size=(ncols, n, 4), dtype=np.uint64)
+    coeff[:, :, 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
+    w_ext = P.fr_omega(log_n + log_e)
+    w_n = pow(w_ext, E, P.FR_R)
+    g = 7
+    scale = pow(n, -1, P.FR_R)
+    gens = np.stack([cref.fr_ints_to_mont([g * pow(w_ext, r, P.FR_R) % P.FR_R])[0] for r in range(E)])
+    d_c = torch.from_numpy(coeff.astype(np.int64)).cuda()
+    d_e = torch.zeros((ncols, n * E, 4), dtype=torch.int64, device="cuda")
+    eng.ntt_extend_dev(d_c.data_ptr(), ncols, 4 * n, d_e.data_ptr(), 4 * n * E, log_n, log_e,
+                       cref.fr_ints_to_mont([w_n])[0], gens, cref.fr_ints_to_mont([scale])[0])
+    eng.sync()
+    got = d_e.cpu().numpy().astype(np.uint64)
+    for j in range(ncols):
+        ext = np.zeros((n * E, 4), dtype=np.uint64)
+        ext[:n] = cref.fr_scale(coeff[j], cref.fr_ints_to_mont([scale])[0])
+        want = cref.ntt_fr(cref.fr_distribute_powers(ext, cref.fr_ints_to_mont([g])[0]), cref.fr_ints_to_mont([w_ext])[0],
+                           log_n + log_e)
+        assert np.array_equal(got[j], want), (log_n, log_e, j)
