@@ -105,13 +105,15 @@ class ProofWorkload:
         self.d_out = torch.zeros((pool, 12), dtype=torch.int64, device=dev)
         # NTT buffers
         self.ext_n = 1 << sh.ext_k
-        self.ntt_batch = min(pool, 16)
+        self.ntt_batch = min(pool, 64)
         self.d_coeff = torch.zeros((self.ntt_batch, self.n, 4), dtype=torch.int64, device=dev)
         self.d_ext = torch.zeros((self.ntt_batch, self.ext_n, 4), dtype=torch.int64, device=dev)
         self.omega_inv = consts.fr_mont_limbs(pow(consts.fr_omega(k), -1, consts.FR_R))
         self.n_inv = consts.fr_mont_limbs(pow(self.n, -1, consts.FR_R))
-        self.omega_ext = consts.fr_mont_limbs(consts.fr_omega(sh.ext_k))
-        self.coset_g = consts.fr_mont_limbs(consts.FR_GENERATOR)
+        w_ext = consts.fr_omega(sh.ext_k)
+        self.omega_n = consts.fr_mont_limbs(consts.fr_omega(k))
+        self.coset_gens = np.stack([consts.fr_mont_limbs(consts.FR_GENERATOR * pow(w_ext, r, consts.FR_R) % consts.FR_R)
+                                    for r in range(1 << (sh.ext_k - k))])
         torch.cuda.synchronize()
 
     # ---- synthetic column values (generated on the GPU; converted to Montgomery by the library)
@@ -143,16 +145,16 @@ class ProofWorkload:
             nc = min(self.pool, self.counts["msm_full"] - done)
             eng.msm_dev(self.bases, self.col_f.data_ptr(), nc, n, 4 * n, self.d_out.data_ptr())
             done += nc
-        # K2: Lagrange -> coeff (iNTT 2^k, 1/n fused) -> extended coset (zero-extend, g^i fused, NTT 2^(k+2))
+        # K2: Lagrange -> coeff (iNTT 2^k) -> extended coset: 4 interleaved coset NTTs with the 1/n divisor folded into
+        # their pre-scale tables (pz_ntt_fr_extend_dev == zero-extend, distribute_powers, best_fft(omega_ext))
         done = 0
         nb = self.ntt_batch
         while done < self.counts["polys"]:
             nc = min(nb, self.counts["polys"] - done)
             self.d_coeff[:nc].copy_(self.col_f[:nc])
-            eng.ntt_dev(self.d_coeff.data_ptr(), nc, 4 * n, self.omega_inv, k, None, self.n_inv)
-            self.d_ext[:nc].zero_()
-            self.d_ext[:nc, :n].copy_(self.d_coeff[:nc])
-            eng.ntt_dev(self.d_ext.data_ptr(), nc, 4 * self.ext_n, self.omega_ext, sh.ext_k, self.coset_g, None)
+            eng.ntt_dev(self.d_coeff.data_ptr(), nc, 4 * n, self.omega_inv, k, None, None)
+            eng.ntt_extend_dev(self.d_coeff.data_ptr(), nc, 4 * n, self.d_ext.data_ptr(), 4 * self.ext_n, k, sh.ext_k - k,
+                               self.omega_n, self.coset_gens, self.n_inv)
             done += nc
 
 

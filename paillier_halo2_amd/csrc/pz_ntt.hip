@@ -151,10 +151,13 @@ __global__ __launch_bounds__(256) void k_ntt_final_ext(const Fr* in, Fr* out, si
 }
 
 // ------------------------------------------------------------------------------------------------
+#ifndef PZ_NTT_LDS
+#define PZ_NTT_LDS 32768
+#endif
 static unsigned pick_tile(size_t extent, unsigned logR) {
     // LDS budget 64 KiB per block -> R*T*32 <= 65536; prefer 128-byte runs (T = 4) or more
     unsigned T = 8;
-    while (T > 1 && (((size_t)32 << logR) * T > 65536 || T > extent)) T >>= 1;
+    while (T > 1 && (((size_t)32 << logR) * T > PZ_NTT_LDS || T > extent)) T >>= 1;
     return T;
 }
 
@@ -315,8 +318,10 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
                 PZCHK(launch_strided(ctx, cin + c0 * is, tmp + r * nc * n, is, n, nc, pa, tw, pre + r * n));
             NttPass pc{};
             pc.logR = lg1; pc.lo = 1; pc.hi = n1; pc.n = n; pc.n1 = n1; pc.n2 = 1;
+            // 32 KiB of LDS per block (4 blocks per CU): with 2^e = 4 interleaved outputs a single row already
+            // stores full 128-byte lines
             unsigned T = 8;
-            while (T > 1 && (((size_t)32 << lg1) * T * E > 65536 || T > n1)) T >>= 1;
+            while (T > 1 && (((size_t)32 << lg1) * T * E > 32768 || T > n1)) T >>= 1;
             pc.T = T;
             const size_t lds = ((size_t)32 << lg1) * T * E;
             hipLaunchKernelGGL(k_ntt_final_ext, dim3((unsigned)(n1 / T), (unsigned)nc), dim3(256), lds, ctx->stream, tmp,
