@@ -33,13 +33,16 @@ __device__ __forceinline__ u64 bcast64(u64 x, unsigned src) {
     u32 hi = __builtin_amdgcn_readlane((u32)(x >> 32), src);
     return ((u64)hi << 32) | lo;
 }
+// one-lane shifts of the whole wave as DPP moves (wave_shl:1 / wave_shr:1, bound_ctrl: the lane without a
+// source reads 0): a VALU op of a few cycles.  __shfl_down/__shfl_up compile to ds_bpermute_b32, whose LDS-crossbar
+// latency (~100 cycles) sat on the critical path of every iteration of the systolic product.
+__device__ __forceinline__ u32 dpp_down1(u32 x) { return __builtin_amdgcn_update_dpp(0u, x, 0x130, 0xf, 0xf, true); }
+__device__ __forceinline__ u32 dpp_up1(u32 x) { return __builtin_amdgcn_update_dpp(0u, x, 0x138, 0xf, 0xf, true); }
 __device__ __forceinline__ u64 shfl_down1(u64 x) {  // lane j <- lane j+1, lane 63 <- 0
-    u64 y = __shfl_down(x, 1, 64);
-    return lane_id() == 63 ? 0 : y;
+    return ((u64)dpp_down1((u32)(x >> 32)) << 32) | dpp_down1((u32)x);
 }
 __device__ __forceinline__ u64 shfl_up1(u64 x) {  // lane j <- lane j-1, lane 0 <- 0
-    u64 y = __shfl_up(x, 1, 64);
-    return lane_id() == 0 ? 0 : y;
+    return ((u64)dpp_up1((u32)(x >> 32)) << 32) | dpp_up1((u32)x);
 }
 
 template <int E> __device__ __forceinline__ LD<E> ld_zero() {
