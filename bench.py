@@ -295,6 +295,16 @@ def main():
     total_cols = (n_adv + cnt["msm_full"]) * args.steps
     alg_bytes_total = total_cols * n * 32.0 + acc_n * n * 64.0
     ach = alg_bytes_total / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+    # measured HBM-side traffic of the dominant kernel: PMC counters cannot be collected from inside this process,
+    # so the per-launch figure of the committed rocprofv3 --pmc passes of this same command is reported
+    traffic, traffic_src = None, None
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if args.scale == 1.0 and (args.enc_bits, args.k) == (2048, 17):
+            traffic = pj["k_msm_accumulate"]["fetch_bytes_per_launch_raw"] + pj["k_msm_accumulate"]["write_bytes_per_launch"]
+            traffic_src = pj["source"]
+    except Exception:
+        pass
     out = {
         "metric": "Paillier-encrypt proofs/s (2048-bit n, k=17); MSM achieved HBM GB/s vs peak",
         "value": value, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -313,7 +323,8 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "kernel": "k_msm_accumulate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": alg_bytes_total / max(1, acc_n),
             "launches": int(acc_n), "avg_launch_ms": acc_ms / max(1, acc_n),
             "note": "integer-multiply-issue bound by construction (v_mad_u64_u32); HBM fraction is the metric's definition, see DESIGN.md section 5",
         },
