@@ -547,3 +547,89 @@ def expand_mul_mod_cells(a: int, b: int, q: int, r: int, n: int, L: int, lookup_
         borrow = lt
     adv.append(borrow)
     return [x % FR_R for x in adv], [x % FR_R for x in lk]
+
+
+# ----------------------------------------------------------------------------------------
+# MockProver analogue for the K4 cell stream: halo2-lib has ONE gate, q * (a + b*c - d) = 0 on four
+# vertically consecutive cells [a, b, c, d].  gate_offsets_mul_mod lists where BigUintChip::mul_mod
+# enables the selector in one step's block (same walk as expand_mul_mod_cells); check_gates verifies the
+# identity on every enabled window.  This is the "circuit satisfied" half of the reference's tests
+# (base_test().expect_satisfied(true), paillier.rs:167-171) restricted to the gate constraints of the
+# hot-path cells; copy constraints and lookups are dependency-defined wiring, not values.
+# ----------------------------------------------------------------------------------------
+def _rc_gates(off, bits, lb):
+    k = -(-bits // lb)
+    rem = bits % lb
+    g = []
+    n = 0
+    if k > 1:
+        g += [off + 3 * i for i in range(k - 1)]  # inner product: windows [acc_{i}, d_{i+1}, base_{i+1}, acc_{i+1}]
+        n = 1 + 3 * (k - 1)
+    if rem >= 1:
+        g.append(off + n)
+        n += 4
+    return g, n
+
+
+def gate_offsets_mul_mod(L: int, lookup_bits: int, limb_bits: int = 64):
+    lb = lookup_bits
+    D = 2 * L - 1
+    gates = []
+    off = 0
+    for _ in range(3):  # assign q, n, r
+        off += L
+        for _ in range(L):
+            g, n = _rc_gates(off, limb_bits, lb)
+            gates += g
+            off += n
+    for _ in range(2):  # two convolutions: rows [0, (x, y, s)...]: windows start at every sum cell / the leading 0
+        off += 1
+        for i in range(D):
+            gates += [off + 3 * j for j in range(i + 1)]
+            off += 1 + 3 * (i + 1)
+    for _ in range(L):  # qn + r : [a, 1, b, out]
+        gates.append(off)
+        off += 4
+    m = (1 << limb_bits) - 1
+    cb = (2 * (L * m * m + m)).bit_length() - limb_bits
+    off += 2
+    def is_equal_gates(o):  # sub gate + is_zero's two gates (rows 0 and 4 of its 8 cells)
+        return [o, o + 4, o + 8]
+    def div_mod_gates(o):  # [qd, rd] witnesses, mul gate, sub gate, is_equal
+        return [o + 2, o + 6] + is_equal_gates(o + 10)
+    for i in range(D):
+        gates.append(off)                    # sub
+        gates += [off + 4, off + 7]          # sum of 3: [x0, x1, 1, s1, x2, 1, s2]
+        gates += div_mod_gates(off + 11)
+        gates.append(off + 33)               # add
+        gates += div_mod_gates(off + 37)
+        gates += is_equal_gates(off + 59)
+        gates.append(off + 71)               # and
+        off += 75
+        if i < D - 1:
+            g, n = _rc_gates(off, cb, lb)
+            gates += g
+            off += n
+        else:
+            gates += is_equal_gates(off)
+            gates.append(off + 12)
+            off += 16
+    for _ in range(L):  # r < n
+        gates.append(off)          # add [n_i, 1, borrow, nb]
+        gates.append(off + 7)      # [r_i, lt, 2^64, r_i + lt*2^64]
+        off += 11                  # (cells 4..6 [shift, lt, out] are witnesses tied by copy constraints)
+        g, n = _rc_gates(off, limb_bits, lb)
+        gates += g
+        off += n
+    off += 1
+    return gates, off
+
+
+def check_gates(cells, gates):
+    """returns the list of gate offsets whose identity a + b*c == d (mod r) fails"""
+    bad = []
+    for o in gates:
+        a, b, c, d = cells[o], cells[o + 1], cells[o + 2], cells[o + 3]
+        if (a + b * c - d) % FR_R != 0:
+            bad.append(o)
+    return bad

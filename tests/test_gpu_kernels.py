@@ -427,3 +427,31 @@ def test_ntt_extend_vs_oracle(eng, cref, log_n, log_e):
         want = cref.ntt_fr(cref.fr_distribute_powers(ext, cref.fr_ints_to_mont([g])[0]), cref.fr_ints_to_mont([w_ext])[0],
                            log_n + log_e)
         assert np.array_equal(got[j], want), (log_n, log_e, j)
+
+
+def test_witness_cells_satisfy_the_gate(eng, cref):
+    """K3 -> K4 on the device at the c2 limb count: the cells the GPU wrote satisfy halo2-lib's gate on every
+    enabled window (MockProver analogue, reference: expect_satisfied(true) paillier.rs:170), lookups in range."""
+    import torch
+
+    nn, g, m, r = P.synth_paillier_inputs(2048, 0x5043)
+    Ln, L, lb = 32, 64, 16
+    m &= (1 << 24) - 1  # short message: a few dozen steps of the g^m chain suffice
+    arr = lambda x: cref.int_to_limbs(x, Ln)
+    res, steps, ns = eng.paillier_trace(L, cref.int_to_limbs(nn * nn, L), cref.int_to_limbs(g, L), cref.int_to_limbs(m, Ln), Ln)
+    adv_n, lk_n = eng.witness_cells_per_step(L, 64, lb)
+    d_steps = torch.from_numpy(steps.astype(np.int64)).cuda()
+    d_mod = torch.from_numpy(cref.int_to_limbs(nn * nn, L).astype(np.int64)).cuda()
+    d_adv = torch.zeros((ns, adv_n, 4), dtype=torch.int64, device="cuda")
+    d_lk = torch.zeros((ns, lk_n, 4), dtype=torch.int64, device="cuda")
+    eng.witness_expand_dev(L, 64, lb, d_steps.data_ptr(), ns, d_mod.data_ptr(), d_adv.data_ptr(), d_lk.data_ptr())
+    eng.sync()
+    gates, end = P.gate_offsets_mul_mod(L, lb)
+    assert end == adv_n
+    adv = d_adv.cpu().numpy().astype(np.uint64)
+    for k in (0, 1, ns // 2, ns - 1):
+        cells = cref.fr_mont_to_ints(adv[k])
+        assert P.check_gates(cells, gates) == [], k
+        assert cells[-1] == 1
+    lk = cref.fr_mont_to_ints(d_lk.cpu().numpy().astype(np.uint64).reshape(-1, 4)[:: 7])
+    assert max(lk) < (1 << lb)

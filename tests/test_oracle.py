@@ -153,3 +153,41 @@ def test_c_ntt_vs_python(cref):
     g = 7
     got = cref.fr_distribute_powers(cref.fr_ints_to_mont(a), cref.fr_ints_to_mont([g])[0])
     assert cref.fr_mont_to_ints(got) == P.coset_scale(a, g)
+
+
+def test_cell_stream_satisfies_the_gate():
+    """MockProver analogue (reference: base_test().expect_satisfied(true), paillier.rs:167-171): every enabled
+    4-cell window of the mul_mod cell stream satisfies halo2-lib's single gate a + b*c = d; a wrong quotient
+    or remainder is caught (the reference never tests expect_satisfied(false))."""
+    rng = random.Random(9)
+    for L, lb in ((2, 15), (4, 16), (4, 14), (4, 8), (64, 16)):
+        bits = 64 * L
+        n = rng.getrandbits(bits) | (1 << (bits - 1))
+        a, b = rng.randrange(n), rng.randrange(n)
+        q, r = divmod(a * b, n)
+        adv, lk = P.expand_mul_mod_cells(a, b, q, r, n, L, lb)
+        gates, end = P.gate_offsets_mul_mod(L, lb)
+        assert end == len(adv)
+        assert P.check_gates(adv, gates) == []
+        assert max(lk) < (1 << lb)
+        assert adv[-1] == 1  # r < n
+        # eq bit chain ends at one: the cell before the lt segment's first gate is the final `and` output
+        # negative: corrupt one cell inside a gate window
+        g0 = gates[len(gates) // 2]
+        bad = list(adv)
+        bad[g0 + 3] = (bad[g0 + 3] + 1) % P.FR_R
+        assert g0 in P.check_gates(bad, gates)
+    # an inconsistent step (r off by one) breaks the carry chain: the final equality bit is 0
+    L, lb = 4, 16
+    n = rng.getrandbits(256) | (1 << 255)
+    a, b = rng.randrange(n), rng.randrange(n)
+    q, r = divmod(a * b, n)
+    try:
+        adv, _ = P.expand_mul_mod_cells(a, b, q, (r + 1) % n, n, L, lb)
+        sc_end = P.gate_offsets_mul_mod(L, lb)[1]
+        # locate the last `and` output of the eq segment: 1 cell + L*(11+rc) before the end
+        from paillier_halo2_amd import layout
+        off_lt = layout.mul_mod_cells(L, 64, lb).seg["lt"]
+        assert adv[off_lt - 1] == 0
+    except AssertionError:
+        raise
