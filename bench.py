@@ -60,7 +60,7 @@ def synth_inputs(enc_bits: int, seed: int):
 class ProofWorkload:
     """device-resident state of the c2 hot path on one GPU"""
 
-    def __init__(self, eng, torch, enc_bits: int, k: int, seed: int, scale: float, pool: int = 256):
+    def __init__(self, eng, torch, enc_bits: int, k: int, seed: int, scale: float, pool: int = 256, circuit: str = "encrypt"):
         from paillier_halo2_amd import consts, layout
 
         self.eng, self.torch = eng, torch
@@ -70,8 +70,13 @@ class ProofWorkload:
         self.L = 2 * self.Ln
         dev = "cuda"
         nn, g, m, r = synth_inputs(enc_bits, seed)
+        self.circuit = circuit
         self.inputs = tuple(consts.int_to_limbs(x, self.Ln) for x in (nn, g, m, r))
-        n_steps = m.bit_length() + bin(m).count("1") + nn.bit_length() + bin(nn).count("1") + 1
+        if circuit == "encrypt":
+            n_steps = m.bit_length() + bin(m).count("1") + nn.bit_length() + bin(nn).count("1") + 1
+        else:  # PaillierChip::add (paillier.rs:62-85): one mul_mod of two ciphertexts assigned at enc_bits (bench.rs:98-103)
+            n_steps = 1
+            self.add_ops = tuple(consts.int_to_limbs(x, self.L) for x in (m, r, nn * nn))
         self.n_steps = n_steps
         self.shape = layout.encrypt_proof_shape(enc_bits, k, n_steps)
         sh = self.shape
@@ -129,7 +134,12 @@ class ProofWorkload:
         n, k, sh = self.n, self.k, self.shape
         # K3: witness trace (steps stay in HBM)
         nn, g, m, r = self.inputs
-        eng.paillier_encrypt_dev(self.Ln, nn, g, m, r, self.d_steps.data_ptr(), self.n_steps)
+        if self.circuit == "encrypt":
+            eng.paillier_encrypt_dev(self.Ln, nn, g, m, r, self.d_steps.data_ptr(), self.n_steps)
+        else:
+            a, b, mod = self.add_ops
+            q, rem = eng.mul_mod(self.L, a, b, mod)
+            self.d_steps.copy_(t.from_numpy(np.stack([a, b, q, rem]).astype(np.int64)).view(1, 4, self.L))
         # K4: expand the trace into the advice / lookup cell streams (the circuit's columns)
         eng.witness_expand_dev(self.L, 64, sh.lookup_bits, self.d_steps.data_ptr(), self.n_steps, self.d_mod.data_ptr(),
                                self.d_adv.data_ptr(), self.d_lk.data_ptr())
@@ -212,7 +222,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c2", "msm22"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "msm22"],
+                    help="c2: encrypt proof hot path (headline); c3: homomorphic-add circuit at --k 15; msm22: one sharded MSM")
     ap.add_argument("--k", type=int, default=17)
     ap.add_argument("--enc-bits", type=int, default=2048)
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the per-proof MSM/NTT counts (debug only; "
@@ -259,7 +270,10 @@ def main():
         return
 
     t0 = time.time()
-    wl = ProofWorkload(eng, torch, args.enc_bits, args.k, seed=0x5043 + rank, scale=args.scale)
+    if args.workload == "c3" and args.k == 17:
+        args.k = 15
+    wl = ProofWorkload(eng, torch, args.enc_bits, args.k, seed=0x5043 + rank, scale=args.scale,
+                       circuit="add" if args.workload == "c3" else "encrypt")
     log("setup %.1fs: %s ; per-step counts %s" % (time.time() - t0, wl.shape, wl.counts))
     for _ in range(args.warmup):
         wl.step()
@@ -311,8 +325,8 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32 limbs (254-bit modular integers), u64 limbs (4096-bit integers)", "data": "synthetic",
         "config": {
-            "workload": "%s: %d-bit n encrypt, KZG prover hot path at k=%d (K3 trace + K4 cell expansion + K1 commitments + K2 NTTs), 1 proof per GPU per step"
-                        % ("c2" if (args.enc_bits, args.k) == (2048, 17) else "c5-shape" if (args.enc_bits, args.k) == (3072, 19) else "custom", args.enc_bits, args.k),
+            "workload": "%s: %d-bit n, KZG prover hot path at k=%d (K3 trace + K4 cell expansion + K1 commitments + K2 NTTs), 1 proof per GPU per step"
+                        % ("c3 homomorphic add" if args.workload == "c3" else "c2 encrypt" if (args.enc_bits, args.k) == (2048, 17) else "c5-shape encrypt" if (args.enc_bits, args.k) == (3072, 19) else "custom encrypt", args.enc_bits, args.k),
             "enc_bits": args.enc_bits, "k": args.k, "lookup_bits": sh.lookup_bits, "limb_bits": 64,
             "mul_mod_steps": wl.n_steps, "advice_cols": sh.advice_cols, "lookup_cols": sh.lookup_cols,
             "perm_cols": sh.perm_cols, "advice_cols_committed": wl.adv_cols, "lookup_cols_committed": wl.lk_cols,
