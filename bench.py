@@ -94,16 +94,19 @@ class ProofWorkload:
         self.d_adv = torch.zeros((self.adv_cols * self.rows, 4), dtype=torch.int64, device=dev)
         self.d_lk = torch.zeros((self.lk_cols * self.rows, 4), dtype=torch.int64, device=dev)
         self.d_out_adv = torch.zeros((self.adv_cols, 12), dtype=torch.int64, device=dev)
-        # SRS stand-in: 2^k distinct points [s_i]G, generated on the GPU (fixed-base mul), window table built once
         gen = torch.Generator(device=dev)
         gen.manual_seed(seed)
         self.gen = gen
-        ks = self._rand_fr(self.n)
+        # the Lagrange-basis SRS g_lagrange[i] = [L_i(s)]G of ParamsKZG::setup for a seeded toxic scalar (what
+        # commit_lagrange multiplies the advice columns with), derived on the device
+        import random as _random
+
+        s_toxic = _random.Random(seed ^ 0x535253).randrange(2, consts.FR_R)
         d_b = torch.zeros((self.n, 8), dtype=torch.int64, device=dev)
-        eng.g1_fixed_base_mul_dev(ks.data_ptr(), self.n, d_b.data_ptr())
+        eng.srs_setup_g1_dev(k, consts.fr_mont_limbs(s_toxic), consts.fr_mont_limbs(consts.fr_omega(k)), 0, d_b.data_ptr())
         eng.sync()
         self.bases = eng.load_bases_dev(d_b.data_ptr(), self.n)
-        del d_b, ks
+        del d_b
         # column pools (values synthetic, Montgomery form): witness-like / lookup digits / full width
         self.pool = pool
         self.col_f = self._rand_fr(pool * self.n).view(pool, self.n, 4)

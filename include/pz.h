@@ -174,6 +174,20 @@ int pz_witness_expand_dev(pz_ctx* ctx, uint32_t limbs, uint32_t limb_bits, uint3
                           uint64_t* d_lookup);
 
 /* ---------------------------------------------------------------------------------------------
+ * "next" rows, built on the kernels above
+ * ------------------------------------------------------------------------------------------- */
+/* ParamsKZG::setup with a known toxic scalar s (what halo2-lib's gen_srs does with its seeded rng; reached from
+ * /root/reference/src/bench.rs:161-171): d_g[i] = [s^i] G, d_g_lagrange[i] = [L_i(s)] G over the 2^k domain
+ * generated by omega (L_i(s) = (s^n - 1) omega^i / (n (s - omega^i))).  Either output may be NULL.  s, omega: Fr
+ * Montgomery (host); outputs: device, 2^k affine points each.  s must not lie in the domain (PZ_ERR_INVALID). */
+int pz_srs_setup_g1_dev(pz_ctx* ctx, uint32_t k, const uint64_t s[4], const uint64_t omega[4], uint64_t* d_g,
+                        uint64_t* d_g_lagrange);
+/* evaluation of n_cols coefficient-form polynomials (n coefficients each, device) at the point x:
+ * d_out[col] = sum_i d_coeffs[col][i] * x^i   (the evals phase of create_proof / eval_polynomial). */
+int pz_poly_eval_dev(pz_ctx* ctx, const uint64_t* d_coeffs, size_t n_cols, size_t col_stride, size_t n,
+                     const uint64_t x[4], uint64_t* d_out);
+
+/* ---------------------------------------------------------------------------------------------
  * measurement helpers (used by bench.py; not part of the reference surface)
  * ------------------------------------------------------------------------------------------- */
 /* HIP-event timing of the dominant kernel on the context's stream: accumulated since the last

@@ -1,0 +1,127 @@
+// pz_poly.hip -- first "next" rows of SURVEY.md section 8f, built on K1/K2's primitives:
+//   pz_srs_setup_g1_dev : ParamsKZG::setup as halo2 does it when the toxic scalar s is known (gen_srs seeds it):
+//                         g[i] = [s^i] G and g_lagrange[i] = [L_i(s)] G with L_i(s) = (s^n - 1) w^i / (n (s - w^i)),
+//                         i.e. Fr arithmetic + fixed-base multiplication, all on the device.
+//   pz_poly_eval_dev    : evaluation of coefficient-form columns at a point x (the "evals" phase before SHPLONK):
+//                         sum_i c_i x^i with a cached x^i table, one multiplication per coefficient.
+// Both are reached in the reference only through bench.rs:161-171 (gen_srs / create_proof inside bench_builder).
+#include "ec.cuh"
+#include "pz_internal.h"
+
+__global__ void k_srs_multiplier(Fr s, Fr n_mont, unsigned k, Fr* out /* [0] = (s^n - 1)/n, [1] = s^n - 1 */) {
+    if (blockIdx.x || threadIdx.x) return;
+    Fr sn = s;
+    for (unsigned i = 0; i < k; ++i) sn = fp_sqr(sn);
+    Fr num = fp_sub(sn, fp_one<FrTag>());
+    fp_store(out + 1, num);
+    fp_store(out, fp_mul(num, fp_inv(n_mont)));
+}
+
+// l_i = mult * w^i / (s - w^i)
+__global__ __launch_bounds__(128) void k_lagrange_scalars(const Fr* __restrict__ tw, Fr s, const Fr* __restrict__ mult,
+                                                          Fr* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr w = fp_load<FrTag>(tw + i);
+    Fr d = fp_sub(s, w);
+    Fr m = fp_load<FrTag>(mult);
+    fp_store(out + i, fp_mul(fp_mul(m, w), fp_inv(d)));
+}
+
+extern "C" int pz_g1_fixed_base_mul_dev(pz_ctx* ctx, const uint64_t* d_scalars, size_t n, uint64_t* d_out_affine);
+
+extern "C" int pz_srs_setup_g1_dev(pz_ctx* ctx, uint32_t k, const uint64_t s[4], const uint64_t omega[4], uint64_t* d_g,
+                                   uint64_t* d_g_lagrange) {
+    if (!ctx || !s || !omega || (!d_g && !d_g_lagrange) || k > 26) return PZ_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)1 << k;
+    void* spow;
+    PZCHK(pz_get_pow_table(ctx, s, n, &spow));
+    if (d_g) PZCHK(pz_g1_fixed_base_mul_dev(ctx, (const uint64_t*)spow, n, d_g));
+    if (d_g_lagrange) {
+        void *tw, *ws;
+        PZCHK(pz_get_pow_table(ctx, omega, n, &tw));
+        PZCHK(pz_ws_get(ctx, WS_IO_A, n * 32 + 64, &ws));
+        Fr* mult = (Fr*)ws;
+        Fr* lag = (Fr*)((char*)ws + 64);
+        Fr sv, nm;
+        memcpy(sv.v, s, 32);
+        // Montgomery form of n = 2^k: computed on the device side as 2^k * R via doubling of R
+        {
+            // R mod r doubled k times on the host would need field arithmetic; do it in the kernel via to_mont
+            Fr raw;
+            memset(&raw, 0, sizeof raw);
+            raw.v[k >> 5] = 1u << (k & 31);
+            nm = raw;  // canonical 2^k; converted below
+        }
+        // canonical -> Montgomery for n: reuse the conversion kernel on a 1-element buffer
+        HIPCHK(ctx, hipMemcpyAsync(mult + 1, &nm, 32, hipMemcpyHostToDevice, ctx->stream));
+        PZCHK(pz_fr_convert_dev(ctx, (uint64_t*)(mult + 1), 1, 1));
+        HIPCHK(ctx, hipMemcpyAsync(&nm, mult + 1, 32, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        hipLaunchKernelGGL(k_srs_multiplier, dim3(1), dim3(64), 0, ctx->stream, sv, nm, (unsigned)k, mult);
+        Fr chk[2];
+        HIPCHK(ctx, hipMemcpyAsync(chk, mult, 64, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        bool zero = true;
+        for (int i = 0; i < 8; ++i) zero = zero && chk[1].v[i] == 0;
+        if (zero) return PZ_ERR_INVALID;  // s lies in the evaluation domain (s^n == 1): halo2 special-cases it, not supported
+        hipLaunchKernelGGL(k_lagrange_scalars, dim3(pz_div_up(n, 128)), dim3(128), 0, ctx->stream, (const Fr*)tw, sv,
+                           (const Fr*)mult, lag, n);
+        HIPCHK(ctx, hipGetLastError());
+        PZCHK(pz_g1_fixed_base_mul_dev(ctx, (const uint64_t*)lag, n, d_g_lagrange));
+    }
+    return PZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- evaluation at a point
+#define EVAL_CH 16u
+__global__ __launch_bounds__(256) void k_poly_eval_partial(const Fr* __restrict__ coeffs, size_t col_stride, size_t n,
+                                                           const Fr* __restrict__ xpow, Fr* __restrict__ partial,
+                                                           unsigned blocks_per_col) {
+    __shared__ Fr s_acc[256];
+    const size_t col = blockIdx.y;
+    const Fr* c = coeffs + col * col_stride;
+    const size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * EVAL_CH;
+    Fr acc = fp_zero<FrTag>();
+    for (unsigned t = 0; t < EVAL_CH; ++t) {
+        const size_t i = base + t;
+        if (i < n) acc = fp_add(acc, fp_mul(fp_load<FrTag>(c + i), fp_load<FrTag>(xpow + i)));
+    }
+    s_acc[threadIdx.x] = acc;
+    __syncthreads();
+    for (unsigned off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) s_acc[threadIdx.x] = fp_add(s_acc[threadIdx.x], s_acc[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) fp_store(partial + col * blocks_per_col + blockIdx.x, s_acc[0]);
+}
+__global__ void k_poly_eval_final(const Fr* __restrict__ partial, unsigned blocks_per_col, size_t n_cols, Fr* __restrict__ out) {
+    size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= n_cols) return;
+    Fr acc = fp_zero<FrTag>();
+    for (unsigned b = 0; b < blocks_per_col; ++b) acc = fp_add(acc, fp_load<FrTag>(partial + col * blocks_per_col + b));
+    fp_store(out + col, acc);
+}
+
+extern "C" int pz_poly_eval_dev(pz_ctx* ctx, const uint64_t* d_coeffs, size_t n_cols, size_t col_stride, size_t n,
+                                const uint64_t x[4], uint64_t* d_out) {
+    if (!ctx || !x || (n_cols && (!d_coeffs || !d_out)) || col_stride % 4 || (n_cols > 1 && col_stride < 4 * n)) return PZ_ERR_INVALID;
+    if (n_cols == 0) return PZ_OK;
+    if (n_cols > 65535) return PZ_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (n == 0) {
+        HIPCHK(ctx, hipMemsetAsync(d_out, 0, n_cols * 32, ctx->stream));
+        return PZ_OK;
+    }
+    void *xp, *part;
+    PZCHK(pz_get_pow_table(ctx, x, n, &xp));
+    const unsigned bpc = pz_div_up(n, 256 * EVAL_CH);
+    PZCHK(pz_ws_get(ctx, WS_IO_B, n_cols * (size_t)bpc * 32, &part));
+    hipLaunchKernelGGL(k_poly_eval_partial, dim3(bpc, (unsigned)n_cols), dim3(256), 0, ctx->stream, (const Fr*)d_coeffs,
+                       col_stride / 4, n, (const Fr*)xp, (Fr*)part, bpc);
+    hipLaunchKernelGGL(k_poly_eval_final, dim3(pz_div_up(n_cols, 64)), dim3(64), 0, ctx->stream, (const Fr*)part, bpc, n_cols,
+                       (Fr*)d_out);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}

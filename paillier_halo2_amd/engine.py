@@ -259,6 +259,15 @@ class Engine:
         self._chk(self.L.pz_witness_expand_dev(self.ctx, limbs, limb_bits, lookup_bits, VP(d_steps), n_steps,
                                                VP(d_modulus), VP(d_advice), VP(d_lookup)), "pz_witness_expand_dev")
 
+    # ------------------------------------------------------------------ "next" rows: SRS setup, evaluation at a point
+    def srs_setup_g1_dev(self, k: int, s, omega, d_g: int = 0, d_g_lagrange: int = 0):
+        self._chk(self.L.pz_srs_setup_g1_dev(self.ctx, k, _ptr(_np(s).reshape(4)), _ptr(_np(omega).reshape(4)), VP(d_g),
+                                             VP(d_g_lagrange)), "pz_srs_setup_g1_dev")
+
+    def poly_eval_dev(self, d_coeffs: int, n_cols: int, col_stride_u64: int, n: int, x, d_out: int):
+        self._chk(self.L.pz_poly_eval_dev(self.ctx, VP(d_coeffs), n_cols, col_stride_u64, n, _ptr(_np(x).reshape(4)),
+                                          VP(d_out)), "pz_poly_eval_dev")
+
     # ------------------------------------------------------------------ measurement
     def timing_enable(self, on: bool = True):
         self._chk(self.L.pz_timing_enable(self.ctx, int(on)), "pz_timing_enable")

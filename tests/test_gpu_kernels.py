@@ -455,3 +455,73 @@ def test_witness_cells_satisfy_the_gate(eng, cref):
         assert cells[-1] == 1
     lk = cref.fr_mont_to_ints(d_lk.cpu().numpy().astype(np.uint64).reshape(-1, 4)[:: 7])
     assert max(lk) < (1 << lb)
+
+
+# ------------------------------------------------------------------------------------------ next rows
+def test_srs_setup_and_commit_equivalence(eng, cref):
+    """ParamsKZG::setup on the device: g[i] = [s^i]G, g_lagrange[i] = [L_i(s)]G vs the Python oracle at k = 5, and the
+    size-independent property that ties K1, K2 and the SRS together at k = 11:
+    commit_lagrange(evals) == commit(ifft(evals))."""
+    import torch
+
+    rng = random.Random(300)
+    s = rng.randrange(2, P.FR_R)
+    for k in (5, 11):
+        n = 1 << k
+        w = P.fr_omega(k)
+        d_g = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+        d_l = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+        eng.srs_setup_g1_dev(k, cref.fr_ints_to_mont([s])[0], cref.fr_ints_to_mont([w])[0], d_g.data_ptr(), d_l.data_ptr())
+        eng.sync()
+        if k == 5:
+            g = cref.affine_mont_to_ints(d_g.cpu().numpy().astype(np.uint64))
+            lag = cref.affine_mont_to_ints(d_l.cpu().numpy().astype(np.uint64))
+            mult = (pow(s, n, P.FR_R) - 1) * pow(n, -1, P.FR_R) % P.FR_R
+            for i in range(n):
+                assert g[i] == P.g1_mul(P.G1_GEN, pow(s, i, P.FR_R)), i
+                li = mult * pow(w, i, P.FR_R) * pow((s - pow(w, i, P.FR_R)) % P.FR_R, -1, P.FR_R) % P.FR_R
+                assert lag[i] == P.g1_mul(P.G1_GEN, li), i
+            continue
+        tb_g = eng.load_bases_dev(d_g.data_ptr(), n)
+        tb_l = eng.load_bases_dev(d_l.data_ptr(), n)
+        evals = cref.fr_ints_to_mont([rng.randrange(P.FR_R) for _ in range(n)])
+        winv = cref.fr_ints_to_mont([pow(w, -1, P.FR_R)])[0]
+        ninv = cref.fr_ints_to_mont([pow(n, -1, P.FR_R)])[0]
+        d_c = torch.from_numpy(evals.astype(np.int64)).cuda()
+        eng.ntt_dev(d_c.data_ptr(), 1, 4 * n, winv, k, None, ninv)  # Lagrange -> coefficient form
+        eng.sync()
+        coeffs = d_c.cpu().numpy().astype(np.uint64)
+        c_lag = eng.g1_normalize(eng.msm(tb_l, evals))[0]
+        c_mon = eng.g1_normalize(eng.msm(tb_g, coeffs))[0]
+        assert np.array_equal(c_lag, c_mon)
+        # and the commitment is [f(s)]G: evaluation at s on the device vs fixed-base multiplication
+        d_out = torch.zeros((1, 4), dtype=torch.int64, device="cuda")
+        eng.poly_eval_dev(d_c.data_ptr(), 1, 4 * n, n, cref.fr_ints_to_mont([s])[0], d_out.data_ptr())
+        eng.sync()
+        fs = d_out.cpu().numpy().astype(np.uint64)
+        assert np.array_equal(eng.g1_fixed_base_mul(fs)[0], c_mon)
+        tb_g.free()
+        tb_l.free()
+
+
+def test_poly_eval_vs_oracle(eng, cref):
+    import torch
+
+    rng = random.Random(301)
+    for n in (1, 2, 17, 256, 4097, 1 << 13):
+        cols = [[rng.randrange(P.FR_R) for _ in range(n)] for _ in range(3)]
+        x = rng.randrange(P.FR_R)
+        stride = 4 * n + 4
+        buf = np.zeros((3, stride), dtype=np.uint64)
+        for j, c in enumerate(cols):
+            buf[j, : 4 * n] = cref.fr_ints_to_mont(c).reshape(-1)
+        d = torch.from_numpy(buf.astype(np.int64)).cuda()
+        d_out = torch.zeros((3, 4), dtype=torch.int64, device="cuda")
+        eng.poly_eval_dev(d.data_ptr(), 3, stride, n, cref.fr_ints_to_mont([x])[0], d_out.data_ptr())
+        eng.sync()
+        got = cref.fr_mont_to_ints(d_out.cpu().numpy().astype(np.uint64))
+        for j, c in enumerate(cols):
+            want = 0
+            for v in reversed(c):
+                want = (want * x + v) % P.FR_R  # Horner
+            assert got[j] == want, (n, j)
