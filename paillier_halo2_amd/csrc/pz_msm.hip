@@ -654,7 +654,18 @@ extern "C" int pz_msm_g1_dev(pz_ctx* ctx, const pz_bases* bases, const uint64_t*
                            (size_t)(1u << (bases->c - 1)) * (172 + 4 * (size_t)pz_div_up(n, SORT_SLICE));
     // group size: sized for 288 GB of HBM -- by default up to 48 GiB of sort / partial-sum workspace per launch
     // sequence (PZ_MSM_WS_GIB overrides), so the latency-bound tree levels are paid once per ~2000 columns
-    size_t group = (pz_msm_ws_gib() << 30) / per_col;
+    size_t ws_budget = pz_msm_ws_gib() << 30;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            // never plan for more than half of what is free right now (plus what this context already holds)
+            size_t held = 0;
+            for (int i = 0; i < WS_COUNT; ++i) held += ctx->ws[i].cap;
+            const size_t avail = (free_b + held) / 2;
+            if (ws_budget > avail) ws_budget = avail;
+        }
+    }
+    size_t group = ws_budget / per_col;
     if (group == 0) group = 1;
     if (group > n_cols) group = n_cols;
     if (group > 4096) group = 4096;
