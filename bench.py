@@ -95,6 +95,7 @@ class ProofWorkload:
         self.d_adv = torch.zeros((self.adv_cols * self.rows, 4), dtype=torch.int64, device=dev)
         self.d_lk = torch.zeros((self.lk_cols * self.rows, 4), dtype=torch.int64, device=dev)
         self.d_out_adv = torch.zeros((self.adv_cols, 12), dtype=torch.int64, device=dev)
+        self.digit_adds = 0  # filled by count_digit_adds() after a warm-up step
         gen = torch.Generator(device=dev)
         gen.manual_seed(seed)
         self.gen = gen
@@ -143,6 +144,35 @@ class ProofWorkload:
         x = t.randint(-(1 << 63), (1 << 63) - 1, (count, 4), dtype=t.int64, device="cuda", generator=self.gen)
         x[:, 3] &= 0x0FFFFFFFFFFFFFFF  # < 2^252 < r: a valid representative; uniform enough for digit statistics
         return x
+
+    def count_digit_adds(self):
+        """non-zero signed 16-bit digits of everything K1 accumulates in one step (torch arithmetic on the canonical
+        values; measurement support only).  Full-width uniform scalars: 16 digits minus the 2^-16 zero chance each."""
+        t = self.torch
+        total = 0
+        full = self.counts["msm_full"] * self.n * 16 * (1.0 - 2.0 ** -16)
+        for buf, ncols in ((self.d_adv, self.adv_cols), (self.d_lk, self.lk_cols)):
+            if self.scale != 1.0:
+                ncols = max(1, int(round(ncols * self.scale)))
+            cells = ncols * self.rows
+            CH = 1 << 22
+            for c0 in range(0, cells, CH):
+                x = buf[c0:min(cells, c0 + CH)].clone()
+                self.eng.fr_convert_dev(x.data_ptr(), x.shape[0], False)  # canonical
+                self.eng.sync()
+                # negative field values (r - small) are negated by the kernel: count digits of min(k, r-k); those
+                # are the cells whose top limb is non-zero here (honest witness values are < 2^192 otherwise)
+                neg = x[:, 3] != 0
+                # 16-bit pieces of the three low limbs; signed recoding adds at most one carry digit per scalar
+                nz = t.zeros(x.shape[0], dtype=t.int64, device=x.device)
+                for limb in range(3):
+                    v = x[:, limb]
+                    for sh in (0, 16, 32, 48):
+                        nz += ((v >> sh) & 0xFFFF) != 0
+                total += int(nz[~neg].sum().item()) + int(neg.sum().item()) * 9
+                del x
+        self.digit_adds = int(total + full)
+        return self.digit_adds
 
     # ---- one pass of the hot path
     def step(self):
@@ -310,6 +340,8 @@ def main():
     log("setup %.1fs: %s ; per-step counts %s" % (time.time() - t0, wl.shape, wl.counts))
     for _ in range(args.warmup):
         wl.step()
+    if args.warmup:
+        wl.count_digit_adds()
     barrier()
     engines = [eng] + ([wl.eng2] if wl.eng2 is not None else [])
     for e_ in engines:
@@ -382,6 +414,15 @@ def main():
             "launches": int(acc_n), "avg_launch_ms": acc_ms / max(1, acc_n),
             "note": "integer-multiply-issue bound by construction (v_mad_u64_u32); HBM fraction is the metric's definition, see DESIGN.md section 5",
         },
+        # the roofline that actually binds this kernel: v_mad_u64_u32 issue.  One mixed addition = 10 Montgomery
+        # products x 128 mads (the addc / moves beside them are the difference to 100 %); peak = 24.1 T mad/s measured
+        # by pz_ubench_mad on this chip
+        "roofline_int": {
+            "bound": "v_mad_u64_u32 issue", "kernel": "k_msm_accumulate",
+            "achieved": (wl.digit_adds * args.steps * 1280.0 / (acc_ms * 1e-3) / 1e12) if (acc_ms > 0 and wl.digit_adds) else None,
+            "peak": 24.1, "unit": "T mad/s", "digit_adds_per_proof": wl.digit_adds,
+            "note": "digit_adds = non-zero signed 16-bit digits accumulated per proof, counted on the device",
+        },
         "breakdown_ms_per_proof": {"trace": trace_ms / args.steps, "expand": exp_ms / args.steps, "msm_all": msm_ms / args.steps,
                                    "msm_accumulate": acc_ms / args.steps, "ntt": ntt_ms / args.steps},
     }
@@ -390,6 +431,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sh, wl.n_steps, args.enc_bits, args.k, log)
         except Exception as ex:  # the checker must never take the bench line down
             out["cpu_baseline"] = {"value": None, "error": repr(ex)}
+    if out["roofline_int"]["achieved"]:
+        out["roofline_int"]["frac"] = out["roofline_int"]["achieved"] / out["roofline_int"]["peak"]
     print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
