@@ -1,0 +1,57 @@
+"""CPU: host-side logic of the package (no GPU): circuit-shape arithmetic, constants, window partition."""
+import random
+
+from oracle import pyref as P
+from paillier_halo2_amd import consts, layout
+from paillier_halo2_amd.dist import window_range
+
+
+def test_layout_counts_match_the_cell_stream():
+    rng = random.Random(21)
+    for L, lb in ((2, 15), (4, 16), (4, 14), (4, 8), (6, 13), (64, 16), (64, 14), (96, 18)):
+        bits = 64 * L
+        n = rng.getrandbits(bits) | (1 << (bits - 1))
+        a, b = rng.randrange(n), rng.randrange(n)
+        q, r = divmod(a * b, n)
+        adv, lk = P.expand_mul_mod_cells(a, b, q, r, n, L, lb)
+        sc = layout.mul_mod_cells(L, 64, lb)
+        assert (sc.advice, sc.lookup) == (len(adv), len(lk)), (L, lb)
+        gates, end = P.gate_offsets_mul_mod(L, lb)
+        assert end == sc.advice
+        # segment offsets are increasing and inside the block
+        offs = [sc.seg[k] for k in ("assign", "mul_ab", "mul_qn", "add_r", "eq", "lt", "end")]
+        assert offs == sorted(offs) and offs[-1] == sc.advice
+
+
+def test_proof_shape_c2_c3_c5():
+    c2 = layout.encrypt_proof_shape(2048, 17, 6145)
+    assert c2.limbs == 64 and c2.lookup_bits == 16 and c2.ext_k == 19
+    assert 2800 <= c2.advice_cols <= 3200          # "about 2.8k advice columns at k=17"
+    assert c2.perm_cols == -(-(c2.advice_cols + c2.lookup_cols + 1) // 2)
+    assert c2.polys == c2.advice_cols + 4 * c2.lookup_cols + c2.perm_cols
+    c3 = layout.encrypt_proof_shape(2048, 15, 1, lookup_bits=14)
+    assert c3.advice_cols <= 8
+    c5 = layout.encrypt_proof_shape(3072, 19, 9217)
+    assert c5.limbs == 96 and 2000 <= c5.advice_cols <= 2600
+
+
+def test_consts_against_oracle():
+    assert consts.FR_R == P.FR_R and consts.FQ_P == P.FQ_P
+    assert consts.FR_ROOT_OF_UNITY == P.FR_ROOT_OF_UNITY
+    for k in (0, 1, 5, 17, 19, 28):
+        assert consts.fr_omega(k) == P.fr_omega(k)
+        assert pow(consts.fr_omega(k), 1 << k, consts.FR_R) == 1
+    x = 0x1234567890ABCDEF1234567890ABCDEF
+    limbs = consts.fr_mont_limbs(x)
+    assert consts.limbs_to_int(limbs) == P.to_mont(x, P.FR_R)
+    assert consts.limbs_to_int(consts.int_to_limbs(x, 4)) == x
+
+
+def test_window_ranges_cover_exactly():
+    for W in range(1, 40):
+        for world in (1, 2, 3, 4, 5, 8, 16):
+            seen = []
+            for r in range(world):
+                lo, hi = window_range(W, r, world)
+                seen += list(range(lo, hi))
+            assert seen == list(range(W))
