@@ -170,12 +170,15 @@ __global__ __launch_bounds__(256) void k_msm_totals(u32* __restrict__ slice_hist
 __global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, MsmP p, u32* __restrict__ offs,
                                                   u32* __restrict__ items, u32* __restrict__ heavy,
                                                   u32* __restrict__ heavy_cnt, u32* __restrict__ fold_order,
-                                                  u32* __restrict__ fold_cnt) {
+                                                  u32* __restrict__ fold_cnt, u32* __restrict__ item_order,
+                                                  u32* __restrict__ item_bucket) {
     __shared__ u32 s_cnt[256], s_itm[256];
     __shared__ u32 s_heavy;
     __shared__ u32 s_bin[MSM_HEAVY + 1], s_base[MSM_HEAVY + 1];
+    __shared__ u32 s_obin[MSM_CHUNK + 1], s_obase[MSM_CHUNK + 1];  // work items by chunk size
     if (threadIdx.x == 0) s_heavy = 0;
     if (threadIdx.x <= MSM_HEAVY) s_bin[threadIdx.x] = 0;
+    if (threadIdx.x <= MSM_CHUNK) s_obin[threadIdx.x] = 0;
     __syncthreads();
     const size_t col = blockIdx.x;
     const u32* h = hist + col * p.B;
@@ -193,6 +196,11 @@ __global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, 
             m += ch;
             if (ch > MSM_HEAVY) heavy[col * p.B + atomicAdd(&s_heavy, 1u)] = b;
             else if (ch > 1) atomicAdd(&s_bin[ch], 1u);
+            if (ch) {  // even split: rem chunks of q+1 entries, ch-rem of q
+                const u32 q = v / ch, rem = v % ch;
+                if (rem) atomicAdd(&s_obin[q + 1], rem);
+                atomicAdd(&s_obin[q], ch - rem);
+            }
         }
     }
     s_cnt[threadIdx.x] = c;
@@ -220,6 +228,14 @@ __global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, 
             s_bin[m2] = 0;
         }
         fold_cnt[col] = run;
+        // work items ordered by chunk size, largest first: the lanes of an accumulation wave then run (nearly)
+        // equal trip counts -- real witness columns have most buckets at 1..16 entries
+        run = 0;
+        for (int sz = (int)MSM_CHUNK; sz >= 1; --sz) {
+            s_obase[sz] = run;
+            run += s_obin[sz];
+            s_obin[sz] = 0;
+        }
     }
     __syncthreads();
     c = s_cnt[threadIdx.x];
@@ -234,6 +250,24 @@ __global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, 
             const u32 ch = (v + MSM_CHUNK - 1) / MSM_CHUNK;
             m += ch;
             if (ch > 1 && ch <= MSM_HEAVY) fold_order[col * p.B + s_base[ch] + atomicAdd(&s_bin[ch], 1u)] = b;
+            if (ch) {
+                const u32 q = v / ch, rem = v % ch;
+                const u32 item0 = m - ch;  // this bucket's first work item
+                u32* ord = item_order + col * p.max_items;
+                u32* obk = item_bucket + col * p.max_items;
+                if (rem) {
+                    const u32 pos = s_obase[q + 1] + atomicAdd(&s_obin[q + 1], rem);
+                    for (u32 j = 0; j < rem; ++j) {
+                        ord[pos + j] = item0 + j;
+                        obk[pos + j] = b;
+                    }
+                }
+                const u32 pos = s_obase[q] + atomicAdd(&s_obin[q], ch - rem);
+                for (u32 j = rem; j < ch; ++j) {
+                    ord[pos + j - rem] = item0 + j;
+                    obk[pos + j - rem] = b;
+                }
+            }
         }
     }
 }
@@ -277,22 +311,18 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restri
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_msm_accumulate(const G1Affine* __restrict__ table, MsmP p,
                                                         const u32* __restrict__ offs, const u32* __restrict__ items,
+                                                        const u32* __restrict__ item_order,
+                                                        const u32* __restrict__ item_bucket,
                                                         const u32* __restrict__ entries, G1X* __restrict__ partials) {
     const size_t col = blockIdx.y;
     const u32* it = items + col * (p.B + 1);
     const u32 total = it[p.B];
-    const u32 item = blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= total) return;
-    // bucket b with it[b] <= item < it[b+1]
-    unsigned lo = 0, hi = p.B;
-    while (hi - lo > 1) {
-        unsigned mid = (lo + hi) >> 1;
-        if (it[mid] <= item) lo = mid; else hi = mid;
-    }
-    const unsigned b = lo;
+    const u32 rank = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rank >= total) return;
+    const u32 item = item_order[col * p.max_items + rank];   // chunk-size order (scan kernel)
+    const unsigned b = item_bucket[col * p.max_items + rank];
     const u32* o = offs + col * (p.B + 1);
-    // the bucket's entries are split EVENLY over its chunks (sizes differ by at most one), so the lanes of
-    // a wave run nearly equal trip counts
+    // the bucket's entries are split EVENLY over its chunks (sizes differ by at most one)
     const u32 cnt = o[b + 1] - o[b], nch = it[b + 1] - it[b], j = item - it[b];
     const u32 q = cnt / nch, rem = cnt % nch;
     const u32 start = o[b] + j * q + (j < rem ? j : rem);
@@ -566,7 +596,7 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     p.B = 1u << (bases->c - 1);
     p.cap = n * (size_t)(win_hi - win_lo);
     p.max_items = p.B + p.cap / MSM_CHUNK;
-    void *hist, *offs, *heavy, *items, *entries, *partials, *na, *nb, *totals, *fold;
+    void *hist, *offs, *heavy, *items, *entries, *partials, *na, *nb, *totals, *fold, *iord;
     const unsigned n_slices = pz_div_up(n, SORT_SLICE);
     PZCHK(pz_ws_get(ctx, WS_HIST, nc * (size_t)n_slices * p.B * 4, &hist));
     PZCHK(pz_ws_get(ctx, WS_CURSOR, nc * (size_t)(p.B + 1) * 4, &heavy));
@@ -574,6 +604,9 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     u32* heavy_cnt = (u32*)heavy + nc * (size_t)p.B;
     PZCHK(pz_ws_get(ctx, WS_MISC, nc * (size_t)(p.B + 1) * 4, &fold));
     u32* fold_cnt = (u32*)fold + nc * (size_t)p.B;
+    PZCHK(pz_ws_get(ctx, WS_ORDER, nc * p.max_items * 8, &iord));
+    u32* item_order = (u32*)iord;
+    u32* item_bucket = (u32*)iord + nc * p.max_items;
     PZCHK(pz_ws_get(ctx, WS_OFFS, nc * (p.B + 1) * 4, &offs));
     PZCHK(pz_ws_get(ctx, WS_ITEMS, nc * (p.B + 1) * 4, &items));
     PZCHK(pz_ws_get(ctx, WS_ENTRIES, nc * p.cap * 4 + 16, &entries));
@@ -590,14 +623,14 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     hipLaunchKernelGGL(k_msm_totals, dim3(pz_div_up(p.B, 256), (unsigned)nc), dim3(256), 0, st, (u32*)hist, n_slices, p,
                        (u32*)totals);
     hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)nc), dim3(256), 0, st, (const u32*)totals, p, (u32*)offs, (u32*)items,
-                       (u32*)heavy, heavy_cnt, (u32*)fold, fold_cnt);
+                       (u32*)heavy, heavy_cnt, (u32*)fold, fold_cnt, item_order, item_bucket);
     hipLaunchKernelGGL(k_msm_scatter, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (const u32*)hist, n_slices,
                        (const u32*)offs, (u32*)entries);
     {
         pz_timer tacc(ctx, PZ_T_MSM_ACC);
         hipLaunchKernelGGL(k_msm_accumulate, dim3(pz_div_up(p.max_items, 256), (unsigned)nc), dim3(256), 0, st,
                            (const G1Affine*)bases->d_table, p, (const u32*)offs, (const u32*)items,
-                           (const u32*)entries, (G1X*)partials);
+                           (const u32*)item_order, (const u32*)item_bucket, (const u32*)entries, (G1X*)partials);
     }
     hipLaunchKernelGGL(k_msm_bucket_sum, dim3(pz_div_up(p.B, 256), (unsigned)nc), dim3(256), 0, st, p, (const u32*)items,
                        (const u32*)fold, (const u32*)fold_cnt, (G1X*)partials);
@@ -650,8 +683,8 @@ extern "C" int pz_msm_g1_dev(pz_ctx* ctx, const pz_bases* bases, const uint64_t*
     const size_t cs = col_stride / 4;
     // column groups: bound the sorted-entry workspace (4 B per digit) to ~1 GiB, grid.y to 65535
     const size_t digits = n * (size_t)(win_hi - win_lo);
-    const size_t per_col = digits * 4 + (digits / MSM_CHUNK) * sizeof(G1X) +
-                           (size_t)(1u << (bases->c - 1)) * (172 + 4 * (size_t)pz_div_up(n, SORT_SLICE));
+    const size_t per_col = digits * 4 + (digits / MSM_CHUNK) * (sizeof(G1X) + 8) +
+                           (size_t)(1u << (bases->c - 1)) * (180 + 4 * (size_t)pz_div_up(n, SORT_SLICE));
     // group size: sized for 288 GB of HBM -- by default up to 48 GiB of sort / partial-sum workspace per launch
     // sequence (PZ_MSM_WS_GIB overrides), so the latency-bound tree levels are paid once per ~2000 columns
     size_t ws_budget = pz_msm_ws_gib() << 30;
