@@ -421,7 +421,7 @@ def main():
             "bound": "v_mad_u64_u32 issue", "kernel": "k_msm_accumulate",
             "achieved": (wl.digit_adds * args.steps * 1280.0 / (acc_ms * 1e-3) / 1e12) if (acc_ms > 0 and wl.digit_adds) else None,
             "peak": 24.1, "unit": "T mad/s", "digit_adds_per_proof": wl.digit_adds,
-            "note": "digit_adds = non-zero signed 16-bit digits accumulated per proof, counted on the device",
+            "note": "digit_adds = non-zero 16-bit digits accumulated per proof, estimated on the device from the canonical cell values (signed-recoding carries and negated cells approximated)",
         },
         "breakdown_ms_per_proof": {"trace": trace_ms / args.steps, "expand": exp_ms / args.steps, "msm_all": msm_ms / args.steps,
                                    "msm_accumulate": acc_ms / args.steps, "ntt": ntt_ms / args.steps},

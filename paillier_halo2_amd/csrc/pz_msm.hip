@@ -25,7 +25,7 @@
 #ifndef MSM_CHUNK
 #define MSM_CHUNK 16u
 #endif
-#define MSM_HEAVY 16u  // buckets with more chunks than this are folded by a whole workgroup  // max entries one lane accumulates for one bucket chunk
+#define MSM_HEAVY 24u  // buckets with more chunks than this are folded by a whole workgroup  // max entries one lane accumulates for one bucket chunk
 
 struct MsmP {
     size_t n;          // scalars per column
