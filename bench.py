@@ -128,7 +128,6 @@ class ProofWorkload:
         # NTT buffers
         self.ext_n = 1 << sh.ext_k
         self.ntt_batch = min(pool, 64)
-        self.d_coeff = torch.zeros((self.ntt_batch, self.n, 4), dtype=torch.int64, device=dev)
         self.d_ext = torch.zeros((self.ntt_batch, self.ext_n, 4), dtype=torch.int64, device=dev)
         self.omega_inv = consts.fr_mont_limbs(pow(consts.fr_omega(k), -1, consts.FR_R))
         self.n_inv = consts.fr_mont_limbs(pow(self.n, -1, consts.FR_R))
@@ -224,9 +223,14 @@ class ProofWorkload:
         nb = self.ntt_batch
         while done < self.counts["polys"]:
             nc = min(nb, self.counts["polys"] - done)
-            self.d_coeff[:nc].copy_(self.col_f[:nc])
-            eng.ntt_dev(self.d_coeff.data_ptr(), nc, 4 * n, self.omega_inv, k, None, None)
-            eng.ntt_extend_dev(self.d_coeff.data_ptr(), nc, 4 * n, self.d_ext.data_ptr(), 4 * self.ext_n, k, sh.ext_k - k,
+            # in place on the resident pool columns (as a prover consumes its own columns): they stay uniformly
+            # random field elements from step to step, which is all the NTT's cost depends on
+            off = (done % self.pool)
+            if off + nc > self.pool:
+                off = 0
+            src = self.col_f[off:off + nc]
+            eng.ntt_dev(src.data_ptr(), nc, 4 * n, self.omega_inv, k, None, None)
+            eng.ntt_extend_dev(src.data_ptr(), nc, 4 * n, self.d_ext.data_ptr(), 4 * self.ext_n, k, sh.ext_k - k,
                                self.omega_n, self.coset_gens, self.n_inv)
             done += nc
 

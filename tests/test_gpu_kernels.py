@@ -525,3 +525,51 @@ def test_poly_eval_vs_oracle(eng, cref):
             for v in reversed(c):
                 want = (want * x + v) % P.FR_R  # Horner
             assert got[j] == want, (n, j)
+
+
+def test_end_to_end_columns_and_commitments(eng, cref):
+    """K3 -> K4 -> K1 chained on the device against the independent oracle chain (Python trace -> Python cell
+    expansion -> C best_multiexp): the advice columns of a small encrypt circuit (128-bit n, the reference's test
+    shape) and their commitments, as one integration check of the hot path."""
+    import torch
+
+    nn, g, m, r = P.synth_paillier_inputs(128, 0x6001, standard_g=False)
+    Ln, L, lb, k = 2, 4, 9, 10
+    rows = (1 << k) - 10
+    arr = lambda x: cref.int_to_limbs(x, Ln)
+    c, steps, ng, nr = eng.paillier_encrypt(Ln, arr(nn), arr(g), arr(m), arr(r))
+    tot = int(ng[0]) + int(nr[0]) + 1
+    assert cref.limbs_to_int(c[0]) == P.paillier_enc_native(nn, g, m, r)
+    adv_n, lk_n = eng.witness_cells_per_step(L, 64, lb)
+    ncols = -(-(tot * adv_n) // rows)
+    d_steps = torch.from_numpy(steps[0, :tot].astype(np.int64)).cuda()
+    d_mod = torch.from_numpy(cref.int_to_limbs(nn * nn, L).astype(np.int64)).cuda()
+    d_adv = torch.zeros((ncols * rows, 4), dtype=torch.int64, device="cuda")
+    eng.witness_expand_dev(L, 64, lb, d_steps.data_ptr(), tot, d_mod.data_ptr(), d_adv.data_ptr(), 0)
+    # SRS: Lagrange bases from a seeded toxic scalar, on the device
+    s_toxic = 0x1234567 * 0x89ABCDEF + 5
+    w = P.fr_omega(k)
+    d_l = torch.zeros((1 << k, 8), dtype=torch.int64, device="cuda")
+    eng.srs_setup_g1_dev(k, cref.fr_ints_to_mont([s_toxic])[0], cref.fr_ints_to_mont([w])[0], 0, d_l.data_ptr())
+    eng.sync()
+    tb = eng.load_bases_dev(d_l.data_ptr(), 1 << k)
+    d_out = torch.zeros((ncols, 12), dtype=torch.int64, device="cuda")
+    eng.msm_dev(tb, d_adv.data_ptr(), ncols, rows, 4 * rows, d_out.data_ptr())
+    eng.sync()
+    got = eng.g1_normalize(d_out.cpu().numpy().astype(np.uint64))
+    # oracle chain
+    _, sg, sr, fin = P.encrypt_trace(nn, g, m, r)
+    cells = []
+    for (a, b, q, rr) in sg + sr + [fin]:
+        cells += P.expand_mul_mod_cells(a, b, q, rr, nn * nn, L, lb)[0]
+    assert len(cells) == tot * adv_n
+    cells += [0] * (ncols * rows - len(cells))
+    bases = d_l.cpu().numpy().astype(np.uint64)
+    assert cref.affine_mont_to_ints(bases[:2]) == [
+        P.g1_mul(P.G1_GEN, ((pow(s_toxic, 1 << k, P.FR_R) - 1) * pow(1 << k, -1, P.FR_R) * pow(w, i, P.FR_R)
+                            * pow((s_toxic - pow(w, i, P.FR_R)) % P.FR_R, -1, P.FR_R)) % P.FR_R) for i in range(2)]
+    for j in list(range(0, ncols, max(1, ncols // 12))) + [ncols - 1]:
+        col = cref.fr_ints_to_mont(cells[j * rows:(j + 1) * rows])
+        want = cref.g1_normalize(cref.msm_g1(col, bases[:rows]))
+        assert np.array_equal(got[j], want), j
+    tb.free()
