@@ -64,7 +64,6 @@ class ProofWorkload:
         from paillier_halo2_amd import consts, layout
 
         self.eng, self.torch = eng, torch
-        self.eng2 = None
         self.enc_bits, self.k = enc_bits, k
         self.n = 1 << k
         self.Ln = enc_bits // 64
@@ -86,15 +85,28 @@ class ProofWorkload:
         self.scale = scale
         # K3 output buffer (steps stay in HBM for K4) and the K4 cell streams: the circuit's advice columns are
         # consecutive runs of `rows` cells (2^k minus the blinding rows), lookup columns likewise
-        self.d_steps = torch.zeros((n_steps, 4, self.L), dtype=torch.int64, device=dev)
         self.d_mod = torch.from_numpy(consts.int_to_limbs(nn * nn, self.L).astype(np.int64)).to(dev)
         self.cells, self.lookups = eng.witness_cells_per_step(self.L, 64, self.shape.lookup_bits)
         self.rows = self.n - 10
         self.adv_cols = -(-(n_steps * self.cells) // self.rows)
         self.lk_cols = -(-(n_steps * self.lookups) // self.rows)
-        self.d_adv = torch.zeros((self.adv_cols * self.rows, 4), dtype=torch.int64, device=dev)
-        self.d_lk = torch.zeros((self.lk_cols * self.rows, 4), dtype=torch.int64, device=dev)
+        # proofs are independent, so the witness of proof i+1 (K3 trace: 4 wavefronts busy for 50 ms, then K4) is
+        # produced on a second context / stream while proof i's commitments and NTTs run: two witness slots
+        self.pipeline = os.environ.get("PZ_BENCH_PIPELINE", "1") == "1"
+        nslots = 2 if self.pipeline else 1
+        self.d_steps = [torch.zeros((n_steps, 4, self.L), dtype=torch.int64, device=dev) for _ in range(nslots)]
+        self.d_adv = [torch.zeros((self.adv_cols * self.rows, 4), dtype=torch.int64, device=dev) for _ in range(nslots)]
+        self.d_lk = [torch.zeros((self.lk_cols * self.rows, 4), dtype=torch.int64, device=dev) for _ in range(nslots)]
         self.d_out_adv = torch.zeros((self.adv_cols, 12), dtype=torch.int64, device=dev)
+        self.engw, self.stream_w = eng, None
+        if self.pipeline:
+            import paillier_halo2_amd as pz
+
+            self.engw = pz.Engine(eng.device)
+            self.stream_w = torch.cuda.Stream()
+            self.engw.set_stream(self.stream_w.cuda_stream)
+            self.ready_ev = [torch.cuda.Event() for _ in range(2)]
+            self.free_ev = [torch.cuda.Event() for _ in range(2)]
         self.digit_adds = 0  # filled by count_digit_adds() after a warm-up step
         gen = torch.Generator(device=dev)
         gen.manual_seed(seed)
@@ -108,18 +120,6 @@ class ProofWorkload:
         eng.srs_setup_g1_dev(k, consts.fr_mont_limbs(s_toxic), consts.fr_mont_limbs(consts.fr_omega(k)), 0, d_b.data_ptr())
         eng.sync()
         self.bases = eng.load_bases_dev(d_b.data_ptr(), self.n)
-        if os.environ.get("PZ_BENCH_TWO_STREAMS", "0") == "1":
-            # optional (PZ_BENCH_TWO_STREAMS=1; measured gain 1.6 %, so off by default): a second context on its own
-            # stream, column groups alternate between the two so the latency-bound tail
-            # of one group's reduction tree overlaps the sort / accumulation of the next (contexts are independent
-            # by the ABI's contract; each owns its workspace and its copy of the window table)
-            import paillier_halo2_amd as pz
-
-            self.eng2 = pz.Engine(eng.device)
-            self.stream2 = torch.cuda.Stream()
-            self.eng2.set_stream(self.stream2.cuda_stream)
-            self.bases2 = self.eng2.load_bases_dev(d_b.data_ptr(), self.n)
-            self.d_out2 = torch.zeros((pool, 12), dtype=torch.int64, device=dev)
         del d_b
         # column pools (values synthetic, Montgomery form): witness-like / lookup digits / full width
         self.pool = pool
@@ -150,7 +150,7 @@ class ProofWorkload:
         t = self.torch
         total = 0
         full = self.counts["msm_full"] * self.n * 16 * (1.0 - 2.0 ** -16)
-        for buf, ncols in ((self.d_adv, self.adv_cols), (self.d_lk, self.lk_cols)):
+        for buf, ncols in ((self.d_adv[0], self.adv_cols), (self.d_lk[0], self.lk_cols)):
             if self.scale != 1.0:
                 ncols = max(1, int(round(ncols * self.scale)))
             cells = ncols * self.rows
@@ -173,50 +173,45 @@ class ProofWorkload:
         self.digit_adds = int(total + full)
         return self.digit_adds
 
-    # ---- one pass of the hot path
-    def step(self):
-        eng, t = self.eng, self.torch
-        n, k, sh = self.n, self.k, self.shape
-        # K3: witness trace (steps stay in HBM)
+    # ---- one pass of the hot path = produce(slot) [K3 + K4] then consume(slot) [K1 + K2]
+    def produce(self, slot):
+        eng, t = self.engw, self.torch
+        sh = self.shape
+        if self.pipeline:
+            self.stream_w.wait_event(self.free_ev[slot])  # the previous consumer of this slot has finished reading it
         nn, g, m, r = self.inputs
         if self.circuit == "encrypt":
-            eng.paillier_encrypt_dev(self.Ln, nn, g, m, r, self.d_steps.data_ptr(), self.n_steps)
+            eng.paillier_encrypt_dev(self.Ln, nn, g, m, r, self.d_steps[slot].data_ptr(), self.n_steps)
         else:
             a, b, mod = self.add_ops
             q, rem = eng.mul_mod(self.L, a, b, mod)
-            self.d_steps.copy_(t.from_numpy(np.stack([a, b, q, rem]).astype(np.int64)).view(1, 4, self.L))
+            with (t.cuda.stream(self.stream_w) if self.pipeline else _null()):
+                self.d_steps[slot].copy_(t.from_numpy(np.stack([a, b, q, rem]).astype(np.int64)).view(1, 4, self.L))
         # K4: expand the trace into the advice / lookup cell streams (the circuit's columns)
-        eng.witness_expand_dev(self.L, 64, sh.lookup_bits, self.d_steps.data_ptr(), self.n_steps, self.d_mod.data_ptr(),
-                               self.d_adv.data_ptr(), self.d_lk.data_ptr())
+        eng.witness_expand_dev(self.L, 64, sh.lookup_bits, self.d_steps[slot].data_ptr(), self.n_steps,
+                               self.d_mod.data_ptr(), self.d_adv[slot].data_ptr(), self.d_lk[slot].data_ptr())
+        if self.pipeline:
+            self.ready_ev[slot].record(self.stream_w)
+
+    def consume(self, slot):
+        eng, t = self.eng, self.torch
+        n, k, sh = self.n, self.k, self.shape
+        if self.pipeline:
+            t.cuda.current_stream().wait_event(self.ready_ev[slot])
         # K1: commitments -- every advice and lookup-advice column (real witness cells) ...
-        two = self.eng2 is not None
-        if two:
-            self.stream2.wait_stream(t.cuda.current_stream())  # K4's cells must be complete before stream 2 reads them
-        calls = []
-        for buf, ncols, out in ((self.d_adv, self.adv_cols, self.d_out_adv), (self.d_lk, self.lk_cols, self.d_out_adv)):
+        for buf, ncols in ((self.d_adv[slot], self.adv_cols), (self.d_lk[slot], self.lk_cols)):
             if self.scale != 1.0:
                 ncols = max(1, int(round(ncols * self.scale)))
-            parts = 4 if (two and ncols >= 64) else 1
-            per = -(-ncols // parts)
-            c0 = 0
-            while c0 < ncols:
-                nc = min(per, ncols - c0)
-                calls.append((buf.data_ptr() + c0 * self.rows * 32, nc, self.rows, 4 * self.rows, out.data_ptr() + c0 * 96))
-                c0 += nc
+            eng.msm_dev(self.bases, buf.data_ptr(), ncols, self.rows, 4 * self.rows, self.d_out_adv.data_ptr())
         # ... and the full-width MSMs of the later prover phases (permuted lookup columns, grand products,
         # quotient pieces, openings): uniformly random scalars
         done = 0
         while done < self.counts["msm_full"]:
             nc = min(self.pool, self.counts["msm_full"] - done)
-            calls.append((self.col_f.data_ptr(), nc, n, 4 * n, None))
+            eng.msm_dev(self.bases, self.col_f.data_ptr(), nc, n, 4 * n, self.d_out.data_ptr())
             done += nc
-        for i, (ptr, nc, nn_, stride, outp) in enumerate(calls):
-            if two and (i & 1):
-                self.eng2.msm_dev(self.bases2, ptr, nc, nn_, stride, outp if outp is not None else self.d_out2.data_ptr())
-            else:
-                eng.msm_dev(self.bases, ptr, nc, nn_, stride, outp if outp is not None else self.d_out.data_ptr())
-        if two:
-            t.cuda.current_stream().wait_stream(self.stream2)
+        if self.pipeline:
+            self.free_ev[slot].record(t.cuda.current_stream())
         # K2: Lagrange -> coeff (iNTT 2^k) -> extended coset: 4 interleaved coset NTTs with the 1/n divisor folded into
         # their pre-scale tables (pz_ntt_fr_extend_dev == zero-extend, distribute_powers, best_fft(omega_ext))
         done = 0
@@ -233,6 +228,33 @@ class ProofWorkload:
             eng.ntt_extend_dev(src.data_ptr(), nc, 4 * n, self.d_ext.data_ptr(), 4 * self.ext_n, k, sh.ext_k - k,
                                self.omega_n, self.coset_gens, self.n_inv)
             done += nc
+
+    def run(self, steps):
+        """exactly `steps` passes of the hot path; with PZ_BENCH_PIPELINE the witness of pass i+1 overlaps the
+        commitments / NTTs of pass i (every pass still does all of its work inside the timed region)"""
+        if steps <= 0:
+            return
+        if not self.pipeline:
+            for _ in range(steps):
+                self.produce(0)
+                self.consume(0)
+            return
+        self.produce(0)
+        for i in range(steps):
+            self.consume(i & 1)              # asynchronous: returns once the launches are queued
+            if i + 1 < steps:
+                self.produce((i + 1) & 1)    # its trace call blocks the host while the GPU works on both streams
+
+    def step(self):
+        self.run(1)
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 def cpu_baseline(shape, n_steps, enc_bits, k, log):
@@ -342,18 +364,17 @@ def main():
     wl = ProofWorkload(eng, torch, args.enc_bits, args.k, seed=0x5043 + rank, scale=args.scale,
                        circuit="add" if args.workload == "c3" else "encrypt")
     log("setup %.1fs: %s ; per-step counts %s" % (time.time() - t0, wl.shape, wl.counts))
-    for _ in range(args.warmup):
-        wl.step()
+    wl.run(args.warmup)
     if args.warmup:
+        torch.cuda.synchronize()
         wl.count_digit_adds()
     barrier()
-    engines = [eng] + ([wl.eng2] if wl.eng2 is not None else [])
+    engines = [eng] + ([wl.engw] if wl.engw is not eng else [])
     for e_ in engines:
         e_.timing_enable(True)
         e_.timing_reset()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wl.step()
+    wl.run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     def tsum(which):
@@ -409,7 +430,7 @@ def main():
             "cells_per_mul_mod": wl.cells, "advice_cells": wl.n_steps * wl.cells, "msm_per_proof": n_adv + cnt["msm_full"],
             "ntt_polys_per_proof": cnt["polys"], "scale": args.scale,
             "scope": "hot path only (SURVEY section 8a): transcript, quotient evaluation and product construction stay on the reference's CPU side",
-            "parallelism": "proof replicas, one per GPU, no collective",
+            "parallelism": "proof replicas, one per GPU, no collective", "pipeline_witness_of_next_proof": wl.pipeline,
         },
         "roofline": {
             "bound": "hbm", "kernel": "k_msm_accumulate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
