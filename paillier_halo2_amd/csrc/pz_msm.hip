@@ -11,7 +11,7 @@
 //   * digits are counting-sorted by bucket in HBM (histogram -> scan -> scatter), then one lane
 //     owns one bucket chunk and accumulates in XYZZ coordinates with a gather of 64-byte table
 //     rows (the table stays Infinity-Cache resident across the columns of a batch); over-full
-//     buckets are split into chunks of MSM_CHUNK entries so skewed scalars cannot serialise;
+//     buckets are split into chunks (MsmP::chunk entries at most) so skewed scalars cannot serialise;
 //   * sum_b b*B_b by a radix-16 tree of (weighted sum, plain sum) nodes.
 // Every kernel takes grid.y = column, so a batch of column commitments is one launch sequence.
 //
@@ -22,10 +22,9 @@
 
 #include "pz_internal.h"
 
-#ifndef MSM_CHUNK
-#define MSM_CHUNK 16u
-#endif
-#define MSM_HEAVY 24u  // buckets with more chunks than this are folded by a whole workgroup  // max entries one lane accumulates for one bucket chunk
+#define MSM_CHUNK_MIN 16u   // chunk = max entries one lane accumulates for one bucket work item (MsmP::chunk,
+#define MSM_CHUNK_MAX 256u  // chosen per launch sequence by msm_chunk_for)
+#define MSM_HEAVY 24u       // buckets with more chunks than this are folded by a whole workgroup
 
 struct MsmP {
     size_t n;          // scalars per column
@@ -35,7 +34,8 @@ struct MsmP {
     unsigned win_lo, win_hi;
     unsigned B;        // buckets = 1 << (c-1)
     size_t cap;        // entry capacity per column = n * (win_hi - win_lo)
-    size_t max_items;  // work items per column (upper bound) = B + cap / MSM_CHUNK
+    size_t max_items;  // work items per column (upper bound) = B + cap / chunk
+    unsigned chunk;    // entries per work item, MSM_CHUNK_MIN..MSM_CHUNK_MAX
 };
 
 __device__ __forceinline__ u32 sel8(const u32 s[8], unsigned i) {
@@ -175,10 +175,10 @@ __global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, 
     __shared__ u32 s_cnt[256], s_itm[256];
     __shared__ u32 s_heavy;
     __shared__ u32 s_bin[MSM_HEAVY + 1], s_base[MSM_HEAVY + 1];
-    __shared__ u32 s_obin[MSM_CHUNK + 1], s_obase[MSM_CHUNK + 1];  // work items by chunk size
+    __shared__ u32 s_obin[MSM_CHUNK_MAX + 1], s_obase[MSM_CHUNK_MAX + 1];  // work items by chunk size
     if (threadIdx.x == 0) s_heavy = 0;
     if (threadIdx.x <= MSM_HEAVY) s_bin[threadIdx.x] = 0;
-    if (threadIdx.x <= MSM_CHUNK) s_obin[threadIdx.x] = 0;
+    for (unsigned t = threadIdx.x; t <= MSM_CHUNK_MAX; t += blockDim.x) s_obin[t] = 0;
     __syncthreads();
     const size_t col = blockIdx.x;
     const u32* h = hist + col * p.B;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, 
         if (b < p.B) {
             u32 v = h[b];
             c += v;
-            const u32 ch = (v + MSM_CHUNK - 1) / MSM_CHUNK;
+            const u32 ch = (v + p.chunk - 1) / p.chunk;
             m += ch;
             if (ch > MSM_HEAVY) heavy[col * p.B + atomicAdd(&s_heavy, 1u)] = b;
             else if (ch > 1) atomicAdd(&s_bin[ch], 1u);
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, 
         // work items ordered by chunk size, largest first: the lanes of an accumulation wave then run (nearly)
         // equal trip counts -- real witness columns have most buckets at 1..16 entries
         run = 0;
-        for (int sz = (int)MSM_CHUNK; sz >= 1; --sz) {
+        for (int sz = (int)p.chunk; sz >= 1; --sz) {
             s_obase[sz] = run;
             run += s_obin[sz];
             s_obin[sz] = 0;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, 
             o[b] = c;
             it[b] = m;
             c += v;
-            const u32 ch = (v + MSM_CHUNK - 1) / MSM_CHUNK;
+            const u32 ch = (v + p.chunk - 1) / p.chunk;
             m += ch;
             if (ch > 1 && ch <= MSM_HEAVY) fold_order[col * p.B + s_base[ch] + atomicAdd(&s_bin[ch], 1u)] = b;
             if (ch) {
@@ -314,10 +314,13 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const G1Affine* __restri
                                                         const u32* __restrict__ item_order,
                                                         const u32* __restrict__ item_bucket,
                                                         const u32* __restrict__ entries, G1X* __restrict__ partials) {
-    const size_t col = blockIdx.y;
+    // grid.x = column, grid.y = block of ranks: workgroups are dispatched x-fastest, so the largest items of EVERY
+    // column start first and the chip always holds work of one size class (with the column in grid.y, each column's
+    // few long items pinned its ~128 resident workgroups and the columns went through 8 at a time)
+    const size_t col = blockIdx.x;
     const u32* it = items + col * (p.B + 1);
     const u32 total = it[p.B];
-    const u32 rank = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 rank = blockIdx.y * blockDim.x + threadIdx.x;
     if (rank >= total) return;
     const u32 item = item_order[col * p.max_items + rank];   // chunk-size order (scan kernel)
     const unsigned b = item_bucket[col * p.max_items + rank];
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const G1Affine* __restri
     x_store(partials + col * p.max_items + item, acc);
 }
 
-// A bucket with more than MSM_CHUNK entries owns several consecutive partials; its sum is left in the
+// A bucket with more than MsmP::chunk entries owns several consecutive partials; its sum is left in the
 // first one.  Ordinary buckets (<= MSM_HEAVY chunks): one lane each, a short serial fold -- uniform
 // columns (every bucket ~4 chunks) keep a wave's lanes on the same trip count.  Heavy buckets (short
 // scalars put half of their signed-digit carries into the single bucket "digit 1", tens of thousands of
@@ -347,8 +350,8 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const G1Affine* __restri
 __global__ __launch_bounds__(256) void k_msm_bucket_sum(MsmP p, const u32* __restrict__ items,
                                                         const u32* __restrict__ fold_order,
                                                         const u32* __restrict__ fold_cnt, G1X* __restrict__ partials) {
-    const size_t col = blockIdx.y;
-    const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t col = blockIdx.x;  // as in k_msm_accumulate: rank blocks of all columns together
+    const unsigned r = blockIdx.y * blockDim.x + threadIdx.x;
     if (r >= fold_cnt[col]) return;
     const unsigned b = fold_order[col * p.B + r];
     const u32* it = items + col * (p.B + 1);
@@ -584,8 +587,24 @@ extern "C" int pz_bases_info(const pz_bases* b, size_t* n_points, uint32_t* wind
     return PZ_OK;
 }
 
+// Work items are handed to lanes in chunk-size order, so a wave's lanes run equal trip counts whatever the
+// chunk bound is; the bound only has to leave enough items to fill the chip (>= ~2^20 lanes per launch)
+// and keep a single skewed bucket from serialising.  Larger chunks mean fewer partial sums to write and fold.
+static unsigned msm_chunk_for(size_t n_cols, size_t digits_per_col) {
+    static int env = -1;
+    if (env < 0) {
+        const char* e = getenv("PZ_MSM_CHUNK");
+        env = e ? atoi(e) : 0;
+    }
+    if (env >= (int)MSM_CHUNK_MIN && env <= (int)MSM_CHUNK_MAX) return (unsigned)env;
+    const size_t want = (n_cols * digits_per_col) >> 20;
+    unsigned chunk = MSM_CHUNK_MIN;
+    while (chunk < MSM_CHUNK_MAX && chunk * 2 <= want) chunk *= 2;
+    return chunk;
+}
+
 static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, size_t nc, size_t n, size_t cs,
-                     unsigned win_lo, unsigned win_hi, G1Jac* d_out) {
+                     unsigned win_lo, unsigned win_hi, unsigned chunk, G1Jac* d_out) {
     MsmP p;
     p.n = n;
     p.n_table = bases->n;
@@ -595,7 +614,9 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     p.win_hi = win_hi;
     p.B = 1u << (bases->c - 1);
     p.cap = n * (size_t)(win_hi - win_lo);
-    p.max_items = p.B + p.cap / MSM_CHUNK;
+    p.chunk = chunk;
+    if (p.B + n * (size_t)(win_hi - win_lo) / chunk > 65535u * 256u) return PZ_ERR_CAPACITY;  // grid.y of k_msm_accumulate
+    p.max_items = p.B + p.cap / chunk;
     void *hist, *offs, *heavy, *items, *entries, *partials, *na, *nb, *totals, *fold, *iord;
     const unsigned n_slices = pz_div_up(n, SORT_SLICE);
     PZCHK(pz_ws_get(ctx, WS_HIST, nc * (size_t)n_slices * p.B * 4, &hist));
@@ -628,11 +649,11 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
                        (const u32*)offs, (u32*)entries);
     {
         pz_timer tacc(ctx, PZ_T_MSM_ACC);
-        hipLaunchKernelGGL(k_msm_accumulate, dim3(pz_div_up(p.max_items, 256), (unsigned)nc), dim3(256), 0, st,
+        hipLaunchKernelGGL(k_msm_accumulate, dim3((unsigned)nc, pz_div_up(p.max_items, 256)), dim3(256), 0, st,
                            (const G1Affine*)bases->d_table, p, (const u32*)offs, (const u32*)items,
                            (const u32*)item_order, (const u32*)item_bucket, (const u32*)entries, (G1X*)partials);
     }
-    hipLaunchKernelGGL(k_msm_bucket_sum, dim3(pz_div_up(p.B, 256), (unsigned)nc), dim3(256), 0, st, p, (const u32*)items,
+    hipLaunchKernelGGL(k_msm_bucket_sum, dim3((unsigned)nc, pz_div_up(p.B, 256)), dim3(256), 0, st, p, (const u32*)items,
                        (const u32*)fold, (const u32*)fold_cnt, (G1X*)partials);
     // heavy buckets are few per column in a column batch, but a single large MSM makes every bucket heavy:
     // size grid.x so the launch has ~8k workgroups either way (workgroups beyond the list exit at once)
@@ -683,7 +704,8 @@ extern "C" int pz_msm_g1_dev(pz_ctx* ctx, const pz_bases* bases, const uint64_t*
     const size_t cs = col_stride / 4;
     // column groups: bound the sorted-entry workspace (4 B per digit) to ~1 GiB, grid.y to 65535
     const size_t digits = n * (size_t)(win_hi - win_lo);
-    const size_t per_col = digits * 4 + (digits / MSM_CHUNK) * (sizeof(G1X) + 8) +
+    const unsigned chunk = msm_chunk_for(n_cols, digits);
+    const size_t per_col = digits * 4 + (digits / chunk) * (sizeof(G1X) + 8) +
                            (size_t)(1u << (bases->c - 1)) * (180 + 4 * (size_t)pz_div_up(n, SORT_SLICE));
     // group size: sized for 288 GB of HBM -- by default up to 48 GiB of sort / partial-sum workspace per launch
     // sequence (PZ_MSM_WS_GIB overrides), so the latency-bound tree levels are paid once per ~2000 columns
@@ -704,7 +726,7 @@ extern "C" int pz_msm_g1_dev(pz_ctx* ctx, const pz_bases* bases, const uint64_t*
     if (group > 4096) group = 4096;
     for (size_t c0 = 0; c0 < n_cols; c0 += group) {
         size_t nc = n_cols - c0 < group ? n_cols - c0 : group;
-        PZCHK(msm_group(ctx, bases, (const Fr*)d_scalars + c0 * cs, nc, n, cs, win_lo, win_hi,
+        PZCHK(msm_group(ctx, bases, (const Fr*)d_scalars + c0 * cs, nc, n, cs, win_lo, win_hi, chunk,
                         (G1Jac*)d_out_jac + c0));
     }
     return PZ_OK;
