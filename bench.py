@@ -355,7 +355,7 @@ def main():
     log = (lambda s: print("[bench] " + s, file=sys.stderr, flush=True)) if rank == 0 else (lambda s: None)
 
     eng = pz.Engine(local)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.bind_torch_stream()  # a real stream, current for torch too: the event waits of the pipeline order against it
 
     def barrier():
         torch.cuda.synchronize()

@@ -187,6 +187,41 @@ int pz_srs_setup_g1_dev(pz_ctx* ctx, uint32_t k, const uint64_t s[4], const uint
 int pz_poly_eval_dev(pz_ctx* ctx, const uint64_t* d_coeffs, size_t n_cols, size_t col_stride, size_t n,
                      const uint64_t x[4], uint64_t* d_out);
 
+/* The prover steps between the commitments and the NTTs (in the reference all of
+ * them run inside create_proof, reached from /root/reference/src/bench.rs:161-171).  Device pointers throughout, field
+ * elements Fr Montgomery, strides in uint64_t units; challenges / constants are host pointers to one element. */
+/* halo2 BatchInvert: d_a[i] <- 1 / d_a[i] in place, zeros stay zero. */
+int pz_fr_batch_invert_dev(pz_ctx* ctx, uint64_t* d_a, size_t n);
+/* running product: d_z[0] = z0, d_z[i+1] = d_z[i] * d_a[i] for i < n-1 (n outputs; d_z may alias d_a). */
+int pz_fr_prefix_product_dev(pz_ctx* ctx, const uint64_t* d_a, size_t n, const uint64_t z0[4], uint64_t* d_z);
+/* permutation::Argument::commit for one chunk of m columns over the 2^log_n domain generated by omega:
+ *   d_z[0] = z0,  d_z[i+1] = d_z[i] * prod_{j<m} (v_j[i] + beta*delta_start*delta^j*omega^i + gamma)
+ *                                              / (v_j[i] + beta*sigma_j[i] + gamma)
+ * v_j = d_cols + j*col_stride (Lagrange values), sigma_j = d_sigma + j*sigma_stride (permutation polynomial values).
+ * delta_start = delta^(index of the chunk's first column).  Blinding rows are the caller's business. */
+int pz_permutation_product_dev(pz_ctx* ctx, const uint64_t* d_cols, size_t col_stride, const uint64_t* d_sigma,
+                               size_t sigma_stride, size_t m, uint32_t log_n, const uint64_t omega[4],
+                               const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta_start[4],
+                               const uint64_t delta[4], const uint64_t z0[4], uint64_t* d_z);
+/* evaluate_h, custom-gate part, for halo2-lib's vertical gate on the extended domain of 2^log_ext points:
+ *   for each column j in order:  d_h[i] = d_h[i]*y + sel_j[i] * (a_j[i] + a_j[i+s]*a_j[i+2s] - a_j[i+3s]),
+ * indices mod 2^log_ext, s = rot_step = 2^(log_ext - k) (one row of the 2^k domain).  d_h is read and written. */
+int pz_quotient_gate_dev(pz_ctx* ctx, const uint64_t* d_adv_ext, size_t adv_stride, const uint64_t* d_sel_ext,
+                         size_t sel_stride, size_t n_cols, uint32_t log_ext, uint32_t rot_step, const uint64_t y[4],
+                         uint64_t* d_h);
+/* division by the vanishing polynomial on the extended coset: d_h[i] /= (coset_g * omega_ext^i)^(2^log_n) - 1,
+ * i < 2^(log_n + log_e) (the divisor takes 2^log_e distinct values). */
+int pz_quotient_finish_dev(pz_ctx* ctx, uint64_t* d_h, uint32_t log_n, uint32_t log_e, const uint64_t coset_g[4],
+                           const uint64_t omega_ext[4]);
+/* d_a[col][i] *= c * g^i, i < n (distribute_powers; with g = 1/coset_g the un-scaling step of extended_to_coeff).
+ * c may be NULL (= 1). */
+int pz_fr_distribute_powers_dev(pz_ctx* ctx, uint64_t* d_a, size_t n_cols, size_t col_stride, size_t n,
+                                const uint64_t g[4], const uint64_t c[4]);
+/* kate_division: d_q[col] = (p_col(X) - p_col(x)) / (X - x) for n-coefficient polynomials: n-1 coefficients, the
+ * n-th slot is written as zero (d_q may alias d_coeffs). */
+int pz_poly_div_linear_dev(pz_ctx* ctx, const uint64_t* d_coeffs, size_t n_cols, size_t col_stride, size_t n,
+                           const uint64_t x[4], uint64_t* d_q, size_t q_stride);
+
 /* ---------------------------------------------------------------------------------------------
  * measurement helpers (used by bench.py; not part of the reference surface)
  * ------------------------------------------------------------------------------------------- */

@@ -370,6 +370,90 @@ def coset_scale(a: Sequence[int], g: int) -> List[int]:
 
 
 # ----------------------------------------------------------------------------------------
+# "next" rows: the prover steps between commitments and NTTs.  The reference
+# reaches them only through create_proof (/root/reference/src/bench.rs:161-171); the formulas restate the published
+# halo2 protocol as halo2-axiom implements it (dependency, tag [D]) -- pinned by their defining identities, which
+# tests/test_oracle.py checks (z recurrence, divisibility by X^n - 1, p(X) - p(x) = (X - x) q(X)).
+# ----------------------------------------------------------------------------------------
+def batch_invert(a: Sequence[int]) -> List[int]:
+    """halo2 BatchInvert: zeros stay zero."""
+    return [pow(x, -1, FR_R) if x % FR_R else 0 for x in a]
+
+
+def prefix_product(a: Sequence[int], z0: int = 1) -> List[int]:
+    """z[0] = z0, z[i+1] = z[i] * a[i]  (n outputs; a[n-1] is not consumed)."""
+    z = [z0 % FR_R]
+    for x in a[:-1]:
+        z.append(z[-1] * x % FR_R)
+    return z
+
+
+def permutation_product(cols: Sequence[Sequence[int]], sigmas: Sequence[Sequence[int]], omega: int, beta: int, gamma: int,
+                        delta_start: int, delta: int, z0: int = 1) -> List[int]:
+    """permutation::Argument::commit for one chunk of columns (no blinding rows):
+    z[i+1] = z[i] * prod_j (v_j[i] + beta*delta_start*delta^j*omega^i + gamma) / (v_j[i] + beta*sigma_j[i] + gamma)."""
+    n = len(cols[0]) if cols else 0
+    mv = []
+    w = 1
+    for i in range(n):
+        num = den = 1
+        d = beta * delta_start % FR_R * w % FR_R
+        for v, sg in zip(cols, sigmas):
+            num = num * ((v[i] + d + gamma) % FR_R) % FR_R
+            den = den * ((v[i] + beta * sg[i] + gamma) % FR_R) % FR_R
+            d = d * delta % FR_R
+        mv.append(num * (pow(den, -1, FR_R) if den else 0) % FR_R)
+        w = w * omega % FR_R
+    return prefix_product(mv, z0) if n else []
+
+
+def quotient_gate(adv_ext: Sequence[Sequence[int]], sel_ext: Sequence[Sequence[int]], step: int, y: int,
+                  h: Sequence[int]) -> List[int]:
+    """evaluate_h, custom-gate part: per column (in order) h = h*y + sel*(a0 + a1*a2 - a3), rotations = step indices
+    of the extended domain (halo2-lib's vertical gate q*(a + b*c - d), rows i..i+3)."""
+    N = len(h)
+    out = list(h)
+    for a, q in zip(adv_ext, sel_ext):
+        for i in range(N):
+            e = (a[i] + a[(i + step) % N] * a[(i + 2 * step) % N] - a[(i + 3 * step) % N]) % FR_R
+            out[i] = (out[i] * y + q[i] * e) % FR_R
+    return out
+
+
+def quotient_finish(h: Sequence[int], log_n: int, log_e: int, coset_g: int, omega_ext: int) -> List[int]:
+    """divide by the vanishing polynomial X^n - 1 at the points coset_g * omega_ext^i."""
+    E = 1 << log_e
+    tinv = [pow((pow(coset_g * pow(omega_ext, r, FR_R) % FR_R, 1 << log_n, FR_R) - 1) % FR_R, -1, FR_R) for r in range(E)]
+    return [x * tinv[i % E] % FR_R for i, x in enumerate(h)]
+
+
+def distribute_powers(a: Sequence[int], g: int, c: int = 1) -> List[int]:
+    out, cur = [], c % FR_R
+    for x in a:
+        out.append(x * cur % FR_R)
+        cur = cur * g % FR_R
+    return out
+
+
+def kate_division(a: Sequence[int], x: int) -> List[int]:
+    """halo2 kate_division: q = (p - p(x)) / (X - x); n-1 coefficients, returned zero-padded to n."""
+    n = len(a)
+    q = [0] * n
+    cur = 0
+    for i in range(n - 1, 0, -1):
+        cur = (a[i] + x * cur) % FR_R
+        q[i - 1] = cur
+    return q
+
+
+def poly_eval(a: Sequence[int], x: int) -> int:
+    acc = 0
+    for c in reversed(a):
+        acc = (acc * x + c) % FR_R
+    return acc
+
+
+# ----------------------------------------------------------------------------------------
 # seeded synthetic inputs (SURVEY.md section 8d)
 # ----------------------------------------------------------------------------------------
 def synth_paillier_inputs(enc_bits: int, seed: int, standard_g: bool = True):

@@ -52,6 +52,14 @@ SIGNATURES = {
     "pz_witness_expand_dev": (C.c_int, [VP, C.c_uint32, C.c_uint32, C.c_uint32, VP, C.c_size_t, VP, VP, VP]),
     "pz_srs_setup_g1_dev": (C.c_int, [VP, C.c_uint32, VP, VP, VP, VP]),
     "pz_poly_eval_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, C.c_size_t, VP, VP]),
+    "pz_fr_batch_invert_dev": (C.c_int, [VP, VP, C.c_size_t]),
+    "pz_fr_prefix_product_dev": (C.c_int, [VP, VP, C.c_size_t, VP, VP]),
+    "pz_permutation_product_dev": (C.c_int, [VP, VP, C.c_size_t, VP, C.c_size_t, C.c_size_t, C.c_uint32, VP, VP, VP, VP,
+                                             VP, VP, VP]),
+    "pz_quotient_gate_dev": (C.c_int, [VP, VP, C.c_size_t, VP, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, VP, VP]),
+    "pz_quotient_finish_dev": (C.c_int, [VP, VP, C.c_uint32, C.c_uint32, VP, VP]),
+    "pz_fr_distribute_powers_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, C.c_size_t, VP, VP]),
+    "pz_poly_div_linear_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, C.c_size_t, VP, VP, C.c_size_t]),
     "pz_timing_enable": (C.c_int, [VP, C.c_int]),
     "pz_timing_reset": (C.c_int, [VP]),
     "pz_timing_get": (C.c_int, [VP, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

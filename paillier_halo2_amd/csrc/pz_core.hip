@@ -156,10 +156,20 @@ int pz_get_pow_table(pz_ctx* ctx, const uint64_t base[4], size_t n, void** d_out
     if (!init) init = ONE;
     for (auto& t : ctx->pow_tables)
         if (t.n >= n && memcmp(t.base, base, 32) == 0 && memcmp(t.init, init, 32) == 0) {
+            t.stamp = ++ctx->pow_clock;
             *d_out = t.d;
             return PZ_OK;
         }
+    if (ctx->pow_tables.size() >= 48) {  // evict the least recently used table (kernels still reading it: drain first)
+        size_t lru = 0;
+        for (size_t k = 1; k < ctx->pow_tables.size(); ++k)
+            if (ctx->pow_tables[k].stamp < ctx->pow_tables[lru].stamp) lru = k;
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipFree(ctx->pow_tables[lru].d));
+        ctx->pow_tables.erase(ctx->pow_tables.begin() + lru);
+    }
     pz_pow_table t;
+    t.stamp = ++ctx->pow_clock;
     memcpy(t.base, base, 32);
     memcpy(t.init, init, 32);
     t.n = n;

@@ -17,6 +17,7 @@ struct pz_pow_table {   // cached table init * base^i, i < n  (twiddles omega^i,
     uint64_t init[4];
     size_t n;
     void* d;            // n x 32 B
+    uint64_t stamp;     // last use (LRU: per-proof challenge points would otherwise grow the cache without bound)
 };
 
 struct pz_ext_table {   // packed [2^e][n] pre-scale tables of pz_ntt_fr_extend_dev, keyed by its parameters
@@ -43,6 +44,7 @@ struct pz_ctx {
     char hip_err[256] = {0};
     pz_wsbuf ws[WS_COUNT];
     std::vector<pz_pow_table> pow_tables;
+    uint64_t pow_clock = 0;
     std::vector<pz_ext_table> ext_tables;
     bool timing = false;
     std::vector<pz_event_pair> ev[PZ_T_COUNT];

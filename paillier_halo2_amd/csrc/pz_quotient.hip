@@ -1,0 +1,338 @@
+// pz_quotient.hip -- SURVEY.md section 8f rank 1 and 3: the prover steps that sit between K1/K2 and are the
+// Amdahl remainder once commitments and NTTs run on the GPU.  In the reference they are reached only through
+// bench.rs:161-171 (create_proof inside bench_builder); the formulas are the published halo2 protocol as
+// halo2-axiom implements it (dependency behaviour, SURVEY tag [D]: results are pinned by the mathematics --
+// recurrences, divisibility by X^n - 1, p(X) - p(x) = (X - x) q(X) -- not by reference fixtures).
+//
+//   pz_fr_batch_invert_dev       halo2 BatchInvert: a[i] <- 1/a[i], zeros stay zero (Montgomery's trick, 3 products
+//                                per element + one inversion per K-element strided run)
+//   pz_fr_prefix_product_dev     z[0] = z0, z[i+1] = z[i] * a[i]: the running product of both grand-product arguments
+//   pz_permutation_product_dev   permutation::Argument::commit for one chunk of columns:
+//                                z[i+1] = z[i] * prod_j (v_j[i] + beta*delta^j*w^i + gamma) / (v_j[i] + beta*sigma_j[i] + gamma)
+//   pz_quotient_gate_dev         evaluate_h for halo2-lib's vertical gate q*(a0 + a1*a2 - a3) on the extended coset,
+//                                Horner-folded in the challenge y over the advice columns
+//   pz_quotient_finish_dev       division by the vanishing polynomial on the coset: only 2^e distinct values of x^n - 1
+//   pz_fr_distribute_powers_dev  a[i] *= c * g^i (the coset un-scaling of extended_to_coeff)
+//   pz_poly_div_linear_dev       kate_division: q(X) = (p(X) - p(x)) / (X - x), blocked Horner recurrence
+//
+// All of it is elementwise / scan work on 32-byte field elements: HBM-bound at >= 8 columns per pass, otherwise
+// bound by the field products (3-5 per element).
+#include "fp.cuh"
+#include "pz_internal.h"
+
+static inline Fr fr_from_u64(const uint64_t x[4]) {
+    Fr r;
+    memcpy(r.v, x, 32);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------- batch inversion
+// thread t owns elements t, t+T, t+2T, ... (coalesced across the wave for every j)
+__global__ __launch_bounds__(256) void k_batch_invert(Fr* __restrict__ a, Fr* __restrict__ scratch, size_t n, size_t T,
+                                                      unsigned K) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    Fr acc = fp_one<FrTag>();
+    for (unsigned j = 0; j < K; ++j) {
+        const size_t i = t + (size_t)j * T;
+        if (i >= n) break;
+        Fr v = fp_load<FrTag>(a + i);
+        if (fp_is_zero(v)) continue;
+        fp_store(scratch + i, acc);
+        acc = fp_mul(acc, v);
+    }
+    Fr inv = fp_inv(acc);  // acc is a product of non-zero elements (or 1)
+    for (unsigned j = K; j-- > 0;) {
+        const size_t i = t + (size_t)j * T;
+        if (i >= n) continue;
+        Fr v = fp_load<FrTag>(a + i);
+        if (fp_is_zero(v)) continue;
+        fp_store(a + i, fp_mul(inv, fp_load<FrTag>(scratch + i)));
+        inv = fp_mul(inv, v);
+    }
+}
+
+static int batch_invert(pz_ctx* ctx, Fr* d_a, size_t n) {
+    if (!n) return PZ_OK;
+    void* scr;
+    PZCHK(pz_ws_get(ctx, WS_BIG_A, n * 32, &scr));
+    // one inversion (~380 products) per K elements: K = 64 once there is enough work to keep >= 2^14 threads
+    unsigned K = 8;
+    while (K < 64 && n / (K * 2) >= 16384) K *= 2;
+    const size_t T = pz_div_up(n, K);
+    hipLaunchKernelGGL(k_batch_invert, dim3(pz_div_up(T, 256)), dim3(256), 0, ctx->stream, d_a, (Fr*)scr, n, T, K);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}
+
+extern "C" int pz_fr_batch_invert_dev(pz_ctx* ctx, uint64_t* d_a, size_t n) {
+    if (!ctx || (n && !d_a)) return PZ_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return batch_invert(ctx, (Fr*)d_a, n);
+}
+
+// ---------------------------------------------------------------------------------------------- prefix product
+#define PP_K 16u
+// phase 1: per-thread run products, block-level exclusive scan; excl[t] = product of the block's earlier runs
+__global__ __launch_bounds__(256) void k_pp_local(const Fr* __restrict__ a, size_t n, Fr* __restrict__ excl,
+                                                  Fr* __restrict__ block_tot) {
+    __shared__ Fr s[256];
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t lo = t * PP_K;
+    Fr p = fp_one<FrTag>();
+    for (unsigned j = 0; j < PP_K; ++j)
+        if (lo + j < n) p = fp_mul(p, fp_load<FrTag>(a + lo + j));
+    s[threadIdx.x] = p;
+    __syncthreads();
+    for (unsigned off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scan
+        Fr v = s[threadIdx.x];
+        Fr u = threadIdx.x >= off ? s[threadIdx.x - off] : fp_one<FrTag>();
+        __syncthreads();
+        if (threadIdx.x >= off) s[threadIdx.x] = fp_mul(u, v);
+        __syncthreads();
+    }
+    fp_store(excl + t, threadIdx.x ? s[threadIdx.x - 1] : fp_one<FrTag>());
+    if (threadIdx.x == 255) fp_store(block_tot + blockIdx.x, s[255]);
+}
+// phase 2: exclusive scan of the block totals, seeded with z0 (a few hundred entries: one lane)
+__global__ void k_pp_blocks(Fr* __restrict__ block_tot, unsigned nb, Fr z0) {
+    if (blockIdx.x || threadIdx.x) return;
+    Fr run = z0;
+    for (unsigned b = 0; b < nb; ++b) {
+        Fr t = fp_load<FrTag>(block_tot + b);
+        fp_store(block_tot + b, run);
+        run = fp_mul(run, t);
+    }
+}
+// phase 3: z[i] = block prefix * thread prefix * run prefix
+__global__ __launch_bounds__(256) void k_pp_apply(const Fr* __restrict__ a, size_t n, const Fr* __restrict__ excl,
+                                                  const Fr* __restrict__ block_tot, Fr* __restrict__ z) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t lo = t * PP_K;
+    if (lo >= n) return;
+    Fr cur = fp_mul(fp_load<FrTag>(block_tot + blockIdx.x), fp_load<FrTag>(excl + t));
+    for (unsigned j = 0; j < PP_K && lo + j < n; ++j) {
+        Fr v = fp_load<FrTag>(a + lo + j);  // read before the store: z may alias a
+        fp_store(z + lo + j, cur);
+        cur = fp_mul(cur, v);
+    }
+}
+
+static int prefix_product(pz_ctx* ctx, const Fr* d_a, size_t n, Fr z0, Fr* d_z) {
+    if (!n) return PZ_OK;
+    const unsigned nb = pz_div_up(pz_div_up(n, PP_K), 256);
+    void* ws;
+    PZCHK(pz_ws_get(ctx, WS_BIG_B, ((size_t)nb * 256 + nb) * 32, &ws));
+    Fr* excl = (Fr*)ws;
+    Fr* tot = excl + (size_t)nb * 256;
+    hipLaunchKernelGGL(k_pp_local, dim3(nb), dim3(256), 0, ctx->stream, d_a, n, excl, tot);
+    hipLaunchKernelGGL(k_pp_blocks, dim3(1), dim3(64), 0, ctx->stream, tot, nb, z0);
+    hipLaunchKernelGGL(k_pp_apply, dim3(nb), dim3(256), 0, ctx->stream, d_a, n, (const Fr*)excl, (const Fr*)tot, d_z);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}
+
+extern "C" int pz_fr_prefix_product_dev(pz_ctx* ctx, const uint64_t* d_a, size_t n, const uint64_t z0[4], uint64_t* d_z) {
+    if (!ctx || !z0 || (n && (!d_a || !d_z))) return PZ_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return prefix_product(ctx, (const Fr*)d_a, n, fr_from_u64(z0), (Fr*)d_z);
+}
+
+// ---------------------------------------------------------------------------------------------- permutation product
+__global__ __launch_bounds__(256) void k_perm_terms(const Fr* __restrict__ cols, size_t cs, const Fr* __restrict__ sigma,
+                                                    size_t ss, unsigned m, size_t n, const Fr* __restrict__ wpow, Fr beta,
+                                                    Fr gamma, Fr delta0, Fr delta, Fr* __restrict__ num,
+                                                    Fr* __restrict__ den) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr nm = fp_one<FrTag>(), dn = fp_one<FrTag>();
+    Fr bd = fp_mul(fp_mul(beta, delta0), fp_load<FrTag>(wpow + i));  // beta * delta^j0 * w^i, times delta per column
+    for (unsigned j = 0; j < m; ++j) {
+        Fr v = fp_add(fp_load<FrTag>(cols + (size_t)j * cs + i), gamma);
+        nm = fp_mul(nm, fp_add(v, bd));
+        dn = fp_mul(dn, fp_add(v, fp_mul(beta, fp_load<FrTag>(sigma + (size_t)j * ss + i))));
+        bd = fp_mul(bd, delta);
+    }
+    fp_store(num + i, nm);
+    fp_store(den + i, dn);
+}
+__global__ __launch_bounds__(256) void k_fr_mul_inplace(Fr* __restrict__ a, const Fr* __restrict__ b, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fp_store(a + i, fp_mul(fp_load<FrTag>(a + i), fp_load<FrTag>(b + i)));
+}
+
+extern "C" int pz_permutation_product_dev(pz_ctx* ctx, const uint64_t* d_cols, size_t col_stride, const uint64_t* d_sigma,
+                                          size_t sigma_stride, size_t m, uint32_t log_n, const uint64_t omega[4],
+                                          const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta_start[4],
+                                          const uint64_t delta[4], const uint64_t z0[4], uint64_t* d_z) {
+    if (!ctx || !omega || !beta || !gamma || !delta_start || !delta || !z0 || !d_z || log_n > 26) return PZ_ERR_INVALID;
+    if (m && (!d_cols || !d_sigma)) return PZ_ERR_INVALID;
+    if (col_stride % 4 || sigma_stride % 4 || m > 65535) return PZ_ERR_INVALID;
+    const size_t n = (size_t)1 << log_n;
+    if (m > 1 && (col_stride < 4 * n || sigma_stride < 4 * n)) return PZ_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    void *wp, *ws;
+    PZCHK(pz_get_pow_table(ctx, omega, n, &wp));
+    PZCHK(pz_ws_get(ctx, WS_BIG_C, 2 * n * 32, &ws));
+    Fr* num = (Fr*)ws;
+    Fr* den = num + n;
+    hipLaunchKernelGGL(k_perm_terms, dim3(pz_div_up(n, 256)), dim3(256), 0, ctx->stream, (const Fr*)d_cols, col_stride / 4,
+                       (const Fr*)d_sigma, sigma_stride / 4, (unsigned)m, n, (const Fr*)wp, fr_from_u64(beta), fr_from_u64(gamma),
+                       fr_from_u64(delta_start), fr_from_u64(delta), num, den);
+    HIPCHK(ctx, hipGetLastError());
+    PZCHK(batch_invert(ctx, den, n));
+    hipLaunchKernelGGL(k_fr_mul_inplace, dim3(pz_div_up(n, 256)), dim3(256), 0, ctx->stream, num, (const Fr*)den, n);
+    HIPCHK(ctx, hipGetLastError());
+    return prefix_product(ctx, num, n, fr_from_u64(z0), (Fr*)d_z);
+}
+
+// ---------------------------------------------------------------------------------------------- gate part of evaluate_h
+__global__ __launch_bounds__(256) void k_quotient_gate(const Fr* __restrict__ adv, size_t as, const Fr* __restrict__ sel,
+                                                       size_t ss, unsigned n_cols, size_t N, unsigned step, Fr y,
+                                                       Fr* __restrict__ h) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const size_t i1 = (i + step) & (N - 1), i2 = (i + 2 * (size_t)step) & (N - 1), i3 = (i + 3 * (size_t)step) & (N - 1);
+    Fr acc = fp_load<FrTag>(h + i);
+    for (unsigned j = 0; j < n_cols; ++j) {
+        const Fr* a = adv + (size_t)j * as;
+        Fr e = fp_sub(fp_add(fp_load<FrTag>(a + i), fp_mul(fp_load<FrTag>(a + i1), fp_load<FrTag>(a + i2))),
+                      fp_load<FrTag>(a + i3));
+        e = fp_mul(e, fp_load<FrTag>(sel + (size_t)j * ss + i));
+        acc = fp_add(fp_mul(acc, y), e);
+    }
+    fp_store(h + i, acc);
+}
+
+extern "C" int pz_quotient_gate_dev(pz_ctx* ctx, const uint64_t* d_adv_ext, size_t adv_stride, const uint64_t* d_sel_ext,
+                                    size_t sel_stride, size_t n_cols, uint32_t log_ext, uint32_t rot_step,
+                                    const uint64_t y[4], uint64_t* d_h) {
+    if (!ctx || !y || !d_h || log_ext > 28 || (n_cols && (!d_adv_ext || !d_sel_ext))) return PZ_ERR_INVALID;
+    if (adv_stride % 4 || sel_stride % 4 || n_cols > 0xffffffffu) return PZ_ERR_INVALID;
+    const size_t N = (size_t)1 << log_ext;
+    if (rot_step == 0 || rot_step >= N) return PZ_ERR_INVALID;
+    if (n_cols > 1 && (adv_stride < 4 * N || sel_stride < 4 * N)) return PZ_ERR_INVALID;
+    if (n_cols == 0) return PZ_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_quotient_gate, dim3(pz_div_up(N, 256)), dim3(256), 0, ctx->stream, (const Fr*)d_adv_ext,
+                       adv_stride / 4, (const Fr*)d_sel_ext, sel_stride / 4, (unsigned)n_cols, N, (unsigned)rot_step,
+                       fr_from_u64(y), (Fr*)d_h);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}
+
+// 1 / ((g * w_ext^r)^n - 1), r < E = 2^e: the vanishing polynomial takes only E values on the extended coset
+__global__ void k_vanishing_inv(Fr g, Fr w_ext, unsigned log_n, unsigned E, Fr* __restrict__ out) {
+    const unsigned r = threadIdx.x;
+    if (blockIdx.x || r >= E) return;
+    Fr x = g;
+    for (unsigned k = 0; k < r; ++k) x = fp_mul(x, w_ext);
+    for (unsigned k = 0; k < log_n; ++k) x = fp_sqr(x);
+    fp_store(out + r, fp_inv(fp_sub(x, fp_one<FrTag>())));
+}
+__global__ __launch_bounds__(256) void k_scale_periodic(Fr* __restrict__ h, size_t N, const Fr* __restrict__ tab,
+                                                        unsigned mask) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) fp_store(h + i, fp_mul(fp_load<FrTag>(h + i), fp_load<FrTag>(tab + (i & mask))));
+}
+
+extern "C" int pz_quotient_finish_dev(pz_ctx* ctx, uint64_t* d_h, uint32_t log_n, uint32_t log_e, const uint64_t coset_g[4],
+                                      const uint64_t omega_ext[4]) {
+    if (!ctx || !d_h || !coset_g || !omega_ext || log_e == 0 || log_e > 6 || log_n + log_e > 28) return PZ_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const unsigned E = 1u << log_e;
+    const size_t N = (size_t)1 << (log_n + log_e);
+    void* tab;
+    PZCHK(pz_ws_get(ctx, WS_MISC, E * 32, &tab));
+    hipLaunchKernelGGL(k_vanishing_inv, dim3(1), dim3(64), 0, ctx->stream, fr_from_u64(coset_g), fr_from_u64(omega_ext),
+                       (unsigned)log_n, E, (Fr*)tab);
+    hipLaunchKernelGGL(k_scale_periodic, dim3(pz_div_up(N, 256)), dim3(256), 0, ctx->stream, (Fr*)d_h, N, (const Fr*)tab,
+                       E - 1);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- a[i] *= c * g^i
+__global__ __launch_bounds__(256) void k_mul_table_cols(Fr* __restrict__ a, size_t cs, size_t n, const Fr* __restrict__ tab) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr* p = a + (size_t)blockIdx.y * cs + i;
+    fp_store(p, fp_mul(fp_load<FrTag>(p), fp_load<FrTag>(tab + i)));
+}
+
+extern "C" int pz_fr_distribute_powers_dev(pz_ctx* ctx, uint64_t* d_a, size_t n_cols, size_t col_stride, size_t n,
+                                           const uint64_t g[4], const uint64_t c[4]) {
+    if (!ctx || !g || (n_cols && n && !d_a) || col_stride % 4 || (n_cols > 1 && col_stride < 4 * n)) return PZ_ERR_INVALID;
+    if (n_cols == 0 || n == 0) return PZ_OK;
+    if (n_cols > 65535) return PZ_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    void* tab;
+    PZCHK(pz_get_pow_table(ctx, g, n, &tab, c));
+    hipLaunchKernelGGL(k_mul_table_cols, dim3(pz_div_up(n, 256), (unsigned)n_cols), dim3(256), 0, ctx->stream, (Fr*)d_a,
+                       col_stride / 4, n, (const Fr*)tab);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- kate_division
+// q_{n-2} = a_{n-1}, q_{i-1} = a_i + x * q_i  (the last step's value, p(x), is dropped).  Blocked: chunk c covers
+// coefficients [lo_c, hi_c) = [c*K, (c+1)*K); L_c = sum_{i in c} a_i x^(i - lo_c);
+// carry_in(c) = q_{hi_c - 1} = sum_{i >= hi_c} a_i x^(i - hi_c) = L_{c+1} + x^K carry_in(c+1), carry_in(top) = q_{n-1} = 0
+#define KD_K 64u
+__global__ __launch_bounds__(256) void k_kd_local(const Fr* __restrict__ a, size_t cs, size_t n, Fr x, Fr* __restrict__ L,
+                                                  size_t n_chunks) {
+    const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const Fr* p = a + (size_t)blockIdx.y * cs;
+    const size_t lo = c * KD_K, hi = (lo + KD_K < n ? lo + KD_K : n);
+    Fr v = fp_zero<FrTag>();
+    for (size_t i = hi; i-- > lo;) v = fp_add(fp_mul(v, x), fp_load<FrTag>(p + i));
+    fp_store(L + (size_t)blockIdx.y * n_chunks + c, v);
+}
+__global__ void k_kd_carry(Fr* __restrict__ L, size_t n_chunks, size_t n_cols, Fr x) {
+    const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= n_cols) return;
+    Fr xk = x;
+    for (unsigned s = 1; s < KD_K; s <<= 1) xk = fp_sqr(xk);  // x^64
+    Fr* l = L + col * n_chunks;
+    Fr carry = fp_zero<FrTag>();
+    for (size_t c = n_chunks; c-- > 0;) {
+        Fr t = fp_load<FrTag>(l + c);
+        fp_store(l + c, carry);  // carry_in(c)
+        carry = fp_add(t, fp_mul(xk, carry));
+    }
+}
+__global__ __launch_bounds__(256) void k_kd_apply(const Fr* __restrict__ a, size_t cs, size_t n, Fr x,
+                                                  const Fr* __restrict__ L, size_t n_chunks, Fr* __restrict__ q, size_t qs) {
+    const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const Fr* p = a + (size_t)blockIdx.y * cs;
+    Fr* o = q + (size_t)blockIdx.y * qs;
+    const size_t lo = c * KD_K, hi = (lo + KD_K < n ? lo + KD_K : n);
+    Fr cur = fp_load<FrTag>(L + (size_t)blockIdx.y * n_chunks + c);  // q_{hi-1}
+    for (size_t i = hi; i-- > lo;) {
+        Fr ai = fp_load<FrTag>(p + i);         // read first: q may alias the coefficients
+        fp_store(o + i, cur);                  // q_i (q_{n-1} = 0: the quotient has n-1 coefficients)
+        cur = fp_add(ai, fp_mul(x, cur));      // q_{i-1}; the last one, p(x), is dropped
+    }
+}
+
+extern "C" int pz_poly_div_linear_dev(pz_ctx* ctx, const uint64_t* d_coeffs, size_t n_cols, size_t col_stride, size_t n,
+                                      const uint64_t x[4], uint64_t* d_q, size_t q_stride) {
+    if (!ctx || !x || (n_cols && n && (!d_coeffs || !d_q)) || col_stride % 4 || q_stride % 4) return PZ_ERR_INVALID;
+    if (n_cols > 1 && (col_stride < 4 * n || q_stride < 4 * n)) return PZ_ERR_INVALID;
+    if (n_cols == 0 || n == 0) return PZ_OK;
+    if (n_cols > 65535) return PZ_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t nch = pz_div_up(n, KD_K);
+    void* L;
+    PZCHK(pz_ws_get(ctx, WS_BIG_A, n_cols * nch * 32, &L));
+    Fr xv = fr_from_u64(x);
+    hipLaunchKernelGGL(k_kd_local, dim3(pz_div_up(nch, 256), (unsigned)n_cols), dim3(256), 0, ctx->stream,
+                       (const Fr*)d_coeffs, col_stride / 4, n, xv, (Fr*)L, nch);
+    hipLaunchKernelGGL(k_kd_carry, dim3(pz_div_up(n_cols, 64)), dim3(64), 0, ctx->stream, (Fr*)L, nch, n_cols, xv);
+    hipLaunchKernelGGL(k_kd_apply, dim3(pz_div_up(nch, 256), (unsigned)n_cols), dim3(256), 0, ctx->stream,
+                       (const Fr*)d_coeffs, col_stride / 4, n, xv, (const Fr*)L, nch, (Fr*)d_q, q_stride / 4);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}

@@ -80,6 +80,21 @@ class Engine:
         """stream_handle: a raw hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); 0 = own."""
         self._chk(self.L.pz_set_stream(self.ctx, VP(stream_handle)), "pz_set_stream")
 
+    def bind_torch_stream(self, stream=None):
+        """Run the library on a torch stream (a fresh one by default) and make that stream torch's current one, so
+        torch fills / copies / event waits and the library's kernels are ordered.  torch's DEFAULT stream is the NULL
+        stream, whose handle 0 means "the library's own non-blocking stream" to pz_set_stream -- binding to it
+        orders nothing."""
+        import torch
+
+        if stream is None:
+            stream = torch.cuda.Stream(device=self.device)
+        assert stream.cuda_stream != 0
+        torch.cuda.set_stream(stream)
+        self.set_stream(stream.cuda_stream)
+        self._torch_stream = stream
+        return stream
+
     def sync(self):
         self._chk(self.L.pz_sync(self.ctx), "pz_sync")
 
@@ -267,6 +282,47 @@ class Engine:
     def poly_eval_dev(self, d_coeffs: int, n_cols: int, col_stride_u64: int, n: int, x, d_out: int):
         self._chk(self.L.pz_poly_eval_dev(self.ctx, VP(d_coeffs), n_cols, col_stride_u64, n, _ptr(_np(x).reshape(4)),
                                           VP(d_out)), "pz_poly_eval_dev")
+
+    # ------------------------------------------------------------------ "next" rows: products, quotient, openings
+    def _fr1(self, x):
+        """host pointer to one Fr element; the array is kept referenced until a few calls later (a temporary
+        converted from a list would otherwise be freed before the C call reads it)"""
+        a = _np(x).reshape(4)
+        keep = self.__dict__.setdefault("_keep", [])
+        keep.append(a)
+        del keep[:-32]
+        return _ptr(a)
+
+    def fr_batch_invert_dev(self, d_a: int, n: int):
+        self._chk(self.L.pz_fr_batch_invert_dev(self.ctx, VP(d_a), n), "pz_fr_batch_invert_dev")
+
+    def fr_prefix_product_dev(self, d_a: int, n: int, z0, d_z: int):
+        self._chk(self.L.pz_fr_prefix_product_dev(self.ctx, VP(d_a), n, self._fr1(z0), VP(d_z)), "pz_fr_prefix_product_dev")
+
+    def permutation_product_dev(self, d_cols: int, col_stride_u64: int, d_sigma: int, sigma_stride_u64: int, m: int,
+                                log_n: int, omega, beta, gamma, delta_start, delta, z0, d_z: int):
+        self._chk(self.L.pz_permutation_product_dev(self.ctx, VP(d_cols), col_stride_u64, VP(d_sigma), sigma_stride_u64, m,
+                                                    log_n, self._fr1(omega), self._fr1(beta), self._fr1(gamma),
+                                                    self._fr1(delta_start), self._fr1(delta), self._fr1(z0), VP(d_z)),
+                  "pz_permutation_product_dev")
+
+    def quotient_gate_dev(self, d_adv_ext: int, adv_stride_u64: int, d_sel_ext: int, sel_stride_u64: int, n_cols: int,
+                          log_ext: int, rot_step: int, y, d_h: int):
+        self._chk(self.L.pz_quotient_gate_dev(self.ctx, VP(d_adv_ext), adv_stride_u64, VP(d_sel_ext), sel_stride_u64,
+                                              n_cols, log_ext, rot_step, self._fr1(y), VP(d_h)), "pz_quotient_gate_dev")
+
+    def quotient_finish_dev(self, d_h: int, log_n: int, log_e: int, coset_g, omega_ext):
+        self._chk(self.L.pz_quotient_finish_dev(self.ctx, VP(d_h), log_n, log_e, self._fr1(coset_g), self._fr1(omega_ext)),
+                  "pz_quotient_finish_dev")
+
+    def fr_distribute_powers_dev(self, d_a: int, n_cols: int, col_stride_u64: int, n: int, g, c=None):
+        self._chk(self.L.pz_fr_distribute_powers_dev(self.ctx, VP(d_a), n_cols, col_stride_u64, n, self._fr1(g),
+                                                     self._fr1(c) if c is not None else None),
+                  "pz_fr_distribute_powers_dev")
+
+    def poly_div_linear_dev(self, d_coeffs: int, n_cols: int, col_stride_u64: int, n: int, x, d_q: int, q_stride_u64: int):
+        self._chk(self.L.pz_poly_div_linear_dev(self.ctx, VP(d_coeffs), n_cols, col_stride_u64, n, self._fr1(x), VP(d_q),
+                                                q_stride_u64), "pz_poly_div_linear_dev")
 
     # ------------------------------------------------------------------ measurement
     def timing_enable(self, on: bool = True):

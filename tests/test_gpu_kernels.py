@@ -19,6 +19,7 @@ def eng():
     import paillier_halo2_amd as pz
 
     e = pz.Engine(0)
+    e.bind_torch_stream()  # torch fills / copies and the library's kernels in one order
     yield e
     e.close()
 

@@ -1,0 +1,267 @@
+"""GPU parity tests of the "next" rows: grand products, the custom-gate part of
+the quotient, division by the vanishing polynomial, kate_division -- through the C ABI against oracle/pyref.py, plus
+size-independent properties (the quotient of a REAL K3 -> K4 witness column is a polynomial of the right degree and
+satisfies h(x) (x^n - 1) = gate(x) at a random point)."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import pyref as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import paillier_halo2_amd as pz
+
+    e = pz.Engine(0)
+    e.bind_torch_stream()  # torch fills / copies and the library's kernels in one order
+    yield e
+    e.close()
+
+
+def _dev(cref, ints):
+    """list (or list of lists) of field ints -> int64 CUDA tensor of Montgomery limbs"""
+    import torch
+
+    a = np.asarray(cref.fr_ints_to_mont([x for row in ints for x in row] if ints and isinstance(ints[0], list) else ints))
+    if ints and isinstance(ints[0], list):
+        a = a.reshape(len(ints), -1, 4)
+    return torch.from_numpy(a.astype(np.int64)).cuda()
+
+
+def _ints(cref, t):
+    return cref.fr_mont_to_ints(t.cpu().numpy().astype(np.uint64).reshape(-1, 4))
+
+
+def _m(cref, x):
+    return cref.fr_ints_to_mont([x % P.FR_R])[0]
+
+
+@pytest.mark.parametrize("n", [1, 5, 64, 1000, (1 << 17) + 3])
+def test_batch_invert_vs_oracle(eng, cref, n):
+    rng = random.Random(400 + n)
+    a = [rng.randrange(P.FR_R) for _ in range(n)]
+    for i in range(0, n, 7):
+        a[i] = 0  # zeros stay zero (halo2 BatchInvert)
+    d = _dev(cref, a)
+    eng.fr_batch_invert_dev(d.data_ptr(), n)
+    eng.sync()
+    got = _ints(cref, d)
+    if n <= 1000:
+        assert got == P.batch_invert(a)
+    else:  # property at size: a * a^-1 == 1 on the non-zeros, a sample against the oracle
+        idx = rng.sample(range(n), 200)
+        assert all((got[i] * a[i] % P.FR_R == 1) if a[i] else got[i] == 0 for i in range(n))
+        assert [got[i] for i in idx] == P.batch_invert([a[i] for i in idx])
+
+
+@pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 4096, 4097, 70001])
+def test_prefix_product_vs_oracle(eng, cref, n):
+    import torch
+
+    rng = random.Random(410 + n)
+    a = [rng.randrange(P.FR_R) for _ in range(n)]
+    z0 = rng.randrange(1, P.FR_R)
+    d = _dev(cref, a)
+    d_z = torch.zeros_like(d)
+    eng.fr_prefix_product_dev(d.data_ptr(), n, _m(cref, z0), d_z.data_ptr())
+    eng.sync()
+    want = P.prefix_product(a, z0)
+    assert _ints(cref, d_z) == want
+    eng.fr_prefix_product_dev(d.data_ptr(), n, _m(cref, z0), d.data_ptr())  # in place
+    eng.sync()
+    assert _ints(cref, d) == want
+
+
+@pytest.mark.parametrize("log_n,m", [(4, 1), (6, 3), (10, 4)])
+def test_permutation_product_vs_oracle(eng, cref, log_n, m):
+    import torch
+
+    rng = random.Random(420 + log_n)
+    n = 1 << log_n
+    omega, delta = P.fr_omega(log_n), pow(P.FR_GENERATOR, 1 << P.FR_S, P.FR_R)
+    beta, gamma, z0 = (rng.randrange(1, P.FR_R) for _ in range(3))
+    dstart = pow(delta, 5, P.FR_R)
+    # a real permutation of the m*n cells with values constant on its cycles: the product telescopes to 1
+    labels = [[dstart * pow(delta, j, P.FR_R) * pow(omega, i, P.FR_R) % P.FR_R for i in range(n)] for j in range(m)]
+    cells = [(j, i) for j in range(m) for i in range(n)]
+    perm = list(cells)
+    rng.shuffle(perm)
+    sigma = [[0] * n for _ in range(m)]
+    val = [[None] * n for _ in range(m)]
+    for (j, i), (pj, pi) in zip(cells, perm):
+        sigma[j][i] = labels[pj][pi]
+    for (j, i) in cells:  # fill cycle by cycle
+        if val[j][i] is None:
+            v = rng.randrange(P.FR_R)
+            cj, ci = j, i
+            while val[cj][ci] is None:
+                val[cj][ci] = v
+                cj, ci = perm[cj * n + ci]
+    stride = 4 * n + 8
+    d_cols = torch.zeros((m, stride), dtype=torch.int64, device="cuda")
+    d_sig = torch.zeros((m, stride), dtype=torch.int64, device="cuda")
+    d_cols[:, : 4 * n] = _dev(cref, val).reshape(m, 4 * n)
+    d_sig[:, : 4 * n] = _dev(cref, sigma).reshape(m, 4 * n)
+    d_z = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    eng.permutation_product_dev(d_cols.data_ptr(), stride, d_sig.data_ptr(), stride, m, log_n, _m(cref, omega),
+                                _m(cref, beta), _m(cref, gamma), _m(cref, dstart), _m(cref, delta), _m(cref, z0),
+                                d_z.data_ptr())
+    eng.sync()
+    got = _ints(cref, d_z)
+    want = P.permutation_product(val, sigma, omega, beta, gamma, dstart, delta, z0)
+    assert got == want
+    # telescoping: one more factor returns to z0
+    i = n - 1
+    num = den = 1
+    for j in range(m):
+        num = num * (val[j][i] + beta * labels[j][i] + gamma) % P.FR_R
+        den = den * (val[j][i] + beta * sigma[j][i] + gamma) % P.FR_R
+    assert got[-1] * num % P.FR_R == z0 * den % P.FR_R
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 1 << 13])
+def test_kate_division_vs_oracle(eng, cref, n):
+    import torch
+
+    rng = random.Random(430 + n)
+    cols = [[rng.randrange(P.FR_R) for _ in range(n)] for _ in range(3)]
+    x = rng.randrange(P.FR_R)
+    d = _dev(cref, cols)
+    d_q = torch.zeros_like(d)
+    eng.poly_div_linear_dev(d.data_ptr(), 3, 4 * n, n, _m(cref, x), d_q.data_ptr(), 4 * n)
+    eng.sync()
+    got = _ints(cref, d_q)
+    for j in range(3):
+        assert got[j * n:(j + 1) * n] == P.kate_division(cols[j], x), (n, j)
+    eng.poly_div_linear_dev(d.data_ptr(), 3, 4 * n, n, _m(cref, x), d.data_ptr(), 4 * n)  # in place
+    eng.sync()
+    assert _ints(cref, d) == got
+
+
+def test_kate_division_identity_at_scale(eng, cref):
+    """2^17 coefficients (the c2 column size): p(t) - p(x) == (t - x) q(t) at a random t, via pz_poly_eval_dev"""
+    import torch
+
+    n, ncols = 1 << 17, 4
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(440)
+    d = torch.randint(-(1 << 63), (1 << 63) - 1, (ncols, n, 4), dtype=torch.int64, device="cuda", generator=gen)
+    d[:, :, 3] &= 0x0FFFFFFFFFFFFFFF
+    rng = random.Random(441)
+    x, t = rng.randrange(P.FR_R), rng.randrange(P.FR_R)
+    d_q = torch.zeros_like(d)
+    eng.poly_div_linear_dev(d.data_ptr(), ncols, 4 * n, n, _m(cref, x), d_q.data_ptr(), 4 * n)
+    ev = torch.zeros((3, ncols, 4), dtype=torch.int64, device="cuda")
+    eng.poly_eval_dev(d.data_ptr(), ncols, 4 * n, n, _m(cref, t), ev[0].data_ptr())
+    eng.poly_eval_dev(d.data_ptr(), ncols, 4 * n, n, _m(cref, x), ev[1].data_ptr())
+    eng.poly_eval_dev(d_q.data_ptr(), ncols, 4 * n, n, _m(cref, t), ev[2].data_ptr())
+    eng.sync()
+    pt, px, qt = (_ints(cref, ev[k]) for k in range(3))
+    for j in range(ncols):
+        assert (pt[j] - px[j]) % P.FR_R == (t - x) * qt[j] % P.FR_R, j
+
+
+@pytest.mark.parametrize("log_n,log_e,ncols", [(3, 2, 1), (5, 2, 3), (6, 1, 2)])
+def test_quotient_gate_finish_distribute_vs_oracle(eng, cref, log_n, log_e, ncols):
+    import torch
+
+    rng = random.Random(450 + log_n)
+    N, step = 1 << (log_n + log_e), 1 << log_e
+    adv = [[rng.randrange(P.FR_R) for _ in range(N)] for _ in range(ncols)]
+    sel = [[rng.randrange(P.FR_R) for _ in range(N)] for _ in range(ncols)]
+    h0 = [rng.randrange(P.FR_R) for _ in range(N)]
+    y, g, c = (rng.randrange(1, P.FR_R) for _ in range(3))
+    w_ext = P.fr_omega(log_n + log_e)
+    d_a, d_s, d_h = _dev(cref, adv), _dev(cref, sel), _dev(cref, h0)
+    eng.quotient_gate_dev(d_a.data_ptr(), 4 * N, d_s.data_ptr(), 4 * N, ncols, log_n + log_e, step, _m(cref, y), d_h.data_ptr())
+    eng.sync()
+    want = P.quotient_gate(adv, sel, step, y, h0)
+    assert _ints(cref, d_h) == want
+    eng.quotient_finish_dev(d_h.data_ptr(), log_n, log_e, _m(cref, g), _m(cref, w_ext))
+    eng.sync()
+    want = P.quotient_finish(want, log_n, log_e, g, w_ext)
+    assert _ints(cref, d_h) == want
+    eng.fr_distribute_powers_dev(d_h.data_ptr(), 1, 4 * N, N, _m(cref, g), _m(cref, c))
+    eng.sync()
+    assert _ints(cref, d_h) == P.distribute_powers(want, g, c)
+    eng.fr_distribute_powers_dev(d_a.data_ptr(), ncols, 4 * N, N, _m(cref, g))  # c = NULL -> 1, batched
+    eng.sync()
+    got = _ints(cref, d_a)
+    for j in range(ncols):
+        assert got[j * N:(j + 1) * N] == P.distribute_powers(adv[j], g), j
+
+
+def test_quotient_of_real_witness_columns(eng, cref):
+    """K3 -> K4 -> K2 -> quotient on the device with a 128-bit key: the advice columns built from the real cell stream
+    satisfy the gate on the whole domain, so sum_j y^(..) q_j (a_j + a_j(wX) a_j(w^2 X) - a_j(w^3 X)) is divisible by
+    X^n - 1: the quotient the library returns has degree <= 2n - 3 and satisfies the identity at a random point."""
+    import torch
+
+    nn, g, m, r = P.synth_paillier_inputs(128, 0x5042, standard_g=False)
+    Ln, L, k = 2, 4, 12
+    lb, n, E, log_e = k - 1, 1 << k, 4, 2
+    arr = lambda x: cref.int_to_limbs(x, Ln)
+    _, steps, ng, nr = eng.paillier_encrypt(Ln, arr(nn), arr(g), arr(m), arr(r))
+    tot = int(ng[0]) + int(nr[0]) + 1
+    adv_n, lk_n = eng.witness_cells_per_step(L, 64, lb)
+    per_col = (n - 10) // adv_n   # whole mul_mod blocks per column: halo2-lib never splits a gate across columns
+    assert per_col >= 1
+    ncols = 5
+    use = ncols * per_col
+    assert use <= tot
+    d_steps = torch.from_numpy(steps[0, :use].astype(np.int64)).cuda()
+    d_mod = torch.from_numpy(cref.int_to_limbs(nn * nn, L).astype(np.int64)).cuda()
+    d_cells = torch.zeros((use, adv_n, 4), dtype=torch.int64, device="cuda")
+    eng.witness_expand_dev(L, 64, lb, d_steps.data_ptr(), use, d_mod.data_ptr(), d_cells.data_ptr(), 0)
+    gates, end = P.gate_offsets_mul_mod(L, lb)
+    assert end == adv_n
+    d_cols = torch.zeros((ncols, n, 4), dtype=torch.int64, device="cuda")
+    sel = np.zeros((ncols, n), dtype=np.uint64)
+    for c in range(ncols):
+        d_cols[c, : per_col * adv_n] = d_cells[c * per_col:(c + 1) * per_col].reshape(-1, 4)
+        for b in range(per_col):
+            sel[c, [b * adv_n + o for o in gates]] = 1
+    one = np.asarray(_m(cref, 1), dtype=np.uint64)
+    d_sel = torch.from_numpy((sel[:, :, None] * one[None, None, :]).astype(np.int64)).cuda()
+    # Lagrange -> coefficients -> extended coset, both column sets
+    w_n, w_ext = P.fr_omega(k), P.fr_omega(k + log_e)
+    cg = P.FR_GENERATOR
+    gens = np.stack([_m(cref, cg * pow(w_ext, rr, P.FR_R)) for rr in range(E)])
+    ext = []
+    for d in (d_cols, d_sel):
+        eng.ntt_dev(d.data_ptr(), ncols, 4 * n, _m(cref, pow(w_n, -1, P.FR_R)), k, None, _m(cref, pow(n, -1, P.FR_R)))
+        e = torch.zeros((ncols, n * E, 4), dtype=torch.int64, device="cuda")
+        eng.ntt_extend_dev(d.data_ptr(), ncols, 4 * n, e.data_ptr(), 4 * n * E, k, log_e, _m(cref, w_n), gens, None)
+        ext.append(e)
+    rng = random.Random(460)
+    y, x = rng.randrange(1, P.FR_R), rng.randrange(2, P.FR_R)
+    d_h = torch.zeros((n * E, 4), dtype=torch.int64, device="cuda")
+    eng.quotient_gate_dev(ext[0].data_ptr(), 4 * n * E, ext[1].data_ptr(), 4 * n * E, ncols, k + log_e, E, _m(cref, y),
+                          d_h.data_ptr())
+    eng.quotient_finish_dev(d_h.data_ptr(), k, log_e, _m(cref, cg), _m(cref, w_ext))
+    # extended_to_coeff: inverse NTT over the extended domain, then undo the coset shift
+    eng.ntt_dev(d_h.data_ptr(), 1, 4 * n * E, _m(cref, pow(w_ext, -1, P.FR_R)), k + log_e, None,
+                _m(cref, pow(n * E, -1, P.FR_R)))
+    eng.fr_distribute_powers_dev(d_h.data_ptr(), 1, 4 * n * E, n * E, _m(cref, pow(cg, -1, P.FR_R)))
+    eng.sync()
+    hc = d_h.cpu().numpy()
+    assert hc[: 2 * n - 2].any()                 # a non-trivial quotient ...
+    assert not hc[2 * n - 2:].any()              # ... of degree <= 2n - 3: the gate expression vanishes on the domain
+    # identity at a random point, all evaluations by the library from the coefficient forms
+    ev = torch.zeros((6, ncols, 4), dtype=torch.int64, device="cuda")
+    for t in range(4):
+        eng.poly_eval_dev(d_cols.data_ptr(), ncols, 4 * n, n, _m(cref, x * pow(w_n, t, P.FR_R)), ev[t].data_ptr())
+    eng.poly_eval_dev(d_sel.data_ptr(), ncols, 4 * n, n, _m(cref, x), ev[4].data_ptr())
+    eng.poly_eval_dev(d_h.data_ptr(), 1, 4 * n * E, n * E, _m(cref, x), ev[5].data_ptr())
+    eng.sync()
+    a0, a1, a2, a3, q = (_ints(cref, ev[t]) for t in range(5))
+    hx = _ints(cref, ev[5])[0]
+    lhs = 0
+    for j in range(ncols):
+        lhs = (lhs * y + q[j] * (a0[j] + a1[j] * a2[j] - a3[j])) % P.FR_R
+    assert lhs == hx * (pow(x, n, P.FR_R) - 1) % P.FR_R
+    assert lhs != 0

@@ -191,3 +191,39 @@ def test_cell_stream_satisfies_the_gate():
         assert adv[off_lt - 1] == 0
     except AssertionError:
         raise
+
+
+# ------------------------------------------------------------------------------------------ next rows
+def test_next_row_oracles_satisfy_their_defining_identities():
+    """the oracle's grand-product / quotient / opening helpers are pinned by their identities (no reference fixture
+    exists for them: dependency behaviour, SURVEY tag [D])"""
+    rng = random.Random(77)
+    R = P.FR_R
+    a = [rng.randrange(R) for _ in range(33)]
+    a[5] = 0
+    inv = P.batch_invert(a)
+    assert all((x * y % R == 1) if x else y == 0 for x, y in zip(a, inv))
+    z = P.prefix_product(a, 9)
+    assert z[0] == 9 and all(z[i + 1] == z[i] * a[i] % R for i in range(len(a) - 1)) and len(z) == len(a)
+    # kate_division: p(t) - p(x) == (t - x) q(t)
+    x, t = rng.randrange(R), rng.randrange(R)
+    q = P.kate_division(a, x)
+    assert q[-1] == 0
+    assert (P.poly_eval(a, t) - P.poly_eval(a, x)) % R == (t - x) * P.poly_eval(q, t) % R
+    # quotient of a gate-satisfying column: h (X^n - 1) == q (a0 + a1 a2 - a3)
+    log_n, log_e = 3, 2
+    n, N = 1 << log_n, 1 << (log_n + log_e)
+    w_n, w_ext, g = P.fr_omega(log_n), P.fr_omega(log_n + log_e), P.FR_GENERATOR
+    col = [rng.randrange(R) for _ in range(n)]
+    col[3] = (col[0] + col[1] * col[2]) % R      # gate enabled at row 0
+    sel = [1] + [0] * (n - 1)
+    def extend(v):
+        c = P.intt(v, w_n) + [0] * (N - n)
+        return P.ntt(P.coset_scale(c, g), w_ext)
+    h = P.quotient_finish(P.quotient_gate([extend(col)], [extend(sel)], 1 << log_e, 1, [0] * N), log_n, log_e, g, w_ext)
+    hc = P.distribute_powers(P.intt(h, w_ext), pow(g, -1, R))
+    assert not any(hc[2 * n - 2:]) and any(hc)
+    cc, sc = P.intt(col, w_n), P.intt(sel, w_n)
+    ev = lambda c, pt: P.poly_eval(c, pt)
+    lhs = ev(sc, x) * (ev(cc, x) + ev(cc, x * w_n % R) * ev(cc, x * w_n * w_n % R) - ev(cc, x * pow(w_n, 3, R) % R)) % R
+    assert lhs == ev(hc, x) * (pow(x, n, R) - 1) % R
