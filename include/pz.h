@@ -163,10 +163,14 @@ int pz_paillier_encrypt_dev(pz_ctx* ctx, uint32_t limbs_n, size_t batch, const u
  * mul_mod (limb convolutions, range-check digit splits, carry chains).  Replaces the cell pushes
  * behind the dependency call sites paillier.rs:39-57, bench.rs:44-74.  Layout: DESIGN.md section 4.
  * ------------------------------------------------------------------------------------------- */
+/* `limbs` = the circuit's limbs per big integer, each `limb_bits` wide (16..90: the reference uses 64 in
+ * bench.rs:140 / paillier.rs:116 and 88 in its add test, paillier.rs:186-187).  Step records stay what K3 emits:
+ * little-endian 64-bit words, words = ceil(limbs * limb_bits / 64) per big integer (== limbs at limb_bits 64);
+ * K4 re-cuts them into limb_bits-wide limbs.  PZ_ERR_UNSUPPORTED outside 2*limb_bits + log2(limbs) + 3 <= 192. */
 /* cells one mul_mod step expands to, for the given shape */
 int pz_witness_cells_per_step(uint32_t limbs, uint32_t limb_bits, uint32_t lookup_bits, size_t* advice_cells,
                               size_t* lookup_cells);
-/* d_steps: n_steps steps on the device (a|b|q|r, `limbs` limbs each), d_modulus: `limbs` limbs on
+/* d_steps: n_steps steps on the device (a|b|q|r, `words` 64-bit words each), d_modulus: `words` words on
  * the device; writes n_steps*advice_cells Fr elements to d_advice and n_steps*lookup_cells to
  * d_lookup (either may be NULL to skip). */
 int pz_witness_expand_dev(pz_ctx* ctx, uint32_t limbs, uint32_t limb_bits, uint32_t lookup_bits,

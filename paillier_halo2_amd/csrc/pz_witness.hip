@@ -7,6 +7,7 @@
 // digit splits | limb convolution a*b | limb convolution q*n | qn + r | carry chain of
 // is_equal_muled | r < n); the value semantics are restated in oracle/pyref.py::expand_mul_mod_cells.
 //
+// Step records are 64-bit words; limbs of any width 16..90 bits are cut out of them into LDS.
 // One workgroup (4 waves) per step.  The two convolutions are 76 % of the cells: a wave owns a
 // product limb (row), lanes own the terms, partial sums come from a 192-bit wave prefix scan, every
 // lane writes a contiguous 96/192-byte run -> fully coalesced streaming stores.  Operand limbs are
@@ -132,13 +133,39 @@ __device__ __forceinline__ void mul64w(u64 a, u64 b, u64& hi, u64& lo) {
     hi = (u64)a1 * b1 + (t >> 32) + (u >> 32);
 }
 
+// product of two limbs of at most 96 bits (x = x0 + x1 2^64, x1 < 2^32): < 2^192.  `wide` is kernel-uniform
+// (limb_bits > 64); the 64-bit-limb configuration pays one 64x64 product as before.
+__device__ __forceinline__ U192 u_mul_limb(const U192& x, const U192& y, bool wide) {
+    u64 hi, lo;
+    mul64w(x.w[0], y.w[0], hi, lo);
+    U192 r = u_make(lo, hi, 0);
+    if (wide) {
+        u64 h1, l1, h2, l2;
+        mul64w(x.w[0], y.w[1], h1, l1);
+        mul64w(x.w[1], y.w[0], h2, l2);
+        r = u_add(r, u_make(0, l1, h1));
+        r = u_add(r, u_make(0, l2, h2));
+        r = u_add(r, u_make(0, 0, x.w[1] * y.w[1]));
+    }
+    return r;
+}
+// limb i (W bits) of the little-endian 64-bit-word integer `words[0..nw)`
+__device__ __forceinline__ void limb_extract(const u64* __restrict__ words, unsigned nw, unsigned i, unsigned W, u64 out[2]) {
+    const unsigned o = i * W, wi = o >> 6, sh = o & 63;
+    const u64 w0 = wi < nw ? words[wi] : 0, w1 = wi + 1 < nw ? words[wi + 1] : 0, w2 = wi + 2 < nw ? words[wi + 2] : 0;
+    U192 v = u_lowbits(u_shr(u_make(w0, w1, w2), sh), W);
+    out[0] = v.w[0];
+    out[1] = v.w[1];
+}
+
 struct ExpP {
     unsigned L, D, lb;
-    unsigned k64, rem64, rc64_adv, rc64_lk;   // range_check(limb, 64)
+    unsigned W, L64;                          // circuit limb width; 64-bit words per big integer of a step record
+    unsigned k64, rem64, rc64_adv, rc64_lk;   // range_check(limb, W)   (names from the 64-bit-limb first version)
     unsigned cb, kcb, remcb, rccb_adv, rccb_lk;  // range_check(carry, cb)
     size_t off_assign, off_ab, off_qn, off_add, off_eq, off_lt, cells;
     size_t lk_assign, lk_eq, lk_lt, lookups;
-    u64 max_w[3];  // L*(2^64-1)^2 + (2^64-1)
+    u64 max_w[3];  // L*(2^W-1)^2 + (2^W-1)
 };
 
 // position p of RangeChip::range_check(x, bits): advice pattern
@@ -185,17 +212,17 @@ __device__ __noinline__ Fr is_equal_cell(const U192& x, const U192& y, unsigned 
         default: return fp_zero<FrTag>();
     }
 }
-// 22 cells of div_mod_unsafe(v, 2^64)
-__device__ __forceinline__ Fr div_mod_cell(const U192& v, unsigned p) {
-    const U192 qd = u_shr(v, 64);
-    const U192 rd = u_make(v.w[0]);
-    const U192 prod = u_shl(qd, 64);
+// 22 cells of div_mod_unsafe(v, 2^W)
+__device__ __forceinline__ Fr div_mod_cell(const U192& v, unsigned p, unsigned W) {
+    const U192 qd = u_shr(v, W);
+    const U192 rd = u_lowbits(v, W);
+    const U192 prod = u_shl(qd, W);
     switch (p) {
         case 0: return fr_from_u(qd);
         case 1: return fr_from_u(rd);
         case 2: return fp_zero<FrTag>();
         case 3: return fr_from_u(qd);
-        case 4: return fr_from_u(u_make(0, 1));
+        case 4: return fr_from_u(u_shl(u_make(1), W));
         case 5: return fr_from_u(prod);
         case 6: return fr_from_u(rd);  // v - prod
         case 7: return fr_from_u(prod);
@@ -211,34 +238,40 @@ __device__ __forceinline__ Fr div_mod_cell(const U192& v, unsigned p) {
 __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u64* __restrict__ steps,
                                                                 const u64* __restrict__ modulus,
                                                                 Fr* __restrict__ advice, Fr* __restrict__ lookup) {
-    __shared__ u64 s_a[EXP_MAXL], s_b[EXP_MAXL], s_q[EXP_MAXL], s_r[EXP_MAXL], s_n[EXP_MAXL];
+    __shared__ u64 s_a[EXP_MAXL][2], s_b[EXP_MAXL][2], s_q[EXP_MAXL][2], s_r[EXP_MAXL][2], s_n[EXP_MAXL][2];
     __shared__ Fr s_am[EXP_MAXL], s_bm[EXP_MAXL], s_qm[EXP_MAXL], s_nm[EXP_MAXL];
     __shared__ u64 s_pab[2 * EXP_MAXL][3], s_pqn[2 * EXP_MAXL][3];
     __shared__ u64 s_carry[2 * EXP_MAXL + 1][2], s_accx[2 * EXP_MAXL + 1][2];
     __shared__ unsigned char s_eqbit[2 * EXP_MAXL + 2], s_borrow[EXP_MAXL + 1];
-    const unsigned L = P.L, D = P.D, lb = P.lb;
+    const unsigned L = P.L, D = P.D, lb = P.lb, W = P.W;
+    const bool wide = W > 64;
     const size_t step = blockIdx.x;
-    const u64* st = steps + step * 4 * (size_t)L;
+    const u64* st = steps + step * 4 * (size_t)P.L64;
     Fr* adv = advice ? advice + step * P.cells : nullptr;
     Fr* lk = lookup ? lookup + step * P.lookups : nullptr;
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const U192 MAXV = u_make(P.max_w[0], P.max_w[1], P.max_w[2]);
+    const U192 BASE = u_shl(u_make(1), W);
+#define LIMB(X, i) u_make((X)[i][0], (X)[i][1])
 
     for (unsigned i = tid; i < L; i += EXP_THREADS) {
-        u64 a = st[i], b = st[L + i], q = st[2 * L + i], r = st[3 * L + i], n = modulus[i];
-        s_a[i] = a; s_b[i] = b; s_q[i] = q; s_r[i] = r; s_n[i] = n;
-        s_am[i] = fr_from_u(u_make(a));
-        s_bm[i] = fr_from_u(u_make(b));
-        s_qm[i] = fr_from_u(u_make(q));
-        s_nm[i] = fr_from_u(u_make(n));
+        limb_extract(st, P.L64, i, W, s_a[i]);
+        limb_extract(st + P.L64, P.L64, i, W, s_b[i]);
+        limb_extract(st + 2 * (size_t)P.L64, P.L64, i, W, s_q[i]);
+        limb_extract(st + 3 * (size_t)P.L64, P.L64, i, W, s_r[i]);
+        limb_extract(modulus, P.L64, i, W, s_n[i]);
+        s_am[i] = fr_from_u(LIMB(s_a, i));
+        s_bm[i] = fr_from_u(LIMB(s_b, i));
+        s_qm[i] = fr_from_u(LIMB(s_q, i));
+        s_nm[i] = fr_from_u(LIMB(s_n, i));
     }
     __syncthreads();
 
     // ---- the two limb convolutions: wave per product limb (row), lanes own terms
     const unsigned PER = (D + 63) / 64;
     for (int which = 0; which < 2; ++which) {
-        const u64* xs = which ? s_q : s_a;
-        const u64* ys = which ? s_n : s_b;
+        const u64(*xs)[2] = which ? s_q : s_a;
+        const u64(*ys)[2] = which ? s_n : s_b;
         const Fr* xm = which ? s_qm : s_am;
         const Fr* ym = which ? s_nm : s_bm;
         u64(*pout)[3] = which ? s_pqn : s_pab;
@@ -252,12 +285,7 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
             for (unsigned t = 0; t < PER; ++t) {
                 const unsigned j = lane * PER + t;
                 U192 p = u_make(0);
-                if (j <= i) {
-                    const u64 x = j < L ? xs[j] : 0, y = (i - j) < L ? ys[i - j] : 0;
-                    u64 hi, lo;
-                    mul64w(x, y, hi, lo);
-                    p = u_make(lo, hi);
-                }
+                if (j <= i && j < L && (i - j) < L) p = u_mul_limb(LIMB(xs, j), LIMB(ys, i - j), wide);
                 run = u_add(run, p);
                 pre[t] = run;
             }
@@ -303,14 +331,14 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
             s_accx[i][0] = accx.w[0]; s_accx[i][1] = accx.w[1];
             const U192 A = u_make(s_pab[i][0], s_pab[i][1], s_pab[i][2]);
             U192 Bq = u_make(s_pqn[i][0], s_pqn[i][1], s_pqn[i][2]);
-            if (i < L) Bq = u_add(Bq, u_make(s_r[i]));
+            if (i < L) Bq = u_add(Bq, LIMB(s_r, i));
             S192 s = s_addu(s_addu(s_sub(A, Bq), carry), MAXV);  // >= 0 for a consistent step
             const U192 t = u_add(accx, MAXV);
-            const unsigned e = (!s.neg && s.m.w[0] == t.w[0]) ? 1u : 0u;
+            const unsigned e = (!s.neg && u_eq(u_lowbits(s.m, W), u_lowbits(t, W))) ? 1u : 0u;
             eq &= e;
             s_eqbit[i + 1] = (unsigned char)eq;
-            carry = u_shr(s.m, 64);
-            accx = u_shr(t, 64);
+            carry = u_shr(s.m, W);
+            accx = u_shr(t, W);
         }
         s_carry[D][0] = carry.w[0]; s_carry[D][1] = carry.w[1];
         s_accx[D][0] = accx.w[0]; s_accx[D][1] = accx.w[1];
@@ -318,10 +346,10 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
         unsigned borrow = 0;
         for (unsigned i = 0; i < L; ++i) {
             s_borrow[i] = (unsigned char)borrow;
-            // r_i < n_i + borrow  (n_i + borrow may be 2^64)
-            const u64 nb = s_n[i] + borrow;
-            const bool wrap = borrow && nb == 0;
-            borrow = (wrap || s_r[i] < nb) ? 1u : 0u;
+            // r_i < n_i + borrow  (n_i + borrow may be 2^W)
+            bool lt;
+            (void)u_sub(LIMB(s_r, i), u_add(LIMB(s_n, i), u_make(borrow)), lt);
+            borrow = lt ? 1u : 0u;
         }
         s_borrow[L] = (unsigned char)borrow;
     }
@@ -332,20 +360,20 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
         const unsigned per_int = L + L * P.rc64_adv;
         for (unsigned t = tid; t < 3 * per_int; t += EXP_THREADS) {
             const unsigned which = t / per_int, u = t % per_int;
-            const u64* X = which == 0 ? s_q : (which == 1 ? s_n : s_r);
+            const u64(*X)[2] = which == 0 ? s_q : (which == 1 ? s_n : s_r);
             Fr v;
-            if (u < L) v = fr_from_u(u_make(X[u]));
+            if (u < L) v = fr_from_u(LIMB(X, u));
             else {
                 const unsigned i = (u - L) / P.rc64_adv, p = (u - L) % P.rc64_adv;
-                v = rc_adv_cell(u_make(X[i]), 64, lb, p);
+                v = rc_adv_cell(LIMB(X, i), W, lb, p);
             }
             if (adv) fp_store(adv + P.off_assign + t, v);
         }
         if (lk)
             for (unsigned t = tid; t < 3 * L * P.rc64_lk; t += EXP_THREADS) {
                 const unsigned which = t / (L * P.rc64_lk), u = t % (L * P.rc64_lk);
-                const u64* X = which == 0 ? s_q : (which == 1 ? s_n : s_r);
-                fp_store(lk + P.lk_assign + t, rc_lk_cell(u_make(X[u / P.rc64_lk]), 64, lb, u % P.rc64_lk));
+                const u64(*X)[2] = which == 0 ? s_q : (which == 1 ? s_n : s_r);
+                fp_store(lk + P.lk_assign + t, rc_lk_cell(LIMB(X, u / P.rc64_lk), W, lb, u % P.rc64_lk));
             }
     }
     // ---- segment: qn + r
@@ -356,8 +384,8 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
             Fr v;
             if (p == 0) v = fr_from_u(qn);
             else if (p == 1) v = fp_one<FrTag>();
-            else if (p == 2) v = fr_from_u(u_make(s_r[i]));
-            else v = fr_from_u(u_add(qn, u_make(s_r[i])));
+            else if (p == 2) v = fr_from_u(LIMB(s_r, i));
+            else v = fr_from_u(u_add(qn, LIMB(s_r, i)));
             fp_store(adv + P.off_add + t, v);
         }
     // ---- segment: is_equal_muled
@@ -374,7 +402,7 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
             else { i = D - 1; p = t - (D - 1) * per; }
             const U192 A = u_make(s_pab[i][0], s_pab[i][1], s_pab[i][2]);
             U192 Bq = u_make(s_pqn[i][0], s_pqn[i][1], s_pqn[i][2]);
-            if (i < L) Bq = u_add(Bq, u_make(s_r[i]));
+            if (i < L) Bq = u_add(Bq, LIMB(s_r, i));
             const U192 carry = u_make(s_carry[i][0], s_carry[i][1]);
             const U192 accx = u_make(s_accx[i][0], s_accx[i][1]);
             const S192 diff = s_sub(A, Bq);
@@ -396,15 +424,15 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
                     default: v = fr_from_s(ssum); break;
                 }
             } else if (p < 33) {
-                v = div_mod_cell(ssum.m, p - 11);
+                v = div_mod_cell(ssum.m, p - 11, W);
             } else if (p < 37) {
                 v = p == 33 ? fr_from_u(accx) : p == 34 ? fp_one<FrTag>() : p == 35 ? fr_from_u(MAXV) : fr_from_u(tt);
             } else if (p < 59) {
-                v = div_mod_cell(tt, p - 37);
+                v = div_mod_cell(tt, p - 37, W);
             } else if (p < 71) {
-                v = is_equal_cell(u_make(ssum.m.w[0]), u_make(tt.w[0]), p - 59);
+                v = is_equal_cell(u_lowbits(ssum.m, W), u_lowbits(tt, W), p - 59);
             } else if (p < 75) {
-                const unsigned e = (ssum.m.w[0] == tt.w[0]) ? 1u : 0u;
+                const unsigned e = u_eq(u_lowbits(ssum.m, W), u_lowbits(tt, W)) ? 1u : 0u;
                 const unsigned in = s_eqbit[i], out = s_eqbit[i + 1];
                 v = p == 71 ? fp_zero<FrTag>() : p == 72 ? (in ? fp_one<FrTag>() : fp_zero<FrTag>())
                     : p == 73 ? (e ? fp_one<FrTag>() : fp_zero<FrTag>()) : (out ? fp_one<FrTag>() : fp_zero<FrTag>());
@@ -435,24 +463,24 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
         for (unsigned t = tid; t < L * per; t += EXP_THREADS) {
             const unsigned i = t / per, p = t % per;
             const unsigned borrow = s_borrow[i], lt = s_borrow[i + 1];
-            const U192 nb = u_add(u_make(s_n[i]), u_make(borrow));
+            const U192 nb = u_add(LIMB(s_n, i), u_make(borrow));
             bool br;
-            const U192 shift = u_sub(u_add(u_make(s_r[i]), u_make(0, 1)), nb, br);  // r_i - nb + 2^64
-            const U192 outv = u_make(shift.w[0]);
+            const U192 shift = u_sub(u_add(LIMB(s_r, i), BASE), nb, br);  // r_i - nb + 2^W
+            const U192 outv = u_lowbits(shift, W);
             Fr v;
             switch (p) {
-                case 0: v = fr_from_u(u_make(s_n[i])); break;
+                case 0: v = fr_from_u(LIMB(s_n, i)); break;
                 case 1: v = fp_one<FrTag>(); break;
                 case 2: v = borrow ? fp_one<FrTag>() : fp_zero<FrTag>(); break;
                 case 3: v = fr_from_u(nb); break;
                 case 4: v = fr_from_u(shift); break;
                 case 5: v = lt ? fp_one<FrTag>() : fp_zero<FrTag>(); break;
                 case 6: v = fr_from_u(outv); break;
-                case 7: v = fr_from_u(u_make(s_r[i])); break;
+                case 7: v = fr_from_u(LIMB(s_r, i)); break;
                 case 8: v = lt ? fp_one<FrTag>() : fp_zero<FrTag>(); break;
-                case 9: v = fr_from_u(u_make(0, 1)); break;
-                case 10: v = fr_from_u(u_add(u_make(s_r[i]), u_make(0, lt))); break;
-                default: v = rc_adv_cell(outv, 64, lb, p - 11); break;
+                case 9: v = fr_from_u(BASE); break;
+                case 10: v = fr_from_u(lt ? u_add(LIMB(s_r, i), BASE) : LIMB(s_r, i)); break;
+                default: v = rc_adv_cell(outv, W, lb, p - 11); break;
             }
             if (adv) fp_store(adv + P.off_lt + t, v);
         }
@@ -460,12 +488,14 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
         if (lk)
             for (unsigned t = tid; t < L * P.rc64_lk; t += EXP_THREADS) {
                 const unsigned i = t / P.rc64_lk, p = t % P.rc64_lk;
-                const unsigned borrow = s_borrow[i];
-                const u64 nbw = s_n[i] + borrow;
-                fp_store(lk + P.lk_lt + t, rc_lk_cell(u_make(s_r[i] - nbw), 64, lb, p));
+                bool br;
+                const U192 shift = u_sub(u_add(LIMB(s_r, i), BASE), u_add(LIMB(s_n, i), u_make(s_borrow[i])), br);
+                fp_store(lk + P.lk_lt + t, rc_lk_cell(u_lowbits(shift, W), W, lb, p));
             }
     }
 }
+
+#undef LIMB
 
 // ------------------------------------------------------------------------------------------------
 // host: layout arithmetic (mirrors paillier_halo2_amd/layout.py::mul_mod_cells)
@@ -479,34 +509,63 @@ static void rc_counts(unsigned bits, unsigned lb, unsigned& k, unsigned& rem, un
     else if (rem > 1) { adv += 4; lk += 1; }
 }
 
+// 192-bit host helpers for MAX = L*(2^W-1)^2 + (2^W-1) = (L << 2W) - (L << (W+1)) + L + (1 << W) - 1
+static void h_shl(const uint64_t a[3], unsigned s, uint64_t r[3]) {
+    uint64_t t[3] = {a[0], a[1], a[2]};
+    while (s >= 64) { t[2] = t[1]; t[1] = t[0]; t[0] = 0; s -= 64; }
+    if (s) { t[2] = (t[2] << s) | (t[1] >> (64 - s)); t[1] = (t[1] << s) | (t[0] >> (64 - s)); t[0] <<= s; }
+    r[0] = t[0]; r[1] = t[1]; r[2] = t[2];
+}
+static void h_add(uint64_t a[3], const uint64_t b[3]) {
+    unsigned __int128 c = 0;
+    for (int i = 0; i < 3; ++i) { c += (unsigned __int128)a[i] + b[i]; a[i] = (uint64_t)c; c >>= 64; }
+}
+static void h_sub(uint64_t a[3], const uint64_t b[3]) {
+    uint64_t br = 0;
+    for (int i = 0; i < 3; ++i) {
+        const uint64_t t = a[i] - b[i], b1 = a[i] < b[i], t2 = t - br;
+        br = b1 | (t < br);
+        a[i] = t2;
+    }
+}
+static unsigned h_bits(const uint64_t a[3]) {
+    for (int i = 2; i >= 0; --i)
+        if (a[i]) return 64 * i + (64 - __builtin_clzll(a[i]));
+    return 0;
+}
+
 static int make_params(uint32_t L, uint32_t limb_bits, uint32_t lb, ExpP& P) {
-    if (limb_bits != 64) return PZ_ERR_UNSUPPORTED;  // K3 emits 64-bit limbs (the reference bench's choice, bench.rs:140)
+    // limb_bits = 64 is the reference bench's choice (bench.rs:140, paillier.rs:116); its add test runs 88-bit limbs
+    // (paillier.rs:186-187).  A limb travels as two 64-bit words and a product limb as three: 2W + log2(L) + 3 <= 192.
+    if (limb_bits < 16 || limb_bits > 90) return PZ_ERR_UNSUPPORTED;
     if (L < 2 || L > EXP_MAXL) return PZ_ERR_UNSUPPORTED;
     if (lb < 4 || lb > 32) return PZ_ERR_INVALID;
+    {
+        unsigned lg = 0;
+        while ((1u << lg) < L) ++lg;
+        if (2 * limb_bits + lg + 3 > 192) return PZ_ERR_UNSUPPORTED;
+    }
     memset(&P, 0, sizeof P);
     P.L = L;
     P.D = 2 * L - 1;
     P.lb = lb;
-    rc_counts(64, lb, P.k64, P.rem64, P.rc64_adv, P.rc64_lk);
+    P.W = limb_bits;
+    P.L64 = (L * limb_bits + 63) / 64;
+    rc_counts(limb_bits, lb, P.k64, P.rem64, P.rc64_adv, P.rc64_lk);
     if (P.k64 < 2) return PZ_ERR_INVALID;
-    // MAX = L*(2^64-1)^2 + (2^64-1) = L*2^128 - (2L-1)*2^64 + (L-1)
-    unsigned __int128 lo = (unsigned __int128)(L - 1);
-    // compute with 192-bit arithmetic: words w0,w1,w2
-    // L*2^128: w2 = L ; subtract (2L-1)*2^64: w1 -= (2L-1) with borrow from w2 ; add (L-1) to w0
-    uint64_t w0 = (uint64_t)lo, w1 = 0, w2 = L;
-    uint64_t sub = 2ull * L - 1;
-    w1 = (uint64_t)0 - sub;
-    w2 -= 1;  // borrow
-    P.max_w[0] = w0; P.max_w[1] = w1; P.max_w[2] = w2;
-    // bits of 2*MAX
-    unsigned bits = 0;
-    {
-        unsigned __int128 hi = ((unsigned __int128)w2 << 64) | w1;  // MAX >> 64
-        unsigned __int128 two_hi = hi << 1 | (w0 >> 63);
-        while (two_hi) { ++bits; two_hi >>= 1; }
-        bits += 64;
-    }
-    P.cb = bits - 64;
+    const uint64_t Lw[3] = {L, 0, 0}, one[3] = {1, 0, 0};
+    uint64_t mx[3], t[3];
+    h_shl(Lw, 2 * limb_bits, mx);
+    h_shl(Lw, limb_bits + 1, t);
+    h_sub(mx, t);
+    h_add(mx, Lw);
+    h_shl(one, limb_bits, t);
+    h_add(mx, t);
+    h_sub(mx, one);
+    P.max_w[0] = mx[0]; P.max_w[1] = mx[1]; P.max_w[2] = mx[2];
+    h_shl(mx, 1, t);  // 2*MAX
+    const unsigned bits = h_bits(t);
+    P.cb = bits - limb_bits;
     rc_counts(P.cb, lb, P.kcb, P.remcb, P.rccb_adv, P.rccb_lk);
     size_t off = 0;
     P.off_assign = off;

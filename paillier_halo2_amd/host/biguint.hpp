@@ -84,6 +84,25 @@ class BigUint {
         if (carry) r.l.push_back(carry);
         return r;
     }
+    friend BigUint operator>>(const BigUint& a, size_t s) {
+        BigUint r;
+        const size_t w = s / 64;
+        const unsigned sh = s % 64;
+        for (size_t i = w; i < a.l.size(); ++i) {
+            uint64_t v = a.l[i] >> sh;
+            if (sh && i + 1 < a.l.size()) v |= a.l[i + 1] << (64 - sh);
+            r.l.push_back(v);
+        }
+        r.trim();
+        return r;
+    }
+    BigUint low_bits(size_t n) const {  // value mod 2^n
+        BigUint r;
+        for (size_t i = 0; i < l.size() && 64 * i < n; ++i)
+            r.l.push_back(n - 64 * i >= 64 ? l[i] : l[i] & ((1ull << (n - 64 * i)) - 1));
+        r.trim();
+        return r;
+    }
     friend BigUint operator*(const BigUint& a, const BigUint& b) {  // schoolbook: only for n*n-sized setup values
         BigUint r;
         if (a.l.empty() || b.l.empty()) return r;

@@ -64,22 +64,27 @@ class Context {
     Context(const Context&) = delete;
     pz_ctx* raw() { return ctx_; }
     size_t load_zero() { return zero_cells_++; }  // paillier.rs:47 ctx.load_zero(): one advice cell
-    // tape of mul_mod steps in emission order (limbs L each); all steps of one circuit share L and the modulus
-    void push_steps(const std::vector<uint64_t>& steps, unsigned L, const BigUint& modulus) {
-        if (L_ && (L_ != L || modulus_ != modulus)) throw std::logic_error("one Context holds steps of one modulus");
-        L_ = L;
+    // tape of mul_mod steps in emission order: (a|b|q|r), `words` 64-bit words each, whatever the circuit's limb
+    // width is; all steps of one circuit share the limb count, the limb width and the modulus
+    void push_steps(const std::vector<uint64_t>& steps, unsigned words, unsigned limbs, unsigned limb_bits, const BigUint& modulus) {
+        if (L_ && (L_ != limbs || W_ != limb_bits || modulus_ != modulus)) throw std::logic_error("one Context holds steps of one modulus");
+        L_ = limbs;
+        W_ = limb_bits;
+        words_ = words;
         modulus_ = modulus;
         tape_.insert(tape_.end(), steps.begin(), steps.end());
     }
-    size_t n_steps() const { return L_ ? tape_.size() / (4 * L_) : 0; }
+    size_t n_steps() const { return words_ ? tape_.size() / (4 * words_) : 0; }
     const std::vector<uint64_t>& tape() const { return tape_; }
-    unsigned limbs() const { return L_; }
+    unsigned limbs() const { return L_; }        // circuit limbs per big integer
+    unsigned limb_bits() const { return W_; }
+    unsigned words() const { return words_; }    // 64-bit words per big integer of a step record
     const BigUint& modulus() const { return modulus_; }
 
   private:
     pz_ctx* ctx_ = nullptr;
     size_t zero_cells_ = 0;
-    unsigned L_ = 0;
+    unsigned L_ = 0, W_ = 64, words_ = 0;
     BigUint modulus_;
     std::vector<uint64_t> tape_;
 };
@@ -100,7 +105,19 @@ template <class Kind> class AssignedBigUint {
     const BigUint& value() const { return value_; }
     unsigned num_limbs() const { return num_limbs_; }
     unsigned max_limb_bits() const { return max_limb_bits_; }
-    std::vector<uint64_t> limbs() const { return value_.to_limbs(num_limbs_); }  // limbs()[0] least significant
+    // the circuit's limbs (max_limb_bits wide, limbs()[0] least significant): what the reference's limbs() cells hold
+    std::vector<BigUint> limbs() const {
+        if (value_.bits() > (size_t)num_limbs_ * max_limb_bits_) throw std::range_error("integer does not fit the limb count");
+        std::vector<BigUint> r;
+        for (unsigned i = 0; i < num_limbs_; ++i) r.push_back((value_ >> ((size_t)i * max_limb_bits_)).low_bits(max_limb_bits_));
+        return r;
+    }
+    // the same integer as the C ABI takes it: little-endian 64-bit words covering num_limbs * max_limb_bits bits
+    unsigned num_words() const { return (num_limbs_ * max_limb_bits_ + 63) / 64; }
+    std::vector<uint64_t> words() const {
+        if (value_.bits() > (size_t)num_limbs_ * max_limb_bits_) throw std::range_error("integer does not fit the limb count");
+        return value_.to_limbs(num_words());
+    }
     AssignedBigUint extend_limbs(unsigned extra, size_t /*zero_cell*/) const {   // paillier.rs:49,53,79-80
         return AssignedBigUint(value_, num_limbs_ + extra, max_limb_bits_);
     }
@@ -115,7 +132,7 @@ class BigUintChip {
     const RangeChip* range;
     unsigned limb_bits;
     static BigUintChip construct(const RangeChip* range, unsigned limb_bits) {
-        if (limb_bits != 64) throw std::invalid_argument("this build emits 64-bit limbs (the reference bench's choice, bench.rs:140)");
+        if (limb_bits < 16 || limb_bits > 90) throw std::invalid_argument("limb_bits outside 16..90 (K4 carries a limb in two 64-bit words)");
         return BigUintChip{range, limb_bits};
     }
     // assign_integer(ctx, Value::known(v), bit_len): bit_len must be a multiple of limb_bits, v must fit
@@ -136,34 +153,39 @@ class BigUintChip {
                                            const AssignedBigUint<Fresh>& n) const {
         const unsigned L = n.num_limbs();
         if (a.num_limbs() != L || b.num_limbs() != L) return Result<AssignedBigUint<Fresh>>::Err(PZ_ERR_INVALID, "limb count mismatch");
-        std::vector<uint64_t> av = a.limbs(), bv = b.limbs(), nv = n.limbs(), q(L), r(L);
-        int rc = pz_mul_mod(ctx.raw(), L, av.data(), bv.data(), nv.data(), q.data(), r.data());
+        const unsigned Wd = n.num_words();
+        std::vector<uint64_t> av = a.words(), bv = b.words(), nv = n.words(), q(Wd), r(Wd);
+        int rc = pz_mul_mod(ctx.raw(), Wd, av.data(), bv.data(), nv.data(), q.data(), r.data());
         if (rc != PZ_OK) return Result<AssignedBigUint<Fresh>>::Err(rc, std::string("pz_mul_mod: ") + pz_strerror(rc));
+        BigUint qv = BigUint::from_limbs(q.data(), Wd);
+        if (qv.bits() > (size_t)L * limb_bits)   // the circuit assigns q with L limbs: its range check would fail
+            return Result<AssignedBigUint<Fresh>>::Err(PZ_ERR_RANGE, "quotient does not fit the assigned limb count");
         std::vector<uint64_t> step;
         step.insert(step.end(), av.begin(), av.end());
         step.insert(step.end(), bv.begin(), bv.end());
         step.insert(step.end(), q.begin(), q.end());
         step.insert(step.end(), r.begin(), r.end());
-        ctx.push_steps(step, L, n.value());
-        return Result<AssignedBigUint<Fresh>>::Ok(AssignedBigUint<Fresh>(BigUint::from_limbs(r.data(), L), L, limb_bits));
+        ctx.push_steps(step, Wd, L, limb_bits, n.value());
+        return Result<AssignedBigUint<Fresh>>::Ok(AssignedBigUint<Fresh>(BigUint::from_limbs(r.data(), Wd), L, limb_bits));
     }
     // pow_mod_fixed_exp(ctx, a, e, n): e is a native BigUint -- the exponent's bits shape the circuit
     Result<AssignedBigUint<Fresh>> pow_mod_fixed_exp(Context& ctx, const AssignedBigUint<Fresh>& a, const BigUint& e,
                                                      const AssignedBigUint<Fresh>& n) const {
         const unsigned L = n.num_limbs();
         if (a.num_limbs() != L) return Result<AssignedBigUint<Fresh>>::Err(PZ_ERR_INVALID, "limb count mismatch");
-        std::vector<uint64_t> av = a.limbs(), nv = n.limbs(), res(L);
+        const unsigned Wd = n.num_words();
+        std::vector<uint64_t> av = a.words(), nv = n.words(), res(Wd);
         const unsigned el = e.l.empty() ? 1 : (unsigned)e.l.size();
         std::vector<uint64_t> ev = e.to_limbs(el);
         size_t cap = e.bits();
         for (uint64_t w : ev) cap += (size_t)__builtin_popcountll(w);
-        std::vector<uint64_t> steps(std::max<size_t>(cap, 1) * 4 * L);
+        std::vector<uint64_t> steps(std::max<size_t>(cap, 1) * 4 * Wd);
         size_t ns = cap;
-        int rc = pz_paillier_trace(ctx.raw(), L, nv.data(), av.data(), ev.data(), el, steps.data(), &ns, res.data());
+        int rc = pz_paillier_trace(ctx.raw(), Wd, nv.data(), av.data(), ev.data(), el, steps.data(), &ns, res.data());
         if (rc != PZ_OK) return Result<AssignedBigUint<Fresh>>::Err(rc, std::string("pz_paillier_trace: ") + pz_strerror(rc));
-        steps.resize(ns * 4 * L);
-        if (ns) ctx.push_steps(steps, L, n.value());
-        return Result<AssignedBigUint<Fresh>>::Ok(AssignedBigUint<Fresh>(BigUint::from_limbs(res.data(), L), L, limb_bits));
+        steps.resize(ns * 4 * Wd);
+        if (ns) ctx.push_steps(steps, Wd, L, limb_bits, n.value());
+        return Result<AssignedBigUint<Fresh>>::Ok(AssignedBigUint<Fresh>(BigUint::from_limbs(res.data(), Wd), L, limb_bits));
     }
     Result<bool> assert_equal_fresh(Context&, const AssignedBigUint<Fresh>& a, const AssignedBigUint<Fresh>& b) const {
         if (a.value() != b.value()) return Result<bool>::Err(PZ_ERR_INVALID, "assert_equal_fresh: constraint not satisfied");
@@ -184,8 +206,8 @@ class PaillierChip {  // paillier.rs:11-15
     // paillier.rs:22-30: fold limbs MSB -> LSB with shift max_limb_bits
     BigUint get_biguint(const AssignedBigUint<Fresh>& assigned) const {
         BigUint acc;
-        std::vector<uint64_t> limbs = assigned.limbs();
-        for (size_t i = limbs.size(); i-- > 0;) acc = (acc << assigned.max_limb_bits()) + BigUint(limbs[i]);
+        std::vector<BigUint> limbs = assigned.limbs();
+        for (size_t i = limbs.size(); i-- > 0;) acc = (acc << assigned.max_limb_bits()) + limbs[i];
         return acc;
     }
 
@@ -290,7 +312,8 @@ inline void paillier_enc_add_test(Context& ctx, const RangeChip& range, const Pa
 // caller provides (hipMalloc'ed; sizes from pz_witness_cells_per_step * n_steps).  d_* may be null to query.
 inline int synthesize_witness(Context& ctx, const RangeChip& range, uint64_t* d_steps, uint64_t* d_modulus, uint64_t* d_advice,
                               uint64_t* d_lookup) {
-    return pz_witness_expand_dev(ctx.raw(), ctx.limbs(), 64, range.lookup_bits, d_steps, ctx.n_steps(), d_modulus, d_advice, d_lookup);
+    return pz_witness_expand_dev(ctx.raw(), ctx.limbs(), ctx.limb_bits(), range.lookup_bits, d_steps, ctx.n_steps(), d_modulus, d_advice,
+                                 d_lookup);
 }
 
 }  // namespace pz

@@ -1,7 +1,6 @@
 // C++ mirror of the reference's own tests, reading like them:
 //   test_paillier_encryption   /root/reference/src/paillier.rs:113-182  (ENC_BIT_LEN 128, LIMB_BIT_LEN 64)
-//   test_encryption_addition   /root/reference/src/paillier.rs:184-259  (reference: 264 / 88-bit limbs; here 256 / 64 --
-//                              this build emits 64-bit limbs)
+//   test_encryption_addition   /root/reference/src/paillier.rs:184-259  (ENC_BIT_LEN 264, LIMB_BIT_LEN 88)
 //   bench_paillier_enc         /root/reference/src/bench.rs:137-179     (k = 14, lookup_bits = 13)
 //   bench_paillier_enc_add     /root/reference/src/bench.rs:181-222
 // plus the 2048-bit key of BASELINE config c2.  Inputs come from a SEEDED generator (the reference uses
@@ -59,14 +58,17 @@ static void test_paillier_encryption(unsigned enc_bits, unsigned lookup_bits) {
     CHECK(paillier_enc_native(ctx, n, g, m, r) == res, "paillier_enc_native == oracle");
 }
 
-static void test_encryption_addition(unsigned enc_bits, unsigned lookup_bits) {
+static void test_encryption_addition(unsigned enc_bits, unsigned lookup_bits, unsigned limb_bits = 64) {
     Context ctx(0);
     RangeChip range{lookup_bits};
     BigUint n = gen_biguint(enc_bits), g = gen_biguint(enc_bits), c1 = gen_biguint(enc_bits), c2 = gen_biguint(enc_bits);
     if (n.is_zero()) n = BigUint(3);
-    BigUint res = oracle_add(n, c1, c2, 2 * enc_bits / 64);
-    paillier_enc_add_test(ctx, range, PaillierAddCipherInput{64, enc_bits, n, g, c1, c2, res});
-    CHECK(ctx.n_steps() == 1, "paillier_enc_add_test: one mul_mod step");
+    BigUint res = oracle_add(n, c1, c2, (2 * enc_bits + 63) / 64);
+    paillier_enc_add_test(ctx, range, PaillierAddCipherInput{limb_bits, enc_bits, n, g, c1, c2, res});
+    char name[96];
+    std::snprintf(name, sizeof name, "paillier_enc_add_test enc_bits=%u limb_bits=%u: one mul_mod step, %u limbs in %u words", enc_bits,
+                  limb_bits, ctx.limbs(), ctx.words());
+    CHECK(ctx.n_steps() == 1 && ctx.limbs() == 2 * enc_bits / limb_bits && ctx.limb_bits() == limb_bits, name);
     CHECK(paillier_add_native(ctx, n, c1, c2) == res, "paillier_add_native == oracle");
 }
 
@@ -76,6 +78,15 @@ static void test_error_behaviour() {
     BigUintChip chip = BigUintChip::construct(&range, 64);
     CHECK(!chip.assign_integer(ctx, gen_biguint(130) + (BigUint(1) << 129), 128).ok, "assign_integer rejects a value wider than bit_len");
     CHECK(!chip.assign_integer(ctx, BigUint(5), 100).ok, "assign_integer rejects bit_len not a multiple of limb_bits");
+    {
+        BigUintChip c88 = BigUintChip::construct(&range, 88);
+        BigUint v = gen_biguint(264);
+        auto a88 = c88.assign_integer(ctx, v, 264).unwrap();
+        BigUint acc;
+        auto lm = a88.limbs();
+        for (size_t i = lm.size(); i-- > 0;) acc = (acc << 88) + lm[i];
+        CHECK(lm.size() == 3 && acc == v && a88.num_words() == 5, "88-bit limbs: 3 limbs of a 264-bit integer fold back (get_biguint, paillier.rs:22-30)");
+    }
     auto a = chip.assign_integer(ctx, BigUint(7), 128).unwrap(), z = chip.assign_integer(ctx, BigUint(), 128).unwrap();
     auto bad = chip.mul_mod(ctx, a, a, z);
     CHECK(!bad.ok && bad.err.status == PZ_ERR_ZERO_MODULUS, "mul_mod by modulus 0 -> PZ_ERR_ZERO_MODULUS (reference: BigUint % 0 panics, paillier.rs:91)");
@@ -93,7 +104,8 @@ static void test_error_behaviour() {
 int main() {
     try {
         test_paillier_encryption(128, 15);  // paillier.rs:113-182
-        test_encryption_addition(256, 15);  // paillier.rs:184-259 at 64-bit limbs
+        test_encryption_addition(264, 15, 88);  // paillier.rs:184-259: 264-bit key, 88-bit limbs
+        test_encryption_addition(256, 15);
         test_paillier_encryption(128, 13);  // bench.rs:137-179
         test_encryption_addition(128, 13);  // bench.rs:181-222
         test_paillier_encryption(2048, 16); // BASELINE config c2 key size

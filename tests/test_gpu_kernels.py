@@ -332,15 +332,19 @@ def test_ubench_reports(eng):
 
 
 # ------------------------------------------------------------------------------------------ K4
-@pytest.mark.parametrize("L,lb", [(2, 15), (4, 16), (4, 14), (4, 8), (64, 16), (64, 14), (96, 18)])
-def test_witness_expand_vs_oracle(eng, cref, L, lb):
-    """cell stream of BigUintChip::mul_mod steps (layout.py / DESIGN.md section 4) vs the Python-int expansion"""
+@pytest.mark.parametrize("L,lb,W", [(2, 15, 64), (4, 16, 64), (4, 14, 64), (4, 8, 64), (64, 16, 64), (64, 14, 64), (96, 18, 64),
+                                    (6, 15, 88),     # the reference's add test: 264-bit key, 88-bit limbs (paillier.rs:186-187,247)
+                                    (4, 13, 32), (8, 16, 40), (47, 16, 88), (6, 11, 90)])
+def test_witness_expand_vs_oracle(eng, cref, L, lb, W):
+    """cell stream of BigUintChip::mul_mod steps (layout.py / DESIGN.md section 4) vs the Python-int expansion;
+    step records are 64-bit words whatever the circuit's limb width W is"""
     import torch
 
     from paillier_halo2_amd import layout
 
-    rng = random.Random(1000 * L + lb)
-    bits = 64 * L
+    rng = random.Random(1000 * L + lb + W)
+    bits = W * L
+    L64 = -(-bits // 64)
     n = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
     steps_int = []
     for it in range(3):
@@ -351,27 +355,31 @@ def test_witness_expand_vs_oracle(eng, cref, L, lb):
             a, b = 1, rng.randrange(n)  # acc = 1 start of a chain (many zero limbs)
         q, r = divmod(a * b, n)
         steps_int.append((a, b, q, r))
-    steps = np.stack([np.stack([cref.int_to_limbs(v, L) for v in st]) for st in steps_int])
-    adv_n, lk_n = eng.witness_cells_per_step(L, 64, lb)
-    sc = layout.mul_mod_cells(L, 64, lb)
+    steps = np.stack([np.stack([cref.int_to_limbs(v, L64) for v in st]) for st in steps_int])
+    adv_n, lk_n = eng.witness_cells_per_step(L, W, lb)
+    sc = layout.mul_mod_cells(L, W, lb)
     assert (adv_n, lk_n) == (sc.advice, sc.lookup)
     d_steps = torch.from_numpy(steps.astype(np.int64)).cuda()
-    d_mod = torch.from_numpy(cref.int_to_limbs(n, L).astype(np.int64)).cuda()
+    d_mod = torch.from_numpy(cref.int_to_limbs(n, L64).astype(np.int64)).cuda()
     d_adv = torch.zeros((len(steps_int), adv_n, 4), dtype=torch.int64, device="cuda")
     d_lk = torch.zeros((len(steps_int), lk_n, 4), dtype=torch.int64, device="cuda")
-    eng.witness_expand_dev(L, 64, lb, d_steps.data_ptr(), len(steps_int), d_mod.data_ptr(), d_adv.data_ptr(),
+    eng.witness_expand_dev(L, W, lb, d_steps.data_ptr(), len(steps_int), d_mod.data_ptr(), d_adv.data_ptr(),
                            d_lk.data_ptr())
     eng.sync()
     adv = d_adv.cpu().numpy().astype(np.uint64)
     lk = d_lk.cpu().numpy().astype(np.uint64)
+    gates, end = P.gate_offsets_mul_mod(L, lb, W)
+    assert end == adv_n
     for i, (a, b, q, r) in enumerate(steps_int):
-        want_adv, want_lk = P.expand_mul_mod_cells(a, b, q, r, n, L, lb)
+        want_adv, want_lk = P.expand_mul_mod_cells(a, b, q, r, n, L, lb, W)
         got_adv = cref.fr_mont_to_ints(adv[i])
         got_lk = cref.fr_mont_to_ints(lk[i])
         if got_adv != want_adv:
             bad = [k for k in range(len(want_adv)) if got_adv[k] != want_adv[k]]
             raise AssertionError("step %d: %d advice cells differ, first at %d (segments %s)" % (i, len(bad), bad[0], sc.seg))
         assert got_lk == want_lk, i
+        assert P.check_gates(got_adv, gates) == [], i   # MockProver analogue at this limb width
+        assert max(got_lk) < (1 << lb)
 
 
 def test_witness_expand_on_real_trace(eng, cref):
