@@ -334,6 +334,8 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the per-proof MSM/NTT counts (debug only; "
                     "any value != 1 marks the line as not comparable)")
     ap.add_argument("--log-n", type=int, default=22, help="msm22 workload: log2 of the MSM size")
+    ap.add_argument("--msm-split", default="windows", choices=["windows", "points"],
+                    help="msm22 workload: shard Pippenger windows (north_star) or point ranges across the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -367,7 +369,7 @@ def main():
         from paillier_halo2_amd import dist as pzd
 
         res = pzd.bench_sharded_msm(eng, torch, dist if use_dist else None, rank, world, args.log_n, args.steps,
-                                    args.warmup, barrier, log)
+                                    args.warmup, barrier, log, split=args.msm_split)
         if rank == 0:
             print(json.dumps(res))
         if use_dist:

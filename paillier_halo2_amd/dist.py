@@ -1,4 +1,6 @@
-"""Multi-GPU split of ONE large MSM (config c4): disjoint Pippenger windows per rank, one exchange.
+"""Multi-GPU split of ONE large MSM (config c4): disjoint Pippenger windows per rank (north_star's split) or
+disjoint point ranges per rank (SURVEY.md section 8e's alternative: N/world bases and scalars per GPU, 1/world of the
+table memory and scalar reads), one exchange either way.
 
 Each rank holds the whole base table and all scalars (402 MB at 2^22 -- nothing next to 288 GB),
 accumulates only its window range [lo, hi) (pz_msm_g1_dev's win_lo / win_hi) and produces one
@@ -23,13 +25,18 @@ def window_range(n_windows: int, rank: int, world: int) -> Tuple[int, int]:
     return (rank * n_windows) // world, ((rank + 1) * n_windows) // world
 
 
-def sharded_msm(torch, dist, rank: int, world: int, n_windows: int,
+def point_range(n_points: int, rank: int, world: int) -> Tuple[int, int]:
+    """the same contiguous split applied to the points [0, n) instead of the windows"""
+    return window_range(n_points, rank, world)
+
+
+def sharded_msm(torch, dist, rank: int, world: int, n_units: int,
                 partial_fn: Callable[[int, int], "torch.Tensor"],
                 fold_fn: Callable[[np.ndarray], np.ndarray]) -> np.ndarray:
-    """partial_fn(lo, hi) -> int64 tensor (12,) holding this rank's partial point (on the device the
-    process group communicates from); fold_fn(parts (world,12) u64) -> (12,) u64.
-    Returns the full MSM as a Jacobian point, identical on every rank."""
-    lo, hi = window_range(n_windows, rank, world)
+    """n_units = number of windows (window split) or of points (point split); partial_fn(lo, hi) -> int64 tensor
+    (12,) holding this rank's partial point for units [lo, hi) (on the device the process group communicates from);
+    fold_fn(parts (world,12) u64) -> (12,) u64.  Returns the full MSM as a Jacobian point, identical on every rank."""
+    lo, hi = window_range(n_units, rank, world)
     part = partial_fn(lo, hi).reshape(12).contiguous()
     if dist is None:
         return fold_fn(part.cpu().numpy().astype(np.uint64).reshape(1, 12))
@@ -49,8 +56,25 @@ def hip_partial_fn(eng, torch, bases, d_scalars, n: int):
     return fn
 
 
-def bench_sharded_msm(eng, torch, dist, rank, world, log_n, steps, warmup, barrier, log):
-    """config c4: one 2^log_n-point MSM, windows sharded over `world` ranks."""
+def hip_partial_points_fn(eng, torch, d_bases, d_scalars, n: int, rank: int, world: int):
+    """point split: this rank's table holds only its own N/world bases (built once, outside the timed loop)"""
+    lo, hi = point_range(n, rank, world)
+    d_out = torch.zeros((1, 12), dtype=torch.int64, device="cuda")
+    bases = eng.load_bases_dev(d_bases.data_ptr() + lo * 64, hi - lo) if hi > lo else None
+
+    def fn(lo_, hi_):
+        assert (lo_, hi_) == (lo, hi)
+        if bases is None:
+            d_out.zero_()  # Jacobian identity: z = 0
+            return d_out
+        eng.msm_dev(bases, d_scalars.data_ptr() + lo * 32, 1, hi - lo, 4 * (hi - lo), d_out.data_ptr(), 0, bases.n_windows)
+        return d_out
+
+    return fn, bases
+
+
+def bench_sharded_msm(eng, torch, dist, rank, world, log_n, steps, warmup, barrier, log, split="windows"):
+    """config c4: one 2^log_n-point MSM, windows (or point ranges) sharded over `world` ranks."""
     n = 1 << log_n
     gen = torch.Generator(device="cuda")
     gen.manual_seed(0x5045)  # same on every rank: identical bases and scalars
@@ -65,21 +89,26 @@ def bench_sharded_msm(eng, torch, dist, rank, world, log_n, steps, warmup, barri
     d_b = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
     eng.g1_fixed_base_mul_dev(ks.data_ptr(), n, d_b.data_ptr())
     eng.sync()
-    bases = eng.load_bases_dev(d_b.data_ptr(), n)
-    del d_b, ks
     d_s = rand_fr(n)
-    log("msm22 setup %.1fs (n=2^%d, c=%d, %d windows)" % (time.time() - t0, log_n, bases.window_bits, bases.n_windows))
-    pfn = hip_partial_fn(eng, torch, bases, d_s, n)
+    if split == "points":
+        pfn, bases = hip_partial_points_fn(eng, torch, d_b, d_s, n, rank, world)
+        units = n
+    else:
+        bases = eng.load_bases_dev(d_b.data_ptr(), n)
+        pfn = hip_partial_fn(eng, torch, bases, d_s, n)
+        units = bases.n_windows
+    del d_b, ks
+    log("msm22 setup %.1fs (n=2^%d, c=%d, %d windows, split by %s)" % (time.time() - t0, log_n, bases.window_bits, bases.n_windows, split))
     fold = eng.g1_sum
     res = None
     for _ in range(warmup):
-        res = sharded_msm(torch, dist, rank, world, bases.n_windows, pfn, fold)
+        res = sharded_msm(torch, dist, rank, world, units, pfn, fold)
     barrier()
     eng.timing_enable(True)
     eng.timing_reset()
     t0 = time.perf_counter()
     for _ in range(steps):
-        res = sharded_msm(torch, dist, rank, world, bases.n_windows, pfn, fold)
+        res = sharded_msm(torch, dist, rank, world, units, pfn, fold)
     barrier()
     dt = time.perf_counter() - t0
     acc_ms, acc_n = eng.timing_get(0)
@@ -97,7 +126,8 @@ def bench_sharded_msm(eng, torch, dist, rank, world, log_n, steps, warmup, barri
         "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u32 limbs (254-bit modular integers)", "data": "synthetic",
         "config": {"workload": "c4: single 2^%d-point MSM, uniform scalars" % log_n, "window_bits": bases.window_bits,
-                   "n_windows": bases.n_windows, "parallelism": "windows/%d + all_gather(96 B) + fold" % world},
+                   "n_windows": bases.n_windows, "split": split,
+                   "parallelism": "%s/%d + all_gather(96 B) + fold" % (split, world)},
         "roofline": {"bound": "hbm", "kernel": "whole MSM", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
                      "frac": ach / 8000.0, "traffic": None, "accumulate_ms_per_msm": acc_ms / max(1, steps)},
         "result_affine_x_limb0": int(aff[0]),

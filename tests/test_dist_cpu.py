@@ -13,7 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import pyref as P
-from paillier_halo2_amd.dist import sharded_msm, window_range
+from paillier_halo2_amd.dist import point_range, sharded_msm, window_range
 
 
 def test_window_range_partition():
@@ -35,7 +35,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, c, seed, q):
+def _worker(rank, world, port, n, c, seed, q, split="windows"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -60,19 +60,29 @@ def _worker(rank, world, port, n, c, seed, q):
             acc = cref.g1_add(acc, p)
         return acc
 
-    res = sharded_msm(torch, dist, rank, world, nwin, partial, fold)
+    def partial_points(lo, hi):
+        assert (lo, hi) == point_range(n, rank, world)
+        if hi == lo:
+            return torch.zeros(12, dtype=torch.int64)
+        jac = cref.msm_g1(cref.fr_ints_to_mont(scalars[lo:hi]), cref.affine_ints_to_mont(bases[lo:hi]))
+        return torch.from_numpy(jac.astype(np.int64))
+
+    if split == "points":
+        res = sharded_msm(torch, dist, rank, world, n, partial_points, fold)
+    else:
+        res = sharded_msm(torch, dist, rank, world, nwin, partial, fold)
     got = cref.affine_mont_to_ints(cref.g1_normalize(res))[0]
     q.put((rank, got, P.msm_walk_expected(scalars, s, t)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
-def test_sharded_msm_gloo(world, cref):
+@pytest.mark.parametrize("world,split", [(2, "windows"), (2, "points")])
+def test_sharded_msm_gloo(world, split, cref):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, 96, 13, 0x5045, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 96, 13, 0x5045, q, split)) for r in range(world)]
     for p in procs:
         p.start()
     out = [q.get(timeout=120) for _ in range(world)]
