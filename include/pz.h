@@ -186,6 +186,10 @@ int pz_witness_expand_dev(pz_ctx* ctx, uint32_t limbs, uint32_t limb_bits, uint3
  * Montgomery (host); outputs: device, 2^k affine points each.  s must not lie in the domain (PZ_ERR_INVALID). */
 int pz_srs_setup_g1_dev(pz_ctx* ctx, uint32_t k, const uint64_t s[4], const uint64_t omega[4], uint64_t* d_g,
                         uint64_t* d_g_lagrange);
+/* on-curve validation of n affine points on the device (y^2 = x^3 + 3, canonical coordinates, identity (0,0)
+ * accepted): *n_bad = number of points that fail.  The check halo2curves' read_raw performs when ParamsKZG::read
+ * loads a `params/kzg_bn254_{k}.srs` file (paillier_halo2_amd/srs.py reads that format). */
+int pz_g1_check_dev(pz_ctx* ctx, const uint64_t* d_points, size_t n, uint64_t* n_bad);
 /* evaluation of n_cols coefficient-form polynomials (n coefficients each, device) at the point x:
  * d_out[col] = sum_i d_coeffs[col][i] * x^i   (the evals phase of create_proof / eval_polynomial). */
 int pz_poly_eval_dev(pz_ctx* ctx, const uint64_t* d_coeffs, size_t n_cols, size_t col_stride, size_t n,

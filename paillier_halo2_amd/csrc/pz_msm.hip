@@ -795,6 +795,44 @@ extern "C" int pz_g1_normalize(pz_ctx* ctx, const uint64_t* jac, size_t n, uint6
     return PZ_OK;
 }
 
+// on-curve check of affine points (identity (0,0) accepted): the is_on_curve assertion of halo2curves' read_raw
+__global__ __launch_bounds__(256) void k_g1_check(const G1Affine* __restrict__ pts, size_t n, unsigned long long* bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1Affine p = aff_load(pts + i);
+    bool ok = aff_is_inf(p);
+    if (!ok) {
+        // coordinates must be canonical (< p) and satisfy y^2 = x^3 + 3
+        Fq three = fp_add(fp_add(fp_one<FqTag>(), fp_one<FqTag>()), fp_one<FqTag>());
+        Fq rhs = fp_add(fp_mul(fp_sqr(p.x), p.x), three);
+        Fq rx = p.x, ry = p.y;
+        fp_reduce_once(rx);
+        fp_reduce_once(ry);
+        bool canon = true;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) canon = canon && rx.v[k] == p.x.v[k] && ry.v[k] == p.y.v[k];
+        Fq d = fp_sub(fp_sqr(p.y), rhs);
+        ok = canon && fp_is_zero(d);
+    }
+    if (!ok) atomicAdd(bad, 1ull);
+}
+
+extern "C" int pz_g1_check_dev(pz_ctx* ctx, const uint64_t* d_points, size_t n, uint64_t* n_bad) {
+    if (!ctx || !n_bad || (n && !d_points)) return PZ_ERR_INVALID;
+    *n_bad = 0;
+    if (!n) return PZ_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    void* cnt;
+    PZCHK(pz_ws_get(ctx, WS_MISC, 8, &cnt));
+    HIPCHK(ctx, hipMemsetAsync(cnt, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_g1_check, dim3(pz_div_up(n, 256)), dim3(256), 0, ctx->stream, (const G1Affine*)d_points, n,
+                       (unsigned long long*)cnt);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(n_bad, cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PZ_OK;
+}
+
 extern "C" int pz_g1_fixed_base_mul_dev(pz_ctx* ctx, const uint64_t* d_scalars, size_t n, uint64_t* d_out_affine) {
     if (!ctx || (n && (!d_scalars || !d_out_affine))) return PZ_ERR_INVALID;
     if (!n) return PZ_OK;

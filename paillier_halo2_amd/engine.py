@@ -279,6 +279,12 @@ class Engine:
         self._chk(self.L.pz_srs_setup_g1_dev(self.ctx, k, _ptr(_np(s).reshape(4)), _ptr(_np(omega).reshape(4)), VP(d_g),
                                              VP(d_g_lagrange)), "pz_srs_setup_g1_dev")
 
+    def g1_check_dev(self, d_points: int, n: int) -> int:
+        """number of points (device, affine) that are not on the curve"""
+        bad = C.c_uint64()
+        self._chk(self.L.pz_g1_check_dev(self.ctx, VP(d_points), n, C.byref(bad)), "pz_g1_check_dev")
+        return bad.value
+
     def poly_eval_dev(self, d_coeffs: int, n_cols: int, col_stride_u64: int, n: int, x, d_out: int):
         self._chk(self.L.pz_poly_eval_dev(self.ctx, VP(d_coeffs), n_cols, col_stride_u64, n, _ptr(_np(x).reshape(4)),
                                           VP(d_out)), "pz_poly_eval_dev")

@@ -265,3 +265,49 @@ def test_quotient_of_real_witness_columns(eng, cref):
         lhs = (lhs * y + q[j] * (a0[j] + a1[j] * a2[j] - a3[j])) % P.FR_R
     assert lhs == hx * (pow(x, n, P.FR_R) - 1) % P.FR_R
     assert lhs != 0
+
+
+def test_params_kzg_file_to_commitments(eng, cref, tmp_path):
+    """SRS through its file format: derive g / g_lagrange on the device (ParamsKZG::setup), write the RawBytes file,
+    read it back (memory-mapped), validate on-curve on the device, and commit a column against the file's
+    g_lagrange: same point as the commitment against the device-resident SRS.  A corrupted point is detected."""
+    import torch
+
+    from paillier_halo2_amd import srs
+
+    k = 10
+    n = 1 << k
+    rng = random.Random(470)
+    s_toxic = rng.randrange(2, P.FR_R)
+    d_g = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    d_gl = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    eng.srs_setup_g1_dev(k, _m(cref, s_toxic), _m(cref, P.fr_omega(k)), d_g.data_ptr(), d_gl.data_ptr())
+    eng.sync()
+    path = str(tmp_path / ("kzg_bn254_%d.srs" % k))
+    srs.write_params_kzg(path, k, d_g.cpu().numpy().astype(np.uint64), d_gl.cpu().numpy().astype(np.uint64))
+    prm = srs.read_params_kzg(path, expect_k=k)
+    d_file = torch.from_numpy(np.ascontiguousarray(prm.g_lagrange).astype(np.int64)).cuda()
+    assert eng.g1_check_dev(d_file.data_ptr(), n) == 0
+    assert eng.g1_check_dev(torch.from_numpy(np.ascontiguousarray(prm.g).astype(np.int64)).cuda().data_ptr(), n) == 0
+    col = [rng.randrange(P.FR_R) for _ in range(n)]
+    d_col = _dev(cref, col)
+    outs = []
+    for src in (d_file, d_gl):
+        bases = eng.load_bases_dev(src.data_ptr(), n)
+        d_out = torch.zeros((1, 12), dtype=torch.int64, device="cuda")
+        eng.msm_dev(bases, d_col.data_ptr(), 1, n, 4 * n, d_out.data_ptr())
+        eng.sync()
+        outs.append(eng.g1_normalize(d_out.cpu().numpy().astype(np.uint64))[0])
+        bases.free()
+    assert np.array_equal(outs[0], outs[1])
+    # f(s) * G with f the interpolant of the column: commit_lagrange == [f(s)] G
+    coeffs = P.intt(col, P.fr_omega(k))
+    want = P.g1_mul(P.G1_GEN, P.poly_eval(coeffs, s_toxic))
+    assert cref.affine_mont_to_ints(outs[0].reshape(1, 8))[0] == want
+    # corruption: flip one limb of one y coordinate, and a non-canonical coordinate
+    bad = d_file.clone()
+    bad[7, 4] ^= 1
+    bad[9, 0:4] = -1
+    assert eng.g1_check_dev(bad.data_ptr(), n) == 2
+    bad[11] = 0  # the identity is a valid element
+    assert eng.g1_check_dev(bad.data_ptr(), n) == 2

@@ -1,5 +1,9 @@
 """CPU: host-side logic of the package (no GPU): circuit-shape arithmetic, constants, window partition."""
+import os
 import random
+
+import numpy as np
+import pytest
 
 from oracle import pyref as P
 from paillier_halo2_amd import consts, layout
@@ -55,3 +59,32 @@ def test_window_ranges_cover_exactly():
                 lo, hi = window_range(W, r, world)
                 seen += list(range(lo, hi))
             assert seen == list(range(W))
+
+
+def test_params_kzg_file_roundtrip_and_malformed(tmp_path):
+    """ParamsKZG RawBytes file (params/kzg_bn254_{k}.srs): write -> read is the identity; wrong sizes / k are refused"""
+    from paillier_halo2_amd import srs
+
+    k = 4
+    rng = np.random.default_rng(5)
+    g = rng.integers(0, 1 << 63, size=(1 << k, 8), dtype=np.uint64)
+    gl = rng.integers(0, 1 << 63, size=(1 << k, 8), dtype=np.uint64)
+    g2, sg2 = bytes(range(128)), bytes(reversed(range(128)))
+    p = str(tmp_path / "kzg_bn254_4.srs")
+    srs.write_params_kzg(p, k, g, gl, g2, sg2)
+    assert os.path.getsize(p) == srs.file_size(k) == 4 + 2 * 16 * 64 + 256
+    prm = srs.read_params_kzg(p, expect_k=k)
+    assert prm.k == k and prm.n == 16 and prm.g2 == g2 and prm.s_g2 == sg2
+    assert np.array_equal(prm.g, g) and np.array_equal(prm.g_lagrange, gl)
+    raw = open(p, "rb").read()
+    assert raw[:4] == (4).to_bytes(4, "little") and raw[4:12] == int(g[0, 0]).to_bytes(8, "little")
+    with pytest.raises(ValueError):
+        srs.read_params_kzg(p, expect_k=5)
+    open(p, "wb").write(raw[:-1])
+    with pytest.raises(ValueError):
+        srs.read_params_kzg(p)
+    open(p, "wb").write(raw[:3])
+    with pytest.raises(ValueError):
+        srs.read_params_kzg(p)
+    with pytest.raises(ValueError):
+        srs.write_params_kzg(p, k, g[:3], gl)
