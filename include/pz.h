@@ -211,6 +211,20 @@ int pz_permutation_product_dev(pz_ctx* ctx, const uint64_t* d_cols, size_t col_s
                                size_t sigma_stride, size_t m, uint32_t log_n, const uint64_t omega[4],
                                const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta_start[4],
                                const uint64_t delta[4], const uint64_t z0[4], uint64_t* d_z);
+/* lookup::prover permute_expression_pair for halo2-lib's range-check lookups: every input column (values in
+ * [0, 2^value_bits), value_bits <= 24) against the shared table column, over the first `rows` (usable) rows:
+ *   d_perm_inputs[col] = the input column sorted ascending;
+ *   d_perm_tables[col][i] = d_perm_inputs[col][i] where a run of equal inputs starts, otherwise the left-over table
+ *   values in ascending order (halo2's BTreeMap order).
+ * PZ_ERR_RANGE if a value is not a canonical integer below 2^value_bits or an input value does not occur in the
+ * table (the reference's prover fails there: the lookup is unsatisfiable).  Rows >= `rows` are not written. */
+int pz_lookup_permute_dev(pz_ctx* ctx, const uint64_t* d_inputs, size_t n_cols, size_t col_stride,
+                          const uint64_t* d_table, size_t rows, uint32_t value_bits, uint64_t* d_perm_inputs,
+                          uint64_t* d_perm_tables, size_t out_stride);
+/* lookup grand product: d_z[0] = z0, d_z[i+1] = d_z[i] * (A[i]+beta)(S[i]+gamma) / ((A'[i]+beta)(S'[i]+gamma)). */
+int pz_lookup_product_dev(pz_ctx* ctx, const uint64_t* d_input, const uint64_t* d_table, const uint64_t* d_perm_input,
+                          const uint64_t* d_perm_table, size_t n, const uint64_t beta[4], const uint64_t gamma[4],
+                          const uint64_t z0[4], uint64_t* d_z);
 /* evaluate_h, custom-gate part, for halo2-lib's vertical gate on the extended domain of 2^log_ext points:
  *   for each column j in order:  d_h[i] = d_h[i]*y + sel_j[i] * (a_j[i] + a_j[i+s]*a_j[i+2s] - a_j[i+3s]),
  * indices mod 2^log_ext, s = rot_step = 2^(log_ext - k) (one row of the 2^k domain).  d_h is read and written. */

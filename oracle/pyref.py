@@ -407,6 +407,41 @@ def permutation_product(cols: Sequence[Sequence[int]], sigmas: Sequence[Sequence
     return prefix_product(mv, z0) if n else []
 
 
+def permute_expression_pair(inp: Sequence[int], tab: Sequence[int]) -> Tuple[List[int], List[int]]:
+    """halo2 lookup::prover::permute_expression_pair on the usable rows: input sorted ascending; the table cell
+    equals the input cell where a run of equal inputs starts, the other rows take the left-over table values in
+    ascending (BTreeMap) order.  Raises if an input value is missing from the table (halo2 returns an error)."""
+    A = sorted(x % FR_R for x in inp)
+    left = {}
+    for t in tab:
+        left[t % FR_R] = left.get(t % FR_R, 0) + 1
+    S: List[int] = [0] * len(A)
+    repeated = []
+    for i, v in enumerate(A):
+        if i == 0 or v != A[i - 1]:
+            if left.get(v, 0) == 0:
+                raise ValueError("lookup input %d not in the table" % v)
+            left[v] -= 1
+            S[i] = v
+        else:
+            repeated.append(i)
+    rest = [v for v in sorted(left) for _ in range(left[v])]
+    assert len(rest) == len(repeated)
+    for i, v in zip(repeated, rest):
+        S[i] = v
+    return A, S
+
+
+def lookup_product(A: Sequence[int], S: Sequence[int], Ap: Sequence[int], Sp: Sequence[int], beta: int, gamma: int,
+                   z0: int = 1) -> List[int]:
+    """z[i+1] = z[i] (A[i]+beta)(S[i]+gamma) / ((A'[i]+beta)(S'[i]+gamma))"""
+    mv = []
+    for a, s_, ap, sp in zip(A, S, Ap, Sp):
+        den = (ap + beta) * (sp + gamma) % FR_R
+        mv.append((a + beta) * (s_ + gamma) % FR_R * (pow(den, -1, FR_R) if den else 0) % FR_R)
+    return prefix_product(mv, z0) if mv else []
+
+
 def quotient_gate(adv_ext: Sequence[Sequence[int]], sel_ext: Sequence[Sequence[int]], step: int, y: int,
                   h: Sequence[int]) -> List[int]:
     """evaluate_h, custom-gate part: per column (in order) h = h*y + sel*(a0 + a1*a2 - a3), rotations = step indices

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_batch_invert(Fr* __restrict__ a, Fr* __
     }
 }
 
-static int batch_invert(pz_ctx* ctx, Fr* d_a, size_t n) {
+int pz_batch_invert_internal(pz_ctx* ctx, Fr* d_a, size_t n) {
     if (!n) return PZ_OK;
     void* scr;
     PZCHK(pz_ws_get(ctx, WS_BIG_A, n * 32, &scr));
@@ -68,7 +68,7 @@ static int batch_invert(pz_ctx* ctx, Fr* d_a, size_t n) {
 extern "C" int pz_fr_batch_invert_dev(pz_ctx* ctx, uint64_t* d_a, size_t n) {
     if (!ctx || (n && !d_a)) return PZ_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    return batch_invert(ctx, (Fr*)d_a, n);
+    return pz_batch_invert_internal(ctx, (Fr*)d_a, n);
 }
 
 // ---------------------------------------------------------------------------------------------- prefix product
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k_pp_apply(const Fr* __restrict__ a, size
     }
 }
 
-static int prefix_product(pz_ctx* ctx, const Fr* d_a, size_t n, Fr z0, Fr* d_z) {
+int pz_prefix_product_internal(pz_ctx* ctx, const Fr* d_a, size_t n, Fr z0, Fr* d_z) {
     if (!n) return PZ_OK;
     const unsigned nb = pz_div_up(pz_div_up(n, PP_K), 256);
     void* ws;
@@ -135,7 +135,7 @@ static int prefix_product(pz_ctx* ctx, const Fr* d_a, size_t n, Fr z0, Fr* d_z) 
 extern "C" int pz_fr_prefix_product_dev(pz_ctx* ctx, const uint64_t* d_a, size_t n, const uint64_t z0[4], uint64_t* d_z) {
     if (!ctx || !z0 || (n && (!d_a || !d_z))) return PZ_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    return prefix_product(ctx, (const Fr*)d_a, n, fr_from_u64(z0), (Fr*)d_z);
+    return pz_prefix_product_internal(ctx, (const Fr*)d_a, n, fr_from_u64(z0), (Fr*)d_z);
 }
 
 // ---------------------------------------------------------------------------------------------- permutation product
@@ -180,10 +180,10 @@ extern "C" int pz_permutation_product_dev(pz_ctx* ctx, const uint64_t* d_cols, s
                        (const Fr*)d_sigma, sigma_stride / 4, (unsigned)m, n, (const Fr*)wp, fr_from_u64(beta), fr_from_u64(gamma),
                        fr_from_u64(delta_start), fr_from_u64(delta), num, den);
     HIPCHK(ctx, hipGetLastError());
-    PZCHK(batch_invert(ctx, den, n));
+    PZCHK(pz_batch_invert_internal(ctx, den, n));
     hipLaunchKernelGGL(k_fr_mul_inplace, dim3(pz_div_up(n, 256)), dim3(256), 0, ctx->stream, num, (const Fr*)den, n);
     HIPCHK(ctx, hipGetLastError());
-    return prefix_product(ctx, num, n, fr_from_u64(z0), (Fr*)d_z);
+    return pz_prefix_product_internal(ctx, num, n, fr_from_u64(z0), (Fr*)d_z);
 }
 
 // ---------------------------------------------------------------------------------------------- gate part of evaluate_h

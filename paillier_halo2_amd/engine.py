@@ -312,6 +312,17 @@ class Engine:
                                                     self._fr1(delta_start), self._fr1(delta), self._fr1(z0), VP(d_z)),
                   "pz_permutation_product_dev")
 
+    def lookup_permute_dev(self, d_inputs: int, n_cols: int, col_stride_u64: int, d_table: int, rows: int, value_bits: int,
+                           d_perm_inputs: int, d_perm_tables: int, out_stride_u64: int):
+        self._chk(self.L.pz_lookup_permute_dev(self.ctx, VP(d_inputs), n_cols, col_stride_u64, VP(d_table), rows, value_bits,
+                                               VP(d_perm_inputs), VP(d_perm_tables), out_stride_u64), "pz_lookup_permute_dev")
+
+    def lookup_product_dev(self, d_input: int, d_table: int, d_perm_input: int, d_perm_table: int, n: int, beta, gamma, z0,
+                           d_z: int):
+        self._chk(self.L.pz_lookup_product_dev(self.ctx, VP(d_input), VP(d_table), VP(d_perm_input), VP(d_perm_table), n,
+                                               self._fr1(beta), self._fr1(gamma), self._fr1(z0), VP(d_z)),
+                  "pz_lookup_product_dev")
+
     def quotient_gate_dev(self, d_adv_ext: int, adv_stride_u64: int, d_sel_ext: int, sel_stride_u64: int, n_cols: int,
                           log_ext: int, rot_step: int, y, d_h: int):
         self._chk(self.L.pz_quotient_gate_dev(self.ctx, VP(d_adv_ext), adv_stride_u64, VP(d_sel_ext), sel_stride_u64,

@@ -311,3 +311,117 @@ def test_params_kzg_file_to_commitments(eng, cref, tmp_path):
     assert eng.g1_check_dev(bad.data_ptr(), n) == 2
     bad[11] = 0  # the identity is a valid element
     assert eng.g1_check_dev(bad.data_ptr(), n) == 2
+
+
+@pytest.mark.parametrize("rows,bits,ncols", [(1, 3, 1), (50, 4, 2), (1000, 8, 3), (4086, 11, 2), ((1 << 17) - 10, 16, 2)])
+def test_lookup_permute_and_product_vs_oracle(eng, cref, rows, bits, ncols):
+    """permute_expression_pair (counting sort) and the lookup product vs the oracle's sort + BTreeMap restatement;
+    table = {0 .. 2^bits - 1} zero-padded, as halo2-lib's RangeChip lays it out"""
+    import torch
+
+    rng = random.Random(480 + rows)
+    M = 1 << bits
+    table = [i if i < M else 0 for i in range(rows)]
+    present = set(table)
+    cols = []
+    for j in range(ncols):
+        if j == 0:   # skewed like range-check digits: many zeros and small values
+            c = [rng.choice((0, 0, 1, rng.randrange(M))) for _ in range(rows)]
+        else:
+            c = [rng.randrange(M) for _ in range(rows)]
+        cols.append([v if v in present else 0 for v in c])
+    stride = 4 * rows + 4
+    d_in = torch.zeros((ncols, stride), dtype=torch.int64, device="cuda")
+    d_in[:, : 4 * rows] = _dev(cref, cols).reshape(ncols, 4 * rows)
+    d_tab = _dev(cref, table)
+    d_pi = torch.zeros((ncols, stride), dtype=torch.int64, device="cuda")
+    d_pt = torch.zeros((ncols, stride), dtype=torch.int64, device="cuda")
+    eng.lookup_permute_dev(d_in.data_ptr(), ncols, stride, d_tab.data_ptr(), rows, bits, d_pi.data_ptr(), d_pt.data_ptr(), stride)
+    eng.sync()
+    beta, gamma, z0 = (rng.randrange(1, P.FR_R) for _ in range(3))
+    for j in range(ncols):
+        Ap, Sp = P.permute_expression_pair(cols[j], table)
+        got_a, got_s = _ints(cref, d_pi[j, : 4 * rows]), _ints(cref, d_pt[j, : 4 * rows])
+        assert got_a == Ap, j
+        assert got_s == Sp, j
+        assert sorted(got_s) == sorted(table)          # S' is a permutation of the table ...
+        assert all(got_a[i] == got_s[i] or got_a[i] == got_a[i - 1] for i in range(rows))   # ... and halo2's row rule holds
+        d_z = torch.zeros((rows, 4), dtype=torch.int64, device="cuda")
+        eng.lookup_product_dev(d_in[j].data_ptr(), d_tab.data_ptr(), d_pi[j].data_ptr(), d_pt[j].data_ptr(), rows,
+                               _m(cref, beta), _m(cref, gamma), _m(cref, z0), d_z.data_ptr())
+        eng.sync()
+        z = _ints(cref, d_z)
+        if rows <= 5000:
+            assert z == P.lookup_product(cols[j], table, Ap, Sp, beta, gamma, z0), j
+        # telescoping: both sides are permutations of each other, so one more factor returns to z0
+        i = rows - 1
+        num = (cols[j][i] + beta) * (table[i] + gamma) % P.FR_R
+        den = (Ap[i] + beta) * (Sp[i] + gamma) % P.FR_R
+        assert z[-1] * num % P.FR_R == z0 * den % P.FR_R, j
+
+
+def test_lookup_permute_rejects_unsatisfiable_inputs(eng, cref):
+    import torch
+
+    import paillier_halo2_amd as pz
+    from paillier_halo2_amd import _lib
+
+    rows, bits = 64, 4
+    table = [i % 16 for i in range(rows)]
+    d_tab = _dev(cref, table)
+    out = torch.zeros((2, rows, 4), dtype=torch.int64, device="cuda")
+    for bad in ([16] + [0] * (rows - 1),               # not below 2^value_bits
+                [P.FR_R - 1] + [0] * (rows - 1)):      # a "negative" cell
+        d_bad = _dev(cref, bad)
+        with pytest.raises(pz.PzError) as e:
+            eng.lookup_permute_dev(d_bad.data_ptr(), 1, 4 * rows, d_tab.data_ptr(), rows, bits, out[0].data_ptr(),
+                                   out[1].data_ptr(), 4 * rows)
+        assert e.value.status == _lib.PZ_ERR_RANGE
+    # value in range but absent from the table
+    d_nine, d_tab2 = _dev(cref, [9] * rows), _dev(cref, [i % 8 for i in range(rows)])
+    with pytest.raises(pz.PzError) as e:
+        eng.lookup_permute_dev(d_nine.data_ptr(), 1, 4 * rows, d_tab2.data_ptr(), rows, bits, out[0].data_ptr(),
+                               out[1].data_ptr(), 4 * rows)
+    assert e.value.status == _lib.PZ_ERR_RANGE
+
+
+def test_lookup_argument_on_real_witness_digits(eng, cref):
+    """K3 -> K4 lookup cell stream (the range-check digits of a real encrypt trace) as lookup columns at k = 12:
+    every digit is in the table, the permuted pair obeys halo2's row rule and the product telescopes"""
+    import torch
+
+    nn, g, m, r = P.synth_paillier_inputs(128, 0x5042, standard_g=False)
+    Ln, L, k = 2, 4, 12
+    lb, n = k - 1, 1 << k
+    rows = n - 10
+    arr = lambda x: cref.int_to_limbs(x, Ln)
+    _, steps, ng, nr = eng.paillier_encrypt(Ln, arr(nn), arr(g), arr(m), arr(r))
+    tot = int(ng[0]) + int(nr[0]) + 1
+    adv_n, lk_n = eng.witness_cells_per_step(L, 64, lb)
+    ncols = (tot * lk_n) // rows
+    assert ncols >= 2
+    ncols = min(ncols, 6)
+    d_steps = torch.from_numpy(steps[0, :tot].astype(np.int64)).cuda()
+    d_mod = torch.from_numpy(cref.int_to_limbs(nn * nn, L).astype(np.int64)).cuda()
+    d_lk = torch.zeros((tot * lk_n, 4), dtype=torch.int64, device="cuda")
+    eng.witness_expand_dev(L, 64, lb, d_steps.data_ptr(), tot, d_mod.data_ptr(), 0, d_lk.data_ptr())
+    table = [i if i < (1 << lb) else 0 for i in range(rows)]
+    d_tab = _dev(cref, table)
+    d_pi = torch.zeros((ncols, rows, 4), dtype=torch.int64, device="cuda")
+    d_pt = torch.zeros((ncols, rows, 4), dtype=torch.int64, device="cuda")
+    eng.lookup_permute_dev(d_lk.data_ptr(), ncols, 4 * rows, d_tab.data_ptr(), rows, lb, d_pi.data_ptr(), d_pt.data_ptr(), 4 * rows)
+    rng = random.Random(490)
+    beta, gamma = rng.randrange(1, P.FR_R), rng.randrange(1, P.FR_R)
+    cells = _ints(cref, d_lk[: ncols * rows])
+    for j in range(ncols):
+        A = cells[j * rows:(j + 1) * rows]
+        Ap, Sp = _ints(cref, d_pi[j]), _ints(cref, d_pt[j])
+        assert Ap == sorted(A) and sorted(Sp) == sorted(table)
+        assert all(Ap[i] == Sp[i] or Ap[i] == Ap[i - 1] for i in range(rows))
+        d_z = torch.zeros((rows, 4), dtype=torch.int64, device="cuda")
+        eng.lookup_product_dev(d_lk[j * rows:].data_ptr(), d_tab.data_ptr(), d_pi[j].data_ptr(), d_pt[j].data_ptr(), rows,
+                               _m(cref, beta), _m(cref, gamma), _m(cref, 1), d_z.data_ptr())
+        eng.sync()
+        z = _ints(cref, d_z)
+        i = rows - 1
+        assert z[-1] * (A[i] + beta) % P.FR_R * (table[i] + gamma) % P.FR_R == (Ap[i] + beta) * (Sp[i] + gamma) % P.FR_R

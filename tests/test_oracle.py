@@ -227,3 +227,22 @@ def test_next_row_oracles_satisfy_their_defining_identities():
     ev = lambda c, pt: P.poly_eval(c, pt)
     lhs = ev(sc, x) * (ev(cc, x) + ev(cc, x * w_n % R) * ev(cc, x * w_n * w_n % R) - ev(cc, x * pow(w_n, 3, R) % R)) % R
     assert lhs == ev(hc, x) * (pow(x, n, R) - 1) % R
+
+
+def test_lookup_oracle_row_rule_and_telescoping():
+    """permute_expression_pair: sorted input, table a permutation of the table, each row starts a run or repeats the
+    previous input; the lookup product returns to z0 after the last row (what halo2's verifier enforces)"""
+    rng = random.Random(78)
+    R = P.FR_R
+    rows, M = 300, 16
+    table = [i if i < M else 0 for i in range(rows)]
+    A = [rng.choice((0, 1, rng.randrange(M))) for _ in range(rows)]
+    Ap, Sp = P.permute_expression_pair(A, table)
+    assert Ap == sorted(A) and sorted(Sp) == sorted(table)
+    assert all(Ap[i] == Sp[i] or Ap[i] == Ap[i - 1] for i in range(rows)) and Ap[0] == Sp[0]
+    beta, gamma = rng.randrange(R), rng.randrange(R)
+    z = P.lookup_product(A, table, Ap, Sp, beta, gamma, 1)
+    i = rows - 1
+    assert z[-1] * (A[i] + beta) * (table[i] + gamma) % R == (Ap[i] + beta) * (Sp[i] + gamma) % R
+    with pytest.raises(ValueError):
+        P.permute_expression_pair([17] + A[1:], table)
