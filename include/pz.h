@@ -231,6 +231,27 @@ int pz_lookup_product_dev(pz_ctx* ctx, const uint64_t* d_input, const uint64_t* 
 int pz_quotient_gate_dev(pz_ctx* ctx, const uint64_t* d_adv_ext, size_t adv_stride, const uint64_t* d_sel_ext,
                          size_t sel_stride, size_t n_cols, uint32_t log_ext, uint32_t rot_step, const uint64_t y[4],
                          uint64_t* d_h);
+/* evaluate_h, permutation argument (halo2 plonk/evaluation.rs "Permutations"): m_total columns in n_sets chunks of
+ * chunk_len, all arrays on the extended domain of 2^log_ext points X_i = coset_g * omega_ext^i, one domain row =
+ * rot_step indices, last_rotation = blinding_factors + 1 rows.  In halo2's order, each folded as h = h*y + term:
+ *   l0 (1 - z_0);  l_last (z_last^2 - z_last);  for j > 0: l0 (z_j - z_{j-1}(omega^-last_rotation X));
+ *   for every set: l_active ( z_j(omega X) prod_c (v_c + beta sigma_c + gamma) - z_j(X) prod_c (v_c + delta^c beta X + gamma) ). */
+int pz_quotient_permutation_dev(pz_ctx* ctx, const uint64_t* d_cols_ext, size_t col_stride, const uint64_t* d_sigma_ext,
+                                size_t sigma_stride, const uint64_t* d_z_ext, size_t z_stride, uint32_t n_sets,
+                                uint32_t chunk_len, uint32_t m_total, uint32_t log_ext, uint32_t rot_step,
+                                uint32_t last_rotation, const uint64_t* d_l0, const uint64_t* d_l_last,
+                                const uint64_t* d_l_active, const uint64_t beta[4], const uint64_t gamma[4],
+                                const uint64_t delta[4], const uint64_t coset_g[4], const uint64_t omega_ext[4],
+                                const uint64_t y[4], uint64_t* d_h);
+/* evaluate_h, lookup arguments (n_lookups of them against one table column), per lookup in halo2's order:
+ *   l0 (1 - z);  l_last (z^2 - z);  l_active ( z(omega X)(a' + beta)(s' + gamma) - z(X)(a + beta)(s + gamma) );
+ *   l0 (a' - s');  l_active (a' - s')(a' - a'(omega^-1 X)). */
+int pz_quotient_lookup_dev(pz_ctx* ctx, const uint64_t* d_input_ext, size_t input_stride, const uint64_t* d_table_ext,
+                           const uint64_t* d_perm_input_ext, size_t perm_input_stride, const uint64_t* d_perm_table_ext,
+                           size_t perm_table_stride, const uint64_t* d_z_ext, size_t z_stride, uint32_t n_lookups,
+                           uint32_t log_ext, uint32_t rot_step, const uint64_t* d_l0, const uint64_t* d_l_last,
+                           const uint64_t* d_l_active, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t y[4],
+                           uint64_t* d_h);
 /* division by the vanishing polynomial on the extended coset: d_h[i] /= (coset_g * omega_ext^i)^(2^log_n) - 1,
  * i < 2^(log_n + log_e) (the divisor takes 2^log_e distinct values). */
 int pz_quotient_finish_dev(pz_ctx* ctx, uint64_t* d_h, uint32_t log_n, uint32_t log_e, const uint64_t coset_g[4],

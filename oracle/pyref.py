@@ -455,6 +455,59 @@ def quotient_gate(adv_ext: Sequence[Sequence[int]], sel_ext: Sequence[Sequence[i
     return out
 
 
+def quotient_permutation(cols_ext, sigma_ext, z_ext, chunk_len: int, step: int, last_rot: int, l0, l_last, l_active,
+                         beta: int, gamma: int, delta: int, x0: int, w_ext: int, y: int, h) -> List[int]:
+    """evaluate_h "Permutations" block (halo2 plonk/evaluation.rs), extended domain, X_i = x0 * w_ext^i."""
+    N = len(h)
+    out = list(h)
+    ns = len(z_ext)
+    xi = x0 % FR_R
+    for i in range(N):
+        inx, ila = (i + step) % N, (i - last_rot * step) % N
+        v = out[i]
+        v = (v * y + (1 - z_ext[0][i]) * l0[i]) % FR_R
+        zl = z_ext[ns - 1][i]
+        v = (v * y + (zl * zl - zl) * l_last[i]) % FR_R
+        for j in range(1, ns):
+            v = (v * y + (z_ext[j][i] - z_ext[j - 1][ila]) * l0[i]) % FR_R
+        cur = beta * xi % FR_R
+        c = 0
+        for j in range(ns):
+            left, right = z_ext[j][inx], z_ext[j][i]
+            for _ in range(chunk_len):
+                if c >= len(cols_ext):
+                    break
+                left = left * ((cols_ext[c][i] + beta * sigma_ext[c][i] + gamma) % FR_R) % FR_R
+                right = right * ((cols_ext[c][i] + cur + gamma) % FR_R) % FR_R
+                cur = cur * delta % FR_R
+                c += 1
+            v = (v * y + (left - right) * l_active[i]) % FR_R
+        out[i] = v
+        xi = xi * w_ext % FR_R
+    return out
+
+
+def quotient_lookup(a_ext, s_ext, ap_ext, sp_ext, z_ext, step: int, l0, l_last, l_active, beta: int, gamma: int, y: int,
+                    h) -> List[int]:
+    """evaluate_h "Lookups" block for single-expression lookups sharing the table s."""
+    N = len(h)
+    out = list(h)
+    for i in range(N):
+        inx, ipr = (i + step) % N, (i - step) % N
+        v = out[i]
+        for a, ap, sp, z in zip(a_ext, ap_ext, sp_ext, z_ext):
+            v = (v * y + (1 - z[i]) * l0[i]) % FR_R
+            v = (v * y + (z[i] * z[i] - z[i]) * l_last[i]) % FR_R
+            lhs = z[inx] * (ap[i] + beta) % FR_R * (sp[i] + gamma) % FR_R
+            rhs = z[i] * (a[i] + beta) % FR_R * (s_ext[i] + gamma) % FR_R
+            v = (v * y + (lhs - rhs) * l_active[i]) % FR_R
+            ams = (ap[i] - sp[i]) % FR_R
+            v = (v * y + ams * l0[i]) % FR_R
+            v = (v * y + ams * (ap[i] - ap[ipr]) % FR_R * l_active[i]) % FR_R
+        out[i] = v
+    return out
+
+
 def quotient_finish(h: Sequence[int], log_n: int, log_e: int, coset_g: int, omega_ext: int) -> List[int]:
     """divide by the vanishing polynomial X^n - 1 at the points coset_g * omega_ext^i."""
     E = 1 << log_e

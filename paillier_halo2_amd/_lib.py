@@ -60,6 +60,11 @@ SIGNATURES = {
     "pz_lookup_permute_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, VP, C.c_size_t, C.c_uint32, VP, VP, C.c_size_t]),
     "pz_lookup_product_dev": (C.c_int, [VP, VP, VP, VP, VP, C.c_size_t, VP, VP, VP, VP]),
     "pz_quotient_gate_dev": (C.c_int, [VP, VP, C.c_size_t, VP, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, VP, VP]),
+    "pz_quotient_permutation_dev": (C.c_int, [VP, VP, C.c_size_t, VP, C.c_size_t, VP, C.c_size_t, C.c_uint32, C.c_uint32,
+                                              C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, VP, VP, VP, VP, VP, VP, VP, VP,
+                                              VP, VP]),
+    "pz_quotient_lookup_dev": (C.c_int, [VP, VP, C.c_size_t, VP, VP, C.c_size_t, VP, C.c_size_t, VP, C.c_size_t, C.c_uint32,
+                                         C.c_uint32, C.c_uint32, VP, VP, VP, VP, VP, VP, VP]),
     "pz_quotient_finish_dev": (C.c_int, [VP, VP, C.c_uint32, C.c_uint32, VP, VP]),
     "pz_fr_distribute_powers_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, C.c_size_t, VP, VP]),
     "pz_poly_div_linear_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, C.c_size_t, VP, VP, C.c_size_t]),

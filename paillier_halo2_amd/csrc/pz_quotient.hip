@@ -336,3 +336,153 @@ extern "C" int pz_poly_div_linear_dev(pz_ctx* ctx, const uint64_t* d_coeffs, siz
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- evaluate_h: permutation
+// halo2 plonk/evaluation.rs, "Permutations" block, on the extended coset (point X_i = x0 * w_ext^i):
+//   h = h*y + l0 (1 - z_0)
+//   h = h*y + l_last (z_last^2 - z_last)
+//   for sets j > 0:  h = h*y + l0 (z_j - z_{j-1}(w^-(blinding+1) X))
+//   for every set j: h = h*y + l_active ( z_j(wX) prod_c (v_c + beta sigma_c + gamma) - z_j(X) prod_c (v_c + delta^c beta X + gamma) )
+// with c running over the set's chunk of columns and delta^c continuing across sets.
+struct PermQ {
+    const Fr *cols, *sigma, *z, *l0, *llast, *lactive;
+    size_t cs, ss, zs, N;
+    unsigned n_sets, chunk_len, m_total, step, last_rot;
+    Fr beta, gamma, delta, x0, w_ext, y;
+};
+__global__ __launch_bounds__(256) void k_quotient_permutation(PermQ q, Fr* __restrict__ h) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q.N) return;
+    const size_t mask = q.N - 1;
+    const size_t i_next = (i + q.step) & mask;
+    const size_t i_last = (i + q.N - (size_t)q.last_rot * q.step) & mask;
+    const Fr one = fp_one<FrTag>();
+    const Fr l0 = fp_load<FrTag>(q.l0 + i), ll = fp_load<FrTag>(q.llast + i), la = fp_load<FrTag>(q.lactive + i);
+    Fr acc = fp_load<FrTag>(h + i);
+    const Fr z_first = fp_load<FrTag>(q.z + i);
+    acc = fp_add(fp_mul(acc, q.y), fp_mul(fp_sub(one, z_first), l0));
+    const Fr z_lastset = fp_load<FrTag>(q.z + (size_t)(q.n_sets - 1) * q.zs + i);
+    acc = fp_add(fp_mul(acc, q.y), fp_mul(fp_sub(fp_sqr(z_lastset), z_lastset), ll));
+    for (unsigned j = 1; j < q.n_sets; ++j) {
+        Fr d = fp_sub(fp_load<FrTag>(q.z + (size_t)j * q.zs + i), fp_load<FrTag>(q.z + (size_t)(j - 1) * q.zs + i_last));
+        acc = fp_add(fp_mul(acc, q.y), fp_mul(d, l0));
+    }
+    // beta * X_i, X_i = x0 * w_ext^i  (square-and-multiply over the bits of i: log2(N) products, no table)
+    Fr xi = q.x0;
+    {
+        Fr p = q.w_ext;
+        for (size_t e = i; e; e >>= 1) {
+            if (e & 1) xi = fp_mul(xi, p);
+            p = fp_sqr(p);
+        }
+    }
+    Fr cur = fp_mul(q.beta, xi);
+    unsigned c = 0;
+    for (unsigned j = 0; j < q.n_sets; ++j) {
+        Fr left = fp_load<FrTag>(q.z + (size_t)j * q.zs + i_next);
+        Fr right = fp_load<FrTag>(q.z + (size_t)j * q.zs + i);
+        for (unsigned t = 0; t < q.chunk_len && c < q.m_total; ++t, ++c) {
+            const Fr v = fp_add(fp_load<FrTag>(q.cols + (size_t)c * q.cs + i), q.gamma);
+            left = fp_mul(left, fp_add(v, fp_mul(q.beta, fp_load<FrTag>(q.sigma + (size_t)c * q.ss + i))));
+            right = fp_mul(right, fp_add(v, cur));
+            cur = fp_mul(cur, q.delta);
+        }
+        acc = fp_add(fp_mul(acc, q.y), fp_mul(fp_sub(left, right), la));
+    }
+    fp_store(h + i, acc);
+}
+
+extern "C" int pz_quotient_permutation_dev(pz_ctx* ctx, const uint64_t* d_cols_ext, size_t col_stride,
+                                           const uint64_t* d_sigma_ext, size_t sigma_stride, const uint64_t* d_z_ext,
+                                           size_t z_stride, uint32_t n_sets, uint32_t chunk_len, uint32_t m_total,
+                                           uint32_t log_ext, uint32_t rot_step, uint32_t last_rotation,
+                                           const uint64_t* d_l0, const uint64_t* d_l_last, const uint64_t* d_l_active,
+                                           const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta[4],
+                                           const uint64_t coset_g[4], const uint64_t omega_ext[4], const uint64_t y[4],
+                                           uint64_t* d_h) {
+    if (!ctx || !d_cols_ext || !d_sigma_ext || !d_z_ext || !d_l0 || !d_l_last || !d_l_active || !beta || !gamma || !delta ||
+        !coset_g || !omega_ext || !y || !d_h)
+        return PZ_ERR_INVALID;
+    if (log_ext > 28 || n_sets == 0 || chunk_len == 0 || m_total == 0 || col_stride % 4 || sigma_stride % 4 || z_stride % 4)
+        return PZ_ERR_INVALID;
+    const size_t N = (size_t)1 << log_ext;
+    if ((size_t)n_sets * chunk_len < m_total || (size_t)(n_sets - 1) * chunk_len >= m_total) return PZ_ERR_INVALID;
+    if (rot_step == 0 || rot_step >= N || (size_t)last_rotation * rot_step >= N) return PZ_ERR_INVALID;
+    if ((m_total > 1 && (col_stride < 4 * N || sigma_stride < 4 * N)) || (n_sets > 1 && z_stride < 4 * N)) return PZ_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PermQ q;
+    q.cols = (const Fr*)d_cols_ext; q.sigma = (const Fr*)d_sigma_ext; q.z = (const Fr*)d_z_ext;
+    q.l0 = (const Fr*)d_l0; q.llast = (const Fr*)d_l_last; q.lactive = (const Fr*)d_l_active;
+    q.cs = col_stride / 4; q.ss = sigma_stride / 4; q.zs = z_stride / 4; q.N = N;
+    q.n_sets = n_sets; q.chunk_len = chunk_len; q.m_total = m_total; q.step = rot_step; q.last_rot = last_rotation;
+    q.beta = fr_from_u64(beta); q.gamma = fr_from_u64(gamma); q.delta = fr_from_u64(delta);
+    q.x0 = fr_from_u64(coset_g); q.w_ext = fr_from_u64(omega_ext); q.y = fr_from_u64(y);
+    hipLaunchKernelGGL(k_quotient_permutation, dim3(pz_div_up(N, 256)), dim3(256), 0, ctx->stream, q, (Fr*)d_h);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- evaluate_h: lookups
+// per lookup (input a, table s, permuted a', s', product z), in halo2's order:
+//   h = h*y + l0 (1 - z);  h = h*y + l_last (z^2 - z)
+//   h = h*y + l_active ( z(wX)(a' + beta)(s' + gamma) - z(X)(a + beta)(s + gamma) )
+//   h = h*y + l0 (a' - s');  h = h*y + l_active (a' - s')(a' - a'(w^-1 X))
+struct LookQ {
+    const Fr *a, *s, *ap, *sp, *z, *l0, *llast, *lactive;
+    size_t as, aps, sps, zs, N;
+    unsigned n_lookups, step;
+    Fr beta, gamma, y;
+};
+__global__ __launch_bounds__(256) void k_quotient_lookup(LookQ q, Fr* __restrict__ h) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q.N) return;
+    const size_t mask = q.N - 1;
+    const size_t i_next = (i + q.step) & mask, i_prev = (i + q.N - q.step) & mask;
+    const Fr one = fp_one<FrTag>();
+    const Fr l0 = fp_load<FrTag>(q.l0 + i), ll = fp_load<FrTag>(q.llast + i), la = fp_load<FrTag>(q.lactive + i);
+    const Fr sg = fp_add(fp_load<FrTag>(q.s + i), q.gamma);
+    Fr acc = fp_load<FrTag>(h + i);
+    for (unsigned k = 0; k < q.n_lookups; ++k) {
+        const Fr z = fp_load<FrTag>(q.z + (size_t)k * q.zs + i), zn = fp_load<FrTag>(q.z + (size_t)k * q.zs + i_next);
+        const Fr ap = fp_load<FrTag>(q.ap + (size_t)k * q.aps + i), sp = fp_load<FrTag>(q.sp + (size_t)k * q.sps + i);
+        const Fr a = fp_load<FrTag>(q.a + (size_t)k * q.as + i);
+        acc = fp_add(fp_mul(acc, q.y), fp_mul(fp_sub(one, z), l0));
+        acc = fp_add(fp_mul(acc, q.y), fp_mul(fp_sub(fp_sqr(z), z), ll));
+        const Fr lhs = fp_mul(zn, fp_mul(fp_add(ap, q.beta), fp_add(sp, q.gamma)));
+        const Fr rhs = fp_mul(z, fp_mul(fp_add(a, q.beta), sg));
+        acc = fp_add(fp_mul(acc, q.y), fp_mul(fp_sub(lhs, rhs), la));
+        const Fr ams = fp_sub(ap, sp);
+        acc = fp_add(fp_mul(acc, q.y), fp_mul(ams, l0));
+        const Fr dprev = fp_sub(ap, fp_load<FrTag>(q.ap + (size_t)k * q.aps + i_prev));
+        acc = fp_add(fp_mul(acc, q.y), fp_mul(fp_mul(ams, dprev), la));
+    }
+    fp_store(h + i, acc);
+}
+
+extern "C" int pz_quotient_lookup_dev(pz_ctx* ctx, const uint64_t* d_input_ext, size_t input_stride, const uint64_t* d_table_ext,
+                                      const uint64_t* d_perm_input_ext, size_t perm_input_stride,
+                                      const uint64_t* d_perm_table_ext, size_t perm_table_stride, const uint64_t* d_z_ext,
+                                      size_t z_stride, uint32_t n_lookups, uint32_t log_ext, uint32_t rot_step,
+                                      const uint64_t* d_l0, const uint64_t* d_l_last, const uint64_t* d_l_active,
+                                      const uint64_t beta[4], const uint64_t gamma[4], const uint64_t y[4], uint64_t* d_h) {
+    if (!ctx || !d_input_ext || !d_table_ext || !d_perm_input_ext || !d_perm_table_ext || !d_z_ext || !d_l0 || !d_l_last ||
+        !d_l_active || !beta || !gamma || !y || !d_h)
+        return PZ_ERR_INVALID;
+    if (log_ext > 28 || input_stride % 4 || perm_input_stride % 4 || perm_table_stride % 4 || z_stride % 4) return PZ_ERR_INVALID;
+    const size_t N = (size_t)1 << log_ext;
+    if (rot_step == 0 || rot_step >= N) return PZ_ERR_INVALID;
+    if (n_lookups > 1 && (input_stride < 4 * N || perm_input_stride < 4 * N || perm_table_stride < 4 * N || z_stride < 4 * N))
+        return PZ_ERR_INVALID;
+    if (n_lookups == 0) return PZ_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    LookQ q;
+    q.a = (const Fr*)d_input_ext; q.s = (const Fr*)d_table_ext; q.ap = (const Fr*)d_perm_input_ext;
+    q.sp = (const Fr*)d_perm_table_ext; q.z = (const Fr*)d_z_ext;
+    q.l0 = (const Fr*)d_l0; q.llast = (const Fr*)d_l_last; q.lactive = (const Fr*)d_l_active;
+    q.as = input_stride / 4; q.aps = perm_input_stride / 4; q.sps = perm_table_stride / 4; q.zs = z_stride / 4; q.N = N;
+    q.n_lookups = n_lookups; q.step = rot_step;
+    q.beta = fr_from_u64(beta); q.gamma = fr_from_u64(gamma); q.y = fr_from_u64(y);
+    hipLaunchKernelGGL(k_quotient_lookup, dim3(pz_div_up(N, 256)), dim3(256), 0, ctx->stream, q, (Fr*)d_h);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}

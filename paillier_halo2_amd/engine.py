@@ -328,6 +328,25 @@ class Engine:
         self._chk(self.L.pz_quotient_gate_dev(self.ctx, VP(d_adv_ext), adv_stride_u64, VP(d_sel_ext), sel_stride_u64,
                                               n_cols, log_ext, rot_step, self._fr1(y), VP(d_h)), "pz_quotient_gate_dev")
 
+    def quotient_permutation_dev(self, d_cols_ext: int, col_stride_u64: int, d_sigma_ext: int, sigma_stride_u64: int,
+                                 d_z_ext: int, z_stride_u64: int, n_sets: int, chunk_len: int, m_total: int, log_ext: int,
+                                 rot_step: int, last_rotation: int, d_l0: int, d_l_last: int, d_l_active: int, beta, gamma,
+                                 delta, coset_g, omega_ext, y, d_h: int):
+        self._chk(self.L.pz_quotient_permutation_dev(
+            self.ctx, VP(d_cols_ext), col_stride_u64, VP(d_sigma_ext), sigma_stride_u64, VP(d_z_ext), z_stride_u64, n_sets,
+            chunk_len, m_total, log_ext, rot_step, last_rotation, VP(d_l0), VP(d_l_last), VP(d_l_active), self._fr1(beta),
+            self._fr1(gamma), self._fr1(delta), self._fr1(coset_g), self._fr1(omega_ext), self._fr1(y), VP(d_h)),
+            "pz_quotient_permutation_dev")
+
+    def quotient_lookup_dev(self, d_input_ext: int, input_stride_u64: int, d_table_ext: int, d_perm_input_ext: int,
+                            perm_input_stride_u64: int, d_perm_table_ext: int, perm_table_stride_u64: int, d_z_ext: int,
+                            z_stride_u64: int, n_lookups: int, log_ext: int, rot_step: int, d_l0: int, d_l_last: int,
+                            d_l_active: int, beta, gamma, y, d_h: int):
+        self._chk(self.L.pz_quotient_lookup_dev(
+            self.ctx, VP(d_input_ext), input_stride_u64, VP(d_table_ext), VP(d_perm_input_ext), perm_input_stride_u64,
+            VP(d_perm_table_ext), perm_table_stride_u64, VP(d_z_ext), z_stride_u64, n_lookups, log_ext, rot_step, VP(d_l0),
+            VP(d_l_last), VP(d_l_active), self._fr1(beta), self._fr1(gamma), self._fr1(y), VP(d_h)), "pz_quotient_lookup_dev")
+
     def quotient_finish_dev(self, d_h: int, log_n: int, log_e: int, coset_g, omega_ext):
         self._chk(self.L.pz_quotient_finish_dev(self.ctx, VP(d_h), log_n, log_e, self._fr1(coset_g), self._fr1(omega_ext)),
                   "pz_quotient_finish_dev")

@@ -425,3 +425,138 @@ def test_lookup_argument_on_real_witness_digits(eng, cref):
         z = _ints(cref, d_z)
         i = rows - 1
         assert z[-1] * (A[i] + beta) % P.FR_R * (table[i] + gamma) % P.FR_R == (Ap[i] + beta) * (Sp[i] + gamma) % P.FR_R
+
+
+def test_full_quotient_of_a_small_circuit(eng, cref):
+    """A complete evaluate_h on the device for a small halo2-shaped instance (k = 6, 5 blinding rows): 5 permuted
+    columns in 3 sets, 2 range-check lookups, blinded tails -- products, permuted columns and every constraint term
+    computed by the library.  (i) each term array equals the oracle's restatement of halo2's formulas; (ii) the
+    numerator vanishes on the domain: after the division the quotient has degree <= 3n - 4."""
+    import torch
+
+    R = P.FR_R
+    k, log_e, bf = 6, 2, 5
+    n, E = 1 << k, 1 << log_e
+    N = n * E
+    u = n - (bf + 1)                                   # usable rows; row u is the "last" row
+    rng = random.Random(500)
+    w_n, w_ext, cg = P.fr_omega(k), P.fr_omega(k + log_e), pow(P.FR_GENERATOR, (R - 1) // 3, R)   # coset gen = ZETA
+    delta = pow(P.FR_GENERATOR, 1 << P.FR_S, R)
+    beta, gamma, y = (rng.randrange(1, R) for _ in range(3))
+    m, chunk = 5, 2
+    nsets = -(-m // chunk)
+    # permutation over the usable rows of all columns; identity elsewhere
+    labels = [[pow(delta, c, R) * pow(w_n, i, R) % R for i in range(n)] for c in range(m)]
+    cells = [(c, i) for c in range(m) for i in range(u)]
+    image = list(cells)
+    rng.shuffle(image)
+    to = dict(zip(cells, image))
+    sigma = [list(labels[c]) for c in range(m)]
+    val = [[rng.randrange(R) for _ in range(n)] for _ in range(m)]     # blinded rows keep their random values
+    seen = set()
+    for cell in cells:
+        if cell in seen:
+            continue
+        v, cur = rng.randrange(R), cell
+        while cur not in seen:
+            seen.add(cur)
+            val[cur[0]][cur[1]] = v
+            cur = to[cur]
+    for (c, i), (pc, pi) in to.items():
+        sigma[c][i] = labels[pc][pi]
+    d_val, d_sig = _dev(cref, val), _dev(cref, sigma)
+    # permutation products, set by set (z_j[0] = z_{j-1}[u]), blinding rows randomised afterwards
+    d_z = torch.zeros((nsets, n, 4), dtype=torch.int64, device="cuda")
+    z0 = 1
+    z_sets = []
+    for j in range(nsets):
+        c0, mc = j * chunk, min(chunk, m - j * chunk)
+        eng.permutation_product_dev(d_val[c0].data_ptr(), 4 * n, d_sig[c0].data_ptr(), 4 * n, mc, k, _m(cref, w_n), _m(cref, beta),
+                                    _m(cref, gamma), _m(cref, pow(delta, c0, R)), _m(cref, delta), _m(cref, z0), d_z[j].data_ptr())
+        eng.sync()
+        zj = _ints(cref, d_z[j])
+        want = P.permutation_product(val[c0:c0 + mc], sigma[c0:c0 + mc], w_n, beta, gamma, pow(delta, c0, R), delta, z0)
+        assert zj == want, j
+        zj[u + 1:] = [rng.randrange(R) for _ in range(n - u - 1)]
+        z_sets.append(zj)
+        z0 = zj[u]
+    assert z_sets[-1][u] == 1          # the grand product closes
+    d_z = _dev(cref, z_sets)
+    # lookups: 2 columns of 4-bit digits on the usable rows, table {0..15} zero-padded
+    lbits, nl = 4, 2
+    table = [i if i < (1 << lbits) else 0 for i in range(n)]
+    A = [[rng.randrange(1 << lbits) if i < u else rng.randrange(R) for i in range(n)] for _ in range(nl)]
+    d_A, d_S = _dev(cref, A), _dev(cref, table)
+    d_Ap = torch.zeros((nl, n, 4), dtype=torch.int64, device="cuda")
+    d_Sp = torch.zeros((nl, n, 4), dtype=torch.int64, device="cuda")
+    eng.lookup_permute_dev(d_A.data_ptr(), nl, 4 * n, d_S.data_ptr(), u, lbits, d_Ap.data_ptr(), d_Sp.data_ptr(), 4 * n)
+    eng.sync()
+    Ap = [_ints(cref, d_Ap[j]) for j in range(nl)]
+    Sp = [_ints(cref, d_Sp[j]) for j in range(nl)]
+    zl = []
+    for j in range(nl):
+        assert (Ap[j][:u], Sp[j][:u]) == P.permute_expression_pair(A[j][:u], table[:u])
+        for arr in (Ap[j], Sp[j]):
+            arr[u:] = [rng.randrange(R) for _ in range(n - u)]
+    d_Ap, d_Sp = _dev(cref, Ap), _dev(cref, Sp)
+    d_zl = torch.zeros((nl, n, 4), dtype=torch.int64, device="cuda")
+    for j in range(nl):
+        eng.lookup_product_dev(d_A[j].data_ptr(), d_S.data_ptr(), d_Ap[j].data_ptr(), d_Sp[j].data_ptr(), n, _m(cref, beta),
+                               _m(cref, gamma), _m(cref, 1), d_zl[j].data_ptr())
+        eng.sync()
+        z = _ints(cref, d_zl[j])
+        assert z[u] == 1, j
+        z[u + 1:] = [rng.randrange(R) for _ in range(n - u - 1)]
+        zl.append(z)
+    d_zl = _dev(cref, zl)
+    l0 = [1] + [0] * (n - 1)
+    l_last = [1 if i == u else 0 for i in range(n)]
+    l_active = [1 if i < u else 0 for i in range(n)]
+    d_l = _dev(cref, [l0, l_last, l_active])
+
+    gens = np.stack([_m(cref, cg * pow(w_ext, rr, R)) for rr in range(E)])
+
+    def extend(d, ncols):
+        """Lagrange values -> extended coset values, on the device (in place iNTT, then coeff_to_extended)"""
+        eng.ntt_dev(d.data_ptr(), ncols, 4 * n, _m(cref, pow(w_n, -1, R)), k, None, _m(cref, pow(n, -1, R)))
+        e = torch.zeros((ncols, N, 4), dtype=torch.int64, device="cuda")
+        eng.ntt_extend_dev(d.data_ptr(), ncols, 4 * n, e.data_ptr(), 4 * N, k, log_e, _m(cref, w_n), gens, None)
+        return e
+
+    e_val, e_sig, e_z = extend(d_val, m), extend(d_sig, m), extend(d_z, nsets)
+    e_A, e_S, e_Ap, e_Sp, e_zl, e_l = extend(d_A, nl), extend(d_S.reshape(1, n, 4), 1), extend(d_Ap, nl), extend(d_Sp, nl), extend(d_zl, nl), extend(d_l, 3)
+    d_h = torch.zeros((N, 4), dtype=torch.int64, device="cuda")
+    eng.quotient_permutation_dev(e_val.data_ptr(), 4 * N, e_sig.data_ptr(), 4 * N, e_z.data_ptr(), 4 * N, nsets, chunk, m,
+                                 k + log_e, E, bf + 1, e_l[0].data_ptr(), e_l[1].data_ptr(), e_l[2].data_ptr(), _m(cref, beta),
+                                 _m(cref, gamma), _m(cref, delta), _m(cref, cg), _m(cref, w_ext), _m(cref, y), d_h.data_ptr())
+    eng.sync()
+    I = lambda t: [_ints(cref, t[j]) for j in range(t.shape[0])]
+    lv = I(e_l)
+    want = P.quotient_permutation(I(e_val), I(e_sig), I(e_z), chunk, E, bf + 1, lv[0], lv[1], lv[2], beta, gamma, delta, cg,
+                                  w_ext, y, [0] * N)
+    assert _ints(cref, d_h) == want
+    eng.quotient_lookup_dev(e_A.data_ptr(), 4 * N, e_S.data_ptr(), e_Ap.data_ptr(), 4 * N, e_Sp.data_ptr(), 4 * N,
+                            e_zl.data_ptr(), 4 * N, nl, k + log_e, E, e_l[0].data_ptr(), e_l[1].data_ptr(), e_l[2].data_ptr(),
+                            _m(cref, beta), _m(cref, gamma), _m(cref, y), d_h.data_ptr())
+    eng.sync()
+    want = P.quotient_lookup(I(e_A), I(e_S)[0], I(e_Ap), I(e_Sp), I(e_zl), E, lv[0], lv[1], lv[2], beta, gamma, y, want)
+    assert _ints(cref, d_h) == want
+    # divide by X^n - 1 and return to coefficients: the quotient is a polynomial of degree <= 3n - 4
+    eng.quotient_finish_dev(d_h.data_ptr(), k, log_e, _m(cref, cg), _m(cref, w_ext))
+    eng.ntt_dev(d_h.data_ptr(), 1, 4 * N, _m(cref, pow(w_ext, -1, R)), k + log_e, None, _m(cref, pow(N, -1, R)))
+    eng.fr_distribute_powers_dev(d_h.data_ptr(), 1, 4 * N, N, _m(cref, pow(cg, -1, R)))
+    eng.sync()
+    hc = _ints(cref, d_h)
+    assert any(hc[: 3 * n - 3]) and not any(hc[3 * n - 3:])
+    # negative control: break one copy constraint and the numerator stops vanishing on the domain
+    val[0][3] = (val[0][3] + 1) % R
+    e_bad = extend(_dev(cref, val), m)
+    d_h2 = torch.zeros((N, 4), dtype=torch.int64, device="cuda")
+    eng.quotient_permutation_dev(e_bad.data_ptr(), 4 * N, e_sig.data_ptr(), 4 * N, e_z.data_ptr(), 4 * N, nsets, chunk, m,
+                                 k + log_e, E, bf + 1, e_l[0].data_ptr(), e_l[1].data_ptr(), e_l[2].data_ptr(), _m(cref, beta),
+                                 _m(cref, gamma), _m(cref, delta), _m(cref, cg), _m(cref, w_ext), _m(cref, y), d_h2.data_ptr())
+    eng.quotient_finish_dev(d_h2.data_ptr(), k, log_e, _m(cref, cg), _m(cref, w_ext))
+    eng.ntt_dev(d_h2.data_ptr(), 1, 4 * N, _m(cref, pow(w_ext, -1, R)), k + log_e, None, _m(cref, pow(N, -1, R)))
+    eng.fr_distribute_powers_dev(d_h2.data_ptr(), 1, 4 * N, N, _m(cref, pow(cg, -1, R)))
+    eng.sync()
+    assert any(_ints(cref, d_h2)[3 * n - 3:])
