@@ -211,6 +211,13 @@ int pz_permutation_product_dev(pz_ctx* ctx, const uint64_t* d_cols, size_t col_s
                                size_t sigma_stride, size_t m, uint32_t log_n, const uint64_t omega[4],
                                const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta_start[4],
                                const uint64_t delta[4], const uint64_t z0[4], uint64_t* d_z);
+/* all sets of the permutation argument in one call: m columns in chunks of chunk_len (set j = columns
+ * [j*chunk_len, ...), delta powers continuing across sets); d_z[0][0] = 1 and d_z[j][0] = d_z[j-1][usable_rows], as
+ * halo2 chains them.  The sets are computed independently (one batched inversion, one batched scan), then chained. */
+int pz_permutation_product_sets_dev(pz_ctx* ctx, const uint64_t* d_cols, size_t col_stride, const uint64_t* d_sigma,
+                                    size_t sigma_stride, size_t m, uint32_t chunk_len, uint32_t log_n, size_t usable_rows,
+                                    const uint64_t omega[4], const uint64_t beta[4], const uint64_t gamma[4],
+                                    const uint64_t delta[4], uint64_t* d_z, size_t z_stride);
 /* lookup::prover permute_expression_pair for halo2-lib's range-check lookups: every input column (values in
  * [0, 2^value_bits), value_bits <= 24) against the shared table column, over the first `rows` (usable) rows:
  *   d_perm_inputs[col] = the input column sorted ascending;
@@ -221,10 +228,13 @@ int pz_permutation_product_dev(pz_ctx* ctx, const uint64_t* d_cols, size_t col_s
 int pz_lookup_permute_dev(pz_ctx* ctx, const uint64_t* d_inputs, size_t n_cols, size_t col_stride,
                           const uint64_t* d_table, size_t rows, uint32_t value_bits, uint64_t* d_perm_inputs,
                           uint64_t* d_perm_tables, size_t out_stride);
-/* lookup grand product: d_z[0] = z0, d_z[i+1] = d_z[i] * (A[i]+beta)(S[i]+gamma) / ((A'[i]+beta)(S'[i]+gamma)). */
-int pz_lookup_product_dev(pz_ctx* ctx, const uint64_t* d_input, const uint64_t* d_table, const uint64_t* d_perm_input,
-                          const uint64_t* d_perm_table, size_t n, const uint64_t beta[4], const uint64_t gamma[4],
-                          const uint64_t z0[4], uint64_t* d_z);
+/* lookup grand products, n_lookups of them against one table column (z0 the same for all, normally 1):
+ *   d_z[k][0] = z0, d_z[k][i+1] = d_z[k][i] * (A_k[i]+beta)(S[i]+gamma) / ((A'_k[i]+beta)(S'_k[i]+gamma)).
+ * One batched inversion and one batched scan for all of them. */
+int pz_lookup_product_dev(pz_ctx* ctx, const uint64_t* d_inputs, size_t input_stride, const uint64_t* d_table,
+                          const uint64_t* d_perm_inputs, size_t perm_input_stride, const uint64_t* d_perm_tables,
+                          size_t perm_table_stride, size_t n_lookups, size_t n, const uint64_t beta[4],
+                          const uint64_t gamma[4], const uint64_t z0[4], uint64_t* d_z, size_t z_stride);
 /* evaluate_h, custom-gate part, for halo2-lib's vertical gate on the extended domain of 2^log_ext points:
  *   for each column j in order:  d_h[i] = d_h[i]*y + sel_j[i] * (a_j[i] + a_j[i+s]*a_j[i+2s] - a_j[i+3s]),
  * indices mod 2^log_ext, s = rot_step = 2^(log_ext - k) (one row of the 2^k domain).  d_h is read and written. */

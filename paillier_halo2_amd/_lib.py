@@ -58,7 +58,10 @@ SIGNATURES = {
     "pz_permutation_product_dev": (C.c_int, [VP, VP, C.c_size_t, VP, C.c_size_t, C.c_size_t, C.c_uint32, VP, VP, VP, VP,
                                              VP, VP, VP]),
     "pz_lookup_permute_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, VP, C.c_size_t, C.c_uint32, VP, VP, C.c_size_t]),
-    "pz_lookup_product_dev": (C.c_int, [VP, VP, VP, VP, VP, C.c_size_t, VP, VP, VP, VP]),
+    "pz_lookup_product_dev": (C.c_int, [VP, VP, C.c_size_t, VP, VP, C.c_size_t, VP, C.c_size_t, C.c_size_t, C.c_size_t, VP, VP,
+                                        VP, VP, C.c_size_t]),
+    "pz_permutation_product_sets_dev": (C.c_int, [VP, VP, C.c_size_t, VP, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32,
+                                                  C.c_size_t, VP, VP, VP, VP, VP, C.c_size_t]),
     "pz_quotient_gate_dev": (C.c_int, [VP, VP, C.c_size_t, VP, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, VP, VP]),
     "pz_quotient_permutation_dev": (C.c_int, [VP, VP, C.c_size_t, VP, C.c_size_t, VP, C.c_size_t, C.c_uint32, C.c_uint32,
                                               C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, VP, VP, VP, VP, VP, VP, VP, VP,

@@ -18,7 +18,8 @@
 #include "pz_internal.h"
 
 int pz_batch_invert_internal(pz_ctx* ctx, Fr* d_a, size_t n);
-int pz_prefix_product_internal(pz_ctx* ctx, const Fr* d_a, size_t n, Fr z0, Fr* d_z);
+int pz_prefix_product_batch_internal(pz_ctx* ctx, const Fr* d_a, size_t a_stride, size_t n_cols, size_t n, Fr z0, Fr* d_z,
+                                     size_t z_stride);
 
 // canonical value of x if it is an integer below M, else 0xffffffff
 __device__ __forceinline__ u32 small_value(const Fr& mont, u32 M) {
@@ -163,39 +164,45 @@ extern "C" int pz_lookup_permute_dev(pz_ctx* ctx, const uint64_t* d_inputs, size
 }
 
 // ------------------------------------------------------------------------------------------------ lookup product
-__global__ __launch_bounds__(256) void k_lk_terms(const Fr* __restrict__ A, const Fr* __restrict__ S,
-                                                  const Fr* __restrict__ Ap, const Fr* __restrict__ Sp, size_t n, Fr beta,
-                                                  Fr gamma, Fr* __restrict__ num, Fr* __restrict__ den) {
+__global__ __launch_bounds__(256) void k_lk_terms(const Fr* __restrict__ A, size_t as, const Fr* __restrict__ S,
+                                                  const Fr* __restrict__ Ap, size_t aps, const Fr* __restrict__ Sp, size_t sps,
+                                                  size_t n, Fr beta, Fr gamma, Fr* __restrict__ num, Fr* __restrict__ den) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    fp_store(num + i, fp_mul(fp_add(fp_load<FrTag>(A + i), beta), fp_add(fp_load<FrTag>(S + i), gamma)));
-    fp_store(den + i, fp_mul(fp_add(fp_load<FrTag>(Ap + i), beta), fp_add(fp_load<FrTag>(Sp + i), gamma)));
+    const size_t k = blockIdx.y;
+    fp_store(num + k * n + i, fp_mul(fp_add(fp_load<FrTag>(A + k * as + i), beta), fp_add(fp_load<FrTag>(S + i), gamma)));
+    fp_store(den + k * n + i, fp_mul(fp_add(fp_load<FrTag>(Ap + k * aps + i), beta), fp_add(fp_load<FrTag>(Sp + k * sps + i), gamma)));
 }
 __global__ __launch_bounds__(256) void k_lk_mul(Fr* __restrict__ a, const Fr* __restrict__ b, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) fp_store(a + i, fp_mul(fp_load<FrTag>(a + i), fp_load<FrTag>(b + i)));
 }
 
-extern "C" int pz_lookup_product_dev(pz_ctx* ctx, const uint64_t* d_input, const uint64_t* d_table,
-                                     const uint64_t* d_perm_input, const uint64_t* d_perm_table, size_t n,
-                                     const uint64_t beta[4], const uint64_t gamma[4], const uint64_t z0[4], uint64_t* d_z) {
-    if (!ctx || !beta || !gamma || !z0 || (n && (!d_input || !d_table || !d_perm_input || !d_perm_table || !d_z)))
+extern "C" int pz_lookup_product_dev(pz_ctx* ctx, const uint64_t* d_inputs, size_t input_stride, const uint64_t* d_table,
+                                     const uint64_t* d_perm_inputs, size_t perm_input_stride, const uint64_t* d_perm_tables,
+                                     size_t perm_table_stride, size_t n_lookups, size_t n, const uint64_t beta[4],
+                                     const uint64_t gamma[4], const uint64_t z0[4], uint64_t* d_z, size_t z_stride) {
+    if (!ctx || !beta || !gamma || !z0 || (n && n_lookups && (!d_inputs || !d_table || !d_perm_inputs || !d_perm_tables || !d_z)))
         return PZ_ERR_INVALID;
-    if (!n) return PZ_OK;
+    if (input_stride % 4 || perm_input_stride % 4 || perm_table_stride % 4 || z_stride % 4 || n_lookups > 65535) return PZ_ERR_INVALID;
+    if (n_lookups > 1 && (input_stride < 4 * n || perm_input_stride < 4 * n || perm_table_stride < 4 * n || z_stride < 4 * n))
+        return PZ_ERR_INVALID;
+    if (!n || !n_lookups) return PZ_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     void* ws;
-    PZCHK(pz_ws_get(ctx, WS_BIG_C, 2 * n * 32, &ws));
+    PZCHK(pz_ws_get(ctx, WS_BIG_C, 2 * n_lookups * n * 32, &ws));
     Fr* num = (Fr*)ws;
-    Fr* den = num + n;
+    Fr* den = num + n_lookups * n;
     Fr b, g, z;
     memcpy(b.v, beta, 32);
     memcpy(g.v, gamma, 32);
     memcpy(z.v, z0, 32);
-    hipLaunchKernelGGL(k_lk_terms, dim3(pz_div_up(n, 256)), dim3(256), 0, ctx->stream, (const Fr*)d_input,
-                       (const Fr*)d_table, (const Fr*)d_perm_input, (const Fr*)d_perm_table, n, b, g, num, den);
+    hipLaunchKernelGGL(k_lk_terms, dim3(pz_div_up(n, 256), (unsigned)n_lookups), dim3(256), 0, ctx->stream, (const Fr*)d_inputs,
+                       input_stride / 4, (const Fr*)d_table, (const Fr*)d_perm_inputs, perm_input_stride / 4,
+                       (const Fr*)d_perm_tables, perm_table_stride / 4, n, b, g, num, den);
     HIPCHK(ctx, hipGetLastError());
-    PZCHK(pz_batch_invert_internal(ctx, den, n));
-    hipLaunchKernelGGL(k_lk_mul, dim3(pz_div_up(n, 256)), dim3(256), 0, ctx->stream, num, (const Fr*)den, n);
+    PZCHK(pz_batch_invert_internal(ctx, den, n_lookups * n));
+    hipLaunchKernelGGL(k_lk_mul, dim3(pz_div_up(n_lookups * n, 256)), dim3(256), 0, ctx->stream, num, (const Fr*)den, n_lookups * n);
     HIPCHK(ctx, hipGetLastError());
-    return pz_prefix_product_internal(ctx, num, n, z, (Fr*)d_z);
+    return pz_prefix_product_batch_internal(ctx, num, n, n_lookups, n, z, (Fr*)d_z, z_stride / 4);
 }

@@ -20,6 +20,12 @@
 #include "fp.cuh"
 #include "pz_internal.h"
 
+static inline Fr fp_one_host() {  // Montgomery one of Fr (R mod r)
+    static const uint64_t ONE[4] = {0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL};
+    Fr r;
+    memcpy(r.v, ONE, 32);
+    return r;
+}
 static inline Fr fr_from_u64(const uint64_t x[4]) {
     Fr r;
     memcpy(r.v, x, 32);
@@ -73,10 +79,12 @@ extern "C" int pz_fr_batch_invert_dev(pz_ctx* ctx, uint64_t* d_a, size_t n) {
 
 // ---------------------------------------------------------------------------------------------- prefix product
 #define PP_K 16u
-// phase 1: per-thread run products, block-level exclusive scan; excl[t] = product of the block's earlier runs
-__global__ __launch_bounds__(256) void k_pp_local(const Fr* __restrict__ a, size_t n, Fr* __restrict__ excl,
-                                                  Fr* __restrict__ block_tot) {
+// (batched over grid.y = column.)  phase 1: per-thread run products, block-level exclusive scan;
+// excl[t] = product of the block's earlier runs
+__global__ __launch_bounds__(256) void k_pp_local(const Fr* __restrict__ a, size_t as, size_t n, Fr* __restrict__ excl,
+                                                  Fr* __restrict__ block_tot, unsigned nb) {
     __shared__ Fr s[256];
+    a += (size_t)blockIdx.y * as;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t lo = t * PP_K;
     Fr p = fp_one<FrTag>();
@@ -91,26 +99,31 @@ __global__ __launch_bounds__(256) void k_pp_local(const Fr* __restrict__ a, size
         if (threadIdx.x >= off) s[threadIdx.x] = fp_mul(u, v);
         __syncthreads();
     }
-    fp_store(excl + t, threadIdx.x ? s[threadIdx.x - 1] : fp_one<FrTag>());
-    if (threadIdx.x == 255) fp_store(block_tot + blockIdx.x, s[255]);
+    fp_store(excl + (size_t)blockIdx.y * nb * 256 + t, threadIdx.x ? s[threadIdx.x - 1] : fp_one<FrTag>());
+    if (threadIdx.x == 255) fp_store(block_tot + (size_t)blockIdx.y * nb + blockIdx.x, s[255]);
 }
-// phase 2: exclusive scan of the block totals, seeded with z0 (a few hundred entries: one lane)
-__global__ void k_pp_blocks(Fr* __restrict__ block_tot, unsigned nb, Fr z0) {
-    if (blockIdx.x || threadIdx.x) return;
+// phase 2: exclusive scan of each column's block totals, seeded with z0 (a few dozen entries: one lane per column)
+__global__ void k_pp_blocks(Fr* __restrict__ block_tot, unsigned nb, size_t n_cols, Fr z0) {
+    const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= n_cols) return;
+    Fr* bt = block_tot + col * nb;
     Fr run = z0;
     for (unsigned b = 0; b < nb; ++b) {
-        Fr t = fp_load<FrTag>(block_tot + b);
-        fp_store(block_tot + b, run);
+        Fr t = fp_load<FrTag>(bt + b);
+        fp_store(bt + b, run);
         run = fp_mul(run, t);
     }
 }
 // phase 3: z[i] = block prefix * thread prefix * run prefix
-__global__ __launch_bounds__(256) void k_pp_apply(const Fr* __restrict__ a, size_t n, const Fr* __restrict__ excl,
-                                                  const Fr* __restrict__ block_tot, Fr* __restrict__ z) {
+__global__ __launch_bounds__(256) void k_pp_apply(const Fr* __restrict__ a, size_t as, size_t n, const Fr* __restrict__ excl,
+                                                  const Fr* __restrict__ block_tot, unsigned nb, Fr* __restrict__ z, size_t zs) {
+    a += (size_t)blockIdx.y * as;
+    z += (size_t)blockIdx.y * zs;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t lo = t * PP_K;
     if (lo >= n) return;
-    Fr cur = fp_mul(fp_load<FrTag>(block_tot + blockIdx.x), fp_load<FrTag>(excl + t));
+    Fr cur = fp_mul(fp_load<FrTag>(block_tot + (size_t)blockIdx.y * nb + blockIdx.x),
+                    fp_load<FrTag>(excl + (size_t)blockIdx.y * nb * 256 + t));
     for (unsigned j = 0; j < PP_K && lo + j < n; ++j) {
         Fr v = fp_load<FrTag>(a + lo + j);  // read before the store: z may alias a
         fp_store(z + lo + j, cur);
@@ -118,18 +131,24 @@ __global__ __launch_bounds__(256) void k_pp_apply(const Fr* __restrict__ a, size
     }
 }
 
-int pz_prefix_product_internal(pz_ctx* ctx, const Fr* d_a, size_t n, Fr z0, Fr* d_z) {
-    if (!n) return PZ_OK;
+int pz_prefix_product_batch_internal(pz_ctx* ctx, const Fr* d_a, size_t a_stride, size_t n_cols, size_t n, Fr z0, Fr* d_z,
+                                     size_t z_stride) {
+    if (!n || !n_cols) return PZ_OK;
+    if (n_cols > 65535) return PZ_ERR_INVALID;
     const unsigned nb = pz_div_up(pz_div_up(n, PP_K), 256);
     void* ws;
-    PZCHK(pz_ws_get(ctx, WS_BIG_B, ((size_t)nb * 256 + nb) * 32, &ws));
+    PZCHK(pz_ws_get(ctx, WS_BIG_B, n_cols * ((size_t)nb * 256 + nb) * 32, &ws));
     Fr* excl = (Fr*)ws;
-    Fr* tot = excl + (size_t)nb * 256;
-    hipLaunchKernelGGL(k_pp_local, dim3(nb), dim3(256), 0, ctx->stream, d_a, n, excl, tot);
-    hipLaunchKernelGGL(k_pp_blocks, dim3(1), dim3(64), 0, ctx->stream, tot, nb, z0);
-    hipLaunchKernelGGL(k_pp_apply, dim3(nb), dim3(256), 0, ctx->stream, d_a, n, (const Fr*)excl, (const Fr*)tot, d_z);
+    Fr* tot = excl + n_cols * (size_t)nb * 256;
+    hipLaunchKernelGGL(k_pp_local, dim3(nb, (unsigned)n_cols), dim3(256), 0, ctx->stream, d_a, a_stride, n, excl, tot, nb);
+    hipLaunchKernelGGL(k_pp_blocks, dim3(pz_div_up(n_cols, 64)), dim3(64), 0, ctx->stream, tot, nb, n_cols, z0);
+    hipLaunchKernelGGL(k_pp_apply, dim3(nb, (unsigned)n_cols), dim3(256), 0, ctx->stream, d_a, a_stride, n, (const Fr*)excl,
+                       (const Fr*)tot, nb, d_z, z_stride);
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
+}
+int pz_prefix_product_internal(pz_ctx* ctx, const Fr* d_a, size_t n, Fr z0, Fr* d_z) {
+    return pz_prefix_product_batch_internal(ctx, d_a, n, 1, n, z0, d_z, n);
 }
 
 extern "C" int pz_fr_prefix_product_dev(pz_ctx* ctx, const uint64_t* d_a, size_t n, const uint64_t z0[4], uint64_t* d_z) {
@@ -184,6 +203,80 @@ extern "C" int pz_permutation_product_dev(pz_ctx* ctx, const uint64_t* d_cols, s
     hipLaunchKernelGGL(k_fr_mul_inplace, dim3(pz_div_up(n, 256)), dim3(256), 0, ctx->stream, num, (const Fr*)den, n);
     HIPCHK(ctx, hipGetLastError());
     return pz_prefix_product_internal(ctx, num, n, fr_from_u64(z0), (Fr*)d_z);
+}
+
+// all sets of the permutation argument at once: set j covers columns [j*chunk_len, ...), its product starts where the
+// previous set's stood at row `usable_rows` (halo2: z_j[0] = z_{j-1}[u]).  The sets are computed independently from 1
+// (one batched inversion, one batched scan) and chained afterwards by a scalar per set.
+__global__ __launch_bounds__(256) void k_perm_terms_sets(const Fr* __restrict__ cols, size_t cs, const Fr* __restrict__ sigma,
+                                                         size_t ss, unsigned m, unsigned chunk_len, size_t n,
+                                                         const Fr* __restrict__ wpow, const Fr* __restrict__ dpow, Fr beta,
+                                                         Fr gamma, Fr delta, Fr* __restrict__ num, Fr* __restrict__ den) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned set = blockIdx.y, c0 = set * chunk_len;
+    Fr nm = fp_one<FrTag>(), dn = fp_one<FrTag>();
+    Fr bd = fp_mul(fp_mul(beta, fp_load<FrTag>(dpow + c0)), fp_load<FrTag>(wpow + i));
+    for (unsigned c = c0; c < c0 + chunk_len && c < m; ++c) {
+        Fr v = fp_add(fp_load<FrTag>(cols + (size_t)c * cs + i), gamma);
+        nm = fp_mul(nm, fp_add(v, bd));
+        dn = fp_mul(dn, fp_add(v, fp_mul(beta, fp_load<FrTag>(sigma + (size_t)c * ss + i))));
+        bd = fp_mul(bd, delta);
+    }
+    fp_store(num + (size_t)set * n + i, nm);
+    fp_store(den + (size_t)set * n + i, dn);
+}
+__global__ void k_perm_chain(const Fr* __restrict__ z, size_t zs, unsigned n_sets, size_t u, Fr* __restrict__ mult) {
+    if (blockIdx.x || threadIdx.x) return;
+    Fr c = fp_one<FrTag>();
+    for (unsigned j = 0; j < n_sets; ++j) {
+        fp_store(mult + j, c);
+        c = fp_mul(c, fp_load<FrTag>(z + (size_t)j * zs + u));
+    }
+}
+__global__ __launch_bounds__(256) void k_scale_sets(Fr* __restrict__ z, size_t zs, size_t n, const Fr* __restrict__ mult) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || blockIdx.y == 0) return;
+    Fr* p = z + (size_t)blockIdx.y * zs + i;
+    fp_store(p, fp_mul(fp_load<FrTag>(p), fp_load<FrTag>(mult + blockIdx.y)));
+}
+
+extern "C" int pz_permutation_product_sets_dev(pz_ctx* ctx, const uint64_t* d_cols, size_t col_stride, const uint64_t* d_sigma,
+                                               size_t sigma_stride, size_t m, uint32_t chunk_len, uint32_t log_n,
+                                               size_t usable_rows, const uint64_t omega[4], const uint64_t beta[4],
+                                               const uint64_t gamma[4], const uint64_t delta[4], uint64_t* d_z,
+                                               size_t z_stride) {
+    if (!ctx || !d_cols || !d_sigma || !d_z || !omega || !beta || !gamma || !delta || m == 0 || chunk_len == 0 || log_n > 26)
+        return PZ_ERR_INVALID;
+    const size_t n = (size_t)1 << log_n;
+    const size_t n_sets = (m + chunk_len - 1) / chunk_len;
+    if (col_stride % 4 || sigma_stride % 4 || z_stride % 4 || usable_rows >= n || n_sets > 65535 || m > 0xffffffu) return PZ_ERR_INVALID;
+    if ((m > 1 && (col_stride < 4 * n || sigma_stride < 4 * n)) || (n_sets > 1 && z_stride < 4 * n)) return PZ_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    void *wp, *dp, *ws, *mu;
+    PZCHK(pz_get_pow_table(ctx, omega, n, &wp));
+    PZCHK(pz_get_pow_table(ctx, delta, m, &dp));
+    PZCHK(pz_ws_get(ctx, WS_BIG_C, 2 * n_sets * n * 32, &ws));
+    PZCHK(pz_ws_get(ctx, WS_MISC, n_sets * 32, &mu));
+    Fr* num = (Fr*)ws;
+    Fr* den = num + n_sets * n;
+    hipLaunchKernelGGL(k_perm_terms_sets, dim3(pz_div_up(n, 256), (unsigned)n_sets), dim3(256), 0, ctx->stream,
+                       (const Fr*)d_cols, col_stride / 4, (const Fr*)d_sigma, sigma_stride / 4, (unsigned)m, (unsigned)chunk_len, n,
+                       (const Fr*)wp, (const Fr*)dp, fr_from_u64(beta), fr_from_u64(gamma), fr_from_u64(delta), num, den);
+    HIPCHK(ctx, hipGetLastError());
+    PZCHK(pz_batch_invert_internal(ctx, den, n_sets * n));
+    hipLaunchKernelGGL(k_fr_mul_inplace, dim3(pz_div_up(n_sets * n, 256)), dim3(256), 0, ctx->stream, num, (const Fr*)den,
+                       n_sets * n);
+    HIPCHK(ctx, hipGetLastError());
+    PZCHK(pz_prefix_product_batch_internal(ctx, num, n, n_sets, n, fp_one_host(), (Fr*)d_z, z_stride / 4));
+    if (n_sets > 1) {
+        hipLaunchKernelGGL(k_perm_chain, dim3(1), dim3(64), 0, ctx->stream, (const Fr*)d_z, z_stride / 4, (unsigned)n_sets,
+                           usable_rows, (Fr*)mu);
+        hipLaunchKernelGGL(k_scale_sets, dim3(pz_div_up(n, 256), (unsigned)n_sets), dim3(256), 0, ctx->stream, (Fr*)d_z,
+                           z_stride / 4, n, (const Fr*)mu);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    return PZ_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- gate part of evaluate_h
@@ -289,14 +382,38 @@ __global__ __launch_bounds__(256) void k_kd_local(const Fr* __restrict__ a, size
     for (size_t i = hi; i-- > lo;) v = fp_add(fp_mul(v, x), fp_load<FrTag>(p + i));
     fp_store(L + (size_t)blockIdx.y * n_chunks + c, v);
 }
-__global__ void k_kd_carry(Fr* __restrict__ L, size_t n_chunks, size_t n_cols, Fr x) {
-    const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= n_cols) return;
+// one workgroup per column: thread t owns `per` consecutive chunks; its segment maps the carry entering at its top to
+// the carry leaving at its bottom as out = V + X * in (V = the segment's own value, X = x^(K * chunks)); a suffix scan of
+// these affine maps over the 256 threads gives every segment its carry-in, then the chunks are walked once more.
+__global__ __launch_bounds__(256) void k_kd_carry(Fr* __restrict__ L, size_t n_chunks, Fr x) {
+    __shared__ Fr s_v[256], s_x[256];
+    Fr* l = L + (size_t)blockIdx.x * n_chunks;
     Fr xk = x;
     for (unsigned s = 1; s < KD_K; s <<= 1) xk = fp_sqr(xk);  // x^64
-    Fr* l = L + col * n_chunks;
-    Fr carry = fp_zero<FrTag>();
-    for (size_t c = n_chunks; c-- > 0;) {
+    const size_t per = (n_chunks + 255) / 256;
+    const size_t lo = threadIdx.x * per, hi = lo + per < n_chunks ? lo + per : n_chunks;
+    Fr V = fp_zero<FrTag>(), X = fp_one<FrTag>();
+    for (size_t c = hi; c-- > lo && c < n_chunks;) {
+        V = fp_add(fp_load<FrTag>(l + c), fp_mul(xk, V));
+        X = fp_mul(X, xk);
+    }
+    s_v[threadIdx.x] = V;
+    s_x[threadIdx.x] = X;
+    __syncthreads();
+    for (unsigned off = 1; off < 256; off <<= 1) {  // suffix scan: compose with the segments above
+        Fr v = s_v[threadIdx.x], xx = s_x[threadIdx.x];
+        Fr uv = fp_zero<FrTag>(), ux = fp_one<FrTag>();
+        const bool has = threadIdx.x + off < 256;
+        if (has) { uv = s_v[threadIdx.x + off]; ux = s_x[threadIdx.x + off]; }
+        __syncthreads();
+        if (has) {
+            s_v[threadIdx.x] = fp_add(v, fp_mul(xx, uv));
+            s_x[threadIdx.x] = fp_mul(xx, ux);
+        }
+        __syncthreads();
+    }
+    Fr carry = threadIdx.x + 1 < 256 ? s_v[threadIdx.x + 1] : fp_zero<FrTag>();
+    for (size_t c = hi; c-- > lo && c < n_chunks;) {
         Fr t = fp_load<FrTag>(l + c);
         fp_store(l + c, carry);  // carry_in(c)
         carry = fp_add(t, fp_mul(xk, carry));
@@ -330,7 +447,7 @@ extern "C" int pz_poly_div_linear_dev(pz_ctx* ctx, const uint64_t* d_coeffs, siz
     Fr xv = fr_from_u64(x);
     hipLaunchKernelGGL(k_kd_local, dim3(pz_div_up(nch, 256), (unsigned)n_cols), dim3(256), 0, ctx->stream,
                        (const Fr*)d_coeffs, col_stride / 4, n, xv, (Fr*)L, nch);
-    hipLaunchKernelGGL(k_kd_carry, dim3(pz_div_up(n_cols, 64)), dim3(64), 0, ctx->stream, (Fr*)L, nch, n_cols, xv);
+    hipLaunchKernelGGL(k_kd_carry, dim3((unsigned)n_cols), dim3(256), 0, ctx->stream, (Fr*)L, nch, xv);
     hipLaunchKernelGGL(k_kd_apply, dim3(pz_div_up(nch, 256), (unsigned)n_cols), dim3(256), 0, ctx->stream,
                        (const Fr*)d_coeffs, col_stride / 4, n, xv, (const Fr*)L, nch, (Fr*)d_q, q_stride / 4);
     HIPCHK(ctx, hipGetLastError());

@@ -317,11 +317,21 @@ class Engine:
         self._chk(self.L.pz_lookup_permute_dev(self.ctx, VP(d_inputs), n_cols, col_stride_u64, VP(d_table), rows, value_bits,
                                                VP(d_perm_inputs), VP(d_perm_tables), out_stride_u64), "pz_lookup_permute_dev")
 
-    def lookup_product_dev(self, d_input: int, d_table: int, d_perm_input: int, d_perm_table: int, n: int, beta, gamma, z0,
-                           d_z: int):
-        self._chk(self.L.pz_lookup_product_dev(self.ctx, VP(d_input), VP(d_table), VP(d_perm_input), VP(d_perm_table), n,
-                                               self._fr1(beta), self._fr1(gamma), self._fr1(z0), VP(d_z)),
+    def lookup_product_dev(self, d_inputs: int, input_stride_u64: int, d_table: int, d_perm_inputs: int,
+                           perm_input_stride_u64: int, d_perm_tables: int, perm_table_stride_u64: int, n_lookups: int, n: int,
+                           beta, gamma, z0, d_z: int, z_stride_u64: int):
+        self._chk(self.L.pz_lookup_product_dev(self.ctx, VP(d_inputs), input_stride_u64, VP(d_table), VP(d_perm_inputs),
+                                               perm_input_stride_u64, VP(d_perm_tables), perm_table_stride_u64, n_lookups, n,
+                                               self._fr1(beta), self._fr1(gamma), self._fr1(z0), VP(d_z), z_stride_u64),
                   "pz_lookup_product_dev")
+
+    def permutation_product_sets_dev(self, d_cols: int, col_stride_u64: int, d_sigma: int, sigma_stride_u64: int, m: int,
+                                     chunk_len: int, log_n: int, usable_rows: int, omega, beta, gamma, delta, d_z: int,
+                                     z_stride_u64: int):
+        self._chk(self.L.pz_permutation_product_sets_dev(self.ctx, VP(d_cols), col_stride_u64, VP(d_sigma), sigma_stride_u64, m,
+                                                         chunk_len, log_n, usable_rows, self._fr1(omega), self._fr1(beta),
+                                                         self._fr1(gamma), self._fr1(delta), VP(d_z), z_stride_u64),
+                  "pz_permutation_product_sets_dev")
 
     def quotient_gate_dev(self, d_adv_ext: int, adv_stride_u64: int, d_sel_ext: int, sel_stride_u64: int, n_cols: int,
                           log_ext: int, rot_step: int, y, d_h: int):

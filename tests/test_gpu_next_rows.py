@@ -339,6 +339,10 @@ def test_lookup_permute_and_product_vs_oracle(eng, cref, rows, bits, ncols):
     eng.lookup_permute_dev(d_in.data_ptr(), ncols, stride, d_tab.data_ptr(), rows, bits, d_pi.data_ptr(), d_pt.data_ptr(), stride)
     eng.sync()
     beta, gamma, z0 = (rng.randrange(1, P.FR_R) for _ in range(3))
+    d_z = torch.zeros((ncols, stride), dtype=torch.int64, device="cuda")
+    eng.lookup_product_dev(d_in.data_ptr(), stride, d_tab.data_ptr(), d_pi.data_ptr(), stride, d_pt.data_ptr(), stride, ncols, rows,
+                           _m(cref, beta), _m(cref, gamma), _m(cref, z0), d_z.data_ptr(), stride)
+    eng.sync()
     for j in range(ncols):
         Ap, Sp = P.permute_expression_pair(cols[j], table)
         got_a, got_s = _ints(cref, d_pi[j, : 4 * rows]), _ints(cref, d_pt[j, : 4 * rows])
@@ -346,11 +350,7 @@ def test_lookup_permute_and_product_vs_oracle(eng, cref, rows, bits, ncols):
         assert got_s == Sp, j
         assert sorted(got_s) == sorted(table)          # S' is a permutation of the table ...
         assert all(got_a[i] == got_s[i] or got_a[i] == got_a[i - 1] for i in range(rows))   # ... and halo2's row rule holds
-        d_z = torch.zeros((rows, 4), dtype=torch.int64, device="cuda")
-        eng.lookup_product_dev(d_in[j].data_ptr(), d_tab.data_ptr(), d_pi[j].data_ptr(), d_pt[j].data_ptr(), rows,
-                               _m(cref, beta), _m(cref, gamma), _m(cref, z0), d_z.data_ptr())
-        eng.sync()
-        z = _ints(cref, d_z)
+        z = _ints(cref, d_z[j, : 4 * rows])
         if rows <= 5000:
             assert z == P.lookup_product(cols[j], table, Ap, Sp, beta, gamma, z0), j
         # telescoping: both sides are permutations of each other, so one more factor returns to z0
@@ -413,16 +413,16 @@ def test_lookup_argument_on_real_witness_digits(eng, cref):
     rng = random.Random(490)
     beta, gamma = rng.randrange(1, P.FR_R), rng.randrange(1, P.FR_R)
     cells = _ints(cref, d_lk[: ncols * rows])
+    d_z = torch.zeros((ncols, rows, 4), dtype=torch.int64, device="cuda")
+    eng.lookup_product_dev(d_lk.data_ptr(), 4 * rows, d_tab.data_ptr(), d_pi.data_ptr(), 4 * rows, d_pt.data_ptr(), 4 * rows, ncols,
+                           rows, _m(cref, beta), _m(cref, gamma), _m(cref, 1), d_z.data_ptr(), 4 * rows)
+    eng.sync()
     for j in range(ncols):
         A = cells[j * rows:(j + 1) * rows]
         Ap, Sp = _ints(cref, d_pi[j]), _ints(cref, d_pt[j])
         assert Ap == sorted(A) and sorted(Sp) == sorted(table)
         assert all(Ap[i] == Sp[i] or Ap[i] == Ap[i - 1] for i in range(rows))
-        d_z = torch.zeros((rows, 4), dtype=torch.int64, device="cuda")
-        eng.lookup_product_dev(d_lk[j * rows:].data_ptr(), d_tab.data_ptr(), d_pi[j].data_ptr(), d_pt[j].data_ptr(), rows,
-                               _m(cref, beta), _m(cref, gamma), _m(cref, 1), d_z.data_ptr())
-        eng.sync()
-        z = _ints(cref, d_z)
+        z = _ints(cref, d_z[j])
         i = rows - 1
         assert z[-1] * (A[i] + beta) % P.FR_R * (table[i] + gamma) % P.FR_R == (Ap[i] + beta) * (Sp[i] + gamma) % P.FR_R
 
@@ -465,18 +465,23 @@ def test_full_quotient_of_a_small_circuit(eng, cref):
     for (c, i), (pc, pi) in to.items():
         sigma[c][i] = labels[pc][pi]
     d_val, d_sig = _dev(cref, val), _dev(cref, sigma)
-    # permutation products, set by set (z_j[0] = z_{j-1}[u]), blinding rows randomised afterwards
+    # permutation products: all sets in one call (z_j[0] = z_{j-1}[u]); cross-checked set by set against the single-chunk
+    # entry point and the oracle; blinding rows randomised afterwards
     d_z = torch.zeros((nsets, n, 4), dtype=torch.int64, device="cuda")
+    eng.permutation_product_sets_dev(d_val.data_ptr(), 4 * n, d_sig.data_ptr(), 4 * n, m, chunk, k, u, _m(cref, w_n), _m(cref, beta),
+                                     _m(cref, gamma), _m(cref, delta), d_z.data_ptr(), 4 * n)
+    d_z1 = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
     z0 = 1
     z_sets = []
     for j in range(nsets):
         c0, mc = j * chunk, min(chunk, m - j * chunk)
         eng.permutation_product_dev(d_val[c0].data_ptr(), 4 * n, d_sig[c0].data_ptr(), 4 * n, mc, k, _m(cref, w_n), _m(cref, beta),
-                                    _m(cref, gamma), _m(cref, pow(delta, c0, R)), _m(cref, delta), _m(cref, z0), d_z[j].data_ptr())
+                                    _m(cref, gamma), _m(cref, pow(delta, c0, R)), _m(cref, delta), _m(cref, z0), d_z1.data_ptr())
         eng.sync()
         zj = _ints(cref, d_z[j])
         want = P.permutation_product(val[c0:c0 + mc], sigma[c0:c0 + mc], w_n, beta, gamma, pow(delta, c0, R), delta, z0)
         assert zj == want, j
+        assert _ints(cref, d_z1) == want, j
         zj[u + 1:] = [rng.randrange(R) for _ in range(n - u - 1)]
         z_sets.append(zj)
         z0 = zj[u]
@@ -500,10 +505,10 @@ def test_full_quotient_of_a_small_circuit(eng, cref):
             arr[u:] = [rng.randrange(R) for _ in range(n - u)]
     d_Ap, d_Sp = _dev(cref, Ap), _dev(cref, Sp)
     d_zl = torch.zeros((nl, n, 4), dtype=torch.int64, device="cuda")
+    eng.lookup_product_dev(d_A.data_ptr(), 4 * n, d_S.data_ptr(), d_Ap.data_ptr(), 4 * n, d_Sp.data_ptr(), 4 * n, nl, n,
+                           _m(cref, beta), _m(cref, gamma), _m(cref, 1), d_zl.data_ptr(), 4 * n)
+    eng.sync()
     for j in range(nl):
-        eng.lookup_product_dev(d_A[j].data_ptr(), d_S.data_ptr(), d_Ap[j].data_ptr(), d_Sp[j].data_ptr(), n, _m(cref, beta),
-                               _m(cref, gamma), _m(cref, 1), d_zl[j].data_ptr())
-        eng.sync()
         z = _ints(cref, d_zl[j])
         assert z[u] == 1, j
         z[u + 1:] = [rng.randrange(R) for _ in range(n - u - 1)]
