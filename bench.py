@@ -245,6 +245,107 @@ class ProofWorkload:
                                self.omega_n, self.coset_gens, self.n_inv)
             done += nc
 
+    # ---- the prover steps that follow the hot path (SURVEY section 8f rank 1/3 rows built this round): measured once,
+    # OUTSIDE the timed region, on pool data of the proof's shape -- reported beside the headline, not inside it
+    def tail(self):
+        from paillier_halo2_amd import consts
+
+        eng, t = self.eng, self.torch
+        n, k, N, sh = self.n, self.k, self.ext_n, self.shape
+        log_e = sh.ext_k - k
+        E = 1 << log_e
+        one = consts.fr_mont_limbs(1)
+        ch = [consts.fr_mont_limbs(pow(consts.FR_GENERATOR, e, consts.FR_R)) for e in (11, 13, 17, 19)]   # stand-ins for beta, gamma, y, x
+        delta = consts.fr_mont_limbs(pow(consts.FR_GENERATOR, 1 << 28, consts.FR_R))
+        zeta = consts.fr_mont_limbs(pow(consts.FR_GENERATOR, (consts.FR_R - 1) // 3, consts.FR_R))
+        w_n, w_ext = consts.fr_mont_limbs(consts.fr_omega(k)), consts.fr_mont_limbs(consts.fr_omega(sh.ext_k))
+        w_ext_inv = consts.fr_mont_limbs(pow(consts.fr_omega(sh.ext_k), -1, consts.FR_R))
+        n_inv_ext = consts.fr_mont_limbs(pow(N, -1, consts.FR_R))
+        zeta_inv = consts.fr_mont_limbs(pow(pow(consts.FR_GENERATOR, (consts.FR_R - 1) // 3, consts.FR_R), -1, consts.FR_R))
+        pool_b = self._rand_fr(self.pool * n).view(self.pool, n, 4)          # sigma / second operand pool
+        sel_ext = self._rand_fr(64 * N).view(64, N, 4)
+        z_ext = self._rand_fr(32 * N).view(32, N, 4)
+        lpoly = self._rand_fr(3 * N).view(3, N, 4)
+        d_h = t.zeros((N, 4), dtype=t.int64, device=self.d_ext.device)
+        d_z = t.zeros((self.pool // 2, n, 4), dtype=t.int64, device=self.d_ext.device)
+        rows, lkc, lb = self.rows, self.lk_cols, sh.lookup_bits
+        tab = t.zeros((rows, 4), dtype=t.int64, device=self.d_ext.device)
+        tab[: 1 << lb, 0] = t.arange(1 << lb, device=self.d_ext.device)
+        eng.fr_convert_dev(tab.data_ptr(), rows, True)
+        d_pi = t.zeros((lkc, rows, 4), dtype=t.int64, device=self.d_ext.device)
+        d_pt = t.zeros_like(d_pi)
+        d_zl = t.zeros_like(d_pi)
+        d_ev = t.zeros((self.pool, 4), dtype=t.int64, device=self.d_ext.device)
+        t.cuda.synchronize()
+        m_perm = sh.advice_cols + sh.lookup_cols + 1
+        out = {}
+
+        def timed(name, fn):
+            t.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            t.cuda.synchronize()
+            out[name] = (time.perf_counter() - t0) * 1e3
+
+        def products():
+            done = 0
+            while done < m_perm:
+                mc = min(self.pool, m_perm - done)
+                eng.permutation_product_sets_dev(self.col_f.data_ptr(), 4 * n, pool_b.data_ptr(), 4 * n, mc, 2, k, rows - 1, w_n,
+                                                 ch[0], ch[1], delta, d_z.data_ptr(), 4 * n)
+                done += mc
+            eng.lookup_permute_dev(self.d_lk[0].data_ptr(), lkc, 4 * rows, tab.data_ptr(), rows, lb, d_pi.data_ptr(),
+                                   d_pt.data_ptr(), 4 * rows)
+            eng.lookup_product_dev(self.d_lk[0].data_ptr(), 4 * rows, tab.data_ptr(), d_pi.data_ptr(), 4 * rows, d_pt.data_ptr(),
+                                   4 * rows, lkc, rows, ch[0], ch[1], one, d_zl.data_ptr(), 4 * rows)
+
+        def quotient():
+            done = 0
+            while done < sh.advice_cols:
+                nc = min(64, sh.advice_cols - done)
+                eng.quotient_gate_dev(self.d_ext.data_ptr(), 4 * N, sel_ext.data_ptr(), 4 * N, nc, sh.ext_k, E, ch[2], d_h.data_ptr())
+                done += nc
+            done = 0
+            while done < m_perm:
+                mc = min(64, m_perm - done)
+                eng.quotient_permutation_dev(self.d_ext.data_ptr(), 4 * N, sel_ext.data_ptr(), 4 * N, z_ext.data_ptr(), 4 * N,
+                                             -(-mc // 2), 2, mc, sh.ext_k, E, 10, lpoly[0].data_ptr(), lpoly[1].data_ptr(),
+                                             lpoly[2].data_ptr(), ch[0], ch[1], delta, zeta, w_ext, ch[2], d_h.data_ptr())
+                done += mc
+            done = 0
+            while done < lkc:
+                nl = min(16, lkc - done)
+                eng.quotient_lookup_dev(self.d_ext.data_ptr(), 4 * N, sel_ext.data_ptr(), self.d_ext[16].data_ptr(), 4 * N,
+                                        self.d_ext[32].data_ptr(), 4 * N, self.d_ext[48].data_ptr(), 4 * N, nl, sh.ext_k, E,
+                                        lpoly[0].data_ptr(), lpoly[1].data_ptr(), lpoly[2].data_ptr(), ch[0], ch[1], ch[2],
+                                        d_h.data_ptr())
+                done += nl
+            eng.quotient_finish_dev(d_h.data_ptr(), k, log_e, zeta, w_ext)
+            eng.ntt_dev(d_h.data_ptr(), 1, 4 * N, w_ext_inv, sh.ext_k, None, n_inv_ext)
+            eng.fr_distribute_powers_dev(d_h.data_ptr(), 1, 4 * N, N, zeta_inv)
+
+        n_evals = 5 * sh.advice_cols + 5 * sh.lookup_cols + 3 * sh.perm_cols + m_perm   # advice at 4 rotations + selector, ...
+
+        def evals():
+            done = 0
+            while done < n_evals:
+                nc = min(self.pool, n_evals - done)
+                eng.poly_eval_dev(self.col_f.data_ptr(), nc, 4 * n, n, ch[3], d_ev.data_ptr())
+                done += nc
+            eng.poly_div_linear_dev(self.col_f.data_ptr(), 8, 4 * n, n, ch[3], pool_b.data_ptr(), 4 * n)
+
+        for name, fn in (("products", products), ("quotient", quotient), ("evaluations_and_openings", evals)):
+            fn()            # warm (pow tables, workspaces)
+            timed(name, fn)
+        out["total"] = sum(out.values())
+        out["counts"] = {"permutation_sets": -(-m_perm // 2), "permuted_columns": m_perm, "lookups": lkc,
+                         "gate_columns": sh.advice_cols, "point_evaluations": n_evals}
+        out["note"] = ("ms per proof of the prover steps after the hot path, run once outside the timed region on pool data of "
+                       "this proof's shape: permutation / lookup products (incl. permute_expression_pair on the real digit "
+                       "columns), evaluate_h (gate + permutation + lookup terms, division, extended iNTT), evaluations at a "
+                       "point and kate_division; transcript, blinding randomness and SHPLONK batching are not included")
+        return out
+
     def run(self, steps):
         """exactly `steps` passes of the hot path; with PZ_BENCH_PIPELINE the witness of pass i+1 overlaps the
         commitments / NTTs of pass i (every pass still does all of its work inside the timed region)"""
@@ -337,6 +438,7 @@ def main():
     ap.add_argument("--msm-split", default="windows", choices=["windows", "points"],
                     help="msm22 workload: shard Pippenger windows (north_star) or point ranges across the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tail", action="store_true", help="skip the (untimed) measurement of the prover steps after the hot path")
     args = ap.parse_args()
 
     import torch
@@ -416,6 +518,12 @@ def main():
         iso_ms, iso_n = eng.timing_get(E.T_MSM_ACC)
     for e_ in engines:
         e_.timing_enable(False)
+    tail = None
+    if rank == 0 and args.scale == 1.0 and not args.no_tail:
+        try:
+            tail = wl.tail()
+        except Exception as ex:   # never take the bench line down
+            tail = {"error": repr(ex)}
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -486,6 +594,8 @@ def main():
         "breakdown_ms_per_proof": {"trace": trace_ms / args.steps, "expand": exp_ms / args.steps, "msm_all": msm_ms / args.steps,
                                    "msm_accumulate": acc_ms / args.steps, "ntt": ntt_ms / args.steps},
     }
+    if tail is not None:
+        out["next_rows_ms_per_proof"] = tail
     if not args.no_cpu_baseline and args.scale == 1.0:
         try:
             out["cpu_baseline"] = cpu_baseline(sh, wl.n_steps, args.enc_bits, args.k, log)
