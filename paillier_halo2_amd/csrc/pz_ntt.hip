@@ -259,7 +259,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
                                     size_t out_stride, uint32_t log_n, uint32_t log_e, const uint64_t omega_n[4],
                                     const uint64_t* coset_gens, const uint64_t* scale) {
     if (!ctx || !omega_n || !coset_gens || (n_cols && (!d_coeff || !d_ext)) || log_e > 3) return PZ_ERR_INVALID;
-    if (log_n > 18) return PZ_ERR_UNSUPPORTED;  // two LDS passes; larger n: zero-extend and use pz_ntt_fr_dev
+    if (log_n > 27) return PZ_ERR_INVALID;
     if (n_cols == 0) return PZ_OK;
     const size_t n = (size_t)1 << log_n, E = (size_t)1 << log_e;
     if (in_stride % 4 || in_stride < 4 * n || out_stride % 4 || out_stride < 4 * n * E) return PZ_ERR_INVALID;
@@ -289,7 +289,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
     const Fr* pre = (const Fr*)prev;
     const Fr* cin = (const Fr*)d_coeff;
     Fr* eout = (Fr*)d_ext;
-    const unsigned npass = log_n <= 9 ? 1 : 2;
+    const unsigned npass = log_n <= 9 ? 1 : (log_n <= 18 ? 2 : 3);
     size_t group = n_cols;
     const size_t max_ws = (size_t)2 << 30;
     if (npass > 1 && group * n * E * 32 > max_ws) group = max_ws / (n * E * 32) ? max_ws / (n * E * 32) : 1;
@@ -309,6 +309,30 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
             const size_t lds = ((size_t)32 << p.logR) * p.T * E;
             hipLaunchKernelGGL(k_ntt_final_ext, dim3(1, (unsigned)nc), dim3(256), lds, ctx->stream, cin + c0 * is,
                                eout + c0 * os, is, (size_t)0, os, p, log_e, tw, pre, n);
+        } else if (npass == 3) {
+            // 2^19 .. 2^27 (config c5 runs k = 19): two strided passes per coset, then the interleaving final pass
+            unsigned lg[3], rem = log_n;
+            for (unsigned i = 0; i < 3; ++i) {
+                lg[i] = (rem + (3 - i) - 1) / (3 - i);
+                rem -= lg[i];
+            }
+            const size_t n1 = (size_t)1 << lg[0], n2 = (size_t)1 << lg[1], n3 = (size_t)1 << lg[2];
+            NttPass pa{};
+            pa.logR = lg[0]; pa.lo = n2 * n3; pa.hi = 1; pa.tw_mul = 1; pa.n = n; pa.T = pick_tile(n2 * n3, lg[0]);
+            NttPass pb{};
+            pb.logR = lg[1]; pb.lo = n3; pb.hi = n1; pb.tw_mul = n1; pb.n = n; pb.T = pick_tile(n3, lg[1]);
+            for (size_t r = 0; r < E; ++r) {  // tmp layout [r][col][n]
+                PZCHK(launch_strided(ctx, cin + c0 * is, tmp + r * nc * n, is, n, nc, pa, tw, pre + r * n));
+                PZCHK(launch_strided(ctx, tmp + r * nc * n, tmp + r * nc * n, n, n, nc, pb, tw, nullptr));
+            }
+            NttPass pc{};
+            pc.logR = lg[2]; pc.lo = 1; pc.hi = n1 * n2; pc.n = n; pc.n1 = n1; pc.n2 = n2;
+            unsigned T = 8;
+            while (T > 1 && (((size_t)32 << lg[2]) * T * E > 32768 || T > n1)) T >>= 1;
+            pc.T = T;
+            const size_t lds = ((size_t)32 << lg[2]) * T * E;
+            hipLaunchKernelGGL(k_ntt_final_ext, dim3((unsigned)(n2 * (n1 / T)), (unsigned)nc), dim3(256), lds, ctx->stream, tmp,
+                               eout + c0 * os, n, nc * n, os, pc, log_e, tw, (const Fr*)nullptr, (size_t)0);
         } else {
             unsigned lg0 = (log_n + 1) / 2, lg1 = log_n - lg0;
             const size_t n1 = (size_t)1 << lg0, n2 = (size_t)1 << lg1;

@@ -408,7 +408,7 @@ def test_witness_expand_on_real_trace(eng, cref):
         assert cref.fr_mont_to_ints(adv[k]) == want_adv, k
 
 
-@pytest.mark.parametrize("log_n,log_e", [(3, 2), (9, 2), (10, 2), (13, 1), (17, 2)])
+@pytest.mark.parametrize("log_n,log_e", [(3, 2), (9, 2), (10, 2), (13, 1), (17, 2), (19, 2), (20, 1)])
 def test_ntt_extend_vs_oracle(eng, cref, log_n, log_e):
     """coeff_to_extended in one call == zero-extend, distribute_powers(g), best_fft(omega_ext), with the ifft
     divisor folded in as `scale`"""
