@@ -519,7 +519,7 @@ def main():
     for e_ in engines:
         e_.timing_enable(False)
     tail = None
-    if rank == 0 and args.scale == 1.0 and not args.no_tail:
+    if rank == 0 and world == 1 and args.scale == 1.0 and not args.no_tail:
         try:
             tail = wl.tail()
         except Exception as ex:   # never take the bench line down
@@ -565,7 +565,7 @@ def main():
             "perm_cols": sh.perm_cols, "advice_cols_committed": wl.adv_cols, "lookup_cols_committed": wl.lk_cols,
             "cells_per_mul_mod": wl.cells, "advice_cells": wl.n_steps * wl.cells, "msm_per_proof": n_adv + cnt["msm_full"],
             "ntt_polys_per_proof": cnt["polys"], "scale": args.scale,
-            "scope": "hot path only (SURVEY section 8a): transcript, quotient evaluation and product construction stay on the reference's CPU side",
+            "scope": "hot path only (SURVEY section 8a): value excludes the prover steps after it (products, evaluate_h, evaluations: measured beside it in next_rows_ms_per_proof) and the transcript",
             "parallelism": "proof replicas, one per GPU, no collective", "pipeline_witness_of_next_proof": wl.pipeline,
             "ntt_on_second_stream": wl.stream_n is not None,
         },
@@ -596,7 +596,7 @@ def main():
     }
     if tail is not None:
         out["next_rows_ms_per_proof"] = tail
-    if not args.no_cpu_baseline and args.scale == 1.0:
+    if not args.no_cpu_baseline and args.scale == 1.0 and world == 1:   # rank 0 at N = 1 only
         try:
             out["cpu_baseline"] = cpu_baseline(sh, wl.n_steps, args.enc_bits, args.k, log)
         except Exception as ex:  # the checker must never take the bench line down
