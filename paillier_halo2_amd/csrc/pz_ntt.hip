@@ -30,14 +30,53 @@ struct NttPass {
 
 __device__ __forceinline__ unsigned bitrev32(unsigned x, unsigned bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 
-// logR radix-2 DIT stages over an LDS tile holding T independent transforms.
-// element (j, t) lives at sm[j*sr + t*st].  Input must be stored bit-reversed in j.
+// logR radix-2 DIT stages over an LDS tile holding T independent transforms, taken TWO STAGES AT A TIME: a thread
+// owns the four elements {base, base+h, base+2h, base+3h} of a radix-4 group, does both layers in registers (same
+// four products as two radix-2 layers) and the tile crosses LDS and a barrier once per pair of stages instead of
+// once per stage.  Stages 0+1 cost one product per group (their other twiddles are 1).  An odd logR ends with one
+// plain radix-2 stage.  element (j, t) lives at sm[j*sr + t*st].  Input must be stored bit-reversed in j.
 __device__ __forceinline__ void lds_dit(Fr* sm, unsigned logR, unsigned T, unsigned sr, unsigned st, bool t_fastest,
                                         const Fr* __restrict__ tw, size_t n) {
     const unsigned R = 1u << logR;
-    const unsigned nbf = (R >> 1) * T;
-    for (unsigned s = 0; s < logR; ++s) {
+    unsigned s = 0;
+    for (; s + 1 < logR; s += 2) {
+        const unsigned h = 1u << s;
+        const unsigned nq = (R >> 2) * T;
+        for (unsigned id = threadIdx.x; id < nq; id += blockDim.x) {
+            unsigned t, q;
+            if (t_fastest) {
+                t = id % T;
+                q = id / T;
+            } else {
+                q = id % (R >> 2);
+                t = id / (R >> 2);
+            }
+            const unsigned pos = q & (h - 1);
+            const unsigned base = ((q >> s) << (s + 2)) + pos;
+            Fr* p0 = sm + (size_t)base * sr + (size_t)t * st;
+            Fr* p1 = p0 + (size_t)h * sr;
+            Fr* p2 = p1 + (size_t)h * sr;
+            Fr* p3 = p2 + (size_t)h * sr;
+            Fr a0 = *p0, a1 = *p1, a2 = *p2, a3 = *p3;
+            if (s) {  // kernel-uniform: the first layer of stages 0+1 has twiddle 1 everywhere
+                const Fr w = fp_load<FrTag>(tw + (size_t)pos * (n >> (s + 1)));
+                a1 = fp_mul(a1, w);
+                a3 = fp_mul(a3, w);
+            }
+            const Fr b0 = fp_add(a0, a1), b1 = fp_sub(a0, a1);
+            Fr b2 = fp_add(a2, a3), b3 = fp_sub(a2, a3);
+            if (s) b2 = fp_mul(b2, fp_load<FrTag>(tw + (size_t)pos * (n >> (s + 2))));
+            b3 = fp_mul(b3, fp_load<FrTag>(tw + (size_t)(pos + h) * (n >> (s + 2))));
+            *p0 = fp_add(b0, b2);
+            *p2 = fp_sub(b0, b2);
+            *p1 = fp_add(b1, b3);
+            *p3 = fp_sub(b1, b3);
+        }
+        __syncthreads();
+    }
+    if (s < logR) {
         const unsigned half = 1u << s;
+        const unsigned nbf = (R >> 1) * T;
         for (unsigned id = threadIdx.x; id < nbf; id += blockDim.x) {
             unsigned t, bf;
             if (t_fastest) {
@@ -49,12 +88,11 @@ __device__ __forceinline__ void lds_dit(Fr* sm, unsigned logR, unsigned T, unsig
             }
             const unsigned pos = bf & (half - 1);
             const unsigned i0 = ((bf >> s) << (s + 1)) + pos;
-            const unsigned i1 = i0 + half;
             Fr* p0 = sm + (size_t)i0 * sr + (size_t)t * st;
-            Fr* p1 = sm + (size_t)i1 * sr + (size_t)t * st;
+            Fr* p1 = p0 + (size_t)half * sr;
             Fr u = *p0;
             Fr v = *p1;
-            if (pos) v = fp_mul(v, fp_load<FrTag>(tw + (size_t)pos * (n >> (s + 1))));
+            if (s) v = fp_mul(v, fp_load<FrTag>(tw + (size_t)pos * (n >> (s + 1))));
             *p0 = fp_add(u, v);
             *p1 = fp_sub(u, v);
         }
