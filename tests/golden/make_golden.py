@@ -29,6 +29,13 @@ def steps_digest(steps, L):
     return h.hexdigest()
 
 
+def cells_digest(cells):
+    h = hashlib.sha256()
+    for v in cells:
+        h.update(int(v).to_bytes(32, "little"))
+    return h.hexdigest()
+
+
 def gen_paillier():
     cases = []
     # (enc_bits, limb_bits) -- the reference's two test shapes (paillier.rs:115-116, 186-187; bench.rs:139-140)
@@ -59,6 +66,15 @@ def gen_paillier():
     c2 = pow(n + 1, 54321, n * n) * pow(5, n, n * n) % (n * n)
     res, st = P.add_trace(n, c1, c2)
     adds.append(dict(enc_bits=2048, full_width=True, n=hx(n), c1=hx(c1), c2=hx(c2), res=hx(res), q=hx(st[2])))
+    # the reference's own add-test shape: 264-bit key on 88-bit limbs, lookup_bits 15 (paillier.rs:186-187, 247);
+    # the cell streams of its single mul_mod step are pinned by digest
+    rng88 = random.Random(0x5847)
+    n, _, _, _ = P.synth_paillier_inputs(264, 0x5847)
+    c1, c2 = rng88.getrandbits(264), rng88.getrandbits(264)
+    res, st = P.add_trace(n, c1, c2)
+    adv, lk = P.expand_mul_mod_cells(st[0], st[1], st[2], st[3], n * n, 6, 15, 88)
+    adds.append(dict(enc_bits=264, limb_bits=88, lookup_bits=15, n=hx(n), c1=hx(c1), c2=hx(c2), res=hx(res), q=hx(st[2]),
+                     advice_cells=len(adv), lookup_cells=len(lk), advice_sha256=cells_digest(adv), lookup_sha256=cells_digest(lk)))
     json.dump(dict(encrypt=cases, add=adds), open(os.path.join(OUT, "paillier.json"), "w"), indent=0)
 
 

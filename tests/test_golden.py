@@ -21,6 +21,21 @@ def test_paillier_golden_python():
     for case in g["add"]:
         n, c1, c2 = (H(case[k]) for k in ("n", "c1", "c2"))
         assert P.paillier_add_native(n, c1, c2) == H(case["res"])
+        if "advice_sha256" in case:   # the reference's add-test shape (264-bit key, 88-bit limbs): cell streams pinned
+            res, st = P.add_trace(n, c1, c2)
+            W, lb = case["limb_bits"], case["lookup_bits"]
+            adv, lk = P.expand_mul_mod_cells(st[0], st[1], st[2], st[3], n * n, 2 * case["enc_bits"] // W, lb, W)
+            assert (len(adv), len(lk)) == (case["advice_cells"], case["lookup_cells"])
+            assert cells_digest(adv) == case["advice_sha256"] and cells_digest(lk) == case["lookup_sha256"]
+
+
+def cells_digest(cells):
+    import hashlib
+
+    h = hashlib.sha256()
+    for v in cells:
+        h.update(int(v).to_bytes(32, "little"))
+    return h.hexdigest()
 
 
 def test_paillier_golden_c(cref):

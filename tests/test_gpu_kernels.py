@@ -294,12 +294,27 @@ def test_encrypt_golden(eng, cref):
         tot = int(ng[0]) + int(nr[0]) + 1
         assert steps_digest_arr(steps[0, :tot], L) == case["steps_sha256"], case["enc_bits"]
     for case in g["add"]:
-        Ln = case["enc_bits"] // 64
-        L = 2 * Ln
+        L = -(-2 * case["enc_bits"] // 64)   # 64-bit words of n^2 (9 for the 264-bit key on 88-bit limbs)
         n = H(case["n"])
-        q, r = eng.mul_mod(L, cref.int_to_limbs(H(case["c1"]), L), cref.int_to_limbs(H(case["c2"]), L),
-                           cref.int_to_limbs(n * n, L))
+        a, b, mod = (cref.int_to_limbs(v, L) for v in (H(case["c1"]), H(case["c2"]), n * n))
+        q, r = eng.mul_mod(L, a, b, mod)
         assert cref.limbs_to_int(r) == H(case["res"]) and cref.limbs_to_int(q) == H(case["q"])
+        if "advice_sha256" in case:   # K4 at the reference's add-test shape, pinned by the fixture's digests
+            import torch
+
+            W, lb = case["limb_bits"], case["lookup_bits"]
+            Lc = 2 * case["enc_bits"] // W
+            adv_n, lk_n = eng.witness_cells_per_step(Lc, W, lb)
+            assert (adv_n, lk_n) == (case["advice_cells"], case["lookup_cells"])
+            d_steps = torch.from_numpy(np.stack([a, b, q.reshape(-1), r.reshape(-1)]).astype(np.int64)).cuda()
+            d_mod = torch.from_numpy(mod.astype(np.int64)).cuda()
+            d_adv = torch.zeros((adv_n, 4), dtype=torch.int64, device="cuda")
+            d_lk = torch.zeros((lk_n, 4), dtype=torch.int64, device="cuda")
+            eng.witness_expand_dev(Lc, W, lb, d_steps.data_ptr(), 1, d_mod.data_ptr(), d_adv.data_ptr(), d_lk.data_ptr())
+            eng.sync()
+            dig = lambda t: hashlib.sha256(b"".join(int(v).to_bytes(32, "little") for v in
+                                                    cref.fr_mont_to_ints(t.cpu().numpy().astype(np.uint64)))).hexdigest()
+            assert dig(d_adv) == case["advice_sha256"] and dig(d_lk) == case["lookup_sha256"]
 
 
 def test_encrypt_batch_full_2048(eng, cref):
