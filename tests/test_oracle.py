@@ -246,3 +246,16 @@ def test_lookup_oracle_row_rule_and_telescoping():
     assert z[-1] * (A[i] + beta) * (table[i] + gamma) % R == (Ap[i] + beta) * (Sp[i] + gamma) % R
     with pytest.raises(ValueError):
         P.permute_expression_pair([17] + A[1:], table)
+
+
+def test_c_oracle_under_address_and_ub_sanitizers():
+    """the C restatement driven through its exported entry points under ASan + UBSan (CPU only: GPU sanitizers are
+    not available on the pool) -- memory errors in the checker would silently weaken every parity claim"""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "asan"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(root, "oracle", "_asan", "selftest")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "ALL OK" in out.stdout
