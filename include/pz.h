@@ -270,6 +270,11 @@ int pz_quotient_finish_dev(pz_ctx* ctx, uint64_t* d_h, uint32_t log_n, uint32_t 
  * c may be NULL (= 1). */
 int pz_fr_distribute_powers_dev(pz_ctx* ctx, uint64_t* d_a, size_t n_cols, size_t col_stride, size_t n,
                                 const uint64_t g[4], const uint64_t c[4]);
+/* random linear combination of n_cols polynomials (n elements each): d_out[i] = sum_j v^(n_cols-1-j) * p_j[i], computed
+ * as acc = acc*v + p_j over the columns; accumulate != 0 starts from the current d_out (continuing a Horner fold
+ * across calls).  The polynomial folding step of the multiopen argument, before pz_poly_div_linear_dev. */
+int pz_fr_lincomb_dev(pz_ctx* ctx, const uint64_t* d_polys, size_t n_cols, size_t col_stride, size_t n,
+                      const uint64_t v[4], uint64_t* d_out, int accumulate);
 /* kate_division: d_q[col] = (p_col(X) - p_col(x)) / (X - x) for n-coefficient polynomials: n-1 coefficients, the
  * n-th slot is written as zero (d_q may alias d_coeffs). */
 int pz_poly_div_linear_dev(pz_ctx* ctx, const uint64_t* d_coeffs, size_t n_cols, size_t col_stride, size_t n,

@@ -70,6 +70,7 @@ SIGNATURES = {
                                          C.c_uint32, C.c_uint32, VP, VP, VP, VP, VP, VP, VP]),
     "pz_quotient_finish_dev": (C.c_int, [VP, VP, C.c_uint32, C.c_uint32, VP, VP]),
     "pz_fr_distribute_powers_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, C.c_size_t, VP, VP]),
+    "pz_fr_lincomb_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, C.c_size_t, VP, VP, C.c_int]),
     "pz_poly_div_linear_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, C.c_size_t, VP, VP, C.c_size_t]),
     "pz_timing_enable": (C.c_int, [VP, C.c_int]),
     "pz_timing_reset": (C.c_int, [VP]),

@@ -603,3 +603,29 @@ extern "C" int pz_quotient_lookup_dev(pz_ctx* ctx, const uint64_t* d_input_ext, 
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- linear combination
+// out[i] = sum_j v^(n_cols-1-j) * p_j[i]  (Horner over the columns: acc = acc*v + p_j): the random linear
+// combinations of the multiopen argument (SHPLONK / GWC fold the polynomials opened at one point set with powers
+// of a challenge before the division by the set's vanishing factors, pz_poly_div_linear_dev per point).
+__global__ __launch_bounds__(256) void k_lincomb(const Fr* __restrict__ p, size_t cs, unsigned n_cols, size_t n, Fr v,
+                                                 Fr* __restrict__ out, int accumulate) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr acc = accumulate ? fp_load<FrTag>(out + i) : fp_zero<FrTag>();
+    for (unsigned j = 0; j < n_cols; ++j) acc = fp_add(fp_mul(acc, v), fp_load<FrTag>(p + (size_t)j * cs + i));
+    fp_store(out + i, acc);
+}
+
+extern "C" int pz_fr_lincomb_dev(pz_ctx* ctx, const uint64_t* d_polys, size_t n_cols, size_t col_stride, size_t n,
+                                 const uint64_t v[4], uint64_t* d_out, int accumulate) {
+    if (!ctx || !v || (n && (!d_out || (n_cols && !d_polys))) || col_stride % 4 || (n_cols > 1 && col_stride < 4 * n))
+        return PZ_ERR_INVALID;
+    if (n_cols > 0xffffffffu) return PZ_ERR_INVALID;
+    if (n == 0) return PZ_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_lincomb, dim3(pz_div_up(n, 256)), dim3(256), 0, ctx->stream, (const Fr*)d_polys, col_stride / 4,
+                       (unsigned)n_cols, n, fr_from_u64(v), (Fr*)d_out, accumulate);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}

@@ -366,6 +366,10 @@ class Engine:
                                                      self._fr1(c) if c is not None else None),
                   "pz_fr_distribute_powers_dev")
 
+    def fr_lincomb_dev(self, d_polys: int, n_cols: int, col_stride_u64: int, n: int, v, d_out: int, accumulate: bool = False):
+        self._chk(self.L.pz_fr_lincomb_dev(self.ctx, VP(d_polys), n_cols, col_stride_u64, n, self._fr1(v), VP(d_out),
+                                           int(accumulate)), "pz_fr_lincomb_dev")
+
     def poly_div_linear_dev(self, d_coeffs: int, n_cols: int, col_stride_u64: int, n: int, x, d_q: int, q_stride_u64: int):
         self._chk(self.L.pz_poly_div_linear_dev(self.ctx, VP(d_coeffs), n_cols, col_stride_u64, n, self._fr1(x), VP(d_q),
                                                 q_stride_u64), "pz_poly_div_linear_dev")

@@ -565,3 +565,30 @@ def test_full_quotient_of_a_small_circuit(eng, cref):
     eng.fr_distribute_powers_dev(d_h2.data_ptr(), 1, 4 * N, N, _m(cref, pow(cg, -1, R)))
     eng.sync()
     assert any(_ints(cref, d_h2)[3 * n - 3:])
+
+
+def test_multiopen_fold_and_division(eng, cref):
+    """multiopen building blocks: w(X) = sum_j v^(m-1-j) p_j(X) folded on the device (continued across calls), divided
+    by (X - x): the fold equals the oracle's, the quotient equals kate_division's and (X - x) q(X) = w(X) - w(x)."""
+    import torch
+
+    rng = random.Random(510)
+    R = P.FR_R
+    n, m = 1 << 10, 5
+    polys = [[rng.randrange(R) for _ in range(n)] for _ in range(m)]
+    v, x, t = (rng.randrange(1, R) for _ in range(3))
+    d_p = _dev(cref, polys)
+    d_w = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    eng.fr_lincomb_dev(d_p.data_ptr(), 2, 4 * n, n, _m(cref, v), d_w.data_ptr())                    # first two columns ...
+    eng.fr_lincomb_dev(d_p[2].data_ptr(), m - 2, 4 * n, n, _m(cref, v), d_w.data_ptr(), True)      # ... continued across calls
+    eng.sync()
+    want = [0] * n
+    for j in range(m):
+        want = [(a * v + b) % R for a, b in zip(want, polys[j])]
+    assert _ints(cref, d_w) == want
+    d_q = torch.zeros_like(d_w)
+    eng.poly_div_linear_dev(d_w.data_ptr(), 1, 4 * n, n, _m(cref, x), d_q.data_ptr(), 4 * n)
+    eng.sync()
+    q = _ints(cref, d_q)
+    assert q == P.kate_division(want, x)
+    assert (P.poly_eval(want, t) - P.poly_eval(want, x)) % R == (t - x) * P.poly_eval(q, t) % R
