@@ -139,9 +139,23 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(const Fr* __restrict_
         for (int k = 0; k < 8; ++k) any |= s[k];
         if (!any) continue;
         unsigned carry = 0;
-        for (unsigned w = 0; w < p.win_hi; ++w) {
-            int d = next_digit(s, w, p.c, carry);
-            if (w >= p.win_lo && d != 0) atomicAdd(&h[(d < 0 ? -d : d) - 1], 1u);
+        if (p.c == 16) {
+            // the production window: digit w is a 16-bit half of limb w/2 -- with the loop unrolled the limb index is
+            // a compile-time register, no 8-way select per digit
+#pragma unroll
+            for (unsigned w = 0; w < 16; ++w) {
+                if (w < p.win_hi) {
+                    const unsigned d0 = ((s[w >> 1] >> (16 * (w & 1))) & 0xffffu) + carry;
+                    carry = d0 > 0x8000u ? 1u : 0u;
+                    const unsigned mag = carry ? 0x10000u - d0 : d0;
+                    if (w >= p.win_lo && mag != 0) atomicAdd(&h[mag - 1], 1u);
+                }
+            }
+        } else {
+            for (unsigned w = 0; w < p.win_hi; ++w) {
+                int d = next_digit(s, w, p.c, carry);
+                if (w >= p.win_lo && d != 0) atomicAdd(&h[(d < 0 ? -d : d) - 1], 1u);
+            }
         }
     }
     __syncthreads();
@@ -294,13 +308,29 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restri
         for (int k = 0; k < 8; ++k) any |= s[k];
         if (!any) continue;
         unsigned carry = 0;
-        for (unsigned w = 0; w < p.win_hi; ++w) {
-            int d = next_digit(s, w, p.c, carry);
-            if (w >= p.win_lo && d != 0) {
-                const unsigned b = (d < 0 ? -d : d) - 1;
-                const u32 pos = atomicAdd(&h[b], 1u);
-                const bool sgn = neg != (d < 0);
-                e[pos] = (u32)((size_t)w * p.n_table + i) | (sgn ? 0x80000000u : 0u);
+        if (p.c == 16) {
+#pragma unroll
+            for (unsigned w = 0; w < 16; ++w) {
+                if (w < p.win_hi) {
+                    const unsigned d0 = ((s[w >> 1] >> (16 * (w & 1))) & 0xffffu) + carry;
+                    carry = d0 > 0x8000u ? 1u : 0u;
+                    const unsigned mag = carry ? 0x10000u - d0 : d0;
+                    if (w >= p.win_lo && mag != 0) {
+                        const u32 pos = atomicAdd(&h[mag - 1], 1u);
+                        const bool sgn = neg != (carry != 0);
+                        e[pos] = (u32)((size_t)w * p.n_table + i) | (sgn ? 0x80000000u : 0u);
+                    }
+                }
+            }
+        } else {
+            for (unsigned w = 0; w < p.win_hi; ++w) {
+                int d = next_digit(s, w, p.c, carry);
+                if (w >= p.win_lo && d != 0) {
+                    const unsigned b = (d < 0 ? -d : d) - 1;
+                    const u32 pos = atomicAdd(&h[b], 1u);
+                    const bool sgn = neg != (d < 0);
+                    e[pos] = (u32)((size_t)w * p.n_table + i) | (sgn ? 0x80000000u : 0u);
+                }
             }
         }
     }
