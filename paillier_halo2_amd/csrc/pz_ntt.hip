@@ -38,6 +38,7 @@ __device__ __forceinline__ unsigned bitrev32(unsigned x, unsigned bits) { return
 __device__ __forceinline__ void lds_dit(Fr* sm, unsigned logR, unsigned T, unsigned sr, unsigned st, bool t_fastest,
                                         const Fr* __restrict__ tw, size_t n) {
     const unsigned R = 1u << logR;
+    const unsigned logT = 31u - (unsigned)__builtin_clz(T);  // T is a power of two: every index split below is a shift / mask
     unsigned s = 0;
     for (; s + 1 < logR; s += 2) {
         const unsigned h = 1u << s;
@@ -45,11 +46,11 @@ __device__ __forceinline__ void lds_dit(Fr* sm, unsigned logR, unsigned T, unsig
         for (unsigned id = threadIdx.x; id < nq; id += blockDim.x) {
             unsigned t, q;
             if (t_fastest) {
-                t = id % T;
-                q = id / T;
+                t = id & (T - 1);
+                q = id >> logT;
             } else {
-                q = id % (R >> 2);
-                t = id / (R >> 2);
+                q = id & ((R >> 2) - 1);
+                t = id >> (logR - 2);
             }
             const unsigned pos = q & (h - 1);
             const unsigned base = ((q >> s) << (s + 2)) + pos;
@@ -80,11 +81,11 @@ __device__ __forceinline__ void lds_dit(Fr* sm, unsigned logR, unsigned T, unsig
         for (unsigned id = threadIdx.x; id < nbf; id += blockDim.x) {
             unsigned t, bf;
             if (t_fastest) {
-                t = id % T;
-                bf = id / T;
+                t = id & (T - 1);
+                bf = id >> logT;
             } else {
-                bf = id % (R >> 1);
-                t = id / (R >> 1);
+                bf = id & ((R >> 1) - 1);
+                t = id >> (logR - 1);
             }
             const unsigned pos = bf & (half - 1);
             const unsigned i0 = ((bf >> s) << (s + 1)) + pos;
@@ -108,13 +109,14 @@ __global__ __launch_bounds__(256) void k_ntt_strided(const Fr* in, Fr* out, size
                                                      const Fr* __restrict__ pre) {
     Fr* sm = reinterpret_cast<Fr*>(pz_smem);
     const unsigned R = 1u << p.logR, T = p.T;
-    const size_t tiles = p.lo / T;
+    const unsigned logT = 31u - (unsigned)__builtin_clz(T);
+    const size_t tiles = p.lo >> logT;   // lo, T powers of two
     const size_t h = blockIdx.x / tiles, lt = blockIdx.x % tiles;
     const Fr* src = in + (size_t)blockIdx.y * in_stride;
     Fr* dst = out + (size_t)blockIdx.y * out_stride;
     const size_t base = h * R * p.lo + lt * T;
     for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
-        unsigned j = idx / T, t = idx % T;
+        unsigned j = idx >> logT, t = idx & (T - 1);
         size_t g = base + (size_t)j * p.lo + t;
         Fr x = fp_load<FrTag>(src + g);
         if (pre) x = fp_mul(x, fp_load<FrTag>(pre + g));
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void k_ntt_strided(const Fr* in, Fr* out, size
     __syncthreads();
     lds_dit(sm, p.logR, T, T, 1, true, tw, p.n);
     for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
-        unsigned k = idx / T, t = idx % T;
+        unsigned k = idx >> logT, t = idx & (T - 1);
         Fr x = sm[(size_t)k * T + t];
         size_t e = p.tw_mul * (lt * T + t) * k;  // < n by construction
         if (e) x = fp_mul(x, fp_load<FrTag>(tw + e));
@@ -137,12 +139,13 @@ __global__ __launch_bounds__(256) void k_ntt_final(const Fr* in, Fr* out, size_t
                                                    Fr post, int has_post) {
     Fr* sm = reinterpret_cast<Fr*>(pz_smem);
     const unsigned R = 1u << p.logR, T = p.T;
-    const size_t tiles = p.n1 / T;
+    const unsigned logT = 31u - (unsigned)__builtin_clz(T);
+    const size_t tiles = p.n1 >> logT;
     const size_t k2 = blockIdx.x / tiles, k1_0 = (blockIdx.x % tiles) * T;
     const Fr* src = in + (size_t)blockIdx.y * in_stride;
     Fr* dst = out + (size_t)blockIdx.y * out_stride;
     for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
-        unsigned r = idx / R, j = idx % R;
+        unsigned r = idx >> p.logR, j = idx & (R - 1);
         size_t g = ((k1_0 + r) * p.n2 + k2) * R + j;
         Fr x = fp_load<FrTag>(src + g);
         if (pre) x = fp_mul(x, fp_load<FrTag>(pre + g));
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void k_ntt_final(const Fr* in, Fr* out, size_t
     __syncthreads();
     lds_dit(sm, p.logR, T, 1, R, false, tw, p.n);
     for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
-        unsigned k = idx / T, r = idx % T;
+        unsigned k = idx >> logT, r = idx & (T - 1);
         Fr x = sm[(size_t)r * R + k];
         if (has_post) x = fp_mul(x, post);
         fp_store(dst + (k1_0 + r) + p.n1 * k2 + p.hi * (size_t)k, x);
@@ -168,12 +171,13 @@ __global__ __launch_bounds__(256) void k_ntt_final_ext(const Fr* in, Fr* out, si
                                                        size_t pre_r_stride) {
     Fr* sm = reinterpret_cast<Fr*>(pz_smem);
     const unsigned R = 1u << p.logR, T = p.T, E = 1u << log_e;
-    const size_t tiles = p.n1 / T;
+    const unsigned logT = 31u - (unsigned)__builtin_clz(T);
+    const size_t tiles = p.n1 >> logT;
     const size_t k2 = blockIdx.x / tiles, k1_0 = (blockIdx.x % tiles) * T;
     const Fr* src = in + (size_t)blockIdx.y * in_stride;
     Fr* dst = out + (size_t)blockIdx.y * out_stride;
     for (unsigned idx = threadIdx.x; idx < R * T * E; idx += blockDim.x) {
-        const unsigned j = idx % R, rr = (idx / R) % T, r = idx / (R * T);
+        const unsigned j = idx & (R - 1), rr = (idx >> p.logR) & (T - 1), r = idx >> (p.logR + logT);
         const size_t g = ((k1_0 + rr) * p.n2 + k2) * R + j;
         Fr x = fp_load<FrTag>(src + (size_t)r * in_r_stride + g);
         if (pre) x = fp_mul(x, fp_load<FrTag>(pre + (size_t)r * pre_r_stride + g));
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256) void k_ntt_final_ext(const Fr* in, Fr* out, si
     __syncthreads();
     lds_dit(sm, p.logR, T * E, 1, R, false, tw, p.n);
     for (unsigned idx = threadIdx.x; idx < R * T * E; idx += blockDim.x) {
-        const unsigned r = idx % E, rr = (idx / E) % T, k = idx / (E * T);
+        const unsigned r = idx & (E - 1), rr = (idx >> log_e) & (T - 1), k = idx >> (log_e + logT);
         Fr x = sm[((size_t)r * T + rr) * R + k];
         fp_store(dst + (((k1_0 + rr) + p.n1 * k2 + p.hi * (size_t)k) << log_e) + r, x);
     }
