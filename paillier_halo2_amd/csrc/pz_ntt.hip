@@ -26,6 +26,7 @@ struct NttPass {
     size_t n;           // total transform size
     unsigned T;         // tile width
     size_t n1, n2;      // final pass: hi = n1*n2, output index = k1 + n1*k2 + hi*k
+    unsigned swap;      // 1: grid.x = column, grid.y = tile (set by the launch helpers)
 };
 
 __device__ __forceinline__ unsigned bitrev32(unsigned x, unsigned bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
@@ -111,9 +112,12 @@ __global__ __launch_bounds__(256) void k_ntt_strided(const Fr* in, Fr* out, size
     const unsigned R = 1u << p.logR, T = p.T;
     const unsigned logT = 31u - (unsigned)__builtin_clz(T);
     const size_t tiles = p.lo >> logT;   // lo, T powers of two
-    const size_t h = blockIdx.x / tiles, lt = blockIdx.x % tiles;
-    const Fr* src = in + (size_t)blockIdx.y * in_stride;
-    Fr* dst = out + (size_t)blockIdx.y * out_stride;
+    // columns of a batch share the pre-scale and twiddle tables: with the column in grid.x (dispatched fastest) the
+    // same tile of every column runs back to back and the table rows it needs stay in L2
+    const size_t bx = p.swap ? blockIdx.y : blockIdx.x, by = p.swap ? blockIdx.x : blockIdx.y;
+    const size_t h = bx / tiles, lt = bx % tiles;
+    const Fr* src = in + by * in_stride;
+    Fr* dst = out + by * out_stride;
     const size_t base = h * R * p.lo + lt * T;
     for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
         unsigned j = idx >> logT, t = idx & (T - 1);
@@ -141,9 +145,10 @@ __global__ __launch_bounds__(256) void k_ntt_final(const Fr* in, Fr* out, size_t
     const unsigned R = 1u << p.logR, T = p.T;
     const unsigned logT = 31u - (unsigned)__builtin_clz(T);
     const size_t tiles = p.n1 >> logT;
-    const size_t k2 = blockIdx.x / tiles, k1_0 = (blockIdx.x % tiles) * T;
-    const Fr* src = in + (size_t)blockIdx.y * in_stride;
-    Fr* dst = out + (size_t)blockIdx.y * out_stride;
+    const size_t bx = p.swap ? blockIdx.y : blockIdx.x, by = p.swap ? blockIdx.x : blockIdx.y;
+    const size_t k2 = bx / tiles, k1_0 = (bx % tiles) * T;
+    const Fr* src = in + by * in_stride;
+    Fr* dst = out + by * out_stride;
     for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
         unsigned r = idx >> p.logR, j = idx & (R - 1);
         size_t g = ((k1_0 + r) * p.n2 + k2) * R + j;
@@ -173,9 +178,10 @@ __global__ __launch_bounds__(256) void k_ntt_final_ext(const Fr* in, Fr* out, si
     const unsigned R = 1u << p.logR, T = p.T, E = 1u << log_e;
     const unsigned logT = 31u - (unsigned)__builtin_clz(T);
     const size_t tiles = p.n1 >> logT;
-    const size_t k2 = blockIdx.x / tiles, k1_0 = (blockIdx.x % tiles) * T;
-    const Fr* src = in + (size_t)blockIdx.y * in_stride;
-    Fr* dst = out + (size_t)blockIdx.y * out_stride;
+    const size_t bx = p.swap ? blockIdx.y : blockIdx.x, by = p.swap ? blockIdx.x : blockIdx.y;
+    const size_t k2 = bx / tiles, k1_0 = (bx % tiles) * T;
+    const Fr* src = in + by * in_stride;
+    Fr* dst = out + by * out_stride;
     for (unsigned idx = threadIdx.x; idx < R * T * E; idx += blockDim.x) {
         const unsigned j = idx & (R - 1), rr = (idx >> p.logR) & (T - 1), r = idx >> (p.logR + logT);
         const size_t g = ((k1_0 + rr) * p.n2 + k2) * R + j;
@@ -207,8 +213,9 @@ static int launch_strided(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t 
                           const Fr* tw, const Fr* pre) {
     size_t blocks = p.hi * (p.lo / p.T);
     size_t lds = ((size_t)32 << p.logR) * p.T;
-    hipLaunchKernelGGL(k_ntt_strided, dim3((unsigned)blocks, (unsigned)ncols), dim3(256), lds, ctx->stream, in, out, is, os,
-                       p, tw, pre);
+    p.swap = (ncols > 1 && blocks <= 65535) ? 1u : 0u;
+    hipLaunchKernelGGL(k_ntt_strided, p.swap ? dim3((unsigned)ncols, (unsigned)blocks) : dim3((unsigned)blocks, (unsigned)ncols),
+                       dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre);
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
 }
@@ -219,8 +226,9 @@ static int launch_final(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t os
     Fr post;
     memset(&post, 0, sizeof post);
     if (post_scale) memcpy(post.v, post_scale, 32);
-    hipLaunchKernelGGL(k_ntt_final, dim3((unsigned)blocks, (unsigned)ncols), dim3(256), lds, ctx->stream, in, out, is, os, p,
-                       tw, pre, post, post_scale ? 1 : 0);
+    p.swap = (ncols > 1 && blocks <= 65535) ? 1u : 0u;
+    hipLaunchKernelGGL(k_ntt_final, p.swap ? dim3((unsigned)ncols, (unsigned)blocks) : dim3((unsigned)blocks, (unsigned)ncols),
+                       dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, post, post_scale ? 1 : 0);
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
 }
@@ -349,6 +357,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
             NttPass p{};
             p.logR = log_n; p.lo = 1; p.hi = 1; p.n = n; p.T = 1; p.n1 = 1; p.n2 = 1;
             const size_t lds = ((size_t)32 << p.logR) * p.T * E;
+            p.swap = 0;
             hipLaunchKernelGGL(k_ntt_final_ext, dim3(1, (unsigned)nc), dim3(256), lds, ctx->stream, cin + c0 * is,
                                eout + c0 * os, is, (size_t)0, os, p, log_e, tw, pre, n);
         } else if (npass == 3) {
@@ -373,7 +382,8 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
             while (T > 1 && (((size_t)32 << lg[2]) * T * E > 32768 || T > n1)) T >>= 1;
             pc.T = T;
             const size_t lds = ((size_t)32 << lg[2]) * T * E;
-            hipLaunchKernelGGL(k_ntt_final_ext, dim3((unsigned)(n2 * (n1 / T)), (unsigned)nc), dim3(256), lds, ctx->stream, tmp,
+            pc.swap = (nc > 1 && n2 * (n1 / T) <= 65535) ? 1u : 0u;
+            hipLaunchKernelGGL(k_ntt_final_ext, pc.swap ? dim3((unsigned)nc, (unsigned)(n2 * (n1 / T))) : dim3((unsigned)(n2 * (n1 / T)), (unsigned)nc), dim3(256), lds, ctx->stream, tmp,
                                eout + c0 * os, n, nc * n, os, pc, log_e, tw, (const Fr*)nullptr, (size_t)0);
         } else {
             unsigned lg0 = (log_n + 1) / 2, lg1 = log_n - lg0;
@@ -390,7 +400,8 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
             while (T > 1 && (((size_t)32 << lg1) * T * E > 32768 || T > n1)) T >>= 1;
             pc.T = T;
             const size_t lds = ((size_t)32 << lg1) * T * E;
-            hipLaunchKernelGGL(k_ntt_final_ext, dim3((unsigned)(n1 / T), (unsigned)nc), dim3(256), lds, ctx->stream, tmp,
+            pc.swap = nc > 1 ? 1u : 0u;
+            hipLaunchKernelGGL(k_ntt_final_ext, pc.swap ? dim3((unsigned)nc, (unsigned)(n1 / T)) : dim3((unsigned)(n1 / T), (unsigned)nc), dim3(256), lds, ctx->stream, tmp,
                                eout + c0 * os, n, nc * n, os, pc, log_e, tw, (const Fr*)nullptr, (size_t)0);
         }
         HIPCHK(ctx, hipGetLastError());
