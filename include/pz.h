@@ -18,8 +18,9 @@
  *     (hipMalloc / torch tensor data_ptr) valid on the context's device and run asynchronously on
  *     the context's stream (pz_set_stream); host-pointer entry points synchronise before returning.
  *   - a pz_ctx is bound to ONE device (one process per GPU, ranks joined by RCCL above this ABI);
- *     distinct contexts may be used concurrently, one context is serialised by the caller.  Entry
- *     points call hipSetDevice themselves, so they may be called from any thread (rayon workers).
+ *     distinct contexts may be used concurrently; one context is serialised INTERNALLY (a recursive mutex held for
+ *     the duration of every entry point), and entry points call hipSetDevice themselves, so they may be called
+ *     from any thread -- e.g. halo2's rayon workers reaching a patched best_multiexp with one shared context.
  */
 #ifndef PZ_H
 #define PZ_H

@@ -550,7 +550,7 @@ extern "C" int pz_mul_mod(pz_ctx* ctx, uint32_t limbs, const uint64_t* a, const 
                           uint64_t* q, uint64_t* r) {
     if (!ctx || !a || !b || !modulus || !q || !r || limbs == 0) return PZ_ERR_INVALID;
     if (limbs > 128) return PZ_ERR_UNSUPPORTED;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     const size_t lb = (size_t)limbs * 8;
     void* d;
     PZCHK(pz_ws_get(ctx, WS_BIG_A, 5 * lb + 256, &d));
@@ -587,7 +587,7 @@ extern "C" int pz_paillier_trace(pz_ctx* ctx, uint32_t limbs_n2, const uint64_t*
     if (!ctx || !n2 || !base || !exp || !result || limbs_n2 == 0 || exp_limbs == 0) return PZ_ERR_INVALID;
     if (steps_out && !n_steps) return PZ_ERR_INVALID;
     if (limbs_n2 > 128) return PZ_ERR_UNSUPPORTED;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     const unsigned L = limbs_n2;
     const size_t lb = (size_t)L * 8, eb = (size_t)exp_limbs * 8;
     // steps needed = bits(exp) + popcount(exp)
@@ -647,7 +647,7 @@ static int encrypt_impl(pz_ctx* ctx, uint32_t Ln, size_t batch, const uint64_t* 
     const unsigned L = 2 * Ln;
     if (L > 128) return PZ_ERR_UNSUPPORTED;
     if (steps_cap > 0x7fffffffu) return PZ_ERR_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     const size_t nb = (size_t)Ln * 8, lb = (size_t)L * 8;
     // exact per-instance step counts from the exponents (host side: they are public structure of the
     // circuit, paillier.rs:50,54)

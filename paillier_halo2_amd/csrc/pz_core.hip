@@ -123,13 +123,14 @@ extern "C" int pz_free(pz_ctx* ctx) {
 
 extern "C" int pz_set_stream(pz_ctx* ctx, void* s) {
     if (!ctx) return PZ_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
     return PZ_OK;
 }
 
 extern "C" int pz_sync(pz_ctx* ctx) {
     if (!ctx) return PZ_ERR_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return PZ_OK;
 }
@@ -221,12 +222,14 @@ static void pz_timing_collect(pz_ctx* ctx) {
 
 extern "C" int pz_timing_enable(pz_ctx* ctx, int on) {
     if (!ctx) return PZ_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!on && ctx->timing) pz_timing_collect(ctx);
     ctx->timing = on != 0;
     return PZ_OK;
 }
 extern "C" int pz_timing_reset(pz_ctx* ctx) {
     if (!ctx) return PZ_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     pz_timing_collect(ctx);
     for (int c = 0; c < PZ_T_COUNT; ++c) {
         ctx->ev_ms[c] = 0;
@@ -236,7 +239,7 @@ extern "C" int pz_timing_reset(pz_ctx* ctx) {
 }
 extern "C" int pz_timing_get(pz_ctx* ctx, int which, double* total_ms, uint64_t* launches) {
     if (!ctx || which < 0 || which >= PZ_T_COUNT) return PZ_ERR_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     pz_timing_collect(ctx);
     if (total_ms) *total_ms = ctx->ev_ms[which];
     if (launches) *launches = ctx->ev_n[which];
@@ -264,14 +267,14 @@ static int timed_launch(pz_ctx* ctx, double* ms, K kern, dim3 g, dim3 b, A... ar
 
 extern "C" int pz_ubench_mad(pz_ctx* ctx, uint32_t blocks, uint32_t iters, double* ms) {
     if (!ctx || !ms || !blocks) return PZ_ERR_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     void* d;
     PZCHK(pz_ws_get(ctx, WS_MISC, (size_t)blocks * 256 * 32, &d));
     return timed_launch(ctx, ms, k_ubench_mad, dim3(blocks), dim3(256), (u64*)d, (unsigned)iters);
 }
 extern "C" int pz_ubench_fqmul(pz_ctx* ctx, uint32_t blocks, uint32_t iters, double* ms) {
     if (!ctx || !ms || !blocks) return PZ_ERR_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     void* d;
     PZCHK(pz_ws_get(ctx, WS_MISC, (size_t)blocks * 256 * 32, &d));
     return timed_launch(ctx, ms, k_ubench_fqmul, dim3(blocks), dim3(256), (Fq*)d, (unsigned)iters);

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "../../include/pz.h"
@@ -52,6 +53,7 @@ struct pz_ctx {
     double ev_ms[PZ_T_COUNT] = {0};
     uint64_t ev_n[PZ_T_COUNT] = {0};
     int cu_count = 256;
+    std::recursive_mutex mu;   // one context is serialised internally: entry points may be called from any thread
 };
 
 struct pz_bases {
@@ -77,6 +79,12 @@ static inline int pz_hip_fail(pz_ctx* ctx, hipError_t e, const char* what) {
         int rc_ = (x);              \
         if (rc_ != PZ_OK) return rc_; \
     } while (0)
+
+// first statement of every entry point that touches the device: serialise on the context (workspaces, caches and the
+// stream order belong to it; entry points call each other, hence recursive) and select its device for this thread
+#define PZ_ENTER(ctx)                                           \
+    std::lock_guard<std::recursive_mutex> pz_lock_((ctx)->mu);  \
+    HIPCHK((ctx), hipSetDevice((ctx)->device))
 
 // grow-only workspace slot; contents are NOT preserved across growth
 int pz_ws_get(pz_ctx* ctx, int slot, size_t bytes, void** out);

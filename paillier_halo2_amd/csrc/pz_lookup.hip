@@ -132,7 +132,7 @@ extern "C" int pz_lookup_permute_dev(pz_ctx* ctx, const uint64_t* d_inputs, size
     if (n_cols > 1 && (col_stride < 4 * rows || out_stride < 4 * rows)) return PZ_ERR_INVALID;
     if (n_cols == 0 || rows == 0) return PZ_OK;
     if (n_cols > 65535 || rows > 0xfffffff0u) return PZ_ERR_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     const u32 M = 1u << value_bits;
     // workspace: cA [n_cols][M] | cS [M] | oA [n_cols][M+1] | dr [n_cols][M] | oL [n_cols][M+1] | flags
     const size_t words = n_cols * (size_t)M + M + 2 * n_cols * (size_t)(M + 1) + n_cols * (size_t)M + 4;
@@ -188,7 +188,7 @@ extern "C" int pz_lookup_product_dev(pz_ctx* ctx, const uint64_t* d_inputs, size
     if (n_lookups > 1 && (input_stride < 4 * n || perm_input_stride < 4 * n || perm_table_stride < 4 * n || z_stride < 4 * n))
         return PZ_ERR_INVALID;
     if (!n || !n_lookups) return PZ_OK;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     void* ws;
     PZCHK(pz_ws_get(ctx, WS_BIG_C, 2 * n_lookups * n * 32, &ws));
     Fr* num = (Fr*)ws;

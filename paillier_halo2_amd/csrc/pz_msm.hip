@@ -562,7 +562,7 @@ extern "C" int pz_bases_load_g1(pz_ctx* ctx, const uint64_t* bases_affine, size_
     if (c < 4 || c > 16) return PZ_ERR_INVALID;
     unsigned nwin = 253 / c + 1;
     if ((uint64_t)nwin * n_points >= (1ull << 31)) return PZ_ERR_UNSUPPORTED;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     pz_bases* b = new pz_bases();
     b->n = n_points;
     b->c = c;
@@ -601,6 +601,7 @@ extern "C" int pz_srs_load_g1(pz_ctx* ctx, uint32_t k, const uint64_t* bases_aff
 extern "C" int pz_bases_free(pz_ctx* ctx, pz_bases* b) {
     if (!b) return PZ_OK;
     if (ctx) {
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
@@ -719,7 +720,7 @@ extern "C" int pz_msm_g1_dev(pz_ctx* ctx, const pz_bases* bases, const uint64_t*
     if (n > bases->n || win_lo > win_hi || win_hi > bases->nwin) return PZ_ERR_INVALID;
     if (col_stride % 4 || (n_cols > 1 && col_stride < 4 * n)) return PZ_ERR_INVALID;
     if (n_cols == 0) return PZ_OK;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     if (n == 0 || win_lo == win_hi) {
         // empty sum: identity for every column
         size_t nn = n_cols;
@@ -767,7 +768,7 @@ extern "C" int pz_msm_g1_batch(pz_ctx* ctx, const pz_bases* bases, const uint64_
     if (!ctx || !bases || (n_cols && (!scalar_cols || !out_jac))) return PZ_ERR_INVALID;
     if (n > bases->n) return PZ_ERR_INVALID;
     if (n_cols == 0) return PZ_OK;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     const size_t bytes = n * 32;
     size_t group = bytes ? ((size_t)1 << 29) / bytes : n_cols;
     if (group == 0) group = 1;
@@ -798,7 +799,7 @@ extern "C" int pz_msm_g1(pz_ctx* ctx, const pz_bases* bases, const uint64_t* sca
 
 extern "C" int pz_g1_sum(pz_ctx* ctx, const uint64_t* jac, size_t n, uint64_t out_jac[12]) {
     if (!ctx || !out_jac || (n && !jac)) return PZ_ERR_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     void* d;
     PZCHK(pz_ws_get(ctx, WS_IO_C, (n + 1) * 96, &d));
     if (n) HIPCHK(ctx, hipMemcpyAsync((char*)d + 96, jac, n * 96, hipMemcpyHostToDevice, ctx->stream));
@@ -812,7 +813,7 @@ extern "C" int pz_g1_sum(pz_ctx* ctx, const uint64_t* jac, size_t n, uint64_t ou
 extern "C" int pz_g1_normalize(pz_ctx* ctx, const uint64_t* jac, size_t n, uint64_t* aff) {
     if (!ctx || (n && (!jac || !aff))) return PZ_ERR_INVALID;
     if (!n) return PZ_OK;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     void *di, *dout;
     PZCHK(pz_ws_get(ctx, WS_IO_B, n * 96, &di));
     PZCHK(pz_ws_get(ctx, WS_IO_C, n * 64, &dout));
@@ -851,7 +852,7 @@ extern "C" int pz_g1_check_dev(pz_ctx* ctx, const uint64_t* d_points, size_t n, 
     if (!ctx || !n_bad || (n && !d_points)) return PZ_ERR_INVALID;
     *n_bad = 0;
     if (!n) return PZ_OK;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     void* cnt;
     PZCHK(pz_ws_get(ctx, WS_MISC, 8, &cnt));
     HIPCHK(ctx, hipMemsetAsync(cnt, 0, 8, ctx->stream));
@@ -866,7 +867,7 @@ extern "C" int pz_g1_check_dev(pz_ctx* ctx, const uint64_t* d_points, size_t n, 
 extern "C" int pz_g1_fixed_base_mul_dev(pz_ctx* ctx, const uint64_t* d_scalars, size_t n, uint64_t* d_out_affine) {
     if (!ctx || (n && (!d_scalars || !d_out_affine))) return PZ_ERR_INVALID;
     if (!n) return PZ_OK;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     hipLaunchKernelGGL(k_fixed_base_mul, dim3(pz_div_up(n, 128)), dim3(128), 0, ctx->stream, (const Fr*)d_scalars, n,
                        (G1Affine*)d_out_affine);
     HIPCHK(ctx, hipGetLastError());
@@ -876,7 +877,7 @@ extern "C" int pz_g1_fixed_base_mul_dev(pz_ctx* ctx, const uint64_t* d_scalars, 
 extern "C" int pz_g1_fixed_base_mul(pz_ctx* ctx, const uint64_t* scalars, size_t n, uint64_t* out_affine) {
     if (!ctx || (n && (!scalars || !out_affine))) return PZ_ERR_INVALID;
     if (!n) return PZ_OK;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     void *di, *dout;
     PZCHK(pz_ws_get(ctx, WS_IO_B, n * 32, &di));
     PZCHK(pz_ws_get(ctx, WS_IO_C, n * 64, &dout));

@@ -239,7 +239,7 @@ extern "C" int pz_ntt_fr_dev(pz_ctx* ctx, uint64_t* d_a, size_t n_cols, size_t c
     if (n_cols == 0) return PZ_OK;
     const size_t n = (size_t)1 << log_n;
     if (col_stride % 4 || col_stride < 4 * n) return PZ_ERR_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     const size_t cs = col_stride / 4;  // column stride in elements
     Fr* a = reinterpret_cast<Fr*>(d_a);
     void* twv = nullptr;
@@ -313,7 +313,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
     if (n_cols == 0) return PZ_OK;
     const size_t n = (size_t)1 << log_n, E = (size_t)1 << log_e;
     if (in_stride % 4 || in_stride < 4 * n || out_stride % 4 || out_stride < 4 * n * E) return PZ_ERR_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     const size_t is = in_stride / 4, os = out_stride / 4;
     void* twv = nullptr;
     PZCHK(pz_get_pow_table(ctx, omega_n, n, &twv));
@@ -414,7 +414,7 @@ extern "C" int pz_ntt_fr_batch(pz_ctx* ctx, uint64_t* const* cols, size_t n_cols
                                uint32_t log_n) {
     if (!ctx || !omega || (n_cols && !cols) || log_n > 27) return PZ_ERR_INVALID;
     if (n_cols == 0) return PZ_OK;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     const size_t n = (size_t)1 << log_n, bytes = n * 32;
     // stage in groups of <= 1 GiB
     size_t group = ((size_t)1 << 30) / bytes;
@@ -453,7 +453,7 @@ __global__ void k_fr_convert(Fr* a, size_t n, int to_mont) {
 extern "C" int pz_fr_convert_dev(pz_ctx* ctx, uint64_t* d_a, size_t n, int to_mont) {
     if (!ctx || (n && !d_a)) return PZ_ERR_INVALID;
     if (!n) return PZ_OK;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     size_t blocks = (n + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(k_fr_convert, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (Fr*)d_a, n, to_mont);

@@ -33,7 +33,7 @@ extern "C" int pz_g1_fixed_base_mul_dev(pz_ctx* ctx, const uint64_t* d_scalars, 
 extern "C" int pz_srs_setup_g1_dev(pz_ctx* ctx, uint32_t k, const uint64_t s[4], const uint64_t omega[4], uint64_t* d_g,
                                    uint64_t* d_g_lagrange) {
     if (!ctx || !s || !omega || (!d_g && !d_g_lagrange) || k > 26) return PZ_ERR_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     const size_t n = (size_t)1 << k;
     void* spow;
     PZCHK(pz_get_pow_table(ctx, s, n, &spow));
@@ -109,7 +109,7 @@ extern "C" int pz_poly_eval_dev(pz_ctx* ctx, const uint64_t* d_coeffs, size_t n_
     if (!ctx || !x || (n_cols && (!d_coeffs || !d_out)) || col_stride % 4 || (n_cols > 1 && col_stride < 4 * n)) return PZ_ERR_INVALID;
     if (n_cols == 0) return PZ_OK;
     if (n_cols > 65535) return PZ_ERR_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     if (n == 0) {
         HIPCHK(ctx, hipMemsetAsync(d_out, 0, n_cols * 32, ctx->stream));
         return PZ_OK;

@@ -73,7 +73,7 @@ int pz_batch_invert_internal(pz_ctx* ctx, Fr* d_a, size_t n) {
 
 extern "C" int pz_fr_batch_invert_dev(pz_ctx* ctx, uint64_t* d_a, size_t n) {
     if (!ctx || (n && !d_a)) return PZ_ERR_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     return pz_batch_invert_internal(ctx, (Fr*)d_a, n);
 }
 
@@ -153,7 +153,7 @@ int pz_prefix_product_internal(pz_ctx* ctx, const Fr* d_a, size_t n, Fr z0, Fr* 
 
 extern "C" int pz_fr_prefix_product_dev(pz_ctx* ctx, const uint64_t* d_a, size_t n, const uint64_t z0[4], uint64_t* d_z) {
     if (!ctx || !z0 || (n && (!d_a || !d_z))) return PZ_ERR_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     return pz_prefix_product_internal(ctx, (const Fr*)d_a, n, fr_from_u64(z0), (Fr*)d_z);
 }
 
@@ -189,7 +189,7 @@ extern "C" int pz_permutation_product_dev(pz_ctx* ctx, const uint64_t* d_cols, s
     if (col_stride % 4 || sigma_stride % 4 || m > 65535) return PZ_ERR_INVALID;
     const size_t n = (size_t)1 << log_n;
     if (m > 1 && (col_stride < 4 * n || sigma_stride < 4 * n)) return PZ_ERR_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     void *wp, *ws;
     PZCHK(pz_get_pow_table(ctx, omega, n, &wp));
     PZCHK(pz_ws_get(ctx, WS_BIG_C, 2 * n * 32, &ws));
@@ -252,7 +252,7 @@ extern "C" int pz_permutation_product_sets_dev(pz_ctx* ctx, const uint64_t* d_co
     const size_t n_sets = (m + chunk_len - 1) / chunk_len;
     if (col_stride % 4 || sigma_stride % 4 || z_stride % 4 || usable_rows >= n || n_sets > 65535 || m > 0xffffffu) return PZ_ERR_INVALID;
     if ((m > 1 && (col_stride < 4 * n || sigma_stride < 4 * n)) || (n_sets > 1 && z_stride < 4 * n)) return PZ_ERR_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     void *wp, *dp, *ws, *mu;
     PZCHK(pz_get_pow_table(ctx, omega, n, &wp));
     PZCHK(pz_get_pow_table(ctx, delta, m, &dp));
@@ -306,7 +306,7 @@ extern "C" int pz_quotient_gate_dev(pz_ctx* ctx, const uint64_t* d_adv_ext, size
     if (rot_step == 0 || rot_step >= N) return PZ_ERR_INVALID;
     if (n_cols > 1 && (adv_stride < 4 * N || sel_stride < 4 * N)) return PZ_ERR_INVALID;
     if (n_cols == 0) return PZ_OK;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     hipLaunchKernelGGL(k_quotient_gate, dim3(pz_div_up(N, 256)), dim3(256), 0, ctx->stream, (const Fr*)d_adv_ext,
                        adv_stride / 4, (const Fr*)d_sel_ext, sel_stride / 4, (unsigned)n_cols, N, (unsigned)rot_step,
                        fr_from_u64(y), (Fr*)d_h);
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void k_scale_periodic(Fr* __restrict__ h, size
 extern "C" int pz_quotient_finish_dev(pz_ctx* ctx, uint64_t* d_h, uint32_t log_n, uint32_t log_e, const uint64_t coset_g[4],
                                       const uint64_t omega_ext[4]) {
     if (!ctx || !d_h || !coset_g || !omega_ext || log_e == 0 || log_e > 6 || log_n + log_e > 28) return PZ_ERR_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     const unsigned E = 1u << log_e;
     const size_t N = (size_t)1 << (log_n + log_e);
     void* tab;
@@ -358,7 +358,7 @@ extern "C" int pz_fr_distribute_powers_dev(pz_ctx* ctx, uint64_t* d_a, size_t n_
     if (!ctx || !g || (n_cols && n && !d_a) || col_stride % 4 || (n_cols > 1 && col_stride < 4 * n)) return PZ_ERR_INVALID;
     if (n_cols == 0 || n == 0) return PZ_OK;
     if (n_cols > 65535) return PZ_ERR_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     void* tab;
     PZCHK(pz_get_pow_table(ctx, g, n, &tab, c));
     hipLaunchKernelGGL(k_mul_table_cols, dim3(pz_div_up(n, 256), (unsigned)n_cols), dim3(256), 0, ctx->stream, (Fr*)d_a,
@@ -440,7 +440,7 @@ extern "C" int pz_poly_div_linear_dev(pz_ctx* ctx, const uint64_t* d_coeffs, siz
     if (n_cols > 1 && (col_stride < 4 * n || q_stride < 4 * n)) return PZ_ERR_INVALID;
     if (n_cols == 0 || n == 0) return PZ_OK;
     if (n_cols > 65535) return PZ_ERR_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     const size_t nch = pz_div_up(n, KD_K);
     void* L;
     PZCHK(pz_ws_get(ctx, WS_BIG_A, n_cols * nch * 32, &L));
@@ -526,7 +526,7 @@ extern "C" int pz_quotient_permutation_dev(pz_ctx* ctx, const uint64_t* d_cols_e
     if ((size_t)n_sets * chunk_len < m_total || (size_t)(n_sets - 1) * chunk_len >= m_total) return PZ_ERR_INVALID;
     if (rot_step == 0 || rot_step >= N || (size_t)last_rotation * rot_step >= N) return PZ_ERR_INVALID;
     if ((m_total > 1 && (col_stride < 4 * N || sigma_stride < 4 * N)) || (n_sets > 1 && z_stride < 4 * N)) return PZ_ERR_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     PermQ q;
     q.cols = (const Fr*)d_cols_ext; q.sigma = (const Fr*)d_sigma_ext; q.z = (const Fr*)d_z_ext;
     q.l0 = (const Fr*)d_l0; q.llast = (const Fr*)d_l_last; q.lactive = (const Fr*)d_l_active;
@@ -591,7 +591,7 @@ extern "C" int pz_quotient_lookup_dev(pz_ctx* ctx, const uint64_t* d_input_ext, 
     if (n_lookups > 1 && (input_stride < 4 * N || perm_input_stride < 4 * N || perm_table_stride < 4 * N || z_stride < 4 * N))
         return PZ_ERR_INVALID;
     if (n_lookups == 0) return PZ_OK;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     LookQ q;
     q.a = (const Fr*)d_input_ext; q.s = (const Fr*)d_table_ext; q.ap = (const Fr*)d_perm_input_ext;
     q.sp = (const Fr*)d_perm_table_ext; q.z = (const Fr*)d_z_ext;
@@ -623,7 +623,7 @@ extern "C" int pz_fr_lincomb_dev(pz_ctx* ctx, const uint64_t* d_polys, size_t n_
         return PZ_ERR_INVALID;
     if (n_cols > 0xffffffffu) return PZ_ERR_INVALID;
     if (n == 0) return PZ_OK;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     hipLaunchKernelGGL(k_lincomb, dim3(pz_div_up(n, 256)), dim3(256), 0, ctx->stream, (const Fr*)d_polys, col_stride / 4,
                        (unsigned)n_cols, n, fr_from_u64(v), (Fr*)d_out, accumulate);
     HIPCHK(ctx, hipGetLastError());

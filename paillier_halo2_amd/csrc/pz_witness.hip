@@ -601,7 +601,7 @@ extern "C" int pz_witness_expand_dev(pz_ctx* ctx, uint32_t limbs, uint32_t limb_
     ExpP P;
     PZCHK(make_params(limbs, limb_bits, lookup_bits, P));
     if (!n_steps || (!d_advice && !d_lookup)) return PZ_OK;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PZ_ENTER(ctx);
     pz_timer tm(ctx, PZ_T_EXPAND);
     hipLaunchKernelGGL(k_witness_expand, dim3((unsigned)n_steps), dim3(EXP_THREADS), 0, ctx->stream, P, d_steps,
                        d_modulus, (Fr*)d_advice, (Fr*)d_lookup);

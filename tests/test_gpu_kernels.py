@@ -597,3 +597,42 @@ def test_end_to_end_columns_and_commitments(eng, cref):
         want = cref.g1_normalize(cref.msm_g1(col, bases[:rows]))
         assert np.array_equal(got[j], want), j
     tb.free()
+
+
+def test_one_context_from_many_threads(eng, cref):
+    """the reference's prover calls best_multiexp / best_fft from rayon worker threads: host-pointer entry points
+    of ONE context hammered from 6 threads (ctypes releases the GIL) must serialise internally and stay correct"""
+    import threading
+
+    rng = random.Random(900)
+    n = 256
+    s_, t_ = rng.randrange(1, P.FR_R), rng.randrange(1, P.FR_R)
+    bases_i = P.walk_bases(n, s_, t_)
+    tb = eng.load_bases(cref.affine_ints_to_mont(bases_i))
+    jobs = []
+    for j in range(6):
+        sc = [rng.randrange(P.FR_R) for _ in range(n)]
+        a = [rng.randrange(P.FR_R) for _ in range(1 << 10)]
+        jobs.append((sc, P.msm_walk_expected(sc, s_, t_), a, P.ntt(a, P.fr_omega(10))))
+    errs = []
+
+    def work(job):
+        sc, want_pt, a, want_ntt = job
+        try:
+            for _ in range(5):
+                got = cref.affine_mont_to_ints(eng.g1_normalize(eng.msm(tb, cref.fr_ints_to_mont(sc))))[0]
+                if got != want_pt:
+                    errs.append("msm")
+                out = eng.ntt(cref.fr_ints_to_mont(a), cref.fr_ints_to_mont([P.fr_omega(10)])[0], 10)
+                if cref.fr_mont_to_ints(out) != want_ntt:
+                    errs.append("ntt")
+        except Exception as ex:  # noqa: BLE001
+            errs.append(repr(ex))
+
+    th = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    tb.free()
+    assert errs == []
