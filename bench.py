@@ -60,7 +60,8 @@ def synth_inputs(enc_bits: int, seed: int):
 class ProofWorkload:
     """device-resident state of the c2 hot path on one GPU"""
 
-    def __init__(self, eng, torch, enc_bits: int, k: int, seed: int, scale: float, pool: int = 256, circuit: str = "encrypt"):
+    def __init__(self, eng, torch, enc_bits: int, k: int, seed: int, scale: float, pool: int = 256, circuit: str = "encrypt",
+                 lookup_bits=None):
         from paillier_halo2_amd import consts, layout
 
         self.eng, self.torch = eng, torch
@@ -78,7 +79,7 @@ class ProofWorkload:
             n_steps = 1
             self.add_ops = tuple(consts.int_to_limbs(x, self.L) for x in (m, r, nn * nn))
         self.n_steps = n_steps
-        self.shape = layout.encrypt_proof_shape(enc_bits, k, n_steps)
+        self.shape = layout.encrypt_proof_shape(enc_bits, k, n_steps, lookup_bits=lookup_bits)
         sh = self.shape
         sc = lambda x: max(1, int(round(x * scale)))
         self.counts = dict(msm_full=sc(sh.msm_full), polys=sc(sh.polys))
@@ -435,6 +436,11 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the per-proof MSM/NTT counts (debug only; "
                     "any value != 1 marks the line as not comparable)")
     ap.add_argument("--log-n", type=int, default=22, help="msm22 workload: log2 of the MSM size")
+    ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5043,
+                    help="base seed of the synthetic key / message (rank r uses seed + r); default = SURVEY section 8d's c2 seed")
+    ap.add_argument("--lookup-bits", type=int, default=None, help="RangeChip lookup bits (default k - 1, the reference's pattern)")
+    ap.add_argument("--msm-scalars", default="uniform", choices=["uniform", "witness"],
+                    help="msm22 workload: uniform scalars, or SURVEY section 8d's witness-like mix (60%% < 2^16, 30%% < 2^64, 10%% < 2^135)")
     ap.add_argument("--msm-split", default="windows", choices=["windows", "points"],
                     help="msm22 workload: shard Pippenger windows (north_star) or point ranges across the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -471,7 +477,7 @@ def main():
         from paillier_halo2_amd import dist as pzd
 
         res = pzd.bench_sharded_msm(eng, torch, dist if use_dist else None, rank, world, args.log_n, args.steps,
-                                    args.warmup, barrier, log, split=args.msm_split)
+                                    args.warmup, barrier, log, split=args.msm_split, scalars=args.msm_scalars)
         if rank == 0:
             print(json.dumps(res))
         if use_dist:
@@ -481,7 +487,7 @@ def main():
     t0 = time.time()
     if args.workload == "c3" and args.k == 17:
         args.k = 15
-    wl = ProofWorkload(eng, torch, args.enc_bits, args.k, seed=0x5043 + rank, scale=args.scale,
+    wl = ProofWorkload(eng, torch, args.enc_bits, args.k, seed=args.seed + rank, scale=args.scale, lookup_bits=args.lookup_bits,
                        circuit="add" if args.workload == "c3" else "encrypt")
     log("setup %.1fs: %s ; per-step counts %s" % (time.time() - t0, wl.shape, wl.counts))
     wl.run(args.warmup)

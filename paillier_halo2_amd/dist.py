@@ -73,7 +73,7 @@ def hip_partial_points_fn(eng, torch, d_bases, d_scalars, n: int, rank: int, wor
     return fn, bases
 
 
-def bench_sharded_msm(eng, torch, dist, rank, world, log_n, steps, warmup, barrier, log, split="windows"):
+def bench_sharded_msm(eng, torch, dist, rank, world, log_n, steps, warmup, barrier, log, split="windows", scalars="uniform"):
     """config c4: one 2^log_n-point MSM, windows (or point ranges) sharded over `world` ranks."""
     n = 1 << log_n
     gen = torch.Generator(device="cuda")
@@ -90,6 +90,14 @@ def bench_sharded_msm(eng, torch, dist, rank, world, log_n, steps, warmup, barri
     eng.g1_fixed_base_mul_dev(ks.data_ptr(), n, d_b.data_ptr())
     eng.sync()
     d_s = rand_fr(n)
+    if scalars == "witness":
+        # 60 % of the scalars below 2^16, 30 % below 2^64, 10 % below 2^135 (canonical values)
+        cls = torch.rand(n, device="cuda", generator=gen)
+        d_s[:, 3] = 0
+        d_s[:, 2] = torch.where(cls >= 0.9, d_s[:, 2] & 0x7F, torch.zeros_like(d_s[:, 2]))
+        d_s[:, 1] = torch.where(cls >= 0.9, d_s[:, 1], torch.zeros_like(d_s[:, 1]))
+        d_s[:, 0] = torch.where(cls < 0.6, d_s[:, 0] & 0xFFFF, d_s[:, 0])
+        eng.fr_convert_dev(d_s.data_ptr(), n, True)   # the ABI takes Montgomery form
     if split == "points":
         pfn, bases = hip_partial_points_fn(eng, torch, d_b, d_s, n, rank, world)
         units = n
@@ -125,7 +133,7 @@ def bench_sharded_msm(eng, torch, dist, rank, world, log_n, steps, warmup, barri
         "value": steps / dt, "unit": "MSM/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u32 limbs (254-bit modular integers)", "data": "synthetic",
-        "config": {"workload": "c4: single 2^%d-point MSM, uniform scalars" % log_n, "window_bits": bases.window_bits,
+        "config": {"workload": "c4: single 2^%d-point MSM, %s scalars" % (log_n, "witness-like" if scalars == "witness" else "uniform"), "window_bits": bases.window_bits,
                    "n_windows": bases.n_windows, "split": split,
                    "parallelism": "%s/%d + all_gather(96 B) + fold" % (split, world)},
         "roofline": {"bound": "hbm", "kernel": "whole MSM", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
