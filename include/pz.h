@@ -178,6 +178,11 @@ int pz_witness_expand_dev(pz_ctx* ctx, uint32_t limbs, uint32_t limb_bits, uint3
                           const uint64_t* d_steps, size_t n_steps, const uint64_t* d_modulus, uint64_t* d_advice,
                           uint64_t* d_lookup);
 
+/* host-pointer form: steps / modulus / outputs in process memory (n_steps*advice_cells and n_steps*lookup_cells Fr
+ * elements; either output may be NULL); synchronises before returning. */
+int pz_witness_expand(pz_ctx* ctx, uint32_t limbs, uint32_t limb_bits, uint32_t lookup_bits, const uint64_t* steps,
+                      size_t n_steps, const uint64_t* modulus, uint64_t* advice_out, uint64_t* lookup_out);
+
 /* ---------------------------------------------------------------------------------------------
  * "next" rows, built on the kernels above
  * ------------------------------------------------------------------------------------------- */

@@ -49,6 +49,7 @@ SIGNATURES = {
     "pz_paillier_encrypt_dev": (C.c_int, [VP, C.c_uint32, C.c_size_t, VP, VP, VP, VP, VP, C.c_size_t, VP, VP, VP]),
     "pz_witness_cells_per_step": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t),
                                             C.POINTER(C.c_size_t)]),
+    "pz_witness_expand": (C.c_int, [VP, C.c_uint32, C.c_uint32, C.c_uint32, VP, C.c_size_t, VP, VP, VP]),
     "pz_witness_expand_dev": (C.c_int, [VP, C.c_uint32, C.c_uint32, C.c_uint32, VP, C.c_size_t, VP, VP, VP]),
     "pz_srs_setup_g1_dev": (C.c_int, [VP, C.c_uint32, VP, VP, VP, VP]),
     "pz_poly_eval_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, C.c_size_t, VP, VP]),

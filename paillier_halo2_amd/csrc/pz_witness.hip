@@ -608,3 +608,39 @@ extern "C" int pz_witness_expand_dev(pz_ctx* ctx, uint32_t limbs, uint32_t limb_
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
 }
+
+// host-pointer form (SURVEY.md section 8b `pz_witness_expand`): stages the trace up, expands on the device in groups
+// of steps and copies the cell streams back; the prover pipeline keeps everything resident and uses the _dev form.
+extern "C" int pz_witness_expand(pz_ctx* ctx, uint32_t limbs, uint32_t limb_bits, uint32_t lookup_bits, const uint64_t* steps,
+                                 size_t n_steps, const uint64_t* modulus, uint64_t* advice_out, uint64_t* lookup_out) {
+    if (!ctx || (n_steps && (!steps || !modulus))) return PZ_ERR_INVALID;
+    ExpP P;
+    PZCHK(make_params(limbs, limb_bits, lookup_bits, P));
+    if (!n_steps || (!advice_out && !lookup_out)) return PZ_OK;
+    PZ_ENTER(ctx);
+    const size_t rec = 4 * (size_t)P.L64 * 8;  // bytes per step record
+    // groups of steps bounded to ~512 MiB of cells
+    size_t group = ((size_t)512 << 20) / (P.cells * 32 + 1);
+    if (group == 0) group = 1;
+    if (group > n_steps) group = n_steps;
+    void *d_steps, *d_mod, *d_adv = nullptr, *d_lk = nullptr;
+    PZCHK(pz_ws_get(ctx, WS_IO_A, group * rec + 64, &d_steps));
+    PZCHK(pz_ws_get(ctx, WS_MISC, (size_t)P.L64 * 8, &d_mod));
+    if (advice_out) PZCHK(pz_ws_get(ctx, WS_IO_B, group * P.cells * 32, &d_adv));
+    if (lookup_out) PZCHK(pz_ws_get(ctx, WS_IO_C, group * P.lookups * 32 + 32, &d_lk));
+    HIPCHK(ctx, hipMemcpyAsync(d_mod, modulus, (size_t)P.L64 * 8, hipMemcpyHostToDevice, ctx->stream));
+    for (size_t s0 = 0; s0 < n_steps; s0 += group) {
+        const size_t ns = n_steps - s0 < group ? n_steps - s0 : group;
+        HIPCHK(ctx, hipMemcpyAsync(d_steps, (const char*)steps + s0 * rec, ns * rec, hipMemcpyHostToDevice, ctx->stream));
+        PZCHK(pz_witness_expand_dev(ctx, limbs, limb_bits, lookup_bits, (const uint64_t*)d_steps, ns, (const uint64_t*)d_mod,
+                                    (uint64_t*)d_adv, (uint64_t*)d_lk));
+        if (advice_out)
+            HIPCHK(ctx, hipMemcpyAsync((char*)advice_out + s0 * P.cells * 32, d_adv, ns * P.cells * 32, hipMemcpyDeviceToHost,
+                                       ctx->stream));
+        if (lookup_out)
+            HIPCHK(ctx, hipMemcpyAsync((char*)lookup_out + s0 * P.lookups * 32, d_lk, ns * P.lookups * 32, hipMemcpyDeviceToHost,
+                                       ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return PZ_OK;
+}

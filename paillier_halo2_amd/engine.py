@@ -269,6 +269,18 @@ class Engine:
                   "pz_witness_cells_per_step")
         return a.value, l.value
 
+    def witness_expand(self, limbs: int, limb_bits: int, lookup_bits: int, steps, modulus, want_lookup: bool = True):
+        """host form: steps (n_steps, 4, words) u64, modulus (words,) -> (advice (n_steps, cells, 4), lookup or None)"""
+        st = np.ascontiguousarray(steps, dtype=np.uint64)
+        n_steps = st.shape[0]
+        md = np.ascontiguousarray(modulus, dtype=np.uint64)
+        adv_n, lk_n = self.witness_cells_per_step(limbs, limb_bits, lookup_bits)
+        adv = np.zeros((n_steps, adv_n, 4), dtype=np.uint64)
+        lk = np.zeros((n_steps, lk_n, 4), dtype=np.uint64) if want_lookup else None
+        self._chk(self.L.pz_witness_expand(self.ctx, limbs, limb_bits, lookup_bits, _ptr(st), n_steps, _ptr(md), _ptr(adv),
+                                           _ptr(lk) if lk is not None else VP()), "pz_witness_expand")
+        return adv, lk
+
     def witness_expand_dev(self, limbs: int, limb_bits: int, lookup_bits: int, d_steps: int, n_steps: int,
                            d_modulus: int, d_advice: int, d_lookup: int = 0):
         self._chk(self.L.pz_witness_expand_dev(self.ctx, limbs, limb_bits, lookup_bits, VP(d_steps), n_steps,

@@ -385,6 +385,8 @@ def test_witness_expand_vs_oracle(eng, cref, L, lb, W):
     lk = d_lk.cpu().numpy().astype(np.uint64)
     gates, end = P.gate_offsets_mul_mod(L, lb, W)
     assert end == adv_n
+    h_adv, h_lk = eng.witness_expand(L, W, lb, steps, cref.int_to_limbs(n, L64))   # host-pointer form of the same entry
+    assert np.array_equal(h_adv, adv) and np.array_equal(h_lk, lk)
     for i, (a, b, q, r) in enumerate(steps_int):
         want_adv, want_lk = P.expand_mul_mod_cells(a, b, q, r, n, L, lb, W)
         got_adv = cref.fr_mont_to_ints(adv[i])
