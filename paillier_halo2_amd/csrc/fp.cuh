@@ -211,11 +211,13 @@ template <class T> __device__ __forceinline__ Fp<T> fp_mul(const Fp<T>& a, const
 
 template <class T> __device__ __forceinline__ Fp<T> fp_sqr(const Fp<T>& a) { return fp_mul(a, a); }
 
+#ifdef PZ_FP_MUL_PLAIN
 template <class T> __device__ __forceinline__ Fp<T> fp_from_mont(const Fp<T>& a) {
     Fp<T> one = fp_zero<T>();
     one.v[0] = 1;
     return fp_mul(a, one);
 }
+#endif  // otherwise generated beside fp_mul (fp_mul_gen.cuh): the reduction alone, 72 mads instead of 128
 template <class T> __device__ __forceinline__ Fp<T> fp_to_mont(const Fp<T>& a) {
     Fp<T> r2;
 #pragma unroll
