@@ -116,6 +116,7 @@ class ProofWorkload:
             self.engw.set_stream(self.stream_w.cuda_stream)
             self.ready_ev = [torch.cuda.Event() for _ in range(2)]
             self.free_ev = [torch.cuda.Event() for _ in range(2)]
+        self.fused_ntt = os.environ.get("PZ_BENCH_FUSED_NTT", "0") == "1"   # measured: not faster
         self.digit_adds = 0  # filled by count_digit_adds() after a warm-up step
         gen = torch.Generator(device=dev)
         gen.manual_seed(seed)
@@ -241,9 +242,13 @@ class ProofWorkload:
             if off + nc > self.pool:
                 off = 0
             src = pool_n[off:off + nc]
-            eng.ntt_dev(src.data_ptr(), nc, 4 * n, self.omega_inv, k, None, None)
-            eng.ntt_extend_dev(src.data_ptr(), nc, 4 * n, self.d_ext.data_ptr(), 4 * self.ext_n, k, sh.ext_k - k,
-                               self.omega_n, self.coset_gens, self.n_inv)
+            if self.fused_ntt:   # lagrange_to_coeff + coeff_to_extended in one call (fused passes; identical results)
+                eng.ntt_coeff_extend_dev(src.data_ptr(), nc, 4 * n, self.d_ext.data_ptr(), 4 * self.ext_n, k, sh.ext_k - k,
+                                         self.omega_n, self.omega_inv, self.n_inv, self.coset_gens)
+            else:
+                eng.ntt_dev(src.data_ptr(), nc, 4 * n, self.omega_inv, k, None, None)
+                eng.ntt_extend_dev(src.data_ptr(), nc, 4 * n, self.d_ext.data_ptr(), 4 * self.ext_n, k, sh.ext_k - k,
+                                   self.omega_n, self.coset_gens, self.n_inv)
             done += nc
 
     # ---- the prover steps that follow the hot path (SURVEY section 8f rank 1/3 rows built this round): measured once,

@@ -126,6 +126,13 @@ int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t n_cols, si
                          const uint64_t* coset_gens, const uint64_t* scale);
 /* in-place representation change of n Fr elements on the device: to_mont != 0: canonical little-endian
  * integers (must be < r) -> Montgomery form (Fr::from_raw); else Montgomery -> canonical (to_repr). */
+/* Lagrange values -> coefficients (in place: lagrange_to_coeff = best_fft(omega_n^-1), then * n_inv) AND -> the extended
+ * coset values of pz_ntt_fr_extend_dev, in one call: the final pass of the inverse transform is fused with the first pass
+ * of the 2^log_e forward transforms, so the coefficients are written once and never read back (10 <= log_n <= 18; other
+ * sizes run the two transforms back to back).  Results are identical to pz_ntt_fr_dev + pz_ntt_fr_extend_dev. */
+int pz_ntt_fr_coeff_extend_dev(pz_ctx* ctx, uint64_t* d_values, size_t n_cols, size_t col_stride, uint64_t* d_ext,
+                               size_t out_stride, uint32_t log_n, uint32_t log_e, const uint64_t omega_n[4],
+                               const uint64_t omega_n_inv[4], const uint64_t n_inv[4], const uint64_t* coset_gens);
 int pz_fr_convert_dev(pz_ctx* ctx, uint64_t* d_a, size_t n, int to_mont);
 
 /* ---------------------------------------------------------------------------------------------

@@ -42,6 +42,8 @@ SIGNATURES = {
     "pz_ntt_fr_batch": (C.c_int, [VP, C.POINTER(VP), C.c_size_t, VP, C.c_uint32]),
     "pz_ntt_fr_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, VP, C.c_uint32, VP, VP]),
     "pz_ntt_fr_extend_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, VP, C.c_size_t, C.c_uint32, C.c_uint32, VP, VP, VP]),
+    "pz_ntt_fr_coeff_extend_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, VP, C.c_size_t, C.c_uint32, C.c_uint32, VP, VP, VP,
+                                             VP]),
     "pz_fr_convert_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_int]),
     "pz_mul_mod": (C.c_int, [VP, C.c_uint32, VP, VP, VP, VP, VP]),
     "pz_paillier_trace": (C.c_int, [VP, C.c_uint32, VP, VP, VP, C.c_uint32, VP, C.POINTER(C.c_size_t), VP]),

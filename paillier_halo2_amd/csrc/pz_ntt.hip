@@ -198,6 +198,70 @@ __global__ __launch_bounds__(256) void k_ntt_final_ext(const Fr* in, Fr* out, si
     }
 }
 
+// Lagrange values -> coefficients -> extended coset in ONE chain (what a prover does with every column): this kernel
+// is the final pass of the INVERSE transform (rows of R contiguous elements) fused with the first, strided pass of the
+// 2^e forward coset transforms.  With the inverse transform factored as n = n1 (strided first) x R (final), a block's
+// T rows hold the coefficients t + n1*k (t = row, k < R) -- exactly the tile [k][t] the forward transform's strided
+// pass over R needs -- so the coefficients go to HBM once (they are an output) and are never read back: per column
+// 64 B * 2^17 less traffic for every one of the 2^e cosets, and 2^e + 1 launches fewer.
+__global__ __launch_bounds__(256) void k_ntt_inv_final_fwd_first(const Fr* in, Fr* coeff_out, size_t in_stride,
+                                                                 size_t coeff_stride, Fr* ext_tmp, size_t ext_e_stride,
+                                                                 NttPass p, unsigned log_e, const Fr* __restrict__ tw_inv,
+                                                                 const Fr* __restrict__ tw_fwd, const Fr* __restrict__ pre,
+                                                                 Fr post) {
+    Fr* sm = reinterpret_cast<Fr*>(pz_smem);
+    const unsigned R = 1u << p.logR, T = p.T, E = 1u << log_e;
+    const unsigned logT = 31u - (unsigned)__builtin_clz(T);
+    const size_t n1 = p.n1;                       // rows of the final pass == lo of the forward strided pass
+    const size_t col = blockIdx.x, k1_0 = (size_t)blockIdx.y * T;
+    const Fr* src = in + col * in_stride;
+    for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
+        const unsigned r = idx >> p.logR, j = idx & (R - 1);
+        sm[(size_t)r * R + bitrev32(j, p.logR)] = fp_load<FrTag>(src + (k1_0 + r) * R + j);
+    }
+    __syncthreads();
+    lds_dit(sm, p.logR, T, 1, R, false, tw_inv, p.n);
+    // the block's coefficients, kept in registers for all cosets (PER = R*T/256 <= 4 elements per thread)
+    constexpr unsigned MAXPER = 4;
+    Fr v[MAXPER];
+#pragma unroll
+    for (unsigned i = 0; i < MAXPER; ++i) {
+        const unsigned idx = threadIdx.x + i * 256;
+        if (idx < R * T) {
+            const unsigned k = idx >> logT, r = idx & (T - 1);
+            const Fr x = fp_mul(sm[(size_t)r * R + k], post);
+            v[i] = x;
+            fp_store(coeff_out + col * coeff_stride + (k1_0 + r) + n1 * (size_t)k, x);
+        }
+    }
+    for (unsigned e = 0; e < E; ++e) {
+        __syncthreads();
+#pragma unroll
+        for (unsigned i = 0; i < MAXPER; ++i) {
+            const unsigned idx = threadIdx.x + i * 256;
+            if (idx < R * T) {
+                const unsigned k = idx >> logT, r = idx & (T - 1);
+                sm[(size_t)r * R + bitrev32(k, p.logR)] =
+                    fp_mul(v[i], fp_load<FrTag>(pre + (size_t)e * p.n + (k1_0 + r) + n1 * (size_t)k));
+            }
+        }
+        __syncthreads();
+        lds_dit(sm, p.logR, T, 1, R, false, tw_fwd, p.n);
+        Fr* dst = ext_tmp + (size_t)e * ext_e_stride + col * p.n;
+#pragma unroll
+        for (unsigned i = 0; i < MAXPER; ++i) {
+            const unsigned idx = threadIdx.x + i * 256;
+            if (idx < R * T) {
+                const unsigned k = idx >> logT, r = idx & (T - 1);
+                Fr x = sm[(size_t)r * R + k];
+                const size_t ex = (k1_0 + r) * (size_t)k;  // inter-pass twiddle of the forward transform, < n
+                if (ex) x = fp_mul(x, fp_load<FrTag>(tw_fwd + ex));
+                fp_store(dst + (size_t)k * n1 + (k1_0 + r), x);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 #ifndef PZ_NTT_LDS
 #define PZ_NTT_LDS 32768
@@ -302,6 +366,30 @@ extern "C" int pz_ntt_fr_dev(pz_ctx* ctx, uint64_t* d_a, size_t n_cols, size_t c
     return PZ_OK;
 }
 
+// E pre-scale tables scale * gens[r]^i, packed [E][n], cached in the context
+static int get_ext_pre_tables(pz_ctx* ctx, const uint64_t* coset_gens, size_t E, uint32_t log_n, const uint64_t* scale,
+                              void** out) {
+    const size_t n = (size_t)1 << log_n;
+    std::vector<uint64_t> key(coset_gens, coset_gens + 4 * E);
+    key.push_back(log_n);
+    if (scale) key.insert(key.end(), scale, scale + 4);
+    for (auto& c : ctx->ext_tables)
+        if (c.key == key) {
+            *out = c.d;
+            return PZ_OK;
+        }
+    void* prev = nullptr;
+    HIPCHK(ctx, hipMalloc(&prev, E * n * 32));
+    for (size_t r = 0; r < E; ++r) {
+        void* t;
+        PZCHK(pz_get_pow_table(ctx, coset_gens + 4 * r, n, &t, scale));
+        HIPCHK(ctx, hipMemcpyAsync((char*)prev + r * n * 32, t, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    ctx->ext_tables.push_back(pz_ext_table{key, prev});
+    *out = prev;
+    return PZ_OK;
+}
+
 // coeff_to_extended in one call: d_ext[col][2^e * q + r] = sum_i d_coeff[col][i] * scale * (gens[r])^i * omega_n^(i q)
 // with gens[r] = g * omega_ext^r supplied by the caller (2^log_e x 4 limbs, host), omega_n = omega_ext^(2^log_e).
 // Saves the zero-fill, the copy and two butterfly layers of the generic zero-extended transform.
@@ -318,24 +406,8 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
     void* twv = nullptr;
     PZCHK(pz_get_pow_table(ctx, omega_n, n, &twv));
     const Fr* tw = (const Fr*)twv;
-    // E pre-scale tables scale * gens[r]^i, packed [E][n], cached in the context
     void* prev = nullptr;
-    {
-        std::vector<uint64_t> key(coset_gens, coset_gens + 4 * E);
-        key.push_back(log_n);
-        if (scale) key.insert(key.end(), scale, scale + 4);
-        for (auto& c : ctx->ext_tables)
-            if (c.key == key) prev = c.d;
-        if (!prev) {
-            HIPCHK(ctx, hipMalloc(&prev, E * n * 32));
-            for (size_t r = 0; r < E; ++r) {
-                void* t;
-                PZCHK(pz_get_pow_table(ctx, coset_gens + 4 * r, n, &t, scale));
-                HIPCHK(ctx, hipMemcpyAsync((char*)prev + r * n * 32, t, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
-            }
-            ctx->ext_tables.push_back(pz_ext_table{key, prev});
-        }
-    }
+    PZCHK(get_ext_pre_tables(ctx, coset_gens, E, log_n, scale, &prev));
     const Fr* pre = (const Fr*)prev;
     const Fr* cin = (const Fr*)d_coeff;
     Fr* eout = (Fr*)d_ext;
@@ -404,6 +476,73 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
             hipLaunchKernelGGL(k_ntt_final_ext, pc.swap ? dim3((unsigned)nc, (unsigned)(n1 / T)) : dim3((unsigned)(n1 / T), (unsigned)nc), dim3(256), lds, ctx->stream, tmp,
                                eout + c0 * os, n, nc * n, os, pc, log_e, tw, (const Fr*)nullptr, (size_t)0);
         }
+        HIPCHK(ctx, hipGetLastError());
+    }
+    return PZ_OK;
+}
+
+// Lagrange values -> coefficients (in place, == EvaluationDomain::lagrange_to_coeff: best_fft(omega^-1) then * 1/n)
+// AND -> extended coset values (== coeff_to_extended) in one call, sharing the fused kernel above.  omega_n_inv and
+// n_inv are supplied by the caller (Montgomery, host) like every other constant of the ABI.
+extern "C" int pz_ntt_fr_coeff_extend_dev(pz_ctx* ctx, uint64_t* d_values, size_t n_cols, size_t col_stride, uint64_t* d_ext,
+                                          size_t out_stride, uint32_t log_n, uint32_t log_e, const uint64_t omega_n[4],
+                                          const uint64_t omega_n_inv[4], const uint64_t n_inv[4], const uint64_t* coset_gens) {
+    if (!ctx || !omega_n || !omega_n_inv || !n_inv || !coset_gens || (n_cols && (!d_values || !d_ext)) || log_e > 3 || log_n > 27)
+        return PZ_ERR_INVALID;
+    if (n_cols == 0) return PZ_OK;
+    const size_t n = (size_t)1 << log_n, E = (size_t)1 << log_e;
+    if (col_stride % 4 || col_stride < 4 * n || out_stride % 4 || out_stride < 4 * n * E) return PZ_ERR_INVALID;
+    if (log_n < 10 || log_n > 18) {  // one- and three-pass sizes: the two transforms back to back
+        PZCHK(pz_ntt_fr_dev(ctx, d_values, n_cols, col_stride, omega_n_inv, log_n, nullptr, n_inv));
+        return pz_ntt_fr_extend_dev(ctx, d_values, n_cols, col_stride, d_ext, out_stride, log_n, log_e, omega_n, coset_gens, nullptr);
+    }
+    PZ_ENTER(ctx);
+    const size_t cs = col_stride / 4, os = out_stride / 4;
+    void *twf, *twi, *prev;
+    PZCHK(pz_get_pow_table(ctx, omega_n, n, &twf));
+    PZCHK(pz_get_pow_table(ctx, omega_n_inv, n, &twi));
+    PZCHK(get_ext_pre_tables(ctx, coset_gens, E, log_n, nullptr, &prev));
+    // inverse transform: strided pass over 2^lgA first, final (fused) pass over R = 2^lgB rows; forward: strided over R
+    // (fused), final over 2^lgA
+    const unsigned lgB = (log_n + 1) / 2, lgA = log_n - lgB;
+    const size_t nA = (size_t)1 << lgA, nB = (size_t)1 << lgB;
+    size_t group = n_cols;
+    const size_t max_ws = (size_t)2 << 30;
+    if (group * n * (E + 1) * 32 > max_ws) group = max_ws / (n * (E + 1) * 32) ? max_ws / (n * (E + 1) * 32) : 1;
+    if (group > 32768) group = 32768;
+    void* t;
+    PZCHK(pz_ws_get(ctx, WS_NTT_TMP, group * n * (E + 1) * 32, &t));
+    Fr* tmp0 = (Fr*)t;                 // [col][n]: inverse transform after its strided pass
+    Fr* tmpe = tmp0 + group * n;       // [e][col][n]: forward transforms after their strided pass
+    Fr post;
+    memcpy(post.v, n_inv, 32);
+    Fr* a = (Fr*)d_values;
+    Fr* eout = (Fr*)d_ext;
+    pz_timer tm(ctx, PZ_T_NTT);
+    for (size_t c0 = 0; c0 < n_cols; c0 += group) {
+        const size_t nc = n_cols - c0 < group ? n_cols - c0 : group;
+        NttPass pa{};
+        pa.logR = lgA; pa.lo = nB; pa.hi = 1; pa.tw_mul = 1; pa.n = n; pa.T = pick_tile(nB, lgA);
+        PZCHK(launch_strided(ctx, a + c0 * cs, tmp0, cs, n, nc, pa, (const Fr*)twi, nullptr));
+        NttPass pf{};
+        pf.logR = lgB; pf.lo = 1; pf.hi = nA; pf.n = n; pf.n1 = nA; pf.n2 = 1;
+        unsigned T = 8;
+        while (T > 1 && (((size_t)32 << lgB) * T > PZ_NTT_LDS || T > nA || (((size_t)T << lgB) > 1024))) T >>= 1;
+        pf.T = T;
+        const size_t lds = ((size_t)32 << lgB) * T;
+        hipLaunchKernelGGL(k_ntt_inv_final_fwd_first, dim3((unsigned)nc, (unsigned)(nA / T)), dim3(256), lds, ctx->stream,
+                           (const Fr*)tmp0, a + c0 * cs, n, cs, tmpe, nc * n, pf, log_e, (const Fr*)twi, (const Fr*)twf,
+                           (const Fr*)prev, post);
+        NttPass pc{};
+        pc.logR = lgA; pc.lo = 1; pc.hi = nB; pc.n = n; pc.n1 = nB; pc.n2 = 1;
+        unsigned Tc = 8;
+        while (Tc > 1 && (((size_t)32 << lgA) * Tc * E > 32768 || Tc > nB)) Tc >>= 1;
+        pc.T = Tc;
+        pc.swap = nc > 1 ? 1u : 0u;
+        const size_t ldsc = ((size_t)32 << lgA) * Tc * E;
+        hipLaunchKernelGGL(k_ntt_final_ext, pc.swap ? dim3((unsigned)nc, (unsigned)(nB / Tc)) : dim3((unsigned)(nB / Tc), (unsigned)nc),
+                           dim3(256), ldsc, ctx->stream, tmpe, eout + c0 * os, n, nc * n, os, pc, log_e, (const Fr*)twf,
+                           (const Fr*)nullptr, (size_t)0);
         HIPCHK(ctx, hipGetLastError());
     }
     return PZ_OK;

@@ -197,6 +197,14 @@ class Engine:
                                               log_n, log_e, _ptr(w), _ptr(g), _ptr(sc) if sc is not None else VP()),
                   "pz_ntt_fr_extend_dev")
 
+    def ntt_coeff_extend_dev(self, d_values: int, n_cols: int, col_stride_u64: int, d_ext: int, out_stride_u64: int, log_n: int,
+                             log_e: int, omega_n, omega_n_inv, n_inv, coset_gens):
+        g = _np(coset_gens).reshape(-1)
+        assert g.size == 4 << log_e
+        self._chk(self.L.pz_ntt_fr_coeff_extend_dev(self.ctx, VP(d_values), n_cols, col_stride_u64, VP(d_ext), out_stride_u64, log_n,
+                                                    log_e, self._fr1(omega_n), self._fr1(omega_n_inv), self._fr1(n_inv), _ptr(g)),
+                  "pz_ntt_fr_coeff_extend_dev")
+
     def fr_convert_dev(self, d_a: int, n: int, to_mont: bool = True):
         self._chk(self.L.pz_fr_convert_dev(self.ctx, VP(d_a), n, int(to_mont)), "pz_fr_convert_dev")
 

@@ -638,3 +638,39 @@ def test_one_context_from_many_threads(eng, cref):
         t.join()
     tb.free()
     assert errs == []
+
+
+@pytest.mark.parametrize("log_n,log_e", [(9, 2), (10, 2), (11, 1), (13, 2), (16, 2), (17, 2), (18, 1), (19, 2)])
+def test_ntt_coeff_extend_fused_vs_separate(eng, cref, log_n, log_e):
+    """lagrange_to_coeff + coeff_to_extended in one call (fused passes) == the two entry points back to back, bit for
+    bit, strided columns included; at small sizes also against the oracle"""
+    import torch
+
+    rng = np.random.default_rng(700 + log_n)
+    n, E, ncols = 1 << log_n, 1 << log_e, 3
+    stride = 4 * n + 8
+    vals = np.zeros((ncols, stride), dtype=np.uint64)
+    raw = rng.integers(0, 1 << 62, size=(ncols, n, 4), dtype=np.uint64)
+    raw[:, :, 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
+    vals[:, : 4 * n] = raw.reshape(ncols, 4 * n)
+    w_ext = P.fr_omega(log_n + log_e)
+    w_n = pow(w_ext, E, P.FR_R)
+    M = lambda x: cref.fr_ints_to_mont([x % P.FR_R])[0]
+    gens = np.stack([M(7 * pow(w_ext, r, P.FR_R)) for r in range(E)])
+    d1 = torch.from_numpy(vals.astype(np.int64)).cuda()
+    d2 = d1.clone()
+    e1 = torch.zeros((ncols, n * E, 4), dtype=torch.int64, device="cuda")
+    e2 = torch.zeros_like(e1)
+    eng.ntt_coeff_extend_dev(d1.data_ptr(), ncols, stride, e1.data_ptr(), 4 * n * E, log_n, log_e, M(w_n), M(pow(w_n, -1, P.FR_R)),
+                             M(pow(n, -1, P.FR_R)), gens)
+    eng.ntt_dev(d2.data_ptr(), ncols, stride, M(pow(w_n, -1, P.FR_R)), log_n, None, M(pow(n, -1, P.FR_R)))
+    eng.ntt_extend_dev(d2.data_ptr(), ncols, stride, e2.data_ptr(), 4 * n * E, log_n, log_e, M(w_n), gens, None)
+    eng.sync()
+    assert torch.equal(d1, d2)
+    assert torch.equal(e1, e2)
+    if log_n <= 11:
+        col = cref.fr_mont_to_ints(raw[1])
+        coeff = P.intt(col, w_n)
+        assert cref.fr_mont_to_ints(d1[1, : 4 * n].cpu().numpy().astype(np.uint64).reshape(n, 4)) == coeff
+        want = P.ntt(P.coset_scale(coeff + [0] * (n * E - n), 7), w_ext)
+        assert cref.fr_mont_to_ints(e1[1].cpu().numpy().astype(np.uint64)) == want
