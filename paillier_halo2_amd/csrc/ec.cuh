@@ -18,8 +18,10 @@ struct alignas(16) G1X {
     Fq x, y, zz, zzz;
 };
 
-__device__ __forceinline__ bool aff_is_inf(const G1Affine& p) { return fp_is_zero(p.x) && fp_is_zero(p.y); }
-__device__ __forceinline__ bool x_is_inf(const G1X& p) { return fp_is_zero(p.zz); }
+// exact tests: affine coordinates come from memory (canonical) or are set to zero for the identity; ZZ is a product of
+// non-zero elements unless it was set to zero (fp.cuh, lazy range)
+__device__ __forceinline__ bool aff_is_inf(const G1Affine& p) { return fp_is_zero_exact(p.x) && fp_is_zero_exact(p.y); }
+__device__ __forceinline__ bool x_is_inf(const G1X& p) { return fp_is_zero_exact(p.zz); }
 
 __device__ __forceinline__ G1X x_inf() {
     G1X r;

@@ -24,6 +24,11 @@ template <> struct FieldParams<FqTag> {
                               0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
         return p[i];
     }
+    __device__ __forceinline__ static constexpr u32 P2(int i) {  // 2p: the lazy range bound (see below)
+        constexpr u32 p[8] = {0xb0f9fa8eu, 0x7841182du, 0xd0e3951au, 0x2f02d522u,
+                              0x0302b0bbu, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u};
+        return p[i];
+    }
     __device__ __forceinline__ static constexpr u32 R1(int i) {  // R mod p
         constexpr u32 r[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
                               0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
@@ -41,6 +46,11 @@ template <> struct FieldParams<FrTag> {
     __device__ __forceinline__ static constexpr u32 P(int i) {
         constexpr u32 p[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
                               0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+        return p[i];
+    }
+    __device__ __forceinline__ static constexpr u32 P2(int i) {  // 2p: the lazy range bound (see below)
+        constexpr u32 p[8] = {0xe0000002u, 0x87c3eb27u, 0xf372e122u, 0x5067d090u,
+                              0x0302b0bau, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u};
         return p[i];
     }
     __device__ __forceinline__ static constexpr u32 R1(int i) {
@@ -73,17 +83,27 @@ template <class T> __device__ __forceinline__ Fp<T> fp_one() {  // Montgomery on
     for (int i = 0; i < 8; ++i) r.v[i] = FieldParams<T>::R1(i);
     return r;
 }
-template <class T> __device__ __forceinline__ bool fp_is_zero(const Fp<T>& a) {
+// LAZY RANGE: inside the kernels a field element is any representative in [0, 2p).  R = 2^256 > 4p, so the Montgomery
+// product of two such values is again below 2p WITHOUT the final conditional subtraction ((4p^2 + Rp)/R < 1.76p):
+// fp_mul skips it (+5.6 % multiplications per second), fp_add / fp_sub fold to [0, 2p) with the same instruction count
+// as the canonical versions, and memory only ever holds canonical values: fp_store subtracts p once if needed, so
+// loads are canonical and nothing lazy crosses the ABI.  Zero tests on COMPUTED differences must accept both
+// representatives of zero (0 and p): fp_is_zero.  fp_is_zero_exact is for values that are zero only when they were
+// set to zero (loaded coordinates, the ZZ of the identity): a product of non-zero elements is never 0 or p.
+template <class T> __device__ __forceinline__ bool fp_is_zero_exact(const Fp<T>& a) {
     u32 o = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) o |= a.v[i];
     return o == 0;
 }
-template <class T> __device__ __forceinline__ bool fp_eq(const Fp<T>& a, const Fp<T>& b) {
-    u32 o = 0;
+template <class T> __device__ __forceinline__ bool fp_is_zero(const Fp<T>& a) {
+    u32 o = 0, q = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o |= a.v[i] ^ b.v[i];
-    return o == 0;
+    for (int i = 0; i < 8; ++i) {
+        o |= a.v[i];
+        q |= a.v[i] ^ FieldParams<T>::P(i);
+    }
+    return o == 0 || q == 0;
 }
 
 // 256-bit add / subtract as 32-bit carry chains.  Written with __builtin_addc / __builtin_subc so hipcc emits
@@ -109,6 +129,33 @@ template <class T> __device__ __forceinline__ void fp_reduce_once(Fp<T>& a) {
     for (int i = 0; i < 8; ++i) a.v[i] = br ? a.v[i] : t[i];
 }
 
+// r = a - 2p if a >= 2p (a < 4p assumed)
+template <class T> __device__ __forceinline__ void fp_reduce_2p(Fp<T>& a) {
+    u32 t[8];
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u32 co;
+        t[i] = __builtin_subc(a.v[i], FieldParams<T>::P2(i), c, &co);
+        c = co;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a.v[i] = c ? a.v[i] : t[i];
+}
+// the canonical representative of a lazy value
+template <class T> __device__ __forceinline__ Fp<T> fp_canon(const Fp<T>& a) {
+    Fp<T> r = a;
+    fp_reduce_once(r);
+    return r;
+}
+template <class T> __device__ __forceinline__ bool fp_eq(const Fp<T>& a, const Fp<T>& b) {
+    const Fp<T> x = fp_canon(a), y = fp_canon(b);
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o |= x.v[i] ^ y.v[i];
+    return o == 0;
+}
+
 template <class T> __device__ __forceinline__ Fp<T> fp_add(const Fp<T>& a, const Fp<T>& b) {
     Fp<T> r;
     u32 c = 0;
@@ -118,8 +165,8 @@ template <class T> __device__ __forceinline__ Fp<T> fp_add(const Fp<T>& a, const
         r.v[i] = __builtin_addc(a.v[i], b.v[i], c, &co);
         c = co;
     }
-    // p < 2^254 so a + b < 2^255: no carry out of limb 7
-    fp_reduce_once(r);
+    // a, b < 2p and 4p < 2^256: no carry out of limb 7; back to [0, 2p)
+    fp_reduce_2p(r);
     return r;
 }
 
@@ -132,28 +179,28 @@ template <class T> __device__ __forceinline__ Fp<T> fp_sub(const Fp<T>& a, const
         r.v[i] = __builtin_subc(a.v[i], b.v[i], c, &co);
         c = co;
     }
-    const u32 mask = (u32)0 - c;  // borrow -> add p back
+    const u32 mask = (u32)0 - c;  // borrow -> add 2p back: a - b + 2p lies in (0, 2p)
     u32 c2 = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         u32 co;
-        r.v[i] = __builtin_addc(r.v[i], FieldParams<T>::P(i) & mask, c2, &co);
+        r.v[i] = __builtin_addc(r.v[i], FieldParams<T>::P2(i) & mask, c2, &co);
         c2 = co;
     }
     return r;
 }
 
 template <class T> __device__ __forceinline__ Fp<T> fp_neg(const Fp<T>& a) {
-    if (fp_is_zero(a)) return a;
+    if (fp_is_zero_exact(a)) return a;  // (a == p stays p: also a representative of zero)
     Fp<T> r;
     u32 c = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         u32 co;
-        r.v[i] = __builtin_subc(FieldParams<T>::P(i), a.v[i], c, &co);
+        r.v[i] = __builtin_subc(FieldParams<T>::P2(i), a.v[i], c, &co);
         c = co;
     }
-    return r;
+    return r;  // in (0, 2p)
 }
 
 template <class T> __device__ __forceinline__ Fp<T> fp_dbl(const Fp<T>& a) { return fp_add(a, a); }
@@ -252,7 +299,9 @@ template <class T> __device__ __forceinline__ Fp<T> fp_load(const void* p) {
     r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
     return r;
 }
-template <class T> __device__ __forceinline__ void fp_store(void* p, const Fp<T>& a) {
+// memory always holds the canonical representative (the ABI's layout; and what makes loads canonical)
+template <class T> __device__ __forceinline__ void fp_store(void* p, const Fp<T>& x) {
+    const Fp<T> a = fp_canon(x);
     uint4* q = reinterpret_cast<uint4*>(p);
     q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
     q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
