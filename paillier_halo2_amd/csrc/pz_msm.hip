@@ -689,7 +689,7 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     // heavy buckets are few per column in a column batch, but a single large MSM makes every bucket heavy:
     // size grid.x so the launch has ~8k workgroups either way (workgroups beyond the list exit at once)
     unsigned hx = (unsigned)(8192 / nc);
-    if (hx < 16) hx = 16;
+    if (hx < 4) hx = 4;   // column batches have a handful of heavy buckets per column at most; empty blocks still cost ~50 ns
     if (hx > p.B) hx = p.B;
     hipLaunchKernelGGL(k_msm_heavy_sum, dim3(hx, (unsigned)nc), dim3(256), 0, st, p, (const u32*)items, (const u32*)heavy,
                        (const u32*)heavy_cnt, (G1X*)partials);
