@@ -61,10 +61,11 @@ class ProofWorkload:
     """device-resident state of the c2 hot path on one GPU"""
 
     def __init__(self, eng, torch, enc_bits: int, k: int, seed: int, scale: float, pool: int = 256, circuit: str = "encrypt",
-                 lookup_bits=None):
+                 lookup_bits=None, shard=(0, 1), dist=None):
         from paillier_halo2_amd import consts, layout
 
         self.eng, self.torch = eng, torch
+        self.shard, self.dist = shard, dist   # (rank, world) when ONE proof's columns are split over the ranks
         self.enc_bits, self.k = enc_bits, k
         self.n = 1 << k
         self.Ln = enc_bits // 64
@@ -135,6 +136,7 @@ class ProofWorkload:
         self.pool = pool
         self.col_f = self._rand_fr(pool * self.n).view(pool, self.n, 4)
         self.d_out = torch.zeros((pool, 12), dtype=torch.int64, device=dev)
+        self.d_out_full = torch.zeros((self.counts["msm_full"], 12), dtype=torch.int64, device=dev)
         if self.stream_n is not None:
             self.col_n = self._rand_fr(pool * self.n).view(pool, self.n, 4)   # its own pool: NTTs run in place
         # NTT buffers
@@ -210,18 +212,29 @@ class ProofWorkload:
         n, k, sh = self.n, self.k, self.shape
         if self.pipeline:
             t.cuda.current_stream().wait_event(self.ready_ev[slot])
+        from paillier_halo2_amd import dist as pzd
+
+        rk, ws = self.shard
         # K1: commitments -- every advice and lookup-advice column (real witness cells) ...
         for buf, ncols in ((self.d_adv[slot], self.adv_cols), (self.d_lk[slot], self.lk_cols)):
             if self.scale != 1.0:
                 ncols = max(1, int(round(ncols * self.scale)))
-            eng.msm_dev(self.bases, buf.data_ptr(), ncols, self.rows, 4 * self.rows, self.d_out_adv.data_ptr())
+            lo, hi = pzd.column_range(ncols, rk, ws)   # column-parallel mode: this rank's columns of the shared proof
+            if hi > lo:
+                eng.msm_dev(self.bases, buf.data_ptr() + lo * self.rows * 32, hi - lo, self.rows, 4 * self.rows,
+                            self.d_out_adv.data_ptr())
+            if ws > 1:
+                pzd.gather_commitments(t, self.dist, self.d_out_adv[: hi - lo], ncols, rk, ws)
         # ... and the full-width MSMs of the later prover phases (permuted lookup columns, grand products,
         # quotient pieces, openings): uniformly random scalars
-        done = 0
-        while done < self.counts["msm_full"]:
-            nc = min(self.pool, self.counts["msm_full"] - done)
-            eng.msm_dev(self.bases, self.col_f.data_ptr(), nc, n, 4 * n, self.d_out.data_ptr())
+        lo, hi = pzd.column_range(self.counts["msm_full"], rk, ws)
+        done = lo
+        while done < hi:
+            nc = min(self.pool, hi - done)
+            eng.msm_dev(self.bases, self.col_f.data_ptr(), nc, n, 4 * n, self.d_out_full[done - lo].data_ptr())
             done += nc
+        if ws > 1:
+            pzd.gather_commitments(t, self.dist, self.d_out_full[: hi - lo], self.counts["msm_full"], rk, ws)
         if self.pipeline:
             self.free_ev[slot].record(t.cuda.current_stream())
         if not msm_only:
@@ -231,11 +244,14 @@ class ProofWorkload:
         eng, n, k, sh = self.engn, self.n, self.k, self.shape
         # K2: Lagrange -> coeff (iNTT 2^k) -> extended coset: 4 interleaved coset NTTs with the 1/n divisor folded into
         # their pre-scale tables (pz_ntt_fr_extend_dev == zero-extend, distribute_powers, best_fft(omega_ext))
+        from paillier_halo2_amd import dist as pzd
+
+        p_lo, p_hi = pzd.column_range(self.counts["polys"], *self.shard)   # column-parallel mode: this rank's polynomials
         done = 0
         nb = self.ntt_batch
         pool_n = self.col_f if self.stream_n is None else self.col_n
-        while done < self.counts["polys"]:
-            nc = min(nb, self.counts["polys"] - done)
+        while done < p_hi - p_lo:
+            nc = min(nb, p_hi - p_lo - done)
             # in place on the resident pool columns (as a prover consumes its own columns): they stay uniformly
             # random field elements from step to step, which is all the NTT's cost depends on
             off = (done % self.pool)
@@ -446,6 +462,9 @@ def main():
     ap.add_argument("--lookup-bits", type=int, default=None, help="RangeChip lookup bits (default k - 1, the reference's pattern)")
     ap.add_argument("--msm-scalars", default="uniform", choices=["uniform", "witness"],
                     help="msm22 workload: uniform scalars, or SURVEY section 8d's witness-like mix (60%% < 2^16, 30%% < 2^64, 10%% < 2^135)")
+    ap.add_argument("--parallel", default="replicas", choices=["replicas", "columns"],
+                    help="N > 1: independent proofs per GPU (weak scaling, the default and the headline) or ONE proof whose "
+                         "columns are split over the ranks with an all-gather of the commitments (strong scaling)")
     ap.add_argument("--msm-split", default="windows", choices=["windows", "points"],
                     help="msm22 workload: shard Pippenger windows (north_star) or point ranges across the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -492,7 +511,9 @@ def main():
     t0 = time.time()
     if args.workload == "c3" and args.k == 17:
         args.k = 15
-    wl = ProofWorkload(eng, torch, args.enc_bits, args.k, seed=args.seed + rank, scale=args.scale, lookup_bits=args.lookup_bits,
+    colpar = args.parallel == "columns"
+    wl = ProofWorkload(eng, torch, args.enc_bits, args.k, seed=args.seed + (0 if colpar else rank), scale=args.scale,
+                       lookup_bits=args.lookup_bits, shard=(rank, world) if colpar else (0, 1), dist=dist if (colpar and use_dist) else None,
                        circuit="add" if args.workload == "c3" else "encrypt")
     log("setup %.1fs: %s ; per-step counts %s" % (time.time() - t0, wl.shape, wl.counts))
     wl.run(args.warmup)
@@ -544,7 +565,7 @@ def main():
             dist.destroy_process_group()
         return
     sh, cnt = wl.shape, wl.counts
-    proofs = args.steps * world
+    proofs = args.steps * (1 if colpar else world)
     value = proofs / dt
     # roofline of the dominant kernel (k_msm_accumulate): algorithmic bytes per launch / avg launch time.
     # one launch accumulates nc columns against the shared bases: 64 B per base + 32 B per scalar
@@ -566,7 +587,7 @@ def main():
     out = {
         "metric": "Paillier-encrypt proofs/s (2048-bit n, k=17); MSM achieved HBM GB/s vs peak",
         "value": value, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if colpar else "weak", "vs_baseline": None,
         "dtype": "u32 limbs (254-bit modular integers), u64 limbs (4096-bit integers)", "data": "synthetic",
         "config": {
             "workload": "%s: %d-bit n, KZG prover hot path at k=%d (K3 trace + K4 cell expansion + K1 commitments + K2 NTTs), 1 proof per GPU per step"
@@ -577,7 +598,8 @@ def main():
             "cells_per_mul_mod": wl.cells, "advice_cells": wl.n_steps * wl.cells, "msm_per_proof": n_adv + cnt["msm_full"],
             "ntt_polys_per_proof": cnt["polys"], "scale": args.scale,
             "scope": "hot path only (SURVEY section 8a): value excludes the prover steps after it (products, evaluate_h, evaluations: measured beside it in next_rows_ms_per_proof) and the transcript",
-            "parallelism": "proof replicas, one per GPU, no collective", "pipeline_witness_of_next_proof": wl.pipeline,
+            "parallelism": ("one proof, columns split over the ranks, all-gather of the commitments" if colpar
+                            else "proof replicas, one per GPU, no collective"), "pipeline_witness_of_next_proof": wl.pipeline,
             "ntt_on_second_stream": wl.stream_n is not None,
         },
         "roofline": {

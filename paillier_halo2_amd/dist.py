@@ -30,6 +30,31 @@ def point_range(n_points: int, rank: int, world: int) -> Tuple[int, int]:
     return window_range(n_points, rank, world)
 
 
+def column_range(n_cols: int, rank: int, world: int) -> Tuple[int, int]:
+    """column-parallel proving (SURVEY.md section 8e, c2 at > 1 GPU): rank r commits / transforms columns [lo, hi)"""
+    return window_range(n_cols, rank, world)
+
+
+def gather_commitments(torch, dist, share, n_cols: int, rank: int, world: int):
+    """share: (hi - lo, 12) int64 tensor with this rank's Jacobian commitments for its column_range(n_cols); returns the
+    (n_cols, 12) tensor of all columns on every rank.  One all-gather of equal-sized (padded) shares: n_cols * 96 B in
+    total (474 KB for a c2 proof) -- latency-bound on xGMI, like the 96-byte exchange of the sharded MSM."""
+    lo, hi = column_range(n_cols, rank, world)
+    assert share.shape[0] == hi - lo
+    if dist is None or world == 1:
+        return share
+    per = -(-n_cols // world)
+    pad = torch.zeros((per, share.shape[1]), dtype=share.dtype, device=share.device)
+    pad[: hi - lo] = share
+    out = torch.zeros((world * per, share.shape[1]), dtype=share.dtype, device=share.device)
+    dist.all_gather_into_tensor(out, pad)
+    parts = []
+    for r in range(world):
+        a, b = column_range(n_cols, r, world)
+        parts.append(out[r * per: r * per + (b - a)])
+    return torch.cat(parts)
+
+
 def sharded_msm(torch, dist, rank: int, world: int, n_units: int,
                 partial_fn: Callable[[int, int], "torch.Tensor"],
                 fold_fn: Callable[[np.ndarray], np.ndarray]) -> np.ndarray:

@@ -13,7 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import pyref as P
-from paillier_halo2_amd.dist import point_range, sharded_msm, window_range
+from paillier_halo2_amd.dist import column_range, gather_commitments, point_range, sharded_msm, window_range
 
 
 def test_window_range_partition():
@@ -92,3 +92,32 @@ def test_sharded_msm_gloo(world, split, cref):
     for rank, got, want in out:
         assert got == want, rank
     assert out[0][1] == out[1][1]
+
+
+def _gather_worker(rank, world, port, n_cols, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = column_range(n_cols, rank, world)
+    share = torch.arange(lo * 12, hi * 12, dtype=torch.int64).reshape(hi - lo, 12)   # column c holds 12c .. 12c+11
+    out = gather_commitments(torch, dist, share, n_cols, rank, world)
+    q.put((rank, out.reshape(-1).tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_cols", [7, 8, 1])
+def test_column_parallel_gather_gloo(n_cols):
+    """column-parallel proving: every rank ends up with all columns' commitments in column order, ragged split included"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, n_cols, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, vals in out:
+        assert vals == list(range(12 * n_cols)), rank
