@@ -674,3 +674,53 @@ def test_ntt_coeff_extend_fused_vs_separate(eng, cref, log_n, log_e):
         assert cref.fr_mont_to_ints(d1[1, : 4 * n].cpu().numpy().astype(np.uint64).reshape(n, 4)) == coeff
         want = P.ntt(P.coset_scale(coeff + [0] * (n * E - n), 7), w_ext)
         assert cref.fr_mont_to_ints(e1[1].cpu().numpy().astype(np.uint64)) == want
+
+
+def test_msm_randomised_families(eng, cref):
+    """150 seeded MSM instances over families that stress the group law's special cases inside buckets -- equal bases
+    (t = 0: every addition into a bucket is a doubling), arithmetic-progression bases with tiny step, scalar pairs
+    (k, -k) and (k, k), scalars from {0, 1, 2, r-1, r-2}, sparse columns -- at window widths 5..16 and batches of 1..8
+    columns, each against the closed form [sum k_i (s + i t)] G"""
+    import torch
+
+    rng = random.Random(20260)
+    R = P.FR_R
+    for it in range(150):
+        logn = rng.choice([6, 8, 10, 12])
+        n = 1 << logn
+        kind = rng.choice(["rand", "dup", "small_t"])
+        s = rng.randrange(1, R)
+        t = {"rand": rng.randrange(1, R), "dup": 0, "small_t": rng.choice([1, 2, R - 1])}[kind]
+        sc_b = [(s + i * t) % R for i in range(n)]
+        d_kb = torch.from_numpy(np.asarray(cref.fr_ints_to_mont(sc_b)).astype(np.int64)).cuda()
+        d_b = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+        eng.g1_fixed_base_mul_dev(d_kb.data_ptr(), n, d_b.data_ptr())
+        c = rng.choice([0, 5, 9, 13, 16])
+        bases = eng.load_bases_dev(d_b.data_ptr(), n, c) if c else eng.load_bases_dev(d_b.data_ptr(), n)
+        ncols = rng.choice([1, 3, 8])
+        cols = []
+        for _ in range(ncols):
+            mode = rng.choice(["full", "small", "ones", "cancel", "sparse"])
+            if mode == "full":
+                k = [rng.randrange(R) for _ in range(n)]
+            elif mode == "small":
+                k = [rng.randrange(1 << rng.choice([1, 16, 64])) for _ in range(n)]
+            elif mode == "ones":
+                k = [rng.choice([0, 1, R - 1, 2, R - 2]) for _ in range(n)]
+            elif mode == "cancel":
+                k = [rng.randrange(R) for _ in range(n)]
+                for i in range(0, n - 1, 2):
+                    k[i + 1] = (R - k[i]) % R if rng.random() < 0.5 else k[i]
+            else:
+                k = [rng.randrange(R) if rng.random() < 0.05 else 0 for _ in range(n)]
+            cols.append(k)
+        d_s = torch.from_numpy(np.asarray(cref.fr_ints_to_mont([x for k in cols for x in k])).reshape(ncols, n, 4).astype(np.int64)).cuda()
+        d_o = torch.zeros((ncols, 12), dtype=torch.int64, device="cuda")
+        eng.msm_dev(bases, d_s.data_ptr(), ncols, n, 4 * n, d_o.data_ptr())
+        eng.sync()
+        got = cref.affine_mont_to_ints(eng.g1_normalize(d_o.cpu().numpy().astype(np.uint64)))
+        for j, k in enumerate(cols):
+            e = sum(ki * bi for ki, bi in zip(k, sc_b)) % R
+            want = P.g1_mul(P.G1_GEN, e) if e else (0, 0)
+            assert tuple(got[j]) == tuple(want), (it, kind, logn, c, j)
+        bases.free()
