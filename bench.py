@@ -448,7 +448,7 @@ def cpu_baseline(shape, n_steps, enc_bits, k, log):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "msm22"],
                     help="c2: encrypt proof hot path (headline); c3: homomorphic-add circuit at --k 15; msm22: one sharded MSM")
