@@ -17,6 +17,11 @@
  *   - "host" pointers are ordinary process memory; "_dev" entry points take device pointers
  *     (hipMalloc / torch tensor data_ptr) valid on the context's device and run asynchronously on
  *     the context's stream (pz_set_stream); host-pointer entry points synchronise before returning.
+ *   - every field element / coordinate handed to the library must be CANONICAL (an integer below the modulus in
+ *     Montgomery form), as halo2curves guarantees for Fr / Fq values; limbs in [p, 2^256) are not reduced on entry
+ *     and give undefined (silently wrong) results.  pz_g1_check_dev validates points on request.
+ *   - pz_set_stream orders the new stream after the work already queued on the previous one (event wait), so cached
+ *     tables / workspaces stay consistent; the caller still orders its OWN buffers between streams.
  *   - a pz_ctx is bound to ONE device (one process per GPU, ranks joined by RCCL above this ABI);
  *     distinct contexts may be used concurrently; one context is serialised INTERNALLY (a recursive mutex held for
  *     the duration of every entry point), and entry points call hipSetDevice themselves, so they may be called
@@ -93,6 +98,9 @@ int pz_msm_g1_dev(pz_ctx* ctx, const pz_bases* bases, const uint64_t* d_scalars,
                   size_t col_stride, uint32_t win_lo, uint32_t win_hi, uint64_t* d_out_jac);
 /* sum of n Jacobian points (host in/out): the fixed-order fold of per-rank partial MSMs. */
 int pz_g1_sum(pz_ctx* ctx, const uint64_t* jac /* n x 12 */, size_t n, uint64_t out_jac[12]);
+/* device form: d_jac (n x 12) and d_out_jac (12) are device pointers; asynchronous on the context's stream.  d_out_jac
+ * must not alias d_jac.  Used after the all-gather of the sharded MSM: every rank folds the same points in rank order. */
+int pz_g1_sum_dev(pz_ctx* ctx, const uint64_t* d_jac, size_t n, uint64_t* d_out_jac);
 /* Jacobian -> affine for n points (host in/out): `batch_normalize`. */
 int pz_g1_normalize(pz_ctx* ctx, const uint64_t* jac /* n x 12 */, size_t n, uint64_t* aff /* n x 8 */);
 /* out[i] = [scalars[i]] * G1 generator, affine; scalars are Fr Montgomery (host in/out).  This is
@@ -307,6 +315,13 @@ int pz_timing_get(pz_ctx* ctx, int which, double* total_ms, uint64_t* launches);
 int pz_ubench_mad(pz_ctx* ctx, uint32_t blocks, uint32_t iters, double* ms);
 /* Fq Montgomery multiplications per second microbenchmark (chains of `iters` per lane) */
 int pz_ubench_fqmul(pz_ctx* ctx, uint32_t blocks, uint32_t iters, double* ms);
+/* the same chain with an alternative field product: variant 0 = the production fp_mul,
+ * 1 = its round-1 form without the two wait states behind a single-product carry (timing only), 2 = a 9 x 29-bit
+ * reduced-radix product whose mads cannot overflow (no v_addc at all; 171 instead of 136 multiplier instructions) */
+int pz_ubench_fqmul_variant(pz_ctx* ctx, int variant, uint32_t blocks, uint32_t iters, double* ms);
+/* one product of variant 2, for its correctness check: a, b 256-bit integers below 2p (host, 4 x u64);
+ * out = a * b * 2^-261 mod p as an integer below 2p */
+int pz_fq_mul29(pz_ctx* ctx, const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,7 @@ SIGNATURES = {
     "pz_msm_g1_batch": (C.c_int, [VP, VP, C.POINTER(VP), C.c_size_t, C.c_size_t, VP]),
     "pz_msm_g1_dev": (C.c_int, [VP, VP, VP, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, VP]),
     "pz_g1_sum": (C.c_int, [VP, VP, C.c_size_t, VP]),
+    "pz_g1_sum_dev": (C.c_int, [VP, VP, C.c_size_t, VP]),
     "pz_g1_normalize": (C.c_int, [VP, VP, C.c_size_t, VP]),
     "pz_g1_fixed_base_mul": (C.c_int, [VP, VP, C.c_size_t, VP]),
     "pz_g1_fixed_base_mul_dev": (C.c_int, [VP, VP, C.c_size_t, VP]),
@@ -80,6 +81,8 @@ SIGNATURES = {
     "pz_timing_get": (C.c_int, [VP, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "pz_ubench_mad": (C.c_int, [VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
     "pz_ubench_fqmul": (C.c_int, [VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
+    "pz_ubench_fqmul_variant": (C.c_int, [VP, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
+    "pz_fq_mul29": (C.c_int, [VP, VP, VP, VP]),
 }
 
 _lib = None

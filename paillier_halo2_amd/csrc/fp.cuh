@@ -210,9 +210,10 @@ template <class T> __device__ __forceinline__ Fp<T> fp_dbl(const Fp<T>& a) { ret
 // goes to VCC) and one v_addc folding the carry into the third accumulator word: 128 mads + 8 v_mul_lo
 // + 128 addc.  hipcc does not use the mad's carry-out from C (it re-derives carries with
 // v_cmp_lt_u64 + v_cndmask, or keeps 64-bit adds + zero-extension moves: 580 instructions), hence inline
-// asm, one statement per column (gen_fp_mul.py).  VALU->VALU dependencies inside a statement are
-// hardware-interlocked on gfx950; VCC written by the mad is read by the next instruction's carry-in,
-// which needs no wait state.  Cost model measured on MI355X: mad 8 cycles, other VALU 2.
+// asm, one statement per column (gen_fp_mul.py).  VALU->VALU register dependencies inside a statement are
+// hardware-interlocked on gfx950; a carry-out (an SGPR pair or VCC written by a VALU) is NOT: it needs two wait
+// states before a VALU reads it, which the generator provides by software-pipelining the carries (and an
+// explicit s_nop 1 where a block has a single product).  Cost model measured on MI355X: DESIGN.md section 5.
 #ifndef PZ_FP_MUL_PLAIN
 #include "fp_mul_gen.cuh"
 #else

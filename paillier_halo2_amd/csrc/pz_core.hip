@@ -1,6 +1,8 @@
 // pz_core.hip -- context, workspaces, cached power tables, timing and the two issue-rate
 // microbenchmarks of libpz_hip.so.  gfx950 only.
+#define PZ_FP_MUL_VARIANTS 1
 #include "fp.cuh"
+#include "fp29_probe.cuh"
 #include "pz_internal.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -54,6 +56,49 @@ __global__ void k_ubench_fqmul(Fq* out, unsigned iters) {
         y = fp_mul(y, x);
     }
     fp_store(out + (size_t)blockIdx.x * blockDim.x + threadIdx.x, fp_add(x, y));
+}
+
+// the same chain with another product: 1 = round 1's back-to-back mad/addc pairs (no wait states -- timing only,
+// its results are not trusted), 2 = the 9 x 29-bit no-carry product of fp29_probe.cuh
+__global__ void k_ubench_fqmul_nowait(Fq* out, unsigned iters) {
+    Fq x = fp_one<FqTag>(), y = fp_one<FqTag>();
+    x.v[0] ^= threadIdx.x;
+    y.v[1] ^= blockIdx.x;
+    for (unsigned i = 0; i < iters; ++i) {
+        x = fp_mul_nowait(x, y);
+        y = fp_mul_nowait(y, x);
+    }
+    fp_store(out + (size_t)blockIdx.x * blockDim.x + threadIdx.x, fp_add(x, y));
+}
+__global__ void k_ubench_fqmul29(Fq* out, unsigned iters) {
+    Fq x0 = fp_one<FqTag>(), y0 = fp_one<FqTag>();
+    x0.v[0] ^= threadIdx.x;
+    y0.v[1] ^= blockIdx.x;
+    Fq29 x = fq29_from_words(x0.v), y = fq29_from_words(y0.v);
+    for (unsigned i = 0; i < iters; ++i) {
+        x = fq29_mul(x, y);
+        y = fq29_mul(y, x);
+    }
+    Fq r;
+    fq29_to_words(x, r.v);
+    Fq r2;
+    fq29_to_words(y, r2.v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r.v[k] ^= r2.v[k];
+    uint4* q = reinterpret_cast<uint4*>(out + (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+// one product of the probe, for its correctness check: out = a * b * 2^-261 mod p as a 256-bit integer below 2p
+__global__ void k_fq_mul29(const u32* a, const u32* b, u32* out) {
+    u32 aw[8], bw[8], rw[8];
+    for (int k = 0; k < 8; ++k) {
+        aw[k] = a[k];
+        bw[k] = b[k];
+    }
+    Fq29 r = fq29_mul(fq29_from_words(aw), fq29_from_words(bw));
+    fq29_to_words(r, rw);
+    for (int k = 0; k < 8; ++k) out[k] = rw[k];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -123,8 +168,19 @@ extern "C" int pz_free(pz_ctx* ctx) {
 
 extern "C" int pz_set_stream(pz_ctx* ctx, void* s) {
     if (!ctx) return PZ_ERR_INVALID;
-    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    PZ_ENTER(ctx);
+    hipStream_t ns = s ? (hipStream_t)s : ctx->own_stream;
+    if (ns != ctx->stream) {
+        // cached tables and workspaces may still be written / read by work queued on the old stream: order the
+        // new stream after it (an event wait, no host synchronisation)
+        hipEvent_t ev;
+        HIPCHK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(ev, ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ns, ev, 0);
+        (void)hipEventDestroy(ev);
+        if (e != hipSuccess) return pz_hip_fail(ctx, e, "pz_set_stream: order the new stream after the old one");
+        ctx->stream = ns;
+    }
     return PZ_OK;
 }
 
@@ -271,6 +327,28 @@ extern "C" int pz_ubench_mad(pz_ctx* ctx, uint32_t blocks, uint32_t iters, doubl
     void* d;
     PZCHK(pz_ws_get(ctx, WS_MISC, (size_t)blocks * 256 * 32, &d));
     return timed_launch(ctx, ms, k_ubench_mad, dim3(blocks), dim3(256), (u64*)d, (unsigned)iters);
+}
+extern "C" int pz_ubench_fqmul_variant(pz_ctx* ctx, int variant, uint32_t blocks, uint32_t iters, double* ms) {
+    if (!ctx || !ms || !blocks || variant < 0 || variant > 2) return PZ_ERR_INVALID;
+    PZ_ENTER(ctx);
+    void* d;
+    PZCHK(pz_ws_get(ctx, WS_MISC, (size_t)blocks * 256 * 32, &d));
+    if (variant == 1) return timed_launch(ctx, ms, k_ubench_fqmul_nowait, dim3(blocks), dim3(256), (Fq*)d, (unsigned)iters);
+    if (variant == 2) return timed_launch(ctx, ms, k_ubench_fqmul29, dim3(blocks), dim3(256), (Fq*)d, (unsigned)iters);
+    return timed_launch(ctx, ms, k_ubench_fqmul, dim3(blocks), dim3(256), (Fq*)d, (unsigned)iters);
+}
+extern "C" int pz_fq_mul29(pz_ctx* ctx, const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
+    if (!ctx || !a || !b || !out) return PZ_ERR_INVALID;
+    PZ_ENTER(ctx);
+    void* d;
+    PZCHK(pz_ws_get(ctx, WS_MISC, 96, &d));
+    HIPCHK(ctx, hipMemcpyAsync(d, a, 32, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync((char*)d + 32, b, 32, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_fq_mul29, dim3(1), dim3(1), 0, ctx->stream, (const u32*)d, (const u32*)d + 8, (u32*)d + 16);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out, (char*)d + 64, 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PZ_OK;
 }
 extern "C" int pz_ubench_fqmul(pz_ctx* ctx, uint32_t blocks, uint32_t iters, double* ms) {
     if (!ctx || !ms || !blocks) return PZ_ERR_INVALID;

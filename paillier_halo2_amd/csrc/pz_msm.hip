@@ -810,6 +810,15 @@ extern "C" int pz_g1_sum(pz_ctx* ctx, const uint64_t* jac, size_t n, uint64_t ou
     return PZ_OK;
 }
 
+// device-resident form: the fold of the all-gathered per-rank partial points, no host hop (n is the world size)
+extern "C" int pz_g1_sum_dev(pz_ctx* ctx, const uint64_t* d_jac, size_t n, uint64_t* d_out_jac) {
+    if (!ctx || !d_out_jac || (n && !d_jac)) return PZ_ERR_INVALID;
+    PZ_ENTER(ctx);
+    hipLaunchKernelGGL(k_g1_sum, dim3(1), dim3(64), 0, ctx->stream, (const G1Jac*)d_jac, n, (G1Jac*)d_out_jac);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}
+
 extern "C" int pz_g1_normalize(pz_ctx* ctx, const uint64_t* jac, size_t n, uint64_t* aff) {
     if (!ctx || (n && (!jac || !aff))) return PZ_ERR_INVALID;
     if (!n) return PZ_OK;

@@ -5,8 +5,8 @@ table memory and scalar reads), one exchange either way.
 Each rank holds the whole base table and all scalars (402 MB at 2^22 -- nothing next to 288 GB),
 accumulates only its window range [lo, hi) (pz_msm_g1_dev's win_lo / win_hi) and produces one
 Jacobian point; the exchange is an all-gather of world x 96 bytes over RCCL (xGMI) followed by the
-same fixed-order elliptic-curve fold on every rank -- an all-reduce in effect (EC addition is not
-an ncclRedOp).  Latency-bound: per-link bandwidth is irrelevant at 96 B.
+same fixed-order elliptic-curve fold on every rank, on the device (pz_g1_sum_dev) -- an all-reduce in effect (EC
+addition is not an ncclRedOp).  Latency-bound: per-link bandwidth is irrelevant at 96 B.
 
 The reference has no distributed path at all; this module is new.
 `partial_fn` / `fold_fn` are injection points so the sharding + collective logic can be tested on
@@ -57,18 +57,30 @@ def gather_commitments(torch, dist, share, n_cols: int, rank: int, world: int):
 
 def sharded_msm(torch, dist, rank: int, world: int, n_units: int,
                 partial_fn: Callable[[int, int], "torch.Tensor"],
-                fold_fn: Callable[[np.ndarray], np.ndarray]) -> np.ndarray:
+                fold_fn: Callable[["torch.Tensor"], "torch.Tensor"]):
     """n_units = number of windows (window split) or of points (point split); partial_fn(lo, hi) -> int64 tensor
     (12,) holding this rank's partial point for units [lo, hi) (on the device the process group communicates from);
-    fold_fn(parts (world,12) u64) -> (12,) u64.  Returns the full MSM as a Jacobian point, identical on every rank."""
+    fold_fn(parts: (world, 12) int64 tensor on that same device, rank order == the fixed fold order) -> (12,) tensor.
+    Returns the full MSM as a Jacobian point, identical on every rank, still on the device: nothing on this path
+    touches the host (the all-gather lands in a device tensor, the fold is one small kernel)."""
     lo, hi = window_range(n_units, rank, world)
     part = partial_fn(lo, hi).reshape(12).contiguous()
-    if dist is None:
-        return fold_fn(part.cpu().numpy().astype(np.uint64).reshape(1, 12))
-    parts = [torch.empty_like(part) for _ in range(world)]
-    dist.all_gather(parts, part)
-    stacked = torch.stack(parts).cpu().numpy().astype(np.uint64)  # rank order == fixed fold order
-    return fold_fn(stacked)
+    if dist is None or world == 1:
+        return fold_fn(part.reshape(1, 12))
+    parts = torch.empty(world * 12, dtype=part.dtype, device=part.device)
+    dist.all_gather_into_tensor(parts, part)
+    return fold_fn(parts.view(world, 12))
+
+
+def hip_fold_fn(eng, torch):
+    """the fixed-order EC fold on the device (pz_g1_sum_dev), into a resident 96-byte result"""
+    d_res = torch.zeros(12, dtype=torch.int64, device="cuda")
+
+    def fn(parts):
+        eng.g1_sum_dev(parts.data_ptr(), parts.shape[0], d_res.data_ptr())
+        return d_res
+
+    return fn
 
 
 def hip_partial_fn(eng, torch, bases, d_scalars, n: int):
@@ -132,7 +144,7 @@ def bench_sharded_msm(eng, torch, dist, rank, world, log_n, steps, warmup, barri
         units = bases.n_windows
     del d_b, ks
     log("msm22 setup %.1fs (n=2^%d, c=%d, %d windows, split by %s)" % (time.time() - t0, log_n, bases.window_bits, bases.n_windows, split))
-    fold = eng.g1_sum
+    fold = hip_fold_fn(eng, torch)
     res = None
     for _ in range(warmup):
         res = sharded_msm(torch, dist, rank, world, units, pfn, fold)
@@ -150,7 +162,7 @@ def bench_sharded_msm(eng, torch, dist, rank, world, log_n, steps, warmup, barri
     if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
-    aff = eng.g1_normalize(res)[0]
+    aff = eng.g1_normalize(res.cpu().numpy().astype(np.uint64))[0]
     alg = n * 96.0
     ach = alg * steps / dt / 1e9
     return {

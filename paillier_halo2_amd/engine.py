@@ -148,6 +148,9 @@ class Engine:
         self._chk(self.L.pz_g1_sum(self.ctx, _ptr(j), j.shape[0], _ptr(out)), "pz_g1_sum")
         return out
 
+    def g1_sum_dev(self, d_jac: int, n: int, d_out: int):
+        self._chk(self.L.pz_g1_sum_dev(self.ctx, VP(d_jac), n, VP(d_out)), "pz_g1_sum_dev")
+
     def g1_normalize(self, jac) -> np.ndarray:
         j = _np(jac, 12)
         out = np.zeros((j.shape[0], 8), dtype=np.uint64)
@@ -416,6 +419,17 @@ class Engine:
         ms = C.c_double()
         self._chk(self.L.pz_ubench_fqmul(self.ctx, blocks, iters, C.byref(ms)), "pz_ubench_fqmul")
         return ms.value
+
+    def ubench_fqmul_variant(self, variant: int, blocks: int, iters: int) -> float:
+        ms = C.c_double()
+        self._chk(self.L.pz_ubench_fqmul_variant(self.ctx, variant, blocks, iters, C.byref(ms)), "pz_ubench_fqmul_variant")
+        return ms.value
+
+    def fq_mul29(self, a, b) -> np.ndarray:
+        a, b = _np(a).reshape(4), _np(b).reshape(4)
+        out = np.zeros(4, dtype=np.uint64)
+        self._chk(self.L.pz_fq_mul29(self.ctx, _ptr(a), _ptr(b), _ptr(out)), "pz_fq_mul29")
+        return out
 
 
 T_MSM_ACC, T_NTT, T_TRACE, T_EXPAND, T_MSM_ALL = 0, 1, 2, 3, 4

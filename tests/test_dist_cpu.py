@@ -54,11 +54,12 @@ def _worker(rank, world, port, n, c, seed, q, split="windows"):
         jac = cref.msm_g1(cref.fr_ints_to_mont(sc), cref.affine_ints_to_mont(bases))
         return torch.from_numpy(jac.astype(np.int64))
 
-    def fold(parts):
+    def fold(parts_t):   # (world, 12) tensor, rank order
+        parts = parts_t.numpy().astype(np.uint64)
         acc = parts[0]
         for p in parts[1:]:
             acc = cref.g1_add(acc, p)
-        return acc
+        return torch.from_numpy(acc.astype(np.int64))
 
     def partial_points(lo, hi):
         assert (lo, hi) == point_range(n, rank, world)
@@ -71,7 +72,7 @@ def _worker(rank, world, port, n, c, seed, q, split="windows"):
         res = sharded_msm(torch, dist, rank, world, n, partial_points, fold)
     else:
         res = sharded_msm(torch, dist, rank, world, nwin, partial, fold)
-    got = cref.affine_mont_to_ints(cref.g1_normalize(res))[0]
+    got = cref.affine_mont_to_ints(cref.g1_normalize(res.numpy().astype(np.uint64)))[0]
     q.put((rank, got, P.msm_walk_expected(scalars, s, t)))
     dist.barrier()
     dist.destroy_process_group()

@@ -176,7 +176,7 @@ def test_ntt_golden(eng, cref):
         assert hashlib.sha256(b"".join(x.to_bytes(32, "little") for x in got)).hexdigest() == case["out_sha256"]
 
 
-@pytest.mark.parametrize("log_n", [9, 10, 11, 13, 14, 17, 18, 19, 20])
+@pytest.mark.parametrize("log_n", [9, 10, 11, 13, 14, 15, 16, 17, 18, 19, 20])
 def test_ntt_vs_oracle(eng, cref, log_n):
     rng = np.random.default_rng(100 + log_n)
     n = 1 << log_n
@@ -425,7 +425,7 @@ def test_witness_expand_on_real_trace(eng, cref):
         assert cref.fr_mont_to_ints(adv[k]) == want_adv, k
 
 
-@pytest.mark.parametrize("log_n,log_e", [(3, 2), (9, 2), (10, 2), (13, 1), (17, 2), (19, 2), (20, 1)])
+@pytest.mark.parametrize("log_n,log_e", [(3, 2), (9, 2), (10, 2), (13, 1), (15, 2), (16, 2), (17, 2), (19, 2), (20, 1)])
 def test_ntt_extend_vs_oracle(eng, cref, log_n, log_e):
     """coeff_to_extended in one call == zero-extend, distribute_powers(g), best_fft(omega_ext), with the ifft
     divisor folded in as `scale`"""
@@ -640,7 +640,7 @@ def test_one_context_from_many_threads(eng, cref):
     assert errs == []
 
 
-@pytest.mark.parametrize("log_n,log_e", [(9, 2), (10, 2), (11, 1), (13, 2), (16, 2), (17, 2), (18, 1), (19, 2)])
+@pytest.mark.parametrize("log_n,log_e", [(9, 2), (10, 2), (11, 1), (13, 2), (15, 2), (16, 2), (17, 2), (18, 1), (19, 2)])
 def test_ntt_coeff_extend_fused_vs_separate(eng, cref, log_n, log_e):
     """lagrange_to_coeff + coeff_to_extended in one call (fused passes) == the two entry points back to back, bit for
     bit, strided columns included; at small sizes also against the oracle"""
@@ -724,3 +724,75 @@ def test_msm_randomised_families(eng, cref):
             want = P.g1_mul(P.G1_GEN, e) if e else (0, 0)
             assert tuple(got[j]) == tuple(want), (it, kind, logn, c, j)
         bases.free()
+
+
+def test_external_kats(eng, cref):
+    """the HIP path on the published vectors of tests/golden/external_kats.json (EIP-196 alt_bn128 ecAdd / ecMul,
+    halo2curves Fr constants): sources outside this repository's own derivations"""
+    k = load_golden("external_kats.json")
+    G = (1, 2)
+    for v in k["ecmul"]:
+        pt, kk, want = (H(v["x"]), H(v["y"])), H(v["k"]) % P.FR_R, (H(v["x3"]), H(v["y3"]))
+        if pt == G:   # [k]G: the fixed-base kernel
+            assert aff_ints(cref, eng.g1_fixed_base_mul(cref.fr_ints_to_mont([kk])))[0] == want, v["source"]
+        # any base: a one-point MSM (window table of a single base), several window widths
+        for c in (0, 8, 16):
+            tb = eng.load_bases(cref.affine_ints_to_mont([pt]), window_bits=c)
+            assert aff_ints(cref, eng.g1_normalize(eng.msm(tb, cref.fr_ints_to_mont([kk]))))[0] == want, (v["source"], c)
+            tb.free()
+    for v in k["ecadd"]:
+        a, b, want = (H(v["x1"]), H(v["y1"])), (H(v["x2"]), H(v["y2"])), (H(v["x3"]), H(v["y3"]))
+        tb = eng.load_bases(cref.affine_ints_to_mont([a, b]))
+        assert aff_ints(cref, eng.g1_normalize(eng.msm(tb, cref.fr_ints_to_mont([1, 1]))))[0] == want, v["source"]
+        tb.free()
+    c = k["halo2curves_fr"]
+    lim = lambda l: sum(int(x, 16) << (64 * i) for i, x in enumerate(l))
+    root, root_inv, two_inv = lim(c["ROOT_OF_UNITY"]), lim(c["ROOT_OF_UNITY_INV"]), lim(c["TWO_INV"])
+    rng = random.Random(77)
+    for log_n in (1, 10, 14):
+        n = 1 << log_n
+        w = pow(root, 1 << (c["S"] - log_n), P.FR_R)
+        w_inv = pow(root_inv, 1 << (c["S"] - log_n), P.FR_R)
+        a = [rng.randrange(P.FR_R) for _ in range(n)]
+        e1 = cref.fr_ints_to_mont([0, 1] + [0] * (n - 2))
+        dom = cref.fr_mont_to_ints(eng.ntt(e1, cref.fr_ints_to_mont([w])[0], log_n))
+        assert dom[1] == w and dom[n // 2] == P.FR_R - 1 and dom[n - 1] == w_inv
+        # ifft = best_fft(omega^-1) then scaling by TWO_INV^log_n (halo2's ifft_divisor)
+        import torch
+
+        d = torch.from_numpy(cref.fr_ints_to_mont(a).astype(np.int64)).cuda()
+        eng.ntt_dev(d.data_ptr(), 1, 4 * n, cref.fr_ints_to_mont([w])[0], log_n)
+        eng.ntt_dev(d.data_ptr(), 1, 4 * n, cref.fr_ints_to_mont([w_inv])[0], log_n, None,
+                    cref.fr_ints_to_mont([pow(two_inv, log_n, P.FR_R)])[0])
+        eng.sync()
+        assert cref.fr_mont_to_ints(d.cpu().numpy().astype(np.uint64)) == a
+    # DELTA and ZETA as coset shifts: distribute_powers fused into the transform
+    delta, zeta = lim(c["DELTA"]), lim(c["ZETA"])
+    log_n, n = 8, 256
+    w = pow(root, 1 << (c["S"] - log_n), P.FR_R)
+    a = [rng.randrange(P.FR_R) for _ in range(n)]
+    import torch
+
+    for shift in (delta, zeta):
+        d = torch.from_numpy(cref.fr_ints_to_mont(a).astype(np.int64)).cuda()
+        eng.ntt_dev(d.data_ptr(), 1, 4 * n, cref.fr_ints_to_mont([w])[0], log_n, cref.fr_ints_to_mont([shift])[0], None)
+        eng.sync()
+        assert cref.fr_mont_to_ints(d.cpu().numpy().astype(np.uint64)) == P.ntt(P.coset_scale(a, shift), w)
+
+
+def test_fp_mul_variants_probe(eng, cref):
+    """the 9 x 29-bit no-carry product (measurement probe) computes a*b*2^-261 mod p, and the
+    issue-rate microbenchmark reports all three variants"""
+    rng = random.Random(29)
+    inv = pow(1 << 261, -1, P.FQ_P)
+    for _ in range(20):
+        a, b = rng.randrange(2 * P.FQ_P), rng.randrange(2 * P.FQ_P)
+        got = cref.limbs_to_int(eng.fq_mul29(cref.int_to_limbs(a, 4), cref.int_to_limbs(b, 4)))
+        assert got < 2 * P.FQ_P and got % P.FQ_P == a * b * inv % P.FQ_P
+    blocks, iters = 256 * 16, 256
+    rates = {}
+    for variant, name in ((0, "fp_mul"), (1, "fp_mul_nowait"), (2, "fq29_mul")):
+        ms = min(eng.ubench_fqmul_variant(variant, blocks, iters) for _ in range(3))
+        rates[name] = blocks * 256 * iters * 2 / (ms * 1e-3) / 1e9
+    print("Fq products per second (G/s):", {k: round(v, 1) for k, v in rates.items()})
+    assert all(v > 10 for v in rates.values())

@@ -259,3 +259,57 @@ def test_c_oracle_under_address_and_ub_sanitizers():
     out = subprocess.run([os.path.join(root, "oracle", "_asan", "selftest")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "ALL OK" in out.stdout
+
+
+# ------------------------------------------------------------------------------------------------------------
+# known-answer vectors from OUTSIDE this repository's own derivations (tests/golden/external_kats.json names the
+# source of each): EIP-196 alt_bn128 ecAdd / ecMul precompile vectors and halo2curves' Fr constants.  Both
+# restatements must reproduce them; tests/test_gpu_kernels.py::test_external_kats runs the HIP path on the same.
+# ------------------------------------------------------------------------------------------------------------
+def _kat_limbs(l):
+    return sum(int(v, 16) << (64 * i) for i, v in enumerate(l))
+
+
+def test_external_kats_ec(cref):
+    from tests.util import H, load_golden
+
+    k = load_golden("external_kats.json")
+    for v in k["ecadd"]:
+        a, b, c = (H(v["x1"]), H(v["y1"])), (H(v["x2"]), H(v["y2"])), (H(v["x3"]), H(v["y3"]))
+        assert P.g1_is_on_curve(a) and P.g1_is_on_curve(b) and P.g1_is_on_curve(c), v["source"]
+        assert P.g1_add_aff(a, b) == c, v["source"]
+        am, bm = cref.affine_ints_to_mont([a])[0], cref.affine_ints_to_mont([b])[0]
+        one = cref.int_to_limbs(1, 4)
+        ja, jb = cref.g1_mul(am, 1), cref.g1_mul(bm, 1)
+        assert cref.affine_mont_to_ints(cref.g1_normalize(cref.g1_add(ja, jb)))[0] == c, v["source"]
+    for v in k["ecmul"]:
+        pt, kk, c = (H(v["x"]), H(v["y"])), H(v["k"]), (H(v["x3"]), H(v["y3"]))
+        assert P.g1_is_on_curve(pt) and P.g1_is_on_curve(c), v["source"]
+        assert P.g1_mul(pt, kk) == c, v["source"]          # g1_mul reduces k mod r (the group order)
+        got = cref.g1_normalize(cref.g1_mul(cref.affine_ints_to_mont([pt])[0], kk % P.FR_R))
+        assert cref.affine_mont_to_ints(got)[0] == c, v["source"]
+
+
+def test_external_kats_halo2curves_fr(cref):
+    from tests.util import load_golden
+
+    c = load_golden("external_kats.json")["halo2curves_fr"]
+    root, root_inv, two_inv, delta, zeta = (_kat_limbs(c[n]) for n in ("ROOT_OF_UNITY", "ROOT_OF_UNITY_INV", "TWO_INV", "DELTA", "ZETA"))
+    g = int(c["GENERATOR"])
+    assert c["S"] == P.FR_S and g == P.FR_GENERATOR
+    assert root == P.FR_ROOT_OF_UNITY == pow(g, (P.FR_R - 1) >> c["S"], P.FR_R)
+    assert root * root_inv % P.FR_R == 1 and 2 * two_inv % P.FR_R == 1
+    assert delta == pow(g, 1 << c["S"], P.FR_R) and pow(delta, (P.FR_R - 1) >> c["S"], P.FR_R) == 1
+    assert zeta != 1 and pow(zeta, 3, P.FR_R) == 1 and zeta == pow(g, 2 * (P.FR_R - 1) // 3, P.FR_R)
+    # the C restatement's Montgomery arithmetic on the same constants
+    m = cref.fr_ints_to_mont([root, root_inv, two_inv, delta, zeta])
+    mul = lambda x, y: cref.fr_scale(x.reshape(1, 4), y)[0]
+    one = cref.fr_ints_to_mont([1])[0]
+    assert np.array_equal(mul(m[0], m[1]), one)
+    assert np.array_equal(mul(mul(m[4], m[4]), m[4]), one)
+    # best_fft with omega = ROOT_OF_UNITY^(2^(S-k)): the transform of e_1 is the domain itself
+    k_ = 6
+    e1 = cref.fr_ints_to_mont([0, 1] + [0] * ((1 << k_) - 2))
+    w = pow(root, 1 << (c["S"] - k_), P.FR_R)
+    dom = cref.fr_mont_to_ints(cref.ntt_fr(e1, cref.fr_ints_to_mont([w])[0], k_))
+    assert dom == [pow(w, i, P.FR_R) for i in range(1 << k_)] and dom[1 << (k_ - 1)] == P.FR_R - 1

@@ -28,3 +28,45 @@ def steps_digest_ints(steps, L):
         for v in st:
             h.update(int(v).to_bytes(8 * L, "little"))
     return h.hexdigest()
+
+
+# ---- bulk helpers for the at-size GPU tests (2^19 .. 2^22 scalars: Python-int loops would take minutes) ----
+def ints_to_u64x4(xs):
+    """list of ints below 2^256 -> (n, 4) uint64 little-endian limbs"""
+    buf = b"".join(int(x).to_bytes(32, "little") for x in xs)
+    return np.frombuffer(buf, dtype="<u8").reshape(-1, 4).copy()
+
+
+def canon_rand_scalars(n, seed):
+    """(n, 4) uint64: uniformly random canonical integers below 2^252 (< r)"""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
+    return a
+
+
+def witness_like_canon(n, seed):
+    """SURVEY.md section 8d mix (ii): 60 % below 2^16, 30 % below 2^64, 10 % below 2^135 -- canonical (n, 4) uint64"""
+    rng = np.random.default_rng(seed)
+    a = canon_rand_scalars(n, seed + 1)
+    u = rng.random(n)
+    a[:, 3] = 0
+    big = u >= 0.9
+    a[:, 2] = np.where(big, a[:, 2] & np.uint64(0x7F), np.uint64(0))
+    a[:, 1] = np.where(big, a[:, 1], np.uint64(0))
+    a[:, 0] = np.where(u < 0.6, a[:, 0] & np.uint64(0xFFFF), a[:, 0])
+    return a
+
+
+def walk_dlog_sum(sc, s, t, r=0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001):
+    """sum_i c_i * (s + i t) mod r for canonical scalars sc (n, 4) uint64, n <= 2^22: exact, by 16-bit pieces
+    (every partial sum stays below 2^64)"""
+    n = sc.shape[0]
+    assert n <= 1 << 22
+    q = np.ascontiguousarray(sc).view(np.uint16).reshape(n, 16).astype(np.uint64)
+    idx = np.arange(n, dtype=np.uint64)[:, None]
+    s0 = q.sum(axis=0)            # < 2^38
+    s1 = (q * idx).sum(axis=0)    # < 2^60
+    c_sum = sum(int(v) << (16 * j) for j, v in enumerate(s0.tolist()))
+    ic_sum = sum(int(v) << (16 * j) for j, v in enumerate(s1.tolist()))
+    return (s * c_sum + t * ic_sum) % r
