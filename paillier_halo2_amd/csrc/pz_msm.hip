@@ -18,6 +18,7 @@
 // Roofline: bounded by 32-bit integer multiply issue (v_mad_u64_u32), NOT by HBM: algorithmic
 // traffic is 96 B per (scalar, base) pair; bench.py reports both fractions.
 #include "ec.cuh"
+#include "ec29.cuh"
 #include <stdlib.h>
 
 #include "pz_internal.h"
@@ -90,18 +91,25 @@ __device__ __forceinline__ int next_digit(const u32 s[8], unsigned w, unsigned c
 // ------------------------------------------------------------------------------------------------
 // table build: T[w][i] = 2^(c*w) * P_i, affine
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_build_table(const G1Affine* __restrict__ bases, G1Affine* __restrict__ table,
+// Rows are 64-byte affine points like the ABI's, but their coordinates are kept in the 2^261 Montgomery domain of
+// fp29.cuh (canonical 256-bit integers): the accumulation kernel unpacks them into 29-bit limbs, nothing else reads them.
+__global__ __launch_bounds__(128) void k_build_table(const G1Aff64* __restrict__ bases, G1Aff64* __restrict__ table,
                                                      size_t n, unsigned c, unsigned nwin) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    G1Affine p = aff_load(bases + i);
-    aff_store(table + i, p);
-    G1X x = x_from_affine(p);
+    G1A29 p = a29_load64(bases + i);          // the ABI's 256-domain
+    if (!a29_is_inf(p)) {
+        p.x = f29_to_261(p.x);
+        p.y = f29_to_261(p.y);
+        p = a29_canon(p);
+    }
+    a29_store64(table + i, p);
+    G1X29 x = x29_from_affine(p);
     for (unsigned w = 1; w < nwin; ++w) {
-        for (unsigned k = 0; k < c; ++k) x = x_dbl(x);
-        G1Affine a = x_to_affine(x);
-        aff_store(table + (size_t)w * n + i, a);
-        x = x_from_affine(a);  // back to Z = 1: keeps the next conversion's operands small
+        for (unsigned k = 0; k < c; ++k) x = x29_dbl(x);
+        const G1A29 a = a29_canon(x29_to_affine(x));
+        a29_store64(table + (size_t)w * n + i, a);
+        x = x29_from_affine(a);  // back to ZZ = 1
     }
 }
 
@@ -339,11 +347,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restri
 // ------------------------------------------------------------------------------------------------
 // bucket accumulation: one lane per (bucket, chunk) work item
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_msm_accumulate(const G1Affine* __restrict__ table, MsmP p,
+__global__ __launch_bounds__(256) void k_msm_accumulate(const G1Aff64* __restrict__ table, MsmP p,
                                                         const u32* __restrict__ offs, const u32* __restrict__ items,
                                                         const u32* __restrict__ item_order,
                                                         const u32* __restrict__ item_bucket,
-                                                        const u32* __restrict__ entries, G1X* __restrict__ partials) {
+                                                        const u32* __restrict__ entries, G1X29Raw* __restrict__ partials) {
     // grid.x = column, grid.y = block of ranks: workgroups are dispatched x-fastest, so the largest items of EVERY
     // column start first and the chip always holds work of one size class (with the column in grid.y, each column's
     // few long items pinned its ~128 resident workgroups and the columns went through 8 at a time)
@@ -361,14 +369,14 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const G1Affine* __restri
     const u32 start = o[b] + j * q + (j < rem ? j : rem);
     const u32 end = start + q + (j < rem ? 1u : 0u);
     const u32* e = entries + col * p.cap;
-    G1X acc = x_inf();
+    G1X29 acc = x29_inf();
     for (u32 k = start; k < end; ++k) {
         u32 ent = e[k];
-        G1Affine q = aff_load(table + (ent & 0x7fffffffu));
-        if (ent & 0x80000000u) q.y = fp_neg(q.y);
-        x_add_affine(acc, q);
+        G1A29 q = a29_load64(table + (ent & 0x7fffffffu));
+        if ((ent & 0x80000000u) && !a29_is_inf(q)) q.y = a29_neg_y(q.y);
+        x29_add_affine(acc, q);
     }
-    x_store(partials + col * p.max_items + item, acc);
+    x29_store_raw(partials + col * p.max_items + item, acc);
 }
 
 // A bucket with more than MsmP::chunk entries owns several consecutive partials; its sum is left in the
@@ -379,50 +387,50 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const G1Affine* __restri
 // then an LDS tree.
 __global__ __launch_bounds__(256) void k_msm_bucket_sum(MsmP p, const u32* __restrict__ items,
                                                         const u32* __restrict__ fold_order,
-                                                        const u32* __restrict__ fold_cnt, G1X* __restrict__ partials) {
+                                                        const u32* __restrict__ fold_cnt, G1X29Raw* __restrict__ partials) {
     const size_t col = blockIdx.x;  // as in k_msm_accumulate: rank blocks of all columns together
     const unsigned r = blockIdx.y * blockDim.x + threadIdx.x;
     if (r >= fold_cnt[col]) return;
     const unsigned b = fold_order[col * p.B + r];
     const u32* it = items + col * (p.B + 1);
     const u32 first = it[b], m = it[b + 1] - first;
-    G1X* pc = partials + col * p.max_items + first;
-    G1X acc = x_load(pc);
+    G1X29Raw* pc = partials + col * p.max_items + first;
+    G1X29 acc = x29_load_raw(pc);
     for (u32 t = 1; t < m; ++t) {
-        G1X o = x_load(pc + t);
-        x_add(acc, o);
+        G1X29 o = x29_load_raw(pc + t);
+        x29_add(acc, o);
     }
-    x_store(pc, acc);
+    x29_store_raw(pc, acc);
 }
 
 __global__ __launch_bounds__(256) void k_msm_heavy_sum(MsmP p, const u32* __restrict__ items,
                                                        const u32* __restrict__ heavy, const u32* __restrict__ heavy_cnt,
-                                                       G1X* __restrict__ partials) {
-    __shared__ G1X s_pt[256];
+                                                       G1X29Raw* __restrict__ partials) {
+    __shared__ G1X29Raw s_pt[256];
     const size_t col = blockIdx.y;
     const u32 nh = heavy_cnt[col];
     const u32* it = items + col * (p.B + 1);
     for (u32 k = blockIdx.x; k < nh; k += gridDim.x) {
         const u32 b = heavy[col * p.B + k];
         const u32 first = it[b], m = it[b + 1] - first;
-        G1X* pc = partials + col * p.max_items + first;
-        G1X acc = x_inf();
+        G1X29Raw* pc = partials + col * p.max_items + first;
+        G1X29 acc = x29_inf();
         for (u32 t = threadIdx.x; t < m; t += blockDim.x) {
-            G1X o = x_load(pc + t);
-            x_add(acc, o);
+            G1X29 o = x29_load_raw(pc + t);
+            x29_add(acc, o);
         }
-        x_store(&s_pt[threadIdx.x], acc);
+        x29_store_raw(&s_pt[threadIdx.x], acc);
         __syncthreads();
         for (unsigned off = 128; off > 0; off >>= 1) {
             if (threadIdx.x < off) {
-                G1X a = x_load(&s_pt[threadIdx.x]);
-                G1X o = x_load(&s_pt[threadIdx.x + off]);
-                x_add(a, o);
-                x_store(&s_pt[threadIdx.x], a);
+                G1X29 a = x29_load_raw(&s_pt[threadIdx.x]);
+                G1X29 o = x29_load_raw(&s_pt[threadIdx.x + off]);
+                x29_add(a, o);
+                x29_store_raw(&s_pt[threadIdx.x], a);
             }
             __syncthreads();
         }
-        if (threadIdx.x == 0) x_store(pc, x_load(&s_pt[0]));
+        if (threadIdx.x == 0) x29_store_raw(pc, x29_load_raw(&s_pt[0]));
         __syncthreads();
     }
 }
@@ -431,31 +439,31 @@ __global__ __launch_bounds__(256) void k_msm_heavy_sum(MsmP p, const u32* __rest
 // sum_b (b+1) * B_b  as a tree of nodes {V = weighted sum with local weights 1.., S = plain sum}
 // ------------------------------------------------------------------------------------------------
 struct alignas(16) MsmNode {
-    G1X V, S;
+    G1X29Raw V, S;
 };
 
 // level 1: node t covers buckets [t*m, (t+1)*m)
 __global__ __launch_bounds__(128) void k_msm_reduce_l1(MsmP p, unsigned m, const u32* __restrict__ items,
-                                                       const G1X* __restrict__ partials, MsmNode* __restrict__ nodes) {
+                                                       const G1X29Raw* __restrict__ partials, MsmNode* __restrict__ nodes) {
     const size_t col = blockIdx.y;
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned nn = p.B / m;
     if (t >= nn) return;
     const u32* it = items + col * (p.B + 1);
-    const G1X* pc = partials + col * p.max_items;
-    G1X run = x_inf(), acc = x_inf();
+    const G1X29Raw* pc = partials + col * p.max_items;
+    G1X29 run = x29_inf(), acc = x29_inf();
     for (unsigned j = m; j-- > 0;) {
         unsigned b = t * m + j;
         u32 a = it[b], z = it[b + 1];
         if (z > a) {  // merged: the bucket's sum sits in its first partial
-            G1X v = x_load(pc + a);
-            x_add(run, v);
+            G1X29 v = x29_load_raw(pc + a);
+            x29_add(run, v);
         }
-        x_add(acc, run);
+        x29_add(acc, run);
     }
     MsmNode* o = nodes + col * nn + t;
-    x_store(&o->V, acc);
-    x_store(&o->S, run);
+    x29_store_raw(&o->V, acc);
+    x29_store_raw(&o->S, run);
 }
 
 // upper levels: m children of span w buckets each -> V = sum V_k + w * sum k*S_k, S = sum S_k
@@ -466,72 +474,73 @@ __global__ __launch_bounds__(128) void k_msm_combine(unsigned n_in, unsigned m, 
     const unsigned n_out = n_in / m;
     if (t >= n_out) return;
     const MsmNode* c = in + col * n_in + (size_t)t * m;
-    G1X run = x_inf(), acc = x_inf();
+    G1X29 run = x29_inf(), acc = x29_inf();
     for (unsigned k = m; k-- > 1;) {
-        G1X s = x_load(&c[k].S);
-        x_add(run, s);
-        x_add(acc, run);
+        G1X29 s = x29_load_raw(&c[k].S);
+        x29_add(run, s);
+        x29_add(acc, run);
     }
-    for (unsigned k = 0; k < log_w; ++k) acc = x_dbl(acc);
-    G1X s0 = x_load(&c[0].S);
-    x_add(run, s0);
+    for (unsigned k = 0; k < log_w; ++k) acc = x29_dbl(acc);
+    G1X29 s0 = x29_load_raw(&c[0].S);
+    x29_add(run, s0);
     for (unsigned k = 0; k < m; ++k) {
-        G1X v = x_load(&c[k].V);
-        x_add(acc, v);
+        G1X29 v = x29_load_raw(&c[k].V);
+        x29_add(acc, v);
     }
     MsmNode* o = out + col * n_out + t;
-    x_store(&o->V, acc);
-    x_store(&o->S, run);
+    x29_store_raw(&o->V, acc);
+    x29_store_raw(&o->S, run);
 }
 
 __global__ void k_msm_emit(const MsmNode* __restrict__ nodes, size_t n_cols, G1Jac* __restrict__ out) {
     size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= n_cols) return;
-    G1X v = x_load(&nodes[col].V);
-    jac_store(out + col, x_to_jac(v));
+    x29_store_jac(out + col, x29_load_raw(&nodes[col].V));
 }
 
 // small utilities -------------------------------------------------------------------------------
 __global__ void k_g1_sum(const G1Jac* __restrict__ in, size_t n, G1Jac* __restrict__ out) {
     if (blockIdx.x || threadIdx.x) return;
-    G1X acc = x_inf();
+    G1X29 acc = x29_inf();
     for (size_t i = 0; i < n; ++i) {
-        G1Jac j;
-        j.x = fp_load<FqTag>(&in[i].x);
-        j.y = fp_load<FqTag>(&in[i].y);
-        j.z = fp_load<FqTag>(&in[i].z);
-        G1X x = jac_to_x(j);
-        x_add(acc, x);
+        G1X29 x = x29_load_jac(in + i);
+        x29_add(acc, x);
     }
-    jac_store(out, x_to_jac(acc));
+    x29_store_jac(out, acc);
 }
 
-__global__ void k_g1_normalize(const G1Jac* __restrict__ in, size_t n, G1Affine* __restrict__ out) {
+__global__ void k_g1_normalize(const G1Jac* __restrict__ in, size_t n, G1Aff64* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    G1Jac j;
-    j.x = fp_load<FqTag>(&in[i].x);
-    j.y = fp_load<FqTag>(&in[i].y);
-    j.z = fp_load<FqTag>(&in[i].z);
-    aff_store(out + i, x_to_affine(jac_to_x(j)));
+    G1A29 a = x29_to_affine(x29_load_jac(in + i));
+    if (!a29_is_inf(a)) {   // back to the ABI's 256-domain
+        a.x = f29_to_256(a.x);
+        a.y = f29_to_256(a.y);
+    }
+    a29_store64(out + i, a);
 }
 
 // out[i] = [k_i] G, G = (1, 2); plain double-and-add over the canonical scalar bits
 __global__ __launch_bounds__(128) void k_fixed_base_mul(const Fr* __restrict__ scalars, size_t n,
-                                                        G1Affine* __restrict__ out) {
+                                                        G1Aff64* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fr k = fp_from_mont(fp_load<FrTag>(scalars + i));
-    G1Affine g;
-    g.x = fp_one<FqTag>();
-    g.y = fp_dbl(g.x);
-    G1X acc = x_inf();
+    G1A29 g;
+    g.x = f29_one<FqTag>();
+    g.y = f29_canon<1>(f29_dbl(g.x));
+    G1X29 acc = x29_inf();
     for (int bit = 253; bit >= 0; --bit) {
-        acc = x_dbl(acc);
+        acc = x29_dbl(acc);
         u32 w = sel8(k.v, (unsigned)bit >> 5);
-        if ((w >> (bit & 31)) & 1) x_add_affine(acc, g);
+        if ((w >> (bit & 31)) & 1) x29_add_affine(acc, g);
     }
-    aff_store(out + i, x_to_affine(acc));
+    G1A29 a = x29_to_affine(acc);
+    if (!a29_is_inf(a)) {
+        a.x = f29_to_256(a.x);
+        a.y = f29_to_256(a.y);
+    }
+    a29_store64(out + i, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -583,7 +592,7 @@ extern "C" int pz_bases_load_g1(pz_ctx* ctx, const uint64_t* bases_affine, size_
         d_src = stage;
     }
     hipLaunchKernelGGL(k_build_table, dim3(pz_div_up(n_points, 128)), dim3(128), 0, ctx->stream,
-                       (const G1Affine*)d_src, (G1Affine*)b->d_table, n_points, c, nwin);
+                       (const G1Aff64*)d_src, (G1Aff64*)b->d_table, n_points, c, nwin);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { (void)hipFree(b->d_table); delete b; return pz_hip_fail(ctx, e, "k_build_table"); }
@@ -662,7 +671,7 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     PZCHK(pz_ws_get(ctx, WS_OFFS, nc * (p.B + 1) * 4, &offs));
     PZCHK(pz_ws_get(ctx, WS_ITEMS, nc * (p.B + 1) * 4, &items));
     PZCHK(pz_ws_get(ctx, WS_ENTRIES, nc * p.cap * 4 + 16, &entries));
-    PZCHK(pz_ws_get(ctx, WS_PARTIALS, nc * p.max_items * sizeof(G1X), &partials));
+    PZCHK(pz_ws_get(ctx, WS_PARTIALS, nc * p.max_items * sizeof(G1X29Raw), &partials));
     // radix of the reduction tree
     const unsigned m1 = p.B >= 16 ? 16 : p.B;
     unsigned n_nodes = p.B / m1;
@@ -681,20 +690,20 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     {
         pz_timer tacc(ctx, PZ_T_MSM_ACC);
         hipLaunchKernelGGL(k_msm_accumulate, dim3((unsigned)nc, pz_div_up(p.max_items, 256)), dim3(256), 0, st,
-                           (const G1Affine*)bases->d_table, p, (const u32*)offs, (const u32*)items,
-                           (const u32*)item_order, (const u32*)item_bucket, (const u32*)entries, (G1X*)partials);
+                           (const G1Aff64*)bases->d_table, p, (const u32*)offs, (const u32*)items,
+                           (const u32*)item_order, (const u32*)item_bucket, (const u32*)entries, (G1X29Raw*)partials);
     }
     hipLaunchKernelGGL(k_msm_bucket_sum, dim3((unsigned)nc, pz_div_up(p.B, 256)), dim3(256), 0, st, p, (const u32*)items,
-                       (const u32*)fold, (const u32*)fold_cnt, (G1X*)partials);
+                       (const u32*)fold, (const u32*)fold_cnt, (G1X29Raw*)partials);
     // heavy buckets are few per column in a column batch, but a single large MSM makes every bucket heavy:
     // size grid.x so the launch has ~8k workgroups either way (workgroups beyond the list exit at once)
     unsigned hx = (unsigned)(8192 / nc);
     if (hx < 4) hx = 4;   // column batches have a handful of heavy buckets per column at most; empty blocks still cost ~50 ns
     if (hx > p.B) hx = p.B;
     hipLaunchKernelGGL(k_msm_heavy_sum, dim3(hx, (unsigned)nc), dim3(256), 0, st, p, (const u32*)items, (const u32*)heavy,
-                       (const u32*)heavy_cnt, (G1X*)partials);
+                       (const u32*)heavy_cnt, (G1X29Raw*)partials);
     hipLaunchKernelGGL(k_msm_reduce_l1, dim3(pz_div_up(n_nodes, 128), (unsigned)nc), dim3(128), 0, st, p, m1,
-                       (const u32*)items, (const G1X*)partials, (MsmNode*)na);
+                       (const u32*)items, (const G1X29Raw*)partials, (MsmNode*)na);
     MsmNode* cur = (MsmNode*)na;
     MsmNode* nxt = (MsmNode*)nb;
     unsigned log_w = 0;
@@ -736,7 +745,7 @@ extern "C" int pz_msm_g1_dev(pz_ctx* ctx, const pz_bases* bases, const uint64_t*
     // column groups: bound the sorted-entry workspace (4 B per digit) to ~1 GiB, grid.y to 65535
     const size_t digits = n * (size_t)(win_hi - win_lo);
     const unsigned chunk = msm_chunk_for(n_cols, digits);
-    const size_t per_col = digits * 4 + (digits / chunk) * (sizeof(G1X) + 8) +
+    const size_t per_col = digits * 4 + (digits / chunk) * (sizeof(G1X29Raw) + 8) +
                            (size_t)(1u << (bases->c - 1)) * (180 + 4 * (size_t)pz_div_up(n, SORT_SLICE));
     // group size: sized for 288 GB of HBM -- by default up to 48 GiB of sort / partial-sum workspace per launch
     // sequence (PZ_MSM_WS_GIB overrides), so the latency-bound tree levels are paid once per ~2000 columns
@@ -828,7 +837,7 @@ extern "C" int pz_g1_normalize(pz_ctx* ctx, const uint64_t* jac, size_t n, uint6
     PZCHK(pz_ws_get(ctx, WS_IO_C, n * 64, &dout));
     HIPCHK(ctx, hipMemcpyAsync(di, jac, n * 96, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_g1_normalize, dim3(pz_div_up(n, 64)), dim3(64), 0, ctx->stream, (const G1Jac*)di, n,
-                       (G1Affine*)dout);
+                       (G1Aff64*)dout);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(aff, dout, n * 64, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -878,7 +887,7 @@ extern "C" int pz_g1_fixed_base_mul_dev(pz_ctx* ctx, const uint64_t* d_scalars, 
     if (!n) return PZ_OK;
     PZ_ENTER(ctx);
     hipLaunchKernelGGL(k_fixed_base_mul, dim3(pz_div_up(n, 128)), dim3(128), 0, ctx->stream, (const Fr*)d_scalars, n,
-                       (G1Affine*)d_out_affine);
+                       (G1Aff64*)d_out_affine);
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
 }
