@@ -3,6 +3,7 @@
 #define PZ_FP_MUL_VARIANTS 1
 #include "fp.cuh"
 #include "fp29_probe.cuh"
+#include "fp29.cuh"
 #include "pz_internal.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -88,6 +89,23 @@ __global__ void k_ubench_fqmul29(Fq* out, unsigned iters) {
     uint4* q = reinterpret_cast<uint4*>(out + (size_t)blockIdx.x * blockDim.x + threadIdx.x);
     q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
     q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+// variants 3 / 4: the production 29-bit product / square of fp29.cuh (asm columns)
+template <int SQR> __global__ void k_ubench_f29(Fq* out, unsigned iters) {
+    Fq x0 = fp_one<FqTag>(), y0 = fp_one<FqTag>();
+    x0.v[0] ^= threadIdx.x;
+    y0.v[1] ^= blockIdx.x;
+    F29<FqTag> x = f29_from_fp(x0), y = f29_from_fp(y0);
+    for (unsigned i = 0; i < iters; ++i) {
+        if (SQR) {
+            x = f29_sqr(y);
+            y = f29_sqr(x);
+        } else {
+            x = f29_mul(x, y);
+            y = f29_mul(y, x);
+        }
+    }
+    f29_store<1>(out + (size_t)blockIdx.x * blockDim.x + threadIdx.x, f29_mul(x, y));
 }
 // one product of the probe, for its correctness check: out = a * b * 2^-261 mod p as a 256-bit integer below 2p
 __global__ void k_fq_mul29(const u32* a, const u32* b, u32* out) {
@@ -329,11 +347,13 @@ extern "C" int pz_ubench_mad(pz_ctx* ctx, uint32_t blocks, uint32_t iters, doubl
     return timed_launch(ctx, ms, k_ubench_mad, dim3(blocks), dim3(256), (u64*)d, (unsigned)iters);
 }
 extern "C" int pz_ubench_fqmul_variant(pz_ctx* ctx, int variant, uint32_t blocks, uint32_t iters, double* ms) {
-    if (!ctx || !ms || !blocks || variant < 0 || variant > 2) return PZ_ERR_INVALID;
+    if (!ctx || !ms || !blocks || variant < 0 || variant > 4) return PZ_ERR_INVALID;
     PZ_ENTER(ctx);
     void* d;
     PZCHK(pz_ws_get(ctx, WS_MISC, (size_t)blocks * 256 * 32, &d));
     if (variant == 1) return timed_launch(ctx, ms, k_ubench_fqmul_nowait, dim3(blocks), dim3(256), (Fq*)d, (unsigned)iters);
+    if (variant == 3) return timed_launch(ctx, ms, k_ubench_f29<0>, dim3(blocks), dim3(256), (Fq*)d, (unsigned)iters);
+    if (variant == 4) return timed_launch(ctx, ms, k_ubench_f29<1>, dim3(blocks), dim3(256), (Fq*)d, (unsigned)iters);
     if (variant == 2) return timed_launch(ctx, ms, k_ubench_fqmul29, dim3(blocks), dim3(256), (Fq*)d, (unsigned)iters);
     return timed_launch(ctx, ms, k_ubench_fqmul, dim3(blocks), dim3(256), (Fq*)d, (unsigned)iters);
 }

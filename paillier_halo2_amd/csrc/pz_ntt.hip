@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "fp.cuh"
+#include "fp29.cuh"
 #include "pz_internal.h"
 
 struct NttPass {
@@ -31,15 +32,55 @@ struct NttPass {
 
 __device__ __forceinline__ unsigned bitrev32(unsigned x, unsigned bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 
+extern __shared__ __attribute__((aligned(16))) unsigned char pz_smem[];
+
+
+// ------------------------------------------------------------------------------------------------
+// The transforms on the reduced-radix field of fp29.cuh (9 x 29-bit limbs).  Data stays in the ABI's 2^256
+// Montgomery domain from load to store (a Montgomery product by a table constant kept as c * 2^261 does not change
+// its other operand's domain), so only the twiddle / pre-scale tables differ from the 32-bit path: they are the same
+// power tables with their first entry multiplied by 32.
+//   LDS tile: 9 words per element (36 B, odd word stride: conflict-free for consecutive elements).
+//   Tile elements stay UNCARRIED between stages (limbs < 2^31.3: f29_mul takes 2^31.4 x 2^29 limbs); only the two
+//   operands of a radix-4 group that are added without being multiplied take one parallel carry round.  Values grow
+//   by at most 4p per pair of stages (one un-multiplied path, two subtractions with +2p each): below 21p after 9
+//   stages, far from 2^261, so nothing is reduced inside a pass.  A pass ends in a Montgomery
+//   product wherever the algorithm has one (inter-pass twiddle, post scale: value < 2p, one conditional
+//   subtraction before the store) and in the conditional-subtraction ladder from 32p otherwise.
+// ------------------------------------------------------------------------------------------------
+typedef F29<FrTag> Fr29;
+
+// tile index -> LDS word offset: 9 words per element and ONE PAD ELEMENT PER 32, which spreads the power-of-two
+// element strides of the bit-reversed fill and of the first pair of stages over all banks (without it 69 % of the
+// LDS cycles of these kernels were bank conflicts: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/)
+__device__ __forceinline__ size_t lds29_off(size_t e) { return (e + (e >> 5)) * 9; }
+__device__ __forceinline__ Fr29 lds29_get(const u32* sm, size_t e) {
+    Fr29 r;
+    const u32* p = sm + lds29_off(e);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.v[i] = p[i];
+    return r;
+}
+__device__ __forceinline__ void lds29_put(u32* sm, size_t e, const Fr29& a) {
+    u32* p = sm + lds29_off(e);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) p[i] = a.v[i];
+}
+// radix-2 butterfly on carried inputs (u any value, v the already multiplied, tight operand below 2p)
+__device__ __forceinline__ void bf29(const Fr29& u, const Fr29& v, Fr29& sum, Fr29& diff) {
+    sum = f29_add(u, v);
+    diff = f29_sub<2, 29>(u, v);
+}
+
 // logR radix-2 DIT stages over an LDS tile holding T independent transforms, taken TWO STAGES AT A TIME: a thread
 // owns the four elements {base, base+h, base+2h, base+3h} of a radix-4 group, does both layers in registers (same
 // four products as two radix-2 layers) and the tile crosses LDS and a barrier once per pair of stages instead of
 // once per stage.  Stages 0+1 cost one product per group (their other twiddles are 1).  An odd logR ends with one
-// plain radix-2 stage.  element (j, t) lives at sm[j*sr + t*st].  Input must be stored bit-reversed in j.
-__device__ __forceinline__ void lds_dit(Fr* sm, unsigned logR, unsigned T, unsigned sr, unsigned st, bool t_fastest,
-                                        const Fr* __restrict__ tw, size_t n) {
+// plain radix-2 stage.  element (j, t) lives at tile index j*sr + t*st.  Input must be stored bit-reversed in j.
+__device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, unsigned sr, unsigned st, bool t_fastest,
+                                          const Fr* __restrict__ tw, size_t n) {
     const unsigned R = 1u << logR;
-    const unsigned logT = 31u - (unsigned)__builtin_clz(T);  // T is a power of two: every index split below is a shift / mask
+    const unsigned logT = 31u - (unsigned)__builtin_clz(T);
     unsigned s = 0;
     for (; s + 1 < logR; s += 2) {
         const unsigned h = 1u << s;
@@ -55,24 +96,40 @@ __device__ __forceinline__ void lds_dit(Fr* sm, unsigned logR, unsigned T, unsig
             }
             const unsigned pos = q & (h - 1);
             const unsigned base = ((q >> s) << (s + 2)) + pos;
-            Fr* p0 = sm + (size_t)base * sr + (size_t)t * st;
-            Fr* p1 = p0 + (size_t)h * sr;
-            Fr* p2 = p1 + (size_t)h * sr;
-            Fr* p3 = p2 + (size_t)h * sr;
-            Fr a0 = *p0, a1 = *p1, a2 = *p2, a3 = *p3;
-            if (s) {  // kernel-uniform: the first layer of stages 0+1 has twiddle 1 everywhere
-                const Fr w = fp_load<FrTag>(tw + (size_t)pos * (n >> (s + 1)));
-                a1 = fp_mul(a1, w);
-                a3 = fp_mul(a3, w);
+            const size_t e0 = (size_t)base * sr + (size_t)t * st, dh = (size_t)h * sr;
+            Fr29 a0 = lds29_get(sm, e0), a1 = lds29_get(sm, e0 + dh), a2 = lds29_get(sm, e0 + 2 * dh), a3 = lds29_get(sm, e0 + 3 * dh);
+            Fr29 b0, b1, b2, b3, o0, o1, o2, o3;
+            if (s) {  // kernel-uniform branch
+                // tile elements arrive with limbs < 2^31.3 (uncarried outputs of the previous pair of stages): legal as
+                // they are for the operands that get multiplied (a1, a3); the two that are only added (a0, a2) take one
+                // parallel carry round each
+                a0 = f29_carry(a0);
+                a2 = f29_carry(a2);
+                const Fr29 w = f29_load<FrTag>(tw + (size_t)pos * (n >> (s + 1)));
+                a1 = f29_mul(a1, w);
+                a3 = f29_mul(a3, w);
+                bf29(a0, a1, b0, b1);
+                bf29(a2, a3, b2, b3);
+                b2 = f29_mul(b2, f29_load<FrTag>(tw + (size_t)pos * (n >> (s + 2))));
+                b3 = f29_mul(b3, f29_load<FrTag>(tw + (size_t)(pos + h) * (n >> (s + 2))));
+                bf29(b0, b2, o0, o2);
+            } else {
+                // stages 0 + 1: operands straight from the load (tight, value < 2p); the first layer's twiddles and the
+                // second layer's even twiddle are 1
+                b0 = f29_add(a0, a1);
+                b1 = f29_sub<2, 29>(a0, a1);
+                b2 = f29_add(a2, a3);          // un-multiplied: limbs < 2^30, value < 4p -> subtrahend of f29_sub<4, 30>
+                b3 = f29_sub<2, 29>(a2, a3);
+                b3 = f29_mul(b3, f29_load<FrTag>(tw + (size_t)(pos + h) * (n >> (s + 2))));
+                o0 = f29_add(b0, b2);
+                o2 = f29_sub<4, 30>(b0, b2);
             }
-            const Fr b0 = fp_add(a0, a1), b1 = fp_sub(a0, a1);
-            Fr b2 = fp_add(a2, a3), b3 = fp_sub(a2, a3);
-            if (s) b2 = fp_mul(b2, fp_load<FrTag>(tw + (size_t)pos * (n >> (s + 2))));
-            b3 = fp_mul(b3, fp_load<FrTag>(tw + (size_t)(pos + h) * (n >> (s + 2))));
-            *p0 = fp_add(b0, b2);
-            *p2 = fp_sub(b0, b2);
-            *p1 = fp_add(b1, b3);
-            *p3 = fp_sub(b1, b3);
+            bf29(b1, b3, o1, o3);
+            // outputs stay uncarried: limbs < 2^31.3, values grow by at most 4p per pair of stages
+            lds29_put(sm, e0, o0);
+            lds29_put(sm, e0 + 2 * dh, o2);
+            lds29_put(sm, e0 + dh, o1);
+            lds29_put(sm, e0 + 3 * dh, o3);
         }
         __syncthreads();
     }
@@ -90,25 +147,30 @@ __device__ __forceinline__ void lds_dit(Fr* sm, unsigned logR, unsigned T, unsig
             }
             const unsigned pos = bf & (half - 1);
             const unsigned i0 = ((bf >> s) << (s + 1)) + pos;
-            Fr* p0 = sm + (size_t)i0 * sr + (size_t)t * st;
-            Fr* p1 = p0 + (size_t)half * sr;
-            Fr u = *p0;
-            Fr v = *p1;
-            if (s) v = fp_mul(v, fp_load<FrTag>(tw + (size_t)pos * (n >> (s + 1))));
-            *p0 = fp_add(u, v);
-            *p1 = fp_sub(u, v);
+            const size_t e0 = (size_t)i0 * sr + (size_t)t * st, e1 = e0 + (size_t)half * sr;
+            Fr29 u = lds29_get(sm, e0);
+            Fr29 v = lds29_get(sm, e1);
+            Fr29 o0, o1;
+            if (s) {
+                u = f29_carry(u);
+                v = f29_mul(v, f29_load<FrTag>(tw + (size_t)pos * (n >> (s + 1))));
+                bf29(u, v, o0, o1);
+            } else {  // a single stage (logR == 1): operands straight from the load (tight, < 2p)
+                o0 = f29_add(u, v);
+                o1 = f29_sub<2, 29>(u, v);
+            }
+            lds29_put(sm, e0, o0);
+            lds29_put(sm, e1, o1);
         }
         __syncthreads();
     }
 }
 
-extern __shared__ __attribute__((aligned(16))) unsigned char pz_smem[];
-
-// strided pass.  grid.x = hi * (lo / T), grid.y = column
-__global__ __launch_bounds__(256) void k_ntt_strided(const Fr* in, Fr* out, size_t in_stride, size_t out_stride,
-                                                     NttPass p, const Fr* __restrict__ tw,
-                                                     const Fr* __restrict__ pre) {
-    Fr* sm = reinterpret_cast<Fr*>(pz_smem);
+// strided pass.  grid.x = hi * (lo / T), grid.y = column.  tw, pre: 261-domain tables
+__global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, size_t in_stride, size_t out_stride,
+                                                       NttPass p, const Fr* __restrict__ tw,
+                                                       const Fr* __restrict__ pre) {
+    u32* sm = reinterpret_cast<u32*>(pz_smem);
     const unsigned R = 1u << p.logR, T = p.T;
     const unsigned logT = 31u - (unsigned)__builtin_clz(T);
     const size_t tiles = p.lo >> logT;   // lo, T powers of two
@@ -122,26 +184,27 @@ __global__ __launch_bounds__(256) void k_ntt_strided(const Fr* in, Fr* out, size
     for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
         unsigned j = idx >> logT, t = idx & (T - 1);
         size_t g = base + (size_t)j * p.lo + t;
-        Fr x = fp_load<FrTag>(src + g);
-        if (pre) x = fp_mul(x, fp_load<FrTag>(pre + g));
-        sm[(size_t)bitrev32(j, p.logR) * T + t] = x;
+        Fr29 x = f29_load<FrTag>(src + g);
+        if (pre) x = f29_mul(x, f29_load<FrTag>(pre + g));
+        lds29_put(sm, (size_t)bitrev32(j, p.logR) * T + t, x);
     }
     __syncthreads();
-    lds_dit(sm, p.logR, T, T, 1, true, tw, p.n);
+    lds_dit29(sm, p.logR, T, T, 1, true, tw, p.n);
     for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
         unsigned k = idx >> logT, t = idx & (T - 1);
-        Fr x = sm[(size_t)k * T + t];
+        Fr29 x = lds29_get(sm, (size_t)k * T + t);
         size_t e = p.tw_mul * (lt * T + t) * k;  // < n by construction
-        if (e) x = fp_mul(x, fp_load<FrTag>(tw + e));
-        fp_store(dst + base + (size_t)k * p.lo + t, x);
+        // always through the product (tw[0] = 1): the result is below 2p whatever the stages accumulated
+        x = f29_mul(x, f29_load<FrTag>(tw + e));
+        f29_store<1>(dst + base + (size_t)k * p.lo + t, x);
     }
 }
 
 // final pass.  grid.x = n2 * (n1 / T), grid.y = column
-__global__ __launch_bounds__(256) void k_ntt_final(const Fr* in, Fr* out, size_t in_stride, size_t out_stride,
-                                                   NttPass p, const Fr* __restrict__ tw, const Fr* __restrict__ pre,
-                                                   Fr post, int has_post) {
-    Fr* sm = reinterpret_cast<Fr*>(pz_smem);
+__global__ __launch_bounds__(256) void k_ntt_final29(const Fr* in, Fr* out, size_t in_stride, size_t out_stride,
+                                                     NttPass p, const Fr* __restrict__ tw, const Fr* __restrict__ pre,
+                                                     Fr post, int has_post) {
+    u32* sm = reinterpret_cast<u32*>(pz_smem);
     const unsigned R = 1u << p.logR, T = p.T;
     const unsigned logT = 31u - (unsigned)__builtin_clz(T);
     const size_t tiles = p.n1 >> logT;
@@ -152,17 +215,19 @@ __global__ __launch_bounds__(256) void k_ntt_final(const Fr* in, Fr* out, size_t
     for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
         unsigned r = idx >> p.logR, j = idx & (R - 1);
         size_t g = ((k1_0 + r) * p.n2 + k2) * R + j;
-        Fr x = fp_load<FrTag>(src + g);
-        if (pre) x = fp_mul(x, fp_load<FrTag>(pre + g));
-        sm[(size_t)r * R + bitrev32(j, p.logR)] = x;
+        Fr29 x = f29_load<FrTag>(src + g);
+        if (pre) x = f29_mul(x, f29_load<FrTag>(pre + g));
+        lds29_put(sm, (size_t)r * R + bitrev32(j, p.logR), x);
     }
     __syncthreads();
-    lds_dit(sm, p.logR, T, 1, R, false, tw, p.n);
+    lds_dit29(sm, p.logR, T, 1, R, false, tw, p.n);
+    const Fr29 post29 = f29_from_fp(post);
     for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
         unsigned k = idx >> logT, r = idx & (T - 1);
-        Fr x = sm[(size_t)r * R + k];
-        if (has_post) x = fp_mul(x, post);
-        fp_store(dst + (k1_0 + r) + p.n1 * k2 + p.hi * (size_t)k, x);
+        Fr29 x = lds29_get(sm, (size_t)r * R + k);
+        Fr* o = dst + (k1_0 + r) + p.n1 * k2 + p.hi * (size_t)k;
+        if (has_post) f29_store<1>(o, f29_mul(x, post29));
+        else f29_store<4>(o, x);
     }
 }
 
@@ -170,11 +235,11 @@ __global__ __launch_bounds__(256) void k_ntt_final(const Fr* in, Fr* out, size_t
 // n-coefficient polynomial is 2^e independent n-point NTTs of a[i] * (g * w_ext^r)^i, r < 2^e, interleaved
 // as out[2^e * q + r].  The strided pass has already run per r (inputs at in + r * in_r_stride); this
 // block finishes T rows for ALL r at once so every store is a full T * 2^e * 32-byte run.
-__global__ __launch_bounds__(256) void k_ntt_final_ext(const Fr* in, Fr* out, size_t in_stride, size_t in_r_stride,
-                                                       size_t out_stride, NttPass p, unsigned log_e,
-                                                       const Fr* __restrict__ tw, const Fr* __restrict__ pre,
-                                                       size_t pre_r_stride) {
-    Fr* sm = reinterpret_cast<Fr*>(pz_smem);
+__global__ __launch_bounds__(256) void k_ntt_final_ext29(const Fr* in, Fr* out, size_t in_stride, size_t in_r_stride,
+                                                         size_t out_stride, NttPass p, unsigned log_e,
+                                                         const Fr* __restrict__ tw, const Fr* __restrict__ pre,
+                                                         size_t pre_r_stride) {
+    u32* sm = reinterpret_cast<u32*>(pz_smem);
     const unsigned R = 1u << p.logR, T = p.T, E = 1u << log_e;
     const unsigned logT = 31u - (unsigned)__builtin_clz(T);
     const size_t tiles = p.n1 >> logT;
@@ -185,80 +250,16 @@ __global__ __launch_bounds__(256) void k_ntt_final_ext(const Fr* in, Fr* out, si
     for (unsigned idx = threadIdx.x; idx < R * T * E; idx += blockDim.x) {
         const unsigned j = idx & (R - 1), rr = (idx >> p.logR) & (T - 1), r = idx >> (p.logR + logT);
         const size_t g = ((k1_0 + rr) * p.n2 + k2) * R + j;
-        Fr x = fp_load<FrTag>(src + (size_t)r * in_r_stride + g);
-        if (pre) x = fp_mul(x, fp_load<FrTag>(pre + (size_t)r * pre_r_stride + g));
-        sm[((size_t)r * T + rr) * R + bitrev32(j, p.logR)] = x;
+        Fr29 x = f29_load<FrTag>(src + (size_t)r * in_r_stride + g);
+        if (pre) x = f29_mul(x, f29_load<FrTag>(pre + (size_t)r * pre_r_stride + g));
+        lds29_put(sm, ((size_t)r * T + rr) * R + bitrev32(j, p.logR), x);
     }
     __syncthreads();
-    lds_dit(sm, p.logR, T * E, 1, R, false, tw, p.n);
+    lds_dit29(sm, p.logR, T * E, 1, R, false, tw, p.n);
     for (unsigned idx = threadIdx.x; idx < R * T * E; idx += blockDim.x) {
         const unsigned r = idx & (E - 1), rr = (idx >> log_e) & (T - 1), k = idx >> (log_e + logT);
-        Fr x = sm[((size_t)r * T + rr) * R + k];
-        fp_store(dst + (((k1_0 + rr) + p.n1 * k2 + p.hi * (size_t)k) << log_e) + r, x);
-    }
-}
-
-// Lagrange values -> coefficients -> extended coset in ONE chain (what a prover does with every column): this kernel
-// is the final pass of the INVERSE transform (rows of R contiguous elements) fused with the first, strided pass of the
-// 2^e forward coset transforms.  With the inverse transform factored as n = n1 (strided first) x R (final), a block's
-// T rows hold the coefficients t + n1*k (t = row, k < R) -- exactly the tile [k][t] the forward transform's strided
-// pass over R needs -- so the coefficients go to HBM once (they are an output) and are never read back: per column
-// 64 B * 2^17 less traffic for every one of the 2^e cosets, and 2^e + 1 launches fewer.
-__global__ __launch_bounds__(256) void k_ntt_inv_final_fwd_first(const Fr* in, Fr* coeff_out, size_t in_stride,
-                                                                 size_t coeff_stride, Fr* ext_tmp, size_t ext_e_stride,
-                                                                 NttPass p, unsigned log_e, const Fr* __restrict__ tw_inv,
-                                                                 const Fr* __restrict__ tw_fwd, const Fr* __restrict__ pre,
-                                                                 Fr post) {
-    Fr* sm = reinterpret_cast<Fr*>(pz_smem);
-    const unsigned R = 1u << p.logR, T = p.T, E = 1u << log_e;
-    const unsigned logT = 31u - (unsigned)__builtin_clz(T);
-    const size_t n1 = p.n1;                       // rows of the final pass == lo of the forward strided pass
-    const size_t col = blockIdx.x, k1_0 = (size_t)blockIdx.y * T;
-    const Fr* src = in + col * in_stride;
-    for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
-        const unsigned r = idx >> p.logR, j = idx & (R - 1);
-        sm[(size_t)r * R + bitrev32(j, p.logR)] = fp_load<FrTag>(src + (k1_0 + r) * R + j);
-    }
-    __syncthreads();
-    lds_dit(sm, p.logR, T, 1, R, false, tw_inv, p.n);
-    // the block's coefficients, kept in registers for all cosets (PER = R*T/256 <= 4 elements per thread)
-    constexpr unsigned MAXPER = 4;
-    Fr v[MAXPER];
-#pragma unroll
-    for (unsigned i = 0; i < MAXPER; ++i) {
-        const unsigned idx = threadIdx.x + i * 256;
-        if (idx < R * T) {
-            const unsigned k = idx >> logT, r = idx & (T - 1);
-            const Fr x = fp_mul(sm[(size_t)r * R + k], post);
-            v[i] = x;
-            fp_store(coeff_out + col * coeff_stride + (k1_0 + r) + n1 * (size_t)k, x);
-        }
-    }
-    for (unsigned e = 0; e < E; ++e) {
-        __syncthreads();
-#pragma unroll
-        for (unsigned i = 0; i < MAXPER; ++i) {
-            const unsigned idx = threadIdx.x + i * 256;
-            if (idx < R * T) {
-                const unsigned k = idx >> logT, r = idx & (T - 1);
-                sm[(size_t)r * R + bitrev32(k, p.logR)] =
-                    fp_mul(v[i], fp_load<FrTag>(pre + (size_t)e * p.n + (k1_0 + r) + n1 * (size_t)k));
-            }
-        }
-        __syncthreads();
-        lds_dit(sm, p.logR, T, 1, R, false, tw_fwd, p.n);
-        Fr* dst = ext_tmp + (size_t)e * ext_e_stride + col * p.n;
-#pragma unroll
-        for (unsigned i = 0; i < MAXPER; ++i) {
-            const unsigned idx = threadIdx.x + i * 256;
-            if (idx < R * T) {
-                const unsigned k = idx >> logT, r = idx & (T - 1);
-                Fr x = sm[(size_t)r * R + k];
-                const size_t ex = (k1_0 + r) * (size_t)k;  // inter-pass twiddle of the forward transform, < n
-                if (ex) x = fp_mul(x, fp_load<FrTag>(tw_fwd + ex));
-                fp_store(dst + (size_t)k * n1 + (k1_0 + r), x);
-            }
-        }
+        const Fr29 x = lds29_get(sm, ((size_t)r * T + rr) * R + k);
+        f29_store<4>(dst + (((k1_0 + rr) + p.n1 * k2 + p.hi * (size_t)k) << log_e) + r, x);
     }
 }
 
@@ -266,19 +267,54 @@ __global__ __launch_bounds__(256) void k_ntt_inv_final_fwd_first(const Fr* in, F
 #ifndef PZ_NTT_LDS
 #define PZ_NTT_LDS 32768
 #endif
+#define NTT29_ELEM 36u   // bytes of one tile element of the 29-bit kernels (9 words)
+static size_t ntt29_lds_bytes(size_t elems) { return (elems + (elems >> 5) + 1) * NTT29_ELEM; }
 static unsigned pick_tile(size_t extent, unsigned logR) {
-    // LDS budget 64 KiB per block -> R*T*32 <= 65536; prefer 128-byte runs (T = 4) or more
+    // 1024 elements per block (36 KiB of the 9-word elements: 4 blocks per CU); prefer 128-byte runs (T = 4) or more
     unsigned T = 8;
     while (T > 1 && (((size_t)32 << logR) * T > PZ_NTT_LDS || T > extent)) T >>= 1;
     return T;
 }
 
+// value * 32 mod r on the host (canonical 4 x u64 in and out): a 256-domain Montgomery constant c * 2^256 becomes the
+// 261-domain constant c * 2^261 the 29-bit kernels multiply by
+static void fr_times32(const uint64_t in[4], uint64_t out[4]) {
+    static const uint64_t R_[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+    uint64_t a[4] = {in[0], in[1], in[2], in[3]};
+    for (int k = 0; k < 5; ++k) {
+        uint64_t d[4], c = 0;
+        for (int i = 0; i < 4; ++i) {   // d = 2a (a < r < 2^254: no carry out)
+            d[i] = (a[i] << 1) | c;
+            c = a[i] >> 63;
+        }
+        uint64_t t[4], br = 0;
+        for (int i = 0; i < 4; ++i) {   // t = d - r
+            const uint64_t x = d[i] - R_[i], b1 = d[i] < R_[i], y = x - br;
+            br = b1 | (x < br);
+            t[i] = y;
+        }
+        for (int i = 0; i < 4; ++i) a[i] = br ? d[i] : t[i];
+    }
+    for (int i = 0; i < 4; ++i) out[i] = a[i];
+}
+// Montgomery one (R mod r) times 32: the first entry of a 261-domain power table
+static const uint64_t* one261() {
+    static uint64_t v[4];
+    static bool init = false;
+    if (!init) {
+        static const uint64_t ONE[4] = {0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL};
+        fr_times32(ONE, v);
+        init = true;
+    }
+    return v;
+}
+
 static int launch_strided(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t os, size_t ncols, NttPass p,
                           const Fr* tw, const Fr* pre) {
     size_t blocks = p.hi * (p.lo / p.T);
-    size_t lds = ((size_t)32 << p.logR) * p.T;
+    size_t lds = ntt29_lds_bytes(((size_t)1 << p.logR) * p.T);
     p.swap = (ncols > 1 && blocks <= 65535) ? 1u : 0u;
-    hipLaunchKernelGGL(k_ntt_strided, p.swap ? dim3((unsigned)ncols, (unsigned)blocks) : dim3((unsigned)blocks, (unsigned)ncols),
+    hipLaunchKernelGGL(k_ntt_strided29, p.swap ? dim3((unsigned)ncols, (unsigned)blocks) : dim3((unsigned)blocks, (unsigned)ncols),
                        dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre);
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
@@ -286,12 +322,16 @@ static int launch_strided(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t 
 static int launch_final(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t os, size_t ncols, NttPass p,
                         const Fr* tw, const Fr* pre, const uint64_t* post_scale) {
     size_t blocks = p.n2 * (p.n1 / p.T);
-    size_t lds = ((size_t)32 << p.logR) * p.T;
+    size_t lds = ntt29_lds_bytes(((size_t)1 << p.logR) * p.T);
     Fr post;
     memset(&post, 0, sizeof post);
-    if (post_scale) memcpy(post.v, post_scale, 32);
+    if (post_scale) {   // into the 261-domain
+        uint64_t ps[4];
+        fr_times32(post_scale, ps);
+        memcpy(post.v, ps, 32);
+    }
     p.swap = (ncols > 1 && blocks <= 65535) ? 1u : 0u;
-    hipLaunchKernelGGL(k_ntt_final, p.swap ? dim3((unsigned)ncols, (unsigned)blocks) : dim3((unsigned)blocks, (unsigned)ncols),
+    hipLaunchKernelGGL(k_ntt_final29, p.swap ? dim3((unsigned)ncols, (unsigned)blocks) : dim3((unsigned)blocks, (unsigned)ncols),
                        dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, post, post_scale ? 1 : 0);
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
@@ -307,10 +347,10 @@ extern "C" int pz_ntt_fr_dev(pz_ctx* ctx, uint64_t* d_a, size_t n_cols, size_t c
     const size_t cs = col_stride / 4;  // column stride in elements
     Fr* a = reinterpret_cast<Fr*>(d_a);
     void* twv = nullptr;
-    PZCHK(pz_get_pow_table(ctx, omega, n, &twv));
+    PZCHK(pz_get_pow_table(ctx, omega, n, &twv, one261()));   // omega^i * 2^261
     const Fr* tw = (const Fr*)twv;
     void* prev = nullptr;
-    if (pre_coset_g) PZCHK(pz_get_pow_table(ctx, pre_coset_g, n, &prev));
+    if (pre_coset_g) PZCHK(pz_get_pow_table(ctx, pre_coset_g, n, &prev, one261()));
     const Fr* pre = (const Fr*)prev;
 
     const unsigned npass = log_n <= 9 ? 1 : (log_n <= 18 ? 2 : 3);
@@ -366,7 +406,7 @@ extern "C" int pz_ntt_fr_dev(pz_ctx* ctx, uint64_t* d_a, size_t n_cols, size_t c
     return PZ_OK;
 }
 
-// E pre-scale tables scale * gens[r]^i, packed [E][n], cached in the context
+// E pre-scale tables scale * gens[r]^i * 2^261 (the 261-domain constants of the 29-bit kernels), packed [E][n], cached
 static int get_ext_pre_tables(pz_ctx* ctx, const uint64_t* coset_gens, size_t E, uint32_t log_n, const uint64_t* scale,
                               void** out) {
     const size_t n = (size_t)1 << log_n;
@@ -378,11 +418,14 @@ static int get_ext_pre_tables(pz_ctx* ctx, const uint64_t* coset_gens, size_t E,
             *out = c.d;
             return PZ_OK;
         }
+    uint64_t init[4];
+    if (scale) fr_times32(scale, init);
+    else memcpy(init, one261(), 32);
     void* prev = nullptr;
     HIPCHK(ctx, hipMalloc(&prev, E * n * 32));
     for (size_t r = 0; r < E; ++r) {
         void* t;
-        PZCHK(pz_get_pow_table(ctx, coset_gens + 4 * r, n, &t, scale));
+        PZCHK(pz_get_pow_table(ctx, coset_gens + 4 * r, n, &t, init));
         HIPCHK(ctx, hipMemcpyAsync((char*)prev + r * n * 32, t, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
     }
     ctx->ext_tables.push_back(pz_ext_table{key, prev});
@@ -404,7 +447,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
     PZ_ENTER(ctx);
     const size_t is = in_stride / 4, os = out_stride / 4;
     void* twv = nullptr;
-    PZCHK(pz_get_pow_table(ctx, omega_n, n, &twv));
+    PZCHK(pz_get_pow_table(ctx, omega_n, n, &twv, one261()));
     const Fr* tw = (const Fr*)twv;
     void* prev = nullptr;
     PZCHK(get_ext_pre_tables(ctx, coset_gens, E, log_n, scale, &prev));
@@ -428,9 +471,9 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
         if (npass == 1) {
             NttPass p{};
             p.logR = log_n; p.lo = 1; p.hi = 1; p.n = n; p.T = 1; p.n1 = 1; p.n2 = 1;
-            const size_t lds = ((size_t)32 << p.logR) * p.T * E;
+            const size_t lds = ntt29_lds_bytes(((size_t)1 << p.logR) * p.T * E);
             p.swap = 0;
-            hipLaunchKernelGGL(k_ntt_final_ext, dim3(1, (unsigned)nc), dim3(256), lds, ctx->stream, cin + c0 * is,
+            hipLaunchKernelGGL(k_ntt_final_ext29, dim3(1, (unsigned)nc), dim3(256), lds, ctx->stream, cin + c0 * is,
                                eout + c0 * os, is, (size_t)0, os, p, log_e, tw, pre, n);
         } else if (npass == 3) {
             // 2^19 .. 2^27 (config c5 runs k = 19): two strided passes per coset, then the interleaving final pass
@@ -453,9 +496,9 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
             unsigned T = 8;
             while (T > 1 && (((size_t)32 << lg[2]) * T * E > 32768 || T > n1)) T >>= 1;
             pc.T = T;
-            const size_t lds = ((size_t)32 << lg[2]) * T * E;
+            const size_t lds = ntt29_lds_bytes(((size_t)1 << lg[2]) * T * E);
             pc.swap = (nc > 1 && n2 * (n1 / T) <= 65535) ? 1u : 0u;
-            hipLaunchKernelGGL(k_ntt_final_ext, pc.swap ? dim3((unsigned)nc, (unsigned)(n2 * (n1 / T))) : dim3((unsigned)(n2 * (n1 / T)), (unsigned)nc), dim3(256), lds, ctx->stream, tmp,
+            hipLaunchKernelGGL(k_ntt_final_ext29, pc.swap ? dim3((unsigned)nc, (unsigned)(n2 * (n1 / T))) : dim3((unsigned)(n2 * (n1 / T)), (unsigned)nc), dim3(256), lds, ctx->stream, tmp,
                                eout + c0 * os, n, nc * n, os, pc, log_e, tw, (const Fr*)nullptr, (size_t)0);
         } else {
             unsigned lg0 = (log_n + 1) / 2, lg1 = log_n - lg0;
@@ -471,9 +514,9 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
             unsigned T = 8;
             while (T > 1 && (((size_t)32 << lg1) * T * E > 32768 || T > n1)) T >>= 1;
             pc.T = T;
-            const size_t lds = ((size_t)32 << lg1) * T * E;
+            const size_t lds = ntt29_lds_bytes(((size_t)1 << lg1) * T * E);
             pc.swap = nc > 1 ? 1u : 0u;
-            hipLaunchKernelGGL(k_ntt_final_ext, pc.swap ? dim3((unsigned)nc, (unsigned)(n1 / T)) : dim3((unsigned)(n1 / T), (unsigned)nc), dim3(256), lds, ctx->stream, tmp,
+            hipLaunchKernelGGL(k_ntt_final_ext29, pc.swap ? dim3((unsigned)nc, (unsigned)(n1 / T)) : dim3((unsigned)(n1 / T), (unsigned)nc), dim3(256), lds, ctx->stream, tmp,
                                eout + c0 * os, n, nc * n, os, pc, log_e, tw, (const Fr*)nullptr, (size_t)0);
         }
         HIPCHK(ctx, hipGetLastError());
@@ -492,60 +535,11 @@ extern "C" int pz_ntt_fr_coeff_extend_dev(pz_ctx* ctx, uint64_t* d_values, size_
     if (n_cols == 0) return PZ_OK;
     const size_t n = (size_t)1 << log_n, E = (size_t)1 << log_e;
     if (col_stride % 4 || col_stride < 4 * n || out_stride % 4 || out_stride < 4 * n * E) return PZ_ERR_INVALID;
-    if (log_n < 10 || log_n > 18) {  // one- and three-pass sizes: the two transforms back to back
-        PZCHK(pz_ntt_fr_dev(ctx, d_values, n_cols, col_stride, omega_n_inv, log_n, nullptr, n_inv));
-        return pz_ntt_fr_extend_dev(ctx, d_values, n_cols, col_stride, d_ext, out_stride, log_n, log_e, omega_n, coset_gens, nullptr);
-    }
-    PZ_ENTER(ctx);
-    const size_t cs = col_stride / 4, os = out_stride / 4;
-    void *twf, *twi, *prev;
-    PZCHK(pz_get_pow_table(ctx, omega_n, n, &twf));
-    PZCHK(pz_get_pow_table(ctx, omega_n_inv, n, &twi));
-    PZCHK(get_ext_pre_tables(ctx, coset_gens, E, log_n, nullptr, &prev));
-    // inverse transform: strided pass over 2^lgA first, final (fused) pass over R = 2^lgB rows; forward: strided over R
-    // (fused), final over 2^lgA
-    const unsigned lgB = (log_n + 1) / 2, lgA = log_n - lgB;
-    const size_t nA = (size_t)1 << lgA, nB = (size_t)1 << lgB;
-    size_t group = n_cols;
-    const size_t max_ws = (size_t)2 << 30;
-    if (group * n * (E + 1) * 32 > max_ws) group = max_ws / (n * (E + 1) * 32) ? max_ws / (n * (E + 1) * 32) : 1;
-    if (group > 32768) group = 32768;
-    void* t;
-    PZCHK(pz_ws_get(ctx, WS_NTT_TMP, group * n * (E + 1) * 32, &t));
-    Fr* tmp0 = (Fr*)t;                 // [col][n]: inverse transform after its strided pass
-    Fr* tmpe = tmp0 + group * n;       // [e][col][n]: forward transforms after their strided pass
-    Fr post;
-    memcpy(post.v, n_inv, 32);
-    Fr* a = (Fr*)d_values;
-    Fr* eout = (Fr*)d_ext;
-    pz_timer tm(ctx, PZ_T_NTT);
-    for (size_t c0 = 0; c0 < n_cols; c0 += group) {
-        const size_t nc = n_cols - c0 < group ? n_cols - c0 : group;
-        NttPass pa{};
-        pa.logR = lgA; pa.lo = nB; pa.hi = 1; pa.tw_mul = 1; pa.n = n; pa.T = pick_tile(nB, lgA);
-        PZCHK(launch_strided(ctx, a + c0 * cs, tmp0, cs, n, nc, pa, (const Fr*)twi, nullptr));
-        NttPass pf{};
-        pf.logR = lgB; pf.lo = 1; pf.hi = nA; pf.n = n; pf.n1 = nA; pf.n2 = 1;
-        unsigned T = 8;
-        while (T > 1 && (((size_t)32 << lgB) * T > PZ_NTT_LDS || T > nA || (((size_t)T << lgB) > 1024))) T >>= 1;
-        pf.T = T;
-        const size_t lds = ((size_t)32 << lgB) * T;
-        hipLaunchKernelGGL(k_ntt_inv_final_fwd_first, dim3((unsigned)nc, (unsigned)(nA / T)), dim3(256), lds, ctx->stream,
-                           (const Fr*)tmp0, a + c0 * cs, n, cs, tmpe, nc * n, pf, log_e, (const Fr*)twi, (const Fr*)twf,
-                           (const Fr*)prev, post);
-        NttPass pc{};
-        pc.logR = lgA; pc.lo = 1; pc.hi = nB; pc.n = n; pc.n1 = nB; pc.n2 = 1;
-        unsigned Tc = 8;
-        while (Tc > 1 && (((size_t)32 << lgA) * Tc * E > 32768 || Tc > nB)) Tc >>= 1;
-        pc.T = Tc;
-        pc.swap = nc > 1 ? 1u : 0u;
-        const size_t ldsc = ((size_t)32 << lgA) * Tc * E;
-        hipLaunchKernelGGL(k_ntt_final_ext, pc.swap ? dim3((unsigned)nc, (unsigned)(nB / Tc)) : dim3((unsigned)(nB / Tc), (unsigned)nc),
-                           dim3(256), ldsc, ctx->stream, tmpe, eout + c0 * os, n, nc * n, os, pc, log_e, (const Fr*)twf,
-                           (const Fr*)nullptr, (size_t)0);
-        HIPCHK(ctx, hipGetLastError());
-    }
-    return PZ_OK;
+    // Round 1 had a kernel fusing the inverse transform's final pass with the first pass of the coset transforms
+    // (one third less traffic, bit-identical results); it measured no faster than the two calls -- the transforms are
+    // multiplier-bound, DESIGN.md section 6.1 -- and was dropped when the kernels moved to the 29-bit field.
+    PZCHK(pz_ntt_fr_dev(ctx, d_values, n_cols, col_stride, omega_n_inv, log_n, nullptr, n_inv));
+    return pz_ntt_fr_extend_dev(ctx, d_values, n_cols, col_stride, d_ext, out_stride, log_n, log_e, omega_n, coset_gens, nullptr);
 }
 
 // host-pointer forms: == best_fft(a, omega, log_n) on each column
