@@ -193,6 +193,28 @@ int pz_witness_expand_dev(pz_ctx* ctx, uint32_t limbs, uint32_t limb_bits, uint3
                           const uint64_t* d_steps, size_t n_steps, const uint64_t* d_modulus, uint64_t* d_advice,
                           uint64_t* d_lookup);
 
+/* The WHOLE circuit's cell stream, operation by operation in the drivers' call order (bench.rs:33-75 paillier_enc_test,
+ * kind = 0; bench.rs:77-117 paillier_enc_add_test, kind = 1): assign_integer of n, g, m|c1, r|c2; square + refresh of n
+ * (paillier.rs:39-45 / 69-75); load_zero; for encrypt both pow_mod_fixed_exp chains (assign_constant(1), load_zero, their
+ * mul_mod steps); the final mul_mod; assign_integer(res, 2*enc_bits); assert_equal_fresh.  Layout and per-operation cell
+ * patterns: paillier_halo2_amd/layout.py::circuit_cells, DESIGN.md section 4 (dependency-derived, SURVEY tag [D]). */
+int pz_circuit_cells(int kind, uint32_t limbs_n, uint32_t limb_bits, uint32_t lookup_bits, size_t n_steps_g,
+                     size_t n_steps_r, size_t* advice_cells, size_t* lookup_cells);
+/* inputs (HOST): n | g | x | y as ceil(limbs_n*limb_bits/64) 64-bit words each, then res as ceil(2*limbs_n*limb_bits/64)
+ * words.  d_steps (device): the n_steps_g + n_steps_r + 1 step records K3 produced (add: one record); the circuit's
+ * result c is the last record's remainder.  d_modulus: n^2 (device).  d_lookup may be NULL. */
+int pz_circuit_expand_dev(pz_ctx* ctx, int kind, uint32_t limbs_n, uint32_t limb_bits, uint32_t lookup_bits,
+                          const uint64_t* inputs, const uint64_t* d_steps, size_t n_steps_g, size_t n_steps_r,
+                          const uint64_t* d_modulus, uint64_t* d_advice, uint64_t* d_lookup);
+
+/* RefreshAux::new(limb_bits, l, r).increased_limbs_vec (paillier.rs:40-44): the number of further limbs each product limb's
+ * maximal value spills into; *n_out entries (= the refreshed integer's limb count) are written. */
+int pz_refresh_aux(uint32_t limb_bits, uint32_t num_limbs_l, uint32_t num_limbs_r, uint8_t* increased_limbs,
+                   uint32_t capacity, uint32_t* n_out);
+/* cells ONE chip operation pushes -- the terms pz_circuit_cells sums; op: 0 assign_integer(limbs), 1 square(limbs),
+ * 2 refresh (limbs x limbs product), 3 load_zero / load_constant, 4 mul_mod(limbs), 5 assert_equal_fresh(limbs). */
+int pz_op_cells(int op, uint32_t limbs, uint32_t limb_bits, uint32_t lookup_bits, size_t* advice_cells, size_t* lookup_cells);
+
 /* host-pointer form: steps / modulus / outputs in process memory (n_steps*advice_cells and n_steps*lookup_cells Fr
  * elements; either output may be NULL); synchronises before returning. */
 int pz_witness_expand(pz_ctx* ctx, uint32_t limbs, uint32_t limb_bits, uint32_t lookup_bits, const uint64_t* steps,

@@ -805,3 +805,206 @@ def check_gates(cells, gates):
         if (a + b * c - d) % FR_R != 0:
             bad.append(o)
     return bad
+
+
+# ----------------------------------------------------------------------------------------
+# The WHOLE circuit's cell stream: every BigUintChip / Context call of the drivers
+# bench.rs:33-75 (paillier_enc_test) and bench.rs:77-117 (paillier_enc_add_test) with PaillierChip::encrypt / add
+# (paillier.rs:32-60, 62-85) in between, in call order.  The per-operation cell patterns restate the biguint-halo2 /
+# halo2-lib dependency code [D] (halo2-rsa lineage) like expand_mul_mod_cells above: layout parity with the reference's
+# floating dependency versions is unpinned, the VALUES follow from the inputs.  Conventions of this restatement:
+#   assign_integer(x, bits)   : the limbs as witness cells, then range_check(limb, limb_bits) each      (bench.rs:44-66)
+#   square(n) = mul(n, n)     : load_zero cell + truncated mul_no_carry over 2 Ln - 1 limbs               (paillier.rs:39)
+#   refresh(n2, aux)          : load_zero; per limb i: (inc[i] + 1) x div_mod_unsafe(limb, 2^W) (22 cells), the j-th
+#                               remainder (j > 0) added into limb i + j (gate.add, 4 cells); the last quotient is
+#                               constrained to the constant 0 (no advice cell); then range_check of every fresh limb
+#                               (paillier.rs:40-45; inc = RefreshAux::new(limb_bits, Ln, Ln).increased_limbs_vec)
+#   ctx.load_zero()           : one cell per call                                                        (paillier.rs:47)
+#   extend_limbs              : no cells (copies of the zero cell)                                      (paillier.rs:49,53)
+#   pow_mod_fixed_exp         : assign_constant(1) (one cell), load_zero (one cell), then its mul_mod steps  (:51,55)
+#   assert_equal_fresh(a, b)  : load_zero, load_constant(1), per limb is_equal (12 cells) + and (4 cells); the result
+#                               is constrained to the constant 1                                        (bench.rs:74)
+# ----------------------------------------------------------------------------------------
+def refresh_aux(limb_bits: int, num_limbs_l: int, num_limbs_r: int) -> List[int]:
+    """RefreshAux::new(..).increased_limbs_vec: how many extra limbs each product limb's maximal value spills into"""
+    mx = (1 << limb_bits) - 1
+    d = num_limbs_l + num_limbs_r - 1
+    muled = []
+    for i in range(d):
+        cnt = sum(1 for j in range(num_limbs_l) if 0 <= i - j < num_limbs_r)
+        muled.append(cnt * mx * mx)
+    inc = []
+    cur = 0
+    while cur < len(muled):
+        bits = muled[cur].bit_length()
+        chunks = max(1, -(-bits // limb_bits))
+        inc.append(chunks - 1)
+        val = muled[cur]
+        for i in range(chunks):
+            piece = val & mx
+            val >>= limb_bits
+            if cur + i < len(muled):
+                muled[cur + i] = piece if i == 0 else muled[cur + i] + piece
+            else:
+                muled.append(piece)
+        cur += 1
+    return inc
+
+
+def expand_assign_cells(x: int, num_limbs: int, limb_bits: int, lb: int):
+    limbs = decompose_biguint(x, num_limbs, limb_bits)
+    adv, lk = list(limbs), []
+    for v in limbs:
+        c, l = _range_check_cells(v, limb_bits, lb)
+        adv += c
+        lk += l
+    return adv, lk
+
+
+def expand_refresh_cells(prod: Sequence[int], inc: Sequence[int], limb_bits: int, lb: int):
+    """-> (advice, lookup, fresh limbs)"""
+    nf = len(inc)
+    cur = list(prod) + [0] * (nf - len(prod))
+    adv, lk = [0], []
+    for i in range(nf):
+        limb = cur[i]
+        for j in range(inc[i] + 1):
+            dm, q, n = _div_mod_cells(limb, limb_bits)
+            adv += dm
+            if j == 0:
+                cur[i] = n
+            else:
+                adv += [cur[i + j], 1, n, cur[i + j] + n]
+                cur[i + j] += n
+            limb = q
+        assert limb == 0, "refresh: the limb does not decompose in inc[i] + 1 pieces"
+    for v in cur:
+        c, l = _range_check_cells(v, limb_bits, lb)
+        adv += c
+        lk += l
+    return adv, lk, cur
+
+
+def expand_assert_equal_fresh_cells(a_limbs: Sequence[int], b_limbs: Sequence[int]):
+    adv = [0, 1]
+    eq = 1
+    for x, y in zip(a_limbs, b_limbs):
+        c, e = _is_equal_cells(x, y)
+        adv += c
+        adv += [0, eq, e, eq & e]
+        eq &= e
+    return adv, eq
+
+
+def expand_circuit_cells(kind: str, n: int, g: int, x: int, y: int, res: int, enc_bits: int, limb_bits: int, lb: int):
+    """kind 'encrypt': (x, y) = (m, r), the cells of paillier_enc_test; kind 'add': (x, y) = (c1, c2), paillier_enc_add_test.
+    -> (advice cells, lookup cells, segment offsets {name: (advice offset, lookup offset)}) as canonical integers"""
+    Ln = enc_bits // limb_bits
+    L = 2 * Ln
+    adv, lk, seg = [], [], {}
+
+    def put(name, a, l=()):
+        seg[name] = (len(adv), len(lk))
+        adv.extend(a)
+        lk.extend(l)
+
+    for name, v in (("assign_n", n), ("assign_g", g), ("assign_x", x), ("assign_y", y)):
+        put(name, *expand_assign_cells(v, Ln, limb_bits, lb))
+    nl = decompose_biguint(n, Ln, limb_bits)
+    sq_cells, prod = _mul_cells(nl, nl, 2 * Ln - 1)
+    put("square", sq_cells)
+    inc = refresh_aux(limb_bits, Ln, Ln)
+    assert len(inc) == L
+    r_adv, r_lk, fresh = expand_refresh_cells(prod, inc, limb_bits, lb)
+    assert get_biguint(fresh, limb_bits) == n * n
+    put("refresh", r_adv, r_lk)
+    put("load_zero", [0])
+    n2 = n * n
+    if kind == "encrypt":
+        c, sg, sr, fin = encrypt_trace(n, g, x, y)
+        for name, steps in (("pow_g", sg), ("pow_r", sr)):
+            put(name, [1, 0])
+            for st in steps:
+                a_, l_ = expand_mul_mod_cells(*st, n2, L, lb, limb_bits)
+                adv.extend(a_)
+                lk.extend(l_)
+    else:
+        c, fin = add_trace(n, x, y)
+    put("final", *expand_mul_mod_cells(*fin, n2, L, lb, limb_bits))
+    put("assign_res", *expand_assign_cells(res, L, limb_bits, lb))
+    ae, bit = expand_assert_equal_fresh_cells(decompose_biguint(c, L, limb_bits), decompose_biguint(res, L, limb_bits))
+    put("assert_equal", ae)
+    seg["end"] = (len(adv), len(lk))
+    seg["satisfied"] = bool(bit)
+    return [v % FR_R for v in adv], [v % FR_R for v in lk], seg
+
+
+# gate positions (MockProver analogue) of the operations above, relative to the operation's first cell
+def gate_offsets_assign(num_limbs: int, limb_bits: int, lb: int):
+    gates, off = [], num_limbs
+    for _ in range(num_limbs):
+        g, n = _rc_gates(off, limb_bits, lb)
+        gates += g
+        off += n
+    return gates, off
+
+
+def gate_offsets_square(Ln: int):
+    gates, off = [], 1
+    for i in range(2 * Ln - 1):
+        gates += [off + 3 * j for j in range(i + 1)]
+        off += 1 + 3 * (i + 1)
+    return gates, off
+
+
+def gate_offsets_refresh(inc: Sequence[int], limb_bits: int, lb: int):
+    gates, off = [], 1
+    for i in range(len(inc)):
+        for j in range(inc[i] + 1):
+            gates += [off + 2, off + 6, off + 10, off + 14, off + 18]   # div_mod_unsafe: mul, sub, is_equal (3 gates)
+            off += 22
+            if j:
+                gates.append(off)
+                off += 4
+    for _ in range(len(inc)):
+        g, n = _rc_gates(off, limb_bits, lb)
+        gates += g
+        off += n
+    return gates, off
+
+
+def gate_offsets_assert_equal(L: int):
+    gates, off = [], 2
+    for _ in range(L):
+        gates += [off, off + 4, off + 8, off + 12]
+        off += 16
+    return gates, off
+
+
+def gate_offsets_circuit(kind: str, enc_bits: int, limb_bits: int, lb: int, n_steps_g: int = 0, n_steps_r: int = 0):
+    """every enabled gate window of the whole circuit's advice stream, and the stream's length"""
+    Ln = enc_bits // limb_bits
+    L = 2 * Ln
+    gates, off = [], 0
+
+    def add(part):
+        nonlocal off
+        g, n = part
+        gates.extend(off + o for o in g)
+        off += n
+
+    for _ in range(4):
+        add(gate_offsets_assign(Ln, limb_bits, lb))
+    add(gate_offsets_square(Ln))
+    add(gate_offsets_refresh(refresh_aux(limb_bits, Ln, Ln), limb_bits, lb))
+    off += 1
+    mm = gate_offsets_mul_mod(L, lb, limb_bits)
+    if kind == "encrypt":
+        for ns in (n_steps_g, n_steps_r):
+            off += 2
+            for _ in range(ns):
+                add(mm)
+    add(mm)
+    add(gate_offsets_assign(L, limb_bits, lb))
+    add(gate_offsets_assert_equal(L))
+    return gates, off

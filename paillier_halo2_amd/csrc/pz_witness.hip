@@ -13,6 +13,9 @@
 // lane writes a contiguous 96/192-byte run -> fully coalesced streaming stores.  Operand limbs are
 // converted to Montgomery form once per step into LDS.  The short serial carry / borrow chains run
 // on one lane between two barriers.  Bound: HBM write bandwidth, 32 B per cell.
+#include <array>
+#include <vector>
+
 #include "fp.cuh"
 #include "pz_internal.h"
 
@@ -605,6 +608,340 @@ extern "C" int pz_witness_expand_dev(pz_ctx* ctx, uint32_t limbs, uint32_t limb_
     pz_timer tm(ctx, PZ_T_EXPAND);
     hipLaunchKernelGGL(k_witness_expand, dim3((unsigned)n_steps), dim3(EXP_THREADS), 0, ctx->stream, P, d_steps,
                        d_modulus, (Fr*)d_advice, (Fr*)d_lookup);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The rest of the circuit: every cell the drivers bench.rs:33-75 / :77-117 push that is
+// NOT inside a mul_mod -- the input assignments, square + refresh of n, load_zero, the constant cells of
+// pow_mod_fixed_exp, the assignment of res and assert_equal_fresh -- in the layout of
+// paillier_halo2_amd/layout.py::circuit_cells (values: oracle/pyref.py::expand_circuit_cells).  A few thousand to a few
+// hundred thousand cells per proof: one workgroup, the serial carry chain of refresh on one lane.
+// ------------------------------------------------------------------------------------------------
+#define CIRC_MAXF 256   // fresh limbs of n^2 (2 Ln)
+#define CIRC_MAXJ 3     // pieces a product limb is cut into (2W + log2(Ln) bits -> at most 3 limbs)
+
+struct CircP {
+    ExpP e;                         // shape of the mul_mod steps (L = 2 Ln): range-check parameters, limb width
+    unsigned Ln, nf, words_n, kind;
+    unsigned rc_adv, rc_lk;         // range_check(limb, W)
+    size_t a_assign[4], a_square, a_refresh, a_zero, a_pow[2], a_res, a_eq;   // advice offsets of the segments
+    size_t l_assign[4], l_refresh, l_res;                                      // lookup offsets
+    unsigned char inc[CIRC_MAXF];
+};
+
+__global__ __launch_bounds__(256) void k_circuit_misc(CircP C, const u64* __restrict__ inputs /* n | g | x | y | res */,
+                                                      const u64* __restrict__ cval /* the circuit's result, L64 words */,
+                                                      Fr* __restrict__ adv, Fr* __restrict__ lk) {
+    __shared__ u64 s_in[4][EXP_MAXL / 2 + 1][2];       // limbs of n, g, x, y
+    __shared__ u64 s_res[CIRC_MAXF][2], s_c[CIRC_MAXF][2], s_fresh[CIRC_MAXF][2];
+    __shared__ u64 s_sq[CIRC_MAXF][3];                 // limbs of n * n (unreduced convolution sums)
+    __shared__ u64 s_dm[CIRC_MAXF][CIRC_MAXJ][3];      // refresh: the value each div_mod_unsafe divides
+    __shared__ u64 s_ad[CIRC_MAXF][CIRC_MAXJ][3];      // refresh: limb i + j before the j-th remainder is added
+    __shared__ unsigned s_roff[CIRC_MAXF + 1];
+    __shared__ unsigned char s_eq[CIRC_MAXF + 1];
+    const unsigned Ln = C.Ln, nf = C.nf, W = C.e.W, lb = C.e.lb, tid = threadIdx.x;
+    const bool wide = W > 64;
+    const unsigned D = 2 * Ln - 1;
+#define LIMB(X, i) u_make((X)[i][0], (X)[i][1])
+    for (unsigned t = tid; t < 4 * Ln; t += blockDim.x) limb_extract(inputs + (size_t)(t / Ln) * C.words_n, C.words_n, t % Ln, W, s_in[t / Ln][t % Ln]);
+    for (unsigned t = tid; t < nf; t += blockDim.x) {
+        limb_extract(inputs + 4 * (size_t)C.words_n, C.e.L64, t, W, s_res[t]);
+        limb_extract(cval, C.e.L64, t, W, s_c[t]);
+    }
+    __syncthreads();
+    // ---- square(n): one lane per product limb, cells written as the row is summed
+    if (tid == 0) fp_store(adv + C.a_square, fp_zero<FrTag>());
+    for (unsigned i = tid; i < D; i += blockDim.x) {
+        const size_t row = 1 + (size_t)i + 3 * ((size_t)i * (i + 1) / 2);
+        Fr* c = adv + C.a_square + row;
+        fp_store(c, fp_zero<FrTag>());
+        U192 sum = u_make(0);
+        for (unsigned j = 0; j <= i; ++j) {
+            const bool in = j < Ln && (i - j) < Ln;
+            if (in) sum = u_add(sum, u_mul_limb(LIMB(s_in[0], j), LIMB(s_in[0], i - j), wide));
+            fp_store(c + 1 + 3 * (size_t)j, j < Ln ? fr_from_u(LIMB(s_in[0], j)) : fp_zero<FrTag>());
+            fp_store(c + 2 + 3 * (size_t)j, (i - j) < Ln ? fr_from_u(LIMB(s_in[0], i - j)) : fp_zero<FrTag>());
+            fp_store(c + 3 + 3 * (size_t)j, fr_from_u(sum));
+        }
+        s_sq[i][0] = sum.w[0]; s_sq[i][1] = sum.w[1]; s_sq[i][2] = sum.w[2];
+    }
+    for (unsigned i = D + tid; i < nf; i += blockDim.x) { s_sq[i][0] = 0; s_sq[i][1] = 0; s_sq[i][2] = 0; }
+    __syncthreads();
+    // ---- serial chains: refresh's carries, assert_equal_fresh's running bit
+    if (tid == 0) {
+        unsigned off = 1;
+        for (unsigned i = 0; i < nf; ++i) {
+            s_roff[i] = off;
+            U192 limb = u_make(s_sq[i][0], s_sq[i][1], s_sq[i][2]);
+            for (unsigned j = 0; j <= C.inc[i]; ++j) {
+                s_dm[i][j][0] = limb.w[0]; s_dm[i][j][1] = limb.w[1]; s_dm[i][j][2] = limb.w[2];
+                const U192 nrem = u_lowbits(limb, W);
+                if (j == 0) {
+                    s_sq[i][0] = nrem.w[0]; s_sq[i][1] = nrem.w[1]; s_sq[i][2] = 0;
+                } else if (i + j < nf) {
+                    s_ad[i][j][0] = s_sq[i + j][0]; s_ad[i][j][1] = s_sq[i + j][1]; s_ad[i][j][2] = s_sq[i + j][2];
+                    const U192 nv = u_add(u_make(s_sq[i + j][0], s_sq[i + j][1], s_sq[i + j][2]), nrem);
+                    s_sq[i + j][0] = nv.w[0]; s_sq[i + j][1] = nv.w[1]; s_sq[i + j][2] = nv.w[2];
+                }
+                limb = u_shr(limb, W);
+                off += 22 + (j ? 4 : 0);
+            }
+            s_fresh[i][0] = s_sq[i][0]; s_fresh[i][1] = s_sq[i][1];
+        }
+        s_roff[nf] = off;
+        unsigned eq = 1;
+        s_eq[0] = 1;
+        for (unsigned i = 0; i < nf; ++i) {
+            eq &= u_eq(LIMB(s_c, i), LIMB(s_res, i)) ? 1u : 0u;
+            s_eq[i + 1] = (unsigned char)eq;
+        }
+    }
+    __syncthreads();
+    // ---- assign_integer of n, g, x, y (Ln limbs) and of res (2 Ln limbs)
+    for (unsigned which = 0; which < 5; ++which) {
+        const unsigned nl = which < 4 ? Ln : nf;
+        const u64(*X)[2] = which < 4 ? s_in[which] : s_res;
+        Fr* a = adv + (which < 4 ? C.a_assign[which] : C.a_res);
+        Fr* l = lk ? lk + (which < 4 ? C.l_assign[which] : C.l_res) : nullptr;
+        for (unsigned t = tid; t < nl * (1 + C.rc_adv); t += blockDim.x) {
+            Fr v;
+            if (t < nl) v = fr_from_u(LIMB(X, t));
+            else v = rc_adv_cell(LIMB(X, (t - nl) / C.rc_adv), W, lb, (t - nl) % C.rc_adv);
+            fp_store(a + t, v);
+        }
+        if (l)
+            for (unsigned t = tid; t < nl * C.rc_lk; t += blockDim.x) fp_store(l + t, rc_lk_cell(LIMB(X, t / C.rc_lk), W, lb, t % C.rc_lk));
+    }
+    // ---- refresh
+    if (tid == 0) fp_store(adv + C.a_refresh, fp_zero<FrTag>());
+    for (unsigned i = 0; i < nf; ++i) {
+        const unsigned len = s_roff[i + 1] - s_roff[i];
+        for (unsigned t = tid; t < len; t += blockDim.x) {
+            // blocks: j = 0: 22 cells; j > 0: 22 + 4 cells
+            unsigned j = 0, p = t;
+            if (p >= 22) { j = 1 + (p - 22) / 26; p = (p - 22) % 26; }
+            const U192 v = u_make(s_dm[i][j][0], s_dm[i][j][1], s_dm[i][j][2]);
+            Fr x;
+            if (p < 22) x = div_mod_cell(v, p, W);
+            else {
+                const U192 before = u_make(s_ad[i][j][0], s_ad[i][j][1], s_ad[i][j][2]), nrem = u_lowbits(v, W);
+                x = p == 22 ? fr_from_u(before) : p == 23 ? fp_one<FrTag>() : p == 24 ? fr_from_u(nrem) : fr_from_u(u_add(before, nrem));
+            }
+            fp_store(adv + C.a_refresh + s_roff[i] + t, x);
+        }
+    }
+    for (unsigned t = tid; t < nf * C.rc_adv; t += blockDim.x)
+        fp_store(adv + C.a_refresh + s_roff[nf] + t, rc_adv_cell(LIMB(s_fresh, t / C.rc_adv), W, lb, t % C.rc_adv));
+    if (lk)
+        for (unsigned t = tid; t < nf * C.rc_lk; t += blockDim.x)
+            fp_store(lk + C.l_refresh + t, rc_lk_cell(LIMB(s_fresh, t / C.rc_lk), W, lb, t % C.rc_lk));
+    // ---- load_zero; assign_constant(1) + load_zero of both pow_mod_fixed_exp
+    if (tid == 0) {
+        fp_store(adv + C.a_zero, fp_zero<FrTag>());
+        if (C.kind == 0)
+            for (int k = 0; k < 2; ++k) {
+                fp_store(adv + C.a_pow[k], fp_one<FrTag>());
+                fp_store(adv + C.a_pow[k] + 1, fp_zero<FrTag>());
+            }
+        fp_store(adv + C.a_eq, fp_zero<FrTag>());
+        fp_store(adv + C.a_eq + 1, fp_one<FrTag>());
+    }
+    // ---- assert_equal_fresh(c, res)
+    for (unsigned t = tid; t < 16 * nf; t += blockDim.x) {
+        const unsigned i = t / 16, p = t % 16;
+        Fr v;
+        if (p < 12) v = is_equal_cell(LIMB(s_c, i), LIMB(s_res, i), p);
+        else {
+            const unsigned e = u_eq(LIMB(s_c, i), LIMB(s_res, i)) ? 1u : 0u, in = s_eq[i], out = s_eq[i + 1];
+            v = p == 12 ? fp_zero<FrTag>() : p == 13 ? (in ? fp_one<FrTag>() : fp_zero<FrTag>())
+                : p == 14 ? (e ? fp_one<FrTag>() : fp_zero<FrTag>()) : (out ? fp_one<FrTag>() : fp_zero<FrTag>());
+        }
+        fp_store(adv + C.a_eq + 2 + t, v);
+    }
+#undef LIMB
+}
+
+// RefreshAux::new(limb_bits, l, r).increased_limbs_vec with the maximal limb values tracked as bit lengths + exact
+// small big-integers (3 x 64-bit words are enough: a product limb is below 2^(2W + 8))
+static int refresh_aux_host(unsigned W, unsigned nl, unsigned nr, unsigned char* inc, unsigned* n_out) {
+    const unsigned d = nl + nr - 1;
+    std::vector<std::array<uint64_t, 3>> muled;
+    uint64_t mx2[3], one[3] = {1, 0, 0}, t[3];
+    // (2^W - 1)^2 = 2^(2W) - 2^(W+1) + 1
+    h_shl(one, 2 * W, mx2);
+    h_shl(one, W + 1, t);
+    h_sub(mx2, t);
+    h_add(mx2, one);
+    for (unsigned i = 0; i < d; ++i) {
+        unsigned cnt = 0;
+        for (unsigned j = 0; j < nl; ++j)
+            if (i >= j && i - j < nr) ++cnt;
+        std::array<uint64_t, 3> v = {0, 0, 0};
+        for (unsigned k = 0; k < cnt; ++k) h_add(v.data(), mx2);
+        muled.push_back(v);
+    }
+    unsigned cur = 0, n = 0;
+    while (cur < muled.size()) {
+        if (n >= CIRC_MAXF) return PZ_ERR_UNSUPPORTED;
+        const unsigned bits = h_bits(muled[cur].data());
+        unsigned chunks = (bits + W - 1) / W;
+        if (chunks == 0) chunks = 1;
+        if (chunks > CIRC_MAXJ) return PZ_ERR_UNSUPPORTED;
+        inc[n++] = (unsigned char)(chunks - 1);
+        uint64_t val[3] = {muled[cur][0], muled[cur][1], muled[cur][2]};
+        for (unsigned i = 0; i < chunks; ++i) {
+            // piece = val mod 2^W ; val >>= W
+            uint64_t piece[3] = {val[0], val[1], val[2]};
+            if (W < 64) { piece[0] &= (1ull << W) - 1; piece[1] = 0; piece[2] = 0; }
+            else if (W == 64) { piece[1] = 0; piece[2] = 0; }
+            else { piece[1] &= (1ull << (W - 64)) - 1; piece[2] = 0; }
+            unsigned sft = W;
+            while (sft >= 64) { val[0] = val[1]; val[1] = val[2]; val[2] = 0; sft -= 64; }
+            if (sft) { val[0] = (val[0] >> sft) | (val[1] << (64 - sft)); val[1] = (val[1] >> sft) | (val[2] << (64 - sft)); val[2] >>= sft; }
+            if (cur + i < muled.size()) {
+                if (i == 0) muled[cur] = {piece[0], piece[1], piece[2]};
+                else h_add(muled[cur + i].data(), piece);
+            } else muled.push_back({piece[0], piece[1], piece[2]});
+        }
+        ++cur;
+    }
+    *n_out = n;
+    return PZ_OK;
+}
+
+static int make_circuit_params(int kind, uint32_t limbs_n, uint32_t limb_bits, uint32_t lb, size_t ng, size_t nr, CircP& C,
+                               size_t* adv_total, size_t* lk_total, size_t step_off[3]) {
+    if (kind != 0 && kind != 1) return PZ_ERR_INVALID;
+    if (limbs_n < 1 || 2 * limbs_n > CIRC_MAXF || 2 * limbs_n > EXP_MAXL) return PZ_ERR_UNSUPPORTED;
+    memset(&C, 0, sizeof C);
+    PZCHK(make_params(2 * limbs_n, limb_bits, lb, C.e));
+    C.Ln = limbs_n;
+    C.kind = (unsigned)kind;
+    C.words_n = (limbs_n * limb_bits + 63) / 64;
+    C.rc_adv = C.e.rc64_adv;
+    C.rc_lk = C.e.rc64_lk;
+    PZCHK(refresh_aux_host(limb_bits, limbs_n, limbs_n, C.inc, &C.nf));
+    if (C.nf != 2 * limbs_n) return PZ_ERR_UNSUPPORTED;   // the chip's mul_mod needs n^2 at the operands' limb count
+    size_t a = 0, l = 0;
+    const size_t asg_a = (size_t)limbs_n * (1 + C.rc_adv), asg_l = (size_t)limbs_n * C.rc_lk;
+    for (int k = 0; k < 4; ++k) { C.a_assign[k] = a; C.l_assign[k] = l; a += asg_a; l += asg_l; }
+    C.a_square = a;
+    a += 1;
+    for (unsigned i = 0; i < 2 * limbs_n - 1; ++i) a += 1 + 3 * ((size_t)i + 1);
+    C.a_refresh = a; C.l_refresh = l;
+    a += 1;
+    for (unsigned i = 0; i < C.nf; ++i) a += ((size_t)C.inc[i] + 1) * 22 + (size_t)C.inc[i] * 4;
+    a += (size_t)C.nf * C.rc_adv;
+    l += (size_t)C.nf * C.rc_lk;
+    C.a_zero = a; a += 1;
+    size_t lstep[3] = {0, 0, 0};
+    if (kind == 0) {
+        C.a_pow[0] = a; a += 2; step_off[0] = a; lstep[0] = l; a += ng * C.e.cells; l += ng * C.e.lookups;
+        C.a_pow[1] = a; a += 2; step_off[1] = a; lstep[1] = l; a += nr * C.e.cells; l += nr * C.e.lookups;
+    } else if (ng || nr) return PZ_ERR_INVALID;
+    step_off[2] = a; lstep[2] = l; a += C.e.cells; l += C.e.lookups;
+    C.a_res = a; C.l_res = l;
+    a += 2 * asg_a; l += 2 * asg_l;
+    C.a_eq = a;
+    a += 2 + 16 * (size_t)C.nf;
+    *adv_total = a;
+    *lk_total = l;
+    // step_off[0..2]: advice offsets of the three runs of mul_mod steps (g^m, r^n, final); [3..5]: their lookup offsets
+    memcpy(step_off + 3, lstep, sizeof lstep);
+    return PZ_OK;
+}
+
+// RefreshAux::new(limb_bits, l, r).increased_limbs_vec for the host mirror (paillier.rs:40-44)
+extern "C" int pz_refresh_aux(uint32_t limb_bits, uint32_t num_limbs_l, uint32_t num_limbs_r, uint8_t* increased_limbs,
+                              uint32_t capacity, uint32_t* n_out) {
+    if (!increased_limbs || !n_out || limb_bits < 16 || limb_bits > 90 || !num_limbs_l || !num_limbs_r) return PZ_ERR_INVALID;
+    unsigned char inc[CIRC_MAXF];
+    unsigned n = 0;
+    PZCHK(refresh_aux_host(limb_bits, num_limbs_l, num_limbs_r, inc, &n));
+    if (n > capacity) return PZ_ERR_CAPACITY;
+    memcpy(increased_limbs, inc, n);
+    *n_out = n;
+    return PZ_OK;
+}
+
+// cells one chip operation pushes (the terms pz_circuit_cells sums): op 0 assign_integer(limbs), 1 square(limbs),
+// 2 refresh of a limbs x limbs product, 3 load_zero / load_constant (one cell), 4 mul_mod(limbs), 5 assert_equal_fresh(limbs)
+extern "C" int pz_op_cells(int op, uint32_t limbs, uint32_t limb_bits, uint32_t lookup_bits, size_t* advice_cells,
+                           size_t* lookup_cells) {
+    size_t a = 0, l = 0;
+    unsigned k, rem, rc_a, rc_l;
+    if (limb_bits < 16 || limb_bits > 90 || lookup_bits < 4 || lookup_bits > 32) return PZ_ERR_INVALID;
+    rc_counts(limb_bits, lookup_bits, k, rem, rc_a, rc_l);
+    switch (op) {
+        case 0: a = (size_t)limbs * (1 + rc_a); l = (size_t)limbs * rc_l; break;
+        case 1:
+            a = 1;
+            for (unsigned i = 0; i + 1 < 2 * limbs; ++i) a += 1 + 3 * ((size_t)i + 1);
+            break;
+        case 2: {
+            unsigned char inc[CIRC_MAXF];
+            unsigned n = 0;
+            PZCHK(refresh_aux_host(limb_bits, limbs, limbs, inc, &n));
+            a = 1;
+            for (unsigned i = 0; i < n; ++i) a += ((size_t)inc[i] + 1) * 22 + (size_t)inc[i] * 4;
+            a += (size_t)n * rc_a;
+            l = (size_t)n * rc_l;
+            break;
+        }
+        case 3: a = 1; break;
+        case 4: {
+            ExpP P;
+            PZCHK(make_params(limbs, limb_bits, lookup_bits, P));
+            a = P.cells;
+            l = P.lookups;
+            break;
+        }
+        case 5: a = 2 + 16 * (size_t)limbs; break;
+        default: return PZ_ERR_INVALID;
+    }
+    if (advice_cells) *advice_cells = a;
+    if (lookup_cells) *lookup_cells = l;
+    return PZ_OK;
+}
+
+extern "C" int pz_circuit_cells(int kind, uint32_t limbs_n, uint32_t limb_bits, uint32_t lookup_bits, size_t n_steps_g,
+                                size_t n_steps_r, size_t* advice_cells, size_t* lookup_cells) {
+    CircP C;
+    size_t a, l, so[6];
+    PZCHK(make_circuit_params(kind, limbs_n, limb_bits, lookup_bits, n_steps_g, n_steps_r, C, &a, &l, so));
+    if (advice_cells) *advice_cells = a;
+    if (lookup_cells) *lookup_cells = l;
+    return PZ_OK;
+}
+
+extern "C" int pz_circuit_expand_dev(pz_ctx* ctx, int kind, uint32_t limbs_n, uint32_t limb_bits, uint32_t lookup_bits,
+                                     const uint64_t* inputs, const uint64_t* d_steps, size_t n_steps_g, size_t n_steps_r,
+                                     const uint64_t* d_modulus, uint64_t* d_advice, uint64_t* d_lookup) {
+    if (!ctx || !inputs || !d_steps || !d_modulus || !d_advice) return PZ_ERR_INVALID;
+    CircP C;
+    size_t a, l, so[6];
+    PZCHK(make_circuit_params(kind, limbs_n, limb_bits, lookup_bits, n_steps_g, n_steps_r, C, &a, &l, so));
+    PZ_ENTER(ctx);
+    const size_t in_words = 4 * (size_t)C.words_n + C.e.L64;
+    void* d_in;
+    PZCHK(pz_ws_get(ctx, WS_MISC, in_words * 8 + 64, &d_in));
+    HIPCHK(ctx, hipMemcpyAsync(d_in, inputs, in_words * 8, hipMemcpyHostToDevice, ctx->stream));
+    pz_timer tm(ctx, PZ_T_EXPAND);
+    const size_t rec = 4 * (size_t)C.e.L64;   // words per step record
+    const size_t runs[3] = {kind == 0 ? n_steps_g : 0, kind == 0 ? n_steps_r : 0, 1};
+    size_t first = 0;
+    for (int k = 0; k < 3; ++k) {
+        if (runs[k])
+            hipLaunchKernelGGL(k_witness_expand, dim3((unsigned)runs[k]), dim3(EXP_THREADS), 0, ctx->stream, C.e, d_steps + first * rec,
+                               d_modulus, (Fr*)d_advice + so[k], d_lookup ? (Fr*)d_lookup + so[3 + k] : (Fr*)nullptr);
+        first += runs[k];
+    }
+    // the circuit's result c = remainder of the last step (the final mul_mod)
+    const uint64_t* d_c = d_steps + (first - 1) * rec + 3 * (size_t)C.e.L64;
+    hipLaunchKernelGGL(k_circuit_misc, dim3(1), dim3(256), 0, ctx->stream, C, (const u64*)d_in, (const u64*)d_c, (Fr*)d_advice,
+                       (Fr*)d_lookup);
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
 }

@@ -297,6 +297,20 @@ class Engine:
         self._chk(self.L.pz_witness_expand_dev(self.ctx, limbs, limb_bits, lookup_bits, VP(d_steps), n_steps,
                                                VP(d_modulus), VP(d_advice), VP(d_lookup)), "pz_witness_expand_dev")
 
+    def circuit_cells(self, kind: int, limbs_n: int, limb_bits: int, lookup_bits: int, n_steps_g: int = 0, n_steps_r: int = 0):
+        a = C.c_size_t()
+        l = C.c_size_t()
+        self._chk(self.L.pz_circuit_cells(kind, limbs_n, limb_bits, lookup_bits, n_steps_g, n_steps_r, C.byref(a), C.byref(l)),
+                  "pz_circuit_cells")
+        return a.value, l.value
+
+    def circuit_expand_dev(self, kind: int, limbs_n: int, limb_bits: int, lookup_bits: int, inputs, d_steps: int, n_steps_g: int,
+                           n_steps_r: int, d_modulus: int, d_advice: int, d_lookup: int = 0):
+        """inputs: host uint64 array n | g | x | y | res (pz.h); writes the whole circuit's cell stream"""
+        inp = np.ascontiguousarray(inputs, dtype=np.uint64).reshape(-1)
+        self._chk(self.L.pz_circuit_expand_dev(self.ctx, kind, limbs_n, limb_bits, lookup_bits, _ptr(inp), VP(d_steps), n_steps_g,
+                                               n_steps_r, VP(d_modulus), VP(d_advice), VP(d_lookup)), "pz_circuit_expand_dev")
+
     # ------------------------------------------------------------------ "next" rows: SRS setup, evaluation at a point
     def srs_setup_g1_dev(self, k: int, s, omega, d_g: int = 0, d_g_lagrange: int = 0):
         self._chk(self.L.pz_srs_setup_g1_dev(self.ctx, k, _ptr(_np(s).reshape(4)), _ptr(_np(omega).reshape(4)), VP(d_g),

@@ -17,9 +17,10 @@
 //   paillier.rs:87-97 paillier_enc_native / _add_native        pz::paillier_enc_native / paillier_add_native
 //   bench.rs:11-31    input structs, :33-117 drivers           pz::PaillierEncryptionInput ... paillier_enc_test ...
 //
-// Where the reference pushes cells into a CPU Context one by one, this Context records the mul_mod STEPS
-// (a|b|q|r, produced by the K3 kernels) and expands them to the advice / lookup cell streams on the device
-// in one K4 launch (Context::synthesize).  Results<> carry plonk::Error's role; unwrap() throws where Rust
+// Where the reference pushes cells into a CPU Context one by one, this Context records a TAPE of the chip
+// operations in call order (assign_integer, square, refresh, load_zero, load_constant, mul_mod steps produced by the
+// K3 kernels, assert_equal_fresh) with the cells each one pushes, and expands the whole tape to the advice / lookup
+// cell streams on the device (synthesize_circuit -> pz_circuit_expand_dev).  Results<> carry plonk::Error's role; unwrap() throws where Rust
 // would panic; value mismatches throw like the reference's assert_eq! (paillier.rs:158-163).
 #pragma once
 #include <memory>
@@ -63,7 +64,30 @@ class Context {
     ~Context() { if (ctx_) pz_free(ctx_); }
     Context(const Context&) = delete;
     pz_ctx* raw() { return ctx_; }
-    size_t load_zero() { return zero_cells_++; }  // paillier.rs:47 ctx.load_zero(): one advice cell
+    // ---- the operation tape: what the reference's Context would hold, operation by operation
+    enum Op { ASSIGN = 0, SQUARE = 1, REFRESH = 2, CONST_CELL = 3, MUL_MOD = 4, ASSERT_EQUAL = 5 };
+    struct OpRec {
+        Op op;
+        unsigned limbs;      // limb count the operation works on
+        size_t count;        // MUL_MOD: number of steps; otherwise 1
+    };
+    void set_shape(unsigned limb_bits, unsigned lookup_bits) { W_ = limb_bits; lookup_bits_ = lookup_bits; }
+    // record an operation and the cells it pushes (pz_op_cells: the same arithmetic pz_circuit_cells sums)
+    void record(Op op, unsigned limbs, size_t count = 1) {
+        size_t a = 0, l = 0;
+        int rc = pz_op_cells((int)op, limbs, W_, lookup_bits_, &a, &l);
+        if (rc != PZ_OK) throw std::runtime_error(std::string("pz_op_cells: ") + pz_strerror(rc));
+        advice_cells_ += a * count;
+        lookup_cells_ += l * count;
+        if (!ops_.empty() && ops_.back().op == op && op == MUL_MOD && ops_.back().limbs == limbs) ops_.back().count += count;
+        else ops_.push_back(OpRec{op, limbs, count});
+    }
+    size_t load_zero() { record(CONST_CELL, 1); return zero_cells_++; }            // paillier.rs:47 ctx.load_zero(): one advice cell
+    size_t load_constant_one() { record(CONST_CELL, 1); return zero_cells_++; }    // assign_constant(1) of pow_mod_fixed_exp
+    const std::vector<OpRec>& ops() const { return ops_; }
+    size_t advice_cells() const { return advice_cells_; }
+    size_t lookup_cells() const { return lookup_cells_; }
+    unsigned lookup_bits() const { return lookup_bits_; }
     // tape of mul_mod steps in emission order: (a|b|q|r), `words` 64-bit words each, whatever the circuit's limb
     // width is; all steps of one circuit share the limb count, the limb width and the modulus
     void push_steps(const std::vector<uint64_t>& steps, unsigned words, unsigned limbs, unsigned limb_bits, const BigUint& modulus) {
@@ -73,6 +97,7 @@ class Context {
         words_ = words;
         modulus_ = modulus;
         tape_.insert(tape_.end(), steps.begin(), steps.end());
+        record(MUL_MOD, limbs, steps.size() / (4 * (size_t)words));
     }
     size_t n_steps() const { return words_ ? tape_.size() / (4 * words_) : 0; }
     const std::vector<uint64_t>& tape() const { return tape_; }
@@ -83,8 +108,9 @@ class Context {
 
   private:
     pz_ctx* ctx_ = nullptr;
-    size_t zero_cells_ = 0;
-    unsigned L_ = 0, W_ = 64, words_ = 0;
+    size_t zero_cells_ = 0, advice_cells_ = 0, lookup_cells_ = 0;
+    unsigned L_ = 0, W_ = 64, words_ = 0, lookup_bits_ = 0;
+    std::vector<OpRec> ops_;
     BigUint modulus_;
     std::vector<uint64_t> tape_;
 };
@@ -92,9 +118,17 @@ class Context {
 struct Fresh {};
 struct Muled {};
 
-struct RefreshAux {
+struct RefreshAux {   // paillier.rs:40-44
     unsigned limb_bits, num_limbs_l, num_limbs_r;
-    static RefreshAux new_(unsigned limb_bits, unsigned l, unsigned r) { return RefreshAux{limb_bits, l, r}; }
+    std::vector<uint8_t> increased_limbs_vec;   // extra limbs each product limb's maximal value spills into
+    static RefreshAux new_(unsigned limb_bits, unsigned l, unsigned r) {
+        RefreshAux a{limb_bits, l, r, std::vector<uint8_t>(256)};
+        uint32_t n = 0;
+        int rc = pz_refresh_aux(limb_bits, l, r, a.increased_limbs_vec.data(), 256, &n);
+        if (rc != PZ_OK) throw std::runtime_error(std::string("RefreshAux::new: ") + pz_strerror(rc));
+        a.increased_limbs_vec.resize(n);
+        return a;
+    }
 };
 
 template <class Kind> class AssignedBigUint {
@@ -135,18 +169,34 @@ class BigUintChip {
         if (limb_bits < 16 || limb_bits > 90) throw std::invalid_argument("limb_bits outside 16..90 (K4 carries a limb in two 64-bit words)");
         return BigUintChip{range, limb_bits};
     }
-    // assign_integer(ctx, Value::known(v), bit_len): bit_len must be a multiple of limb_bits, v must fit
-    Result<AssignedBigUint<Fresh>> assign_integer(Context&, const BigUint& v, unsigned bit_len) const {
+    // assign_integer(ctx, Value::known(v), bit_len): bit_len must be a multiple of limb_bits, v must fit (its limbs'
+    // range checks would fail otherwise); pushes the limbs and one range check each
+    Result<AssignedBigUint<Fresh>> assign_integer(Context& ctx, const BigUint& v, unsigned bit_len) const {
         if (bit_len % limb_bits) return Result<AssignedBigUint<Fresh>>::Err(PZ_ERR_INVALID, "bit_len % limb_bits != 0");
         if (v.bits() > bit_len) return Result<AssignedBigUint<Fresh>>::Err(PZ_ERR_RANGE, "value exceeds bit_len");
+        ctx.set_shape(limb_bits, range->lookup_bits);
+        ctx.record(Context::ASSIGN, bit_len / limb_bits);
         return Result<AssignedBigUint<Fresh>>::Ok(AssignedBigUint<Fresh>(v, bit_len / limb_bits, limb_bits));
     }
-    Result<AssignedBigUint<Muled>> square(Context&, const AssignedBigUint<Fresh>& a) const {  // paillier.rs:39
+    // square = mul(a, a): unreduced limb products (2 l - 1 limbs of up to 2 W + log2(l) bits); the cells are the limb
+    // convolution K4 writes on the device
+    Result<AssignedBigUint<Muled>> square(Context& ctx, const AssignedBigUint<Fresh>& a) const {  // paillier.rs:39
+        ctx.record(Context::SQUARE, a.num_limbs());
+        unsigned lg = 0;
+        while ((1u << lg) < a.num_limbs()) ++lg;
         return Result<AssignedBigUint<Muled>>::Ok(AssignedBigUint<Muled>(a.value() * a.value(), 2 * a.num_limbs() - 1,
-                                                                         2 * limb_bits + 8));
+                                                                         2 * limb_bits + lg));
     }
-    Result<AssignedBigUint<Fresh>> refresh(Context&, const AssignedBigUint<Muled>& a, const RefreshAux& aux) const {  // :45
-        return Result<AssignedBigUint<Fresh>>::Ok(AssignedBigUint<Fresh>(a.value(), aux.num_limbs_l + aux.num_limbs_r, limb_bits));
+    // refresh: cut every product limb back to limb_bits-wide limbs, carrying into the limbs above as aux says
+    Result<AssignedBigUint<Fresh>> refresh(Context& ctx, const AssignedBigUint<Muled>& a, const RefreshAux& aux) const {  // :45
+        using R = Result<AssignedBigUint<Fresh>>;
+        if (aux.limb_bits != limb_bits) return R::Err(PZ_ERR_INVALID, "refresh: aux.limb_bits != limb_bits");
+        if (a.num_limbs() != aux.num_limbs_l + aux.num_limbs_r - 1) return R::Err(PZ_ERR_INVALID, "refresh: limb count does not match aux");
+        if (aux.num_limbs_l != aux.num_limbs_r) return R::Err(PZ_ERR_UNSUPPORTED, "refresh: only squares are expanded on the device");
+        const unsigned fresh = (unsigned)aux.increased_limbs_vec.size();
+        if (a.value().bits() > (size_t)fresh * limb_bits) return R::Err(PZ_ERR_RANGE, "refresh: value exceeds the refreshed limbs");
+        ctx.record(Context::REFRESH, aux.num_limbs_l);
+        return R::Ok(AssignedBigUint<Fresh>(a.value(), fresh, limb_bits));
     }
     // mul_mod(ctx, a, b, n): witness (q, r) from the K3 kernel, step recorded for K4
     Result<AssignedBigUint<Fresh>> mul_mod(Context& ctx, const AssignedBigUint<Fresh>& a, const AssignedBigUint<Fresh>& b,
@@ -173,6 +223,8 @@ class BigUintChip {
                                                      const AssignedBigUint<Fresh>& n) const {
         const unsigned L = n.num_limbs();
         if (a.num_limbs() != L) return Result<AssignedBigUint<Fresh>>::Err(PZ_ERR_INVALID, "limb count mismatch");
+        (void)ctx.load_constant_one();   // acc = assign_constant(1) ...
+        (void)ctx.load_zero();           // ... extended with the zero cell
         const unsigned Wd = n.num_words();
         std::vector<uint64_t> av = a.words(), nv = n.words(), res(Wd);
         const unsigned el = e.l.empty() ? 1 : (unsigned)e.l.size();
@@ -187,8 +239,14 @@ class BigUintChip {
         if (ns) ctx.push_steps(steps, Wd, L, limb_bits, n.value());
         return Result<AssignedBigUint<Fresh>>::Ok(AssignedBigUint<Fresh>(BigUint::from_limbs(res.data(), Wd), L, limb_bits));
     }
-    Result<bool> assert_equal_fresh(Context&, const AssignedBigUint<Fresh>& a, const AssignedBigUint<Fresh>& b) const {
-        if (a.value() != b.value()) return Result<bool>::Err(PZ_ERR_INVALID, "assert_equal_fresh: constraint not satisfied");
+    // is_equal_fresh limb by limb (load_zero, load_constant(1), is_equal + and per limb), result constrained to 1
+    Result<bool> assert_equal_fresh(Context& ctx, const AssignedBigUint<Fresh>& a, const AssignedBigUint<Fresh>& b) const {
+        const unsigned max_n = std::max(a.num_limbs(), b.num_limbs());
+        ctx.record(Context::ASSERT_EQUAL, max_n);
+        std::vector<BigUint> al = a.extend_limbs(max_n - a.num_limbs(), 0).limbs(), bl = b.extend_limbs(max_n - b.num_limbs(), 0).limbs();
+        bool eq = true;
+        for (unsigned i = 0; i < max_n; ++i) eq = eq && al[i] == bl[i];
+        if (!eq) return Result<bool>::Err(PZ_ERR_INVALID, "assert_equal_fresh: constraint not satisfied");
         return Result<bool>::Ok(true);
     }
 };
@@ -308,12 +366,33 @@ inline void paillier_enc_add_test(Context& ctx, const RangeChip& range, const Pa
     biguint_chip.assert_equal_fresh(ctx, res, res_assigned).unwrap();
 }
 
-// K4 over the recorded tape: returns the number of advice / lookup cells written to the device buffers the
-// caller provides (hipMalloc'ed; sizes from pz_witness_cells_per_step * n_steps).  d_* may be null to query.
+// K4 over the mul_mod steps alone (the bulk of the stream; the caller places the buffers)
 inline int synthesize_witness(Context& ctx, const RangeChip& range, uint64_t* d_steps, uint64_t* d_modulus, uint64_t* d_advice,
                               uint64_t* d_lookup) {
     return pz_witness_expand_dev(ctx.raw(), ctx.limbs(), ctx.limb_bits(), range.lookup_bits, d_steps, ctx.n_steps(), d_modulus, d_advice,
                                  d_lookup);
+}
+
+// The whole tape of one of the two drivers expanded on the device (pz_circuit_expand_dev).  kind 0 = paillier_enc_test
+// (x, y = m, r), 1 = paillier_enc_add_test (x, y = c1, c2).  The tape must have the driver's shape; its cell total equals
+// pz_circuit_cells (checked).  d_steps / d_modulus / d_advice / d_lookup: device buffers of the caller.
+inline int synthesize_circuit(Context& ctx, int kind, unsigned enc_bits, const BigUint& n, const BigUint& g, const BigUint& x,
+                              const BigUint& y, const BigUint& res, size_t n_steps_g, size_t n_steps_r, uint64_t* d_steps,
+                              uint64_t* d_modulus, uint64_t* d_advice, uint64_t* d_lookup) {
+    const unsigned W = ctx.limb_bits(), Ln = enc_bits / W, wn = (Ln * W + 63) / 64, wr = (2 * Ln * W + 63) / 64;
+    size_t a = 0, l = 0;
+    int rc = pz_circuit_cells(kind, Ln, W, ctx.lookup_bits(), n_steps_g, n_steps_r, &a, &l);
+    if (rc != PZ_OK) return rc;
+    if (a != ctx.advice_cells() || l != ctx.lookup_cells()) return PZ_ERR_INVALID;   // the tape is not this driver's
+    std::vector<uint64_t> in;
+    for (const BigUint* v : {&n, &g, &x, &y}) {
+        std::vector<uint64_t> w = v->to_limbs(wn);
+        in.insert(in.end(), w.begin(), w.end());
+    }
+    std::vector<uint64_t> w = res.to_limbs(wr);
+    in.insert(in.end(), w.begin(), w.end());
+    return pz_circuit_expand_dev(ctx.raw(), kind, Ln, W, ctx.lookup_bits(), in.data(), d_steps, n_steps_g, n_steps_r, d_modulus,
+                                 d_advice, d_lookup);
 }
 
 }  // namespace pz

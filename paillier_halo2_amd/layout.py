@@ -79,6 +79,85 @@ def mul_mod_cells(limbs: int, limb_bits: int, lookup_bits: int) -> StepCells:
     return StepCells(off, lookups, seg)
 
 
+def refresh_aux(limb_bits: int, num_limbs_l: int, num_limbs_r: int):
+    """RefreshAux::new(limb_bits, l, r).increased_limbs_vec (paillier.rs:40-44): how many further limbs the maximal
+    value of each product limb spills into when it is cut back to limb_bits-wide limbs; its length is the limb count
+    of the refreshed integer (l + r for the shapes of this circuit)."""
+    mx = (1 << limb_bits) - 1
+    d = num_limbs_l + num_limbs_r - 1
+    muled = [sum(1 for j in range(num_limbs_l) if 0 <= i - j < num_limbs_r) * mx * mx for i in range(d)]
+    inc = []
+    cur = 0
+    while cur < len(muled):
+        chunks = max(1, -(-muled[cur].bit_length() // limb_bits))
+        inc.append(chunks - 1)
+        val = muled[cur]
+        for i in range(chunks):
+            piece, val = val & mx, val >> limb_bits
+            if cur + i < len(muled):
+                muled[cur + i] = piece if i == 0 else muled[cur + i] + piece
+            else:
+                muled.append(piece)
+        cur += 1
+    return inc
+
+
+def assign_cells(num_limbs: int, limb_bits: int, lookup_bits: int):
+    """assign_integer: the limbs as witnesses, then one range check each -> (advice, lookup)"""
+    a, l = range_check_cells(limb_bits, lookup_bits)
+    return num_limbs * (1 + a), num_limbs * l
+
+
+def square_cells(limbs: int) -> int:
+    """square(n) = mul(n, n): load_zero + truncated mul_no_carry over 2 limbs - 1 product limbs"""
+    return 1 + sum(1 + 3 * (i + 1) for i in range(2 * limbs - 1))
+
+
+def refresh_cells(inc, limb_bits: int, lookup_bits: int):
+    a, l = range_check_cells(limb_bits, lookup_bits)
+    adv = 1 + sum((k + 1) * 22 + k * 4 for k in inc) + len(inc) * a
+    return adv, len(inc) * l
+
+
+def assert_equal_cells(limbs: int) -> int:
+    return 2 + 16 * limbs
+
+
+@dataclass
+class CircuitCells:
+    advice: int
+    lookup: int
+    seg: dict   # name -> (advice offset, lookup offset), in emission order
+
+
+def circuit_cells(kind: str, limbs_n: int, limb_bits: int, lookup_bits: int, n_steps_g: int = 0, n_steps_r: int = 0) -> CircuitCells:
+    """The whole cell stream of paillier_enc_test (bench.rs:33-75, kind 'encrypt') or paillier_enc_add_test
+    (bench.rs:77-117, kind 'add'), operation by operation in call order -- what pz_circuit_expand_dev writes."""
+    Ln, L = limbs_n, 2 * limbs_n
+    mm = mul_mod_cells(L, limb_bits, lookup_bits)
+    seg, a, l = {}, 0, 0
+
+    def put(name, da, dl=0):
+        nonlocal a, l
+        seg[name] = (a, l)
+        a += da
+        l += dl
+
+    for name in ("assign_n", "assign_g", "assign_x", "assign_y"):
+        put(name, *assign_cells(Ln, limb_bits, lookup_bits))
+    put("square", square_cells(Ln))
+    put("refresh", *refresh_cells(refresh_aux(limb_bits, Ln, Ln), limb_bits, lookup_bits))
+    put("load_zero", 1)
+    if kind == "encrypt":
+        put("pow_g", 2 + n_steps_g * mm.advice, n_steps_g * mm.lookup)
+        put("pow_r", 2 + n_steps_r * mm.advice, n_steps_r * mm.lookup)
+    put("final", mm.advice, mm.lookup)
+    put("assign_res", *assign_cells(L, limb_bits, lookup_bits))
+    put("assert_equal", assert_equal_cells(L))
+    seg["end"] = (a, l)
+    return CircuitCells(a, l, seg)
+
+
 @dataclass
 class ProofShape:
     k: int
@@ -95,22 +174,30 @@ class ProofShape:
     msm_full: int         # permuted lookup columns, lookup/permutation products, h pieces, openings
     polys: int            # polynomials taken Lagrange -> coeff -> extended coset
     ext_k: int
+    advice_cells: int = 0   # the whole circuit's stream (circuit_cells)
+    lookup_cells: int = 0
 
 
 def encrypt_proof_shape(enc_bits: int, k: int, n_steps: int, limb_bits: int = 64, lookup_bits: int | None = None,
-                        blinding_rows: int = 10, max_degree: int = 4) -> ProofShape:
-    """Column / MSM / NTT counts of one encrypt proof (SURVEY.md section 3.4's table, made concrete)."""
+                        blinding_rows: int = 10, max_degree: int = 4, kind: str = "encrypt", n_steps_g: int | None = None) -> ProofShape:
+    """Column / MSM / NTT counts of one encrypt (or add) proof (SURVEY.md section 3.4's table, made concrete).  n_steps
+    counts every mul_mod of the circuit (both chains + the final one); the split between the chains only moves the four
+    constant cells of pow_mod_fixed_exp and does not change any count."""
     if lookup_bits is None:
         lookup_bits = k - 1  # the reference's pattern: paillier.rs:168-169, bench.rs:162-163
-    L = 2 * (enc_bits // limb_bits)
+    Ln = enc_bits // limb_bits
+    L = 2 * Ln
     sc = mul_mod_cells(L, limb_bits, lookup_bits)
     rows = (1 << k) - blinding_rows
-    # the four input assignments + n^2 square/refresh + the result assignment are < 1 step's worth
-    fixed_cells = sc.advice
-    A = math.ceil((n_steps * sc.advice + fixed_cells) / rows)
-    Lk = math.ceil((n_steps * sc.lookup + 8 * L) / rows)
+    if kind == "encrypt":
+        ng = (n_steps - 1) // 2 if n_steps_g is None else n_steps_g
+        cc = circuit_cells("encrypt", Ln, limb_bits, lookup_bits, ng, n_steps - 1 - ng)
+    else:
+        cc = circuit_cells("add", Ln, limb_bits, lookup_bits)
+    A = math.ceil(cc.advice / rows)
+    Lk = math.ceil(cc.lookup / rows)
     P = math.ceil((A + Lk + 1) / (max_degree - 2))
     return ProofShape(k=k, lookup_bits=lookup_bits, limbs=L, n_steps=n_steps, cells_per_step=sc.advice,
                       lookups_per_step=sc.lookup, advice_cols=A, lookup_cols=Lk, perm_cols=P, msm_witness=A,
                       msm_lookup=Lk, msm_full=3 * Lk + P + 1 + (max_degree - 1) + 2, polys=A + 4 * Lk + P,
-                      ext_k=k + 2)
+                      ext_k=k + 2, advice_cells=cc.advice, lookup_cells=cc.lookup)

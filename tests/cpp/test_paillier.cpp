@@ -10,6 +10,8 @@
 #include <cstring>
 #include <random>
 
+#include <hip/hip_runtime_api.h>
+
 #include "../../paillier_halo2_amd/host/paillier_chip.hpp"
 
 extern "C" int ora_paillier_enc(uint32_t Ln, const uint64_t* n, const uint64_t* g, const uint64_t* m, const uint64_t* r, uint64_t* c_out);
@@ -45,17 +47,65 @@ static int failures = 0;
         else std::printf("ok   %s\n", what);                       \
     } while (0)
 
+static size_t popcount(const BigUint& v) {
+    size_t p = 0;
+    for (auto w : v.l) p += (size_t)__builtin_popcountll(w);
+    return p;
+}
+
+// the tape the driver recorded == the whole circuit's stream (layout.py::circuit_cells / pz_circuit_cells), and its
+// expansion on the device ends in assert_equal_fresh's result bit: Montgomery 1 for the honest witness
+static void check_tape(Context& ctx, int kind, unsigned enc_bits, const BigUint& n, const BigUint& g, const BigUint& x, const BigUint& y,
+                       const BigUint& res, size_t ng, size_t nr, const char* what) {
+    static const uint64_t ONE[4] = {0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL};
+    const unsigned W = ctx.limb_bits(), Ln = enc_bits / W;
+    size_t a = 0, l = 0;
+    int rc = pz_circuit_cells(kind, Ln, W, ctx.lookup_bits(), ng, nr, &a, &l);
+    char name[160];
+    std::snprintf(name, sizeof name, "%s: tape of %zu operations = %zu advice + %zu lookup cells == pz_circuit_cells", what, ctx.ops().size(),
+                  ctx.advice_cells(), ctx.lookup_cells());
+    CHECK(rc == PZ_OK && a == ctx.advice_cells() && l == ctx.lookup_cells(), name);
+    // operation order of the driver: 4 assigns, square, refresh, load_zero, [const, zero, steps] x 2, final step, assign, assert
+    std::vector<int> want = {0, 0, 0, 0, 1, 2, 3};
+    if (kind == 0) want.insert(want.end(), {3, 3, 4, 3, 3, 4});   // the final mul_mod merges into the r^n run of steps
+    else want.push_back(4);
+    want.insert(want.end(), {0, 5});
+    std::vector<int> got;
+    for (auto& o : ctx.ops()) got.push_back((int)o.op);
+    CHECK(got == want, "operation order of the tape (bench.rs:33-75 / 77-117, paillier.rs:32-85)");
+    uint64_t *d_steps = nullptr, *d_mod = nullptr, *d_adv = nullptr, *d_lk = nullptr;
+    std::vector<uint64_t> mod = ctx.modulus().to_limbs(ctx.words());
+    bool ok = hipMalloc((void**)&d_steps, ctx.tape().size() * 8) == hipSuccess && hipMalloc((void**)&d_mod, mod.size() * 8) == hipSuccess &&
+              hipMalloc((void**)&d_adv, a * 32) == hipSuccess && hipMalloc((void**)&d_lk, l * 32 + 32) == hipSuccess;
+    ok = ok && hipMemcpy(d_steps, ctx.tape().data(), ctx.tape().size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(d_mod, mod.data(), mod.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+    uint64_t last[4] = {0, 0, 0, 0}, last_bad[4] = {1, 1, 1, 1};
+    if (ok) {
+        ok = synthesize_circuit(ctx, kind, enc_bits, n, g, x, y, res, ng, nr, d_steps, d_mod, d_adv, d_lk) == PZ_OK && pz_sync(ctx.raw()) == PZ_OK &&
+             hipMemcpy(last, d_adv + 4 * (a - 1), 32, hipMemcpyDeviceToHost) == hipSuccess;
+        BigUint wrong = res + BigUint(1);
+        ok = ok && synthesize_circuit(ctx, kind, enc_bits, n, g, x, y, wrong, ng, nr, d_steps, d_mod, d_adv, d_lk) == PZ_OK && pz_sync(ctx.raw()) == PZ_OK &&
+             hipMemcpy(last_bad, d_adv + 4 * (a - 1), 32, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(d_steps); (void)hipFree(d_mod); (void)hipFree(d_adv); (void)hipFree(d_lk);
+    CHECK(ok && std::memcmp(last, ONE, 32) == 0, "device expansion of the whole tape ends in assert_equal_fresh == 1");
+    CHECK(ok && (last_bad[0] | last_bad[1] | last_bad[2] | last_bad[3]) == 0, "a wrong `res` expands to assert_equal_fresh == 0");
+}
+
 static void test_paillier_encryption(unsigned enc_bits, unsigned lookup_bits) {
     Context ctx(0);
     RangeChip range{lookup_bits};
     BigUint n = gen_biguint(enc_bits), g = gen_biguint(enc_bits), m = gen_biguint(enc_bits), r = gen_biguint(enc_bits);
     if (n.is_zero()) n = BigUint(3);
+    if (enc_bits > 512) m = m.low_bits(48);   // keeps the 2048-bit tape's cell stream (12.7 GB at full width) small
     BigUint res = oracle_enc(n, g, m, r, enc_bits / 64);
     paillier_enc_test(ctx, range, PaillierEncryptionInput{enc_bits, 64, n, g, m, r, res});  // throws on any mismatch
     char name[96];
     std::snprintf(name, sizeof name, "paillier_enc_test enc_bits=%u (%zu mul_mod steps on the tape)", enc_bits, ctx.n_steps());
-    CHECK(ctx.n_steps() == m.bits() + n.bits() + (size_t)[&] { size_t p = 0; for (auto w : m.l) p += __builtin_popcountll(w); for (auto w : n.l) p += __builtin_popcountll(w); return p; }() + 1, name);
+    const size_t ng = m.bits() + popcount(m), nr = n.bits() + popcount(n);
+    CHECK(ctx.n_steps() == ng + nr + 1, name);
     CHECK(paillier_enc_native(ctx, n, g, m, r) == res, "paillier_enc_native == oracle");
+    if (enc_bits <= 512 || nr < 4200) check_tape(ctx, 0, enc_bits, n, g, m, r, res, ng, nr, "paillier_enc_test");
 }
 
 static void test_encryption_addition(unsigned enc_bits, unsigned lookup_bits, unsigned limb_bits = 64) {
@@ -70,6 +120,7 @@ static void test_encryption_addition(unsigned enc_bits, unsigned lookup_bits, un
                   limb_bits, ctx.limbs(), ctx.words());
     CHECK(ctx.n_steps() == 1 && ctx.limbs() == 2 * enc_bits / limb_bits && ctx.limb_bits() == limb_bits, name);
     CHECK(paillier_add_native(ctx, n, c1, c2) == res, "paillier_add_native == oracle");
+    check_tape(ctx, 1, enc_bits, n, g, c1, c2, res, 0, 0, "paillier_enc_add_test");
 }
 
 static void test_error_behaviour() {

@@ -796,3 +796,77 @@ def test_fp_mul_variants_probe(eng, cref):
         rates[name] = blocks * 256 * iters * 2 / (ms * 1e-3) / 1e9
     print("Fq products per second (G/s):", {k: round(v, 1) for k, v in rates.items()})
     assert all(v > 10 for v in rates.values())
+
+
+# ------------------------------------------------------------------------------------------ the whole circuit (row a6)
+def _circuit_inputs(cref, n, g, x, y, res, Ln, W):
+    wn, wr = -(-Ln * W // 64), -(-2 * Ln * W // 64)
+    return np.concatenate([cref.int_to_limbs(v, wn) for v in (n, g, x, y)] + [cref.int_to_limbs(res, wr)])
+
+
+@pytest.mark.parametrize("kind,bits,W,lb", [("encrypt", 128, 64, 15),     # paillier.rs:113-182 (k = 16, lookup_bits 15)
+                                            ("add", 264, 88, 15),         # paillier.rs:184-259: 264-bit key on 88-bit limbs
+                                            ("encrypt", 128, 64, 13),     # bench.rs:137-179 (k = 14, lookup_bits 13)
+                                            ("add", 128, 64, 13),         # bench.rs:181-222
+                                            ("add", 2048, 64, 14),        # BASELINE config c3
+                                            ("encrypt", 192, 32, 9)])
+def test_whole_circuit_cell_stream(eng, cref, kind, bits, W, lb):
+    """Every cell of the drivers paillier_enc_test / paillier_enc_add_test (bench.rs:33-117) -- the input assignments,
+    square + refresh of n, load_zero, both pow_mod_fixed_exp chains, the final mul_mod, the assignment of res and
+    assert_equal_fresh -- written on the device (K3 steps -> pz_circuit_expand_dev) vs the oracle's expansion, bit for
+    bit; the gate identity holds on every enabled window of the GPU-written stream (MockProver analogue)."""
+    import torch
+
+    from paillier_halo2_amd import layout
+
+    rng = random.Random(bits * 131 + W + lb)
+    Ln = bits // W
+    L = 2 * Ln
+    wn, wr = -(-Ln * W // 64), -(-L * W // 64)
+    n, g, x, y = (rng.getrandbits(bits) for _ in range(4))
+    n |= 1
+    if kind == "encrypt":
+        x &= (1 << min(bits, 40)) - 1     # a short message keeps the g^m chain (and the oracle's Python expansion) small
+        n &= (1 << bits) - 1
+        res = P.paillier_enc_native(n, g, x, y)
+        c, sg, sr, fin = P.encrypt_trace(n, g, x, y)
+        steps_int = sg + sr + [fin]
+        ng, nr = len(sg), len(sr)
+        # the steps come from the K3 kernels
+        arr = lambda v: cref.int_to_limbs(v, wn)
+        if W == 64:
+            cc, steps, ngd, nrd = eng.paillier_encrypt(Ln, arr(n), arr(g), arr(x), arr(y))
+            assert (int(ngd[0]), int(nrd[0])) == (ng, nr) and cref.limbs_to_int(cc[0]) == res
+            steps = steps[0, : ng + nr + 1]
+        else:   # other limb widths: the words of the step records are still 64-bit (K3 works on words)
+            steps = np.stack([np.stack([cref.int_to_limbs(v, wr) for v in st]) for st in steps_int])
+    else:
+        res = P.paillier_add_native(n, x, y)
+        c, fin = P.add_trace(n, x, y)
+        ng = nr = 0
+        q, rem = eng.mul_mod(wr, cref.int_to_limbs(x, wr), cref.int_to_limbs(y, wr), cref.int_to_limbs(n * n, wr))
+        assert (cref.limbs_to_int(q), cref.limbs_to_int(rem)) == (fin[2], fin[3])
+        steps = np.stack([cref.int_to_limbs(v, wr) for v in (x, y, cref.limbs_to_int(q), cref.limbs_to_int(rem))]).reshape(1, 4, wr)
+    adv_n, lk_n = eng.circuit_cells(0 if kind == "encrypt" else 1, Ln, W, lb, ng, nr)
+    cc_l = layout.circuit_cells(kind, Ln, W, lb, ng, nr)
+    assert (adv_n, lk_n) == (cc_l.advice, cc_l.lookup)
+    d_steps = torch.from_numpy(np.ascontiguousarray(steps).astype(np.int64)).cuda()
+    d_mod = torch.from_numpy(cref.int_to_limbs(n * n, wr).astype(np.int64)).cuda()
+    for res_in in (res, res ^ 2):     # the honest witness, then a wrong `res` (the circuit must come out unsatisfied)
+        d_adv = torch.zeros((adv_n, 4), dtype=torch.int64, device="cuda")
+        d_lk = torch.zeros((lk_n, 4), dtype=torch.int64, device="cuda")
+        eng.circuit_expand_dev(0 if kind == "encrypt" else 1, Ln, W, lb, _circuit_inputs(cref, n, g, x, y, res_in, Ln, W),
+                               d_steps.data_ptr(), ng, nr, d_mod.data_ptr(), d_adv.data_ptr(), d_lk.data_ptr())
+        eng.sync()
+        got_adv = cref.fr_mont_to_ints(d_adv.cpu().numpy().astype(np.uint64))
+        got_lk = cref.fr_mont_to_ints(d_lk.cpu().numpy().astype(np.uint64))
+        want_adv, want_lk, seg = P.expand_circuit_cells(kind, n, g, x, y, res_in, bits, W, lb)
+        assert {k: v for k, v in seg.items() if k not in ("satisfied",)} == dict(cc_l.seg), "segment offsets"
+        if got_adv != want_adv:
+            bad = [k for k in range(len(want_adv)) if got_adv[k] != want_adv[k]]
+            raise AssertionError("%d advice cells differ, first at %d; segments %s" % (len(bad), bad[0], cc_l.seg))
+        assert got_lk == want_lk
+        gates, end = P.gate_offsets_circuit(kind, bits, W, lb, ng, nr)
+        assert end == adv_n and P.check_gates(got_adv, gates) == []      # every gate holds either way ...
+        assert max(got_lk) < (1 << lb)
+        assert seg["satisfied"] == (res_in == res) and got_adv[-1] == (1 if res_in == res else 0)   # ... the final bit says it
