@@ -202,10 +202,13 @@ int pz_circuit_cells(int kind, uint32_t limbs_n, uint32_t limb_bits, uint32_t lo
                      size_t n_steps_r, size_t* advice_cells, size_t* lookup_cells);
 /* inputs (HOST): n | g | x | y as ceil(limbs_n*limb_bits/64) 64-bit words each, then res as ceil(2*limbs_n*limb_bits/64)
  * words.  d_steps (device): the n_steps_g + n_steps_r + 1 step records K3 produced (add: one record); the circuit's
- * result c is the last record's remainder.  d_modulus: n^2 (device).  d_lookup may be NULL. */
+ * result c is the last record's remainder.  d_modulus: n^2 (device).  d_lookup may be NULL.
+ * rows / col_stride cut the streams into the circuit's columns: cell c goes to column c / rows, row c % rows, columns
+ * col_stride elements apart (rows = 2^k - blinding rows, col_stride = 2^k: every column is then a 2^k-row Lagrange vector
+ * the commitment, product and NTT entry points take as it stands; rows above `rows` are not written).  0, 0 = dense. */
 int pz_circuit_expand_dev(pz_ctx* ctx, int kind, uint32_t limbs_n, uint32_t limb_bits, uint32_t lookup_bits,
                           const uint64_t* inputs, const uint64_t* d_steps, size_t n_steps_g, size_t n_steps_r,
-                          const uint64_t* d_modulus, uint64_t* d_advice, uint64_t* d_lookup);
+                          const uint64_t* d_modulus, uint64_t* d_advice, uint64_t* d_lookup, size_t rows, size_t col_stride);
 
 /* RefreshAux::new(limb_bits, l, r).increased_limbs_vec (paillier.rs:40-44): the number of further limbs each product limb's
  * maximal value spills into; *n_out entries (= the refreshed integer's limb count) are written. */
@@ -328,7 +331,8 @@ int pz_poly_div_linear_dev(pz_ctx* ctx, const uint64_t* d_coeffs, size_t n_cols,
  * ------------------------------------------------------------------------------------------- */
 /* HIP-event timing of the dominant kernel on the context's stream: accumulated since the last
  * reset, for kernel class `which` (0 = MSM bucket accumulation, 1 = NTT passes, 2 = modexp trace,
- * 3 = witness expand, 4 = MSM whole pipeline).  Enabled by pz_timing_enable(ctx, 1). */
+ * 3 = witness expand, 4 = MSM whole pipeline, 5 = MSM digit sort (histogram, scans, scatter), 6 = MSM bucket folds and
+ * reduction tree).  Enabled by pz_timing_enable(ctx, 1). */
 int pz_timing_enable(pz_ctx* ctx, int on);
 int pz_timing_reset(pz_ctx* ctx);
 int pz_timing_get(pz_ctx* ctx, int which, double* total_ms, uint64_t* launches);

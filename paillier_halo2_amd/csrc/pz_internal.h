@@ -11,7 +11,7 @@
 
 #include "../../include/pz.h"
 
-enum { PZ_T_MSM_ACC = 0, PZ_T_NTT = 1, PZ_T_TRACE = 2, PZ_T_EXPAND = 3, PZ_T_MSM_ALL = 4, PZ_T_COUNT = 5 };
+enum { PZ_T_MSM_ACC = 0, PZ_T_NTT = 1, PZ_T_TRACE = 2, PZ_T_EXPAND = 3, PZ_T_MSM_ALL = 4, PZ_T_MSM_SORT = 5, PZ_T_MSM_TREE = 6, PZ_T_COUNT = 7 };
 
 struct pz_pow_table {   // cached table init * base^i, i < n  (twiddles omega^i, coset powers s*g^i)
     uint64_t base[4];

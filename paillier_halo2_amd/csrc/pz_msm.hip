@@ -680,19 +680,23 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     hipStream_t st = ctx->stream;
     pz_timer tall(ctx, PZ_T_MSM_ALL);
     dim3 gs(n_slices, (unsigned)nc);
-    hipLaunchKernelGGL(k_msm_hist, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (u32*)hist, n_slices);
-    hipLaunchKernelGGL(k_msm_totals, dim3(pz_div_up(p.B, 256), (unsigned)nc), dim3(256), 0, st, (u32*)hist, n_slices, p,
-                       (u32*)totals);
-    hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)nc), dim3(256), 0, st, (const u32*)totals, p, (u32*)offs, (u32*)items,
-                       (u32*)heavy, heavy_cnt, (u32*)fold, fold_cnt, item_order, item_bucket);
-    hipLaunchKernelGGL(k_msm_scatter, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (const u32*)hist, n_slices,
-                       (const u32*)offs, (u32*)entries);
+    {
+        pz_timer tsort(ctx, PZ_T_MSM_SORT);
+        hipLaunchKernelGGL(k_msm_hist, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (u32*)hist, n_slices);
+        hipLaunchKernelGGL(k_msm_totals, dim3(pz_div_up(p.B, 256), (unsigned)nc), dim3(256), 0, st, (u32*)hist, n_slices, p,
+                           (u32*)totals);
+        hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)nc), dim3(256), 0, st, (const u32*)totals, p, (u32*)offs, (u32*)items,
+                           (u32*)heavy, heavy_cnt, (u32*)fold, fold_cnt, item_order, item_bucket);
+        hipLaunchKernelGGL(k_msm_scatter, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (const u32*)hist, n_slices,
+                           (const u32*)offs, (u32*)entries);
+    }
     {
         pz_timer tacc(ctx, PZ_T_MSM_ACC);
         hipLaunchKernelGGL(k_msm_accumulate, dim3((unsigned)nc, pz_div_up(p.max_items, 256)), dim3(256), 0, st,
                            (const G1Aff64*)bases->d_table, p, (const u32*)offs, (const u32*)items,
                            (const u32*)item_order, (const u32*)item_bucket, (const u32*)entries, (G1X29Raw*)partials);
     }
+    pz_timer ttree(ctx, PZ_T_MSM_TREE);
     hipLaunchKernelGGL(k_msm_bucket_sum, dim3((unsigned)nc, pz_div_up(p.B, 256)), dim3(256), 0, st, p, (const u32*)items,
                        (const u32*)fold, (const u32*)fold_cnt, (G1X29Raw*)partials);
     // heavy buckets are few per column in a column batch, but a single large MSM makes every bucket heavy:

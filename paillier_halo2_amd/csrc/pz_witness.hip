@@ -161,6 +161,22 @@ __device__ __forceinline__ void limb_extract(const u64* __restrict__ words, unsi
     out[1] = v.w[1];
 }
 
+// Where a cell of the stream lives: the stream is cut into the circuit's columns of `rows` usable rows, and a column
+// may be stored with a larger stride (2^k: room for the blinding rows) -- cell c sits at c + (c / rows) * pad.
+// rows == 0: the stream is dense.
+struct CellPtr {
+    Fr* base;
+    size_t idx, rows, pad;
+    __device__ __forceinline__ CellPtr operator+(size_t o) const {
+        CellPtr r = *this;
+        r.idx += o;
+        return r;
+    }
+    __device__ __forceinline__ explicit operator bool() const { return base != nullptr; }
+    __device__ __forceinline__ Fr* addr() const { return base + idx + (rows ? (idx / rows) * pad : 0); }
+};
+__device__ __forceinline__ void fp_store(const CellPtr& p, const Fr& v) { fp_store(p.addr(), v); }
+
 struct ExpP {
     unsigned L, D, lb;
     unsigned W, L64;                          // circuit limb width; 64-bit words per big integer of a step record
@@ -169,6 +185,8 @@ struct ExpP {
     size_t off_assign, off_ab, off_qn, off_add, off_eq, off_lt, cells;
     size_t lk_assign, lk_eq, lk_lt, lookups;
     u64 max_w[3];  // L*(2^W-1)^2 + (2^W-1)
+    size_t cell0, lk0;        // stream index of this launch's first advice / lookup cell
+    size_t rows, pad;         // column cut of the stream (CellPtr); 0, 0 = dense
 };
 
 // position p of RangeChip::range_check(x, bits): advice pattern
@@ -250,8 +268,8 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
     const bool wide = W > 64;
     const size_t step = blockIdx.x;
     const u64* st = steps + step * 4 * (size_t)P.L64;
-    Fr* adv = advice ? advice + step * P.cells : nullptr;
-    Fr* lk = lookup ? lookup + step * P.lookups : nullptr;
+    const CellPtr adv{advice, P.cell0 + step * P.cells, P.rows, P.pad};
+    const CellPtr lk{lookup, P.lk0 + step * P.lookups, P.rows, P.pad};
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const U192 MAXV = u_make(P.max_w[0], P.max_w[1], P.max_w[2]);
     const U192 BASE = u_shl(u_make(1), W);
@@ -278,7 +296,7 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
         const Fr* xm = which ? s_qm : s_am;
         const Fr* ym = which ? s_nm : s_bm;
         u64(*pout)[3] = which ? s_pqn : s_pab;
-        Fr* seg = adv ? adv + (which ? P.off_qn : P.off_ab) : nullptr;
+        const CellPtr seg = adv + (which ? P.off_qn : P.off_ab);
         if (seg && tid == 0) fp_store(seg, fp_zero<FrTag>());  // load_zero
         for (unsigned i = wave; i < D; i += EXP_THREADS / 64) {
             const size_t row = 1 + (size_t)i + 3 * ((size_t)i * (i + 1) / 2);
@@ -310,7 +328,7 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
                 if (j <= i) {
                     const U192 s = u_add(excl, pre[t]);
                     if (seg) {
-                        Fr* c = seg + row + 1 + 3 * (size_t)j;
+                        const CellPtr c = seg + row + 1 + 3 * (size_t)j;
                         fp_store(c, j < L ? xm[j] : fp_zero<FrTag>());
                         fp_store(c + 1, (i - j) < L ? ym[i - j] : fp_zero<FrTag>());
                         fp_store(c + 2, fr_from_u(s));
@@ -633,7 +651,8 @@ struct CircP {
 
 __global__ __launch_bounds__(256) void k_circuit_misc(CircP C, const u64* __restrict__ inputs /* n | g | x | y | res */,
                                                       const u64* __restrict__ cval /* the circuit's result, L64 words */,
-                                                      Fr* __restrict__ adv, Fr* __restrict__ lk) {
+                                                      Fr* __restrict__ advice, Fr* __restrict__ lookup) {
+    const CellPtr adv{advice, 0, C.e.rows, C.e.pad}, lk{lookup, 0, C.e.rows, C.e.pad};
     __shared__ u64 s_in[4][EXP_MAXL / 2 + 1][2];       // limbs of n, g, x, y
     __shared__ u64 s_res[CIRC_MAXF][2], s_c[CIRC_MAXF][2], s_fresh[CIRC_MAXF][2];
     __shared__ u64 s_sq[CIRC_MAXF][3];                 // limbs of n * n (unreduced convolution sums)
@@ -655,7 +674,7 @@ __global__ __launch_bounds__(256) void k_circuit_misc(CircP C, const u64* __rest
     if (tid == 0) fp_store(adv + C.a_square, fp_zero<FrTag>());
     for (unsigned i = tid; i < D; i += blockDim.x) {
         const size_t row = 1 + (size_t)i + 3 * ((size_t)i * (i + 1) / 2);
-        Fr* c = adv + C.a_square + row;
+        const CellPtr c = adv + C.a_square + row;
         fp_store(c, fp_zero<FrTag>());
         U192 sum = u_make(0);
         for (unsigned j = 0; j <= i; ++j) {
@@ -703,8 +722,8 @@ __global__ __launch_bounds__(256) void k_circuit_misc(CircP C, const u64* __rest
     for (unsigned which = 0; which < 5; ++which) {
         const unsigned nl = which < 4 ? Ln : nf;
         const u64(*X)[2] = which < 4 ? s_in[which] : s_res;
-        Fr* a = adv + (which < 4 ? C.a_assign[which] : C.a_res);
-        Fr* l = lk ? lk + (which < 4 ? C.l_assign[which] : C.l_res) : nullptr;
+        const CellPtr a = adv + (which < 4 ? C.a_assign[which] : C.a_res);
+        const CellPtr l = lk + (which < 4 ? C.l_assign[which] : C.l_res);
         for (unsigned t = tid; t < nl * (1 + C.rc_adv); t += blockDim.x) {
             Fr v;
             if (t < nl) v = fr_from_u(LIMB(X, t));
@@ -918,11 +937,15 @@ extern "C" int pz_circuit_cells(int kind, uint32_t limbs_n, uint32_t limb_bits, 
 
 extern "C" int pz_circuit_expand_dev(pz_ctx* ctx, int kind, uint32_t limbs_n, uint32_t limb_bits, uint32_t lookup_bits,
                                      const uint64_t* inputs, const uint64_t* d_steps, size_t n_steps_g, size_t n_steps_r,
-                                     const uint64_t* d_modulus, uint64_t* d_advice, uint64_t* d_lookup) {
+                                     const uint64_t* d_modulus, uint64_t* d_advice, uint64_t* d_lookup, size_t rows,
+                                     size_t col_stride) {
     if (!ctx || !inputs || !d_steps || !d_modulus || !d_advice) return PZ_ERR_INVALID;
+    if ((rows == 0) != (col_stride == 0) || col_stride < rows) return PZ_ERR_INVALID;
     CircP C;
     size_t a, l, so[6];
     PZCHK(make_circuit_params(kind, limbs_n, limb_bits, lookup_bits, n_steps_g, n_steps_r, C, &a, &l, so));
+    C.e.rows = rows;
+    C.e.pad = col_stride - rows;
     PZ_ENTER(ctx);
     const size_t in_words = 4 * (size_t)C.words_n + C.e.L64;
     void* d_in;
@@ -933,9 +956,13 @@ extern "C" int pz_circuit_expand_dev(pz_ctx* ctx, int kind, uint32_t limbs_n, ui
     const size_t runs[3] = {kind == 0 ? n_steps_g : 0, kind == 0 ? n_steps_r : 0, 1};
     size_t first = 0;
     for (int k = 0; k < 3; ++k) {
-        if (runs[k])
-            hipLaunchKernelGGL(k_witness_expand, dim3((unsigned)runs[k]), dim3(EXP_THREADS), 0, ctx->stream, C.e, d_steps + first * rec,
-                               d_modulus, (Fr*)d_advice + so[k], d_lookup ? (Fr*)d_lookup + so[3 + k] : (Fr*)nullptr);
+        if (runs[k]) {
+            ExpP P = C.e;
+            P.cell0 = so[k];
+            P.lk0 = so[3 + k];
+            hipLaunchKernelGGL(k_witness_expand, dim3((unsigned)runs[k]), dim3(EXP_THREADS), 0, ctx->stream, P, d_steps + first * rec,
+                               d_modulus, (Fr*)d_advice, (Fr*)d_lookup);
+        }
         first += runs[k];
     }
     // the circuit's result c = remainder of the last step (the final mul_mod)

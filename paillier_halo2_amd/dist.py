@@ -177,3 +177,101 @@ def bench_sharded_msm(eng, torch, dist, rank, world, log_n, steps, warmup, barri
                      "frac": ach / 8000.0, "traffic": None, "accumulate_ms_per_msm": acc_ms / max(1, steps)},
         "result_affine_x_limb0": int(aff[0]),
     }
+
+
+def emulate_sharded_msm(eng, torch, world: int, log_n: int, steps: int, warmup: int, log, scalars="uniform", share_window_bits=0):
+    """config c4 on ONE GPU: each of `world` ranks' shares of the 2^log_n-point MSM run in turn (window split and point
+    split), with per-share stage times from HIP events (digit sort, bucket accumulation, bucket folds + reduction tree) and
+    the device fold of the `world` partial points.  predicted_efficiency = T(one GPU, whole MSM) / (world * T(slowest
+    share + fold)): what an N-GPU run can reach at best (the 96-byte all-gather, tens of microseconds over xGMI, comes on
+    top and is not emulated).  The shares' results are folded and compared with the whole MSM."""
+    from . import engine as E
+
+    n = 1 << log_n
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(0x5045)
+
+    def rand_fr(count):
+        x = torch.randint(-(1 << 63), (1 << 63) - 1, (count, 4), dtype=torch.int64, device="cuda", generator=gen)
+        x[:, 3] &= 0x0FFFFFFFFFFFFFFF
+        return x
+
+    ks = rand_fr(n)
+    d_b = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    eng.g1_fixed_base_mul_dev(ks.data_ptr(), n, d_b.data_ptr())
+    eng.sync()
+    d_s = rand_fr(n)
+    if scalars == "witness":
+        cls = torch.rand(n, device="cuda", generator=gen)
+        d_s[:, 3] = 0
+        d_s[:, 2] = torch.where(cls >= 0.9, d_s[:, 2] & 0x7F, torch.zeros_like(d_s[:, 2]))
+        d_s[:, 1] = torch.where(cls >= 0.9, d_s[:, 1], torch.zeros_like(d_s[:, 1]))
+        d_s[:, 0] = torch.where(cls < 0.6, d_s[:, 0] & 0xFFFF, d_s[:, 0])
+        eng.fr_convert_dev(d_s.data_ptr(), n, True)
+    del ks
+    d_out = torch.zeros((1, 12), dtype=torch.int64, device="cuda")
+    d_parts = torch.zeros((world, 12), dtype=torch.int64, device="cuda")
+    eng.timing_enable(True)
+
+    def timed(fn):
+        """-> dict of ms per run: wall (device time between two events on the stream) + the library's stage classes"""
+        for _ in range(warmup):
+            fn()
+        eng.sync()
+        eng.timing_reset()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        out = {"total": e0.elapsed_time(e1) / steps}
+        for name, cls_ in (("sort", E.T_MSM_SORT), ("accumulate", E.T_MSM_ACC), ("tree", E.T_MSM_TREE)):
+            out[name] = eng.timing_get(cls_)[0] / steps
+        return out
+
+    tb = eng.load_bases_dev(d_b.data_ptr(), n)
+    full = timed(lambda: eng.msm_dev(tb, d_s.data_ptr(), 1, n, 4 * n, d_out.data_ptr()))
+    eng.sync()
+    ref = eng.g1_normalize(d_out.cpu().numpy().astype(np.uint64))[0]
+    res = {"full": full, "splits": {}}
+    t_fold = timed(lambda: eng.g1_sum_dev(d_parts.data_ptr(), world, d_out.data_ptr()))["total"]
+    # ---- window split
+    shares = []
+    for r in range(world):
+        lo, hi = window_range(tb.n_windows, r, world)
+        shares.append(timed(lambda: eng.msm_dev(tb, d_s.data_ptr(), 1, n, 4 * n, d_parts[r].data_ptr(), lo, hi)))
+    eng.g1_sum_dev(d_parts.data_ptr(), world, d_out.data_ptr())
+    eng.sync()
+    ok_w = bool(np.array_equal(eng.g1_normalize(d_out.cpu().numpy().astype(np.uint64))[0], ref))
+    worst = max(sh["total"] for sh in shares)
+    res["splits"]["windows"] = {"shares": shares, "slowest_share_ms": worst, "fold_ms": t_fold,
+                                "predicted_efficiency": full["total"] / (world * (worst + t_fold)), "equals_full_msm": ok_w}
+    tb.free()
+    # ---- point split: every rank's table holds its own n / world bases
+    shares = []
+    for r in range(world):
+        lo, hi = point_range(n, r, world)
+        tr = eng.load_bases_dev(d_b.data_ptr() + lo * 64, hi - lo, share_window_bits)
+        shares.append(timed(lambda: eng.msm_dev(tr, d_s.data_ptr() + lo * 32, 1, hi - lo, 4 * (hi - lo), d_parts[r].data_ptr())))
+        eng.sync()
+        tr.free()
+    eng.g1_sum_dev(d_parts.data_ptr(), world, d_out.data_ptr())
+    eng.sync()
+    ok_p = bool(np.array_equal(eng.g1_normalize(d_out.cpu().numpy().astype(np.uint64))[0], ref))
+    worst = max(sh["total"] for sh in shares)
+    res["splits"]["points"] = {"shares": shares, "slowest_share_ms": worst, "fold_ms": t_fold,
+                               "predicted_efficiency": full["total"] / (world * (worst + t_fold)), "equals_full_msm": ok_p}
+    eng.timing_enable(False)
+    best = max(res["splits"], key=lambda k: res["splits"][k]["predicted_efficiency"])
+    log("msm22 emulate-world %d: full %.2f ms; windows %.3f, points %.3f predicted efficiency" % (
+        world, full["total"], res["splits"]["windows"]["predicted_efficiency"], res["splits"]["points"]["predicted_efficiency"]))
+    return {
+        "metric": "predicted %d-GPU efficiency of one 2^%d-point MSM (each rank's share emulated on one GPU)" % (world, log_n),
+        "value": res["splits"][best]["predicted_efficiency"], "unit": "fraction of linear speed-up", "n_gpus": 1, "steps": steps,
+        "warmup": warmup, "ms_per_step": full["total"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u32 limbs (29-bit reduced radix, 254-bit modular integers)", "data": "synthetic",
+        "config": {"workload": "c4 emulated: single 2^%d-point MSM, %s scalars, world %d" % (log_n, "witness-like" if scalars == "witness" else "uniform", world),
+                   "best_split": best, "point_share_window_bits": share_window_bits or 16},
+        "emulation": res,
+    }

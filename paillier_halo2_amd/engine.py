@@ -181,6 +181,12 @@ class Engine:
         self._chk(self.L.pz_ntt_fr_batch(self.ctx, arr, len(cols), _ptr(w), log_n), "pz_ntt_fr_batch")
         return cols
 
+    def ntt_batch_inplace(self, cols: Sequence[np.ndarray], omega, log_n: int):
+        """host-pointer pz_ntt_fr_batch IN PLACE on the caller's arrays (uint64, contiguous): no staging copies on the host"""
+        arr = (VP * len(cols))(*[_ptr(c) for c in cols])
+        w = _np(omega).reshape(4)
+        self._chk(self.L.pz_ntt_fr_batch(self.ctx, arr, len(cols), _ptr(w), log_n), "pz_ntt_fr_batch")
+
     def ntt_dev(self, d_a: int, n_cols: int, col_stride_u64: int, omega, log_n: int, pre_coset_g=None,
                 post_scale=None):
         w = _np(omega).reshape(4)
@@ -305,11 +311,13 @@ class Engine:
         return a.value, l.value
 
     def circuit_expand_dev(self, kind: int, limbs_n: int, limb_bits: int, lookup_bits: int, inputs, d_steps: int, n_steps_g: int,
-                           n_steps_r: int, d_modulus: int, d_advice: int, d_lookup: int = 0):
-        """inputs: host uint64 array n | g | x | y | res (pz.h); writes the whole circuit's cell stream"""
+                           n_steps_r: int, d_modulus: int, d_advice: int, d_lookup: int = 0, rows: int = 0, col_stride: int = 0):
+        """inputs: host uint64 array n | g | x | y | res (pz.h); writes the whole circuit's cell stream, dense or cut into
+        columns of `rows` cells stored `col_stride` elements apart"""
         inp = np.ascontiguousarray(inputs, dtype=np.uint64).reshape(-1)
         self._chk(self.L.pz_circuit_expand_dev(self.ctx, kind, limbs_n, limb_bits, lookup_bits, _ptr(inp), VP(d_steps), n_steps_g,
-                                               n_steps_r, VP(d_modulus), VP(d_advice), VP(d_lookup)), "pz_circuit_expand_dev")
+                                               n_steps_r, VP(d_modulus), VP(d_advice), VP(d_lookup), rows, col_stride),
+                  "pz_circuit_expand_dev")
 
     # ------------------------------------------------------------------ "next" rows: SRS setup, evaluation at a point
     def srs_setup_g1_dev(self, k: int, s, omega, d_g: int = 0, d_g_lagrange: int = 0):
@@ -446,4 +454,4 @@ class Engine:
         return out
 
 
-T_MSM_ACC, T_NTT, T_TRACE, T_EXPAND, T_MSM_ALL = 0, 1, 2, 3, 4
+T_MSM_ACC, T_NTT, T_TRACE, T_EXPAND, T_MSM_ALL, T_MSM_SORT, T_MSM_TREE = 0, 1, 2, 3, 4, 5, 6

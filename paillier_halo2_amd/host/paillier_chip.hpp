@@ -392,7 +392,7 @@ inline int synthesize_circuit(Context& ctx, int kind, unsigned enc_bits, const B
     std::vector<uint64_t> w = res.to_limbs(wr);
     in.insert(in.end(), w.begin(), w.end());
     return pz_circuit_expand_dev(ctx.raw(), kind, Ln, W, ctx.lookup_bits(), in.data(), d_steps, n_steps_g, n_steps_r, d_modulus,
-                                 d_advice, d_lookup);
+                                 d_advice, d_lookup, 0, 0);
 }
 
 }  // namespace pz

@@ -870,3 +870,17 @@ def test_whole_circuit_cell_stream(eng, cref, kind, bits, W, lb):
         assert end == adv_n and P.check_gates(got_adv, gates) == []      # every gate holds either way ...
         assert max(got_lk) < (1 << lb)
         assert seg["satisfied"] == (res_in == res) and got_adv[-1] == (1 if res_in == res else 0)   # ... the final bit says it
+    # the same stream cut into the circuit's columns (rows usable rows each, stored 2^k apart): what the prover commits
+    rows, stride = 1000, 1024
+    ncol_a, ncol_l = -(-adv_n // rows), -(-lk_n // rows)
+    d_adv = torch.zeros((ncol_a * stride, 4), dtype=torch.int64, device="cuda")
+    d_lk = torch.zeros((ncol_l * stride, 4), dtype=torch.int64, device="cuda")
+    eng.circuit_expand_dev(0 if kind == "encrypt" else 1, Ln, W, lb, _circuit_inputs(cref, n, g, x, y, res, Ln, W),
+                           d_steps.data_ptr(), ng, nr, d_mod.data_ptr(), d_adv.data_ptr(), d_lk.data_ptr(), rows, stride)
+    eng.sync()
+    want_adv, want_lk, _ = P.expand_circuit_cells(kind, n, g, x, y, res, bits, W, lb)
+    for d_buf, want, nc in ((d_adv, want_adv, ncol_a), (d_lk, want_lk, ncol_l)):
+        got = d_buf.cpu().numpy().astype(np.uint64).reshape(nc, stride, 4)
+        assert not got[:, rows:].any(), "rows above the usable ones stay untouched"
+        flat = cref.fr_mont_to_ints(got[:, :rows].reshape(-1, 4))
+        assert flat[: len(want)] == want and not any(flat[len(want):])
