@@ -552,8 +552,9 @@ def main():
     ap.add_argument("--parallel", default="replicas", choices=["replicas", "columns"],
                     help="N > 1: independent proofs per GPU (weak scaling, the default and the headline) or ONE proof whose "
                          "columns are split over the ranks with an all-gather of the commitments (strong scaling)")
-    ap.add_argument("--msm-split", default="windows", choices=["windows", "points"],
-                    help="msm22 workload: shard Pippenger windows (north_star) or point ranges across the ranks")
+    ap.add_argument("--msm-split", default="points", choices=["windows", "points"],
+                    help="msm22 workload: shard point ranges across the ranks (default: measured / emulated to scale better, "
+                         "DESIGN.md section 8) or Pippenger windows (north_star's split)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the host-pointer (drop-in binding) measurement")
     ap.add_argument("--no-body", action="store_true", help="skip the second timed loop (hot path + the prover steps after it)")

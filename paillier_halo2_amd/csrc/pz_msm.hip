@@ -26,6 +26,9 @@
 #define MSM_CHUNK_MIN 16u   // chunk = max entries one lane accumulates for one bucket work item (MsmP::chunk,
 #define MSM_CHUNK_MAX 256u  // chosen per launch sequence by msm_chunk_for)
 #define MSM_HEAVY 24u       // buckets with more chunks than this are folded by a whole workgroup
+#define MSM_MEDIUM 1024u    // ... up to this many chunks by a 32-lane group (k_msm_medium_sum), more by a whole workgroup
+#define SLICE_PER_THREAD 4u
+#define MSM_SLICE_MAX_COLS 8u   // up to this many columns per launch sequence take the bit-sliced reduction (latency), more the radix-16 tree (throughput)
 
 struct MsmP {
     size_t n;          // scalars per column
@@ -189,12 +192,13 @@ __global__ __launch_bounds__(256) void k_msm_totals(u32* __restrict__ slice_hist
 }
 
 // pass 2b: per column exclusive scans of the bucket totals (entry offsets) and of ceil(cnt/CHUNK) (item offsets)
-__global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, MsmP p, u32* __restrict__ offs,
+#define SCAN_THREADS 1024
+__global__ __launch_bounds__(SCAN_THREADS) void k_msm_scan(const u32* __restrict__ hist, MsmP p, u32* __restrict__ offs,
                                                   u32* __restrict__ items, u32* __restrict__ heavy,
                                                   u32* __restrict__ heavy_cnt, u32* __restrict__ fold_order,
                                                   u32* __restrict__ fold_cnt, u32* __restrict__ item_order,
                                                   u32* __restrict__ item_bucket) {
-    __shared__ u32 s_cnt[256], s_itm[256];
+    __shared__ u32 s_cnt[SCAN_THREADS], s_itm[SCAN_THREADS];
     __shared__ u32 s_heavy;
     __shared__ u32 s_bin[MSM_HEAVY + 1], s_base[MSM_HEAVY + 1];
     __shared__ u32 s_obin[MSM_CHUNK_MAX + 1], s_obase[MSM_CHUNK_MAX + 1];  // work items by chunk size
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, 
     const u32* h = hist + col * p.B;
     u32* o = offs + col * (p.B + 1);
     u32* it = items + col * (p.B + 1);
-    const unsigned per = (p.B + 255) / 256;
+    const unsigned per = (p.B + SCAN_THREADS - 1) / SCAN_THREADS;
     const unsigned lo = threadIdx.x * per;
     u32 c = 0, m = 0;
     for (unsigned k = 0; k < per; ++k) {
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(256) void k_msm_scan(const u32* __restrict__ hist, 
     __syncthreads();
     if (threadIdx.x == 0) {
         u32 a = 0, b2 = 0;
-        for (int k = 0; k < 256; ++k) {
+        for (int k = 0; k < SCAN_THREADS; ++k) {
             u32 t = s_cnt[k];
             s_cnt[k] = a;
             a += t;
@@ -413,6 +417,7 @@ __global__ __launch_bounds__(256) void k_msm_heavy_sum(MsmP p, const u32* __rest
     for (u32 k = blockIdx.x; k < nh; k += gridDim.x) {
         const u32 b = heavy[col * p.B + k];
         const u32 first = it[b], m = it[b + 1] - first;
+        if (m <= MSM_MEDIUM) continue;   // k_msm_medium_sum's (block-uniform branch)
         G1X29Raw* pc = partials + col * p.max_items + first;
         G1X29 acc = x29_inf();
         for (u32 t = threadIdx.x; t < m; t += blockDim.x) {
@@ -421,8 +426,11 @@ __global__ __launch_bounds__(256) void k_msm_heavy_sum(MsmP p, const u32* __rest
         }
         x29_store_raw(&s_pt[threadIdx.x], acc);
         __syncthreads();
-        for (unsigned off = 128; off > 0; off >>= 1) {
-            if (threadIdx.x < off) {
+        // tree over the lanes that hold something: depth log2(min(m, 256)) additions, not always 8
+        unsigned top = 128;
+        while (top >= m && top > 0) top >>= 1;   // largest power of two below m (m > MSM_HEAVY >= 2)
+        for (unsigned off = top; off > 0; off >>= 1) {
+            if (threadIdx.x < off && threadIdx.x + off < (m < 256u ? m : 256u)) {
                 G1X29 a = x29_load_raw(&s_pt[threadIdx.x]);
                 G1X29 o = x29_load_raw(&s_pt[threadIdx.x + off]);
                 x29_add(a, o);
@@ -431,6 +439,49 @@ __global__ __launch_bounds__(256) void k_msm_heavy_sum(MsmP p, const u32* __rest
             __syncthreads();
         }
         if (threadIdx.x == 0) x29_store_raw(pc, x29_load_raw(&s_pt[0]));
+        __syncthreads();
+    }
+}
+
+// Buckets of MSM_HEAVY < m <= MSM_MEDIUM chunks: a 32-lane group each (eight buckets per workgroup at a time).  One large
+// MSM makes EVERY bucket such a bucket (2^22 points: 2^15 buckets of 32 chunks): a whole workgroup per bucket left 7/8 of
+// its lanes idle through an 8-level tree and cost 2.5 ms whatever the MSM's size.
+__global__ __launch_bounds__(256) void k_msm_medium_sum(MsmP p, const u32* __restrict__ items,
+                                                        const u32* __restrict__ heavy, const u32* __restrict__ heavy_cnt,
+                                                        G1X29Raw* __restrict__ partials) {
+    __shared__ G1X29Raw s_pt[256];
+    const size_t col = blockIdx.y;
+    const u32 nh = heavy_cnt[col];
+    const u32* it = items + col * (p.B + 1);
+    const unsigned g = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const u32 rounds = (nh + gridDim.x * 8 - 1) / (gridDim.x * 8);
+    for (u32 r = 0; r < rounds; ++r) {
+        const u32 k = (r * gridDim.x + blockIdx.x) * 8 + g;
+        u32 first = 0, m = 0;
+        if (k < nh) {
+            const u32 b = heavy[col * p.B + k];
+            first = it[b];
+            m = it[b + 1] - first;
+            if (m > MSM_MEDIUM) m = 0;   // k_msm_heavy_sum's
+        }
+        G1X29Raw* pc = partials + col * p.max_items + first;
+        G1X29 acc = x29_inf();
+        for (u32 t = l; t < m; t += 32) {
+            G1X29 o = x29_load_raw(pc + t);
+            x29_add(acc, o);
+        }
+        x29_store_raw(&s_pt[threadIdx.x], acc);
+        __syncthreads();
+        for (unsigned off = 16; off > 0; off >>= 1) {
+            if (l < off && l + off < m) {
+                G1X29 a = x29_load_raw(&s_pt[threadIdx.x]);
+                G1X29 o = x29_load_raw(&s_pt[threadIdx.x + off]);
+                x29_add(a, o);
+                x29_store_raw(&s_pt[threadIdx.x], a);
+            }
+            __syncthreads();
+        }
+        if (l == 0 && m) x29_store_raw(pc, x29_load_raw(&s_pt[threadIdx.x]));
         __syncthreads();
     }
 }
@@ -490,6 +541,89 @@ __global__ __launch_bounds__(128) void k_msm_combine(unsigned n_in, unsigned m, 
     MsmNode* o = out + col * n_out + t;
     x29_store_raw(&o->V, acc);
     x29_store_raw(&o->S, run);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same sum for FEW columns (one large MSM, a single best_multiexp call of the drop-in binding), where the radix-16
+// tree above is pure latency: its lanes chain ~50 dependent point additions per level (1.4 ms for one column whatever
+// its size).  Bit-sliced instead:  sum_b w_b B_b = sum_j 2^j T_j  with  T_j = sum of the buckets whose weight w_b = b + 1
+// has bit j set -- c subset sums, each a fully parallel tree reduction (depth log2 B additions instead of ~150), then
+// a pairwise Horner fold of the c slices (depth log2 c).
+//   k_msm_slice_partial : block of 256 buckets x bit j  -> one partial (LDS tree)
+//   k_msm_slice_reduce  : the B/256 partials of (column, bit j) -> T_j (LDS tree)
+//   k_msm_slice_horner  : U = T_0 + 2 T_1, ...; then pairs of pairs with 2, 4, 8 doublings: one workgroup per column
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_tree_sum(G1X29Raw* s_pt, unsigned nthreads) {   // nthreads a power of two <= 256
+    for (unsigned off = nthreads >> 1; off > 0; off >>= 1) {
+        __syncthreads();
+        if (threadIdx.x < off) {
+            G1X29 a = x29_load_raw(&s_pt[threadIdx.x]);
+            G1X29 o = x29_load_raw(&s_pt[threadIdx.x + off]);
+            x29_add(a, o);
+            x29_store_raw(&s_pt[threadIdx.x], a);
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_msm_slice_partial(MsmP p, const u32* __restrict__ items,
+                                                           const G1X29Raw* __restrict__ partials, unsigned nblk,
+                                                           G1X29Raw* __restrict__ slice_part) {
+    __shared__ G1X29Raw s_pt[256];
+    const size_t col = blockIdx.z;
+    const unsigned j = blockIdx.y;
+    const u32* it = items + col * (p.B + 1);
+    G1X29 v = x29_inf();
+    for (unsigned q = 0; q < SLICE_PER_THREAD; ++q) {   // a few buckets per lane, then the tree
+        const unsigned b = (blockIdx.x * SLICE_PER_THREAD + q) * 256 + threadIdx.x;
+        if (b < p.B && (((b + 1) >> j) & 1u) && it[b + 1] > it[b]) {
+            G1X29 o = x29_load_raw(partials + col * p.max_items + it[b]);
+            x29_add(v, o);
+        }
+    }
+    x29_store_raw(&s_pt[threadIdx.x], v);
+    lds_tree_sum(s_pt, 256);
+    if (threadIdx.x == 0) slice_part[(col * p.c + j) * nblk + blockIdx.x] = s_pt[0];
+}
+
+__global__ __launch_bounds__(256) void k_msm_slice_reduce(MsmP p, unsigned nblk, const G1X29Raw* __restrict__ slice_part,
+                                                          G1X29Raw* __restrict__ slices) {
+    __shared__ G1X29Raw s_pt[256];
+    const size_t col = blockIdx.y;
+    const unsigned j = blockIdx.x;
+    const G1X29Raw* in = slice_part + (col * p.c + j) * nblk;
+    G1X29 acc = x29_inf();
+    for (unsigned t = threadIdx.x; t < nblk; t += 256) {
+        G1X29 o = x29_load_raw(in + t);
+        x29_add(acc, o);
+    }
+    x29_store_raw(&s_pt[threadIdx.x], acc);
+    lds_tree_sum(s_pt, 256);
+    if (threadIdx.x == 0) slices[col * 16 + j] = s_pt[0];
+}
+
+// sum_j 2^j T_j for c <= 16 slices: four pairwise levels, level l combining neighbours with 2^l doublings
+__global__ __launch_bounds__(64) void k_msm_slice_horner(MsmP p, const G1X29Raw* __restrict__ slices, G1Jac* __restrict__ out) {
+    __shared__ G1X29Raw s_pt[16];
+    const size_t col = blockIdx.x;
+    if (threadIdx.x < 16) {
+        G1X29 v = threadIdx.x < p.c ? x29_load_raw(slices + col * 16 + threadIdx.x) : x29_inf();
+        x29_store_raw(&s_pt[threadIdx.x], v);
+    }
+    for (unsigned l = 0; l < 4; ++l) {
+        __syncthreads();
+        const unsigned stride = 1u << l;
+        if (threadIdx.x < (8u >> l)) {
+            const unsigned i = threadIdx.x * 2 * stride;
+            G1X29 hi = x29_load_raw(&s_pt[i + stride]);
+            for (unsigned k = 0; k < stride; ++k) hi = x29_dbl(hi);
+            G1X29 lo = x29_load_raw(&s_pt[i]);
+            x29_add(lo, hi);
+            x29_store_raw(&s_pt[i], lo);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) x29_store_jac(out + col, x29_load_raw(&s_pt[0]));
 }
 
 __global__ void k_msm_emit(const MsmNode* __restrict__ nodes, size_t n_cols, G1Jac* __restrict__ out) {
@@ -628,7 +762,7 @@ extern "C" int pz_bases_info(const pz_bases* b, size_t* n_points, uint32_t* wind
 }
 
 // Work items are handed to lanes in chunk-size order, so a wave's lanes run equal trip counts whatever the
-// chunk bound is; the bound only has to leave enough items to fill the chip (>= ~2^20 lanes per launch)
+// chunk bound is; the bound only has to leave enough items to fill the chip (>= ~2^18 lanes per launch)
 // and keep a single skewed bucket from serialising.  Larger chunks mean fewer partial sums to write and fold.
 static unsigned msm_chunk_for(size_t n_cols, size_t digits_per_col) {
     static int env = -1;
@@ -637,7 +771,7 @@ static unsigned msm_chunk_for(size_t n_cols, size_t digits_per_col) {
         env = e ? atoi(e) : 0;
     }
     if (env >= (int)MSM_CHUNK_MIN && env <= (int)MSM_CHUNK_MAX) return (unsigned)env;
-    const size_t want = (n_cols * digits_per_col) >> 20;
+    const size_t want = (n_cols * digits_per_col) >> 18;   // >= 2^18 lanes: four waves per SIMD
     unsigned chunk = MSM_CHUNK_MIN;
     while (chunk < MSM_CHUNK_MAX && chunk * 2 <= want) chunk *= 2;
     return chunk;
@@ -685,7 +819,7 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
         hipLaunchKernelGGL(k_msm_hist, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (u32*)hist, n_slices);
         hipLaunchKernelGGL(k_msm_totals, dim3(pz_div_up(p.B, 256), (unsigned)nc), dim3(256), 0, st, (u32*)hist, n_slices, p,
                            (u32*)totals);
-        hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)nc), dim3(256), 0, st, (const u32*)totals, p, (u32*)offs, (u32*)items,
+        hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)nc), dim3(SCAN_THREADS), 0, st, (const u32*)totals, p, (u32*)offs, (u32*)items,
                            (u32*)heavy, heavy_cnt, (u32*)fold, fold_cnt, item_order, item_bucket);
         hipLaunchKernelGGL(k_msm_scatter, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (const u32*)hist, n_slices,
                            (const u32*)offs, (u32*)entries);
@@ -706,6 +840,21 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     if (hx > p.B) hx = p.B;
     hipLaunchKernelGGL(k_msm_heavy_sum, dim3(hx, (unsigned)nc), dim3(256), 0, st, p, (const u32*)items, (const u32*)heavy,
                        (const u32*)heavy_cnt, (G1X29Raw*)partials);
+    hipLaunchKernelGGL(k_msm_medium_sum, dim3(hx, (unsigned)nc), dim3(256), 0, st, p, (const u32*)items, (const u32*)heavy,
+                       (const u32*)heavy_cnt, (G1X29Raw*)partials);
+    if (nc <= MSM_SLICE_MAX_COLS) {
+        // few columns: bit-sliced parallel reduction (depth ~ log2 B + log2 c point additions)
+        const unsigned nblk = pz_div_up(p.B, 256 * SLICE_PER_THREAD);
+        void *sp, *sl;
+        PZCHK(pz_ws_get(ctx, WS_NODES_A, nc * (size_t)p.c * nblk * sizeof(G1X29Raw), &sp));
+        PZCHK(pz_ws_get(ctx, WS_NODES_B, nc * 16 * sizeof(G1X29Raw), &sl));
+        hipLaunchKernelGGL(k_msm_slice_partial, dim3(nblk, p.c, (unsigned)nc), dim3(256), 0, st, p, (const u32*)items,
+                           (const G1X29Raw*)partials, nblk, (G1X29Raw*)sp);
+        hipLaunchKernelGGL(k_msm_slice_reduce, dim3(p.c, (unsigned)nc), dim3(256), 0, st, p, nblk, (const G1X29Raw*)sp, (G1X29Raw*)sl);
+        hipLaunchKernelGGL(k_msm_slice_horner, dim3((unsigned)nc), dim3(64), 0, st, p, (const G1X29Raw*)sl, d_out);
+        HIPCHK(ctx, hipGetLastError());
+        return PZ_OK;
+    }
     hipLaunchKernelGGL(k_msm_reduce_l1, dim3(pz_div_up(n_nodes, 128), (unsigned)nc), dim3(128), 0, st, p, m1,
                        (const u32*)items, (const G1X29Raw*)partials, (MsmNode*)na);
     MsmNode* cur = (MsmNode*)na;
