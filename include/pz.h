@@ -232,6 +232,12 @@ int pz_witness_expand(pz_ctx* ctx, uint32_t limbs, uint32_t limb_bits, uint32_t 
  * Montgomery (host); outputs: device, 2^k affine points each.  s must not lie in the domain (PZ_ERR_INVALID). */
 int pz_srs_setup_g1_dev(pz_ctx* ctx, uint32_t k, const uint64_t s[4], const uint64_t omega[4], uint64_t* d_g,
                         uint64_t* d_g_lagrange);
+/* The Lagrange-basis SRS from the monomial one WITHOUT the toxic scalar (what ParamsKZG does with a params file's `g`):
+ * d_g_lagrange[i] = (1/n) sum_j omega^(-i j) d_g[j], a radix-2 inverse FFT over G1 (the twiddle product is a scalar
+ * multiplication).  d_g, d_g_lagrange: 2^k affine points on the device (may not alias); omega_inv, n_inv: Fr Montgomery
+ * (host).  One-time cost per SRS, (k + 1) 2^(k-1) scalar multiplications. */
+int pz_srs_lagrange_from_monomial_dev(pz_ctx* ctx, uint32_t k, const uint64_t omega_inv[4], const uint64_t n_inv[4],
+                                      const uint64_t* d_g, uint64_t* d_g_lagrange);
 /* on-curve validation of n affine points on the device (y^2 = x^3 + 3, canonical coordinates, identity (0,0)
  * accepted): *n_bad = number of points that fail.  The check halo2curves' read_raw performs when ParamsKZG::read
  * loads a `params/kzg_bn254_{k}.srs` file (paillier_halo2_amd/srs.py reads that format). */

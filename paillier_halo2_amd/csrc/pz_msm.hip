@@ -997,6 +997,95 @@ extern "C" int pz_g1_normalize(pz_ctx* ctx, const uint64_t* jac, size_t n, uint6
     return PZ_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// G1 radix-2 inverse FFT: the Lagrange-basis SRS g_lagrange from the monomial g of a params file WITHOUT the toxic
+// scalar -- what halo2's ParamsKZG::setup / read path does with best_fft over G1Projective (SURVEY.md section 8f rank 2;
+// reached from /root/reference/src/bench.rs:161-171 through gen_srs):
+//   g_lagrange[i] = (1/n) sum_j omega^(-i j) g[j]
+// The butterflies are those of the field transform, with the twiddle product a 254-bit scalar multiplication (double-and-
+// add in XYZZ).  DIT over a bit-reversed XYZZ image in HBM, one launch per stage, one lane per butterfly.  A one-time cost
+// per SRS: (k + 1) * 2^(k-1) scalar multiplications (~0.1 s at k = 17).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ G1X29 x29_scalar_mul(const G1X29& pt, const u32 k[8]) {
+    G1X29 acc = x29_inf();
+    bool started = false;   // skip the leading zero bits (wave-uniform only when every lane agrees: plain branch)
+    for (int bit = 253; bit >= 0; --bit) {
+        if (started) acc = x29_dbl(acc);
+        if ((sel8(k, (unsigned)bit >> 5) >> (bit & 31)) & 1u) {
+            x29_add(acc, pt);
+            started = true;
+        }
+    }
+    return acc;
+}
+__device__ __forceinline__ G1X29 x29_neg(const G1X29& p) {
+    G1X29 r = p;
+    if (!x29_is_inf(p)) r.y = f29_carry(f29_neg<4, 31>(p.y));   // value < 4p, limbs back below 2^29 + 8
+    return r;
+}
+
+// load: A[bitrev(i)] = [scale] g[i]   (scale = 1/n as a canonical integer)
+__global__ __launch_bounds__(128) void k_gfft_load(const G1Aff64* __restrict__ g, G1X29Raw* __restrict__ A, unsigned log_n, Fr scale) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> log_n) return;
+    G1A29 p = a29_load64(g + i);
+    G1X29 x = x29_inf();
+    if (!a29_is_inf(p)) {
+        p.x = f29_to_261(p.x);
+        p.y = f29_to_261(p.y);
+        const Fr kc = fp_from_mont(scale);
+        x = x29_scalar_mul(x29_from_affine(a29_canon(p)), kc.v);
+    }
+    const size_t r = log_n ? (size_t)(__brev((unsigned)i) >> (32 - log_n)) : 0;
+    x29_store_raw(A + r, x);
+}
+// one DIT stage: pairs (i0, i0 + half), twiddle tw[pos << (log_n - s - 1)]
+__global__ __launch_bounds__(128) void k_gfft_stage(G1X29Raw* __restrict__ A, const Fr* __restrict__ tw, unsigned log_n, unsigned s) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >> (log_n - 1)) return;
+    const size_t half = (size_t)1 << s, pos = t & (half - 1), i0 = ((t >> s) << (s + 1)) + pos, i1 = i0 + half;
+    const G1X29 u = x29_load_raw(A + i0);
+    G1X29 v = x29_load_raw(A + i1);
+    if (pos) {
+        const Fr w = fp_from_mont(fp_load<FrTag>(tw + (pos << (log_n - s - 1))));
+        v = x29_scalar_mul(v, w.v);
+    }
+    G1X29 a = u, b = u;
+    x29_add(a, v);
+    const G1X29 nv = x29_neg(v);
+    x29_add(b, nv);
+    x29_store_raw(A + i0, a);
+    x29_store_raw(A + i1, b);
+}
+__global__ __launch_bounds__(128) void k_gfft_store(const G1X29Raw* __restrict__ A, G1Aff64* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1A29 a = x29_to_affine(x29_load_raw(A + i));
+    if (!a29_is_inf(a)) {
+        a.x = f29_to_256(a.x);
+        a.y = f29_to_256(a.y);
+    }
+    a29_store64(out + i, a);
+}
+
+extern "C" int pz_srs_lagrange_from_monomial_dev(pz_ctx* ctx, uint32_t k, const uint64_t omega_inv[4], const uint64_t n_inv[4],
+                                                 const uint64_t* d_g, uint64_t* d_g_lagrange) {
+    if (!ctx || !omega_inv || !n_inv || !d_g || !d_g_lagrange || k > 26) return PZ_ERR_INVALID;
+    PZ_ENTER(ctx);
+    const size_t n = (size_t)1 << k;
+    void *tw, *A;
+    PZCHK(pz_get_pow_table(ctx, omega_inv, n, &tw));
+    PZCHK(pz_ws_get(ctx, WS_PARTIALS, n * sizeof(G1X29Raw), &A));
+    Fr sc;
+    memcpy(sc.v, n_inv, 32);
+    hipLaunchKernelGGL(k_gfft_load, dim3(pz_div_up(n, 128)), dim3(128), 0, ctx->stream, (const G1Aff64*)d_g, (G1X29Raw*)A, (unsigned)k, sc);
+    for (unsigned s2 = 0; s2 < k; ++s2)
+        hipLaunchKernelGGL(k_gfft_stage, dim3(pz_div_up(n / 2, 128)), dim3(128), 0, ctx->stream, (G1X29Raw*)A, (const Fr*)tw, (unsigned)k, s2);
+    hipLaunchKernelGGL(k_gfft_store, dim3(pz_div_up(n, 128)), dim3(128), 0, ctx->stream, (const G1X29Raw*)A, (G1Aff64*)d_g_lagrange, n);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}
+
 // on-curve check of affine points (identity (0,0) accepted): the is_on_curve assertion of halo2curves' read_raw
 __global__ __launch_bounds__(256) void k_g1_check(const G1Affine* __restrict__ pts, size_t n, unsigned long long* bad) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

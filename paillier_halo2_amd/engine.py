@@ -324,6 +324,10 @@ class Engine:
         self._chk(self.L.pz_srs_setup_g1_dev(self.ctx, k, _ptr(_np(s).reshape(4)), _ptr(_np(omega).reshape(4)), VP(d_g),
                                              VP(d_g_lagrange)), "pz_srs_setup_g1_dev")
 
+    def srs_lagrange_from_monomial_dev(self, k: int, omega_inv, n_inv, d_g: int, d_g_lagrange: int):
+        self._chk(self.L.pz_srs_lagrange_from_monomial_dev(self.ctx, k, self._fr1(omega_inv), self._fr1(n_inv), VP(d_g), VP(d_g_lagrange)),
+                  "pz_srs_lagrange_from_monomial_dev")
+
     def g1_check_dev(self, d_points: int, n: int) -> int:
         """number of points (device, affine) that are not on the curve"""
         bad = C.c_uint64()

@@ -884,3 +884,59 @@ def test_whole_circuit_cell_stream(eng, cref, kind, bits, W, lb):
         assert not got[:, rows:].any(), "rows above the usable ones stay untouched"
         flat = cref.fr_mont_to_ints(got[:, :rows].reshape(-1, 4))
         assert flat[: len(want)] == want and not any(flat[len(want):])
+
+
+@pytest.mark.parametrize("k", [0, 1, 5, 11, 14])
+def test_srs_lagrange_from_monomial(eng, cref, k):
+    """g_lagrange derived from the MONOMIAL bases alone (G1 inverse FFT on the device, no toxic scalar)
+    == the Lagrange bases computed from the known scalar (pz_srs_setup_g1_dev), through a params-file round trip; plus an
+    identity base in the input and the property commit_lagrange(evals) == commit(ifft(evals)) on the derived bases."""
+    import os
+    import tempfile
+
+    import torch
+
+    from paillier_halo2_amd import srs as srsmod
+
+    rng = random.Random(4000 + k)
+    n = 1 << k
+    s, w = rng.randrange(2, P.FR_R), P.fr_omega(k)
+    d_g = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    d_l = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    eng.srs_setup_g1_dev(k, cref.fr_ints_to_mont([s])[0], cref.fr_ints_to_mont([w])[0], d_g.data_ptr(), d_l.data_ptr())
+    eng.sync()
+    winv, ninv = cref.fr_ints_to_mont([pow(w, -1, P.FR_R)])[0], cref.fr_ints_to_mont([pow(n, -1, P.FR_R)])[0]
+    d_out = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    eng.srs_lagrange_from_monomial_dev(k, winv, ninv, d_g.data_ptr(), d_out.data_ptr())
+    eng.sync()
+    got, want = d_out.cpu().numpy().astype(np.uint64), d_l.cpu().numpy().astype(np.uint64)
+    assert np.array_equal(got, want), k
+    assert eng.g1_check_dev(d_out.data_ptr(), n) == 0
+    if k == 5:
+        # an identity among the inputs: the transform is linear, so zeroing g[3] subtracts its column of the DFT matrix
+        g2 = d_g.clone()
+        g2[3] = 0
+        eng.srs_lagrange_from_monomial_dev(k, winv, ninv, g2.data_ptr(), d_out.data_ptr())
+        eng.sync()
+        lag2 = cref.affine_mont_to_ints(d_out.cpu().numpy().astype(np.uint64))
+        g3 = cref.affine_mont_to_ints(d_g.cpu().numpy().astype(np.uint64))[3]
+        lag = cref.affine_mont_to_ints(want)
+        for i in (0, 1, 7, 31):
+            coef = pow(w, -3 * i, P.FR_R) * pow(n, -1, P.FR_R) % P.FR_R
+            assert lag2[i] == P.g1_add_aff(lag[i], P.aff_neg(P.g1_mul(g3, coef))), i
+    if k == 11:
+        # from a params FILE: write the monomial bases, read them back memory-mapped, derive, commit both ways
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "kzg_bn254_%d.srs" % k)
+            srsmod.write_params_kzg(path, k, d_g.cpu().numpy().astype(np.uint64), want)
+            par = srsmod.read_params_kzg(path)
+            d_gf = torch.from_numpy(np.ascontiguousarray(par.g).astype(np.int64)).cuda()
+        eng.srs_lagrange_from_monomial_dev(k, winv, ninv, d_gf.data_ptr(), d_out.data_ptr())
+        tb_g, tb_l = eng.load_bases_dev(d_gf.data_ptr(), n), eng.load_bases_dev(d_out.data_ptr(), n)
+        evals = cref.fr_ints_to_mont([rng.randrange(P.FR_R) for _ in range(n)])
+        d_c = torch.from_numpy(evals.astype(np.int64)).cuda()
+        eng.ntt_dev(d_c.data_ptr(), 1, 4 * n, winv, k, None, ninv)
+        eng.sync()
+        assert np.array_equal(eng.g1_normalize(eng.msm(tb_l, evals))[0], eng.g1_normalize(eng.msm(tb_g, d_c.cpu().numpy().astype(np.uint64)))[0])
+        tb_g.free()
+        tb_l.free()
