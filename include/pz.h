@@ -238,6 +238,19 @@ int pz_srs_setup_g1_dev(pz_ctx* ctx, uint32_t k, const uint64_t s[4], const uint
  * (host).  One-time cost per SRS, (k + 1) 2^(k-1) scalar multiplications. */
 int pz_srs_lagrange_from_monomial_dev(pz_ctx* ctx, uint32_t k, const uint64_t omega_inv[4], const uint64_t n_inv[4],
                                       const uint64_t* d_g, uint64_t* d_g_lagrange);
+/* keygen, permutation polynomials (halo2 permutation::keygen::Assembly::build_pk): d_sigma[j][i] = delta^(d_map_col[j*n+i]) *
+ * omega^(d_map_row[j*n+i]) over the 2^k domain, n = 2^k, for m columns -- (map_col, map_row) is the cell the copy-constraint
+ * cycle maps (j, i) to (circuit structure, supplied by the caller: device arrays of m * n u32 each). */
+int pz_permutation_sigma_dev(pz_ctx* ctx, const uint32_t* d_map_col, const uint32_t* d_map_row, size_t m, uint32_t k,
+                             const uint64_t omega[4], const uint64_t delta[4], uint64_t* d_sigma, size_t sigma_stride);
+/* keygen_vk + keygen_pk for n_cols Lagrange-form fixed columns (selectors, constants, table, sigma) on the device: their
+ * commitments (commit_lagrange, n_cols x 12), then IN PLACE their coefficient form, and (d_ext != NULL) their values on the
+ * extended coset (as pz_ntt_fr_extend_dev) -- the proving key's polynomials, resident in HBM for every later proof.
+ * Reached in the reference through bench.rs:161-175 (keygen_vk / keygen_pk inside bench_builder). */
+int pz_keygen_columns_dev(pz_ctx* ctx, const pz_bases* bases_lagrange, uint64_t* d_cols, size_t n_cols, size_t col_stride,
+                          uint32_t k, uint32_t log_e, const uint64_t omega_n[4], const uint64_t omega_n_inv[4],
+                          const uint64_t n_inv[4], const uint64_t* coset_gens, uint64_t* d_commit_jac, uint64_t* d_ext,
+                          size_t ext_stride);
 /* on-curve validation of n affine points on the device (y^2 = x^3 + 3, canonical coordinates, identity (0,0)
  * accepted): *n_bad = number of points that fail.  The check halo2curves' read_raw performs when ParamsKZG::read
  * loads a `params/kzg_bn254_{k}.srs` file (paillier_halo2_amd/srs.py reads that format). */

@@ -62,6 +62,8 @@ SIGNATURES = {
                                         C.c_size_t, C.c_size_t]),
     "pz_srs_setup_g1_dev": (C.c_int, [VP, C.c_uint32, VP, VP, VP, VP]),
     "pz_srs_lagrange_from_monomial_dev": (C.c_int, [VP, C.c_uint32, VP, VP, VP, VP]),
+    "pz_permutation_sigma_dev": (C.c_int, [VP, VP, VP, C.c_size_t, C.c_uint32, VP, VP, VP, C.c_size_t]),
+    "pz_keygen_columns_dev": (C.c_int, [VP, VP, VP, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, VP, VP, VP, VP, VP, VP, C.c_size_t]),
     "pz_poly_eval_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, C.c_size_t, VP, VP]),
     "pz_g1_check_dev": (C.c_int, [VP, VP, C.c_size_t, C.POINTER(C.c_uint64)]),
     "pz_fr_batch_invert_dev": (C.c_int, [VP, VP, C.c_size_t]),

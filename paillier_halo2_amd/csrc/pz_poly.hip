@@ -125,3 +125,50 @@ extern "C" int pz_poly_eval_dev(pz_ctx* ctx, const uint64_t* d_coeffs, size_t n_
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- keygen
+// permutation::keygen: the sigma polynomial of column j holds, at row i, the label delta^(col') * omega^(row') of the cell
+// the copy-constraint cycle maps (j, i) to.  The cycles themselves are circuit structure (the reference's dependency
+// builds them while synthesising); they arrive as two index arrays.
+__global__ __launch_bounds__(256) void k_perm_sigma(const u32* __restrict__ map_col, const u32* __restrict__ map_row, size_t n,
+                                                    size_t total, const Fr* __restrict__ wpow, const Fr* __restrict__ dpow,
+                                                    Fr* __restrict__ sigma, size_t stride) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const size_t j = t / n, i = t % n;
+    fp_store(sigma + j * stride + i, fp_mul(fp_load<FrTag>(dpow + map_col[t]), fp_load<FrTag>(wpow + map_row[t])));
+}
+
+extern "C" int pz_permutation_sigma_dev(pz_ctx* ctx, const uint32_t* d_map_col, const uint32_t* d_map_row, size_t m, uint32_t k,
+                                        const uint64_t omega[4], const uint64_t delta[4], uint64_t* d_sigma, size_t sigma_stride) {
+    if (!ctx || !d_map_col || !d_map_row || !omega || !delta || !d_sigma || k > 26 || m == 0 || m > 0xffffffu) return PZ_ERR_INVALID;
+    const size_t n = (size_t)1 << k;
+    if (sigma_stride % 4 || (m > 1 && sigma_stride < 4 * n)) return PZ_ERR_INVALID;
+    PZ_ENTER(ctx);
+    void *wp, *dp;
+    PZCHK(pz_get_pow_table(ctx, omega, n, &wp));
+    PZCHK(pz_get_pow_table(ctx, delta, m, &dp));
+    hipLaunchKernelGGL(k_perm_sigma, dim3(pz_div_up(m * n, 256)), dim3(256), 0, ctx->stream, d_map_col, d_map_row, n, m * n,
+                       (const Fr*)wp, (const Fr*)dp, (Fr*)d_sigma, sigma_stride / 4);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}
+
+// keygen_vk + keygen_pk for a batch of Lagrange-form fixed columns (selectors, constants, lookup table, sigma): their
+// commitments (commit_lagrange), coefficient forms (in place) and extended-coset forms -- the proving key's polynomials,
+// left RESIDENT in the caller's device buffers for every proof that follows.
+extern "C" int pz_msm_g1_dev(pz_ctx* ctx, const pz_bases* bases, const uint64_t* d_scalars, size_t n_cols, size_t n, size_t col_stride,
+                             uint32_t win_lo, uint32_t win_hi, uint64_t* d_out_jac);
+extern "C" int pz_keygen_columns_dev(pz_ctx* ctx, const pz_bases* bases_lagrange, uint64_t* d_cols, size_t n_cols, size_t col_stride,
+                                     uint32_t k, uint32_t log_e, const uint64_t omega_n[4], const uint64_t omega_n_inv[4],
+                                     const uint64_t n_inv[4], const uint64_t* coset_gens, uint64_t* d_commit_jac, uint64_t* d_ext,
+                                     size_t ext_stride) {
+    if (!ctx || !bases_lagrange || !d_cols || !d_commit_jac || k > 26) return PZ_ERR_INVALID;
+    const size_t n = (size_t)1 << k;
+    if (bases_lagrange->n < n) return PZ_ERR_INVALID;
+    PZ_ENTER(ctx);
+    PZCHK(pz_msm_g1_dev(ctx, bases_lagrange, d_cols, n_cols, n, col_stride, 0, bases_lagrange->nwin, d_commit_jac));
+    PZCHK(pz_ntt_fr_dev(ctx, d_cols, n_cols, col_stride, omega_n_inv, k, nullptr, n_inv));
+    if (d_ext) PZCHK(pz_ntt_fr_extend_dev(ctx, d_cols, n_cols, col_stride, d_ext, ext_stride, k, log_e, omega_n, coset_gens, nullptr));
+    return PZ_OK;
+}

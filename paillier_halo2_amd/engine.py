@@ -328,6 +328,17 @@ class Engine:
         self._chk(self.L.pz_srs_lagrange_from_monomial_dev(self.ctx, k, self._fr1(omega_inv), self._fr1(n_inv), VP(d_g), VP(d_g_lagrange)),
                   "pz_srs_lagrange_from_monomial_dev")
 
+    def permutation_sigma_dev(self, d_map_col: int, d_map_row: int, m: int, k: int, omega, delta, d_sigma: int, sigma_stride_u64: int):
+        self._chk(self.L.pz_permutation_sigma_dev(self.ctx, VP(d_map_col), VP(d_map_row), m, k, self._fr1(omega), self._fr1(delta),
+                                                  VP(d_sigma), sigma_stride_u64), "pz_permutation_sigma_dev")
+
+    def keygen_columns_dev(self, bases: Bases, d_cols: int, n_cols: int, col_stride_u64: int, k: int, log_e: int, omega_n, omega_n_inv,
+                           n_inv, coset_gens, d_commit: int, d_ext: int = 0, ext_stride_u64: int = 0):
+        g = _np(coset_gens).reshape(-1)
+        self._chk(self.L.pz_keygen_columns_dev(self.ctx, bases.handle, VP(d_cols), n_cols, col_stride_u64, k, log_e, self._fr1(omega_n),
+                                               self._fr1(omega_n_inv), self._fr1(n_inv), _ptr(g), VP(d_commit), VP(d_ext), ext_stride_u64),
+                  "pz_keygen_columns_dev")
+
     def g1_check_dev(self, d_points: int, n: int) -> int:
         """number of points (device, affine) that are not on the curve"""
         bad = C.c_uint64()

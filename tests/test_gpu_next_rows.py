@@ -592,3 +592,59 @@ def test_multiopen_fold_and_division(eng, cref):
     q = _ints(cref, d_q)
     assert q == P.kate_division(want, x)
     assert (P.poly_eval(want, t) - P.poly_eval(want, x)) % R == (t - x) * P.poly_eval(q, t) % R
+
+
+def test_keygen_sigma_and_resident_columns(eng, cref):
+    """SURVEY 8f rank 2, keygen on the device: the permutation polynomials of a given copy-constraint structure
+    (sigma_j[i] = delta^col' omega^row') and keygen_vk / keygen_pk of a batch of fixed columns -- commitments, coefficient
+    forms and extended-coset forms left resident -- against the oracle restatements."""
+    import torch
+
+    rng = random.Random(5150)
+    k, m, log_e = 6, 3, 2
+    n, E = 1 << k, 1 << log_e
+    w, delta = P.fr_omega(k), pow(P.FR_GENERATOR, 1 << 28, P.FR_R)
+    # identity mapping with one 3-cycle and one 2-cycle of copy constraints
+    mc = np.repeat(np.arange(m, dtype=np.uint32), n).reshape(m, n)
+    mr = np.tile(np.arange(n, dtype=np.uint32), m).reshape(m, n)
+    for cyc in ([(0, 1), (2, 5), (1, 7)], [(1, 0), (1, 63)]):
+        for a, b in zip(cyc, cyc[1:] + cyc[:1]):
+            mc[a], mr[a] = b[0], b[1]
+    d_mc, d_mr = torch.from_numpy(mc.astype(np.int32)).cuda(), torch.from_numpy(mr.astype(np.int32)).cuda()
+    d_sig = torch.zeros((m, n, 4), dtype=torch.int64, device="cuda")
+    eng.permutation_sigma_dev(d_mc.data_ptr(), d_mr.data_ptr(), m, k, cref.fr_ints_to_mont([w])[0], cref.fr_ints_to_mont([delta])[0],
+                              d_sig.data_ptr(), 4 * n)
+    eng.sync()
+    got = d_sig.cpu().numpy().astype(np.uint64)
+    for j in range(m):
+        want = [pow(delta, int(mc[j, i]), P.FR_R) * pow(w, int(mr[j, i]), P.FR_R) % P.FR_R for i in range(n)]
+        assert cref.fr_mont_to_ints(got[j]) == want, j
+    # keygen of these sigma columns + a selector column: commit, coefficient form, extended coset
+    sel = [rng.getrandbits(1) for _ in range(n)]
+    cols = np.concatenate([got, cref.fr_ints_to_mont(sel).reshape(1, n, 4)])
+    nc = cols.shape[0]
+    s_tox = rng.randrange(2, P.FR_R)
+    d_l = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    eng.srs_setup_g1_dev(k, cref.fr_ints_to_mont([s_tox])[0], cref.fr_ints_to_mont([w])[0], 0, d_l.data_ptr())
+    eng.sync()
+    tb = eng.load_bases_dev(d_l.data_ptr(), n)
+    bases = d_l.cpu().numpy().astype(np.uint64)
+    d_cols = torch.from_numpy(cols.astype(np.int64)).cuda()
+    d_com = torch.zeros((nc, 12), dtype=torch.int64, device="cuda")
+    d_ext = torch.zeros((nc, n * E, 4), dtype=torch.int64, device="cuda")
+    w_ext = P.fr_omega(k + log_e)
+    gens = np.stack([cref.fr_ints_to_mont([7 * pow(w_ext, r, P.FR_R) % P.FR_R])[0] for r in range(E)])
+    eng.keygen_columns_dev(tb, d_cols.data_ptr(), nc, 4 * n, k, log_e, cref.fr_ints_to_mont([w])[0], cref.fr_ints_to_mont([pow(w, -1, P.FR_R)])[0],
+                           cref.fr_ints_to_mont([pow(n, -1, P.FR_R)])[0], gens, d_com.data_ptr(), d_ext.data_ptr(), 4 * n * E)
+    eng.sync()
+    com = eng.g1_normalize(d_com.cpu().numpy().astype(np.uint64))
+    coeff = d_cols.cpu().numpy().astype(np.uint64)
+    ext = d_ext.cpu().numpy().astype(np.uint64)
+    for j in range(nc):
+        vals = cref.fr_mont_to_ints(cols[j])
+        assert np.array_equal(com[j], cref.g1_normalize(cref.msm_g1(cols[j], bases))), j
+        cf = P.intt(vals, w)
+        assert cref.fr_mont_to_ints(coeff[j]) == cf, j
+        want_ext = P.ntt(P.coset_scale(cf + [0] * (n * E - n), 7), w_ext)
+        assert cref.fr_mont_to_ints(ext[j]) == want_ext, j
+    tb.free()
