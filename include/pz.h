@@ -345,6 +345,22 @@ int pz_fr_lincomb_dev(pz_ctx* ctx, const uint64_t* d_polys, size_t n_cols, size_
 int pz_poly_div_linear_dev(pz_ctx* ctx, const uint64_t* d_coeffs, size_t n_cols, size_t col_stride, size_t n,
                            const uint64_t x[4], uint64_t* d_q, size_t q_stride);
 
+/* SHPLONK multi-point opening (halo2 multiopen::shplonk::prover, the last step of create_proof; SURVEY.md section 8f
+ * rank 3).  Queries are grouped by rotation set: set k opens set_n_polys[k] coefficient-form polynomials (device
+ * pointers, n coefficients each, listed set after set in d_polys) at set_n_points[k] points given as indices into
+ * `points` (host, n_points_total x 4 limbs; the union of all sets' points, no duplicates).  evals (host): for each set,
+ * for each of its polynomials, its value at each of the set's points.  y, v, u: the transcript's challenges (host).
+ *   begin : d_h = sum_k v^k (sum_j y^j P_kj - R_k) / Z_{S_k}   (n coefficients; commit it, hash it, draw u)
+ *   finish: d_h2 = (sum_k v^k z_k (sum_j y^j P_kj - R_k(u)) - Z_T(u) h) / (X - u) / z_0,  z_k = Z_{T \ S_k}(u);
+ *           frees the state.  d_h2 may not alias d_h.
+ * At most 16 sets, 8 points per set, 32 points overall. */
+typedef struct pz_shplonk pz_shplonk;
+int pz_shplonk_begin_dev(pz_ctx* ctx, size_t n, uint32_t n_sets, const uint32_t* set_n_polys, const uint64_t* const* d_polys,
+                         const uint32_t* set_n_points, const uint32_t* point_idx, uint32_t n_points_total, const uint64_t* points,
+                         const uint64_t* evals, const uint64_t y[4], const uint64_t v[4], uint64_t* d_h, pz_shplonk** state);
+int pz_shplonk_finish_dev(pz_ctx* ctx, pz_shplonk* state, const uint64_t u[4], const uint64_t* d_h, uint64_t* d_h2);
+int pz_shplonk_free(pz_ctx* ctx, pz_shplonk* state);
+
 /* ---------------------------------------------------------------------------------------------
  * measurement helpers (used by bench.py; not part of the reference surface)
  * ------------------------------------------------------------------------------------------- */

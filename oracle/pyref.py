@@ -1008,3 +1008,74 @@ def gate_offsets_circuit(kind: str, enc_bits: int, limb_bits: int, lb: int, n_st
     add(gate_offsets_assign(L, limb_bits, lb))
     add(gate_offsets_assert_equal(L))
     return gates, off
+
+
+# ----------------------------------------------------------------------------------------
+# SHPLONK multi-point opening (halo2 multiopen::shplonk::prover).  Restated from the published
+# protocol as halo2 implements it (dependency, tag [D]); pinned by the opening identity the two output polynomials satisfy
+# (tests/test_oracle.py::test_shplonk_identity).  sets: list of (polys (coefficient lists), point indices); points: the union.
+# ----------------------------------------------------------------------------------------
+def _poly_mul_linear(p, x):   # p(X) * (X - x)
+    out = [0] * (len(p) + 1)
+    for i, c in enumerate(p):
+        out[i + 1] = (out[i + 1] + c) % FR_R
+        out[i] = (out[i] - c * x) % FR_R
+    return out
+
+
+def interpolate(xs: Sequence[int], ys: Sequence[int]) -> List[int]:
+    r = [0] * len(xs)
+    for t, (xt, yt) in enumerate(zip(xs, ys)):
+        b, den = [1], 1
+        for s_, xs_ in enumerate(xs):
+            if s_ != t:
+                b = _poly_mul_linear(b, xs_)
+                den = den * (xt - xs_) % FR_R
+        c = yt * pow(den, -1, FR_R) % FR_R
+        for k, bk in enumerate(b):
+            r[k] = (r[k] + bk * c) % FR_R
+    return r
+
+
+def shplonk_h(sets, points: Sequence[int], y: int, v: int, n: int):
+    """-> (h coefficients (n), folded polynomials C_k, interpolations R_k)"""
+    h = [0] * n
+    Cs, Rs = [], []
+    for k, (polys, idx) in enumerate(sets):
+        C = [sum(pow(y, j, FR_R) * p[i] for j, p in enumerate(polys)) % FR_R for i in range(n)]
+        xs = [points[i] for i in idx]
+        R = interpolate(xs, [poly_eval(C, x) for x in xs])
+        N = list(C)
+        for i, c in enumerate(R):
+            N[i] = (N[i] - c) % FR_R
+        for x in xs:
+            assert poly_eval(N, x) == 0
+            N = kate_division(N, x)
+        vk = pow(v, k, FR_R)
+        h = [(a + vk * b) % FR_R for a, b in zip(h, N)]
+        Cs.append(C)
+        Rs.append(R)
+    return h, Cs, Rs
+
+
+def shplonk_h2(sets, points: Sequence[int], y: int, v: int, u: int, n: int):
+    h, Cs, Rs = shplonk_h(sets, points, y, v, n)
+    zt = 1
+    for t in points:
+        zt = zt * (u - t) % FR_R
+    L = [(-zt * c) % FR_R for c in h]
+    z0 = None
+    for k, ((polys, idx), C, R) in enumerate(zip(sets, Cs, Rs)):
+        zk = 1
+        for t, x in enumerate(points):
+            if t not in idx:
+                zk = zk * (u - x) % FR_R
+        if k == 0:
+            z0 = zk
+        ck = pow(v, k, FR_R) * zk % FR_R
+        L = [(a + ck * b) % FR_R for a, b in zip(L, C)]
+        L[0] = (L[0] - ck * poly_eval(R, u)) % FR_R
+    assert poly_eval(L, u) == 0
+    q = kate_division(L, u)
+    z0i = pow(z0, -1, FR_R)
+    return h, [c * z0i % FR_R for c in q], z0

@@ -85,6 +85,10 @@ SIGNATURES = {
     "pz_fr_distribute_powers_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, C.c_size_t, VP, VP]),
     "pz_fr_lincomb_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, C.c_size_t, VP, VP, C.c_int]),
     "pz_poly_div_linear_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, C.c_size_t, VP, VP, C.c_size_t]),
+    "pz_shplonk_begin_dev": (C.c_int, [VP, C.c_size_t, C.c_uint32, U32P, C.POINTER(VP), U32P, U32P, C.c_uint32, VP, VP, VP, VP, VP,
+                                       C.POINTER(VP)]),
+    "pz_shplonk_finish_dev": (C.c_int, [VP, VP, VP, VP, VP]),
+    "pz_shplonk_free": (C.c_int, [VP, VP]),
     "pz_timing_enable": (C.c_int, [VP, C.c_int]),
     "pz_timing_reset": (C.c_int, [VP]),
     "pz_timing_get": (C.c_int, [VP, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

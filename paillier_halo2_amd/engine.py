@@ -434,6 +434,26 @@ class Engine:
         self._chk(self.L.pz_poly_div_linear_dev(self.ctx, VP(d_coeffs), n_cols, col_stride_u64, n, self._fr1(x), VP(d_q),
                                                 q_stride_u64), "pz_poly_div_linear_dev")
 
+    def shplonk_begin_dev(self, n: int, sets, points, y, v, d_h: int):
+        """sets: list of (list of device pointers, list of point indices, evals array (n_polys, n_points, 4)); points: (T, 4).
+        Returns the opaque state for shplonk_finish_dev."""
+        n_sets = len(sets)
+        npol = (C.c_uint32 * n_sets)(*[len(s_[0]) for s_ in sets])
+        npts = (C.c_uint32 * n_sets)(*[len(s_[1]) for s_ in sets])
+        ptrs = [p for s_ in sets for p in s_[0]]
+        parr = (VP * len(ptrs))(*[VP(p) for p in ptrs])
+        idx = [i for s_ in sets for i in s_[1]]
+        iarr = (C.c_uint32 * len(idx))(*idx)
+        pts = _np(points, 4)
+        ev = np.ascontiguousarray(np.concatenate([_np(s_[2]).reshape(-1, 4) for s_ in sets]), dtype=np.uint64)
+        st = VP()
+        self._chk(self.L.pz_shplonk_begin_dev(self.ctx, n, n_sets, npol, parr, npts, iarr, pts.shape[0], _ptr(pts), _ptr(ev), self._fr1(y),
+                                              self._fr1(v), VP(d_h), C.byref(st)), "pz_shplonk_begin_dev")
+        return st
+
+    def shplonk_finish_dev(self, state, u, d_h: int, d_h2: int):
+        self._chk(self.L.pz_shplonk_finish_dev(self.ctx, state, self._fr1(u), VP(d_h), VP(d_h2)), "pz_shplonk_finish_dev")
+
     # ------------------------------------------------------------------ measurement
     def timing_enable(self, on: bool = True):
         self._chk(self.L.pz_timing_enable(self.ctx, int(on)), "pz_timing_enable")

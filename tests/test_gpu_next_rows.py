@@ -648,3 +648,64 @@ def test_keygen_sigma_and_resident_columns(eng, cref):
         want_ext = P.ntt(P.coset_scale(cf + [0] * (n * E - n), 7), w_ext)
         assert cref.fr_mont_to_ints(ext[j]) == want_ext, j
     tb.free()
+
+
+@pytest.mark.parametrize("k", [5, 8])
+def test_shplonk_two_commitments(eng, cref, k):
+    """SHPLONK's multi-point batching on the device -- both output polynomials vs the oracle restatement,
+    their commitments with a known-scalar SRS, and the opening identity in the exponent:
+    sum_k v^k z_k (sum_j y^j [p_kj(s)] - R_k(u)) G - Z_T(u) H == z_0 (s - u) H'."""
+    import torch
+
+    rng = random.Random(600 + k)
+    n = 1 << k
+    w = P.fr_omega(k)
+    x = rng.randrange(P.FR_R)
+    points = [x, x * w % P.FR_R, x * pow(w, -1, P.FR_R) % P.FR_R, x * pow(w, n - 11, P.FR_R) % P.FR_R]
+    npoly = 7
+    polys = [[rng.randrange(P.FR_R) for _ in range(n)] for _ in range(npoly)]
+    groups = [([0, 1, 2], [0]), ([3, 4], [0, 1]), ([5], [0, 1, 2]), ([6], [0, 3])]   # (polynomial ids, point indices)
+    y, v, u, s_tox = (rng.randrange(2, P.FR_R) for _ in range(4))
+    d_p = torch.from_numpy(np.stack([cref.fr_ints_to_mont(p) for p in polys]).astype(np.int64)).cuda()
+    sets_dev, sets_ref = [], []
+    for ids, idx in groups:
+        ev = np.stack([cref.fr_ints_to_mont([P.poly_eval(polys[i], points[t]) for t in idx]) for i in ids])
+        sets_dev.append(([d_p[i].data_ptr() for i in ids], idx, ev))
+        sets_ref.append(([polys[i] for i in ids], idx))
+    d_h = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    d_h2 = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    F = lambda val: cref.fr_ints_to_mont([val])[0]
+    st = eng.shplonk_begin_dev(n, sets_dev, cref.fr_ints_to_mont(points), F(y), F(v), d_h.data_ptr())
+    eng.sync()
+    want_h, want_h2, z0 = P.shplonk_h2(sets_ref, points, y, v, u, n)
+    assert cref.fr_mont_to_ints(d_h.cpu().numpy().astype(np.uint64)) == want_h
+    eng.shplonk_finish_dev(st, F(u), d_h.data_ptr(), d_h2.data_ptr())
+    eng.sync()
+    assert cref.fr_mont_to_ints(d_h2.cpu().numpy().astype(np.uint64)) == want_h2
+    # the two commitments (monomial SRS from a known scalar) and the verifier's identity in the exponent
+    d_g = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    eng.srs_setup_g1_dev(k, F(s_tox), F(w), d_g.data_ptr(), 0)
+    eng.sync()
+    tb = eng.load_bases_dev(d_g.data_ptr(), n)
+    d_out = torch.zeros((2, 12), dtype=torch.int64, device="cuda")
+    eng.msm_dev(tb, d_h.data_ptr(), 1, n, 4 * n, d_out[0].data_ptr())
+    eng.msm_dev(tb, d_h2.data_ptr(), 1, n, 4 * n, d_out[1].data_ptr())
+    eng.sync()
+    H, H2 = cref.affine_mont_to_ints(eng.g1_normalize(d_out.cpu().numpy().astype(np.uint64)))
+    assert H == P.g1_mul(P.G1_GEN, P.poly_eval(want_h, s_tox)) and H2 == P.g1_mul(P.G1_GEN, P.poly_eval(want_h2, s_tox))
+    zt = 1
+    for t in points:
+        zt = zt * (u - t) % P.FR_R
+    acc = 0
+    for kk, (ps, idx) in enumerate(sets_ref):
+        zk = 1
+        for t, pt in enumerate(points):
+            if t not in idx:
+                zk = zk * (u - pt) % P.FR_R
+        C_s = sum(pow(y, j, P.FR_R) * P.poly_eval(p, s_tox) for j, p in enumerate(ps)) % P.FR_R
+        xs = [points[i] for i in idx]
+        R = P.interpolate(xs, [sum(pow(y, j, P.FR_R) * P.poly_eval(p, xx) for j, p in enumerate(ps)) % P.FR_R for xx in xs])
+        acc = (acc + pow(v, kk, P.FR_R) * zk * (C_s - P.poly_eval(R, u))) % P.FR_R
+    lhs = P.g1_add_aff(P.g1_mul(P.G1_GEN, acc), P.aff_neg(P.g1_mul(H, zt)))
+    assert lhs == P.g1_mul(H2, z0 * (s_tox - u) % P.FR_R)
+    tb.free()

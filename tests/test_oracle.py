@@ -313,3 +313,31 @@ def test_external_kats_halo2curves_fr(cref):
     w = pow(root, 1 << (c["S"] - k_), P.FR_R)
     dom = cref.fr_mont_to_ints(cref.ntt_fr(e1, cref.fr_ints_to_mont([w])[0], k_))
     assert dom == [pow(w, i, P.FR_R) for i in range(1 << k_)] and dom[1 << (k_ - 1)] == P.FR_R - 1
+
+
+def test_shplonk_identity():
+    """the SHPLONK restatement satisfies the opening identity at a 'toxic' point s:
+    sum_k v^k z_k (sum_j y^j p_kj(s) - R_k(u)) - Z_T(u) h(s) == z_0 (s - u) h'(s)"""
+    rng = random.Random(88)
+    n = 32
+    w = P.fr_omega(5)
+    x = rng.randrange(P.FR_R)
+    points = [x, x * w % P.FR_R, x * pow(w, -1, P.FR_R) % P.FR_R]
+    polys = [[rng.randrange(P.FR_R) for _ in range(n)] for _ in range(5)]
+    sets = [(polys[0:2], [0]), (polys[2:4], [0, 1]), (polys[4:5], [0, 1, 2])]
+    y, v, u, s = (rng.randrange(P.FR_R) for _ in range(4))
+    h, h2, z0 = P.shplonk_h2(sets, points, y, v, u, n)
+    zt = 1
+    for t in points:
+        zt = zt * (u - t) % P.FR_R
+    lhs = (-zt * P.poly_eval(h, s)) % P.FR_R
+    for k, (ps, idx) in enumerate(sets):
+        zk = 1
+        for t, pt in enumerate(points):
+            if t not in idx:
+                zk = zk * (u - pt) % P.FR_R
+        C_s = sum(pow(y, j, P.FR_R) * P.poly_eval(p, s) for j, p in enumerate(ps)) % P.FR_R
+        xs = [points[i] for i in idx]
+        R = P.interpolate(xs, [sum(pow(y, j, P.FR_R) * P.poly_eval(p, xx) for j, p in enumerate(ps)) % P.FR_R for xx in xs])
+        lhs = (lhs + pow(v, k, P.FR_R) * zk * (C_s - P.poly_eval(R, u))) % P.FR_R
+    assert lhs == z0 * (s - u) * P.poly_eval(h2, s) % P.FR_R
