@@ -173,6 +173,17 @@ int pz_paillier_encrypt_dev(pz_ctx* ctx, uint32_t limbs_n, size_t batch, const u
                             const uint64_t* m, const uint64_t* r, uint64_t* d_steps_out, size_t steps_cap,
                             uint32_t* n_steps_g, uint32_t* n_steps_r, uint64_t* c_out);
 
+/* Uniform-shape variant (NOT the reference's circuit): g^m as BigUintChip::pow_mod over exactly
+ * m_bits in-circuit exponent bits -- per bit the step (acc, sq) [kept only if the bit is set: select] then the step (sq, sq)
+ * -- so n_steps_g = 2 * m_bits for every message and one vk / pk serves every proof of a key.  r^n and the final mul_mod as
+ * above.  PZ_ERR_RANGE if a message does not fit m_bits.  Same buffer conventions as pz_paillier_encrypt[_dev]. */
+int pz_paillier_encrypt_uniform(pz_ctx* ctx, uint32_t limbs_n, size_t batch, uint32_t m_bits, const uint64_t* n, const uint64_t* g,
+                                const uint64_t* m, const uint64_t* r, uint64_t* steps_out, size_t steps_cap, uint32_t* n_steps_g,
+                                uint32_t* n_steps_r, uint64_t* c_out);
+int pz_paillier_encrypt_uniform_dev(pz_ctx* ctx, uint32_t limbs_n, size_t batch, uint32_t m_bits, const uint64_t* n,
+                                    const uint64_t* g, const uint64_t* m, const uint64_t* r, uint64_t* d_steps_out, size_t steps_cap,
+                                    uint32_t* n_steps_g, uint32_t* n_steps_r, uint64_t* c_out);
+
 /* ---------------------------------------------------------------------------------------------
  * K4 -- expansion of a step trace into advice-column cells (Fr Montgomery, 32 B each), i.e. the
  * values halo2-lib's Context would hold after BigUintChip emitted the constraints of every

@@ -1079,3 +1079,31 @@ def shplonk_h2(sets, points: Sequence[int], y: int, v: int, u: int, n: int):
     q = kate_division(L, u)
     z0i = pow(z0, -1, FR_R)
     return h, [c * z0i % FR_R for c in q], z0
+
+
+# ----------------------------------------------------------------------------------------
+# the uniform-shape encrypt circuit.  g^m through BigUintChip::pow_mod (exponent bits IN the
+# circuit, halo2-rsa lineage [D]): for each of exactly m_bits bits, LSB first:  muled = mul_mod(acc, squared);
+# acc = select(bit, muled, acc); squared = square_mod(squared).  The step count no longer depends on the message.
+# ----------------------------------------------------------------------------------------
+def pow_mod_uniform_trace(a: int, e: int, m_bits: int, modulus: int) -> Tuple[int, List[Step]]:
+    assert e >> m_bits == 0, "exponent does not fit m_bits"
+    steps: List[Step] = []
+    acc, squared = 1, a
+    for i in range(m_bits):
+        st = mul_mod_step(acc, squared, modulus)
+        steps.append(st)
+        if (e >> i) & 1:
+            acc = st[3]
+        st = mul_mod_step(squared, squared, modulus)
+        steps.append(st)
+        squared = st[3]
+    return acc, steps
+
+
+def encrypt_uniform_trace(n: int, g: int, m: int, r: int, m_bits: int):
+    n2 = n * n
+    gm, steps_g = pow_mod_uniform_trace(g, m, m_bits, n2)
+    rn, steps_r = pow_mod_fixed_exp_trace(r, n, n2)
+    final = mul_mod_step(gm, rn, n2)
+    return final[3], steps_g, steps_r, final

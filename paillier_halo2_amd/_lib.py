@@ -50,6 +50,8 @@ SIGNATURES = {
     "pz_paillier_trace": (C.c_int, [VP, C.c_uint32, VP, VP, VP, C.c_uint32, VP, C.POINTER(C.c_size_t), VP]),
     "pz_paillier_encrypt": (C.c_int, [VP, C.c_uint32, C.c_size_t, VP, VP, VP, VP, VP, C.c_size_t, VP, VP, VP]),
     "pz_paillier_encrypt_dev": (C.c_int, [VP, C.c_uint32, C.c_size_t, VP, VP, VP, VP, VP, C.c_size_t, VP, VP, VP]),
+    "pz_paillier_encrypt_uniform": (C.c_int, [VP, C.c_uint32, C.c_size_t, C.c_uint32, VP, VP, VP, VP, VP, C.c_size_t, VP, VP, VP]),
+    "pz_paillier_encrypt_uniform_dev": (C.c_int, [VP, C.c_uint32, C.c_size_t, C.c_uint32, VP, VP, VP, VP, VP, C.c_size_t, VP, VP, VP]),
     "pz_witness_cells_per_step": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t),
                                             C.POINTER(C.c_size_t)]),
     "pz_witness_expand": (C.c_int, [VP, C.c_uint32, C.c_uint32, C.c_uint32, VP, C.c_size_t, VP, VP, VP]),

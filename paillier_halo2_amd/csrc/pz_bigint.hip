@@ -401,6 +401,8 @@ struct ChainDesc {
     u32 L;               // operand/result limb count (limbs of the modulus n^2)
     u32 square_modulus;
     u32 steps_cap;
+    u32 uniform_bits;    // != 0: pow_mod with the exponent's bits IN the circuit: exactly this many
+                         // bits, per bit the step (acc, sq) then the step (sq, sq); acc takes the product only if the bit is set
 };
 
 template <int E> __global__ __launch_bounds__(128) void k_pow_mod_chain(const ChainDesc* __restrict__ descs) {
@@ -433,42 +435,47 @@ template <int E> __global__ __launch_bounds__(128) void k_pow_mod_chain(const Ch
     }
     LD<E> sq = ld_load<E>(D.base, D.limbs_base);
     LD<E> acc = ld_small<E>(1);
-    unsigned step_idx = 0;  // index of this bit's squaring step
+    unsigned step_idx = 0;  // index of this bit's first step
+    const bool uni = D.uniform_bits != 0;
+    if (uni) nbits = D.uniform_bits;
     if (mod_ok) {
         for (unsigned i = 0; i < nbits; ++i) {
-            const bool bit = (D.exp[i >> 6] >> (i & 63)) & 1;
+            const bool bit = (i >> 6) < D.exp_limbs && ((D.exp[i >> 6] >> (i & 63)) & 1);
             if (wave == 0) {
 #pragma unroll
                 for (int e = 0; e < E; ++e) s_cur[i & 1][lane_id() * E + e] = sq.v[e];
             }
             __syncthreads();
+            // reference schedule (pow_mod_fixed_exp): squaring step, then the multiply step on set bits;
+            // uniform schedule (pow_mod): multiply step for EVERY bit, then the squaring step
+            const unsigned sq_slot = uni ? step_idx + 1 : step_idx, mul_slot = uni ? step_idx : step_idx + 1;
             if (wave == 0) {
                 LD<E> q, r;
                 st |= mul_mod(B, q, r, sq, sq);
-                if (D.steps && step_idx < D.steps_cap) {
-                    u64* o = D.steps + (size_t)step_idx * 4 * D.L;
+                if (D.steps && sq_slot < D.steps_cap) {
+                    u64* o = D.steps + (size_t)sq_slot * 4 * D.L;
                     ld_store(o, sq, D.L);
                     ld_store(o + D.L, sq, D.L);
                     ld_store(o + 2 * D.L, q, D.L);
                     ld_store(o + 3 * D.L, r, D.L);
                 }
                 sq = r;
-            } else if (bit) {
+            } else if (bit || uni) {
                 LD<E> cur;
 #pragma unroll
                 for (int e = 0; e < E; ++e) cur.v[e] = s_cur[i & 1][lane_id() * E + e];
                 LD<E> q, r;
                 st |= mul_mod(B, q, r, acc, cur);
-                if (D.steps && step_idx + 1 < D.steps_cap) {
-                    u64* o = D.steps + (size_t)(step_idx + 1) * 4 * D.L;
+                if (D.steps && mul_slot < D.steps_cap) {
+                    u64* o = D.steps + (size_t)mul_slot * 4 * D.L;
                     ld_store(o, acc, D.L);
                     ld_store(o + D.L, cur, D.L);
                     ld_store(o + 2 * D.L, q, D.L);
                     ld_store(o + 3 * D.L, r, D.L);
                 }
-                acc = r;
+                if (bit) acc = r;   // select(bit, muled, acc)
             }
-            step_idx += bit ? 2 : 1;
+            step_idx += (bit || uni) ? 2 : 1;
         }
     }
     if (D.steps && step_idx > D.steps_cap) st |= ST_INTERNAL;
@@ -642,8 +649,9 @@ extern "C" int pz_paillier_trace(pz_ctx* ctx, uint32_t limbs_n2, const uint64_t*
 
 static int encrypt_impl(pz_ctx* ctx, uint32_t Ln, size_t batch, const uint64_t* n, const uint64_t* g,
                         const uint64_t* m, const uint64_t* r, uint64_t* steps_out, int steps_on_device,
-                        size_t steps_cap, uint32_t* n_steps_g, uint32_t* n_steps_r, uint64_t* c_out) {
+                        size_t steps_cap, uint32_t* n_steps_g, uint32_t* n_steps_r, uint64_t* c_out, uint32_t uniform_m_bits = 0) {
     if (!ctx || !n || !g || !m || !r || !c_out || Ln == 0 || batch == 0) return PZ_ERR_INVALID;
+    if (uniform_m_bits > 64 * Ln) return PZ_ERR_INVALID;
     const unsigned L = 2 * Ln;
     if (L > 128) return PZ_ERR_UNSUPPORTED;
     if (steps_cap > 0x7fffffffu) return PZ_ERR_INVALID;
@@ -661,8 +669,12 @@ static int encrypt_impl(pz_ctx* ctx, uint32_t Ln, size_t batch, const uint64_t* 
             for (uint32_t k = 0; k < Ln; ++k) need += (size_t)__builtin_popcountll(e[k]);
             return (uint32_t)need;
         };
-        ng[i] = count(m + i * Ln);
+        ng[i] = uniform_m_bits ? 2 * uniform_m_bits : count(m + i * Ln);
         nr[i] = count(n + i * Ln);
+        if (uniform_m_bits) {   // the message must fit the bits the circuit decomposes
+            for (uint32_t b = uniform_m_bits; b < 64 * Ln; ++b)
+                if ((m[i * Ln + (b >> 6)] >> (b & 63)) & 1) return PZ_ERR_RANGE;
+        }
         if (steps_out && (size_t)ng[i] + nr[i] + 1 > steps_cap) return PZ_ERR_CAPACITY;
     }
     // device staging: inputs n,g,m,r (batch x Ln each), results gm, rn, c (batch x L), status, descs
@@ -714,8 +726,10 @@ static int encrypt_impl(pz_ctx* ctx, uint32_t Ln, size_t batch, const uint64_t* 
         a.L = L;
         a.square_modulus = 1;
         a.steps_cap = ng[i];
+        a.uniform_bits = uniform_m_bits;
         ChainDesc& b = ch[2 * i + 1];
         b = a;
+        b.uniform_bits = 0;   // n is the public key: its bits stay circuit structure (pow_mod_fixed_exp)
         b.base = d_r + i * Ln;
         b.exp = d_n + i * Ln;
         b.steps = st_i ? st_i + (size_t)ng[i] * 4 * L : nullptr;
@@ -770,4 +784,23 @@ extern "C" int pz_paillier_encrypt_dev(pz_ctx* ctx, uint32_t limbs_n, size_t bat
                                        const uint64_t* g, const uint64_t* m, const uint64_t* r, uint64_t* d_steps_out,
                                        size_t steps_cap, uint32_t* n_steps_g, uint32_t* n_steps_r, uint64_t* c_out) {
     return encrypt_impl(ctx, limbs_n, batch, n, g, m, r, d_steps_out, 1, steps_cap, n_steps_g, n_steps_r, c_out);
+}
+
+// the UNIFORM-SHAPE encrypt circuit's witness.  The reference pulls the exponent m out of the
+// witness (paillier.rs:50: pow_mod_fixed_exp), so its circuit -- hence vk / pk -- is shaped by the secret message; here
+// g^m runs as BigUintChip::pow_mod over exactly `m_bits` in-circuit bits (per bit: mul_mod(acc, sq), select, square_mod),
+// so every message of a key shares one circuit shape: 2 * m_bits steps for g^m, then the r^n chain (n is public: fixed
+// exponent as in the reference) and the final mul_mod.  `batch` independent messages per call.  Not bit-compatible with
+// the reference's circuit by construction (a different constraint system proving the same statement).
+extern "C" int pz_paillier_encrypt_uniform(pz_ctx* ctx, uint32_t limbs_n, size_t batch, uint32_t m_bits, const uint64_t* n,
+                                           const uint64_t* g, const uint64_t* m, const uint64_t* r, uint64_t* steps_out,
+                                           size_t steps_cap, uint32_t* n_steps_g, uint32_t* n_steps_r, uint64_t* c_out) {
+    if (m_bits == 0) return PZ_ERR_INVALID;
+    return encrypt_impl(ctx, limbs_n, batch, n, g, m, r, steps_out, 0, steps_cap, n_steps_g, n_steps_r, c_out, m_bits);
+}
+extern "C" int pz_paillier_encrypt_uniform_dev(pz_ctx* ctx, uint32_t limbs_n, size_t batch, uint32_t m_bits, const uint64_t* n,
+                                               const uint64_t* g, const uint64_t* m, const uint64_t* r, uint64_t* d_steps_out,
+                                               size_t steps_cap, uint32_t* n_steps_g, uint32_t* n_steps_r, uint64_t* c_out) {
+    if (m_bits == 0) return PZ_ERR_INVALID;
+    return encrypt_impl(ctx, limbs_n, batch, n, g, m, r, d_steps_out, 1, steps_cap, n_steps_g, n_steps_r, c_out, m_bits);
 }

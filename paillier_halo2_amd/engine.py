@@ -278,6 +278,28 @@ class Engine:
                                              VP(nr.ctypes.data), _ptr(c)), "pz_paillier_encrypt")
         return c, steps, ng, nr
 
+    def paillier_encrypt_uniform(self, limbs_n: int, m_bits: int, n, g, m, r, want_steps: bool = True):
+        """uniform-shape circuit (pz.h): batch form, 2*m_bits steps for g^m whatever the messages are.
+        Returns (c, steps or None, n_steps_g, n_steps_r)."""
+        n, g, m, r = (_np(x).reshape(-1, limbs_n) for x in (n, g, m, r))
+        batch = n.shape[0]
+        L = 2 * limbs_n
+        cap, steps = 0, None
+        if want_steps:
+            for i in range(batch):
+                e_int = 0
+                for k, l in enumerate(n[i].tolist()):
+                    e_int |= int(l) << (64 * k)
+                cap = max(cap, 2 * m_bits + e_int.bit_length() + bin(e_int).count("1") + 1)
+            steps = np.zeros((batch, cap, 4, L), dtype=np.uint64)
+        ng = np.zeros(batch, dtype=np.uint32)
+        nr = np.zeros(batch, dtype=np.uint32)
+        c = np.zeros((batch, L), dtype=np.uint64)
+        self._chk(self.L.pz_paillier_encrypt_uniform(self.ctx, limbs_n, batch, m_bits, _ptr(n), _ptr(g), _ptr(m), _ptr(r),
+                                                     _ptr(steps) if want_steps else VP(), cap, VP(ng.ctypes.data), VP(nr.ctypes.data),
+                                                     _ptr(c)), "pz_paillier_encrypt_uniform")
+        return c, steps, ng, nr
+
     # ------------------------------------------------------------------ K4: witness expansion
     def witness_cells_per_step(self, limbs: int, limb_bits: int, lookup_bits: int) -> Tuple[int, int]:
         a = C.c_size_t()

@@ -940,3 +940,38 @@ def test_srs_lagrange_from_monomial(eng, cref, k):
         assert np.array_equal(eng.g1_normalize(eng.msm(tb_l, evals))[0], eng.g1_normalize(eng.msm(tb_g, d_c.cpu().numpy().astype(np.uint64)))[0])
         tb_g.free()
         tb_l.free()
+
+
+def test_uniform_shape_encrypt_batch(eng, cref):
+    """the uniform-shape witness (g^m as pow_mod over m_bits in-circuit bits): a batch of different
+    messages under one key gives traces of IDENTICAL length (2 m_bits + the r^n chain + 1), each equal to the oracle's
+    schedule and ending in the same ciphertext as the reference formula; a message wider than m_bits is refused."""
+    import paillier_halo2_amd as pz
+
+    Ln, bits, m_bits = 2, 128, 40
+    rng = random.Random(4040)
+    n = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+    g = n + 1
+    msgs = [0, 1, (1 << m_bits) - 1, rng.getrandbits(m_bits), rng.getrandbits(m_bits - 7)]
+    rs = [rng.randrange(1, n) for _ in msgs]
+    arr = lambda vals: np.stack([cref.int_to_limbs(v, Ln) for v in vals])
+    c, steps, ng, nr = eng.paillier_encrypt_uniform(Ln, m_bits, arr([n] * len(msgs)), arr([g] * len(msgs)), arr(msgs), arr(rs))
+    assert set(int(x) for x in ng) == {2 * m_bits} and len(set(int(x) for x in nr)) == 1
+    for i, (m, r) in enumerate(zip(msgs, rs)):
+        res, sg, sr, fin = P.encrypt_uniform_trace(n, g, m, r, m_bits)
+        assert res == P.paillier_enc_native(n, g, m, r) == cref.limbs_to_int(c[i])
+        want = sg + sr + [fin]
+        got = [tuple(cref.limbs_to_int(steps[i, k, q]) for q in range(4)) for k in range(len(want))]
+        assert got == want, i
+    with pytest.raises(pz._lib.PzError) as ei:
+        eng.paillier_encrypt_uniform(Ln, m_bits, arr([n]), arr([g]), arr([1 << m_bits]), arr([rs[0]]))
+    assert ei.value.status == pz._lib.PZ_ERR_RANGE
+    # 2048-bit key, full-width message bits: values only (no trace), batch of 3
+    Ln, bits = 32, 2048
+    n, g, _, _ = P.synth_paillier_inputs(bits, 0x5047)
+    msgs = [rng.randrange(n) for _ in range(3)]
+    rs = [rng.randrange(1, n) for _ in range(3)]
+    arr = lambda vals: np.stack([cref.int_to_limbs(v, Ln) for v in vals])
+    c, _, ng, nr = eng.paillier_encrypt_uniform(Ln, bits, arr([n] * 3), arr([g] * 3), arr(msgs), arr(rs), want_steps=False)
+    assert [cref.limbs_to_int(c[i]) for i in range(3)] == [P.paillier_enc_native(n, g, m, r) for m, r in zip(msgs, rs)]
+    assert set(int(x) for x in ng) == {2 * bits}
