@@ -208,7 +208,9 @@ int pz_witness_expand_dev(pz_ctx* ctx, uint32_t limbs, uint32_t limb_bits, uint3
  * kind = 0; bench.rs:77-117 paillier_enc_add_test, kind = 1): assign_integer of n, g, m|c1, r|c2; square + refresh of n
  * (paillier.rs:39-45 / 69-75); load_zero; for encrypt both pow_mod_fixed_exp chains (assign_constant(1), load_zero, their
  * mul_mod steps); the final mul_mod; assign_integer(res, 2*enc_bits); assert_equal_fresh.  Layout and per-operation cell
- * patterns: paillier_halo2_amd/layout.py::circuit_cells, DESIGN.md section 4 (dependency-derived, SURVEY tag [D]). */
+ * patterns: paillier_halo2_amd/layout.py::circuit_cells, DESIGN.md section 4 (dependency-derived, SURVEY tag [D]).
+ * kind = 2: the uniform-shape encrypt circuit of pz_paillier_encrypt_uniform (g^m as pow_mod: num_to_bits of m's limbs, per
+ * bit mul_mod + limb-wise select + square_mod; n_steps_g = 2 * limbs_n * limb_bits). */
 int pz_circuit_cells(int kind, uint32_t limbs_n, uint32_t limb_bits, uint32_t lookup_bits, size_t n_steps_g,
                      size_t n_steps_r, size_t* advice_cells, size_t* lookup_cells);
 /* inputs (HOST): n | g | x | y as ceil(limbs_n*limb_bits/64) 64-bit words each, then res as ceil(2*limbs_n*limb_bits/64)

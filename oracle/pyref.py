@@ -1107,3 +1107,111 @@ def encrypt_uniform_trace(n: int, g: int, m: int, r: int, m_bits: int):
     rn, steps_r = pow_mod_fixed_exp_trace(r, n, n2)
     final = mul_mod_step(gm, rn, n2)
     return final[3], steps_g, steps_r, final
+
+
+def _num_to_bits_cells(x: int, nbits: int):
+    """FlexGate::num_to_bits(x, nbits): the inner product of the bits with the powers of two (1 + 3 (nbits - 1) cells, the
+    bits are its a-operands), then assert_bit of every bit ([0, b, b, b])"""
+    bits = [(x >> i) & 1 for i in range(nbits)]
+    adv = [bits[0]]
+    acc = bits[0]
+    for i in range(1, nbits):
+        acc += bits[i] << i
+        adv += [bits[i], 1 << i, acc]
+    for b in bits:
+        adv += [0, b, b, b]
+    return adv, bits
+
+
+def _select_cells(a: int, b: int, sel: int):
+    """FlexGate::select(a, b, sel) = sel ? a : b : | a - b | 1 | b | a | b | sel | a - b | out |"""
+    d = a - b
+    return [d, 1, b, a, b, sel, d, d * sel + b]
+
+
+def expand_uniform_circuit_cells(n: int, g: int, m: int, r: int, res: int, enc_bits: int, limb_bits: int, lb: int):
+    """the uniform-shape encrypt circuit: as expand_circuit_cells('encrypt'), with g^m through pow_mod:
+    assign_constant(1), load_zero, then per limb of m: num_to_bits, and per bit: mul_mod(acc, sq), select limb by limb,
+    square_mod(sq)"""
+    Ln = enc_bits // limb_bits
+    L = 2 * Ln
+    adv, lk, seg = [], [], {}
+
+    def put(name, a, l=()):
+        seg[name] = (len(adv), len(lk))
+        adv.extend(a)
+        lk.extend(l)
+
+    for name, v in (("assign_n", n), ("assign_g", g), ("assign_x", m), ("assign_y", r)):
+        put(name, *expand_assign_cells(v, Ln, limb_bits, lb))
+    nl = decompose_biguint(n, Ln, limb_bits)
+    sq_cells, prod = _mul_cells(nl, nl, 2 * Ln - 1)
+    put("square", sq_cells)
+    r_adv, r_lk, fresh = expand_refresh_cells(prod, refresh_aux(limb_bits, Ln, Ln), limb_bits, lb)
+    put("refresh", r_adv, r_lk)
+    put("load_zero", [0])
+    n2 = n * n
+    c, sg, sr, fin = encrypt_uniform_trace(n, g, m, r, enc_bits)
+    put("pow_g", [1, 0])
+    ml = decompose_biguint(m, Ln, limb_bits)
+    for li in range(Ln):
+        nb_cells, bits = _num_to_bits_cells(ml[li], limb_bits)
+        adv.extend(nb_cells)
+        for bi in range(limb_bits):
+            i = li * limb_bits + bi
+            st_mul, st_sq = sg[2 * i], sg[2 * i + 1]
+            a_, l_ = expand_mul_mod_cells(*st_mul, n2, L, lb, limb_bits)
+            adv.extend(a_)
+            lk.extend(l_)
+            acc_l, mul_l = decompose_biguint(st_mul[0], L, limb_bits), decompose_biguint(st_mul[3], L, limb_bits)
+            for t in range(L):
+                adv.extend(_select_cells(mul_l[t], acc_l[t], bits[bi]))
+            a_, l_ = expand_mul_mod_cells(*st_sq, n2, L, lb, limb_bits)
+            adv.extend(a_)
+            lk.extend(l_)
+    put("pow_r", [1, 0])
+    for st in sr:
+        a_, l_ = expand_mul_mod_cells(*st, n2, L, lb, limb_bits)
+        adv.extend(a_)
+        lk.extend(l_)
+    put("final", *expand_mul_mod_cells(*fin, n2, L, lb, limb_bits))
+    put("assign_res", *expand_assign_cells(res, L, limb_bits, lb))
+    ae, bit = expand_assert_equal_fresh_cells(decompose_biguint(c, L, limb_bits), decompose_biguint(res, L, limb_bits))
+    put("assert_equal", ae)
+    seg["end"] = (len(adv), len(lk))
+    seg["satisfied"] = bool(bit)
+    return [v % FR_R for v in adv], [v % FR_R for v in lk], seg
+
+
+def gate_offsets_uniform_circuit(enc_bits: int, limb_bits: int, lb: int, n_steps_r: int):
+    Ln = enc_bits // limb_bits
+    L = 2 * Ln
+    gates, off = [], 0
+
+    def add(part):
+        nonlocal off
+        g_, n_ = part
+        gates.extend(off + o for o in g_)
+        off += n_
+
+    for _ in range(4):
+        add(gate_offsets_assign(Ln, limb_bits, lb))
+    add(gate_offsets_square(Ln))
+    add(gate_offsets_refresh(refresh_aux(limb_bits, Ln, Ln), limb_bits, lb))
+    off += 1
+    mm = gate_offsets_mul_mod(L, lb, limb_bits)
+    off += 2
+    W = limb_bits
+    for _ in range(Ln):
+        add(([3 * i for i in range(W - 1)] + [1 + 3 * (W - 1) + 4 * i for i in range(W)], 7 * W - 2))
+        for _ in range(W):
+            add(mm)
+            add(([8 * t + o for t in range(L) for o in (0, 4)], 8 * L))
+            add(mm)
+    off += 2
+    for _ in range(n_steps_r):
+        add(mm)
+    add(mm)
+    add(gate_offsets_assign(L, limb_bits, lb))
+    add(gate_offsets_assert_equal(L))
+    return gates, off

@@ -187,6 +187,8 @@ struct ExpP {
     u64 max_w[3];  // L*(2^W-1)^2 + (2^W-1)
     size_t cell0, lk0;        // stream index of this launch's first advice / lookup cell
     size_t rows, pad;         // column cut of the stream (CellPtr); 0, 0 = dense
+    size_t pair_stride, odd_off;   // != 0: steps come in pairs (uniform-shape circuit): step s sits at
+                                   // cell0 + (s / 2) * pair_stride + (s & 1) * odd_off instead of cell0 + s * cells
 };
 
 // position p of RangeChip::range_check(x, bits): advice pattern
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
     const bool wide = W > 64;
     const size_t step = blockIdx.x;
     const u64* st = steps + step * 4 * (size_t)P.L64;
-    const CellPtr adv{advice, P.cell0 + step * P.cells, P.rows, P.pad};
+    const CellPtr adv{advice, P.cell0 + (P.pair_stride ? (step >> 1) * P.pair_stride + (step & 1) * P.odd_off : step * P.cells), P.rows, P.pad};
     const CellPtr lk{lookup, P.lk0 + step * P.lookups, P.rows, P.pad};
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const U192 MAXV = u_make(P.max_w[0], P.max_w[1], P.max_w[2]);
@@ -759,7 +761,7 @@ __global__ __launch_bounds__(256) void k_circuit_misc(CircP C, const u64* __rest
     // ---- load_zero; assign_constant(1) + load_zero of both pow_mod_fixed_exp
     if (tid == 0) {
         fp_store(adv + C.a_zero, fp_zero<FrTag>());
-        if (C.kind == 0)
+        if (C.kind != 1)
             for (int k = 0; k < 2; ++k) {
                 fp_store(adv + C.a_pow[k], fp_one<FrTag>());
                 fp_store(adv + C.a_pow[k] + 1, fp_zero<FrTag>());
@@ -780,6 +782,60 @@ __global__ __launch_bounds__(256) void k_circuit_misc(CircP C, const u64* __rest
         fp_store(adv + C.a_eq + 2 + t, v);
     }
 #undef LIMB
+}
+
+// ---- uniform-shape circuit: FlexGate::num_to_bits of the message's limbs and the limb-wise select after
+// every mul_mod(acc, sq) of pow_mod.  grid.x = limb of m (num_to_bits) / exponent bit (select).
+__global__ __launch_bounds__(256) void k_circuit_bits(ExpP P, unsigned Ln, unsigned words_n, const u64* __restrict__ m_words,
+                                                      size_t cell_base, size_t limb_stride, Fr* __restrict__ advice) {
+    const unsigned li = blockIdx.x, W = P.W;
+    u64 lw[2];
+    limb_extract(m_words, words_n, li, W, lw);
+    const U192 x = u_make(lw[0], lw[1]);
+    const CellPtr a{advice, cell_base + (size_t)li * limb_stride, P.rows, P.pad};
+    const unsigned nip = 1 + 3 * (W - 1);
+    for (unsigned t = threadIdx.x; t < nip + 4 * W; t += blockDim.x) {
+        Fr v;
+        if (t == 0) v = fr_from_u(u_lowbits(x, 1));
+        else if (t < nip) {
+            const unsigned i = (t - 1) / 3 + 1, w = (t - 1) % 3;
+            v = w == 0 ? fr_from_u(u_lowbits(u_shr(x, i), 1)) : w == 1 ? fr_from_u(u_shl(u_make(1), i)) : fr_from_u(u_lowbits(x, i + 1));
+        } else {
+            const unsigned i = (t - nip) / 4, w = (t - nip) % 4;
+            v = w == 0 ? fp_zero<FrTag>() : fr_from_u(u_lowbits(u_shr(x, i), 1));
+        }
+        fp_store(a + t, v);
+    }
+}
+__global__ __launch_bounds__(256) void k_circuit_select(ExpP P, unsigned Ln, unsigned words_n, const u64* __restrict__ m_words,
+                                                        const u64* __restrict__ steps, size_t cell_base, size_t limb_stride,
+                                                        size_t bit_stride, size_t nbits_cells, Fr* __restrict__ advice) {
+    const unsigned i = blockIdx.x, W = P.W, L = P.L;        // exponent bit i = limb li, bit bi
+    const unsigned li = i / W, bi = i % W;
+    u64 lw[2];
+    limb_extract(m_words, words_n, li, W, lw);
+    const unsigned bit = (unsigned)(u_lowbits(u_shr(u_make(lw[0], lw[1]), bi), 1).w[0]);
+    const u64* st = steps + (size_t)(2 * i) * 4 * P.L64;    // the mul_mod(acc, sq) step: a = acc, r = muled
+    // cells of this bit: after its limb's num_to_bits block and its mul_mod step
+    const CellPtr a{advice, cell_base + (size_t)li * limb_stride + nbits_cells + (size_t)bi * bit_stride + P.cells, P.rows, P.pad};
+    for (unsigned t = threadIdx.x; t < 8 * L; t += blockDim.x) {
+        const unsigned limb = t / 8, p = t % 8;
+        u64 aw[2], mw[2];
+        limb_extract(st, P.L64, limb, W, aw);                           // acc
+        limb_extract(st + 3 * (size_t)P.L64, P.L64, limb, W, mw);       // muled
+        const U192 acc = u_make(aw[0], aw[1]), mul = u_make(mw[0], mw[1]);
+        const S192 d = s_sub(mul, acc);
+        Fr v;
+        switch (p) {
+            case 0: case 6: v = fr_from_s(d); break;
+            case 1: v = fp_one<FrTag>(); break;
+            case 2: case 4: v = fr_from_u(acc); break;
+            case 3: v = fr_from_u(mul); break;
+            case 5: v = bit ? fp_one<FrTag>() : fp_zero<FrTag>(); break;
+            default: v = fr_from_u(bit ? mul : acc); break;
+        }
+        fp_store(a + t, v);
+    }
 }
 
 // RefreshAux::new(limb_bits, l, r).increased_limbs_vec with the maximal limb values tracked as bit lengths + exact
@@ -832,7 +888,7 @@ static int refresh_aux_host(unsigned W, unsigned nl, unsigned nr, unsigned char*
 
 static int make_circuit_params(int kind, uint32_t limbs_n, uint32_t limb_bits, uint32_t lb, size_t ng, size_t nr, CircP& C,
                                size_t* adv_total, size_t* lk_total, size_t step_off[3]) {
-    if (kind != 0 && kind != 1) return PZ_ERR_INVALID;
+    if (kind < 0 || kind > 2) return PZ_ERR_INVALID;
     if (limbs_n < 1 || 2 * limbs_n > CIRC_MAXF || 2 * limbs_n > EXP_MAXL) return PZ_ERR_UNSUPPORTED;
     memset(&C, 0, sizeof C);
     PZCHK(make_params(2 * limbs_n, limb_bits, lb, C.e));
@@ -858,6 +914,14 @@ static int make_circuit_params(int kind, uint32_t limbs_n, uint32_t limb_bits, u
     size_t lstep[3] = {0, 0, 0};
     if (kind == 0) {
         C.a_pow[0] = a; a += 2; step_off[0] = a; lstep[0] = l; a += ng * C.e.cells; l += ng * C.e.lookups;
+        C.a_pow[1] = a; a += 2; step_off[1] = a; lstep[1] = l; a += nr * C.e.cells; l += nr * C.e.lookups;
+    } else if (kind == 2) {
+        // uniform shape: per limb of m [num_to_bits | per bit: mul_mod, select (8 cells per limb), square_mod]
+        const size_t m_bits = (size_t)limbs_n * limb_bits;
+        if (ng != 2 * m_bits) return PZ_ERR_INVALID;
+        C.a_pow[0] = a; a += 2; step_off[0] = a; lstep[0] = l;
+        a += (size_t)limbs_n * (7 * (size_t)limb_bits - 2) + m_bits * (2 * C.e.cells + 8 * (size_t)C.e.L);
+        l += ng * C.e.lookups;
         C.a_pow[1] = a; a += 2; step_off[1] = a; lstep[1] = l; a += nr * C.e.cells; l += nr * C.e.lookups;
     } else if (ng || nr) return PZ_ERR_INVALID;
     step_off[2] = a; lstep[2] = l; a += C.e.cells; l += C.e.lookups;
@@ -953,13 +1017,34 @@ extern "C" int pz_circuit_expand_dev(pz_ctx* ctx, int kind, uint32_t limbs_n, ui
     HIPCHK(ctx, hipMemcpyAsync(d_in, inputs, in_words * 8, hipMemcpyHostToDevice, ctx->stream));
     pz_timer tm(ctx, PZ_T_EXPAND);
     const size_t rec = 4 * (size_t)C.e.L64;   // words per step record
-    const size_t runs[3] = {kind == 0 ? n_steps_g : 0, kind == 0 ? n_steps_r : 0, 1};
+    const size_t runs[3] = {kind != 1 ? n_steps_g : 0, kind != 1 ? n_steps_r : 0, 1};
     size_t first = 0;
     for (int k = 0; k < 3; ++k) {
         if (runs[k]) {
             ExpP P = C.e;
             P.cell0 = so[k];
             P.lk0 = so[3 + k];
+            if (kind == 2 && k == 0) {
+                // the g^m steps come in (mul_mod, square_mod) pairs with the select cells in between and a num_to_bits block
+                // in front of every limb's 64 bits: launch limb by limb
+                const size_t W = limb_bits, nbc = 7 * W - 2, bit_stride = 2 * C.e.cells + 8 * (size_t)C.e.L;
+                const size_t limb_stride = nbc + W * bit_stride;
+                hipLaunchKernelGGL(k_circuit_bits, dim3(limbs_n), dim3(256), 0, ctx->stream, C.e, limbs_n, C.words_n,
+                                   (const u64*)d_in + 2 * (size_t)C.words_n, so[0], limb_stride, (Fr*)d_advice);
+                hipLaunchKernelGGL(k_circuit_select, dim3((unsigned)(limbs_n * W)), dim3(256), 0, ctx->stream, C.e, limbs_n, C.words_n,
+                                   (const u64*)d_in + 2 * (size_t)C.words_n, d_steps, so[0], limb_stride, bit_stride, nbc, (Fr*)d_advice);
+                for (unsigned li = 0; li < limbs_n; ++li) {
+                    ExpP Q = P;
+                    Q.cell0 = so[0] + li * limb_stride + nbc;
+                    Q.lk0 = so[3] + (size_t)li * 2 * W * C.e.lookups;
+                    Q.pair_stride = bit_stride;
+                    Q.odd_off = C.e.cells + 8 * (size_t)C.e.L;
+                    hipLaunchKernelGGL(k_witness_expand, dim3((unsigned)(2 * W)), dim3(EXP_THREADS), 0, ctx->stream, Q,
+                                       d_steps + (size_t)li * 2 * W * rec, d_modulus, (Fr*)d_advice, (Fr*)d_lookup);
+                }
+                first += runs[k];
+                continue;
+            }
             hipLaunchKernelGGL(k_witness_expand, dim3((unsigned)runs[k]), dim3(EXP_THREADS), 0, ctx->stream, P, d_steps + first * rec,
                                d_modulus, (Fr*)d_advice, (Fr*)d_lookup);
         }

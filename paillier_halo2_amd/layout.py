@@ -151,6 +151,13 @@ def circuit_cells(kind: str, limbs_n: int, limb_bits: int, lookup_bits: int, n_s
     if kind == "encrypt":
         put("pow_g", 2 + n_steps_g * mm.advice, n_steps_g * mm.lookup)
         put("pow_r", 2 + n_steps_r * mm.advice, n_steps_r * mm.lookup)
+    elif kind == "encrypt_uniform":
+        # g^m as pow_mod over Ln * limb_bits in-circuit bits: per limb of m num_to_bits (7 W - 2 cells), per
+        # bit two mul_mods and a limb-wise select (8 cells per limb); the step count is fixed by the key size
+        m_bits = Ln * limb_bits
+        assert n_steps_g in (0, 2 * m_bits)
+        put("pow_g", 2 + Ln * (7 * limb_bits - 2) + m_bits * (2 * mm.advice + 8 * L), 2 * m_bits * mm.lookup)
+        put("pow_r", 2 + n_steps_r * mm.advice, n_steps_r * mm.lookup)
     put("final", mm.advice, mm.lookup)
     put("assign_res", *assign_cells(L, limb_bits, lookup_bits))
     put("assert_equal", assert_equal_cells(L))

@@ -975,3 +975,52 @@ def test_uniform_shape_encrypt_batch(eng, cref):
     c, _, ng, nr = eng.paillier_encrypt_uniform(Ln, bits, arr([n] * 3), arr([g] * 3), arr(msgs), arr(rs), want_steps=False)
     assert [cref.limbs_to_int(c[i]) for i in range(3)] == [P.paillier_enc_native(n, g, m, r) for m, r in zip(msgs, rs)]
     assert set(int(x) for x in ng) == {2 * bits}
+
+
+@pytest.mark.parametrize("bits,W,lb", [(128, 64, 15), (96, 32, 9)])
+def test_uniform_shape_circuit_cell_stream(eng, cref, bits, W, lb):
+    """the whole cell stream of the uniform-shape encrypt circuit on the device (kind = 2: num_to_bits of
+    the message's limbs, per exponent bit mul_mod / limb-wise select / square_mod) vs the oracle, gate check included; two
+    different messages give streams of the same length and the same gate positions."""
+    import torch
+
+    from paillier_halo2_amd import layout
+
+    rng = random.Random(bits + W)
+    Ln = bits // W
+    wn, wr = -(-Ln * W // 64), -(-2 * Ln * W // 64)
+    n = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+    g = rng.getrandbits(bits)
+    nr = n.bit_length() + bin(n).count("1")
+    lens = set()
+    for m in (rng.getrandbits(bits), 5):
+        r = rng.randrange(1, n)
+        res, sg, sr, fin = P.encrypt_uniform_trace(n, g, m, r, bits)
+        if W == 64:
+            arr = lambda v: cref.int_to_limbs(v, wn).reshape(1, -1)
+            c, steps, ngd, nrd = eng.paillier_encrypt_uniform(Ln, bits, arr(n), arr(g), arr(m), arr(r))
+            assert cref.limbs_to_int(c[0]) == res
+            steps = steps[0, : 2 * bits + nr + 1]
+        else:
+            steps = np.stack([np.stack([cref.int_to_limbs(v, wr) for v in st]) for st in sg + sr + [fin]])
+        adv_n, lk_n = eng.circuit_cells(2, Ln, W, lb, 2 * bits, nr)
+        cc = layout.circuit_cells("encrypt_uniform", Ln, W, lb, 2 * bits, nr)
+        assert (adv_n, lk_n) == (cc.advice, cc.lookup)
+        lens.add((adv_n, lk_n))
+        d_steps = torch.from_numpy(np.ascontiguousarray(steps).astype(np.int64)).cuda()
+        d_mod = torch.from_numpy(cref.int_to_limbs(n * n, wr).astype(np.int64)).cuda()
+        d_adv = torch.zeros((adv_n, 4), dtype=torch.int64, device="cuda")
+        d_lk = torch.zeros((lk_n, 4), dtype=torch.int64, device="cuda")
+        eng.circuit_expand_dev(2, Ln, W, lb, _circuit_inputs(cref, n, g, m, r, res, Ln, W), d_steps.data_ptr(), 2 * bits, nr,
+                               d_mod.data_ptr(), d_adv.data_ptr(), d_lk.data_ptr())
+        eng.sync()
+        got_adv = cref.fr_mont_to_ints(d_adv.cpu().numpy().astype(np.uint64))
+        got_lk = cref.fr_mont_to_ints(d_lk.cpu().numpy().astype(np.uint64))
+        want_adv, want_lk, seg = P.expand_uniform_circuit_cells(n, g, m, r, res, bits, W, lb)
+        if got_adv != want_adv:
+            bad = [k for k in range(len(want_adv)) if got_adv[k] != want_adv[k]]
+            raise AssertionError("%d advice cells differ, first at %d; segments %s" % (len(bad), bad[0], cc.seg))
+        assert got_lk == want_lk and seg["satisfied"]
+        gates, end = P.gate_offsets_uniform_circuit(bits, W, lb, nr)
+        assert end == adv_n and P.check_gates(got_adv, gates) == []
+    assert len(lens) == 1
