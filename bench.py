@@ -38,6 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+MULT_PER_MADD = 8 * 180.0 + 2 * 135.0   # v_mad_u64_u32 + v_mul_lo_u32 per XYZZ mixed addition on the 29-bit field
 
 
 def synth_inputs(enc_bits: int, seed: int):
@@ -582,6 +583,8 @@ def main():
 
     eng = pz.Engine(local)
     eng.bind_torch_stream()  # a real stream, current for torch too: the event waits of the pipeline order against it
+    # multiplier issue peak of this device, measured live (8 independent mads per lane and iteration)
+    mad_peak = max(8192 * 256 * 1024 * 8 / (eng.ubench_mad_indep(8192, 1024) * 1e-3) / 1e12 for _ in range(3))
 
     def barrier():
         torch.cuda.synchronize()
@@ -704,7 +707,7 @@ def main():
     # so the per-launch figure of the committed rocprofv3 --pmc passes of this same command is reported
     traffic, traffic_src = None, None
     try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
         if args.scale == 1.0 and (args.enc_bits, args.k) == (2048, 17):
             traffic = pj["k_msm_accumulate"]["fetch_bytes_per_launch_raw"] + pj["k_msm_accumulate"]["write_bytes_per_launch"]
             traffic_src = pj["source"]
@@ -714,7 +717,7 @@ def main():
         "metric": "Paillier-encrypt proofs/s (2048-bit n, k=17); MSM achieved HBM GB/s vs peak",
         "value": value, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if colpar else "weak", "vs_baseline": None,
-        "dtype": "u32 limbs (254-bit modular integers), u64 limbs (4096-bit integers)", "data": "synthetic",
+        "dtype": "u32 limbs (29-bit reduced radix, 254-bit modular integers), u64 limbs (4096-bit integers)", "data": "synthetic",
         "config": {
             "workload": "%s: %d-bit n, KZG prover hot path at k=%d (K3 trace + K4 cell expansion + K1 commitments + K2 NTTs), 1 proof per GPU per step"
                         % ("c3 homomorphic add" if args.workload == "c3" else "c2 encrypt" if (args.enc_bits, args.k) == (2048, 17) else "c5-shape encrypt" if (args.enc_bits, args.k) == (3072, 19) else "custom encrypt", args.enc_bits, args.k),
@@ -741,15 +744,16 @@ def main():
                                "in the timed region the kernel shares the CUs with the NTT stream"} if iso_n else None),
             "note": "integer-multiply-issue bound by construction (v_mad_u64_u32); HBM fraction is the metric's definition, see DESIGN.md section 5",
         },
-        # the roofline that actually binds this kernel: v_mad_u64_u32 issue.  One mixed addition = 10 Montgomery
-        # products x 128 mads (the addc / moves beside them are the difference to 100 %); peak = 24.1 T mad/s measured
-        # by pz_ubench_mad on this chip
+        # the roofline that actually binds this kernel: multiplier-instruction issue (v_mad_u64_u32 / v_mul_lo_u32).  One mixed
+        # addition = 8 products x 180 + 2 squares x 135 multiplier instructions of the 29-bit field (fp29.cuh); peak = the
+        # independent-multiplicand mad issue rate measured live by pz_ubench_mad_indep
         "roofline_int": {
             "bound": "v_mad_u64_u32 issue", "kernel": "k_msm_accumulate",
-            "achieved": (wl.digit_adds * args.steps * 1280.0 / (acc_ms * 1e-3) / 1e12) if (acc_ms > 0 and wl.digit_adds) else None,
-            "achieved_alone": (wl.digit_adds * 1280.0 / (iso_ms * 1e-3) / 1e12) if (iso_n and wl.digit_adds) else None,
-            "peak": 24.1, "unit": "T mad/s", "digit_adds_per_proof": wl.digit_adds,
-            "note": "digit_adds = non-zero 16-bit digits accumulated per proof, estimated on the device from the canonical cell values (signed-recoding carries and negated cells approximated)",
+            "achieved": (wl.digit_adds * args.steps * MULT_PER_MADD / (acc_ms * 1e-3) / 1e12) if (acc_ms > 0 and wl.digit_adds) else None,
+            "achieved_alone": (wl.digit_adds * MULT_PER_MADD / (iso_ms * 1e-3) / 1e12) if (iso_n and wl.digit_adds) else None,
+            "peak": mad_peak, "unit": "T multiplier instructions/s", "digit_adds_per_proof": wl.digit_adds,
+            "multiplier_instructions_per_mixed_addition": MULT_PER_MADD,
+            "note": "digit_adds = non-zero 16-bit digits accumulated per proof, estimated on the device from the canonical cell values (signed-recoding carries and negated cells approximated); peak measured in this run",
         },
         # per-class HIP-event sums; with the witness / NTT streams on, the classes overlap in time (sum > ms_per_step)
         "breakdown_ms_per_proof": {"trace": trace_ms / args.steps, "expand": exp_ms / args.steps, "msm_all": msm_ms / args.steps,

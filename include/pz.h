@@ -387,6 +387,9 @@ int pz_timing_get(pz_ctx* ctx, int which, double* total_ms, uint64_t* launches);
 /* integer-multiply issue-rate microbenchmark: runs `iters` dependent-free v_mad_u64_u32 per lane
  * on `blocks` x 256 threads, returns elapsed ms (device time) */
 int pz_ubench_mad(pz_ctx* ctx, uint32_t blocks, uint32_t iters, double* ms);
+/* the same with multiplicands that do not depend on the accumulators (8 mads per iteration): the issue rate of the mads of a
+ * reduced-radix field product, the peak `roofline_int` is priced against */
+int pz_ubench_mad_indep(pz_ctx* ctx, uint32_t blocks, uint32_t iters, double* ms);
 /* Fq Montgomery multiplications per second microbenchmark (chains of `iters` per lane) */
 int pz_ubench_fqmul(pz_ctx* ctx, uint32_t blocks, uint32_t iters, double* ms);
 /* the same chain with an alternative field product: variant 0 = the production fp_mul,

@@ -95,6 +95,7 @@ SIGNATURES = {
     "pz_timing_reset": (C.c_int, [VP]),
     "pz_timing_get": (C.c_int, [VP, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "pz_ubench_mad": (C.c_int, [VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
+    "pz_ubench_mad_indep": (C.c_int, [VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
     "pz_ubench_fqmul": (C.c_int, [VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
     "pz_ubench_fqmul_variant": (C.c_int, [VP, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
     "pz_fq_mul29": (C.c_int, [VP, VP, VP, VP]),

@@ -48,6 +48,22 @@ __global__ void k_ubench_mad(u64* out, unsigned iters) {
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7;
 }
 
+// the same with multiplicands that do NOT depend on the accumulators (what a column of a field product looks like: only the
+// 64-bit addend chains): the issue rate the 29-bit kernels actually see
+__global__ void k_ubench_mad_indep(u64* out, unsigned iters) {
+    u32 a = threadIdx.x * 2654435761u + 12345u, b = blockIdx.x * 40503u + 7u, c = a ^ 0x9e3779b9u, d = b + 0x7f4a7c15u;
+    u64 x0 = a, x1 = b, x2 = a ^ b, x3 = a + b, x4 = a * 3, x5 = b * 5, x6 = a - b, x7 = ~a;
+    for (unsigned i = 0; i < iters; ++i) {
+        asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_mad_u64_u32 %1, vcc, %9, %10, %1\n\tv_mad_u64_u32 %2, vcc, %10, %11, %2\n\t"
+                     "v_mad_u64_u32 %3, vcc, %8, %11, %3\n\tv_mad_u64_u32 %4, vcc, %8, %10, %4\n\tv_mad_u64_u32 %5, vcc, %9, %11, %5\n\t"
+                     "v_mad_u64_u32 %6, vcc, %8, %8, %6\n\tv_mad_u64_u32 %7, vcc, %9, %9, %7"
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+                     : "v"(a), "v"(b), "v"(c), "v"(d)
+                     : "vcc");
+    }
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7;
+}
+
 __global__ void k_ubench_fqmul(Fq* out, unsigned iters) {
     Fq x = fp_one<FqTag>(), y = fp_one<FqTag>();
     x.v[0] ^= threadIdx.x;
@@ -345,6 +361,13 @@ extern "C" int pz_ubench_mad(pz_ctx* ctx, uint32_t blocks, uint32_t iters, doubl
     void* d;
     PZCHK(pz_ws_get(ctx, WS_MISC, (size_t)blocks * 256 * 32, &d));
     return timed_launch(ctx, ms, k_ubench_mad, dim3(blocks), dim3(256), (u64*)d, (unsigned)iters);
+}
+extern "C" int pz_ubench_mad_indep(pz_ctx* ctx, uint32_t blocks, uint32_t iters, double* ms) {
+    if (!ctx || !ms || !blocks) return PZ_ERR_INVALID;
+    PZ_ENTER(ctx);
+    void* d;
+    PZCHK(pz_ws_get(ctx, WS_MISC, (size_t)blocks * 256 * 32, &d));
+    return timed_launch(ctx, ms, k_ubench_mad_indep, dim3(blocks), dim3(256), (u64*)d, (unsigned)iters);
 }
 extern "C" int pz_ubench_fqmul_variant(pz_ctx* ctx, int variant, uint32_t blocks, uint32_t iters, double* ms) {
     if (!ctx || !ms || !blocks || variant < 0 || variant > 4) return PZ_ERR_INVALID;

@@ -494,6 +494,11 @@ class Engine:
         self._chk(self.L.pz_ubench_mad(self.ctx, blocks, iters, C.byref(ms)), "pz_ubench_mad")
         return ms.value
 
+    def ubench_mad_indep(self, blocks: int, iters: int) -> float:
+        ms = C.c_double()
+        self._chk(self.L.pz_ubench_mad_indep(self.ctx, blocks, iters, C.byref(ms)), "pz_ubench_mad_indep")
+        return ms.value
+
     def ubench_fqmul(self, blocks: int, iters: int) -> float:
         ms = C.c_double()
         self._chk(self.L.pz_ubench_fqmul(self.ctx, blocks, iters, C.byref(ms)), "pz_ubench_fqmul")

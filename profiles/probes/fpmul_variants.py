@@ -10,3 +10,9 @@ for blocks, iters in ((256 * 16, 256), (256 * 4, 1024)):
         ms = min(eng.ubench_fqmul_variant(v, blocks, iters) for _ in range(3))
         out[nm] = round(blocks * 256 * iters * 2 / (ms * 1e-3) / 1e9, 1)
     print("blocks=%d iters=%d:" % (blocks, iters), out)
+
+for blocks, iters in ((2048, 4096), (8192, 1024)):
+    ms = min(eng.ubench_mad(blocks, iters) for _ in range(3))
+    ms2 = min(eng.ubench_mad_indep(blocks, iters) for _ in range(3))
+    print("v_mad_u64_u32 issue rate, blocks=%d iters=%d: dependent multiplicand %.1f T/s, independent %.1f T/s" % (
+        blocks, iters, blocks * 256 * iters * 8 / ms / 1e9, blocks * 256 * iters * 8 / ms2 / 1e9))
