@@ -517,6 +517,52 @@ __global__ __launch_bounds__(128) void k_msm_reduce_l1(MsmP p, unsigned m, const
     x29_store_raw(&o->S, run);
 }
 
+// A/B variant of level 1 (BASELINE north_star: "LDS-staged Pippenger buckets and wavefront-level bucket reduction"): a
+// WAVE owns a tile of 64 consecutive buckets staged in LDS and reduces it with cross-lane scans -- suffix sums
+// R_k = sum_{j >= k} B_j by 6 Hillis-Steele steps, then V = sum_k R_k by a 6-step tree -- instead of one lane walking 16
+// buckets.  Depth 12 point additions instead of 32, but 64 x 12 lane-additions per 64 buckets instead of 128: the
+// throughput comparison is in DESIGN.md section 6.1 (selected by PZ_MSM_REDUCE=wave, never the default).
+__global__ __launch_bounds__(256) void k_msm_reduce_wave(MsmP p, const u32* __restrict__ items,
+                                                         const G1X29Raw* __restrict__ partials, MsmNode* __restrict__ nodes) {
+    __shared__ G1X29Raw s_pt[256];
+    const size_t col = blockIdx.y;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned tile = blockIdx.x * 4 + wave, nn = p.B / 64;
+    G1X29Raw* sp = s_pt + wave * 64;
+    const u32* it = items + col * (p.B + 1);
+    G1X29 v = x29_inf();
+    if (tile < nn) {
+        const unsigned b = tile * 64 + lane;
+        if (it[b + 1] > it[b]) v = x29_load_raw(partials + col * p.max_items + it[b]);
+    }
+    // suffix scan: R_k = sum_{j >= k} B_j
+    for (unsigned off = 1; off < 64; off <<= 1) {
+        x29_store_raw(&sp[lane], v);
+        __syncthreads();
+        if (lane + off < 64) {
+            G1X29 o = x29_load_raw(&sp[lane + off]);
+            x29_add(v, o);
+        }
+        __syncthreads();
+    }
+    const G1X29 S = v;   // lane 0 holds the tile's plain sum
+    // V = sum_k R_k  (= sum_k (k + 1) B_k)
+    for (unsigned off = 32; off > 0; off >>= 1) {
+        x29_store_raw(&sp[lane], v);
+        __syncthreads();
+        if (lane < off) {
+            G1X29 o = x29_load_raw(&sp[lane + off]);
+            x29_add(v, o);
+        }
+        __syncthreads();
+    }
+    if (tile < nn && lane == 0) {
+        MsmNode* o = nodes + col * nn + tile;
+        x29_store_raw(&o->V, v);
+        x29_store_raw(&o->S, S);
+    }
+}
+
 // upper levels: m children of span w buckets each -> V = sum V_k + w * sum k*S_k, S = sum S_k
 __global__ __launch_bounds__(128) void k_msm_combine(unsigned n_in, unsigned m, unsigned log_w,
                                                      const MsmNode* __restrict__ in, MsmNode* __restrict__ out) {
@@ -855,12 +901,24 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
         HIPCHK(ctx, hipGetLastError());
         return PZ_OK;
     }
-    hipLaunchKernelGGL(k_msm_reduce_l1, dim3(pz_div_up(n_nodes, 128), (unsigned)nc), dim3(128), 0, st, p, m1,
-                       (const u32*)items, (const G1X29Raw*)partials, (MsmNode*)na);
+    static int reduce_wave = -1;
+    if (reduce_wave < 0) {
+        const char* e = getenv("PZ_MSM_REDUCE");
+        reduce_wave = (e && !strcmp(e, "wave")) ? 1 : 0;
+    }
+    unsigned m1_used = m1;
+    if (reduce_wave && p.B >= 64) {   // A/B variant: wave-level scan over LDS-staged tiles of 64 buckets
+        m1_used = 64;
+        n_nodes = p.B / 64;
+        hipLaunchKernelGGL(k_msm_reduce_wave, dim3(pz_div_up(n_nodes, 4), (unsigned)nc), dim3(256), 0, st, p, (const u32*)items,
+                           (const G1X29Raw*)partials, (MsmNode*)na);
+    } else
+        hipLaunchKernelGGL(k_msm_reduce_l1, dim3(pz_div_up(n_nodes, 128), (unsigned)nc), dim3(128), 0, st, p, m1,
+                           (const u32*)items, (const G1X29Raw*)partials, (MsmNode*)na);
     MsmNode* cur = (MsmNode*)na;
     MsmNode* nxt = (MsmNode*)nb;
     unsigned log_w = 0;
-    for (unsigned t = m1; t > 1; t >>= 1) ++log_w;
+    for (unsigned t = m1_used; t > 1; t >>= 1) ++log_w;
     while (n_nodes > 1) {
         unsigned m = n_nodes >= 16 ? 16 : n_nodes;
         hipLaunchKernelGGL(k_msm_combine, dim3(pz_div_up(n_nodes / m, 128), (unsigned)nc), dim3(128), 0, st, n_nodes, m,
