@@ -30,6 +30,13 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert L.pz_strerror(0) == b"ok" and L.pz_strerror(-6).startswith(b"quotient")
 
 
+def test_integration_doc_binds_every_entry_point():
+    """INTEGRATION.md's `extern "C"` block (the reference-side binding) names every function include/pz.h declares"""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in declared_functions() if ("pub fn %s(" % n) not in text]
+    assert not missing, missing
+
+
 def test_product_never_imports_oracle():
     """the product path must not import, link, dlopen or execute anything under oracle/"""
     pkg = os.path.join(ROOT, "paillier_halo2_amd")
