@@ -366,7 +366,8 @@ int pz_poly_div_linear_dev(pz_ctx* ctx, const uint64_t* d_coeffs, size_t n_cols,
  *   begin : d_h = sum_k v^k (sum_j y^j P_kj - R_k) / Z_{S_k}   (n coefficients; commit it, hash it, draw u)
  *   finish: d_h2 = (sum_k v^k z_k (sum_j y^j P_kj - R_k(u)) - Z_T(u) h) / (X - u) / z_0,  z_k = Z_{T \ S_k}(u);
  *           frees the state.  d_h2 may not alias d_h.
- * At most 16 sets, 8 points per set, 32 points overall. */
+ * At most 16 sets, 8 points per set, 32 points overall; one opening in flight per context (the state lives in the context's
+ * workspace). */
 typedef struct pz_shplonk pz_shplonk;
 int pz_shplonk_begin_dev(pz_ctx* ctx, size_t n, uint32_t n_sets, const uint32_t* set_n_polys, const uint64_t* const* d_polys,
                          const uint32_t* set_n_points, const uint32_t* point_idx, uint32_t n_points_total, const uint64_t* points,

@@ -141,19 +141,10 @@ __device__ __forceinline__ void x29_add(G1X29& acc, const G1X29& q) {
     acc.zzz = f29_mul(f29_mul(acc.zzz, q.zzz), PPP);
 }
 
-// -y of an affine point (tight, value <= p)
-__device__ __forceinline__ Fq29 a29_neg_y(const Fq29& y) {
-    // p - y, exact limbs: y is canonical and non-zero here (the identity is handled before); borrow chain on 29-bit limbs
-    Fq29 r;
-    u32 br = 0;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const u32 t = P29<FqTag>::P(i) - y.v[i] - br;
-        br = t >> 31;
-        r.v[i] = i < 8 ? (t & F29_MASK) : t;
-    }
-    return r;
-}
+// -y of an affine point: 2p - y limb-wise from 2p spelled with low limbs >= 2^29 (9 subtractions, no borrow chain; 2p, not p:
+// y's top limb may equal p's, and a limb must not go negative); the result's limbs are loose (< 2^30) -- a legal operand of
+// the mixed addition's S2 = y * ZZZ (ZZZ is tight)
+__device__ __forceinline__ Fq29 a29_neg_y(const Fq29& y) { return f29_neg<2, 29>(y); }
 
 // ---- memory images
 // table row / ABI affine point: two 256-bit integers

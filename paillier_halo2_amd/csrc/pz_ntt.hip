@@ -12,6 +12,8 @@
 //                         k1 + n1*k2 + n1*n2*k so the result lands in natural order; a block
 //                         owns T consecutive k1 for one k2, so stores are T*32-byte runs.
 // Algorithmic HBM bytes: 64 B per element (one 32 B read + one 32 B write), see DESIGN.md.
+#include <stdlib.h>
+
 #include <utility>
 #include <vector>
 
@@ -269,10 +271,19 @@ __global__ __launch_bounds__(256) void k_ntt_final_ext29(const Fr* in, Fr* out, 
 #endif
 #define NTT29_ELEM 36u   // bytes of one tile element of the 29-bit kernels (9 words)
 static size_t ntt29_lds_bytes(size_t elems) { return (elems + (elems >> 5) + 1) * NTT29_ELEM; }
+static size_t ntt_tile_budget() {   // tile size in 32-byte units x 32 (PZ_NTT_TILE_KIB overrides for tuning: 16, 32, 64)
+    static size_t v = 0;
+    if (!v) {
+        const char* e = getenv("PZ_NTT_TILE_KIB");
+        v = e ? (size_t)atol(e) * 1024 : PZ_NTT_LDS;
+        if (v < 4096) v = PZ_NTT_LDS;
+    }
+    return v;
+}
 static unsigned pick_tile(size_t extent, unsigned logR) {
     // 1024 elements per block (36 KiB of the 9-word elements: 4 blocks per CU); prefer 128-byte runs (T = 4) or more
-    unsigned T = 8;
-    while (T > 1 && (((size_t)32 << logR) * T > PZ_NTT_LDS || T > extent)) T >>= 1;
+    unsigned T = 16;
+    while (T > 1 && (((size_t)32 << logR) * T > ntt_tile_budget() || T > extent)) T >>= 1;
     return T;
 }
 
@@ -494,7 +505,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
             NttPass pc{};
             pc.logR = lg[2]; pc.lo = 1; pc.hi = n1 * n2; pc.n = n; pc.n1 = n1; pc.n2 = n2;
             unsigned T = 8;
-            while (T > 1 && (((size_t)32 << lg[2]) * T * E > 32768 || T > n1)) T >>= 1;
+            while (T > 1 && (((size_t)32 << lg[2]) * T * E > ntt_tile_budget() || T > n1)) T >>= 1;
             pc.T = T;
             const size_t lds = ntt29_lds_bytes(((size_t)1 << lg[2]) * T * E);
             pc.swap = (nc > 1 && n2 * (n1 / T) <= 65535) ? 1u : 0u;
@@ -512,7 +523,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
             // 32 KiB of LDS per block (4 blocks per CU): with 2^e = 4 interleaved outputs a single row already
             // stores full 128-byte lines
             unsigned T = 8;
-            while (T > 1 && (((size_t)32 << lg1) * T * E > 32768 || T > n1)) T >>= 1;
+            while (T > 1 && (((size_t)32 << lg1) * T * E > ntt_tile_budget() || T > n1)) T >>= 1;
             pc.T = T;
             const size_t lds = ntt29_lds_bytes(((size_t)1 << lg1) * T * E);
             pc.swap = nc > 1 ? 1u : 0u;

@@ -26,41 +26,57 @@ struct pz_shplonk {
     size_t n = 0;
     unsigned n_sets = 0, n_t = 0;
     std::vector<unsigned> set_np, set_npt, pt_idx;   // polys per set, points per set, flattened point indices
-    void* d_C = nullptr;        // n_sets x n: the folded polynomials C_k
-    void* d_small = nullptr;    // device scalars: T points | y | v | R_k coefficients | evals ...
+    void* d_C = nullptr;        // n_sets x n: the folded polynomials C_k          (context workspace slots WS_SH_C /
+    void* d_small = nullptr;    // device scalars: T points | y | R_k | evals ...   WS_SH_SMALL: one opening at a time per context)
     size_t off_T = 0, off_R = 0, off_out = 0;
     uint64_t v[4];
 };
 
-// C[i] = sum_j ypow[j] * P_j[i] over the polynomials of one set (addresses in plist)
+// C[i] = sum_j ypow[j] * P_j[i] over the polynomials of one set (addresses in plist).  A set holds thousands of polynomials
+// (every advice column of the proof): grid.y cuts them into chunks of SH_FOLD_CHUNK so the dependent load -> product -> add
+// chain of a lane is 32 long, not 6000 (the loop is latency-bound on the loads); k_sh_fold_sum adds the chunks' partials.
+#define SH_FOLD_CHUNK 32u
 __global__ __launch_bounds__(256) void k_sh_fold(const u64* __restrict__ plist, unsigned np, const Fr* __restrict__ ypow, size_t n,
-                                                 Fr* __restrict__ C) {
+                                                 Fr* __restrict__ part) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fr acc = fp_load<FrTag>(reinterpret_cast<const Fr*>(plist[0]) + i);
-    for (unsigned j = 1; j < np; ++j)
+    const unsigned j0 = blockIdx.y * SH_FOLD_CHUNK, j1 = j0 + SH_FOLD_CHUNK < np ? j0 + SH_FOLD_CHUNK : np;
+    Fr acc = fp_load<FrTag>(reinterpret_cast<const Fr*>(plist[j0]) + i);
+    if (j0) acc = fp_mul(acc, fp_load<FrTag>(ypow + j0));
+    for (unsigned j = j0 + 1; j < j1; ++j)
         acc = fp_add(acc, fp_mul(fp_load<FrTag>(reinterpret_cast<const Fr*>(plist[j]) + i), fp_load<FrTag>(ypow + j)));
+    fp_store(part + (size_t)blockIdx.y * n + i, acc);
+}
+__global__ __launch_bounds__(256) void k_sh_fold_sum(const Fr* __restrict__ part, unsigned n_chunks, size_t n, Fr* __restrict__ C) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr acc = fp_load<FrTag>(part + i);
+    for (unsigned c = 1; c < n_chunks; ++c) acc = fp_add(acc, fp_load<FrTag>(part + (size_t)c * n + i));
     fp_store(C + i, acc);
 }
-// y^j table
-__global__ void k_sh_ypow(Fr y, unsigned m, Fr* __restrict__ out) {
-    if (blockIdx.x || threadIdx.x) return;
-    Fr acc = fp_one<FrTag>();
-    for (unsigned j = 0; j < m; ++j) {
-        fp_store(out + j, acc);
-        acc = fp_mul(acc, y);
+// e_t = sum_j y^j evals[j][t]: one workgroup per point of the set (a set holds thousands of polynomials)
+__global__ __launch_bounds__(256) void k_sh_fold_evals(const Fr* __restrict__ evals, unsigned np, unsigned npt, const Fr* __restrict__ ypow,
+                                                       Fr* __restrict__ e_out) {
+    __shared__ Fr s_acc[256];
+    const unsigned t = blockIdx.x;
+    Fr acc = fp_zero<FrTag>();
+    for (unsigned j = threadIdx.x; j < np; j += 256) acc = fp_add(acc, fp_mul(fp_load<FrTag>(evals + (size_t)j * npt + t), fp_load<FrTag>(ypow + j)));
+    s_acc[threadIdx.x] = acc;
+    __syncthreads();
+    for (unsigned off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) s_acc[threadIdx.x] = fp_add(s_acc[threadIdx.x], s_acc[threadIdx.x + off]);
+        __syncthreads();
     }
+    if (threadIdx.x == 0) fp_store(e_out + t, s_acc[0]);
 }
-// one lane: R_k = interpolation of e_t = sum_j y^j evals[j][t] over the set's points (coefficients, ascending)
-__global__ void k_sh_interpolate(const Fr* __restrict__ T, const u32* __restrict__ idx, unsigned npt, const Fr* __restrict__ evals,
-                                 unsigned np, const Fr* __restrict__ ypow, Fr* __restrict__ R) {
+// one lane: R_k = interpolation of the folded evaluations e_t over the set's points (coefficients, ascending)
+__global__ void k_sh_interpolate(const Fr* __restrict__ T, const u32* __restrict__ idx, unsigned npt, const Fr* __restrict__ e_in,
+                                 Fr* __restrict__ R) {
     if (blockIdx.x || threadIdx.x) return;
     Fr x[SH_MAX_PTS], e[SH_MAX_PTS], r[SH_MAX_PTS];
     for (unsigned t = 0; t < npt; ++t) {
         x[t] = fp_load<FrTag>(T + idx[t]);
-        Fr acc = fp_zero<FrTag>();
-        for (unsigned j = 0; j < np; ++j) acc = fp_add(acc, fp_mul(fp_load<FrTag>(evals + (size_t)j * npt + t), fp_load<FrTag>(ypow + j)));
-        e[t] = acc;
+        e[t] = fp_load<FrTag>(e_in + t);
         r[t] = fp_zero<FrTag>();
     }
     for (unsigned t = 0; t < npt; ++t) {
@@ -151,15 +167,9 @@ static Fr fr_host(const uint64_t x[4]) {
 }
 
 extern "C" int pz_shplonk_free(pz_ctx* ctx, pz_shplonk* st) {
+    (void)ctx;
     if (!st) return PZ_OK;
-    if (ctx) {
-        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-        (void)hipSetDevice(ctx->device);
-        (void)hipStreamSynchronize(ctx->stream);
-    }
-    if (st->d_C) (void)hipFree(st->d_C);
-    if (st->d_small) (void)hipFree(st->d_small);
-    delete st;
+    delete st;   // the buffers are the context's grow-only workspace slots: nothing to free, no device synchronisation
     return PZ_OK;
 }
 
@@ -195,13 +205,15 @@ extern "C" int pz_shplonk_begin_dev(pz_ctx* ctx, size_t n, uint32_t n_sets, cons
     // small device block: [T points][ypow max_np][R: n_sets x SH_MAX_PTS][finish scalars: n_sets + 3][evals][poly pointers]
     // [point idx][set offsets]
     const size_t o_T = 0, o_y = o_T + n_points_total, o_R = o_y + max_np, o_out = o_R + (size_t)n_sets * SH_MAX_PTS,
-                 o_ev = o_out + n_sets + 3, fr_end = o_ev + tot_evals;
+                 o_e = o_out + n_sets + 3, o_ev = o_e + SH_MAX_PTS, fr_end = o_ev + tot_evals;
     const size_t b_ptr = fr_end * 32, b_idx = b_ptr + tot_polys * 8, b_off = b_idx + tot_pts * 4, b_end = b_off + (n_sets + 1) * 4;
-    hipError_t e = hipMalloc(&st->d_small, b_end + 64);
-    if (e == hipSuccess) e = hipMalloc(&st->d_C, (size_t)n_sets * n * 32);
-    if (e != hipSuccess) {
-        pz_shplonk_free(nullptr, st);
-        return pz_hip_fail(ctx, e, "hipMalloc(shplonk state)");
+    {
+        int rc = pz_ws_get(ctx, WS_SH_SMALL, b_end + 64, &st->d_small);
+        if (rc == PZ_OK) rc = pz_ws_get(ctx, WS_SH_C, (size_t)n_sets * n * 32, &st->d_C);
+        if (rc != PZ_OK) {
+            delete st;
+            return rc;
+        }
     }
     st->off_T = o_T; st->off_R = o_R; st->off_out = o_out;
     char* sm = (char*)st->d_small;
@@ -215,7 +227,11 @@ extern "C" int pz_shplonk_begin_dev(pz_ctx* ctx, size_t n, uint32_t n_sets, cons
     HIPCHK(ctx, hipMemcpyAsync(sm + b_idx, point_idx, tot_pts * 4, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(sm + b_off, offs.data(), (n_sets + 1) * 4, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipStreamSynchronize(s));   // the host arrays may go away after the call
-    hipLaunchKernelGGL(k_sh_ypow, dim3(1), dim3(64), 0, s, fr_host(y), (unsigned)max_np, fsm + o_y);
+    {   // y^j, j < max_np: the cached power-table kernel (parallel) rather than one lane walking thousands of products
+        void* yp;
+        PZCHK(pz_get_pow_table(ctx, y, max_np, &yp));
+        HIPCHK(ctx, hipMemcpyAsync(fsm + o_y, yp, max_np * 32, hipMemcpyDeviceToDevice, s));
+    }
     void* wsN;
     PZCHK(pz_ws_get(ctx, WS_NTT_TMP, n * 32, &wsN));   // (pz_poly_div_linear_dev owns WS_BIG_A)
     Fr* N = (Fr*)wsN;
@@ -229,9 +245,18 @@ extern "C" int pz_shplonk_begin_dev(pz_ctx* ctx, size_t n, uint32_t n_sets, cons
     }
     for (unsigned kk = n_sets; kk-- > 0;) {
         Fr* Ck = (Fr*)st->d_C + (size_t)kk * n;
-        hipLaunchKernelGGL(k_sh_fold, dim3(gb), dim3(256), 0, s, (const u64*)(sm + b_ptr) + p_off[kk], set_n_polys[kk], fsm + o_y, n, Ck);
+        {
+            const unsigned nch = pz_div_up(set_n_polys[kk], SH_FOLD_CHUNK);
+            void* part;
+            PZCHK(pz_ws_get(ctx, WS_BIG_C, (size_t)nch * n * 32, &part));
+            hipLaunchKernelGGL(k_sh_fold, dim3(gb, nch), dim3(256), 0, s, (const u64*)(sm + b_ptr) + p_off[kk], set_n_polys[kk], fsm + o_y, n,
+                               (Fr*)part);
+            hipLaunchKernelGGL(k_sh_fold_sum, dim3(gb), dim3(256), 0, s, (const Fr*)part, nch, n, Ck);
+        }
+        hipLaunchKernelGGL(k_sh_fold_evals, dim3(set_n_points[kk]), dim3(256), 0, s, fsm + o_ev + e_off[kk], set_n_polys[kk], set_n_points[kk],
+                           fsm + o_y, fsm + o_e);
         hipLaunchKernelGGL(k_sh_interpolate, dim3(1), dim3(64), 0, s, fsm + o_T, (const u32*)(sm + b_idx) + offs[kk], set_n_points[kk],
-                           fsm + o_ev + e_off[kk], set_n_polys[kk], fsm + o_y, fsm + o_R + (size_t)kk * SH_MAX_PTS);
+                           fsm + o_e, fsm + o_R + (size_t)kk * SH_MAX_PTS);
         hipLaunchKernelGGL(k_sh_numerator, dim3(gb), dim3(256), 0, s, Ck, fsm + o_R + (size_t)kk * SH_MAX_PTS, set_n_points[kk], n, N);
         HIPCHK(ctx, hipGetLastError());
         for (unsigned q = 0; q < set_n_points[kk]; ++q)   // exact division by (X - s) for every point of the set
@@ -258,7 +283,7 @@ extern "C" int pz_shplonk_finish_dev(pz_ctx* ctx, pz_shplonk* st, const uint64_t
         tot_evals += (size_t)st->set_np[k] * st->set_npt[k];
         if (st->set_np[k] > max_np) max_np = st->set_np[k];
     }
-    const size_t o_ev = st->off_out + st->n_sets + 3, fr_end = o_ev + tot_evals;
+    const size_t o_ev = st->off_out + st->n_sets + 3 + SH_MAX_PTS, fr_end = o_ev + tot_evals;
     const size_t b_ptr = fr_end * 32, b_idx = b_ptr + tot_polys * 8, b_off = b_idx + tot_pts * 4;
     hipLaunchKernelGGL(k_sh_finish_scalars, dim3(1), dim3(64), 0, s, fsm + st->off_T, st->n_t, (const u32*)(sm + b_idx),
                        (const u32*)(sm + b_off), st->n_sets, fsm + st->off_R, fr_host(u), fr_host(st->v), fsm + st->off_out);
