@@ -85,9 +85,14 @@ class ProofWorkload:
         self.nr = (nn.bit_length() + bin(nn).count("1")) if circuit == "encrypt" else 0
         self.shape = layout.encrypt_proof_shape(enc_bits, k, n_steps, lookup_bits=lookup_bits, kind=circuit, n_steps_g=self.ng)
         self.kind = 0 if circuit == "encrypt" else 1
-        # the driver's inputs as the C ABI takes them (n | g | m | r | res words); res = the ciphertext K3 produces
-        self.res_int = (pow(g, m, nn * nn) * pow(r, nn, nn * nn)) % (nn * nn) if circuit == "encrypt" else (m * r) % (nn * nn)
-        self.circ_inputs = np.concatenate([consts.int_to_limbs(x, self.Ln) for x in (nn, g, m, r)] + [consts.int_to_limbs(self.res_int, self.L)])
+        # the driver's inputs as the C ABI takes them (n | g | m | r | res words).  `res` is the expected ciphertext the
+        # reference's driver receives from paillier_enc_native / paillier_add_native (bench.rs:149,193): here the library's own
+        # native entry points (pz_paillier_encrypt without a trace, pz_mul_mod) -- no host big-integer arithmetic
+        if circuit == "encrypt":
+            res_limbs = eng.paillier_encrypt(self.Ln, *self.inputs, want_steps=False)[0][0]
+        else:
+            res_limbs = eng.mul_mod(self.L, consts.int_to_limbs(m, self.L), consts.int_to_limbs(r, self.L), consts.int_to_limbs(nn * nn, self.L))[1]
+        self.circ_inputs = np.concatenate([consts.int_to_limbs(x, self.Ln) for x in (nn, g, m, r)] + [np.asarray(res_limbs, dtype=np.uint64)])
         sh = self.shape
         sc = lambda x: max(1, int(round(x * scale)))
         self.counts = dict(msm_full=sc(sh.msm_full), polys=sc(sh.polys))

@@ -939,6 +939,59 @@ def expand_circuit_cells(kind: str, n: int, g: int, x: int, y: int, res: int, en
     return [v % FR_R for v in adv], [v % FR_R for v in lk], seg
 
 
+def encrypt_circuit_cells_windows(n: int, g: int, m: int, r: int, res: int, enc_bits: int, limb_bits: int, lb: int, adv_windows,
+                                   lk_windows=()):
+    """The cells [lo, hi) of expand_circuit_cells('encrypt', ...)'s advice / lookup streams WITHOUT building the streams (4e8
+    cells at 2048 bits): every mul_mod has the same cell count, so only the steps a window touches are expanded.
+    -> (total advice cells, total lookup cells, [cells of each advice window], [cells of each lookup window])"""
+    Ln = enc_bits // limb_bits
+    L = 2 * Ln
+    n2 = n * n
+    pre_a, pre_l = [], []
+    for v in (n, g, m, r):
+        a_, l_ = expand_assign_cells(v, Ln, limb_bits, lb)
+        pre_a += a_
+        pre_l += l_
+    nl = decompose_biguint(n, Ln, limb_bits)
+    sq_cells, prod = _mul_cells(nl, nl, 2 * Ln - 1)
+    pre_a += sq_cells
+    r_adv, r_lk, _ = expand_refresh_cells(prod, refresh_aux(limb_bits, Ln, Ln), limb_bits, lb)
+    pre_a += r_adv + [0]          # refresh, load_zero
+    pre_l += r_lk
+    c, sg, sr, fin = encrypt_trace(n, g, m, r)
+    fa, fl = expand_mul_mod_cells(*fin, n2, L, lb, limb_bits)
+    cps, lps = len(fa), len(fl)
+    ta, tl = expand_assign_cells(res, L, limb_bits, lb)
+    ae, _ = expand_assert_equal_fresh_cells(decompose_biguint(c, L, limb_bits), decompose_biguint(res, L, limb_bits))
+    # pieces in stream order: (advice cells, lookup cells, maker of both lists)
+    pieces = [(len(pre_a), len(pre_l), lambda: (pre_a, pre_l))]
+    for steps in (sg, sr):
+        pieces.append((2, 0, lambda: ([1, 0], [])))
+        pieces += [(cps, lps, (lambda st=st: expand_mul_mod_cells(*st, n2, L, lb, limb_bits))) for st in steps]
+    pieces.append((cps, lps, lambda: (fa, fl)))
+    pieces.append((len(ta), len(tl), lambda: (ta, tl)))
+    pieces.append((len(ae), 0, lambda: (ae, [])))
+    tot_a, tot_l = sum(p[0] for p in pieces), sum(p[1] for p in pieces)
+
+    def cut(windows, which):
+        outs = []
+        for lo, hi in windows:
+            out, off = [], 0
+            for p_ in pieces:
+                ln = p_[which]
+                if ln and off < hi and off + ln > lo:
+                    cells = p_[2]()[which]
+                    assert len(cells) == ln
+                    out += cells[max(lo - off, 0): hi - off]
+                off += ln
+                if off >= hi:
+                    break
+            outs.append([v % FR_R for v in out])
+        return outs
+
+    return tot_a, tot_l, cut(adv_windows, 0), cut(lk_windows, 1)
+
+
 # gate positions (MockProver analogue) of the operations above, relative to the operation's first cell
 def gate_offsets_assign(num_limbs: int, limb_bits: int, lb: int):
     gates, off = [], num_limbs

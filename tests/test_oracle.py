@@ -341,3 +341,21 @@ def test_shplonk_identity():
         R = P.interpolate(xs, [sum(pow(y, j, P.FR_R) * P.poly_eval(p, xx) for j, p in enumerate(ps)) % P.FR_R for xx in xs])
         lhs = (lhs + pow(v, k, P.FR_R) * zk * (C_s - P.poly_eval(R, u))) % P.FR_R
     assert lhs == z0 * (s - u) * P.poly_eval(h2, s) % P.FR_R
+
+
+def test_circuit_cell_windows_match_the_full_expansion():
+    """encrypt_circuit_cells_windows (what the at-size GPU test of config c2 samples columns with) returns exactly the
+    slices of expand_circuit_cells' streams"""
+    import random
+
+    bits, W, lb = 128, 64, 8
+    rng = random.Random(5)
+    n, g, m, r = rng.getrandbits(bits) | 1, rng.getrandbits(bits), rng.getrandbits(20), rng.getrandbits(bits)
+    res = P.paillier_enc_native(n, g, m, r)
+    adv, lk, _ = P.expand_circuit_cells("encrypt", n, g, m, r, res, bits, W, lb)
+    wins = [(0, 1000), (777, 5555), (len(adv) // 2, len(adv) // 2 + 3000), (len(adv) - 900, len(adv))]
+    lwins = [(0, 100), (1000, 2500), (len(lk) - 50, len(lk))]
+    ta, tl, a, l = P.encrypt_circuit_cells_windows(n, g, m, r, res, bits, W, lb, wins, lwins)
+    assert (ta, tl) == (len(adv), len(lk))
+    assert all(c == adv[lo:hi] for (lo, hi), c in zip(wins, a))
+    assert all(c == lk[lo:hi] for (lo, hi), c in zip(lwins, l))
