@@ -232,8 +232,9 @@ class ProofWorkload:
         from paillier_halo2_amd import dist as pzd
 
         rk, ws = self.shard
+        skip = os.environ.get("PZ_BENCH_SKIP", "")   # debug only ("msm" / "ntt"): time one half of the hot path alone
         # K1: commitments -- every advice and lookup-advice column (real witness cells) ...
-        for buf, ncols in ((self.d_adv[slot], self.adv_cols), (self.d_lk[slot], self.lk_cols)):
+        for buf, ncols in (() if "msm" in skip else ((self.d_adv[slot], self.adv_cols), (self.d_lk[slot], self.lk_cols))):
             if self.scale != 1.0:
                 ncols = max(1, int(round(ncols * self.scale)))
             lo, hi = pzd.column_range(ncols, rk, ws)   # column-parallel mode: this rank's columns of the shared proof
@@ -245,14 +246,15 @@ class ProofWorkload:
         # ... and the full-width MSMs of the later prover phases (permuted lookup columns, grand products,
         # quotient pieces, openings): uniformly random scalars
         lo, hi = pzd.column_range(self.counts["msm_full"], rk, ws)
-        done = lo
+        done = hi if "msm" in skip else lo
         while done < hi:
             nc = min(self.pool, hi - done)
-            eng.msm_dev(self.bases, self.col_f.data_ptr(), nc, n, 4 * n, self.d_out_full[done - lo].data_ptr())
+            e_ = self.engn if (os.environ.get("PZ_BENCH_MSM2") == "1" and (done // self.pool) & 1) else eng   # experiment
+            e_.msm_dev(self.bases, self.col_f.data_ptr(), nc, n, 4 * n, self.d_out_full[done - lo].data_ptr())
             done += nc
         if ws > 1:
             pzd.gather_commitments(t, self.dist, self.d_out_full[: hi - lo], self.counts["msm_full"], rk, ws)
-        if not msm_only:
+        if not msm_only and "ntt" not in skip:
             self.consume_ntt()
         if tail:
             self.tail_run(slot)

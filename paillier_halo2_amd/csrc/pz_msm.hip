@@ -128,7 +128,9 @@ __global__ __launch_bounds__(128) void k_build_table(const G1Aff64* __restrict__
 //                           slot; (table index | sign << 31) is written to the sorted entry list
 // ------------------------------------------------------------------------------------------------
 #define SORT_THREADS 1024u
+#ifndef SORT_PER_THREAD
 #define SORT_PER_THREAD 8u
+#endif
 #define SORT_SLICE (SORT_THREADS * SORT_PER_THREAD)
 #define SORT_MAXB 32768u
 

@@ -52,6 +52,46 @@ extern __shared__ __attribute__((aligned(16))) unsigned char pz_smem[];
 // ------------------------------------------------------------------------------------------------
 typedef F29<FrTag> Fr29;
 
+// ---- timing experiments (profiles/probes/ntt_variants.py): any PZ_NTT_EXP value breaks the results ----
+#ifndef PZ_NTT_EXP
+#define PZ_NTT_EXP 0
+#endif
+#ifndef NTT_LB
+#define NTT_LB 4u    // elements a thread loads per batch of outstanding global loads
+#endif
+#if PZ_NTT_EXP == 1 || (PZ_NTT_EXP >= 5 && PZ_NTT_EXP <= 7)      // no products inside the stages
+#define STAGE_MUL(a, b) f29_add(a, b)
+#else
+#define STAGE_MUL(a, b) f29_mul(a, b)
+#endif
+#if PZ_NTT_EXP == 3      // no barriers
+#define NTT_SYNC()
+#else
+#define NTT_SYNC() __syncthreads()
+#endif
+#if PZ_NTT_EXP == 4      // stage twiddles from registers instead of the table
+#define STAGE_TW(ptr) tw_fake
+#else
+#define STAGE_TW(ptr) f29_load<FrTag>(ptr)
+#endif
+#if PZ_NTT_EXP == 7      // no global data traffic: inputs made up in registers, stores never taken (but not removable)
+__device__ __forceinline__ Fr fake_raw(const Fr* p_) {
+    Fr r;
+    for (int i = 0; i < 8; ++i) r.v[i] = ((u32)(size_t)p_ * 2654435761u + i * 40503u) & 0x0fffffffu;
+    return r;
+}
+#define DATA_LOAD_RAW(ptr) fake_raw(ptr)
+#define DATA_STORE(J, ptr, x) do { Fr29 x_ = (x); if (x_.v[0] == 0xffffffffu) f29_store<J>(ptr, x_); } while (0)
+#else
+#define DATA_LOAD_RAW(ptr) fp_load<FrTag>(ptr)
+#define DATA_STORE(J, ptr, x) f29_store<J>(ptr, x)
+#endif
+#if PZ_NTT_EXP >= 5 && PZ_NTT_EXP <= 7      // no products at all (stages, pre-scale, inter-pass twiddle, post scale)
+#define EDGE_MUL(a, b) f29_carry(f29_add(a, b))
+#else
+#define EDGE_MUL(a, b) f29_mul(a, b)
+#endif
+
 // tile index -> LDS word offset: 9 words per element and ONE PAD ELEMENT PER 32, which spreads the power-of-two
 // element strides of the bit-reversed fill and of the first pair of stages over all banks (without it 69 % of the
 // LDS cycles of these kernels were bank conflicts: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/)
@@ -82,6 +122,13 @@ __device__ __forceinline__ void bf29(const Fr29& u, const Fr29& v, Fr29& sum, Fr
 __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, unsigned sr, unsigned st, bool t_fastest,
                                           const Fr* __restrict__ tw, size_t n) {
     const unsigned R = 1u << logR;
+#if PZ_NTT_EXP == 6
+    return;
+#endif
+#if PZ_NTT_EXP == 4
+    Fr29 tw_fake;
+    for (int i = 0; i < 9; ++i) tw_fake.v[i] = (threadIdx.x * 2654435761u + i * 40503u) & 0x1fffffffu;
+#endif
     const unsigned logT = 31u - (unsigned)__builtin_clz(T);
     unsigned s = 0;
     for (; s + 1 < logR; s += 2) {
@@ -107,13 +154,13 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
                 // parallel carry round each
                 a0 = f29_carry(a0);
                 a2 = f29_carry(a2);
-                const Fr29 w = f29_load<FrTag>(tw + (size_t)pos * (n >> (s + 1)));
-                a1 = f29_mul(a1, w);
-                a3 = f29_mul(a3, w);
+                const Fr29 w = STAGE_TW(tw + (size_t)pos * (n >> (s + 1)));
+                a1 = STAGE_MUL(a1, w);
+                a3 = STAGE_MUL(a3, w);
                 bf29(a0, a1, b0, b1);
                 bf29(a2, a3, b2, b3);
-                b2 = f29_mul(b2, f29_load<FrTag>(tw + (size_t)pos * (n >> (s + 2))));
-                b3 = f29_mul(b3, f29_load<FrTag>(tw + (size_t)(pos + h) * (n >> (s + 2))));
+                b2 = STAGE_MUL(b2, STAGE_TW(tw + (size_t)pos * (n >> (s + 2))));
+                b3 = STAGE_MUL(b3, STAGE_TW(tw + (size_t)(pos + h) * (n >> (s + 2))));
                 bf29(b0, b2, o0, o2);
             } else {
                 // stages 0 + 1: operands straight from the load (tight, value < 2p); the first layer's twiddles and the
@@ -122,7 +169,7 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
                 b1 = f29_sub<2, 29>(a0, a1);
                 b2 = f29_add(a2, a3);          // un-multiplied: limbs < 2^30, value < 4p -> subtrahend of f29_sub<4, 30>
                 b3 = f29_sub<2, 29>(a2, a3);
-                b3 = f29_mul(b3, f29_load<FrTag>(tw + (size_t)(pos + h) * (n >> (s + 2))));
+                b3 = STAGE_MUL(b3, STAGE_TW(tw + (size_t)(pos + h) * (n >> (s + 2))));
                 o0 = f29_add(b0, b2);
                 o2 = f29_sub<4, 30>(b0, b2);
             }
@@ -133,7 +180,7 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
             lds29_put(sm, e0 + dh, o1);
             lds29_put(sm, e0 + 3 * dh, o3);
         }
-        __syncthreads();
+        NTT_SYNC();
     }
     if (s < logR) {
         const unsigned half = 1u << s;
@@ -155,7 +202,7 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
             Fr29 o0, o1;
             if (s) {
                 u = f29_carry(u);
-                v = f29_mul(v, f29_load<FrTag>(tw + (size_t)pos * (n >> (s + 1))));
+                v = STAGE_MUL(v, STAGE_TW(tw + (size_t)pos * (n >> (s + 1))));
                 bf29(u, v, o0, o1);
             } else {  // a single stage (logR == 1): operands straight from the load (tight, < 2p)
                 o0 = f29_add(u, v);
@@ -164,11 +211,12 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
             lds29_put(sm, e0, o0);
             lds29_put(sm, e1, o1);
         }
-        __syncthreads();
+        NTT_SYNC();
     }
 }
 
 // strided pass.  grid.x = hi * (lo / T), grid.y = column.  tw, pre: 261-domain tables
+template <bool PRE>
 __global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, size_t in_stride, size_t out_stride,
                                                        NttPass p, const Fr* __restrict__ tw,
                                                        const Fr* __restrict__ pre) {
@@ -183,26 +231,52 @@ __global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, si
     const Fr* src = in + by * in_stride;
     Fr* dst = out + by * out_stride;
     const size_t base = h * R * p.lo + lt * T;
-    for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
-        unsigned j = idx >> logT, t = idx & (T - 1);
-        size_t g = base + (size_t)j * p.lo + t;
-        Fr29 x = f29_load<FrTag>(src + g);
-        if (pre) x = f29_mul(x, f29_load<FrTag>(pre + g));
-        lds29_put(sm, (size_t)bitrev32(j, p.logR) * T + t, x);
+    // global loads are issued NTT_LB elements at a time before anything waits on them (one exposed memory round trip per
+    // batch instead of two per element: the load, then the pre-scale table row)
+    const unsigned nelem = R * T;
+    for (unsigned i0 = 0; i0 < nelem; i0 += NTT_LB * 256u) {
+        Fr raw[NTT_LB], praw[NTT_LB];
+#pragma unroll
+        for (unsigned k = 0; k < NTT_LB; ++k) {
+            const unsigned idx = (i0 + k * 256u + threadIdx.x) & (nelem - 1);   // lanes past the tile re-read one of its elements: no branch around the loads
+            const size_t g = base + (size_t)(idx >> logT) * p.lo + (idx & (T - 1));
+            raw[k] = DATA_LOAD_RAW(src + g);
+            if (PRE) praw[k] = fp_load<FrTag>(pre + g);
+        }
+#pragma unroll
+        for (unsigned k = 0; k < NTT_LB; ++k) {
+            const unsigned idx = i0 + k * 256u + threadIdx.x;
+            if (idx < nelem) {
+                Fr29 x = f29_from_fp(raw[k]);
+                if (PRE) x = EDGE_MUL(x, f29_from_fp(praw[k]));
+                lds29_put(sm, (size_t)bitrev32(idx >> logT, p.logR) * T + (idx & (T - 1)), x);
+            }
+        }
     }
-    __syncthreads();
+    NTT_SYNC();
     lds_dit29(sm, p.logR, T, T, 1, true, tw, p.n);
-    for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
-        unsigned k = idx >> logT, t = idx & (T - 1);
-        Fr29 x = lds29_get(sm, (size_t)k * T + t);
-        size_t e = p.tw_mul * (lt * T + t) * k;  // < n by construction
-        // always through the product (tw[0] = 1): the result is below 2p whatever the stages accumulated
-        x = f29_mul(x, f29_load<FrTag>(tw + e));
-        f29_store<1>(dst + base + (size_t)k * p.lo + t, x);
+    for (unsigned i0 = 0; i0 < nelem; i0 += NTT_LB * 256u) {
+        Fr traw[NTT_LB];
+#pragma unroll
+        for (unsigned k = 0; k < NTT_LB; ++k) {
+            const unsigned idx = (i0 + k * 256u + threadIdx.x) & (nelem - 1);
+            traw[k] = fp_load<FrTag>(tw + p.tw_mul * (lt * T + (idx & (T - 1))) * (idx >> logT));  // exponent < n by construction
+        }
+#pragma unroll
+        for (unsigned k = 0; k < NTT_LB; ++k) {
+            const unsigned idx = i0 + k * 256u + threadIdx.x;
+            if (idx < nelem) {
+                const unsigned kk = idx >> logT, t = idx & (T - 1);
+                // always through the product (tw[0] = 1): the result is below 2p whatever the stages accumulated
+                const Fr29 x = EDGE_MUL(lds29_get(sm, (size_t)kk * T + t), f29_from_fp(traw[k]));
+                DATA_STORE(1, dst + base + (size_t)kk * p.lo + t, x);
+            }
+        }
     }
 }
 
 // final pass.  grid.x = n2 * (n1 / T), grid.y = column
+template <bool PRE>
 __global__ __launch_bounds__(256) void k_ntt_final29(const Fr* in, Fr* out, size_t in_stride, size_t out_stride,
                                                      NttPass p, const Fr* __restrict__ tw, const Fr* __restrict__ pre,
                                                      Fr post, int has_post) {
@@ -214,22 +288,35 @@ __global__ __launch_bounds__(256) void k_ntt_final29(const Fr* in, Fr* out, size
     const size_t k2 = bx / tiles, k1_0 = (bx % tiles) * T;
     const Fr* src = in + by * in_stride;
     Fr* dst = out + by * out_stride;
-    for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
-        unsigned r = idx >> p.logR, j = idx & (R - 1);
-        size_t g = ((k1_0 + r) * p.n2 + k2) * R + j;
-        Fr29 x = f29_load<FrTag>(src + g);
-        if (pre) x = f29_mul(x, f29_load<FrTag>(pre + g));
-        lds29_put(sm, (size_t)r * R + bitrev32(j, p.logR), x);
+    const unsigned nelem = R * T;
+    for (unsigned i0 = 0; i0 < nelem; i0 += NTT_LB * 256u) {
+        Fr raw[NTT_LB], praw[NTT_LB];
+#pragma unroll
+        for (unsigned k = 0; k < NTT_LB; ++k) {
+            const unsigned idx = (i0 + k * 256u + threadIdx.x) & (nelem - 1);
+            const size_t g = ((k1_0 + (idx >> p.logR)) * p.n2 + k2) * R + (idx & (R - 1));
+            raw[k] = DATA_LOAD_RAW(src + g);
+            if (PRE) praw[k] = fp_load<FrTag>(pre + g);
+        }
+#pragma unroll
+        for (unsigned k = 0; k < NTT_LB; ++k) {
+            const unsigned idx = i0 + k * 256u + threadIdx.x;
+            if (idx < nelem) {
+                Fr29 x = f29_from_fp(raw[k]);
+                if (PRE) x = EDGE_MUL(x, f29_from_fp(praw[k]));
+                lds29_put(sm, (size_t)(idx >> p.logR) * R + bitrev32(idx & (R - 1), p.logR), x);
+            }
+        }
     }
-    __syncthreads();
+    NTT_SYNC();
     lds_dit29(sm, p.logR, T, 1, R, false, tw, p.n);
     const Fr29 post29 = f29_from_fp(post);
     for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
         unsigned k = idx >> logT, r = idx & (T - 1);
         Fr29 x = lds29_get(sm, (size_t)r * R + k);
         Fr* o = dst + (k1_0 + r) + p.n1 * k2 + p.hi * (size_t)k;
-        if (has_post) f29_store<1>(o, f29_mul(x, post29));
-        else f29_store<4>(o, x);
+        if (has_post) DATA_STORE(1, o, EDGE_MUL(x, post29));
+        else DATA_STORE(4, o, x);
     }
 }
 
@@ -237,6 +324,7 @@ __global__ __launch_bounds__(256) void k_ntt_final29(const Fr* in, Fr* out, size
 // n-coefficient polynomial is 2^e independent n-point NTTs of a[i] * (g * w_ext^r)^i, r < 2^e, interleaved
 // as out[2^e * q + r].  The strided pass has already run per r (inputs at in + r * in_r_stride); this
 // block finishes T rows for ALL r at once so every store is a full T * 2^e * 32-byte run.
+template <bool PRE>
 __global__ __launch_bounds__(256) void k_ntt_final_ext29(const Fr* in, Fr* out, size_t in_stride, size_t in_r_stride,
                                                          size_t out_stride, NttPass p, unsigned log_e,
                                                          const Fr* __restrict__ tw, const Fr* __restrict__ pre,
@@ -249,19 +337,34 @@ __global__ __launch_bounds__(256) void k_ntt_final_ext29(const Fr* in, Fr* out, 
     const size_t k2 = bx / tiles, k1_0 = (bx % tiles) * T;
     const Fr* src = in + by * in_stride;
     Fr* dst = out + by * out_stride;
-    for (unsigned idx = threadIdx.x; idx < R * T * E; idx += blockDim.x) {
-        const unsigned j = idx & (R - 1), rr = (idx >> p.logR) & (T - 1), r = idx >> (p.logR + logT);
-        const size_t g = ((k1_0 + rr) * p.n2 + k2) * R + j;
-        Fr29 x = f29_load<FrTag>(src + (size_t)r * in_r_stride + g);
-        if (pre) x = f29_mul(x, f29_load<FrTag>(pre + (size_t)r * pre_r_stride + g));
-        lds29_put(sm, ((size_t)r * T + rr) * R + bitrev32(j, p.logR), x);
+    const unsigned nelem = R * T * E;
+    for (unsigned i0 = 0; i0 < nelem; i0 += NTT_LB * 256u) {
+        Fr raw[NTT_LB], praw[NTT_LB];
+#pragma unroll
+        for (unsigned k = 0; k < NTT_LB; ++k) {
+            const unsigned idx = (i0 + k * 256u + threadIdx.x) & (nelem - 1);
+            const unsigned j = idx & (R - 1), rr = (idx >> p.logR) & (T - 1), r = idx >> (p.logR + logT);
+            const size_t g = ((k1_0 + rr) * p.n2 + k2) * R + j;
+            raw[k] = DATA_LOAD_RAW(src + (size_t)r * in_r_stride + g);
+            if (PRE) praw[k] = fp_load<FrTag>(pre + (size_t)r * pre_r_stride + g);
+        }
+#pragma unroll
+        for (unsigned k = 0; k < NTT_LB; ++k) {
+            const unsigned idx = i0 + k * 256u + threadIdx.x;
+            if (idx < nelem) {
+                const unsigned j = idx & (R - 1), rr = (idx >> p.logR) & (T - 1), r = idx >> (p.logR + logT);
+                Fr29 x = f29_from_fp(raw[k]);
+                if (PRE) x = EDGE_MUL(x, f29_from_fp(praw[k]));
+                lds29_put(sm, ((size_t)r * T + rr) * R + bitrev32(j, p.logR), x);
+            }
+        }
     }
-    __syncthreads();
+    NTT_SYNC();
     lds_dit29(sm, p.logR, T * E, 1, R, false, tw, p.n);
     for (unsigned idx = threadIdx.x; idx < R * T * E; idx += blockDim.x) {
         const unsigned r = idx & (E - 1), rr = (idx >> log_e) & (T - 1), k = idx >> (log_e + logT);
         const Fr29 x = lds29_get(sm, ((size_t)r * T + rr) * R + k);
-        f29_store<4>(dst + (((k1_0 + rr) + p.n1 * k2 + p.hi * (size_t)k) << log_e) + r, x);
+        DATA_STORE(4, dst + (((k1_0 + rr) + p.n1 * k2 + p.hi * (size_t)k) << log_e) + r, x);
     }
 }
 
@@ -325,8 +428,9 @@ static int launch_strided(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t 
     size_t blocks = p.hi * (p.lo / p.T);
     size_t lds = ntt29_lds_bytes(((size_t)1 << p.logR) * p.T);
     p.swap = (ncols > 1 && blocks <= 65535) ? 1u : 0u;
-    hipLaunchKernelGGL(k_ntt_strided29, p.swap ? dim3((unsigned)ncols, (unsigned)blocks) : dim3((unsigned)blocks, (unsigned)ncols),
-                       dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre);
+    const dim3 grid = p.swap ? dim3((unsigned)ncols, (unsigned)blocks) : dim3((unsigned)blocks, (unsigned)ncols);
+    if (pre) hipLaunchKernelGGL(k_ntt_strided29<true>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre);
+    else hipLaunchKernelGGL(k_ntt_strided29<false>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre);
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
 }
@@ -342,8 +446,9 @@ static int launch_final(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t os
         memcpy(post.v, ps, 32);
     }
     p.swap = (ncols > 1 && blocks <= 65535) ? 1u : 0u;
-    hipLaunchKernelGGL(k_ntt_final29, p.swap ? dim3((unsigned)ncols, (unsigned)blocks) : dim3((unsigned)blocks, (unsigned)ncols),
-                       dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, post, post_scale ? 1 : 0);
+    const dim3 grid = p.swap ? dim3((unsigned)ncols, (unsigned)blocks) : dim3((unsigned)blocks, (unsigned)ncols);
+    if (pre) hipLaunchKernelGGL(k_ntt_final29<true>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, post, post_scale ? 1 : 0);
+    else hipLaunchKernelGGL(k_ntt_final29<false>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, post, post_scale ? 1 : 0);
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
 }
@@ -484,7 +589,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
             p.logR = log_n; p.lo = 1; p.hi = 1; p.n = n; p.T = 1; p.n1 = 1; p.n2 = 1;
             const size_t lds = ntt29_lds_bytes(((size_t)1 << p.logR) * p.T * E);
             p.swap = 0;
-            hipLaunchKernelGGL(k_ntt_final_ext29, dim3(1, (unsigned)nc), dim3(256), lds, ctx->stream, cin + c0 * is,
+            hipLaunchKernelGGL(k_ntt_final_ext29<true>, dim3(1, (unsigned)nc), dim3(256), lds, ctx->stream, cin + c0 * is,
                                eout + c0 * os, is, (size_t)0, os, p, log_e, tw, pre, n);
         } else if (npass == 3) {
             // 2^19 .. 2^27 (config c5 runs k = 19): two strided passes per coset, then the interleaving final pass
@@ -509,7 +614,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
             pc.T = T;
             const size_t lds = ntt29_lds_bytes(((size_t)1 << lg[2]) * T * E);
             pc.swap = (nc > 1 && n2 * (n1 / T) <= 65535) ? 1u : 0u;
-            hipLaunchKernelGGL(k_ntt_final_ext29, pc.swap ? dim3((unsigned)nc, (unsigned)(n2 * (n1 / T))) : dim3((unsigned)(n2 * (n1 / T)), (unsigned)nc), dim3(256), lds, ctx->stream, tmp,
+            hipLaunchKernelGGL(k_ntt_final_ext29<false>, pc.swap ? dim3((unsigned)nc, (unsigned)(n2 * (n1 / T))) : dim3((unsigned)(n2 * (n1 / T)), (unsigned)nc), dim3(256), lds, ctx->stream, tmp,
                                eout + c0 * os, n, nc * n, os, pc, log_e, tw, (const Fr*)nullptr, (size_t)0);
         } else {
             unsigned lg0 = (log_n + 1) / 2, lg1 = log_n - lg0;
@@ -527,7 +632,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
             pc.T = T;
             const size_t lds = ntt29_lds_bytes(((size_t)1 << lg1) * T * E);
             pc.swap = nc > 1 ? 1u : 0u;
-            hipLaunchKernelGGL(k_ntt_final_ext29, pc.swap ? dim3((unsigned)nc, (unsigned)(n1 / T)) : dim3((unsigned)(n1 / T), (unsigned)nc), dim3(256), lds, ctx->stream, tmp,
+            hipLaunchKernelGGL(k_ntt_final_ext29<false>, pc.swap ? dim3((unsigned)nc, (unsigned)(n1 / T)) : dim3((unsigned)(n1 / T), (unsigned)nc), dim3(256), lds, ctx->stream, tmp,
                                eout + c0 * os, n, nc * n, os, pc, log_e, tw, (const Fr*)nullptr, (size_t)0);
         }
         HIPCHK(ctx, hipGetLastError());
