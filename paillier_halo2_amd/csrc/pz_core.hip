@@ -195,6 +195,10 @@ extern "C" int pz_free(pz_ctx* ctx) {
             (void)hipEventDestroy(p.a);
             (void)hipEventDestroy(p.b);
         }
+    for (auto& e : ctx->io_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->io_h2d) (void)hipStreamDestroy(ctx->io_h2d);
+    if (ctx->io_d2h) (void)hipStreamDestroy(ctx->io_d2h);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return PZ_OK;
@@ -215,6 +219,17 @@ extern "C" int pz_set_stream(pz_ctx* ctx, void* s) {
         if (e != hipSuccess) return pz_hip_fail(ctx, e, "pz_set_stream: order the new stream after the old one");
         ctx->stream = ns;
     }
+    return PZ_OK;
+}
+
+int pz_io_init(pz_ctx* ctx) {
+    if (!ctx->io_h2d) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->io_h2d, hipStreamNonBlocking));
+    if (!ctx->io_d2h) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->io_d2h, hipStreamNonBlocking));
+    for (auto& e : ctx->io_ev)
+        if (!e) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // the staging buffers may still be in use by work queued on the caller's stream (an earlier call): uploads start after it
+    HIPCHK(ctx, hipEventRecord(ctx->io_ev[PZ_IO_EVENTS - 1], ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->io_h2d, ctx->io_ev[PZ_IO_EVENTS - 1], 0));
     return PZ_OK;
 }
 

@@ -38,6 +38,7 @@ struct pz_event_pair {
     hipEvent_t a, b;
 };
 
+#define PZ_IO_EVENTS 10
 struct pz_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -53,6 +54,10 @@ struct pz_ctx {
     double ev_ms[PZ_T_COUNT] = {0};
     uint64_t ev_n[PZ_T_COUNT] = {0};
     int cu_count = 256;
+    // host-pointer entry points (pz_msm_g1_batch, pz_ntt_fr_batch): copy engines of their own, so that the PCIe transfers
+    // of the next / previous column group run beside the kernels of the current one (pz_io_init creates them on first use)
+    hipStream_t io_h2d = nullptr, io_d2h = nullptr;
+    hipEvent_t io_ev[PZ_IO_EVENTS] = {};
     std::recursive_mutex mu;   // one context is serialised internally: entry points may be called from any thread
 };
 
@@ -100,5 +105,7 @@ struct pz_timer {
     pz_timer(pz_ctx* c, int cls_);
     ~pz_timer();
 };
+
+int pz_io_init(pz_ctx* ctx);   // streams + events of the host-pointer pipelines; orders io_h2d after ctx->stream
 
 static inline unsigned pz_div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

@@ -992,25 +992,46 @@ extern "C" int pz_msm_g1_batch(pz_ctx* ctx, const pz_bases* bases, const uint64_
     if (n_cols == 0) return PZ_OK;
     PZ_ENTER(ctx);
     const size_t bytes = n * 32;
-    size_t group = bytes ? ((size_t)1 << 29) / bytes : n_cols;
-    if (group == 0) group = 1;
-    if (group > n_cols) group = n_cols;
+    for (size_t j = 0; j < n_cols; ++j)
+        if (!scalar_cols[j] && n) return PZ_ERR_INVALID;
+    // column groups through two staging buffers: the upload of group g+1 (io_h2d) runs under the kernels of group g.  Group
+    // sizes ramp up 128 MiB, 256 MiB, ... to 1 GiB: only the first, small upload is exposed, and the later launch sequences
+    // are wide enough (256 columns at 2^17) for the reduction tree's fixed latency to vanish
+    const size_t g_min = bytes ? (((size_t)1 << 27) / bytes ? ((size_t)1 << 27) / bytes : 1) : n_cols;
+    size_t g_max = bytes ? (((size_t)1 << 30) / bytes ? ((size_t)1 << 30) / bytes : 1) : n_cols;
+    if (g_max > n_cols) g_max = n_cols;
     void *d_s, *d_o;
-    PZCHK(pz_ws_get(ctx, WS_IO_B, group * bytes + 32, &d_s));
-    PZCHK(pz_ws_get(ctx, WS_IO_C, group * 96, &d_o));
-    for (size_t c0 = 0; c0 < n_cols; c0 += group) {
-        size_t nc = n_cols - c0 < group ? n_cols - c0 : group;
-        for (size_t j = 0; j < nc; ++j) {
-            if (!scalar_cols[c0 + j] && n) return PZ_ERR_INVALID;
-            if (bytes)
-                HIPCHK(ctx, hipMemcpyAsync((char*)d_s + j * bytes, scalar_cols[c0 + j], bytes, hipMemcpyHostToDevice,
-                                           ctx->stream));
-        }
-        PZCHK(pz_msm_g1_dev(ctx, bases, (const uint64_t*)d_s, nc, n, 4 * n, 0, bases->nwin, (uint64_t*)d_o));
-        HIPCHK(ctx, hipMemcpyAsync(out_jac + c0 * 12, d_o, nc * 96, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    PZCHK(pz_ws_get(ctx, WS_IO_B, 2 * g_max * bytes + 32, &d_s));
+    PZCHK(pz_ws_get(ctx, WS_IO_C, n_cols * 96, &d_o));
+    PZCHK(pz_io_init(ctx));
+    hipEvent_t* ev_in = ctx->io_ev;        // [2] group uploaded
+    hipEvent_t* ev_done = ctx->io_ev + 2;  // [2] group consumed by its kernels
+    int rc = PZ_OK;
+    size_t g = 0, group = g_min < g_max ? g_min : g_max;
+    for (size_t c0 = 0; c0 < n_cols && rc == PZ_OK; ++g) {
+        const size_t nc = n_cols - c0 < group ? n_cols - c0 : group;
+        const unsigned b = (unsigned)(g & 1);
+        char* buf = (char*)d_s + b * g_max * bytes;
+        hipError_t e = hipSuccess;
+        if (g >= 2) e = hipStreamWaitEvent(ctx->io_h2d, ev_done[b], 0);
+        for (size_t j = 0; j < nc && e == hipSuccess && bytes; ++j)
+            e = hipMemcpyAsync(buf + j * bytes, scalar_cols[c0 + j], bytes, hipMemcpyHostToDevice, ctx->io_h2d);
+        if (e == hipSuccess) e = hipEventRecord(ev_in[b], ctx->io_h2d);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ev_in[b], 0);
+        if (e != hipSuccess) { rc = pz_hip_fail(ctx, e, "pz_msm_g1_batch: upload"); break; }
+        rc = pz_msm_g1_dev(ctx, bases, (const uint64_t*)buf, nc, n, 4 * n, 0, bases->nwin, (uint64_t*)d_o + c0 * 12);
+        if (rc == PZ_OK && (e = hipEventRecord(ev_done[b], ctx->stream)) != hipSuccess) rc = pz_hip_fail(ctx, e, "pz_msm_g1_batch: event");
+        c0 += nc;
+        group = group * 2 < g_max ? group * 2 : g_max;
     }
-    return PZ_OK;
+    if (rc == PZ_OK) {
+        hipError_t e = hipMemcpyAsync(out_jac, d_o, n_cols * 96, hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess) rc = pz_hip_fail(ctx, e, "pz_msm_g1_batch: download");
+    }
+    // the host buffers belong to the caller again when this returns, whatever happened
+    hipError_t e1 = hipStreamSynchronize(ctx->io_h2d), e2 = hipStreamSynchronize(ctx->stream);
+    if (rc == PZ_OK && (e1 != hipSuccess || e2 != hipSuccess)) rc = pz_hip_fail(ctx, e1 != hipSuccess ? e1 : e2, "pz_msm_g1_batch: synchronize");
+    return rc;
 }
 
 extern "C" int pz_msm_g1(pz_ctx* ctx, const pz_bases* bases, const uint64_t* scalars, size_t n, uint64_t out_jac[12]) {

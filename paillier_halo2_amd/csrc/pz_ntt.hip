@@ -665,24 +665,46 @@ extern "C" int pz_ntt_fr_batch(pz_ctx* ctx, uint64_t* const* cols, size_t n_cols
     if (n_cols == 0) return PZ_OK;
     PZ_ENTER(ctx);
     const size_t n = (size_t)1 << log_n, bytes = n * 32;
-    // stage in groups of <= 1 GiB
-    size_t group = ((size_t)1 << 30) / bytes;
+    for (size_t j = 0; j < n_cols; ++j)
+        if (!cols[j]) return PZ_ERR_INVALID;
+    // column groups of ~128 MiB in three staging buffers: upload of group g+1 (io_h2d), kernels of group g (caller's stream)
+    // and download of group g-1 (io_d2h) run at the same time -- PCIe is full duplex
+    size_t group = ((size_t)1 << 27) / bytes;
     if (group == 0) group = 1;
     if (group > n_cols) group = n_cols;
     void* d;
-    PZCHK(pz_ws_get(ctx, WS_IO_A, group * bytes, &d));
-    for (size_t c0 = 0; c0 < n_cols; c0 += group) {
-        size_t nc = n_cols - c0 < group ? n_cols - c0 : group;
-        for (size_t j = 0; j < nc; ++j) {
-            if (!cols[c0 + j]) return PZ_ERR_INVALID;
-            HIPCHK(ctx, hipMemcpyAsync((char*)d + j * bytes, cols[c0 + j], bytes, hipMemcpyHostToDevice, ctx->stream));
-        }
-        PZCHK(pz_ntt_fr_dev(ctx, (uint64_t*)d, nc, 4 * n, omega, log_n, nullptr, nullptr));
-        for (size_t j = 0; j < nc; ++j)
-            HIPCHK(ctx, hipMemcpyAsync(cols[c0 + j], (char*)d + j * bytes, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    PZCHK(pz_ws_get(ctx, WS_IO_A, 3 * group * bytes, &d));
+    PZCHK(pz_io_init(ctx));
+    hipEvent_t* ev_in = ctx->io_ev;         // [3] group uploaded
+    hipEvent_t* ev_done = ctx->io_ev + 3;   // [3] group transformed
+    hipEvent_t* ev_out = ctx->io_ev + 6;    // [3] group downloaded (its staging buffer is free again)
+    int rc = PZ_OK;
+    size_t g = 0;
+    for (size_t c0 = 0; c0 < n_cols && rc == PZ_OK; c0 += group, ++g) {
+        const size_t nc = n_cols - c0 < group ? n_cols - c0 : group;
+        const unsigned b = (unsigned)(g % 3);
+        char* buf = (char*)d + b * group * bytes;
+        hipError_t e = hipSuccess;
+        if (g >= 3) e = hipStreamWaitEvent(ctx->io_h2d, ev_out[b], 0);
+        for (size_t j = 0; j < nc && e == hipSuccess; ++j)
+            e = hipMemcpyAsync(buf + j * bytes, cols[c0 + j], bytes, hipMemcpyHostToDevice, ctx->io_h2d);
+        if (e == hipSuccess) e = hipEventRecord(ev_in[b], ctx->io_h2d);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ev_in[b], 0);
+        if (e != hipSuccess) { rc = pz_hip_fail(ctx, e, "pz_ntt_fr_batch: upload"); break; }
+        rc = pz_ntt_fr_dev(ctx, (uint64_t*)buf, nc, 4 * n, omega, log_n, nullptr, nullptr);
+        if (rc != PZ_OK) break;
+        e = hipEventRecord(ev_done[b], ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->io_d2h, ev_done[b], 0);
+        for (size_t j = 0; j < nc && e == hipSuccess; ++j)
+            e = hipMemcpyAsync(cols[c0 + j], buf + j * bytes, bytes, hipMemcpyDeviceToHost, ctx->io_d2h);
+        if (e == hipSuccess) e = hipEventRecord(ev_out[b], ctx->io_d2h);
+        if (e != hipSuccess) rc = pz_hip_fail(ctx, e, "pz_ntt_fr_batch: download");
     }
-    return PZ_OK;
+    // the host buffers belong to the caller again when this returns, whatever happened
+    hipError_t e1 = hipStreamSynchronize(ctx->io_h2d), e2 = hipStreamSynchronize(ctx->stream), e3 = hipStreamSynchronize(ctx->io_d2h);
+    if (rc == PZ_OK && (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess))
+        rc = pz_hip_fail(ctx, e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3), "pz_ntt_fr_batch: synchronize");
+    return rc;
 }
 
 extern "C" int pz_ntt_fr(pz_ctx* ctx, uint64_t* a, const uint64_t omega[4], uint32_t log_n) {

@@ -1024,3 +1024,42 @@ def test_uniform_shape_circuit_cell_stream(eng, cref, bits, W, lb):
         gates, end = P.gate_offsets_uniform_circuit(bits, W, lb, nr)
         assert end == adv_n and P.check_gates(got_adv, gates) == []
     assert len(lens) == 1
+
+
+def test_host_pointer_batches_pipelined_over_many_groups(eng, cref):
+    """pz_msm_g1_batch / pz_ntt_fr_batch (the drop-in binding's entry points, host pointers) stream their column groups
+    through double / triple staging buffers with the uploads and downloads on copy streams of their own: enough columns of
+    2^17 elements for several groups (incl. a ragged last one), from pageable host memory, against the device-resident
+    entry points on the same data; then a second call right behind the first (the staging buffers are reused)."""
+    import torch
+
+    k = 17
+    n = 1 << k
+    rng = np.random.default_rng(77)
+
+    def rand_cols(m):
+        a = rng.integers(0, 1 << 62, size=(m, n, 4), dtype=np.uint64)   # < 2^254: canonical Montgomery words of some value
+        return a
+
+    d_b = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    eng.srs_setup_g1_dev(k, cref.fr_ints_to_mont([0x1234567 * 0x89ABCDE + 1])[0], cref.fr_ints_to_mont([P.fr_omega(k)])[0], 0, d_b.data_ptr())
+    eng.sync()
+    tb = eng.load_bases_dev(d_b.data_ptr(), n)
+    for m in (150, 70):     # 32 columns per group -> 5 and 3 groups
+        a = rand_cols(m)
+        d_a = torch.from_numpy(a.view(np.int64)).cuda()
+        d_out = torch.zeros((m, 12), dtype=torch.int64, device="cuda")
+        eng.msm_dev(tb, d_a.data_ptr(), m, n, 4 * n, d_out.data_ptr())
+        eng.sync()
+        want = eng.g1_normalize(d_out.cpu().numpy().astype(np.uint64))
+        got = eng.g1_normalize(eng.msm_batch(tb, [a[j] for j in range(m)]))
+        assert np.array_equal(got, want), "host-pointer commitments"
+        omega = cref.fr_ints_to_mont([P.fr_omega(k)])[0]
+        eng.ntt_dev(d_a.data_ptr(), m, 4 * n, omega, k)
+        eng.sync()
+        want = d_a.cpu().numpy().view(np.uint64).reshape(m, n, 4)
+        cols = [np.ascontiguousarray(a[j]) for j in range(m)]
+        eng.ntt_batch_inplace(cols, omega, k)
+        for j in range(m):
+            assert np.array_equal(cols[j], want[j]), ("host-pointer transform, column", j)
+    tb.free()
