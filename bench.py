@@ -82,18 +82,20 @@ class ProofWorkload:
         self.inputs = tuple(consts.int_to_limbs(x, self.Ln) for x in (nn, g, m, r))
         if circuit == "encrypt":
             n_steps = m.bit_length() + bin(m).count("1") + nn.bit_length() + bin(nn).count("1") + 1
+        elif circuit == "encrypt_uniform":   # g^m over enc_bits in-circuit bits, two mul_mods per bit
+            n_steps = 2 * enc_bits + nn.bit_length() + bin(nn).count("1") + 1
         else:  # PaillierChip::add (paillier.rs:62-85): one mul_mod of two ciphertexts assigned at enc_bits (bench.rs:98-103)
             n_steps = 1
             self.add_ops = tuple(consts.int_to_limbs(x, self.L) for x in (m, r, nn * nn))
         self.n_steps = n_steps
-        self.ng = (m.bit_length() + bin(m).count("1")) if circuit == "encrypt" else 0
-        self.nr = (nn.bit_length() + bin(nn).count("1")) if circuit == "encrypt" else 0
+        self.ng = (m.bit_length() + bin(m).count("1")) if circuit == "encrypt" else 2 * enc_bits if circuit == "encrypt_uniform" else 0
+        self.nr = (nn.bit_length() + bin(nn).count("1")) if circuit != "add" else 0
         self.shape = layout.encrypt_proof_shape(enc_bits, k, n_steps, lookup_bits=lookup_bits, kind=circuit, n_steps_g=self.ng)
-        self.kind = 0 if circuit == "encrypt" else 1
+        self.kind = {"encrypt": 0, "add": 1, "encrypt_uniform": 2}[circuit]
         # the driver's inputs as the C ABI takes them (n | g | m | r | res words).  `res` is the expected ciphertext the
         # reference's driver receives from paillier_enc_native / paillier_add_native (bench.rs:149,193): here the library's own
         # native entry points (pz_paillier_encrypt without a trace, pz_mul_mod) -- no host big-integer arithmetic
-        if circuit == "encrypt":
+        if circuit != "add":
             res_limbs = eng.paillier_encrypt(self.Ln, *self.inputs, want_steps=False)[0][0]
         else:
             res_limbs = eng.mul_mod(self.L, consts.int_to_limbs(m, self.L), consts.int_to_limbs(r, self.L), consts.int_to_limbs(nn * nn, self.L))[1]
@@ -218,6 +220,8 @@ class ProofWorkload:
         nn, g, m, r = self.inputs
         if self.circuit == "encrypt":
             eng.paillier_encrypt_dev(self.Ln, nn, g, m, r, self.d_steps[slot].data_ptr(), self.n_steps)
+        elif self.circuit == "encrypt_uniform":
+            eng.paillier_encrypt_uniform_dev(self.Ln, self.enc_bits, nn, g, m, r, self.d_steps[slot].data_ptr(), self.n_steps)
         else:
             a, b, mod = self.add_ops
             q, rem = eng.mul_mod(self.L, a, b, mod)
@@ -586,8 +590,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "msm22"],
-                    help="c2: encrypt proof hot path (headline); c3: homomorphic-add circuit at --k 15; msm22: one sharded MSM")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2u", "c3", "msm22"],
+                    help="c2: encrypt proof hot path (headline); c2u: the same key size through the uniform-shape circuit (g^m over all message bits in circuit, SURVEY 8f rank 4); c3: homomorphic-add circuit at --k 15; msm22: one sharded MSM")
     ap.add_argument("--k", type=int, default=17)
     ap.add_argument("--enc-bits", type=int, default=2048)
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the per-proof MSM/NTT counts (debug only; "
@@ -661,7 +665,7 @@ def main():
     colpar = args.parallel == "columns"
     wl = ProofWorkload(eng, torch, args.enc_bits, args.k, seed=args.seed + (0 if colpar else rank), scale=args.scale,
                        lookup_bits=args.lookup_bits, shard=(rank, world) if colpar else (0, 1), dist=dist if (colpar and use_dist) else None,
-                       circuit="add" if args.workload == "c3" else "encrypt")
+                       circuit="add" if args.workload == "c3" else "encrypt_uniform" if args.workload == "c2u" else "encrypt")
     log("setup %.1fs: %s ; per-step counts %s" % (time.time() - t0, wl.shape, wl.counts))
     wl.run(args.warmup)
     if args.warmup:
@@ -768,7 +772,7 @@ def main():
         "dtype": "u32 limbs (29-bit reduced radix, 254-bit modular integers), u64 limbs (4096-bit integers)", "data": "synthetic",
         "config": {
             "workload": "%s: %d-bit n, KZG prover hot path at k=%d (K3 trace + K4 cell expansion + K1 commitments + K2 NTTs), 1 proof per GPU per step"
-                        % ("c3 homomorphic add" if args.workload == "c3" else "c2 encrypt" if (args.enc_bits, args.k) == (2048, 17) else "c5-shape encrypt" if (args.enc_bits, args.k) == (3072, 19) else "custom encrypt", args.enc_bits, args.k),
+                        % ("c3 homomorphic add" if args.workload == "c3" else "c2u uniform-shape encrypt" if args.workload == "c2u" else "c2 encrypt" if (args.enc_bits, args.k) == (2048, 17) else "c5-shape encrypt" if (args.enc_bits, args.k) == (3072, 19) else "custom encrypt", args.enc_bits, args.k),
             "enc_bits": args.enc_bits, "k": args.k, "lookup_bits": sh.lookup_bits, "limb_bits": 64,
             "mul_mod_steps": wl.n_steps, "advice_cols": sh.advice_cols, "lookup_cols": sh.lookup_cols,
             "perm_cols": sh.perm_cols, "advice_cols_committed": wl.adv_cols, "lookup_cols_committed": wl.lk_cols,

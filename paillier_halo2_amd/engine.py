@@ -300,6 +300,18 @@ class Engine:
                                                      _ptr(c)), "pz_paillier_encrypt_uniform")
         return c, steps, ng, nr
 
+    def paillier_encrypt_uniform_dev(self, limbs_n: int, m_bits: int, n, g, m, r, d_steps: int, steps_cap: int):
+        """uniform-shape trace, steps stay on the device (d_steps: batch x steps_cap x 4 x 2*limbs_n u64). Returns (c, ng, nr)."""
+        n, g, m, r = (_np(x).reshape(-1, limbs_n) for x in (n, g, m, r))
+        batch = n.shape[0]
+        ng = np.zeros(batch, dtype=np.uint32)
+        nr = np.zeros(batch, dtype=np.uint32)
+        c = np.zeros((batch, 2 * limbs_n), dtype=np.uint64)
+        self._chk(self.L.pz_paillier_encrypt_uniform_dev(self.ctx, limbs_n, batch, m_bits, _ptr(n), _ptr(g), _ptr(m), _ptr(r),
+                                                         VP(d_steps), steps_cap, VP(ng.ctypes.data), VP(nr.ctypes.data), _ptr(c)),
+                  "pz_paillier_encrypt_uniform_dev")
+        return c, ng, nr
+
     # ------------------------------------------------------------------ K4: witness expansion
     def witness_cells_per_step(self, limbs: int, limb_bits: int, lookup_bits: int) -> Tuple[int, int]:
         a = C.c_size_t()

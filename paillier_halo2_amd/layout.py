@@ -199,6 +199,9 @@ def encrypt_proof_shape(enc_bits: int, k: int, n_steps: int, limb_bits: int = 64
     if kind == "encrypt":
         ng = (n_steps - 1) // 2 if n_steps_g is None else n_steps_g
         cc = circuit_cells("encrypt", Ln, limb_bits, lookup_bits, ng, n_steps - 1 - ng)
+    elif kind == "encrypt_uniform":   # g^m takes 2 * (Ln * limb_bits) steps whatever the message is
+        ng = 2 * Ln * limb_bits
+        cc = circuit_cells("encrypt_uniform", Ln, limb_bits, lookup_bits, ng, n_steps - 1 - ng)
     else:
         cc = circuit_cells("add", Ln, limb_bits, lookup_bits)
     A = math.ceil(cc.advice / rows)
