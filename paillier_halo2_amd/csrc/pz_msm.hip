@@ -134,11 +134,38 @@ __global__ __launch_bounds__(128) void k_build_table(const G1Aff64* __restrict__
 #define SORT_SLICE (SORT_THREADS * SORT_PER_THREAD)
 #define SORT_MAXB 32768u
 
+// Workgroup -> (column, slice) for the two sort passes.  Workgroups are dealt round-robin over the 8 XCDs (ids b and b + 8
+// share one, MI355X_MICROARCH.md "Workgroup dispatch"), and each XCD has its own L2: with PZ_SORT_XCD all slices of a column
+// get ids of one residue mod 8, so the 4-byte entry stores of the scatter pass that fall into the same 128-byte line (same
+// bucket, different slices) meet in ONE L2 instead of leaving eight partially written copies of it.  A speed choice only.
+#ifndef PZ_SORT_XCD
+#define PZ_SORT_XCD 1
+#endif
+__device__ __forceinline__ bool sort_block_coords(unsigned n_slices, size_t n_cols, unsigned& slice, size_t& col) {
+#if PZ_SORT_XCD
+    const unsigned w = blockIdx.x >> 3;
+    slice = w % n_slices;
+    col = (size_t)(w / n_slices) * 8 + (blockIdx.x & 7u);
+#else
+    slice = blockIdx.x % n_slices;
+    col = blockIdx.x / n_slices;
+#endif
+    return col < n_cols;
+}
+static unsigned sort_grid(unsigned n_slices, size_t n_cols) {
+#if PZ_SORT_XCD
+    return n_slices * (unsigned)((n_cols + 7) / 8 * 8);
+#else
+    return n_slices * (unsigned)n_cols;
+#endif
+}
+
 __global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(const Fr* __restrict__ scalars, size_t col_stride, MsmP p,
-                                                           u32* __restrict__ slice_hist, unsigned n_slices) {
+                                                           u32* __restrict__ slice_hist, unsigned n_slices, size_t n_cols) {
     __shared__ u32 h[SORT_MAXB];
-    const size_t col = blockIdx.y;
-    const unsigned slice = blockIdx.x;
+    size_t col;
+    unsigned slice;
+    if (!sort_block_coords(n_slices, n_cols, slice, col)) return;
     for (unsigned b = threadIdx.x; b < p.B; b += SORT_THREADS) h[b] = 0;
     __syncthreads();
     const size_t base = (size_t)slice * SORT_SLICE;
@@ -302,10 +329,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_msm_scan(const u32* __restrict
 
 __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restrict__ scalars, size_t col_stride, MsmP p,
                                                               const u32* __restrict__ slice_hist, unsigned n_slices,
-                                                              const u32* __restrict__ offs, u32* __restrict__ entries) {
+                                                              const u32* __restrict__ offs, u32* __restrict__ entries, size_t n_cols) {
     __shared__ u32 h[SORT_MAXB];
-    const size_t col = blockIdx.y;
-    const unsigned slice = blockIdx.x;
+    size_t col;
+    unsigned slice;
+    if (!sort_block_coords(n_slices, n_cols, slice, col)) return;
     const u32* in = slice_hist + (col * n_slices + slice) * (size_t)p.B;
     const u32* o = offs + col * (p.B + 1);
     for (unsigned b = threadIdx.x; b < p.B; b += SORT_THREADS) h[b] = o[b] + in[b];
@@ -861,16 +889,16 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     PZCHK(pz_ws_get(ctx, WS_NODES_B, nc * (size_t)(n_nodes / 2 + 1) * sizeof(MsmNode), &nb));
     hipStream_t st = ctx->stream;
     pz_timer tall(ctx, PZ_T_MSM_ALL);
-    dim3 gs(n_slices, (unsigned)nc);
+    dim3 gs(sort_grid(n_slices, nc));
     {
         pz_timer tsort(ctx, PZ_T_MSM_SORT);
-        hipLaunchKernelGGL(k_msm_hist, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (u32*)hist, n_slices);
+        hipLaunchKernelGGL(k_msm_hist, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (u32*)hist, n_slices, nc);
         hipLaunchKernelGGL(k_msm_totals, dim3(pz_div_up(p.B, 256), (unsigned)nc), dim3(256), 0, st, (u32*)hist, n_slices, p,
                            (u32*)totals);
         hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)nc), dim3(SCAN_THREADS), 0, st, (const u32*)totals, p, (u32*)offs, (u32*)items,
                            (u32*)heavy, heavy_cnt, (u32*)fold, fold_cnt, item_order, item_bucket);
         hipLaunchKernelGGL(k_msm_scatter, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (const u32*)hist, n_slices,
-                           (const u32*)offs, (u32*)entries);
+                           (const u32*)offs, (u32*)entries, nc);
     }
     {
         pz_timer tacc(ctx, PZ_T_MSM_ACC);
