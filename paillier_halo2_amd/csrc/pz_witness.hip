@@ -173,7 +173,12 @@ struct CellPtr {
         return r;
     }
     __device__ __forceinline__ explicit operator bool() const { return base != nullptr; }
-    __device__ __forceinline__ Fr* addr() const { return base + idx + (rows ? (idx / rows) * pad : 0); }
+    __device__ __forceinline__ Fr* addr() const {
+        if (!rows) return base + idx;
+        // one division per cell: 32-bit whenever the stream has fewer than 2^32 cells (a 64-bit division is ~100 instructions)
+        const size_t col = ((idx | rows) >> 32) == 0 ? (size_t)((u32)idx / (u32)rows) : idx / rows;
+        return base + idx + col * pad;
+    }
 };
 __device__ __forceinline__ void fp_store(const CellPtr& p, const Fr& v) { fp_store(p.addr(), v); }
 
@@ -191,66 +196,86 @@ struct ExpP {
                                    // cell0 + (s / 2) * pair_stride + (s & 1) * odd_off instead of cell0 + s * cells
 };
 
+// A cell's value as an integer: +-m, or the field inverse of that.  The helpers below pick the VALUE of a cell (cheap integer
+// selects, even when the lanes of a wave sit at different positions of a pattern) and the caller converts it to Montgomery
+// form ONCE (cv_to_fr): with the conversion inside every switch arm a wave paid one Montgomery product per arm.
+struct CV {
+    U192 m;
+    bool neg, inv;
+};
+__device__ __forceinline__ CV cv_u(const U192& m) { return CV{m, false, false}; }
+__device__ __forceinline__ CV cv_s(const S192& v) { return CV{v.m, v.neg, false}; }
+__device__ __forceinline__ CV cv_inv(const S192& v) { return CV{v.m, v.neg, true}; }
+__device__ __forceinline__ CV cv_one() { return CV{u_make(1), false, false}; }
+__device__ __forceinline__ CV cv_zero() { return CV{u_make(0), false, false}; }
+__device__ __forceinline__ Fr cv_to_fr(const CV& c) {
+    Fr x = fr_from_u(c.m);
+    if (c.neg) x = fp_neg(x);
+    if (c.inv) x = fp_inv(x);   // is_zero's inverse cell of a non-zero difference: rare
+    return x;
+}
+
+
 // position p of RangeChip::range_check(x, bits): advice pattern
-__device__ __forceinline__ Fr rc_adv_cell(const U192& x, unsigned bits, unsigned lb, unsigned p) {
+__device__ __forceinline__ CV rc_adv_cell(const U192& x, unsigned bits, unsigned lb, unsigned p) {
     const unsigned k = (bits + lb - 1) / lb, rem = bits % lb;
     const unsigned body = k > 1 ? 1 + 3 * (k - 1) : 0;
     if (p < body) {
-        if (p == 0) return fr_from_u(u_lowbits(x, lb));
+        if (p == 0) return cv_u(u_lowbits(x, lb));
         const unsigned g = (p - 1) / 3 + 1, w = (p - 1) % 3;
-        if (w == 0) return fr_from_u(u_lowbits(u_shr(x, lb * g), lb));
-        if (w == 1) return fr_from_u(u_shl(u_make(1), lb * g));
-        return fr_from_u(u_lowbits(x, lb * (g + 1)));
+        if (w == 0) return cv_u(u_lowbits(u_shr(x, lb * g), lb));
+        if (w == 1) return cv_u(u_shl(u_make(1), lb * g));
+        return cv_u(u_lowbits(x, lb * (g + 1)));
     }
     const unsigned t = p - body;  // tail gate
     const U192 last = u_lowbits(u_shr(x, lb * (k - 1)), lb);
-    if (t == 0) return fp_zero<FrTag>();
-    if (rem == 1) return fr_from_u(last);
-    if (t == 1) return fr_from_u(last);
-    if (t == 2) return fr_from_u(u_make(1ull << (lb - rem)));
-    return fr_from_u(u_shl(last, lb - rem));
+    if (t == 0) return cv_zero();
+    if (rem == 1) return cv_u(last);
+    if (t == 1) return cv_u(last);
+    if (t == 2) return cv_u(u_make(1ull << (lb - rem)));
+    return cv_u(u_shl(last, lb - rem));
 }
-__device__ __forceinline__ Fr rc_lk_cell(const U192& x, unsigned bits, unsigned lb, unsigned p) {
+__device__ __forceinline__ CV rc_lk_cell(const U192& x, unsigned bits, unsigned lb, unsigned p) {
     const unsigned k = (bits + lb - 1) / lb, rem = bits % lb;
-    if (p < k) return fr_from_u(u_lowbits(u_shr(x, lb * p), lb));
-    return fr_from_u(u_shl(u_lowbits(u_shr(x, lb * (k - 1)), lb), lb - rem));
+    if (p < k) return cv_u(u_lowbits(u_shr(x, lb * p), lb));
+    return cv_u(u_shl(u_lowbits(u_shr(x, lb * (k - 1)), lb), lb - rem));
 }
 
 // 8-cell is_zero pattern on the (signed) difference d, then positions 0..11 of is_equal(x, y)
-__device__ __noinline__ Fr is_equal_cell(const U192& x, const U192& y, unsigned p) {
+__device__ __forceinline__ CV is_equal_cell(const U192& x, const U192& y, unsigned p) {
     S192 d = s_sub(x, y);
     const bool z = !d.neg && (d.m.w[0] | d.m.w[1] | d.m.w[2]) == 0;
     switch (p) {
-        case 0: return fr_from_s(d);
-        case 1: return fr_from_u(y);
-        case 2: return fp_one<FrTag>();
-        case 3: return fr_from_u(x);
-        case 4: return z ? fp_one<FrTag>() : fp_zero<FrTag>();
-        case 5: return fr_from_s(d);
-        case 6: return z ? fp_one<FrTag>() : fp_inv(fr_from_s(d));
-        case 7: return fp_one<FrTag>();
-        case 8: return fp_zero<FrTag>();
-        case 9: return fr_from_s(d);
-        case 10: return z ? fp_one<FrTag>() : fp_zero<FrTag>();
-        default: return fp_zero<FrTag>();
+        case 0: return cv_s(d);
+        case 1: return cv_u(y);
+        case 2: return cv_one();
+        case 3: return cv_u(x);
+        case 4: return z ? cv_one() : cv_zero();
+        case 5: return cv_s(d);
+        case 6: return z ? cv_one() : cv_inv(d);
+        case 7: return cv_one();
+        case 8: return cv_zero();
+        case 9: return cv_s(d);
+        case 10: return z ? cv_one() : cv_zero();
+        default: return cv_zero();
     }
 }
 // 22 cells of div_mod_unsafe(v, 2^W)
-__device__ __forceinline__ Fr div_mod_cell(const U192& v, unsigned p, unsigned W) {
+__device__ __forceinline__ CV div_mod_cell(const U192& v, unsigned p, unsigned W) {
     const U192 qd = u_shr(v, W);
     const U192 rd = u_lowbits(v, W);
     const U192 prod = u_shl(qd, W);
     switch (p) {
-        case 0: return fr_from_u(qd);
-        case 1: return fr_from_u(rd);
-        case 2: return fp_zero<FrTag>();
-        case 3: return fr_from_u(qd);
-        case 4: return fr_from_u(u_shl(u_make(1), W));
-        case 5: return fr_from_u(prod);
-        case 6: return fr_from_u(rd);  // v - prod
-        case 7: return fr_from_u(prod);
-        case 8: return fp_one<FrTag>();
-        case 9: return fr_from_u(v);
+        case 0: return cv_u(qd);
+        case 1: return cv_u(rd);
+        case 2: return cv_zero();
+        case 3: return cv_u(qd);
+        case 4: return cv_u(u_shl(u_make(1), W));
+        case 5: return cv_u(prod);
+        case 6: return cv_u(rd);  // v - prod
+        case 7: return cv_u(prod);
+        case 8: return cv_one();
+        case 9: return cv_u(v);
         default: return is_equal_cell(rd, rd, p - 10);
     }
 }
@@ -303,13 +328,16 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
         for (unsigned i = wave; i < D; i += EXP_THREADS / 64) {
             const size_t row = 1 + (size_t)i + 3 * ((size_t)i * (i + 1) / 2);
             // local inclusive prefix over this lane's PER terms
-            U192 pre[4];
+            U192 pre[4];      // PER <= 4 (D <= 2 * EXP_MAXL - 1): unrolled so that pre[] stays in registers
             U192 run = u_make(0);
-            for (unsigned t = 0; t < PER; ++t) {
-                const unsigned j = lane * PER + t;
-                U192 p = u_make(0);
-                if (j <= i && j < L && (i - j) < L) p = u_mul_limb(LIMB(xs, j), LIMB(ys, i - j), wide);
-                run = u_add(run, p);
+#pragma unroll
+            for (unsigned t = 0; t < 4; ++t) {
+                if (t < PER) {
+                    const unsigned j = lane * PER + t;
+                    U192 p = u_make(0);
+                    if (j <= i && j < L && (i - j) < L) p = u_mul_limb(LIMB(xs, j), LIMB(ys, i - j), wide);
+                    run = u_add(run, p);
+                }
                 pre[t] = run;
             }
             // wave inclusive scan of lane totals
@@ -325,9 +353,10 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
             bool dummy;
             const U192 excl = u_sub(tot, run, dummy);
             if (seg && lane == 0) fp_store(seg + row, fp_zero<FrTag>());
-            for (unsigned t = 0; t < PER; ++t) {
+#pragma unroll
+            for (unsigned t = 0; t < 4; ++t) {
                 const unsigned j = lane * PER + t;
-                if (j <= i) {
+                if (t < PER && j <= i) {
                     const U192 s = u_add(excl, pre[t]);
                     if (seg) {
                         const CellPtr c = seg + row + 1 + 3 * (size_t)j;
@@ -384,19 +413,19 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
         for (unsigned t = tid; t < 3 * per_int; t += EXP_THREADS) {
             const unsigned which = t / per_int, u = t % per_int;
             const u64(*X)[2] = which == 0 ? s_q : (which == 1 ? s_n : s_r);
-            Fr v;
-            if (u < L) v = fr_from_u(LIMB(X, u));
+            CV v;
+            if (u < L) v = cv_u(LIMB(X, u));
             else {
                 const unsigned i = (u - L) / P.rc64_adv, p = (u - L) % P.rc64_adv;
                 v = rc_adv_cell(LIMB(X, i), W, lb, p);
             }
-            if (adv) fp_store(adv + P.off_assign + t, v);
+            if (adv) fp_store(adv + P.off_assign + t, cv_to_fr(v));
         }
         if (lk)
             for (unsigned t = tid; t < 3 * L * P.rc64_lk; t += EXP_THREADS) {
                 const unsigned which = t / (L * P.rc64_lk), u = t % (L * P.rc64_lk);
                 const u64(*X)[2] = which == 0 ? s_q : (which == 1 ? s_n : s_r);
-                fp_store(lk + P.lk_assign + t, rc_lk_cell(LIMB(X, u / P.rc64_lk), W, lb, u % P.rc64_lk));
+                fp_store(lk + P.lk_assign + t, cv_to_fr(rc_lk_cell(LIMB(X, u / P.rc64_lk), W, lb, u % P.rc64_lk)));
             }
     }
     // ---- segment: qn + r
@@ -404,12 +433,12 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
         for (unsigned t = tid; t < 4 * L; t += EXP_THREADS) {
             const unsigned i = t / 4, p = t % 4;
             const U192 qn = u_make(s_pqn[i][0], s_pqn[i][1], s_pqn[i][2]);
-            Fr v;
-            if (p == 0) v = fr_from_u(qn);
-            else if (p == 1) v = fp_one<FrTag>();
-            else if (p == 2) v = fr_from_u(LIMB(s_r, i));
-            else v = fr_from_u(u_add(qn, LIMB(s_r, i)));
-            fp_store(adv + P.off_add + t, v);
+            CV v;
+            if (p == 0) v = cv_u(qn);
+            else if (p == 1) v = cv_one();
+            else if (p == 2) v = cv_u(LIMB(s_r, i));
+            else v = cv_u(u_add(qn, LIMB(s_r, i)));
+            fp_store(adv + P.off_add + t, cv_to_fr(v));
         }
     // ---- segment: is_equal_muled
     {
@@ -433,23 +462,23 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
             const S192 ssum = s_addu(dc, MAXV);
             const U192 tt = u_add(accx, MAXV);
             const U192 ncarry = u_make(s_carry[i + 1][0], s_carry[i + 1][1]);
-            Fr v;
+            CV v;
             if (p < 4) {
-                v = p == 0 ? fr_from_s(diff) : p == 1 ? fr_from_u(Bq) : p == 2 ? fp_one<FrTag>() : fr_from_u(A);
+                v = p == 0 ? cv_s(diff) : p == 1 ? cv_u(Bq) : p == 2 ? cv_one() : cv_u(A);
             } else if (p < 11) {
                 switch (p - 4) {
-                    case 0: v = fr_from_s(diff); break;
-                    case 1: v = fr_from_u(carry); break;
-                    case 2: v = fp_one<FrTag>(); break;
-                    case 3: v = fr_from_s(dc); break;
-                    case 4: v = fr_from_u(MAXV); break;
-                    case 5: v = fp_one<FrTag>(); break;
-                    default: v = fr_from_s(ssum); break;
+                    case 0: v = cv_s(diff); break;
+                    case 1: v = cv_u(carry); break;
+                    case 2: v = cv_one(); break;
+                    case 3: v = cv_s(dc); break;
+                    case 4: v = cv_u(MAXV); break;
+                    case 5: v = cv_one(); break;
+                    default: v = cv_s(ssum); break;
                 }
             } else if (p < 33) {
                 v = div_mod_cell(ssum.m, p - 11, W);
             } else if (p < 37) {
-                v = p == 33 ? fr_from_u(accx) : p == 34 ? fp_one<FrTag>() : p == 35 ? fr_from_u(MAXV) : fr_from_u(tt);
+                v = p == 33 ? cv_u(accx) : p == 34 ? cv_one() : p == 35 ? cv_u(MAXV) : cv_u(tt);
             } else if (p < 59) {
                 v = div_mod_cell(tt, p - 37, W);
             } else if (p < 71) {
@@ -457,8 +486,8 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
             } else if (p < 75) {
                 const unsigned e = u_eq(u_lowbits(ssum.m, W), u_lowbits(tt, W)) ? 1u : 0u;
                 const unsigned in = s_eqbit[i], out = s_eqbit[i + 1];
-                v = p == 71 ? fp_zero<FrTag>() : p == 72 ? (in ? fp_one<FrTag>() : fp_zero<FrTag>())
-                    : p == 73 ? (e ? fp_one<FrTag>() : fp_zero<FrTag>()) : (out ? fp_one<FrTag>() : fp_zero<FrTag>());
+                v = p == 71 ? cv_zero() : p == 72 ? (in ? cv_one() : cv_zero())
+                    : p == 73 ? (e ? cv_one() : cv_zero()) : (out ? cv_one() : cv_zero());
             } else if (i < D - 1) {
                 v = rc_adv_cell(ncarry, P.cb, lb, p - 75);
             } else {
@@ -468,16 +497,16 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
                     const unsigned e = u_eq(ncarry, qacc) ? 1u : 0u;
                     const unsigned in = s_eqbit[D], out = s_eqbit[D + 1];
                     const unsigned pp = p - 87;
-                    v = pp == 0 ? fp_zero<FrTag>() : pp == 1 ? (in ? fp_one<FrTag>() : fp_zero<FrTag>())
-                        : pp == 2 ? (e ? fp_one<FrTag>() : fp_zero<FrTag>()) : (out ? fp_one<FrTag>() : fp_zero<FrTag>());
+                    v = pp == 0 ? cv_zero() : pp == 1 ? (in ? cv_one() : cv_zero())
+                        : pp == 2 ? (e ? cv_one() : cv_zero()) : (out ? cv_one() : cv_zero());
                 }
             }
-            if (adv) fp_store(adv + P.off_eq + 2 + t, v);
+            if (adv) fp_store(adv + P.off_eq + 2 + t, cv_to_fr(v));
         }
         if (lk)
             for (unsigned t = tid; t < (D - 1) * P.rccb_lk; t += EXP_THREADS) {
                 const unsigned i = t / P.rccb_lk, p = t % P.rccb_lk;
-                fp_store(lk + P.lk_eq + t, rc_lk_cell(u_make(s_carry[i + 1][0], s_carry[i + 1][1]), P.cb, lb, p));
+                fp_store(lk + P.lk_eq + t, cv_to_fr(rc_lk_cell(u_make(s_carry[i + 1][0], s_carry[i + 1][1]), P.cb, lb, p)));
             }
     }
     // ---- segment: r < n
@@ -490,22 +519,22 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
             bool br;
             const U192 shift = u_sub(u_add(LIMB(s_r, i), BASE), nb, br);  // r_i - nb + 2^W
             const U192 outv = u_lowbits(shift, W);
-            Fr v;
+            CV v;
             switch (p) {
-                case 0: v = fr_from_u(LIMB(s_n, i)); break;
-                case 1: v = fp_one<FrTag>(); break;
-                case 2: v = borrow ? fp_one<FrTag>() : fp_zero<FrTag>(); break;
-                case 3: v = fr_from_u(nb); break;
-                case 4: v = fr_from_u(shift); break;
-                case 5: v = lt ? fp_one<FrTag>() : fp_zero<FrTag>(); break;
-                case 6: v = fr_from_u(outv); break;
-                case 7: v = fr_from_u(LIMB(s_r, i)); break;
-                case 8: v = lt ? fp_one<FrTag>() : fp_zero<FrTag>(); break;
-                case 9: v = fr_from_u(BASE); break;
-                case 10: v = fr_from_u(lt ? u_add(LIMB(s_r, i), BASE) : LIMB(s_r, i)); break;
+                case 0: v = cv_u(LIMB(s_n, i)); break;
+                case 1: v = cv_one(); break;
+                case 2: v = borrow ? cv_one() : cv_zero(); break;
+                case 3: v = cv_u(nb); break;
+                case 4: v = cv_u(shift); break;
+                case 5: v = lt ? cv_one() : cv_zero(); break;
+                case 6: v = cv_u(outv); break;
+                case 7: v = cv_u(LIMB(s_r, i)); break;
+                case 8: v = lt ? cv_one() : cv_zero(); break;
+                case 9: v = cv_u(BASE); break;
+                case 10: v = cv_u(lt ? u_add(LIMB(s_r, i), BASE) : LIMB(s_r, i)); break;
                 default: v = rc_adv_cell(outv, W, lb, p - 11); break;
             }
-            if (adv) fp_store(adv + P.off_lt + t, v);
+            if (adv) fp_store(adv + P.off_lt + t, cv_to_fr(v));
         }
         if (adv && tid == 0) fp_store(adv + P.off_lt + (size_t)L * per, s_borrow[L] ? fp_one<FrTag>() : fp_zero<FrTag>());
         if (lk)
@@ -513,7 +542,7 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
                 const unsigned i = t / P.rc64_lk, p = t % P.rc64_lk;
                 bool br;
                 const U192 shift = u_sub(u_add(LIMB(s_r, i), BASE), u_add(LIMB(s_n, i), u_make(s_borrow[i])), br);
-                fp_store(lk + P.lk_lt + t, rc_lk_cell(u_lowbits(shift, W), W, lb, p));
+                fp_store(lk + P.lk_lt + t, cv_to_fr(rc_lk_cell(u_lowbits(shift, W), W, lb, p)));
             }
     }
 }
@@ -729,11 +758,11 @@ __global__ __launch_bounds__(256) void k_circuit_misc(CircP C, const u64* __rest
         for (unsigned t = tid; t < nl * (1 + C.rc_adv); t += blockDim.x) {
             Fr v;
             if (t < nl) v = fr_from_u(LIMB(X, t));
-            else v = rc_adv_cell(LIMB(X, (t - nl) / C.rc_adv), W, lb, (t - nl) % C.rc_adv);
+            else v = cv_to_fr(rc_adv_cell(LIMB(X, (t - nl) / C.rc_adv), W, lb, (t - nl) % C.rc_adv));
             fp_store(a + t, v);
         }
         if (l)
-            for (unsigned t = tid; t < nl * C.rc_lk; t += blockDim.x) fp_store(l + t, rc_lk_cell(LIMB(X, t / C.rc_lk), W, lb, t % C.rc_lk));
+            for (unsigned t = tid; t < nl * C.rc_lk; t += blockDim.x) fp_store(l + t, cv_to_fr(rc_lk_cell(LIMB(X, t / C.rc_lk), W, lb, t % C.rc_lk)));
     }
     // ---- refresh
     if (tid == 0) fp_store(adv + C.a_refresh, fp_zero<FrTag>());
@@ -745,7 +774,7 @@ __global__ __launch_bounds__(256) void k_circuit_misc(CircP C, const u64* __rest
             if (p >= 22) { j = 1 + (p - 22) / 26; p = (p - 22) % 26; }
             const U192 v = u_make(s_dm[i][j][0], s_dm[i][j][1], s_dm[i][j][2]);
             Fr x;
-            if (p < 22) x = div_mod_cell(v, p, W);
+            if (p < 22) x = cv_to_fr(div_mod_cell(v, p, W));
             else {
                 const U192 before = u_make(s_ad[i][j][0], s_ad[i][j][1], s_ad[i][j][2]), nrem = u_lowbits(v, W);
                 x = p == 22 ? fr_from_u(before) : p == 23 ? fp_one<FrTag>() : p == 24 ? fr_from_u(nrem) : fr_from_u(u_add(before, nrem));
@@ -754,10 +783,10 @@ __global__ __launch_bounds__(256) void k_circuit_misc(CircP C, const u64* __rest
         }
     }
     for (unsigned t = tid; t < nf * C.rc_adv; t += blockDim.x)
-        fp_store(adv + C.a_refresh + s_roff[nf] + t, rc_adv_cell(LIMB(s_fresh, t / C.rc_adv), W, lb, t % C.rc_adv));
+        fp_store(adv + C.a_refresh + s_roff[nf] + t, cv_to_fr(rc_adv_cell(LIMB(s_fresh, t / C.rc_adv), W, lb, t % C.rc_adv)));
     if (lk)
         for (unsigned t = tid; t < nf * C.rc_lk; t += blockDim.x)
-            fp_store(lk + C.l_refresh + t, rc_lk_cell(LIMB(s_fresh, t / C.rc_lk), W, lb, t % C.rc_lk));
+            fp_store(lk + C.l_refresh + t, cv_to_fr(rc_lk_cell(LIMB(s_fresh, t / C.rc_lk), W, lb, t % C.rc_lk)));
     // ---- load_zero; assign_constant(1) + load_zero of both pow_mod_fixed_exp
     if (tid == 0) {
         fp_store(adv + C.a_zero, fp_zero<FrTag>());
@@ -773,7 +802,7 @@ __global__ __launch_bounds__(256) void k_circuit_misc(CircP C, const u64* __rest
     for (unsigned t = tid; t < 16 * nf; t += blockDim.x) {
         const unsigned i = t / 16, p = t % 16;
         Fr v;
-        if (p < 12) v = is_equal_cell(LIMB(s_c, i), LIMB(s_res, i), p);
+        if (p < 12) v = cv_to_fr(is_equal_cell(LIMB(s_c, i), LIMB(s_res, i), p));
         else {
             const unsigned e = u_eq(LIMB(s_c, i), LIMB(s_res, i)) ? 1u : 0u, in = s_eq[i], out = s_eq[i + 1];
             v = p == 12 ? fp_zero<FrTag>() : p == 13 ? (in ? fp_one<FrTag>() : fp_zero<FrTag>())
