@@ -54,6 +54,8 @@ struct pz_ctx {
     double ev_ms[PZ_T_COUNT] = {0};
     uint64_t ev_n[PZ_T_COUNT] = {0};
     int cu_count = 256;
+    size_t mem_avail = 0;      // (free + held) / 2 as last queried by pz_msm_g1_dev; hipMemGetInfo drains the queue on ROCm,
+    unsigned mem_avail_age = 0; // so it is asked again only every 64 calls
     // host-pointer entry points (pz_msm_g1_batch, pz_ntt_fr_batch): copy engines of their own, so that the PCIe transfers
     // of the next / previous column group run beside the kernels of the current one (pz_io_init creates them on first use)
     hipStream_t io_h2d = nullptr, io_d2h = nullptr;
