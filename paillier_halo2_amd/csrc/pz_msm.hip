@@ -40,6 +40,7 @@ struct MsmP {
     size_t cap;        // entry capacity per column = n * (win_hi - win_lo)
     size_t max_items;  // work items per column (upper bound) = B + cap / chunk
     unsigned chunk;    // entries per work item, MSM_CHUNK_MIN..MSM_CHUNK_MAX
+    unsigned spt;      // scalars per thread of the sort passes: a slice is SORT_THREADS * spt scalars (msm_spt_for)
 };
 
 __device__ __forceinline__ u32 sel8(const u32 s[8], unsigned i) {
@@ -141,23 +142,21 @@ __global__ __launch_bounds__(128) void k_build_table(const G1Aff64* __restrict__
 #ifndef PZ_SORT_XCD
 #define PZ_SORT_XCD 1
 #endif
+// Fewer than 8 columns keep the plain order: their slices must spread over all XCDs, not fill one.
 __device__ __forceinline__ bool sort_block_coords(unsigned n_slices, size_t n_cols, unsigned& slice, size_t& col) {
-#if PZ_SORT_XCD
-    const unsigned w = blockIdx.x >> 3;
-    slice = w % n_slices;
-    col = (size_t)(w / n_slices) * 8 + (blockIdx.x & 7u);
-#else
-    slice = blockIdx.x % n_slices;
-    col = blockIdx.x / n_slices;
-#endif
+    if (PZ_SORT_XCD && n_cols >= 8) {
+        const unsigned w = blockIdx.x >> 3;
+        slice = w % n_slices;
+        col = (size_t)(w / n_slices) * 8 + (blockIdx.x & 7u);
+    } else {
+        slice = blockIdx.x % n_slices;
+        col = blockIdx.x / n_slices;
+    }
     return col < n_cols;
 }
 static unsigned sort_grid(unsigned n_slices, size_t n_cols) {
-#if PZ_SORT_XCD
-    return n_slices * (unsigned)((n_cols + 7) / 8 * 8);
-#else
+    if (PZ_SORT_XCD && n_cols >= 8) return n_slices * (unsigned)((n_cols + 7) / 8 * 8);
     return n_slices * (unsigned)n_cols;
-#endif
 }
 
 __global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(const Fr* __restrict__ scalars, size_t col_stride, MsmP p,
@@ -168,8 +167,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(const Fr* __restrict_
     if (!sort_block_coords(n_slices, n_cols, slice, col)) return;
     for (unsigned b = threadIdx.x; b < p.B; b += SORT_THREADS) h[b] = 0;
     __syncthreads();
-    const size_t base = (size_t)slice * SORT_SLICE;
-    for (unsigned t = 0; t < SORT_PER_THREAD; ++t) {
+    const size_t base = (size_t)slice * SORT_THREADS * p.spt;
+    for (unsigned t = 0; t < p.spt; ++t) {
         const size_t i = base + (size_t)t * SORT_THREADS + threadIdx.x;
         if (i >= p.n) break;
         u32 s[8];
@@ -212,7 +211,18 @@ __global__ __launch_bounds__(256) void k_msm_totals(u32* __restrict__ slice_hist
     if (b >= p.B) return;
     u32* sh = slice_hist + col * n_slices * (size_t)p.B + b;
     u32 run = 0;
-    for (unsigned sl = 0; sl < n_slices; ++sl) {
+    unsigned sl = 0;
+    for (; sl + 8 <= n_slices; sl += 8) {   // eight loads in flight: a single column is cut into hundreds of slices
+        u32 v[8];
+#pragma unroll
+        for (unsigned k = 0; k < 8; ++k) v[k] = sh[(size_t)(sl + k) * p.B];
+#pragma unroll
+        for (unsigned k = 0; k < 8; ++k) {
+            sh[(size_t)(sl + k) * p.B] = run;
+            run += v[k];
+        }
+    }
+    for (; sl < n_slices; ++sl) {
         const u32 v = sh[(size_t)sl * p.B];
         sh[(size_t)sl * p.B] = run;
         run += v;
@@ -225,7 +235,8 @@ __global__ __launch_bounds__(256) void k_msm_totals(u32* __restrict__ slice_hist
 __global__ __launch_bounds__(SCAN_THREADS) void k_msm_scan(const u32* __restrict__ hist, MsmP p, u32* __restrict__ offs,
                                                   u32* __restrict__ items, u32* __restrict__ heavy,
                                                   u32* __restrict__ heavy_cnt, u32* __restrict__ fold_order,
-                                                  u32* __restrict__ fold_cnt, u32* __restrict__ item_order,
+                                                  u32* __restrict__ fold_cnt, u32* __restrict__ pos_hi,
+                                                  u32* __restrict__ pos_lo, u32* __restrict__ item_order,
                                                   u32* __restrict__ item_bucket) {
     __shared__ u32 s_cnt[SCAN_THREADS], s_itm[SCAN_THREADS];
     __shared__ u32 s_heavy;
@@ -239,13 +250,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_msm_scan(const u32* __restrict
     const u32* h = hist + col * p.B;
     u32* o = offs + col * (p.B + 1);
     u32* it = items + col * (p.B + 1);
-    const unsigned per = (p.B + SCAN_THREADS - 1) / SCAN_THREADS;
+    const unsigned per = (p.B + SCAN_THREADS - 1) / SCAN_THREADS;   // <= 32 (B <= 2^15)
     const unsigned lo = threadIdx.x * per;
+    // this thread's bucket totals, all loads in flight at once (a loop that waits for each one costs `per` round trips, twice)
+    u32 hv[32];
+#pragma unroll
+    for (unsigned k = 0; k < 32; ++k) hv[k] = (k < per && lo + k < p.B) ? h[lo + k] : 0u;
     u32 c = 0, m = 0;
-    for (unsigned k = 0; k < per; ++k) {
-        unsigned b = lo + k;
-        if (b < p.B) {
-            u32 v = h[b];
+#pragma unroll
+    for (unsigned k = 0; k < 32; ++k) {
+        const unsigned b = lo + k;
+        if (k < per && b < p.B) {
+            const u32 v = hv[k];
             c += v;
             const u32 ch = (v + p.chunk - 1) / p.chunk;
             m += ch;
@@ -261,18 +277,27 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_msm_scan(const u32* __restrict
     s_cnt[threadIdx.x] = c;
     s_itm[threadIdx.x] = m;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        u32 a = 0, b2 = 0;
-        for (int k = 0; k < SCAN_THREADS; ++k) {
-            u32 t = s_cnt[k];
-            s_cnt[k] = a;
-            a += t;
-            u32 t2 = s_itm[k];
-            s_itm[k] = b2;
-            b2 += t2;
+    {   // exclusive scan of the per-thread sums over the workgroup: wave scans, then the 16 wave totals
+        __shared__ u32 s_wc[SCAN_THREADS / 64], s_wm[SCAN_THREADS / 64];
+        const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        u32 ic = c, im = m;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 tc = __shfl_up(ic, off, 64), tm = __shfl_up(im, off, 64);
+            if (lane >= (unsigned)off) { ic += tc; im += tm; }
         }
-        o[p.B] = a;
-        it[p.B] = b2;
+        if (lane == 63) { s_wc[wv] = ic; s_wm[wv] = im; }
+        __syncthreads();
+        u32 bc = 0, bm = 0;
+        for (unsigned k = 0; k < wv; ++k) { bc += s_wc[k]; bm += s_wm[k]; }
+        s_cnt[threadIdx.x] = bc + ic - c;
+        s_itm[threadIdx.x] = bm + im - m;
+        if (threadIdx.x == SCAN_THREADS - 1) {
+            o[p.B] = bc + ic;
+            it[p.B] = bm + im;
+        }
+    }
+    if (threadIdx.x == 0) {
         heavy_cnt[col] = s_heavy;
         // buckets with 2..MSM_HEAVY chunks, ordered by chunk count (largest first): the fold kernel's lanes
         // then run equal trip counts within a wave
@@ -295,10 +320,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_msm_scan(const u32* __restrict
     __syncthreads();
     c = s_cnt[threadIdx.x];
     m = s_itm[threadIdx.x];
-    for (unsigned k = 0; k < per; ++k) {
-        unsigned b = lo + k;
-        if (b < p.B) {
-            u32 v = h[b];
+#pragma unroll
+    for (unsigned k = 0; k < 32; ++k) {
+        const unsigned b = lo + k;
+        if (k < per && b < p.B) {
+            const u32 v = hv[k];
             o[b] = c;
             it[b] = m;
             c += v;
@@ -306,23 +332,68 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_msm_scan(const u32* __restrict
             m += ch;
             if (ch > 1 && ch <= MSM_HEAVY) fold_order[col * p.B + s_base[ch] + atomicAdd(&s_bin[ch], 1u)] = b;
             if (ch) {
+                // where this bucket's work items go in the size-ordered list: its `rem` chunks of q + 1 entries and its
+                // ch - rem chunks of q entries (k_msm_items writes the list: half a million scattered stores for one
+                // 2^19-point column are too many for the single workgroup this kernel is)
                 const u32 q = v / ch, rem = v % ch;
-                const u32 item0 = m - ch;  // this bucket's first work item
-                u32* ord = item_order + col * p.max_items;
-                u32* obk = item_bucket + col * p.max_items;
-                if (rem) {
-                    const u32 pos = s_obase[q + 1] + atomicAdd(&s_obin[q + 1], rem);
-                    for (u32 j = 0; j < rem; ++j) {
-                        ord[pos + j] = item0 + j;
-                        obk[pos + j] = b;
+                const u32 ph = rem ? s_obase[q + 1] + atomicAdd(&s_obin[q + 1], rem) : 0u;
+                const u32 pl = s_obase[q] + atomicAdd(&s_obin[q], ch - rem);
+                if (pos_hi) {   // few columns: the list is written by k_msm_items
+                    pos_hi[col * p.B + b] = ph;
+                    pos_lo[col * p.B + b] = pl;
+                } else {        // column batches: one workgroup per column is parallel enough, write it here
+                    const u32 item0 = m - ch;
+                    u32* ord = item_order + col * p.max_items;
+                    u32* obk = item_bucket + col * p.max_items;
+                    for (u32 j = 0; j < ch; ++j) {
+                        const u32 pos = j < rem ? ph + j : pl + j - rem;
+                        ord[pos] = item0 + j;
+                        obk[pos] = b;
                     }
                 }
-                const u32 pos = s_obase[q] + atomicAdd(&s_obin[q], ch - rem);
-                for (u32 j = rem; j < ch; ++j) {
-                    ord[pos + j - rem] = item0 + j;
-                    obk[pos + j - rem] = b;
-                }
             }
+        }
+    }
+}
+
+// the size-ordered work item list of k_msm_accumulate: item_order[rank] = work item, item_bucket[rank] = its bucket.
+// grid (B / 256, columns): a thread per bucket; buckets with many chunks are shared by the whole workgroup afterwards
+#define ITEMS_SOLO 64u
+__global__ __launch_bounds__(256) void k_msm_items(MsmP p, const u32* __restrict__ offs, const u32* __restrict__ items,
+                                                   const u32* __restrict__ pos_hi, const u32* __restrict__ pos_lo,
+                                                   u32* __restrict__ item_order, u32* __restrict__ item_bucket) {
+    __shared__ u32 s_big[256];
+    __shared__ u32 s_nbig;
+    if (threadIdx.x == 0) s_nbig = 0;
+    __syncthreads();
+    const size_t col = blockIdx.y;
+    const u32* o = offs + col * (p.B + 1);
+    const u32* it = items + col * (p.B + 1);
+    u32* ord = item_order + col * p.max_items;
+    u32* obk = item_bucket + col * p.max_items;
+    const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < p.B) {
+        const u32 ch = it[b + 1] - it[b];
+        if (ch > ITEMS_SOLO) s_big[atomicAdd(&s_nbig, 1u)] = b;
+        else if (ch) {
+            const u32 v = o[b + 1] - o[b], rem = v % ch, item0 = it[b];
+            const u32 ph = pos_hi[col * p.B + b], pl = pos_lo[col * p.B + b];
+            for (u32 j = 0; j < ch; ++j) {
+                const u32 pos = j < rem ? ph + j : pl + j - rem;
+                ord[pos] = item0 + j;
+                obk[pos] = b;
+            }
+        }
+    }
+    __syncthreads();
+    for (unsigned k = 0; k < s_nbig; ++k) {
+        const unsigned bb = s_big[k];
+        const u32 ch = it[bb + 1] - it[bb], v = o[bb + 1] - o[bb], rem = v % ch, item0 = it[bb];
+        const u32 ph = pos_hi[col * p.B + bb], pl = pos_lo[col * p.B + bb];
+        for (u32 j = threadIdx.x; j < ch; j += blockDim.x) {
+            const u32 pos = j < rem ? ph + j : pl + j - rem;
+            ord[pos] = item0 + j;
+            obk[pos] = bb;
         }
     }
 }
@@ -336,11 +407,26 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restri
     if (!sort_block_coords(n_slices, n_cols, slice, col)) return;
     const u32* in = slice_hist + (col * n_slices + slice) * (size_t)p.B;
     const u32* o = offs + col * (p.B + 1);
-    for (unsigned b = threadIdx.x; b < p.B; b += SORT_THREADS) h[b] = o[b] + in[b];
+    // eight buckets per thread in flight (a plain loop waited for each pair of loads: 32 round trips per workgroup, the
+    // whole cost of the pass for a single column cut into many slices)
+    for (unsigned b0 = threadIdx.x; b0 < p.B; b0 += 8 * SORT_THREADS) {
+        u32 va[8], vb[8];
+#pragma unroll
+        for (unsigned k = 0; k < 8; ++k) {
+            const unsigned b = b0 + k * SORT_THREADS, bc = b < p.B ? b : p.B - 1;
+            va[k] = o[bc];
+            vb[k] = in[bc];
+        }
+#pragma unroll
+        for (unsigned k = 0; k < 8; ++k) {
+            const unsigned b = b0 + k * SORT_THREADS;
+            if (b < p.B) h[b] = va[k] + vb[k];
+        }
+    }
     __syncthreads();
     u32* e = entries + col * p.cap;
-    const size_t base = (size_t)slice * SORT_SLICE;
-    for (unsigned t = 0; t < SORT_PER_THREAD; ++t) {
+    const size_t base = (size_t)slice * SORT_THREADS * p.spt;
+    for (unsigned t = 0; t < p.spt; ++t) {
         const size_t i = base + (size_t)t * SORT_THREADS + threadIdx.x;
         if (i >= p.n) break;
         u32 s[8];
@@ -853,6 +939,15 @@ static unsigned msm_chunk_for(size_t n_cols, size_t digits_per_col) {
     return chunk;
 }
 
+// Scalars per thread of the sort passes.  A slice costs its workgroup ~0.4 MB of fixed traffic (zeroing / loading / storing
+// the 2^15 bucket counters), so slices are as large as SORT_PER_THREAD allows -- unless that leaves fewer workgroups than
+// CUs: a single 2^19-point column in 64 slices kept 3/4 of the chip idle through both passes.
+static unsigned msm_spt_for(size_t n_cols, size_t n) {
+    unsigned spt = SORT_PER_THREAD;
+    while (spt > 1 && n_cols * pz_div_up(n, (size_t)SORT_THREADS * spt) < 512) spt >>= 1;
+    return spt;
+}
+
 static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, size_t nc, size_t n, size_t cs,
                      unsigned win_lo, unsigned win_hi, unsigned chunk, G1Jac* d_out) {
     MsmP p;
@@ -868,10 +963,15 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     if (p.B + n * (size_t)(win_hi - win_lo) / chunk > 65535u * 256u) return PZ_ERR_CAPACITY;  // grid.y of k_msm_accumulate
     p.max_items = p.B + p.cap / chunk;
     void *hist, *offs, *heavy, *items, *entries, *partials, *na, *nb, *totals, *fold, *iord;
-    const unsigned n_slices = pz_div_up(n, SORT_SLICE);
+    p.spt = msm_spt_for(nc, n);
+    const unsigned n_slices = pz_div_up(n, (size_t)SORT_THREADS * p.spt);
     PZCHK(pz_ws_get(ctx, WS_HIST, nc * (size_t)n_slices * p.B * 4, &hist));
     PZCHK(pz_ws_get(ctx, WS_CURSOR, nc * (size_t)(p.B + 1) * 4, &heavy));
-    PZCHK(pz_ws_get(ctx, WS_TOTALS, nc * p.B * 4, &totals));
+    // few columns: k_msm_scan (one workgroup per column) leaves the work item list to k_msm_items
+    const bool split_items = nc <= MSM_SLICE_MAX_COLS;
+    PZCHK(pz_ws_get(ctx, WS_TOTALS, (split_items ? 3 : 1) * nc * (size_t)p.B * 4, &totals));   // bucket totals | pos_hi | pos_lo
+    u32* pos_hi = (u32*)totals + nc * (size_t)p.B;
+    u32* pos_lo = pos_hi + nc * (size_t)p.B;
     u32* heavy_cnt = (u32*)heavy + nc * (size_t)p.B;
     PZCHK(pz_ws_get(ctx, WS_MISC, nc * (size_t)(p.B + 1) * 4, &fold));
     u32* fold_cnt = (u32*)fold + nc * (size_t)p.B;
@@ -896,7 +996,10 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
         hipLaunchKernelGGL(k_msm_totals, dim3(pz_div_up(p.B, 256), (unsigned)nc), dim3(256), 0, st, (u32*)hist, n_slices, p,
                            (u32*)totals);
         hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)nc), dim3(SCAN_THREADS), 0, st, (const u32*)totals, p, (u32*)offs, (u32*)items,
-                           (u32*)heavy, heavy_cnt, (u32*)fold, fold_cnt, item_order, item_bucket);
+                           (u32*)heavy, heavy_cnt, (u32*)fold, fold_cnt, split_items ? pos_hi : nullptr, pos_lo, item_order, item_bucket);
+        if (split_items)
+            hipLaunchKernelGGL(k_msm_items, dim3(pz_div_up(p.B, 256), (unsigned)nc), dim3(256), 0, st, p, (const u32*)offs,
+                               (const u32*)items, (const u32*)pos_hi, (const u32*)pos_lo, item_order, item_bucket);
         hipLaunchKernelGGL(k_msm_scatter, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (const u32*)hist, n_slices,
                            (const u32*)offs, (u32*)entries, nc);
     }
@@ -987,7 +1090,7 @@ extern "C" int pz_msm_g1_dev(pz_ctx* ctx, const pz_bases* bases, const uint64_t*
     const size_t digits = n * (size_t)(win_hi - win_lo);
     const unsigned chunk = msm_chunk_for(n_cols, digits);
     const size_t per_col = digits * 4 + (digits / chunk) * (sizeof(G1X29Raw) + 8) +
-                           (size_t)(1u << (bases->c - 1)) * (180 + 4 * (size_t)pz_div_up(n, SORT_SLICE));
+                           (size_t)(1u << (bases->c - 1)) * (180 + 4 * (size_t)pz_div_up(n, (size_t)SORT_THREADS * msm_spt_for(n_cols, n)));
     // group size: sized for 288 GB of HBM -- by default up to 48 GiB of sort / partial-sum workspace per launch
     // sequence (PZ_MSM_WS_GIB overrides), so the latency-bound tree levels are paid once per ~2000 columns
     size_t ws_budget = pz_msm_ws_gib() << 30;
