@@ -219,7 +219,8 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
 template <bool PRE>
 __global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, size_t in_stride, size_t out_stride,
                                                        NttPass p, const Fr* __restrict__ tw,
-                                                       const Fr* __restrict__ pre) {
+                                                       const Fr* __restrict__ pre0, unsigned n_r, size_t pre_r_stride,
+                                                       size_t out_r_stride) {
     u32* sm = reinterpret_cast<u32*>(pz_smem);
     const unsigned R = 1u << p.logR, T = p.T;
     const unsigned logT = 31u - (unsigned)__builtin_clz(T);
@@ -234,6 +235,13 @@ __global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, si
     // global loads are issued NTT_LB elements at a time before anything waits on them (one exposed memory round trip per
     // batch instead of two per element: the load, then the pre-scale table row)
     const unsigned nelem = R * T;
+    // n_r > 1: the first pass of the coset-extended transform -- the SAME input tile, pre-scaled by n_r different tables
+    // (one per coset) into n_r outputs; the tile is re-read from L2, not from HBM, and one launch does the work of n_r
+    Fr* const dst0 = dst;
+    for (unsigned rr = 0; rr < n_r; ++rr) {
+    const Fr* __restrict__ pre = pre0 + (size_t)rr * pre_r_stride;
+    dst = dst0 + (size_t)rr * out_r_stride;
+    if (rr) NTT_SYNC();   // the previous coset's stores have read the tile
     for (unsigned i0 = 0; i0 < nelem; i0 += NTT_LB * 256u) {
         Fr raw[NTT_LB], praw[NTT_LB];
 #pragma unroll
@@ -272,6 +280,7 @@ __global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, si
                 DATA_STORE(1, dst + base + (size_t)kk * p.lo + t, x);
             }
         }
+    }
     }
 }
 
@@ -424,13 +433,13 @@ static const uint64_t* one261() {
 }
 
 static int launch_strided(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t os, size_t ncols, NttPass p,
-                          const Fr* tw, const Fr* pre) {
+                          const Fr* tw, const Fr* pre, unsigned n_r = 1, size_t pre_r_stride = 0, size_t out_r_stride = 0) {
     size_t blocks = p.hi * (p.lo / p.T);
     size_t lds = ntt29_lds_bytes(((size_t)1 << p.logR) * p.T);
     p.swap = (ncols > 1 && blocks <= 65535) ? 1u : 0u;
     const dim3 grid = p.swap ? dim3((unsigned)ncols, (unsigned)blocks) : dim3((unsigned)blocks, (unsigned)ncols);
-    if (pre) hipLaunchKernelGGL(k_ntt_strided29<true>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre);
-    else hipLaunchKernelGGL(k_ntt_strided29<false>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre);
+    if (pre) hipLaunchKernelGGL(k_ntt_strided29<true>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, n_r, pre_r_stride, out_r_stride);
+    else hipLaunchKernelGGL(k_ntt_strided29<false>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, n_r, pre_r_stride, out_r_stride);
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
 }
@@ -603,10 +612,9 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
             pa.logR = lg[0]; pa.lo = n2 * n3; pa.hi = 1; pa.tw_mul = 1; pa.n = n; pa.T = pick_tile(n2 * n3, lg[0]);
             NttPass pb{};
             pb.logR = lg[1]; pb.lo = n3; pb.hi = n1; pb.tw_mul = n1; pb.n = n; pb.T = pick_tile(n3, lg[1]);
-            for (size_t r = 0; r < E; ++r) {  // tmp layout [r][col][n]
-                PZCHK(launch_strided(ctx, cin + c0 * is, tmp + r * nc * n, is, n, nc, pa, tw, pre + r * n));
-                PZCHK(launch_strided(ctx, tmp + r * nc * n, tmp + r * nc * n, n, n, nc, pb, tw, nullptr));
-            }
+            // tmp layout [r][col][n]: all cosets of the first pass in one launch, then the E * nc intermediate columns together
+            PZCHK(launch_strided(ctx, cin + c0 * is, tmp, is, n, nc, pa, tw, pre, (unsigned)E, n, nc * n));
+            PZCHK(launch_strided(ctx, tmp, tmp, n, n, E * nc, pb, tw, nullptr));
             NttPass pc{};
             pc.logR = lg[2]; pc.lo = 1; pc.hi = n1 * n2; pc.n = n; pc.n1 = n1; pc.n2 = n2;
             unsigned T = 8;
@@ -621,8 +629,8 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
             const size_t n1 = (size_t)1 << lg0, n2 = (size_t)1 << lg1;
             NttPass pa{};
             pa.logR = lg0; pa.lo = n2; pa.hi = 1; pa.tw_mul = 1; pa.n = n; pa.T = pick_tile(n2, lg0);
-            for (size_t r = 0; r < E; ++r)  // tmp layout [r][col][n]
-                PZCHK(launch_strided(ctx, cin + c0 * is, tmp + r * nc * n, is, n, nc, pa, tw, pre + r * n));
+            // all cosets in one launch: tmp layout [r][col][n]
+            PZCHK(launch_strided(ctx, cin + c0 * is, tmp, is, n, nc, pa, tw, pre, (unsigned)E, n, nc * n));
             NttPass pc{};
             pc.logR = lg1; pc.lo = 1; pc.hi = n1; pc.n = n; pc.n1 = n1; pc.n2 = 1;
             // 32 KiB of LDS per block (4 blocks per CU): with 2^e = 4 interleaved outputs a single row already
