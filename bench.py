@@ -362,7 +362,13 @@ class ProofWorkload:
         T["d_sh"] = t.zeros((2, n, 4), dtype=t.int64, device=dev)
         T["d_sh_out"] = t.zeros((2, 12), dtype=t.int64, device=dev)
         T["m_perm"] = sh.advice_cols + sh.lookup_cols + 1
-        T["n_evals"] = 5 * sh.advice_cols + 5 * sh.lookup_cols + 3 * sh.perm_cols + T["m_perm"]   # advice at 4 rotations + selector, ...
+        # advice at 4 rotations, its selector at x; per lookup: the permuted input at {x, w^-1 x}, the permuted table at x, the product at
+        # {x, wx}; permutation products at {x, wx, w^last x}; sigma polynomials at x
+        T["eval_classes"] = [(sh.advice_cols, [0, 1, 2, 3]), (sh.advice_cols, [0]), (sh.lookup_cols, [0, 4]), (sh.lookup_cols, [0]),
+                             (sh.lookup_cols, [0, 1]), (sh.perm_cols, [0, 1, 5]), (T["m_perm"], [0])]
+        T["n_evals"] = sum(c_ * len(p_) for c_, p_ in T["eval_classes"])
+        assert T["n_evals"] == 5 * sh.advice_cols + 5 * sh.lookup_cols + 3 * sh.perm_cols + T["m_perm"]
+        T["d_ev"] = t.zeros((self.pool, 4, 4), dtype=t.int64, device=dev)
         t.cuda.synchronize()
         self._tail = T
         return T
@@ -420,11 +426,14 @@ class ProofWorkload:
 
     def tail_evals(self):
         eng, T, n = self.eng, self._tail, self.n
-        done = 0
-        while done < T["n_evals"]:
-            nc = min(self.pool, T["n_evals"] - done)
-            eng.poly_eval_dev(self.col_f.data_ptr(), nc, 4 * n, n, T["ch"][3], T["d_ev"].data_ptr())
-            done += nc
+        # every committed polynomial at its rotation set, one pass over the coefficients per polynomial (pz_poly_eval_multi_dev):
+        # (count, points) classes as in halo2's evals phase; together T["n_evals"] point evaluations
+        for cnt, pts in T["eval_classes"]:
+            done = 0
+            while done < cnt:
+                nc = min(self.pool, cnt - done)
+                eng.poly_eval_multi_dev(self.col_f.data_ptr(), nc, 4 * n, n, T["sh_points"][pts], T["d_ev"].data_ptr())
+                done += nc
         # SHPLONK (halo2 multiopen): every polynomial of the proof in its rotation set -- fixed / selector / sigma columns at
         # {x}; advice at {x, wx, w^2 x, w^3 x} (the vertical gate's rotations); lookup polynomials at {x, wx, w^-1 x};
         # permutation products at {x, wx, w^last x} -- folded into the two final polynomials, each committed (pool

@@ -272,6 +272,10 @@ int pz_g1_check_dev(pz_ctx* ctx, const uint64_t* d_points, size_t n, uint64_t* n
  * d_out[col] = sum_i d_coeffs[col][i] * x^i   (the evals phase of create_proof / eval_polynomial). */
 int pz_poly_eval_dev(pz_ctx* ctx, const uint64_t* d_coeffs, size_t n_cols, size_t col_stride, size_t n,
                      const uint64_t x[4], uint64_t* d_out);
+/* the same at 1..4 points in one pass over the coefficients (a polynomial's rotation set x, omega x, ...):
+ * xs = n_points x 4 words, d_out[col][point].  Identical values to n_points calls of pz_poly_eval_dev. */
+int pz_poly_eval_multi_dev(pz_ctx* ctx, const uint64_t* d_coeffs, size_t n_cols, size_t col_stride, size_t n,
+                           const uint64_t* xs, uint32_t n_points, uint64_t* d_out);
 
 /* The prover steps between the commitments and the NTTs (in the reference all of
  * them run inside create_proof, reached from /root/reference/src/bench.rs:161-171).  Device pointers throughout, field

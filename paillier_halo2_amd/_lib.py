@@ -67,6 +67,7 @@ SIGNATURES = {
     "pz_permutation_sigma_dev": (C.c_int, [VP, VP, VP, C.c_size_t, C.c_uint32, VP, VP, VP, C.c_size_t]),
     "pz_keygen_columns_dev": (C.c_int, [VP, VP, VP, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, VP, VP, VP, VP, VP, VP, C.c_size_t]),
     "pz_poly_eval_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, C.c_size_t, VP, VP]),
+    "pz_poly_eval_multi_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, C.c_size_t, VP, C.c_uint32, VP]),
     "pz_g1_check_dev": (C.c_int, [VP, VP, C.c_size_t, C.POINTER(C.c_uint64)]),
     "pz_fr_batch_invert_dev": (C.c_int, [VP, VP, C.c_size_t]),
     "pz_fr_prefix_product_dev": (C.c_int, [VP, VP, C.c_size_t, VP, VP]),

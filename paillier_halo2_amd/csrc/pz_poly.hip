@@ -126,6 +126,79 @@ extern "C" int pz_poly_eval_dev(pz_ctx* ctx, const uint64_t* d_coeffs, size_t n_
     return PZ_OK;
 }
 
+// The same at up to four points at once -- a polynomial's rotation set {x, wx, w^2 x, ...} (halo2 evaluates every advice
+// polynomial at each rotation its gates query): the coefficient is read ONCE and multiplied into P accumulators, against P
+// cached power tables.  One point at a time the evaluations of a c2 proof read 98 GB of coefficients; this way 20 GB.
+template <unsigned P>
+__global__ __launch_bounds__(256) void k_poly_eval_partial_multi(const Fr* __restrict__ coeffs, size_t col_stride, size_t n,
+                                                                 const Fr* __restrict__ xp0, const Fr* __restrict__ xp1,
+                                                                 const Fr* __restrict__ xp2, const Fr* __restrict__ xp3,
+                                                                 Fr* __restrict__ partial, unsigned blocks_per_col) {
+    __shared__ Fr s_acc[256];
+    const size_t col = blockIdx.y;
+    const Fr* c = coeffs + col * col_stride;
+    const Fr* xp[4] = {xp0, xp1, xp2, xp3};
+    const size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * EVAL_CH;
+    Fr acc[P];
+#pragma unroll
+    for (unsigned q = 0; q < P; ++q) acc[q] = fp_zero<FrTag>();
+    for (unsigned t = 0; t < EVAL_CH; ++t) {
+        const size_t i = base + t;
+        if (i < n) {
+            const Fr v = fp_load<FrTag>(c + i);
+#pragma unroll
+            for (unsigned q = 0; q < P; ++q) acc[q] = fp_add(acc[q], fp_mul(v, fp_load<FrTag>(xp[q] + i)));
+        }
+    }
+#pragma unroll
+    for (unsigned q = 0; q < P; ++q) {
+        s_acc[threadIdx.x] = acc[q];
+        __syncthreads();
+        for (unsigned off = 128; off > 0; off >>= 1) {
+            if (threadIdx.x < off) s_acc[threadIdx.x] = fp_add(s_acc[threadIdx.x], s_acc[threadIdx.x + off]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) fp_store(partial + ((col * P + q) * blocks_per_col) + blockIdx.x, s_acc[0]);
+        __syncthreads();
+    }
+}
+
+extern "C" int pz_poly_eval_multi_dev(pz_ctx* ctx, const uint64_t* d_coeffs, size_t n_cols, size_t col_stride, size_t n,
+                                      const uint64_t* xs, uint32_t n_points, uint64_t* d_out) {
+    if (!ctx || !xs || n_points == 0 || n_points > 4 || (n_cols && (!d_coeffs || !d_out)) || col_stride % 4 ||
+        (n_cols > 1 && col_stride < 4 * n))
+        return PZ_ERR_INVALID;
+    if (n_cols == 0) return PZ_OK;
+    if (n_cols > 65535) return PZ_ERR_INVALID;
+    PZ_ENTER(ctx);
+    if (n == 0) {
+        HIPCHK(ctx, hipMemsetAsync(d_out, 0, n_cols * (size_t)n_points * 32, ctx->stream));
+        return PZ_OK;
+    }
+    void* xp[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (uint32_t q = 0; q < n_points; ++q) PZCHK(pz_get_pow_table(ctx, xs + 4 * q, n, &xp[q]));
+    for (uint32_t q = n_points; q < 4; ++q) xp[q] = xp[0];
+    const unsigned bpc = pz_div_up(n, 256 * EVAL_CH);
+    void* part;
+    PZCHK(pz_ws_get(ctx, WS_IO_B, n_cols * (size_t)n_points * bpc * 32, &part));
+    const dim3 grid(bpc, (unsigned)n_cols);
+#define PZ_EVAL_LAUNCH(P_)                                                                                                   \
+    hipLaunchKernelGGL(k_poly_eval_partial_multi<P_>, grid, dim3(256), 0, ctx->stream, (const Fr*)d_coeffs, col_stride / 4, n, \
+                       (const Fr*)xp[0], (const Fr*)xp[1], (const Fr*)xp[2], (const Fr*)xp[3], (Fr*)part, bpc)
+    switch (n_points) {
+        case 1: PZ_EVAL_LAUNCH(1); break;
+        case 2: PZ_EVAL_LAUNCH(2); break;
+        case 3: PZ_EVAL_LAUNCH(3); break;
+        default: PZ_EVAL_LAUNCH(4); break;
+    }
+#undef PZ_EVAL_LAUNCH
+    // partial[(col * P + q)][block]: the reduction over blocks is the single-point one over n_cols * P rows
+    hipLaunchKernelGGL(k_poly_eval_final, dim3(pz_div_up(n_cols * n_points, 64)), dim3(64), 0, ctx->stream, (const Fr*)part, bpc,
+                       n_cols * (size_t)n_points, (Fr*)d_out);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- keygen
 // permutation::keygen: the sigma polynomial of column j holds, at row i, the label delta^(col') * omega^(row') of the cell
 // the copy-constraint cycle maps (j, i) to.  The cycles themselves are circuit structure (the reference's dependency

@@ -383,6 +383,12 @@ class Engine:
         self._chk(self.L.pz_poly_eval_dev(self.ctx, VP(d_coeffs), n_cols, col_stride_u64, n, _ptr(_np(x).reshape(4)),
                                           VP(d_out)), "pz_poly_eval_dev")
 
+    def poly_eval_multi_dev(self, d_coeffs: int, n_cols: int, col_stride_u64: int, n: int, xs, d_out: int):
+        """xs: (n_points, 4), n_points <= 4; d_out: (n_cols, n_points, 4) on the device"""
+        x = _np(xs).reshape(-1, 4)
+        self._chk(self.L.pz_poly_eval_multi_dev(self.ctx, VP(d_coeffs), n_cols, col_stride_u64, n, _ptr(x), x.shape[0], VP(d_out)),
+                  "pz_poly_eval_multi_dev")
+
     # ------------------------------------------------------------------ "next" rows: products, quotient, openings
     def _fr1(self, x):
         """host pointer to one Fr element; the array is kept referenced until a few calls later (a temporary

@@ -165,6 +165,41 @@ def test_kate_division_identity_at_scale(eng, cref):
         assert (pt[j] - px[j]) % P.FR_R == (t - x) * qt[j] % P.FR_R, j
 
 
+@pytest.mark.parametrize("n,npts", [(1, 1), (5, 2), (300, 3), (4097, 4), (1 << 17, 4)])
+def test_poly_eval_multi_point(eng, cref, n, npts):
+    """pz_poly_eval_multi_dev: a batch of polynomials at their whole rotation set in one pass == the oracle's Horner value
+    (small n) and == pz_poly_eval_dev point by point (every n)"""
+    import torch
+
+    rng = random.Random(450 + n)
+    ncols = 3
+    w = P.fr_omega(17)
+    x0 = rng.randrange(P.FR_R)
+    pts = [x0 * pow(w, k, P.FR_R) % P.FR_R for k in (0, 1, P.FR_R - 2, 3)][:npts]     # x, wx, w^-1 x, w^3 x
+    if n <= 5000:
+        cols = [[rng.randrange(P.FR_R) for _ in range(n)] for _ in range(ncols)]
+        d = _dev(cref, cols)
+    else:
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(451)
+        d = torch.randint(-(1 << 63), (1 << 63) - 1, (ncols * n, 4), dtype=torch.int64, device="cuda", generator=gen)
+        d[:, 3] &= 0x0FFFFFFFFFFFFFFF
+        cols = None
+    d_out = torch.zeros((ncols, npts, 4), dtype=torch.int64, device="cuda")
+    eng.poly_eval_multi_dev(d.data_ptr(), ncols, 4 * n, n, np.stack([_m(cref, x) for x in pts]), d_out.data_ptr())
+    d_one = torch.zeros((npts, ncols, 4), dtype=torch.int64, device="cuda")
+    for q, x in enumerate(pts):
+        eng.poly_eval_dev(d.data_ptr(), ncols, 4 * n, n, _m(cref, x), d_one[q].data_ptr())
+    eng.sync()
+    got = _ints(cref, d_out)
+    one = _ints(cref, d_one)
+    for j in range(ncols):
+        for q in range(npts):
+            assert got[j * npts + q] == one[q * ncols + j], (j, q)
+            if cols is not None:
+                assert got[j * npts + q] == P.poly_eval(cols[j], pts[q]), (j, q)
+
+
 @pytest.mark.parametrize("log_n,log_e,ncols", [(3, 2, 1), (5, 2, 3), (6, 1, 2)])
 def test_quotient_gate_finish_distribute_vs_oracle(eng, cref, log_n, log_e, ncols):
     import torch
