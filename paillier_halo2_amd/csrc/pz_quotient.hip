@@ -462,7 +462,7 @@ extern "C" int pz_poly_div_linear_dev(pz_ctx* ctx, const uint64_t* d_coeffs, siz
 //   for every set j: h = h*y + l_active ( z_j(wX) prod_c (v_c + beta sigma_c + gamma) - z_j(X) prod_c (v_c + delta^c beta X + gamma) )
 // with c running over the set's chunk of columns and delta^c continuing across sets.
 struct PermQ {
-    const Fr *cols, *sigma, *z, *l0, *llast, *lactive;
+    const Fr *cols, *sigma, *z, *l0, *llast, *lactive, *xpow;
     size_t cs, ss, zs, N;
     unsigned n_sets, chunk_len, m_total, step, last_rot;
     Fr beta, gamma, delta, x0, w_ext, y;
@@ -484,23 +484,21 @@ __global__ __launch_bounds__(256) void k_quotient_permutation(PermQ q, Fr* __res
         Fr d = fp_sub(fp_load<FrTag>(q.z + (size_t)j * q.zs + i), fp_load<FrTag>(q.z + (size_t)(j - 1) * q.zs + i_last));
         acc = fp_add(fp_mul(acc, q.y), fp_mul(d, l0));
     }
-    // beta * X_i, X_i = x0 * w_ext^i  (square-and-multiply over the bits of i: log2(N) products, no table)
-    Fr xi = q.x0;
-    {
-        Fr p = q.w_ext;
-        for (size_t e = i; e; e >>= 1) {
-            if (e & 1) xi = fp_mul(xi, p);
-            p = fp_sqr(p);
-        }
-    }
-    Fr cur = fp_mul(q.beta, xi);
+    // beta * X_i, X_i = x0 * w_ext^i from the cached power table (square-and-multiply over the bits of i cost a wave
+    // 2 log2(N) products per row and call: both arms of every bit)
+    Fr cur = fp_mul(q.beta, fp_load<FrTag>(q.xpow + i));
     unsigned c = 0;
+    // the next column's value and sigma are requested before the current column's four products start
+    Fr v_n = fp_load<FrTag>(q.cols + i), s_n = fp_load<FrTag>(q.sigma + i);
     for (unsigned j = 0; j < q.n_sets; ++j) {
         Fr left = fp_load<FrTag>(q.z + (size_t)j * q.zs + i_next);
         Fr right = fp_load<FrTag>(q.z + (size_t)j * q.zs + i);
         for (unsigned t = 0; t < q.chunk_len && c < q.m_total; ++t, ++c) {
-            const Fr v = fp_add(fp_load<FrTag>(q.cols + (size_t)c * q.cs + i), q.gamma);
-            left = fp_mul(left, fp_add(v, fp_mul(q.beta, fp_load<FrTag>(q.sigma + (size_t)c * q.ss + i))));
+            const Fr v = fp_add(v_n, q.gamma), sg = s_n;
+            const unsigned cn = c + 1 < q.m_total ? c + 1 : c;
+            v_n = fp_load<FrTag>(q.cols + (size_t)cn * q.cs + i);
+            s_n = fp_load<FrTag>(q.sigma + (size_t)cn * q.ss + i);
+            left = fp_mul(left, fp_add(v, fp_mul(q.beta, sg)));
             right = fp_mul(right, fp_add(v, cur));
             cur = fp_mul(cur, q.delta);
         }
@@ -534,6 +532,9 @@ extern "C" int pz_quotient_permutation_dev(pz_ctx* ctx, const uint64_t* d_cols_e
     q.n_sets = n_sets; q.chunk_len = chunk_len; q.m_total = m_total; q.step = rot_step; q.last_rot = last_rotation;
     q.beta = fr_from_u64(beta); q.gamma = fr_from_u64(gamma); q.delta = fr_from_u64(delta);
     q.x0 = fr_from_u64(coset_g); q.w_ext = fr_from_u64(omega_ext); q.y = fr_from_u64(y);
+    void* xp;
+    PZCHK(pz_get_pow_table(ctx, omega_ext, N, &xp, coset_g));   // X_i = coset_g * omega_ext^i, cached across calls
+    q.xpow = (const Fr*)xp;
     hipLaunchKernelGGL(k_quotient_permutation, dim3(pz_div_up(N, 256)), dim3(256), 0, ctx->stream, q, (Fr*)d_h);
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
