@@ -253,6 +253,13 @@ template <unsigned J, class T> __device__ __forceinline__ void f29_store(void* p
     q[0] = make_uint4(w[0], w[1], w[2], w[3]);
     q[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
+// the canonical representative as an 8 x 32-bit element (value below 2^(J+1) p)
+template <unsigned J, class T> __device__ __forceinline__ Fp<T> f29_to_fp(const F29<T>& x) {
+    const F29<T> c = f29_canon<J>(x);
+    Fp<T> r;
+    f29_pack(c, r.v);
+    return r;
+}
 // internal 36-byte form (9 words, strict limbs not required): workspaces that never cross the ABI
 template <class T> __device__ __forceinline__ F29<T> f29_load_raw(const u32* p) {
     F29<T> r;

@@ -108,6 +108,7 @@ struct pz_timer {
     ~pz_timer();
 };
 
+const uint64_t* pz_fr_one261();   // Montgomery one times 32: first entry of a power table kept in the 2^261 domain (fp29.cuh)
 int pz_io_init(pz_ctx* ctx);   // streams + events of the host-pointer pipelines; orders io_h2d after ctx->stream
 
 static inline unsigned pz_div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

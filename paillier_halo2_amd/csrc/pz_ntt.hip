@@ -432,6 +432,8 @@ static const uint64_t* one261() {
     return v;
 }
 
+const uint64_t* pz_fr_one261() { return one261(); }   // for the other translation units' 261-domain power tables
+
 static int launch_strided(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t os, size_t ncols, NttPass p,
                           const Fr* tw, const Fr* pre, unsigned n_r = 1, size_t pre_r_stride = 0, size_t out_r_stride = 0) {
     size_t blocks = p.hi * (p.lo / p.T);

@@ -6,6 +6,7 @@
 //                         sum_i c_i x^i with a cached x^i table, one multiplication per coefficient.
 // Both are reached in the reference only through bench.rs:161-171 (gen_srs / create_proof inside bench_builder).
 #include "ec.cuh"
+#include "fp29.cuh"
 #include "pz_internal.h"
 
 __global__ void k_srs_multiplier(Fr s, Fr n_mont, unsigned k, Fr* out /* [0] = (s^n - 1)/n, [1] = s^n - 1 */) {
@@ -76,26 +77,6 @@ extern "C" int pz_srs_setup_g1_dev(pz_ctx* ctx, uint32_t k, const uint64_t s[4],
 
 // ---------------------------------------------------------------------------------------------- evaluation at a point
 #define EVAL_CH 16u
-__global__ __launch_bounds__(256) void k_poly_eval_partial(const Fr* __restrict__ coeffs, size_t col_stride, size_t n,
-                                                           const Fr* __restrict__ xpow, Fr* __restrict__ partial,
-                                                           unsigned blocks_per_col) {
-    __shared__ Fr s_acc[256];
-    const size_t col = blockIdx.y;
-    const Fr* c = coeffs + col * col_stride;
-    const size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * EVAL_CH;
-    Fr acc = fp_zero<FrTag>();
-    for (unsigned t = 0; t < EVAL_CH; ++t) {
-        const size_t i = base + t;
-        if (i < n) acc = fp_add(acc, fp_mul(fp_load<FrTag>(c + i), fp_load<FrTag>(xpow + i)));
-    }
-    s_acc[threadIdx.x] = acc;
-    __syncthreads();
-    for (unsigned off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) s_acc[threadIdx.x] = fp_add(s_acc[threadIdx.x], s_acc[threadIdx.x + off]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) fp_store(partial + col * blocks_per_col + blockIdx.x, s_acc[0]);
-}
 __global__ void k_poly_eval_final(const Fr* __restrict__ partial, unsigned blocks_per_col, size_t n_cols, Fr* __restrict__ out) {
     size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= n_cols) return;
@@ -104,6 +85,8 @@ __global__ void k_poly_eval_final(const Fr* __restrict__ partial, unsigned block
     fp_store(out + col, acc);
 }
 
+extern "C" int pz_poly_eval_multi_dev(pz_ctx* ctx, const uint64_t* d_coeffs, size_t n_cols, size_t col_stride, size_t n,
+                                      const uint64_t* xs, uint32_t n_points, uint64_t* d_out);
 extern "C" int pz_poly_eval_dev(pz_ctx* ctx, const uint64_t* d_coeffs, size_t n_cols, size_t col_stride, size_t n,
                                 const uint64_t x[4], uint64_t* d_out) {
     if (!ctx || !x || (n_cols && (!d_coeffs || !d_out)) || col_stride % 4 || (n_cols > 1 && col_stride < 4 * n)) return PZ_ERR_INVALID;
@@ -114,16 +97,7 @@ extern "C" int pz_poly_eval_dev(pz_ctx* ctx, const uint64_t* d_coeffs, size_t n_
         HIPCHK(ctx, hipMemsetAsync(d_out, 0, n_cols * 32, ctx->stream));
         return PZ_OK;
     }
-    void *xp, *part;
-    PZCHK(pz_get_pow_table(ctx, x, n, &xp));
-    const unsigned bpc = pz_div_up(n, 256 * EVAL_CH);
-    PZCHK(pz_ws_get(ctx, WS_IO_B, n_cols * (size_t)bpc * 32, &part));
-    hipLaunchKernelGGL(k_poly_eval_partial, dim3(bpc, (unsigned)n_cols), dim3(256), 0, ctx->stream, (const Fr*)d_coeffs,
-                       col_stride / 4, n, (const Fr*)xp, (Fr*)part, bpc);
-    hipLaunchKernelGGL(k_poly_eval_final, dim3(pz_div_up(n_cols, 64)), dim3(64), 0, ctx->stream, (const Fr*)part, bpc, n_cols,
-                       (Fr*)d_out);
-    HIPCHK(ctx, hipGetLastError());
-    return PZ_OK;
+    return pz_poly_eval_multi_dev(ctx, d_coeffs, n_cols, col_stride, n, x, 1, d_out);
 }
 
 // The same at up to four points at once -- a polynomial's rotation set {x, wx, w^2 x, ...} (halo2 evaluates every advice
@@ -139,20 +113,28 @@ __global__ __launch_bounds__(256) void k_poly_eval_partial_multi(const Fr* __res
     const Fr* c = coeffs + col * col_stride;
     const Fr* xp[4] = {xp0, xp1, xp2, xp3};
     const size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * EVAL_CH;
-    Fr acc[P];
+    // products on the 9 x 29-bit field (fp29.cuh): the power tables are kept in the 2^261 domain, so coefficient (2^256
+    // domain) x table entry stays in the ABI's domain; sums are limb-wise with one parallel carry round per four terms
+    // (limbs < 4 * 2^29 + 8, values < 2 * EVAL_CH * p)
+    F29<FrTag> acc[P];
 #pragma unroll
-    for (unsigned q = 0; q < P; ++q) acc[q] = fp_zero<FrTag>();
+    for (unsigned q = 0; q < P; ++q) acc[q] = f29_zero<FrTag>();
+#pragma unroll 4
     for (unsigned t = 0; t < EVAL_CH; ++t) {
         const size_t i = base + t;
         if (i < n) {
-            const Fr v = fp_load<FrTag>(c + i);
+            const F29<FrTag> v = f29_load<FrTag>(c + i);
 #pragma unroll
-            for (unsigned q = 0; q < P; ++q) acc[q] = fp_add(acc[q], fp_mul(v, fp_load<FrTag>(xp[q] + i)));
+            for (unsigned q = 0; q < P; ++q) acc[q] = f29_add(acc[q], f29_mul(v, f29_load<FrTag>(xp[q] + i)));
+        }
+        if ((t & 3u) == 3u) {
+#pragma unroll
+            for (unsigned q = 0; q < P; ++q) acc[q] = f29_carry(acc[q]);
         }
     }
 #pragma unroll
     for (unsigned q = 0; q < P; ++q) {
-        s_acc[threadIdx.x] = acc[q];
+        s_acc[threadIdx.x] = f29_to_fp<5>(acc[q]);
         __syncthreads();
         for (unsigned off = 128; off > 0; off >>= 1) {
             if (threadIdx.x < off) s_acc[threadIdx.x] = fp_add(s_acc[threadIdx.x], s_acc[threadIdx.x + off]);
@@ -176,7 +158,7 @@ extern "C" int pz_poly_eval_multi_dev(pz_ctx* ctx, const uint64_t* d_coeffs, siz
         return PZ_OK;
     }
     void* xp[4] = {nullptr, nullptr, nullptr, nullptr};
-    for (uint32_t q = 0; q < n_points; ++q) PZCHK(pz_get_pow_table(ctx, xs + 4 * q, n, &xp[q]));
+    for (uint32_t q = 0; q < n_points; ++q) PZCHK(pz_get_pow_table(ctx, xs + 4 * q, n, &xp[q], pz_fr_one261()));
     for (uint32_t q = n_points; q < 4; ++q) xp[q] = xp[0];
     const unsigned bpc = pz_div_up(n, 256 * EVAL_CH);
     void* part;
