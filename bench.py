@@ -165,8 +165,11 @@ class ProofWorkload:
             self.col_n = self._rand_fr(pool * self.n).view(pool, self.n, 4)   # its own pool: NTTs run in place
         # NTT buffers
         self.ext_n = 1 << sh.ext_k
-        self.ntt_batch = min(pool, 64)
-        self.d_ext = torch.zeros((self.ntt_batch, self.ext_n, 4), dtype=torch.int64, device=dev)
+        self.ntt_batch = min(pool, int(os.environ.get("PZ_BENCH_NTT_BATCH", "40")))
+        # 40 polynomials per call: the size at which the NTT stream and the commitment stream of a proof finish together
+        # (64: the transforms end ~130 ms early and the commitments run 10 ms longer; 32: the other way round).  The extended
+        # tile keeps 64 columns: the steps after the hot path read it 64 columns at a time
+        self.d_ext = torch.zeros((max(64, self.ntt_batch), self.ext_n, 4), dtype=torch.int64, device=dev)
         self.omega_inv = consts.fr_mont_limbs(pow(consts.fr_omega(k), -1, consts.FR_R))
         self.n_inv = consts.fr_mont_limbs(pow(self.n, -1, consts.FR_R))
         w_ext = consts.fr_omega(sh.ext_k)
