@@ -683,6 +683,7 @@ def main():
         args.k = 15
     colpar = args.parallel == "columns"
     wl = ProofWorkload(eng, torch, args.enc_bits, args.k, seed=args.seed + (0 if colpar else rank), scale=args.scale,
+                       pool=int(os.environ.get("PZ_BENCH_POOL", "256")),   # columns per full-width commitment call (tuning only)
                        lookup_bits=args.lookup_bits, shard=(rank, world) if colpar else (0, 1), dist=dist if (colpar and use_dist) else None,
                        circuit="add" if args.workload == "c3" else "encrypt_uniform" if args.workload == "c2u" else "encrypt")
     log("setup %.1fs: %s ; per-step counts %s" % (time.time() - t0, wl.shape, wl.counts))
