@@ -79,3 +79,7 @@ print("pz_msm_g1_batch, 256 pinned columns: %.1f ms" % t(lambda: eng.msm_batch(b
 import numpy as np
 pcols = [np.array(c, copy=True) for c in cols]
 print("pz_msm_g1_batch, 256 pageable columns: %.1f ms" % t(lambda: eng.msm_batch(bases, pcols)))
+
+w_inv = consts.fr_mont_limbs(pow(consts.fr_omega(k), -1, consts.FR_R))
+print("pz_ntt_fr_batch 2^17, 256 pinned columns: %.1f ms" % t(lambda: eng.ntt_batch_inplace(cols, w_inv, k)))
+print("pz_ntt_fr_batch 2^17, 256 pageable columns: %.1f ms" % t(lambda: eng.ntt_batch_inplace(pcols, w_inv, k)))
