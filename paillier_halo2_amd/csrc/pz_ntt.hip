@@ -95,15 +95,15 @@ __device__ __forceinline__ Fr fake_raw(const Fr* p_) {
 // tile index -> LDS word offset: 9 words per element and ONE PAD ELEMENT PER 32, which spreads the power-of-two
 // element strides of the bit-reversed fill and of the first pair of stages over all banks (without it 69 % of the
 // LDS cycles of these kernels were bank conflicts: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/)
-__device__ __forceinline__ size_t lds29_off(size_t e) { return (e + (e >> 5)) * 9; }
-__device__ __forceinline__ Fr29 lds29_get(const u32* sm, size_t e) {
+__device__ __forceinline__ unsigned lds29_off(unsigned e) { return (e + (e >> 5)) * 9u; }   // tile indices are < 2^16: 32-bit arithmetic
+__device__ __forceinline__ Fr29 lds29_get(const u32* sm, unsigned e) {
     Fr29 r;
     const u32* p = sm + lds29_off(e);
 #pragma unroll
     for (int i = 0; i < 9; ++i) r.v[i] = p[i];
     return r;
 }
-__device__ __forceinline__ void lds29_put(u32* sm, size_t e, const Fr29& a) {
+__device__ __forceinline__ void lds29_put(u32* sm, unsigned e, const Fr29& a) {
     u32* p = sm + lds29_off(e);
 #pragma unroll
     for (int i = 0; i < 9; ++i) p[i] = a.v[i];
@@ -120,7 +120,8 @@ __device__ __forceinline__ void bf29(const Fr29& u, const Fr29& v, Fr29& sum, Fr
 // once per stage.  Stages 0+1 cost one product per group (their other twiddles are 1).  An odd logR ends with one
 // plain radix-2 stage.  element (j, t) lives at tile index j*sr + t*st.  Input must be stored bit-reversed in j.
 __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, unsigned sr, unsigned st, bool t_fastest,
-                                          const Fr* __restrict__ tw, size_t n) {
+                                          const Fr* __restrict__ tw, size_t n_) {
+    const unsigned n = (unsigned)n_;   // n <= 2^27: twiddle indices fit 32 bits
     const unsigned R = 1u << logR;
 #if PZ_NTT_EXP == 6
     return;
@@ -145,7 +146,7 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
             }
             const unsigned pos = q & (h - 1);
             const unsigned base = ((q >> s) << (s + 2)) + pos;
-            const size_t e0 = (size_t)base * sr + (size_t)t * st, dh = (size_t)h * sr;
+            const unsigned e0 = base * sr + t * st, dh = h * sr;
             Fr29 a0 = lds29_get(sm, e0), a1 = lds29_get(sm, e0 + dh), a2 = lds29_get(sm, e0 + 2 * dh), a3 = lds29_get(sm, e0 + 3 * dh);
             Fr29 b0, b1, b2, b3, o0, o1, o2, o3;
             if (s) {  // kernel-uniform branch
@@ -154,13 +155,13 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
                 // parallel carry round each
                 a0 = f29_carry(a0);
                 a2 = f29_carry(a2);
-                const Fr29 w = STAGE_TW(tw + (size_t)pos * (n >> (s + 1)));
+                const Fr29 w = STAGE_TW(tw + pos * (n >> (s + 1)));
                 a1 = STAGE_MUL(a1, w);
                 a3 = STAGE_MUL(a3, w);
                 bf29(a0, a1, b0, b1);
                 bf29(a2, a3, b2, b3);
-                b2 = STAGE_MUL(b2, STAGE_TW(tw + (size_t)pos * (n >> (s + 2))));
-                b3 = STAGE_MUL(b3, STAGE_TW(tw + (size_t)(pos + h) * (n >> (s + 2))));
+                b2 = STAGE_MUL(b2, STAGE_TW(tw + pos * (n >> (s + 2))));
+                b3 = STAGE_MUL(b3, STAGE_TW(tw + (pos + h) * (n >> (s + 2))));
                 bf29(b0, b2, o0, o2);
             } else {
                 // stages 0 + 1: operands straight from the load (tight, value < 2p); the first layer's twiddles and the
@@ -169,7 +170,7 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
                 b1 = f29_sub<2, 29>(a0, a1);
                 b2 = f29_add(a2, a3);          // un-multiplied: limbs < 2^30, value < 4p -> subtrahend of f29_sub<4, 30>
                 b3 = f29_sub<2, 29>(a2, a3);
-                b3 = STAGE_MUL(b3, STAGE_TW(tw + (size_t)(pos + h) * (n >> (s + 2))));
+                b3 = STAGE_MUL(b3, STAGE_TW(tw + (pos + h) * (n >> (s + 2))));
                 o0 = f29_add(b0, b2);
                 o2 = f29_sub<4, 30>(b0, b2);
             }
@@ -196,13 +197,13 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
             }
             const unsigned pos = bf & (half - 1);
             const unsigned i0 = ((bf >> s) << (s + 1)) + pos;
-            const size_t e0 = (size_t)i0 * sr + (size_t)t * st, e1 = e0 + (size_t)half * sr;
+            const unsigned e0 = i0 * sr + t * st, e1 = e0 + half * sr;
             Fr29 u = lds29_get(sm, e0);
             Fr29 v = lds29_get(sm, e1);
             Fr29 o0, o1;
             if (s) {
                 u = f29_carry(u);
-                v = STAGE_MUL(v, STAGE_TW(tw + (size_t)pos * (n >> (s + 1))));
+                v = STAGE_MUL(v, STAGE_TW(tw + pos * (n >> (s + 1))));
                 bf29(u, v, o0, o1);
             } else {  // a single stage (logR == 1): operands straight from the load (tight, < 2p)
                 o0 = f29_add(u, v);
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, si
             if (idx < nelem) {
                 Fr29 x = f29_from_fp(raw[k]);
                 if (PRE) x = EDGE_MUL(x, f29_from_fp(praw[k]));
-                lds29_put(sm, (size_t)bitrev32(idx >> logT, p.logR) * T + (idx & (T - 1)), x);
+                lds29_put(sm, bitrev32(idx >> logT, p.logR) * T + (idx & (T - 1)), x);
             }
         }
     }
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, si
             if (idx < nelem) {
                 const unsigned kk = idx >> logT, t = idx & (T - 1);
                 // always through the product (tw[0] = 1): the result is below 2p whatever the stages accumulated
-                const Fr29 x = EDGE_MUL(lds29_get(sm, (size_t)kk * T + t), f29_from_fp(traw[k]));
+                const Fr29 x = EDGE_MUL(lds29_get(sm, kk * T + t), f29_from_fp(traw[k]));
                 DATA_STORE(1, dst + base + (size_t)kk * p.lo + t, x);
             }
         }
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256) void k_ntt_final29(const Fr* in, Fr* out, size
             if (idx < nelem) {
                 Fr29 x = f29_from_fp(raw[k]);
                 if (PRE) x = EDGE_MUL(x, f29_from_fp(praw[k]));
-                lds29_put(sm, (size_t)(idx >> p.logR) * R + bitrev32(idx & (R - 1), p.logR), x);
+                lds29_put(sm, (idx >> p.logR) * R + bitrev32(idx & (R - 1), p.logR), x);
             }
         }
     }
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256) void k_ntt_final29(const Fr* in, Fr* out, size
     const Fr29 post29 = f29_from_fp(post);
     for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
         unsigned k = idx >> logT, r = idx & (T - 1);
-        Fr29 x = lds29_get(sm, (size_t)r * R + k);
+        Fr29 x = lds29_get(sm, r * R + k);
         Fr* o = dst + (k1_0 + r) + p.n1 * k2 + p.hi * (size_t)k;
         if (has_post) DATA_STORE(1, o, EDGE_MUL(x, post29));
         else DATA_STORE(4, o, x);
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(256) void k_ntt_final_ext29(const Fr* in, Fr* out, 
                 const unsigned j = idx & (R - 1), rr = (idx >> p.logR) & (T - 1), r = idx >> (p.logR + logT);
                 Fr29 x = f29_from_fp(raw[k]);
                 if (PRE) x = EDGE_MUL(x, f29_from_fp(praw[k]));
-                lds29_put(sm, ((size_t)r * T + rr) * R + bitrev32(j, p.logR), x);
+                lds29_put(sm, (r * T + rr) * R + bitrev32(j, p.logR), x);
             }
         }
     }
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256) void k_ntt_final_ext29(const Fr* in, Fr* out, 
     lds_dit29(sm, p.logR, T * E, 1, R, false, tw, p.n);
     for (unsigned idx = threadIdx.x; idx < R * T * E; idx += blockDim.x) {
         const unsigned r = idx & (E - 1), rr = (idx >> log_e) & (T - 1), k = idx >> (log_e + logT);
-        const Fr29 x = lds29_get(sm, ((size_t)r * T + rr) * R + k);
+        const Fr29 x = lds29_get(sm, (r * T + rr) * R + k);
         DATA_STORE(4, dst + (((k1_0 + rr) + p.n1 * k2 + p.hi * (size_t)k) << log_e) + r, x);
     }
 }
