@@ -1112,10 +1112,18 @@ extern "C" int pz_msm_g1_dev(pz_ctx* ctx, const pz_bases* bases, const uint64_t*
     if (group == 0) group = 1;
     if (group > n_cols) group = n_cols;
     if (group > 4096) group = 4096;
-    for (size_t c0 = 0; c0 < n_cols; c0 += group) {
-        size_t nc = n_cols - c0 < group ? n_cols - c0 : group;
-        PZCHK(msm_group(ctx, bases, (const Fr*)d_scalars + c0 * cs, nc, n, cs, win_lo, win_hi, chunk,
-                        (G1Jac*)d_out_jac + c0));
+    for (size_t c0 = 0; c0 < n_cols;) {
+        const size_t nc = n_cols - c0 < group ? n_cols - c0 : group;
+        const int rc = msm_group(ctx, bases, (const Fr*)d_scalars + c0 * cs, nc, n, cs, win_lo, win_hi, chunk, (G1Jac*)d_out_jac + c0);
+        if (rc == PZ_ERR_OOM && group > 1) {
+            // the cached free-memory figure was stale (someone else allocated since): halve the group, ask again next call
+            ctx->mem_avail = 0;
+            (void)hipGetLastError();
+            group = (group + 1) / 2;
+            continue;
+        }
+        PZCHK(rc);
+        c0 += nc;
     }
     return PZ_OK;
 }
