@@ -939,6 +939,30 @@ def expand_circuit_cells(kind: str, n: int, g: int, x: int, y: int, res: int, en
     return [v % FR_R for v in adv], [v % FR_R for v in lk], seg
 
 
+def _cut_windows(pieces, adv_windows, lk_windows):
+    """pieces: [(advice cells, lookup cells, maker of both lists)] in stream order -> (total advice cells, total lookup cells,
+    [cells of each advice window], [cells of each lookup window]); only the pieces a window touches are expanded"""
+    tot_a, tot_l = sum(p[0] for p in pieces), sum(p[1] for p in pieces)
+
+    def cut(windows, which):
+        outs = []
+        for lo, hi in windows:
+            out, off = [], 0
+            for p_ in pieces:
+                ln = p_[which]
+                if ln and off < hi and off + ln > lo:
+                    cells = p_[2]()[which]
+                    assert len(cells) == ln
+                    out += cells[max(lo - off, 0): hi - off]
+                off += ln
+                if off >= hi:
+                    break
+            outs.append([v % FR_R for v in out])
+        return outs
+
+    return tot_a, tot_l, cut(adv_windows, 0), cut(lk_windows, 1)
+
+
 def encrypt_circuit_cells_windows(n: int, g: int, m: int, r: int, res: int, enc_bits: int, limb_bits: int, lb: int, adv_windows,
                                    lk_windows=()):
     """The cells [lo, hi) of expand_circuit_cells('encrypt', ...)'s advice / lookup streams WITHOUT building the streams (4e8
@@ -971,25 +995,7 @@ def encrypt_circuit_cells_windows(n: int, g: int, m: int, r: int, res: int, enc_
     pieces.append((cps, lps, lambda: (fa, fl)))
     pieces.append((len(ta), len(tl), lambda: (ta, tl)))
     pieces.append((len(ae), 0, lambda: (ae, [])))
-    tot_a, tot_l = sum(p[0] for p in pieces), sum(p[1] for p in pieces)
-
-    def cut(windows, which):
-        outs = []
-        for lo, hi in windows:
-            out, off = [], 0
-            for p_ in pieces:
-                ln = p_[which]
-                if ln and off < hi and off + ln > lo:
-                    cells = p_[2]()[which]
-                    assert len(cells) == ln
-                    out += cells[max(lo - off, 0): hi - off]
-                off += ln
-                if off >= hi:
-                    break
-            outs.append([v % FR_R for v in out])
-        return outs
-
-    return tot_a, tot_l, cut(adv_windows, 0), cut(lk_windows, 1)
+    return _cut_windows(pieces, adv_windows, lk_windows)
 
 
 # gate positions (MockProver analogue) of the operations above, relative to the operation's first cell
@@ -1234,6 +1240,56 @@ def expand_uniform_circuit_cells(n: int, g: int, m: int, r: int, res: int, enc_b
     seg["end"] = (len(adv), len(lk))
     seg["satisfied"] = bool(bit)
     return [v % FR_R for v in adv], [v % FR_R for v in lk], seg
+
+
+def uniform_circuit_cells_windows(n: int, g: int, m: int, r: int, res: int, enc_bits: int, limb_bits: int, lb: int, adv_windows,
+                                  lk_windows=()):
+    """encrypt_circuit_cells_windows for the uniform-shape circuit (expand_uniform_circuit_cells' streams)"""
+    Ln = enc_bits // limb_bits
+    L = 2 * Ln
+    n2 = n * n
+    pre_a, pre_l = [], []
+    for v in (n, g, m, r):
+        a_, l_ = expand_assign_cells(v, Ln, limb_bits, lb)
+        pre_a += a_
+        pre_l += l_
+    nl = decompose_biguint(n, Ln, limb_bits)
+    sq_cells, prod = _mul_cells(nl, nl, 2 * Ln - 1)
+    pre_a += sq_cells
+    r_adv, r_lk, _ = expand_refresh_cells(prod, refresh_aux(limb_bits, Ln, Ln), limb_bits, lb)
+    pre_a += r_adv + [0]
+    pre_l += r_lk
+    c, sg, sr, fin = encrypt_uniform_trace(n, g, m, r, enc_bits)
+    fa, fl = expand_mul_mod_cells(*fin, n2, L, lb, limb_bits)
+    cps, lps = len(fa), len(fl)
+    ta, tl = expand_assign_cells(res, L, limb_bits, lb)
+    ae, _ = expand_assert_equal_fresh_cells(decompose_biguint(c, L, limb_bits), decompose_biguint(res, L, limb_bits))
+    step = lambda st: (cps, lps, (lambda st=st: expand_mul_mod_cells(*st, n2, L, lb, limb_bits)))
+    pieces = [(len(pre_a), len(pre_l), lambda: (pre_a, pre_l)), (2, 0, lambda: ([1, 0], []))]
+    ml = decompose_biguint(m, Ln, limb_bits)
+    for li in range(Ln):
+        nb_cells, bits = _num_to_bits_cells(ml[li], limb_bits)
+        pieces.append((len(nb_cells), 0, (lambda c_=nb_cells: (c_, []))))
+        for bi in range(limb_bits):
+            i = li * limb_bits + bi
+            st_mul, st_sq = sg[2 * i], sg[2 * i + 1]
+            pieces.append(step(st_mul))
+
+            def sel(st_mul=st_mul, b=bits[bi]):
+                acc_l, mul_l = decompose_biguint(st_mul[0], L, limb_bits), decompose_biguint(st_mul[3], L, limb_bits)
+                out = []
+                for t in range(L):
+                    out.extend(_select_cells(mul_l[t], acc_l[t], b))
+                return out, []
+
+            pieces.append((8 * L, 0, sel))
+            pieces.append(step(st_sq))
+    pieces.append((2, 0, lambda: ([1, 0], [])))
+    pieces += [step(st) for st in sr]
+    pieces.append((cps, lps, lambda: (fa, fl)))
+    pieces.append((len(ta), len(tl), lambda: (ta, tl)))
+    pieces.append((len(ae), 0, lambda: (ae, [])))
+    return _cut_windows(pieces, adv_windows, lk_windows)
 
 
 def gate_offsets_uniform_circuit(enc_bits: int, limb_bits: int, lb: int, n_steps_r: int):

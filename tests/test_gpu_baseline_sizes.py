@@ -235,6 +235,63 @@ def test_c2_encrypt_circuit_k17_at_size(eng, cref):
     tb.free()
 
 
+def test_c2_uniform_circuit_k17_at_size(eng, cref):
+    """The uniform-shape circuit at the c2 key size: 2 * 2048 + ~3070 mul_mod steps, num_to_bits and
+    limb-wise selects, 4.6e8 advice cells in 3544 columns -- K3 (uniform schedule) -> K4 (kind 2) -> K1 on the device; sampled
+    columns vs the oracle chain, every column through linearity of the commitment."""
+    import torch
+
+    enc_bits, k, lb = 2048, 17, 16
+    Ln, L = enc_bits // 64, 2 * (enc_bits // 64)
+    n = 1 << k
+    rows = n - 10
+    nn, g, m, r = P.synth_paillier_inputs(enc_bits, 0x5047)
+    res = P.paillier_enc_native(nn, g, m, r)
+    arr = lambda x: cref.int_to_limbs(x, Ln)
+    cap = 2 * enc_bits + nn.bit_length() + bin(nn).count("1") + 1
+    d_steps = torch.zeros((cap, 4, L), dtype=torch.int64, device="cuda")
+    c, ng, nr = eng.paillier_encrypt_uniform_dev(Ln, enc_bits, arr(nn), arr(g), arr(m), arr(r), d_steps.data_ptr(), cap)
+    ng, nr = int(ng[0]), int(nr[0])
+    assert cref.limbs_to_int(c[0]) == res and ng == 2 * enc_bits and ng + nr + 1 == cap
+    adv_n, lk_n = eng.circuit_cells(2, Ln, 64, lb, ng, nr)
+    ncol_a, ncol_l = -(-adv_n // rows), -(-lk_n // rows)
+    d_adv = torch.zeros((ncol_a * n, 4), dtype=torch.int64, device="cuda")
+    d_lk = torch.zeros((ncol_l * n, 4), dtype=torch.int64, device="cuda")
+    d_mod = torch.from_numpy(cref.int_to_limbs(nn * nn, L).astype(np.int64)).cuda()
+    inputs = np.concatenate([arr(nn), arr(g), arr(m), arr(r), cref.int_to_limbs(res, L)])
+    eng.circuit_expand_dev(2, Ln, 64, lb, inputs, d_steps.data_ptr(), ng, nr, d_mod.data_ptr(), d_adv.data_ptr(), d_lk.data_ptr(), rows, n)
+    d_l = _lagrange_srs_dev(eng, torch, cref, k, 0x4444444 * 0x5555555 + 7)
+    tb = eng.load_bases_dev(d_l.data_ptr(), n)
+    d_ca = torch.zeros((ncol_a, 12), dtype=torch.int64, device="cuda")
+    eng.msm_dev(tb, d_adv.data_ptr(), ncol_a, n, 4 * n, d_ca.data_ptr())
+    eng.sync()
+    com_a = eng.g1_normalize(d_ca.cpu().numpy().astype(np.uint64))
+    bases = d_l.cpu().numpy().astype(np.uint64)
+    # columns inside num_to_bits / select territory (the first of the g^m chain), in the middle of it, in the r^n chain, the last
+    sample_a = (0, 1, ncol_a // 2, ncol_a - 1)
+    win = lambda j, tot: (j * rows, min((j + 1) * rows, tot))
+    tot_a, tot_l, cells_a, cells_l = P.uniform_circuit_cells_windows(nn, g, m, r, res, enc_bits, 64, lb, [win(j, adv_n) for j in sample_a],
+                                                                     [win(0, lk_n), win(ncol_l - 1, lk_n)])
+    assert (tot_a, tot_l) == (adv_n, lk_n)
+    for j, col in zip(sample_a, cells_a):
+        col_m = cref.fr_ints_to_mont(col + [0] * (n - len(col)))
+        assert np.array_equal(d_adv[j * n:(j + 1) * n].cpu().numpy().astype(np.uint64), col_m), ("cells of column", j)
+        assert np.array_equal(com_a[j], cref.g1_normalize(cref.msm_g1(col_m, bases))), ("commitment of column", j)
+    for j, col in zip((0, ncol_l - 1), cells_l):
+        col_m = cref.fr_ints_to_mont(col + [0] * (n - len(col)))
+        assert np.array_equal(d_lk[j * n:(j + 1) * n].cpu().numpy().astype(np.uint64), col_m), ("lookup cells of column", j)
+    assert cells_a[-1][-1] == 1
+    v = pow(P.FR_GENERATOR, 0x7654321, P.FR_R)
+    d_fold = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    d_cf = torch.zeros((1, 12), dtype=torch.int64, device="cuda")
+    eng.fr_lincomb_dev(d_adv.data_ptr(), ncol_a, 4 * n, n, cref.fr_ints_to_mont([v])[0], d_fold.data_ptr())
+    eng.msm_dev(tb, d_fold.data_ptr(), 1, n, 4 * n, d_cf.data_ptr())
+    eng.sync()
+    pw = cref.fr_ints_to_mont([pow(v, ncol_a - 1 - j, P.FR_R) for j in range(ncol_a)])
+    assert np.array_equal(eng.g1_normalize(d_cf.cpu().numpy().astype(np.uint64))[0], cref.g1_normalize(cref.msm_g1(pw, com_a))), "linearity"
+    tb.free()
+
+
 def test_c3_add_circuit_k15_whole(eng, cref):
     """config c3: c1 * c2 mod n^2 at a 2048-bit key (operands assigned at enc_bits, bench.rs:98-103), k = 15,
     lookup_bits 14 -- K3 (pz_mul_mod) -> K4 -> K1 over ALL of the circuit's columns vs the oracle chain."""

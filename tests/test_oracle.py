@@ -359,3 +359,21 @@ def test_circuit_cell_windows_match_the_full_expansion():
     assert (ta, tl) == (len(adv), len(lk))
     assert all(c == adv[lo:hi] for (lo, hi), c in zip(wins, a))
     assert all(c == lk[lo:hi] for (lo, hi), c in zip(lwins, l))
+
+
+def test_uniform_circuit_cell_windows_match_the_full_expansion():
+    """uniform_circuit_cells_windows (the at-size GPU test of the uniform-shape circuit samples columns with it) returns
+    exactly the slices of expand_uniform_circuit_cells' streams"""
+    import random
+
+    bits, W, lb = 128, 64, 8
+    rng = random.Random(6)
+    n, g, m, r = rng.getrandbits(bits) | 1, rng.getrandbits(bits), rng.getrandbits(bits), rng.getrandbits(bits)
+    res = P.paillier_enc_native(n, g, m, r)
+    adv, lk, _ = P.expand_uniform_circuit_cells(n, g, m, r, res, bits, W, lb)
+    wins = [(0, 1000), (777, 9555), (len(adv) // 2, len(adv) // 2 + 30000), (len(adv) - 900, len(adv))]
+    lwins = [(0, 100), (1000, 2500), (len(lk) - 50, len(lk))]
+    ta, tl, a, l = P.uniform_circuit_cells_windows(n, g, m, r, res, bits, W, lb, wins, lwins)
+    assert (ta, tl) == (len(adv), len(lk))
+    assert all(c == adv[lo:hi] for (lo, hi), c in zip(wins, a))
+    assert all(c == lk[lo:hi] for (lo, hi), c in zip(lwins, l))
