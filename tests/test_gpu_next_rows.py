@@ -744,3 +744,75 @@ def test_shplonk_two_commitments(eng, cref, k):
     lhs = P.g1_add_aff(P.g1_mul(P.G1_GEN, acc), P.aff_neg(P.g1_mul(H, zt)))
     assert lhs == P.g1_mul(H2, z0 * (s_tox - u) % P.FR_R)
     tb.free()
+
+
+def test_shplonk_identities_at_scale(eng, cref):
+    """SHPLONK at the bench's scale (k = 17, 460 polynomials in four rotation sets: the chunked parallel folds): both output
+    polynomials satisfy their defining identities at a random point t,
+        h(t)  = sum_k v^k (C_k(t) - R_k(t)) / Z_{S_k}(t),   C_k = sum_j y^j p_kj,  R_k = the interpolation of C_k on S_k
+        h'(t) z_0 (t - u) = sum_k v^k z_k (C_k(t) - R_k(u)) - Z_T(u) h(t)
+    with every polynomial evaluated on the device (pz_poly_eval_multi_dev, itself checked against the oracle)."""
+    import torch
+
+    k = 17
+    n = 1 << k
+    rng = random.Random(700)
+    w = P.fr_omega(k)
+    x = rng.randrange(P.FR_R)
+    points = [x, x * w % P.FR_R, x * pow(w, 2, P.FR_R) % P.FR_R, x * pow(w, 3, P.FR_R) % P.FR_R, x * pow(w, -1, P.FR_R) % P.FR_R,
+              x * pow(w, n - 11, P.FR_R) % P.FR_R]
+    groups = [(300, [0]), (100, [0, 1, 2, 3]), (40, [0, 1, 4]), (20, [0, 1, 5])]
+    npoly = sum(c for c, _ in groups)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(701)
+    d_p = torch.randint(-(1 << 63), (1 << 63) - 1, (npoly, n, 4), dtype=torch.int64, device="cuda", generator=gen)
+    d_p[:, :, 3] &= 0x0FFFFFFFFFFFFFFF
+    y, v, u, t = (rng.randrange(2, P.FR_R) for _ in range(4))
+    F = lambda val: cref.fr_ints_to_mont([val])[0]
+    pts_m = cref.fr_ints_to_mont(points)
+
+    def evals(d_polys, count, xs):   # (count, len(xs)) integers
+        d_o = torch.zeros((count, len(xs), 4), dtype=torch.int64, device="cuda")
+        eng.poly_eval_multi_dev(d_polys.data_ptr(), count, 4 * n, n, cref.fr_ints_to_mont(xs), d_o.data_ptr())
+        eng.sync()
+        flat = cref.fr_mont_to_ints(d_o.cpu().numpy().astype(np.uint64).reshape(-1, 4))
+        return [flat[i * len(xs):(i + 1) * len(xs)] for i in range(count)]
+
+    sets_dev, ev_sets, off = [], [], 0
+    for cnt, idx in groups:
+        ev = evals(d_p[off:off + cnt], cnt, [points[i] for i in idx])
+        ev_sets.append(ev)
+        ev_m = np.stack([cref.fr_ints_to_mont(row) for row in ev])
+        sets_dev.append(([d_p[off + i].data_ptr() for i in range(cnt)], idx, ev_m))
+        off += cnt
+    d_h = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    d_h2 = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    st = eng.shplonk_begin_dev(n, sets_dev, pts_m, F(y), F(v), d_h.data_ptr())
+    d_hc = d_h.clone()
+    eng.shplonk_finish_dev(st, F(u), d_h.data_ptr(), d_h2.data_ptr())
+    eng.sync()
+    h_t = evals(d_hc.view(1, n, 4), 1, [t])[0][0]
+    h2_t = evals(d_h2.view(1, n, 4), 1, [t])[0][0]
+    zt_u = 1
+    for pt in points:
+        zt_u = zt_u * (u - pt) % P.FR_R
+    rhs_h, rhs_l, z0, off = 0, (-zt_u * h_t) % P.FR_R, None, 0
+    for kk, ((cnt, idx), ev) in enumerate(zip(groups, ev_sets)):
+        p_t = [e[0] for e in evals(d_p[off:off + cnt], cnt, [t])]
+        off += cnt
+        C_t = sum(pow(y, j, P.FR_R) * p_t[j] for j in range(cnt)) % P.FR_R
+        xs = [points[i] for i in idx]
+        R = P.interpolate(xs, [sum(pow(y, j, P.FR_R) * ev[j][q] for j in range(cnt)) % P.FR_R for q in range(len(xs))])
+        zs_t, zk_u = 1, 1
+        for q, pt in enumerate(points):
+            if q in idx:
+                zs_t = zs_t * (t - pt) % P.FR_R
+            else:
+                zk_u = zk_u * (u - pt) % P.FR_R
+        if kk == 0:
+            z0 = zk_u
+        vk = pow(v, kk, P.FR_R)
+        rhs_h = (rhs_h + vk * (C_t - P.poly_eval(R, t)) * pow(zs_t, -1, P.FR_R)) % P.FR_R
+        rhs_l = (rhs_l + vk * zk_u * (C_t - P.poly_eval(R, u))) % P.FR_R
+    assert h_t == rhs_h, "h(t)"
+    assert h2_t * z0 % P.FR_R * ((t - u) % P.FR_R) % P.FR_R == rhs_l, "h'(t)"
