@@ -443,26 +443,28 @@ def lookup_product(A: Sequence[int], S: Sequence[int], Ap: Sequence[int], Sp: Se
 
 
 def quotient_gate(adv_ext: Sequence[Sequence[int]], sel_ext: Sequence[Sequence[int]], step: int, y: int,
-                  h: Sequence[int]) -> List[int]:
+                  h: Sequence[int], rows=None, N=None):
     """evaluate_h, custom-gate part: per column (in order) h = h*y + sel*(a0 + a1*a2 - a3), rotations = step indices
-    of the extended domain (halo2-lib's vertical gate q*(a + b*c - d), rows i..i+3)."""
-    N = len(h)
-    out = list(h)
+    of the extended domain (halo2-lib's vertical gate q*(a + b*c - d), rows i..i+3).
+    rows / N: only these rows of a domain of N points (the arrays may then be sparse {index: value} maps holding just the rows
+    touched); returns {row: value}.  Same for the two functions below."""
+    N = len(h) if N is None else N
+    out = list(h) if rows is None else {i: h[i] for i in rows}
     for a, q in zip(adv_ext, sel_ext):
-        for i in range(N):
+        for i in (range(N) if rows is None else rows):
             e = (a[i] + a[(i + step) % N] * a[(i + 2 * step) % N] - a[(i + 3 * step) % N]) % FR_R
             out[i] = (out[i] * y + q[i] * e) % FR_R
     return out
 
 
 def quotient_permutation(cols_ext, sigma_ext, z_ext, chunk_len: int, step: int, last_rot: int, l0, l_last, l_active,
-                         beta: int, gamma: int, delta: int, x0: int, w_ext: int, y: int, h) -> List[int]:
+                         beta: int, gamma: int, delta: int, x0: int, w_ext: int, y: int, h, rows=None, N=None):
     """evaluate_h "Permutations" block (halo2 plonk/evaluation.rs), extended domain, X_i = x0 * w_ext^i."""
-    N = len(h)
-    out = list(h)
+    N = len(h) if N is None else N
+    out = list(h) if rows is None else {i: h[i] for i in rows}
     ns = len(z_ext)
-    xi = x0 % FR_R
-    for i in range(N):
+    for i in (range(N) if rows is None else rows):
+        xi = x0 * pow(w_ext, i, FR_R) % FR_R
         inx, ila = (i + step) % N, (i - last_rot * step) % N
         v = out[i]
         v = (v * y + (1 - z_ext[0][i]) * l0[i]) % FR_R
@@ -483,16 +485,15 @@ def quotient_permutation(cols_ext, sigma_ext, z_ext, chunk_len: int, step: int, 
                 c += 1
             v = (v * y + (left - right) * l_active[i]) % FR_R
         out[i] = v
-        xi = xi * w_ext % FR_R
     return out
 
 
 def quotient_lookup(a_ext, s_ext, ap_ext, sp_ext, z_ext, step: int, l0, l_last, l_active, beta: int, gamma: int, y: int,
-                    h) -> List[int]:
+                    h, rows=None, N=None):
     """evaluate_h "Lookups" block for single-expression lookups sharing the table s."""
-    N = len(h)
-    out = list(h)
-    for i in range(N):
+    N = len(h) if N is None else N
+    out = list(h) if rows is None else {i: h[i] for i in rows}
+    for i in (range(N) if rows is None else rows):
         inx, ipr = (i + step) % N, (i - step) % N
         v = out[i]
         for a, ap, sp, z in zip(a_ext, ap_ext, sp_ext, z_ext):

@@ -816,3 +816,58 @@ def test_shplonk_identities_at_scale(eng, cref):
         rhs_l = (rhs_l + vk * zk_u * (C_t - P.poly_eval(R, u))) % P.FR_R
     assert h_t == rhs_h, "h(t)"
     assert h2_t * z0 % P.FR_R * ((t - u) % P.FR_R) % P.FR_R == rhs_l, "h'(t)"
+
+
+def test_quotient_kernels_at_scale_on_sampled_rows(eng, cref):
+    """evaluate_h at the c2 sizes (extended domain 2^19, 64 columns / 32 permutation sets / 16 lookups per call, the calls
+    chained through h as bench.py chains them): the three device kernels against the oracle's formulas on sampled rows --
+    the first and last rows (where the rotations wrap around), and random ones."""
+    import torch
+
+    k, log_e = 17, 2
+    N = 1 << (k + log_e)
+    step = 1 << log_e
+    ncol, nsets, nlk, last_rot = 64, 32, 16, 10
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(800)
+
+    def rnd(count):
+        x = torch.randint(-(1 << 63), (1 << 63) - 1, (count, N, 4), dtype=torch.int64, device="cuda", generator=gen)
+        x[:, :, 3] &= 0x0FFFFFFFFFFFFFFF
+        return x
+
+    cols, sigma, z, sel, lp = rnd(ncol), rnd(ncol), rnd(nsets), rnd(ncol), rnd(3)
+    lk_a, lk_ap, lk_sp, lk_z, lk_s = rnd(nlk), rnd(nlk), rnd(nlk), rnd(nlk), rnd(1)
+    d_h = rnd(1)[0].contiguous()
+    rng = random.Random(801)
+    beta, gamma, delta, y, x0 = (rng.randrange(2, P.FR_R) for _ in range(5))
+    w_ext = P.fr_omega(k + log_e)
+    rows = sorted(set([0, 1, 2, step, N - 1, N - step, N - 3 * step - 1, N - last_rot * step] + [rng.randrange(N) for _ in range(12)]))
+    need = sorted(set((i + d) % N for i in rows for d in (0, step, 2 * step, 3 * step, -step, -last_rot * step)))
+    idx = torch.tensor(need, device="cuda")
+
+    def sparse(t):   # (count, N, 4) -> list of {row: int}
+        vals = cref.fr_mont_to_ints(t[:, idx, :].cpu().numpy().astype(np.uint64).reshape(-1, 4))
+        return [dict(zip(need, vals[j * len(need):(j + 1) * len(need)])) for j in range(t.shape[0])]
+
+    S = {name: sparse(t) for name, t in dict(cols=cols, sigma=sigma, z=z, sel=sel, lp=lp, a=lk_a, ap=lk_ap, sp=lk_sp, lz=lk_z, s=lk_s).items()}
+    h0 = sparse(d_h.view(1, N, 4))[0]
+    F = lambda v_: _m(cref, v_)
+    # device: gate, then permutation, then lookups, all accumulating into h
+    eng.quotient_gate_dev(cols.data_ptr(), 4 * N, sel.data_ptr(), 4 * N, ncol, k + log_e, step, F(y), d_h.data_ptr())
+    eng.quotient_permutation_dev(cols.data_ptr(), 4 * N, sigma.data_ptr(), 4 * N, z.data_ptr(), 4 * N, nsets, 2, ncol, k + log_e, step,
+                                 last_rot, lp[0].data_ptr(), lp[1].data_ptr(), lp[2].data_ptr(), F(beta), F(gamma), F(delta), F(x0),
+                                 F(w_ext), F(y), d_h.data_ptr())
+    eng.quotient_lookup_dev(lk_a.data_ptr(), 4 * N, lk_s.data_ptr(), lk_ap.data_ptr(), 4 * N, lk_sp.data_ptr(), 4 * N, lk_z.data_ptr(),
+                            4 * N, nlk, k + log_e, step, lp[0].data_ptr(), lp[1].data_ptr(), lp[2].data_ptr(), F(beta), F(gamma), F(y),
+                            d_h.data_ptr())
+    eng.sync()
+    got = sparse(d_h.view(1, N, 4))[0]
+    # oracle on the sampled rows
+    want = P.quotient_gate(S["cols"], S["sel"], step, y, h0, rows=rows, N=N)
+    want = P.quotient_permutation(S["cols"], S["sigma"], S["z"], 2, step, last_rot, S["lp"][0], S["lp"][1], S["lp"][2], beta, gamma, delta,
+                                  x0, w_ext, y, want, rows=rows, N=N)
+    want = P.quotient_lookup(S["a"], S["s"][0], S["ap"], S["sp"], S["lz"], step, S["lp"][0], S["lp"][1], S["lp"][2], beta, gamma, y, want,
+                             rows=rows, N=N)
+    for i in rows:
+        assert got[i] == want[i], ("row", i)
