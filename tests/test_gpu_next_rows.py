@@ -871,3 +871,50 @@ def test_quotient_kernels_at_scale_on_sampled_rows(eng, cref):
                              rows=rows, N=N)
     for i in rows:
         assert got[i] == want[i], ("row", i)
+
+
+def test_permutation_product_sets_at_scale(eng, cref):
+    """permutation::Argument::commit at the c2 column size (2^17 rows, 64 columns in 32 sets of 2, as bench.py calls it): the
+    recurrence z_j[i+1] * den_j(i) == z_j[i] * num_j(i) on sampled rows of every set, z_0[0] = 1 and the chaining
+    z_j[0] = z_(j-1)[usable_rows]."""
+    import torch
+
+    k, m, chunk = 17, 64, 2
+    n = 1 << k
+    usable = n - 11
+    nsets = m // chunk
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(810)
+
+    def rnd(count):
+        x = torch.randint(-(1 << 63), (1 << 63) - 1, (count, n, 4), dtype=torch.int64, device="cuda", generator=gen)
+        x[:, :, 3] &= 0x0FFFFFFFFFFFFFFF
+        return x
+
+    cols, sigma = rnd(m), rnd(m)
+    d_z = torch.zeros((nsets, n, 4), dtype=torch.int64, device="cuda")
+    rng = random.Random(811)
+    beta, gamma = rng.randrange(2, P.FR_R), rng.randrange(2, P.FR_R)
+    w, delta = P.fr_omega(k), pow(P.FR_GENERATOR, 1 << P.FR_S, P.FR_R)
+    eng.permutation_product_sets_dev(cols.data_ptr(), 4 * n, sigma.data_ptr(), 4 * n, m, chunk, k, usable, _m(cref, w), _m(cref, beta),
+                                     _m(cref, gamma), _m(cref, delta), d_z.data_ptr(), 4 * n)
+    eng.sync()
+    rows = sorted(set([0, 1, usable - 1, usable - 2] + [rng.randrange(usable) for _ in range(10)]))
+    need = sorted(set(rows + [i + 1 for i in rows] + [0, usable]))
+    idx = torch.tensor(need, device="cuda")
+
+    def sparse(t):
+        vals = cref.fr_mont_to_ints(t[:, idx, :].cpu().numpy().astype(np.uint64).reshape(-1, 4))
+        return [dict(zip(need, vals[j * len(need):(j + 1) * len(need)])) for j in range(t.shape[0])]
+
+    C, S, Z = sparse(cols), sparse(sigma), sparse(d_z)
+    assert Z[0][0] == 1
+    for j in range(nsets):
+        if j:
+            assert Z[j][0] == Z[j - 1][usable], ("chain", j)
+        for i in rows:
+            num = den = 1
+            for c in range(j * chunk, (j + 1) * chunk):
+                num = num * ((C[c][i] + beta * pow(delta, c, P.FR_R) % P.FR_R * pow(w, i, P.FR_R) + gamma) % P.FR_R) % P.FR_R
+                den = den * ((C[c][i] + beta * S[c][i] + gamma) % P.FR_R) % P.FR_R
+            assert Z[j][i + 1] * den % P.FR_R == Z[j][i] * num % P.FR_R, ("set", j, "row", i)
