@@ -87,7 +87,9 @@ int pz_bases_info(const pz_bases* bases, size_t* n_points, uint32_t* window_bits
 
 /* == best_multiexp(scalars[0..n], bases[0..n]);  n <= n_points.  Host pointers. */
 int pz_msm_g1(pz_ctx* ctx, const pz_bases* bases, const uint64_t* scalars, size_t n, uint64_t out_jac[12]);
-/* n_cols column commitments against the same bases (commit_lagrange per advice column). */
+/* n_cols column commitments against the same bases (commit_lagrange per advice column).  Host pointers (pageable or
+ * page-locked); the columns are streamed through device staging buffers in groups, uploads on a copy stream of the
+ * library's own beside the kernels of the previous group; the call returns when out_jac is complete. */
 int pz_msm_g1_batch(pz_ctx* ctx, const pz_bases* bases, const uint64_t* const* scalar_cols, size_t n_cols,
                     size_t n, uint64_t* out_jac /* n_cols x 12 */);
 /* device-resident form: scalars = n_cols columns, column j at d_scalars + j*col_stride (in u64
@@ -116,6 +118,8 @@ int pz_g1_fixed_base_mul_dev(pz_ctx* ctx, const uint64_t* d_scalars, size_t n, u
  * extended_to_coeff}:  a[k] <- sum_j a[j] * omega^(j k), natural order in and out, in place.
  * ------------------------------------------------------------------------------------------- */
 int pz_ntt_fr(pz_ctx* ctx, uint64_t* a /* 2^log_n x 4 */, const uint64_t omega[4], uint32_t log_n);
+/* n_cols transforms in place in HOST memory: column groups are uploaded, transformed and downloaded concurrently (two copy
+ * streams of the library's own + the context's stream); the call returns when every column is back. */
 int pz_ntt_fr_batch(pz_ctx* ctx, uint64_t* const* cols, size_t n_cols, const uint64_t omega[4], uint32_t log_n);
 /* device-resident, n_cols columns at d_a + j*col_stride (u64 units).  Optional fused steps
  * (either may be NULL):
