@@ -500,6 +500,11 @@ class ProofWorkload:
         self.run(1)
 
 
+def env_switches():
+    """every PZ_* / GPU_MAX_HW_QUEUES environment switch in effect, for the JSON line"""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("PZ_") or k == "GPU_MAX_HW_QUEUES"}
+
+
 class _null:
     def __enter__(self):
         return self
@@ -604,12 +609,79 @@ def dropin_host_pointer_path(wl, torch, log, sample=256):
                     "binding and is not counted" % (n_wit, wl.counts["msm_full"], wl.counts["polys"], k, sh.ext_k)}
 
 
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n_gpus: int, argv) -> int:
+    """`python bench.py --gpus N` typed as it stands (no WORLD_SIZE in the environment): this parent makes NO GPU call
+    (it never imports torch or the library) and starts `python -m torch.distributed.run` as a CHILD process -- one rank
+    per GPU -- with the same arguments; the ranks' stdout / stderr are inherited, so rank 0's JSON line is this process's
+    output; returns the launcher's exit code (non-zero if any rank failed)."""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n_gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def stub_workload(args):
+    """launcher / timing-contract rehearsal with NO GPU and no library call (tests/test_bench_launcher.py, gloo on the
+    CPU): every rank runs the same barrier + max-over-ranks timing as the real workloads around a host-only loop and
+    rank 0 prints the JSON line.  The line is marked not comparable: it measures nothing of the hot path."""
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend or "gloo", rank=rank, world_size=world)
+    x = np.arange(1 << 16, dtype=np.uint64)
+
+    def step():
+        return int((x * np.uint64(rank + 3)).sum() & np.uint64(0xFFFF))
+
+    for _ in range(args.warmup):
+        step()
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if use_dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64)
+    if use_dist:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "stub steps/s (launcher rehearsal, no GPU work)", "value": args.steps * world / float(tt.item()), "unit": "steps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(tt.item()) / max(1, args.steps) * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic", "comparable": False,
+                          "config": {"workload": "stub"}, "rccl_ranks": dist.get_world_size() if use_dist else 1,
+                          "backend": dist.get_backend() if use_dist else None}), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c2u", "c3", "msm22"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2u", "c3", "msm22", "stub"],
                     help="c2: encrypt proof hot path (headline); c2u: the same key size through the uniform-shape circuit (g^m over all message bits in circuit, SURVEY 8f rank 4); c3: homomorphic-add circuit at --k 15; msm22: one sharded MSM")
     ap.add_argument("--k", type=int, default=17)
     ap.add_argument("--enc-bits", type=int, default=2048)
@@ -633,7 +705,15 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0, help="msm22 workload on ONE GPU: run each of W ranks' shares in turn, "
                     "print per-share stage times and the predicted W-GPU efficiency for both splits")
     ap.add_argument("--no-tail", action="store_true", help="skip the (untimed) measurement of the prover steps after the hot path")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo only with --workload stub)")
     args = ap.parse_args()
+
+    # typed as `python bench.py --gpus N` (not pre-launched by torch.distributed.run): become the launcher.  Nothing above
+    # this line has touched the GPU (numpy only), and the ranks are CHILD processes -- never an exec of this one
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if args.workload == "stub":
+        return stub_workload(args)
 
     import torch
     import torch.distributed as dist
@@ -649,7 +729,7 @@ def main():
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)  # launched by torch.distributed.run
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        dist.init_process_group(args.backend or "nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     log = (lambda s: print("[bench] " + s, file=sys.stderr, flush=True)) if rank == 0 else (lambda s: None)
 
     eng = pz.Engine(local)
@@ -673,6 +753,9 @@ def main():
             res = pzd.bench_sharded_msm(eng, torch, dist if use_dist else None, rank, world, args.log_n, args.steps,
                                         args.warmup, barrier, log, split=args.msm_split, scalars=args.msm_scalars)
         if rank == 0:
+            res["rccl_ranks"] = dist.get_world_size() if use_dist else 1
+            res["backend"] = dist.get_backend() if use_dist else None
+            res["config"]["env_switches"] = env_switches()
             print(json.dumps(res))
         if use_dist:
             dist.destroy_process_group()
@@ -831,6 +914,13 @@ def main():
         "breakdown_ms_per_proof": {"trace": trace_ms / args.steps, "expand": exp_ms / args.steps, "msm_all": msm_ms / args.steps,
                                    "msm_accumulate": acc_ms / args.steps, "ntt": ntt_ms / args.steps},
     }
+    # what RCCL itself reports (not the launcher's environment): the rank count of the process group the timing used
+    out["rccl_ranks"] = dist.get_world_size() if use_dist else 1
+    out["backend"] = dist.get_backend() if use_dist else None
+    # every PZ_* switch set for this run is echoed; anything that removes or resizes work inside the timed region
+    # (PZ_BENCH_SKIP, --scale) marks the line as not comparable
+    out["config"]["env_switches"] = env_switches()
+    out["comparable"] = bool(args.scale == 1.0 and not os.environ.get("PZ_BENCH_SKIP"))
     if tail is not None:
         out["next_rows_ms_per_proof"] = tail
     if body is not None:
