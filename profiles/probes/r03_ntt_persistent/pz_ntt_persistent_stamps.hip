@@ -29,7 +29,6 @@ struct NttPass {
     size_t n;           // total transform size
     unsigned T;         // tile width
     size_t n1, n2;      // final pass: hi = n1*n2, output index = k1 + n1*k2 + hi*k
-    unsigned swap;      // 1: grid.x = column, grid.y = tile (set by the launch helpers)
 };
 
 __device__ __forceinline__ unsigned bitrev32(unsigned x, unsigned bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
@@ -49,26 +48,38 @@ extern __shared__ __attribute__((aligned(16))) unsigned char pz_smem[];
 //   stages, far from 2^261, so nothing is reduced inside a pass.  A pass ends in a Montgomery
 //   product wherever the algorithm has one (inter-pass twiddle, post scale: value < 2p, one conditional
 //   subtraction before the store) and in the conditional-subtraction ladder from 32p otherwise.
+//
+// Round 3: the kernels are PERSISTENT and SOFTWARE-PIPELINED.  Round 2's kernels ran load -> stages -> store per workgroup
+// and the workgroups of a CU marched through those phases together: memory idle while the multiplier worked and the other way
+// round (57 us per polynomial = ~31 us of products + ~26 us of tile movement that did not overlap).  Now a
+// workgroup loops over its tiles and issues the global loads of tile i+1 (into registers) before the stages of tile i, so
+// they fly under ~10 us of butterflies.  Two things make that work on CDNA4:
+//   * vmcnt retires in order, so NO global load may sit inside the stage loop (waiting for a twiddle would wait for the
+//     prefetch): the stage twiddles omega^(j n/R), j < R/2, live in LDS in raw 9-limb form (9 KiB), loaded once per workgroup;
+//   * three workgroups per CU (3 waves per SIMD, <= 168 VGPRs): the 29-bit product already issues at 97 % of its rate
+//     with 2 waves per SIMD (profiles/r03_occupancy_probe.txt), the registers go to the prefetch.
+// Intermediate passes store the product's result packed but NOT canonicalised (< 2p < 2^256: the ping-pong buffer never
+// crosses the ABI); only the last pass writes canonical values.
 // ------------------------------------------------------------------------------------------------
 typedef F29<FrTag> Fr29;
 
-#ifndef NTT_LB
-#define NTT_LB 4u    // elements a thread loads per batch of outstanding global loads
-#endif
-// a tile element to HBM.  CANON: the ABI's canonical representative (value below 2^(J+1) p).  Otherwise the packed 256-bit
-// integer as it is (tight limbs, below 2p after a product): the ping-pong buffer between two passes never crosses the ABI,
-// and the next pass takes any tight value below 2p
-template <bool CANON, unsigned J> __device__ __forceinline__ void ntt_store(Fp<FrTag>* p, const F29<FrTag>& x) {
-    if (CANON) {
-        f29_store<J>(p, x);
-    } else {
-        u32 w[8];
-        f29_pack(x, w);
-        uint4* q = reinterpret_cast<uint4*>(p);
-        q[0] = make_uint4(w[0], w[1], w[2], w[3]);
-        q[1] = make_uint4(w[4], w[5], w[6], w[7]);
-    }
+// ---- PROBE BUILD ONLY: per-phase cycle accumulation (s_memtime) ----
+__device__ unsigned long long pz_stamp_acc[16];
+struct Stamps { unsigned long long prev; unsigned long long a[12]; };
+#define STAMP_INIT(S) do { for (int i_ = 0; i_ < 12; ++i_) (S).a[i_] = 0; (S).prev = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP(S, i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); (S).a[i] += t_ - (S).prev; (S).prev = t_; } while (0)
+#define STAMP_FLUSH(S) do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&pz_stamp_acc[i_], (S).a[i_]); atomicAdd(&pz_stamp_acc[15], 1ull); } } while (0)
+extern "C" int pz_probe_stamps(unsigned long long* out, int reset) {
+    if (out) { if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pz_stamp_acc), sizeof(unsigned long long) * 16) != hipSuccess) return -1; }
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pz_stamp_acc), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
 }
+
+#define NTT_EPT 4u            // elements per thread and tile: a tile holds at most 256 * NTT_EPT = 1024 elements
+#define NTT_TILE_MAX (256u * NTT_EPT)
+#ifndef NTT_WG_PER_CU
+#define NTT_WG_PER_CU 3u
+#endif
 
 // tile index -> LDS word offset: 9 words per element and ONE PAD ELEMENT PER 32, which spreads the power-of-two
 // element strides of the bit-reversed fill and of the first pair of stages over all banks (without it 69 % of the
@@ -86,6 +97,28 @@ __device__ __forceinline__ void lds29_put(u32* sm, unsigned e, const Fr29& a) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) p[i] = a.v[i];
 }
+// stage twiddle j of the LDS table (raw limbs, 9 words per entry)
+__device__ __forceinline__ Fr29 ldstw_get(const u32* twl, unsigned j) {
+    Fr29 r;
+    const u32* p = twl + j * 9u;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.v[i] = p[i];
+    return r;
+}
+// words of LDS in front of the twiddle table: the padded tile
+__device__ __host__ __forceinline__ unsigned ntt_tile_words(unsigned elems) { return (elems + (elems >> 5) + 1u) * 9u; }
+
+// twl[j] = omega^(j * n / R) * 2^261, j < R / 2: every twiddle the stages of an R-point transform use
+__device__ __forceinline__ void ntt_fill_twiddles(u32* twl, const Fr* __restrict__ tw, unsigned logR, unsigned n) {
+    const unsigned half = (1u << logR) >> 1, step = n >> logR;
+    for (unsigned j = threadIdx.x; j < half; j += blockDim.x) {
+        const Fr29 w = f29_load<FrTag>(tw + (size_t)j * step);
+        u32* p = twl + j * 9u;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) p[i] = w.v[i];
+    }
+}
+
 // radix-2 butterfly on carried inputs (u any value, v the already multiplied, tight operand below 2p)
 __device__ __forceinline__ void bf29(const Fr29& u, const Fr29& v, Fr29& sum, Fr29& diff) {
     sum = f29_add(u, v);
@@ -97,15 +130,16 @@ __device__ __forceinline__ void bf29(const Fr29& u, const Fr29& v, Fr29& sum, Fr
 // four products as two radix-2 layers) and the tile crosses LDS and a barrier once per pair of stages instead of
 // once per stage.  Stages 0+1 cost one product per group (their other twiddles are 1).  An odd logR ends with one
 // plain radix-2 stage.  element (j, t) lives at tile index j*sr + t*st.  Input must be stored bit-reversed in j.
+// Twiddles come from the LDS table twl (ntt_fill_twiddles): no global load inside the stages.
 __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, unsigned sr, unsigned st, bool t_fastest,
-                                          const Fr* __restrict__ tw, size_t n_) {
-    const unsigned n = (unsigned)n_;   // n <= 2^27: twiddle indices fit 32 bits
+                                          const u32* twl, Stamps& S) {
     const unsigned R = 1u << logR;
     const unsigned logT = 31u - (unsigned)__builtin_clz(T);
     unsigned s = 0;
     for (; s + 1 < logR; s += 2) {
         const unsigned h = 1u << s;
         const unsigned nq = (R >> 2) * T;
+        const unsigned sh1 = logR - s - 1, sh2 = logR - s - 2;   // twiddle index = position << shift
         for (unsigned id = threadIdx.x; id < nq; id += blockDim.x) {
             unsigned t, q;
             if (t_fastest) {
@@ -120,19 +154,20 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
             const unsigned e0 = base * sr + t * st, dh = h * sr;
             Fr29 a0 = lds29_get(sm, e0), a1 = lds29_get(sm, e0 + dh), a2 = lds29_get(sm, e0 + 2 * dh), a3 = lds29_get(sm, e0 + 3 * dh);
             Fr29 b0, b1, b2, b3, o0, o1, o2, o3;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); STAMP(S, 2);
             if (s) {  // kernel-uniform branch
                 // tile elements arrive with limbs < 2^31.3 (uncarried outputs of the previous pair of stages): legal as
                 // they are for the operands that get multiplied (a1, a3); the two that are only added (a0, a2) take one
                 // parallel carry round each
                 a0 = f29_carry(a0);
                 a2 = f29_carry(a2);
-                const Fr29 w = f29_load<FrTag>(tw + pos * (n >> (s + 1)));
+                const Fr29 w = ldstw_get(twl, pos << sh1);
                 a1 = f29_mul(a1, w);
                 a3 = f29_mul(a3, w);
                 bf29(a0, a1, b0, b1);
                 bf29(a2, a3, b2, b3);
-                b2 = f29_mul(b2, f29_load<FrTag>(tw + pos * (n >> (s + 2))));
-                b3 = f29_mul(b3, f29_load<FrTag>(tw + (pos + h) * (n >> (s + 2))));
+                b2 = f29_mul(b2, ldstw_get(twl, pos << sh2));
+                b3 = f29_mul(b3, ldstw_get(twl, (pos + h) << sh2));
                 bf29(b0, b2, o0, o2);
             } else {
                 // stages 0 + 1: operands straight from the load (tight, value < 2p); the first layer's twiddles and the
@@ -141,18 +176,20 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
                 b1 = f29_sub<2, 29>(a0, a1);
                 b2 = f29_add(a2, a3);          // un-multiplied: limbs < 2^30, value < 4p -> subtrahend of f29_sub<4, 30>
                 b3 = f29_sub<2, 29>(a2, a3);
-                b3 = f29_mul(b3, f29_load<FrTag>(tw + (pos + h) * (n >> (s + 2))));
+                b3 = f29_mul(b3, ldstw_get(twl, (pos + h) << sh2));
                 o0 = f29_add(b0, b2);
                 o2 = f29_sub<4, 30>(b0, b2);
             }
             bf29(b1, b3, o1, o3);
-            // outputs stay uncarried: limbs < 2^31.3, values grow by at most 4p per pair of stages
+            STAMP(S, 3);
             lds29_put(sm, e0, o0);
             lds29_put(sm, e0 + 2 * dh, o2);
             lds29_put(sm, e0 + dh, o1);
             lds29_put(sm, e0 + 3 * dh, o3);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); STAMP(S, 4);
         __syncthreads();
+        STAMP(S, 5);
     }
     if (s < logR) {
         const unsigned half = 1u << s;
@@ -174,164 +211,260 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
             Fr29 o0, o1;
             if (s) {
                 u = f29_carry(u);
-                v = f29_mul(v, f29_load<FrTag>(tw + pos * (n >> (s + 1))));
+                v = f29_mul(v, ldstw_get(twl, pos));   // s = logR - 1: index pos << 0
                 bf29(u, v, o0, o1);
             } else {  // a single stage (logR == 1): operands straight from the load (tight, < 2p)
                 o0 = f29_add(u, v);
                 o1 = f29_sub<2, 29>(u, v);
             }
             lds29_put(sm, e0, o0);
-            lds29_put(sm, e1, o1);
+            lds29_put(sm, e0 + half * sr, o1);
         }
+        STAMP(S, 6);
         __syncthreads();
+        STAMP(S, 5);
     }
 }
 
-// strided pass.  grid.x = hi * (lo / T), grid.y = column.  tw, pre: 261-domain tables
-template <bool PRE>
-__global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, size_t in_stride, size_t out_stride,
-                                                       NttPass p, const Fr* __restrict__ tw,
-                                                       const Fr* __restrict__ pre0, unsigned n_r, size_t pre_r_stride,
-                                                       size_t out_r_stride) {
-    u32* sm = reinterpret_cast<u32*>(pz_smem);
-    const unsigned R = 1u << p.logR, T = p.T;
-    const unsigned logT = 31u - (unsigned)__builtin_clz(T);
-    const size_t tiles = p.lo >> logT;   // lo, T powers of two
-    // columns of a batch share the pre-scale and twiddle tables: with the column in grid.x (dispatched fastest) the
-    // same tile of every column runs back to back and the table rows it needs stay in L2
-    const size_t bx = p.swap ? blockIdx.y : blockIdx.x, by = p.swap ? blockIdx.x : blockIdx.y;
-    const size_t h = bx / tiles, lt = bx % tiles;
-    const Fr* src = in + by * in_stride;
-    Fr* dst = out + by * out_stride;
-    const size_t base = h * R * p.lo + lt * T;
-    // global loads are issued NTT_LB elements at a time before anything waits on them (one exposed memory round trip per
-    // batch instead of two per element: the load, then the pre-scale table row)
-    const unsigned nelem = R * T;
-    // n_r > 1: the first pass of the coset-extended transform -- the SAME input tile, pre-scaled by n_r different tables
-    // (one per coset) into n_r outputs; the tile is re-read from L2, not from HBM, and one launch does the work of n_r
-    Fr* const dst0 = dst;
-    for (unsigned rr = 0; rr < n_r; ++rr) {
-    const Fr* __restrict__ pre = pre0 + (size_t)rr * pre_r_stride;
-    dst = dst0 + (size_t)rr * out_r_stride;
-    if (rr) __syncthreads();   // the previous coset's stores have read the tile
-    for (unsigned i0 = 0; i0 < nelem; i0 += NTT_LB * 256u) {
-        Fr raw[NTT_LB], praw[NTT_LB];
-#pragma unroll
-        for (unsigned k = 0; k < NTT_LB; ++k) {
-            const unsigned idx = (i0 + k * 256u + threadIdx.x) & (nelem - 1);   // lanes past the tile re-read one of its elements: no branch around the loads
-            const size_t g = base + (size_t)(idx >> logT) * p.lo + (idx & (T - 1));
-            raw[k] = fp_load<FrTag>(src + g);
-            if (PRE) praw[k] = fp_load<FrTag>(pre + g);
-        }
-#pragma unroll
-        for (unsigned k = 0; k < NTT_LB; ++k) {
-            const unsigned idx = i0 + k * 256u + threadIdx.x;
-            if (idx < nelem) {
-                Fr29 x = f29_from_fp(raw[k]);
-                if (PRE) x = f29_mul(x, f29_from_fp(praw[k]));
-                lds29_put(sm, bitrev32(idx >> logT, p.logR) * T + (idx & (T - 1)), x);
-            }
-        }
-    }
-    __syncthreads();
-    lds_dit29(sm, p.logR, T, T, 1, true, tw, p.n);
-    for (unsigned i0 = 0; i0 < nelem; i0 += NTT_LB * 256u) {
-        Fr traw[NTT_LB];
-#pragma unroll
-        for (unsigned k = 0; k < NTT_LB; ++k) {
-            const unsigned idx = (i0 + k * 256u + threadIdx.x) & (nelem - 1);
-            traw[k] = fp_load<FrTag>(tw + p.tw_mul * (lt * T + (idx & (T - 1))) * (idx >> logT));  // exponent < n by construction
-        }
-#pragma unroll
-        for (unsigned k = 0; k < NTT_LB; ++k) {
-            const unsigned idx = i0 + k * 256u + threadIdx.x;
-            if (idx < nelem) {
-                const unsigned kk = idx >> logT, t = idx & (T - 1);
-                // always through the product (tw[0] = 1): the result is below 2p whatever the stages accumulated
-                const Fr29 x = f29_mul(lds29_get(sm, kk * T + t), f29_from_fp(traw[k]));
-                ntt_store<false, 1>(dst + base + (size_t)kk * p.lo + t, x);
-            }
-        }
-    }
+// a tile element to HBM.  CANON: the ABI's canonical representative (the value must be below 2^(J+1) p); otherwise the
+// packed 256-bit integer as it is (tight limbs, < 2p after a product): internal ping-pong buffers only
+template <bool CANON, unsigned J> __device__ __forceinline__ void ntt_store(Fr* p, const Fr29& x) {
+    if (CANON) {
+        f29_store<J>(p, x);
+    } else {
+        u32 w[8];
+        f29_pack(x, w);
+        uint4* q = reinterpret_cast<uint4*>(p);
+        q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        q[1] = make_uint4(w[4], w[5], w[6], w[7]);
     }
 }
 
-// final pass.  grid.x = n2 * (n1 / T), grid.y = column
+// strided pass.  Work item = (tile bx = h * (lo / T) + lt, column by), column fastest: the workgroups running at the same
+// time work on the same tile of neighbouring columns and share its pre-scale / twiddle table rows in L2.  n_r > 1: the first
+// pass of the coset-extended transform -- the SAME input tile (kept in registers), pre-scaled by n_r different tables (one
+// per coset) into n_r outputs.  tw, pre: 261-domain tables.  Output: packed, below 2p, not canonical (always a ping-pong buffer).
 template <bool PRE>
-__global__ __launch_bounds__(256) void k_ntt_final29(const Fr* in, Fr* out, size_t in_stride, size_t out_stride,
-                                                     NttPass p, const Fr* __restrict__ tw, const Fr* __restrict__ pre,
-                                                     Fr post, int has_post) {
+__global__ __launch_bounds__(256, NTT_WG_PER_CU) void k_ntt_strided29(const Fr* in, Fr* out, size_t in_stride, size_t out_stride,
+                                                                     NttPass p, const Fr* __restrict__ tw,
+                                                                     const Fr* __restrict__ pre0, unsigned n_r, size_t pre_r_stride,
+                                                                     size_t out_r_stride, unsigned ncols, unsigned n_items) {
     u32* sm = reinterpret_cast<u32*>(pz_smem);
     const unsigned R = 1u << p.logR, T = p.T;
     const unsigned logT = 31u - (unsigned)__builtin_clz(T);
-    const size_t tiles = p.n1 >> logT;
-    const size_t bx = p.swap ? blockIdx.y : blockIdx.x, by = p.swap ? blockIdx.x : blockIdx.y;
-    const size_t k2 = bx / tiles, k1_0 = (bx % tiles) * T;
-    const Fr* src = in + by * in_stride;
-    Fr* dst = out + by * out_stride;
-    const unsigned nelem = R * T;
-    for (unsigned i0 = 0; i0 < nelem; i0 += NTT_LB * 256u) {
-        Fr raw[NTT_LB], praw[NTT_LB];
+    const unsigned nelem = R * T, lo = (unsigned)p.lo, tiles = lo >> logT;   // lo, T powers of two
+    u32* twl = sm + ntt_tile_words(nelem);
+    ntt_fill_twiddles(twl, tw, p.logR, (unsigned)p.n);
+    unsigned item = blockIdx.x;
+    if (item >= n_items) return;
+    // this thread's NTT_EPT slots of a tile: idx = k * 256 + threadIdx.x -> row idx >> logT, column idx & (T - 1)
+    auto slot_off = [&](unsigned k) {   // offset inside the column's slab (lanes past a small tile re-read one of its elements)
+        const unsigned idx = (k * 256u + threadIdx.x) & (nelem - 1);
+        return (idx >> logT) * lo + (idx & (T - 1));
+    };
+    auto item_base = [&](unsigned it, unsigned& by, unsigned& lt) {
+        by = it % ncols;
+        const unsigned bx = it / ncols;
+        lt = bx % tiles;
+        return (size_t)(bx / tiles) * R * lo + (size_t)lt * T;
+    };
+    Fr raw[NTT_EPT], praw[NTT_EPT];
+    unsigned by, lt;
+    Stamps S; STAMP_INIT(S);
+    size_t base = item_base(item, by, lt);
 #pragma unroll
-        for (unsigned k = 0; k < NTT_LB; ++k) {
-            const unsigned idx = (i0 + k * 256u + threadIdx.x) & (nelem - 1);
-            const size_t g = ((k1_0 + (idx >> p.logR)) * p.n2 + k2) * R + (idx & (R - 1));
-            raw[k] = fp_load<FrTag>(src + g);
-            if (PRE) praw[k] = fp_load<FrTag>(pre + g);
+    for (unsigned k = 0; k < NTT_EPT; ++k) {
+        raw[k] = fp_load<FrTag>(in + by * in_stride + base + slot_off(k));
+        if (PRE) praw[k] = fp_load<FrTag>(pre0 + base + slot_off(k));
+    }
+    for (;;) {
+        const unsigned next = item + gridDim.x;
+        Fr* const dst0 = out + by * out_stride + base;
+        const unsigned lt_cur = lt;
+        for (unsigned rr = 0; rr < n_r; ++rr) {
+            STAMP(S, 11);
+            // the tile into LDS, rows bit-reversed
+#pragma unroll
+            for (unsigned k = 0; k < NTT_EPT; ++k) {
+                const unsigned idx = k * 256u + threadIdx.x;
+                if (idx < nelem) {
+                    Fr29 x = f29_from_fp(raw[k]);
+                    if (PRE) x = f29_mul(x, f29_from_fp(praw[k]));
+                    lds29_put(sm, bitrev32(idx >> logT, p.logR) * T + (idx & (T - 1)), x);
+                }
+            }
+            // the NEXT tile's input goes in flight under this round's stages (HBM latency); the next round's pre-scale rows
+            // (L2-resident tables, shared by every column) are requested after the stages, under the epilogue's products:
+            // they are never live inside the stage loop
+            STAMP(S, 0);
+            const bool last = rr + 1 == n_r;
+            size_t pbase = base + (size_t)(rr + 1) * pre_r_stride;
+            if (last && next < n_items) {
+                base = item_base(next, by, lt);
+                pbase = base;
+#pragma unroll
+                for (unsigned k = 0; k < NTT_EPT; ++k) raw[k] = fp_load<FrTag>(in + by * in_stride + base + slot_off(k));
+            }
+            STAMP(S, 1);
+            __syncthreads();
+            STAMP(S, 5);
+            lds_dit29(sm, p.logR, T, T, 1, true, twl, S);
+            // inter-pass twiddle omega^(tw_mul * l * k) and store.  Always through the product (tw[0] = 1): the result is
+            // below 2p whatever the stages accumulated
+            Fr traw[NTT_EPT];
+#pragma unroll
+            for (unsigned k = 0; k < NTT_EPT; ++k) {
+                const unsigned idx = (k * 256u + threadIdx.x) & (nelem - 1);
+                traw[k] = fp_load<FrTag>(tw + (unsigned)p.tw_mul * (lt_cur * T + (idx & (T - 1))) * (idx >> logT));  // exponent < n by construction
+            }
+            if (PRE && (!last || next < n_items)) {
+#pragma unroll
+                for (unsigned k = 0; k < NTT_EPT; ++k) praw[k] = fp_load<FrTag>(pre0 + pbase + slot_off(k));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(S, 7);
+            Fr* const dst = dst0 + (size_t)rr * out_r_stride;
+#pragma unroll
+            for (unsigned k = 0; k < NTT_EPT; ++k) {
+                const unsigned idx = k * 256u + threadIdx.x;
+                if (idx < nelem) {
+                    const Fr29 x = f29_mul(lds29_get(sm, idx), f29_from_fp(traw[k]));
+                    ntt_store<false, 1>(dst + (idx >> logT) * lo + (idx & (T - 1)), x);
+                }
+            }
+            STAMP(S, 8);
+            __syncthreads();   // the tile is free again
+            STAMP(S, 9);
         }
+        if (next >= n_items) break;
+        item = next;
+    }
+    STAMP_FLUSH(S);
+}
+
+// final pass.  Work item = (bx = k2 * (n1 / T) + tile, column by), column fastest.  Output canonical.
+template <bool PRE>
+__global__ __launch_bounds__(256, NTT_WG_PER_CU) void k_ntt_final29(const Fr* in, Fr* out, size_t in_stride, size_t out_stride,
+                                                                   NttPass p, const Fr* __restrict__ tw, const Fr* __restrict__ pre,
+                                                                   Fr post, int has_post, unsigned ncols, unsigned n_items) {
+    u32* sm = reinterpret_cast<u32*>(pz_smem);
+    const unsigned R = 1u << p.logR, T = p.T;
+    const unsigned logT = 31u - (unsigned)__builtin_clz(T);
+    const unsigned nelem = R * T, tiles = (unsigned)(p.n1 >> logT), n2 = (unsigned)p.n2;
+    u32* twl = sm + ntt_tile_words(nelem);
+    ntt_fill_twiddles(twl, tw, p.logR, (unsigned)p.n);
+    unsigned item = blockIdx.x;
+    if (item >= n_items) return;
+    // input element of slot k: row (idx >> logR) of the tile, position idx & (R - 1) along the contiguous R
+    auto in_off = [&](unsigned k, unsigned k1_0, unsigned k2) {
+        const unsigned idx = (k * 256u + threadIdx.x) & (nelem - 1);
+        return (size_t)((k1_0 + (idx >> p.logR)) * n2 + k2) * R + (idx & (R - 1));
+    };
+    auto decode = [&](unsigned it, unsigned& by, unsigned& k1_0, unsigned& k2) {
+        by = it % ncols;
+        const unsigned bx = it / ncols;
+        k2 = bx / tiles;
+        k1_0 = (bx % tiles) * T;
+    };
+    Fr raw[NTT_EPT], praw[NTT_EPT];
+    unsigned by, k1_0, k2;
+    Stamps S; STAMP_INIT(S);
+    decode(item, by, k1_0, k2);
 #pragma unroll
-        for (unsigned k = 0; k < NTT_LB; ++k) {
-            const unsigned idx = i0 + k * 256u + threadIdx.x;
+    for (unsigned k = 0; k < NTT_EPT; ++k) {
+        raw[k] = fp_load<FrTag>(in + by * in_stride + in_off(k, k1_0, k2));
+        if (PRE) praw[k] = fp_load<FrTag>(pre + in_off(k, k1_0, k2));
+    }
+    const Fr29 post29 = f29_from_fp(post);
+    for (;;) {
+        const unsigned next = item + gridDim.x;
+        Fr* const dst = out + by * out_stride + k1_0 + (size_t)p.n1 * k2;
+#pragma unroll
+        for (unsigned k = 0; k < NTT_EPT; ++k) {
+            const unsigned idx = k * 256u + threadIdx.x;
             if (idx < nelem) {
                 Fr29 x = f29_from_fp(raw[k]);
                 if (PRE) x = f29_mul(x, f29_from_fp(praw[k]));
                 lds29_put(sm, (idx >> p.logR) * R + bitrev32(idx & (R - 1), p.logR), x);
             }
         }
-    }
-    __syncthreads();
-    lds_dit29(sm, p.logR, T, 1, R, false, tw, p.n);
-    const Fr29 post29 = f29_from_fp(post);
-    for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
-        unsigned k = idx >> logT, r = idx & (T - 1);
-        Fr29 x = lds29_get(sm, r * R + k);
-        Fr* o = dst + (k1_0 + r) + p.n1 * k2 + p.hi * (size_t)k;
-        if (has_post) ntt_store<true, 1>(o, f29_mul(x, post29));
-        else ntt_store<true, 4>(o, x);
+        if (next < n_items) {
+            decode(next, by, k1_0, k2);
+#pragma unroll
+            for (unsigned k = 0; k < NTT_EPT; ++k) {
+                raw[k] = fp_load<FrTag>(in + by * in_stride + in_off(k, k1_0, k2));
+                if (PRE) praw[k] = fp_load<FrTag>(pre + in_off(k, k1_0, k2));
+            }
+        }
+        __syncthreads();
+        lds_dit29(sm, p.logR, T, 1, R, false, twl, S);
+#pragma unroll
+        for (unsigned k0 = 0; k0 < NTT_EPT; ++k0) {
+            const unsigned idx = k0 * 256u + threadIdx.x;
+            if (idx < nelem) {
+                const unsigned k = idx >> logT, r = idx & (T - 1);
+                const Fr29 x = lds29_get(sm, r * R + k);
+                Fr* o = dst + r + p.hi * (size_t)k;
+                if (has_post) ntt_store<true, 1>(o, f29_mul(x, post29));
+                else ntt_store<true, 4>(o, x);
+            }
+        }
+        __syncthreads();
+        if (next >= n_items) break;
+        item = next;
     }
 }
 
 // final pass of the coset-EXTENDED transform (coeff_to_extended): the 2^e * n point NTT of a zero-extended
 // n-coefficient polynomial is 2^e independent n-point NTTs of a[i] * (g * w_ext^r)^i, r < 2^e, interleaved
 // as out[2^e * q + r].  The strided pass has already run per r (inputs at in + r * in_r_stride); this
-// block finishes T rows for ALL r at once so every store is a full T * 2^e * 32-byte run.
+// workgroup finishes T rows for ALL r at once so every store is a full T * 2^e * 32-byte run.
 template <bool PRE>
-__global__ __launch_bounds__(256) void k_ntt_final_ext29(const Fr* in, Fr* out, size_t in_stride, size_t in_r_stride,
-                                                         size_t out_stride, NttPass p, unsigned log_e,
-                                                         const Fr* __restrict__ tw, const Fr* __restrict__ pre,
-                                                         size_t pre_r_stride) {
+__global__ __launch_bounds__(256, NTT_WG_PER_CU) void k_ntt_final_ext29(const Fr* in, Fr* out, size_t in_stride, size_t in_r_stride,
+                                                                       size_t out_stride, NttPass p, unsigned log_e,
+                                                                       const Fr* __restrict__ tw, const Fr* __restrict__ pre,
+                                                                       size_t pre_r_stride, unsigned ncols, unsigned n_items,
+                                                                       unsigned r_base, unsigned log_e_out) {
+    // log_e: cosets held by one tile; they are cosets r_base .. r_base + 2^log_e - 1 of the 2^log_e_out interleaved in the output
+    // (a tile holds them all except for tiny single-pass transforms, which take several launches)
     u32* sm = reinterpret_cast<u32*>(pz_smem);
     const unsigned R = 1u << p.logR, T = p.T, E = 1u << log_e;
     const unsigned logT = 31u - (unsigned)__builtin_clz(T);
-    const size_t tiles = p.n1 >> logT;
-    const size_t bx = p.swap ? blockIdx.y : blockIdx.x, by = p.swap ? blockIdx.x : blockIdx.y;
-    const size_t k2 = bx / tiles, k1_0 = (bx % tiles) * T;
-    const Fr* src = in + by * in_stride;
-    Fr* dst = out + by * out_stride;
-    const unsigned nelem = R * T * E;
-    for (unsigned i0 = 0; i0 < nelem; i0 += NTT_LB * 256u) {
-        Fr raw[NTT_LB], praw[NTT_LB];
+    const unsigned nelem = R * T * E, tiles = (unsigned)(p.n1 >> logT), n2 = (unsigned)p.n2;
+    u32* twl = sm + ntt_tile_words(nelem);
+    ntt_fill_twiddles(twl, tw, p.logR, (unsigned)p.n);
+    unsigned item = blockIdx.x;
+    if (item >= n_items) return;
+    auto decode = [&](unsigned it, unsigned& by, unsigned& k1_0, unsigned& k2) {
+        by = it % ncols;
+        const unsigned bx = it / ncols;
+        k2 = bx / tiles;
+        k1_0 = (bx % tiles) * T;
+    };
+    // slot k: position j along R, row rr of the tile, coset r
+    auto in_g = [&](unsigned k, unsigned k1_0, unsigned k2, unsigned& r) {
+        const unsigned idx = (k * 256u + threadIdx.x) & (nelem - 1);
+        const unsigned j = idx & (R - 1), rr = (idx >> p.logR) & (T - 1);
+        r = idx >> (p.logR + logT);
+        return (size_t)((k1_0 + rr) * n2 + k2) * R + j;
+    };
+    Fr raw[NTT_EPT], praw[NTT_EPT];
+    unsigned by, k1_0, k2;
+    Stamps S; STAMP_INIT(S);
+    decode(item, by, k1_0, k2);
 #pragma unroll
-        for (unsigned k = 0; k < NTT_LB; ++k) {
-            const unsigned idx = (i0 + k * 256u + threadIdx.x) & (nelem - 1);
-            const unsigned j = idx & (R - 1), rr = (idx >> p.logR) & (T - 1), r = idx >> (p.logR + logT);
-            const size_t g = ((k1_0 + rr) * p.n2 + k2) * R + j;
-            raw[k] = fp_load<FrTag>(src + (size_t)r * in_r_stride + g);
-            if (PRE) praw[k] = fp_load<FrTag>(pre + (size_t)r * pre_r_stride + g);
-        }
+    for (unsigned k = 0; k < NTT_EPT; ++k) {
+        unsigned r;
+        const size_t g = in_g(k, k1_0, k2, r);
+        raw[k] = fp_load<FrTag>(in + by * in_stride + (size_t)(r_base + r) * in_r_stride + g);
+        if (PRE) praw[k] = fp_load<FrTag>(pre + (size_t)(r_base + r) * pre_r_stride + g);
+    }
+    for (;;) {
+        const unsigned next = item + gridDim.x;
+        Fr* const dst = out + by * out_stride;
+        const unsigned k1_cur = k1_0, k2_cur = k2;
 #pragma unroll
-        for (unsigned k = 0; k < NTT_LB; ++k) {
-            const unsigned idx = i0 + k * 256u + threadIdx.x;
+        for (unsigned k = 0; k < NTT_EPT; ++k) {
+            const unsigned idx = k * 256u + threadIdx.x;
             if (idx < nelem) {
                 const unsigned j = idx & (R - 1), rr = (idx >> p.logR) & (T - 1), r = idx >> (p.logR + logT);
                 Fr29 x = f29_from_fp(raw[k]);
@@ -339,13 +472,30 @@ __global__ __launch_bounds__(256) void k_ntt_final_ext29(const Fr* in, Fr* out, 
                 lds29_put(sm, (r * T + rr) * R + bitrev32(j, p.logR), x);
             }
         }
-    }
-    __syncthreads();
-    lds_dit29(sm, p.logR, T * E, 1, R, false, tw, p.n);
-    for (unsigned idx = threadIdx.x; idx < R * T * E; idx += blockDim.x) {
-        const unsigned r = idx & (E - 1), rr = (idx >> log_e) & (T - 1), k = idx >> (log_e + logT);
-        const Fr29 x = lds29_get(sm, (r * T + rr) * R + k);
-        ntt_store<true, 4>(dst + (((k1_0 + rr) + p.n1 * k2 + p.hi * (size_t)k) << log_e) + r, x);
+        if (next < n_items) {
+            decode(next, by, k1_0, k2);
+#pragma unroll
+            for (unsigned k = 0; k < NTT_EPT; ++k) {
+                unsigned r;
+                const size_t g = in_g(k, k1_0, k2, r);
+                raw[k] = fp_load<FrTag>(in + by * in_stride + (size_t)(r_base + r) * in_r_stride + g);
+                if (PRE) praw[k] = fp_load<FrTag>(pre + (size_t)(r_base + r) * pre_r_stride + g);
+            }
+        }
+        __syncthreads();
+        lds_dit29(sm, p.logR, T * E, 1, R, false, twl, S);
+#pragma unroll
+        for (unsigned k0 = 0; k0 < NTT_EPT; ++k0) {
+            const unsigned idx = k0 * 256u + threadIdx.x;
+            if (idx < nelem) {
+                const unsigned r = idx & (E - 1), rr = (idx >> log_e) & (T - 1), k = idx >> (log_e + logT);
+                const Fr29 x = lds29_get(sm, (r * T + rr) * R + k);
+                ntt_store<true, 4>(dst + (((k1_cur + rr) + p.n1 * k2_cur + p.hi * (size_t)k) << log_e_out) + r_base + r, x);
+            }
+        }
+        __syncthreads();
+        if (next >= n_items) break;
+        item = next;
     }
 }
 
@@ -354,21 +504,19 @@ __global__ __launch_bounds__(256) void k_ntt_final_ext29(const Fr* in, Fr* out, 
 #define PZ_NTT_LDS 32768
 #endif
 #define NTT29_ELEM 36u   // bytes of one tile element of the 29-bit kernels (9 words)
-static size_t ntt29_lds_bytes(size_t elems) { return (elems + (elems >> 5) + 1) * NTT29_ELEM; }
-static size_t ntt_tile_budget() {   // tile size in 32-byte units x 32 (PZ_NTT_TILE_KIB overrides for tuning: 16, 32, 64)
-    static size_t v = 0;
-    if (!v) {
-        const char* e = getenv("PZ_NTT_TILE_KIB");
-        v = e ? (size_t)atol(e) * 1024 : PZ_NTT_LDS;
-        if (v < 4096) v = PZ_NTT_LDS;
-    }
-    return v;
-}
+// LDS of a workgroup: the padded tile and, behind it, the stage twiddle table (R / 2 entries of 9 words)
+static size_t ntt29_lds_bytes(size_t elems, unsigned logR) { return ((size_t)ntt_tile_words((unsigned)elems) + (((size_t)1 << logR) >> 1) * 9u) * 4u; }
+static size_t ntt_tile_budget() { return PZ_NTT_LDS; }   // tile size in 32-byte units x 32: 1024 elements = NTT_TILE_MAX
 static unsigned pick_tile(size_t extent, unsigned logR) {
-    // 1024 elements per block (36 KiB of the 9-word elements: 4 blocks per CU); prefer 128-byte runs (T = 4) or more
+    // 1024 elements per workgroup (36 KiB of the 9-word elements + 9 KiB of twiddles: 3 workgroups per CU); prefer 128-byte runs (T = 4) or more
     unsigned T = 16;
     while (T > 1 && (((size_t)32 << logR) * T > ntt_tile_budget() || T > extent)) T >>= 1;
     return T;
+}
+// persistent grid: NTT_WG_PER_CU workgroups per CU, each looping over its share of the work items
+static unsigned ntt_grid(pz_ctx* ctx, size_t n_items) {
+    const size_t g = (size_t)ctx->cu_count * NTT_WG_PER_CU;
+    return (unsigned)(n_items < g ? n_items : g);
 }
 
 // value * 32 mod r on the host (canonical 4 x u64 in and out): a 256-domain Montgomery constant c * 2^256 becomes the
@@ -408,19 +556,20 @@ const uint64_t* pz_fr_one261() { return one261(); }   // for the other translati
 
 static int launch_strided(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t os, size_t ncols, NttPass p,
                           const Fr* tw, const Fr* pre, unsigned n_r = 1, size_t pre_r_stride = 0, size_t out_r_stride = 0) {
-    size_t blocks = p.hi * (p.lo / p.T);
-    size_t lds = ntt29_lds_bytes(((size_t)1 << p.logR) * p.T);
-    p.swap = (ncols > 1 && blocks <= 65535) ? 1u : 0u;
-    const dim3 grid = p.swap ? dim3((unsigned)ncols, (unsigned)blocks) : dim3((unsigned)blocks, (unsigned)ncols);
-    if (pre) hipLaunchKernelGGL(k_ntt_strided29<true>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, n_r, pre_r_stride, out_r_stride);
-    else hipLaunchKernelGGL(k_ntt_strided29<false>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, n_r, pre_r_stride, out_r_stride);
+    const size_t blocks = p.hi * (p.lo / p.T), n_items = blocks * ncols;
+    if (((size_t)1 << p.logR) * p.T > NTT_TILE_MAX || n_items >= ((size_t)1 << 31)) return PZ_ERR_UNSUPPORTED;
+    const size_t lds = ntt29_lds_bytes(((size_t)1 << p.logR) * p.T, p.logR);
+    const dim3 grid(ntt_grid(ctx, n_items));
+    if (pre) hipLaunchKernelGGL(k_ntt_strided29<true>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, n_r, pre_r_stride, out_r_stride, (unsigned)ncols, (unsigned)n_items);
+    else hipLaunchKernelGGL(k_ntt_strided29<false>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, n_r, pre_r_stride, out_r_stride, (unsigned)ncols, (unsigned)n_items);
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
 }
 static int launch_final(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t os, size_t ncols, NttPass p,
                         const Fr* tw, const Fr* pre, const uint64_t* post_scale) {
-    size_t blocks = p.n2 * (p.n1 / p.T);
-    size_t lds = ntt29_lds_bytes(((size_t)1 << p.logR) * p.T);
+    const size_t blocks = p.n2 * (p.n1 / p.T), n_items = blocks * ncols;
+    if (((size_t)1 << p.logR) * p.T > NTT_TILE_MAX || n_items >= ((size_t)1 << 31)) return PZ_ERR_UNSUPPORTED;
+    const size_t lds = ntt29_lds_bytes(((size_t)1 << p.logR) * p.T, p.logR);
     Fr post;
     memset(&post, 0, sizeof post);
     if (post_scale) {   // into the 261-domain
@@ -428,10 +577,27 @@ static int launch_final(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t os
         fr_times32(post_scale, ps);
         memcpy(post.v, ps, 32);
     }
-    p.swap = (ncols > 1 && blocks <= 65535) ? 1u : 0u;
-    const dim3 grid = p.swap ? dim3((unsigned)ncols, (unsigned)blocks) : dim3((unsigned)blocks, (unsigned)ncols);
-    if (pre) hipLaunchKernelGGL(k_ntt_final29<true>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, post, post_scale ? 1 : 0);
-    else hipLaunchKernelGGL(k_ntt_final29<false>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, post, post_scale ? 1 : 0);
+    const dim3 grid(ntt_grid(ctx, n_items));
+    if (pre) hipLaunchKernelGGL(k_ntt_final29<true>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, post, post_scale ? 1 : 0, (unsigned)ncols, (unsigned)n_items);
+    else hipLaunchKernelGGL(k_ntt_final29<false>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, post, post_scale ? 1 : 0, (unsigned)ncols, (unsigned)n_items);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}
+// final pass of the extended transform: T rows x 2^log_e cosets per tile (tiny single-pass transforms: as many cosets per
+// launch as a tile holds)
+static int launch_final_ext(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t in_r_stride, size_t os, size_t ncols, NttPass p,
+                            unsigned log_e, const Fr* tw, const Fr* pre, size_t pre_r_stride) {
+    const size_t blocks = p.n2 * (p.n1 / p.T), n_items = blocks * ncols;
+    const size_t rows = ((size_t)1 << p.logR) * p.T;
+    if (rows > NTT_TILE_MAX || n_items >= ((size_t)1 << 31)) return PZ_ERR_UNSUPPORTED;
+    unsigned log_et = log_e;
+    while (log_et > 0 && (rows << log_et) > NTT_TILE_MAX) --log_et;
+    const size_t lds = ntt29_lds_bytes(rows << log_et, p.logR);
+    const dim3 grid(ntt_grid(ctx, n_items));
+    for (unsigned r_base = 0; r_base < (1u << log_e); r_base += 1u << log_et) {
+        if (pre) hipLaunchKernelGGL(k_ntt_final_ext29<true>, grid, dim3(256), lds, ctx->stream, in, out, is, in_r_stride, os, p, log_et, tw, pre, pre_r_stride, (unsigned)ncols, (unsigned)n_items, r_base, log_e);
+        else hipLaunchKernelGGL(k_ntt_final_ext29<false>, grid, dim3(256), lds, ctx->stream, in, out, is, in_r_stride, os, p, log_et, tw, pre, pre_r_stride, (unsigned)ncols, (unsigned)n_items, r_base, log_e);
+    }
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
 }
@@ -570,10 +736,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
         if (npass == 1) {
             NttPass p{};
             p.logR = log_n; p.lo = 1; p.hi = 1; p.n = n; p.T = 1; p.n1 = 1; p.n2 = 1;
-            const size_t lds = ntt29_lds_bytes(((size_t)1 << p.logR) * p.T * E);
-            p.swap = 0;
-            hipLaunchKernelGGL(k_ntt_final_ext29<true>, dim3(1, (unsigned)nc), dim3(256), lds, ctx->stream, cin + c0 * is,
-                               eout + c0 * os, is, (size_t)0, os, p, log_e, tw, pre, n);
+            PZCHK(launch_final_ext(ctx, cin + c0 * is, eout + c0 * os, is, (size_t)0, os, nc, p, log_e, tw, pre, n));
         } else if (npass == 3) {
             // 2^19 .. 2^27 (config c5 runs k = 19): two strided passes per coset, then the interleaving final pass
             unsigned lg[3], rem = log_n;
@@ -594,10 +757,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
             unsigned T = 8;
             while (T > 1 && (((size_t)32 << lg[2]) * T * E > ntt_tile_budget() || T > n1)) T >>= 1;
             pc.T = T;
-            const size_t lds = ntt29_lds_bytes(((size_t)1 << lg[2]) * T * E);
-            pc.swap = (nc > 1 && n2 * (n1 / T) <= 65535) ? 1u : 0u;
-            hipLaunchKernelGGL(k_ntt_final_ext29<false>, pc.swap ? dim3((unsigned)nc, (unsigned)(n2 * (n1 / T))) : dim3((unsigned)(n2 * (n1 / T)), (unsigned)nc), dim3(256), lds, ctx->stream, tmp,
-                               eout + c0 * os, n, nc * n, os, pc, log_e, tw, (const Fr*)nullptr, (size_t)0);
+            PZCHK(launch_final_ext(ctx, tmp, eout + c0 * os, n, nc * n, os, nc, pc, log_e, tw, (const Fr*)nullptr, (size_t)0));
         } else {
             unsigned lg0 = (log_n + 1) / 2, lg1 = log_n - lg0;
             const size_t n1 = (size_t)1 << lg0, n2 = (size_t)1 << lg1;
@@ -612,10 +772,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
             unsigned T = 8;
             while (T > 1 && (((size_t)32 << lg1) * T * E > ntt_tile_budget() || T > n1)) T >>= 1;
             pc.T = T;
-            const size_t lds = ntt29_lds_bytes(((size_t)1 << lg1) * T * E);
-            pc.swap = nc > 1 ? 1u : 0u;
-            hipLaunchKernelGGL(k_ntt_final_ext29<false>, pc.swap ? dim3((unsigned)nc, (unsigned)(n1 / T)) : dim3((unsigned)(n1 / T), (unsigned)nc), dim3(256), lds, ctx->stream, tmp,
-                               eout + c0 * os, n, nc * n, os, pc, log_e, tw, (const Fr*)nullptr, (size_t)0);
+            PZCHK(launch_final_ext(ctx, tmp, eout + c0 * os, n, nc * n, os, nc, pc, log_e, tw, (const Fr*)nullptr, (size_t)0));
         }
         HIPCHK(ctx, hipGetLastError());
     }
