@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256) void k_msm_totals(u32* __restrict__ slice_hist
     totals[col * p.B + b] = run;
 }
 
+#define ITEMS_SOLO 64u   // buckets with more chunks than this get their list entries written by a whole workgroup
 // pass 2b: per column exclusive scans of the bucket totals (entry offsets) and of ceil(cnt/CHUNK) (item offsets)
 #define SCAN_THREADS 1024
 __global__ __launch_bounds__(SCAN_THREADS) void k_msm_scan(const u32* __restrict__ hist, MsmP p, u32* __restrict__ offs,
@@ -358,7 +359,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_msm_scan(const u32* __restrict
 
 // the size-ordered work item list of k_msm_accumulate: item_order[rank] = work item, item_bucket[rank] = its bucket.
 // grid (B / 256, columns): a thread per bucket; buckets with many chunks are shared by the whole workgroup afterwards
-#define ITEMS_SOLO 64u
 __global__ __launch_bounds__(256) void k_msm_items(MsmP p, const u32* __restrict__ offs, const u32* __restrict__ items,
                                                    const u32* __restrict__ pos_hi, const u32* __restrict__ pos_lo,
                                                    u32* __restrict__ item_order, u32* __restrict__ item_bucket) {
@@ -394,6 +394,185 @@ __global__ __launch_bounds__(256) void k_msm_items(MsmP p, const u32* __restrict
             const u32 pos = j < rem ? ph + j : pl + j - rem;
             ord[pos] = item0 + j;
             obk[pos] = bb;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FEW columns (one large MSM, a rank's share of it: nc <= MSM_SLICE_MAX_COLS): k_msm_scan's single workgroup per column is the
+// whole chip's critical path there (114 us for 2^15 buckets: strided global accesses from one CU, a few LDS counters every
+// thread adds to).  The same offsets, item counts and size-ordered work item list from two kernels with a thread per bucket:
+//   k_msm_totals_few : k_msm_totals + per 256-bucket block: entry sum, item sum, items by chunk size (257 bins)
+//   k_msm_items_few  : block prefix from the block sums, in-block scans, list positions = [sizes larger] + [same size in
+//                      earlier blocks] + [rank inside the block]; writes offs / items / item_order / item_bucket
+// No heavy / fold lists: the fold kernels of this path look at every bucket themselves (k_msm_fold_few).
+// ------------------------------------------------------------------------------------------------
+#define FEW_BINS (MSM_CHUNK_MAX + 1u)
+__device__ __forceinline__ u32 block_sum_256(u32 v, u32* s_tmp) {   // sum over the 256 threads of a workgroup (s_tmp: 4 words)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+}
+
+__global__ __launch_bounds__(256) void k_msm_totals_few(u32* __restrict__ slice_hist, unsigned n_slices, MsmP p,
+                                                        u32* __restrict__ totals, u32* __restrict__ blk_cnt,
+                                                        u32* __restrict__ blk_itm, u32* __restrict__ blk_bins) {
+    __shared__ u32 s_bin[FEW_BINS];
+    __shared__ u32 s_tmp[4];
+    const size_t col = blockIdx.y;
+    const unsigned nblk = gridDim.x;
+    const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
+    for (unsigned t = threadIdx.x; t < FEW_BINS; t += blockDim.x) s_bin[t] = 0;
+    u32 run = 0;
+    if (b < p.B) {
+        u32* sh = slice_hist + col * n_slices * (size_t)p.B + b;
+        unsigned sl = 0;
+        for (; sl + 8 <= n_slices; sl += 8) {   // eight loads in flight: a single column is cut into hundreds of slices
+            u32 v[8];
+#pragma unroll
+            for (unsigned k = 0; k < 8; ++k) v[k] = sh[(size_t)(sl + k) * p.B];
+#pragma unroll
+            for (unsigned k = 0; k < 8; ++k) {
+                sh[(size_t)(sl + k) * p.B] = run;
+                run += v[k];
+            }
+        }
+        for (; sl < n_slices; ++sl) {
+            const u32 v = sh[(size_t)sl * p.B];
+            sh[(size_t)sl * p.B] = run;
+            run += v;
+        }
+        totals[col * p.B + b] = run;
+    }
+    __syncthreads();
+    const u32 ch = (run + p.chunk - 1) / p.chunk;
+    if (ch) {   // even split: rem chunks of q + 1 entries, ch - rem of q
+        const u32 q = run / ch, rem = run % ch;
+        if (rem) atomicAdd(&s_bin[q + 1], rem);
+        atomicAdd(&s_bin[q], ch - rem);
+    }
+    const u32 sc = block_sum_256(run, s_tmp);
+    const u32 sm = block_sum_256(ch, s_tmp);
+    if (threadIdx.x == 0) {
+        blk_cnt[col * nblk + blockIdx.x] = sc;
+        blk_itm[col * nblk + blockIdx.x] = sm;
+    }
+    __syncthreads();
+    u32* bo = blk_bins + (col * nblk + blockIdx.x) * (size_t)FEW_BINS;
+    for (unsigned t = threadIdx.x; t < FEW_BINS; t += blockDim.x) bo[t] = s_bin[t];
+}
+
+__global__ __launch_bounds__(256) void k_msm_items_few(MsmP p, const u32* __restrict__ totals, const u32* __restrict__ blk_cnt,
+                                                       const u32* __restrict__ blk_itm, const u32* __restrict__ blk_bins,
+                                                       u32* __restrict__ offs, u32* __restrict__ items,
+                                                       u32* __restrict__ item_order, u32* __restrict__ item_bucket) {
+    __shared__ u32 s_pos[FEW_BINS], s_tot[FEW_BINS], s_rank[FEW_BINS];
+    __shared__ u32 s_tmp[4], s_wc[4], s_wm[4];
+    __shared__ u32 s_big[256];
+    __shared__ u32 s_nbig;
+    const size_t col = blockIdx.y;
+    const unsigned nblk = gridDim.x, blk = blockIdx.x;
+    const unsigned b = blk * blockDim.x + threadIdx.x;
+    if (threadIdx.x == 0) s_nbig = 0;
+    // entries / items in the blocks before this one
+    u32 pc = 0, pm = 0;
+    for (unsigned i = threadIdx.x; i < blk; i += blockDim.x) {
+        pc += blk_cnt[col * nblk + i];
+        pm += blk_itm[col * nblk + i];
+    }
+    pc = block_sum_256(pc, s_tmp);
+    pm = block_sum_256(pm, s_tmp);
+    // list positions by chunk size: items of a larger size come first, then the same size in earlier blocks
+    for (unsigned sz = threadIdx.x; sz < FEW_BINS; sz += blockDim.x) {
+        u32 tot = 0, pre = 0;
+        const u32* bb = blk_bins + col * nblk * (size_t)FEW_BINS + sz;
+        unsigned i = 0;
+        for (; i + 8 <= nblk; i += 8) {
+            u32 v[8];
+#pragma unroll
+            for (unsigned k = 0; k < 8; ++k) v[k] = bb[(size_t)(i + k) * FEW_BINS];
+#pragma unroll
+            for (unsigned k = 0; k < 8; ++k) {
+                tot += v[k];
+                if (i + k < blk) pre += v[k];
+            }
+        }
+        for (; i < nblk; ++i) {
+            const u32 v = bb[(size_t)i * FEW_BINS];
+            tot += v;
+            if (i < blk) pre += v;
+        }
+        s_tot[sz] = tot;
+        s_pos[sz] = pre;
+        s_rank[sz] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 run = 0;
+        for (int sz = (int)MSM_CHUNK_MAX; sz >= 1; --sz) {
+            s_pos[sz] += run;
+            run += s_tot[sz];
+        }
+    }
+    // in-block exclusive scans of the bucket totals and chunk counts
+    const u32 v = b < p.B ? totals[col * p.B + b] : 0u;
+    const u32 ch = (v + p.chunk - 1) / p.chunk;
+    u32 ic = v, im = ch;
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 tc = __shfl_up(ic, off, 64), tm = __shfl_up(im, off, 64);
+        if (lane >= (unsigned)off) { ic += tc; im += tm; }
+    }
+    if (lane == 63) { s_wc[wv] = ic; s_wm[wv] = im; }
+    __syncthreads();
+    u32 bc = 0, bm = 0;
+    for (unsigned k = 0; k < wv; ++k) { bc += s_wc[k]; bm += s_wm[k]; }
+    const u32 o_b = pc + bc + ic - v, it_b = pm + bm + im - ch;
+    u32* o = offs + col * (p.B + 1);
+    u32* it = items + col * (p.B + 1);
+    if (b < p.B) {
+        o[b] = o_b;
+        it[b] = it_b;
+        if (b == p.B - 1) {
+            o[p.B] = o_b + v;
+            it[p.B] = it_b + ch;
+        }
+    }
+    u32* ord = item_order + col * p.max_items;
+    u32* obk = item_bucket + col * p.max_items;
+    u32 ph = 0, pl = 0, rem = 0;
+    if (ch) {
+        const u32 q = v / ch;
+        rem = v % ch;
+        if (rem) ph = s_pos[q + 1] + atomicAdd(&s_rank[q + 1], rem);
+        pl = s_pos[q] + atomicAdd(&s_rank[q], ch - rem);
+        if (ch > ITEMS_SOLO) {
+            s_big[atomicAdd(&s_nbig, 1u)] = threadIdx.x;
+        } else {
+            for (u32 j = 0; j < ch; ++j) {
+                const u32 pos = j < rem ? ph + j : pl + j - rem;
+                ord[pos] = it_b + j;
+                obk[pos] = b;
+            }
+        }
+    }
+    // buckets with many chunks: their list entries are written by the whole workgroup (parameters through LDS)
+    __shared__ u32 s_par[256][5];
+    if (ch > ITEMS_SOLO) {
+        s_par[threadIdx.x][0] = ch; s_par[threadIdx.x][1] = rem; s_par[threadIdx.x][2] = ph; s_par[threadIdx.x][3] = pl; s_par[threadIdx.x][4] = it_b;
+    }
+    __syncthreads();
+    for (unsigned k = 0; k < s_nbig; ++k) {
+        const unsigned tt = s_big[k];
+        const u32 ch2 = s_par[tt][0], rem2 = s_par[tt][1], ph2 = s_par[tt][2], pl2 = s_par[tt][3], it2 = s_par[tt][4];
+        for (u32 j = threadIdx.x; j < ch2; j += blockDim.x) {
+            const u32 pos = j < rem2 ? ph2 + j : pl2 + j - rem2;
+            ord[pos] = it2 + j;
+            obk[pos] = blk * blockDim.x + tt;
         }
     }
 }
@@ -598,6 +777,92 @@ __global__ __launch_bounds__(256) void k_msm_medium_sum(MsmP p, const u32* __res
             __syncthreads();
         }
         if (l == 0 && m) x29_store_raw(pc, x29_load_raw(&s_pt[threadIdx.x]));
+        __syncthreads();
+    }
+}
+
+// FEW columns: the bucket folds without the scan kernel's lists.  Every addition of a fold is ~6 us of dependent latency on a
+// nearly empty chip, so a bucket's partial sums are folded by a GROUP of G lanes: strided serial sums, then a log2(G)-level
+// tree through LDS.  Launched twice: G = 4 for buckets of 2 .. MSM_FEW_SMALL chunks (uniform scalars: 8 - 9 chunks per bucket,
+// depth 2 + 2 additions), G = 32 for MSM_FEW_SMALL + 1 .. MSM_MEDIUM; longer buckets are found and folded by whole workgroups
+// in k_msm_heavy_few.  All groups of a workgroup run the same number of rounds (256 / G buckets per workgroup and round).
+#define MSM_FEW_SMALL 32u
+__global__ __launch_bounds__(256) void k_msm_fold_few(MsmP p, const u32* __restrict__ items, G1X29Raw* __restrict__ partials,
+                                                      unsigned logG, unsigned m_lo, unsigned m_hi) {
+    __shared__ G1X29Raw s_pt[256];
+    const size_t col = blockIdx.y;
+    const u32* it = items + col * (p.B + 1);
+    const unsigned G = 1u << logG, gpw = 256u >> logG;   // lanes per group, groups per workgroup
+    const unsigned g = threadIdx.x >> logG, l = threadIdx.x & (G - 1);
+    const unsigned per_round = gridDim.x * gpw;
+    const u32 rounds = (p.B + per_round - 1) / per_round;
+    for (u32 r = 0; r < rounds; ++r) {
+        const u32 b = (r * gridDim.x + blockIdx.x) * gpw + g;
+        u32 first = 0, m = 0;
+        if (b < p.B) {
+            first = it[b];
+            m = it[b + 1] - first;
+            if (m <= m_lo || m > m_hi) m = 0;
+        }
+        if (!__syncthreads_or(m != 0)) continue;   // nothing to fold in this round (block-uniform)
+        G1X29Raw* pc = partials + col * p.max_items + first;
+        G1X29 acc = x29_inf();
+        for (u32 t = l; t < m; t += G) {
+            G1X29 o = x29_load_raw(pc + t);
+            x29_add(acc, o);
+        }
+        x29_store_raw(&s_pt[threadIdx.x], acc);
+        __syncthreads();
+        for (unsigned off = G >> 1; off > 0; off >>= 1) {
+            if (l < off && l + off < m) {
+                G1X29 a = x29_load_raw(&s_pt[threadIdx.x]);
+                G1X29 o = x29_load_raw(&s_pt[threadIdx.x + off]);
+                x29_add(a, o);
+                x29_store_raw(&s_pt[threadIdx.x], a);
+            }
+            __syncthreads();
+        }
+        if (l == 0 && m) x29_store_raw(pc, x29_load_raw(&s_pt[threadIdx.x]));
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_msm_heavy_few(MsmP p, const u32* __restrict__ items, G1X29Raw* __restrict__ partials) {
+    __shared__ G1X29Raw s_pt[256];
+    __shared__ u32 s_list[256];
+    __shared__ u32 s_n;
+    const size_t col = blockIdx.y;
+    const u32* it = items + col * (p.B + 1);
+    for (unsigned b0 = blockIdx.x * 256u; b0 < p.B; b0 += gridDim.x * 256u) {
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        const unsigned bq = b0 + threadIdx.x;
+        if (bq < p.B && it[bq + 1] - it[bq] > MSM_MEDIUM) s_list[atomicAdd(&s_n, 1u)] = bq;
+        __syncthreads();
+        const unsigned nl = s_n;
+        for (unsigned k = 0; k < nl; ++k) {
+            const u32 b = s_list[k];
+            const u32 first = it[b], m = it[b + 1] - first;
+            G1X29Raw* pc = partials + col * p.max_items + first;
+            G1X29 acc = x29_inf();
+            for (u32 t = threadIdx.x; t < m; t += blockDim.x) {
+                G1X29 o = x29_load_raw(pc + t);
+                x29_add(acc, o);
+            }
+            x29_store_raw(&s_pt[threadIdx.x], acc);
+            __syncthreads();
+            for (unsigned off = 128; off > 0; off >>= 1) {
+                if (threadIdx.x < off) {
+                    G1X29 a = x29_load_raw(&s_pt[threadIdx.x]);
+                    G1X29 o = x29_load_raw(&s_pt[threadIdx.x + off]);
+                    x29_add(a, o);
+                    x29_store_raw(&s_pt[threadIdx.x], a);
+                }
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) x29_store_raw(pc, x29_load_raw(&s_pt[0]));
+            __syncthreads();
+        }
         __syncthreads();
     }
 }
@@ -969,9 +1234,12 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     PZCHK(pz_ws_get(ctx, WS_CURSOR, nc * (size_t)(p.B + 1) * 4, &heavy));
     // few columns: k_msm_scan (one workgroup per column) leaves the work item list to k_msm_items
     const bool split_items = nc <= MSM_SLICE_MAX_COLS;
-    PZCHK(pz_ws_get(ctx, WS_TOTALS, (split_items ? 3 : 1) * nc * (size_t)p.B * 4, &totals));   // bucket totals | pos_hi | pos_lo
-    u32* pos_hi = (u32*)totals + nc * (size_t)p.B;
-    u32* pos_lo = pos_hi + nc * (size_t)p.B;
+    const unsigned nblk_few = pz_div_up(p.B, 256);
+    // bucket totals | (few columns) per 256-bucket block: entry sums, item sums, items by chunk size
+    PZCHK(pz_ws_get(ctx, WS_TOTALS, nc * ((size_t)p.B + (split_items ? (size_t)nblk_few * (2 + FEW_BINS) : 0)) * 4, &totals));
+    u32* blk_cnt = (u32*)totals + nc * (size_t)p.B;
+    u32* blk_itm = blk_cnt + nc * (size_t)nblk_few;
+    u32* blk_bins = blk_itm + nc * (size_t)nblk_few;
     u32* heavy_cnt = (u32*)heavy + nc * (size_t)p.B;
     PZCHK(pz_ws_get(ctx, WS_MISC, nc * (size_t)(p.B + 1) * 4, &fold));
     u32* fold_cnt = (u32*)fold + nc * (size_t)p.B;
@@ -993,13 +1261,18 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     {
         pz_timer tsort(ctx, PZ_T_MSM_SORT);
         hipLaunchKernelGGL(k_msm_hist, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (u32*)hist, n_slices, nc);
-        hipLaunchKernelGGL(k_msm_totals, dim3(pz_div_up(p.B, 256), (unsigned)nc), dim3(256), 0, st, (u32*)hist, n_slices, p,
-                           (u32*)totals);
-        hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)nc), dim3(SCAN_THREADS), 0, st, (const u32*)totals, p, (u32*)offs, (u32*)items,
-                           (u32*)heavy, heavy_cnt, (u32*)fold, fold_cnt, split_items ? pos_hi : nullptr, pos_lo, item_order, item_bucket);
-        if (split_items)
-            hipLaunchKernelGGL(k_msm_items, dim3(pz_div_up(p.B, 256), (unsigned)nc), dim3(256), 0, st, p, (const u32*)offs,
-                               (const u32*)items, (const u32*)pos_hi, (const u32*)pos_lo, item_order, item_bucket);
+        if (split_items) {
+            // few columns: offsets, item counts and the size-ordered list from two bucket-parallel kernels (no single-workgroup scan)
+            hipLaunchKernelGGL(k_msm_totals_few, dim3(nblk_few, (unsigned)nc), dim3(256), 0, st, (u32*)hist, n_slices, p, (u32*)totals,
+                               blk_cnt, blk_itm, blk_bins);
+            hipLaunchKernelGGL(k_msm_items_few, dim3(nblk_few, (unsigned)nc), dim3(256), 0, st, p, (const u32*)totals, (const u32*)blk_cnt,
+                               (const u32*)blk_itm, (const u32*)blk_bins, (u32*)offs, (u32*)items, item_order, item_bucket);
+        } else {
+            hipLaunchKernelGGL(k_msm_totals, dim3(pz_div_up(p.B, 256), (unsigned)nc), dim3(256), 0, st, (u32*)hist, n_slices, p,
+                               (u32*)totals);
+            hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)nc), dim3(SCAN_THREADS), 0, st, (const u32*)totals, p, (u32*)offs, (u32*)items,
+                               (u32*)heavy, heavy_cnt, (u32*)fold, fold_cnt, (u32*)nullptr, (u32*)nullptr, item_order, item_bucket);
+        }
         hipLaunchKernelGGL(k_msm_scatter, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (const u32*)hist, n_slices,
                            (const u32*)offs, (u32*)entries, nc);
     }
@@ -1010,6 +1283,15 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
                            (const u32*)item_order, (const u32*)item_bucket, (const u32*)entries, (G1X29Raw*)partials);
     }
     pz_timer ttree(ctx, PZ_T_MSM_TREE);
+    if (split_items) {
+        // 4-lane groups: 64 buckets per workgroup; 32-lane groups: 8 per workgroup and round (rounds without work cost one barrier)
+        const unsigned gx4 = pz_div_up(p.B, 64), gx32 = p.B / 8 < 2048u ? (p.B / 8 ? p.B / 8 : 1u) : 2048u;
+        hipLaunchKernelGGL(k_msm_fold_few, dim3(gx4, (unsigned)nc), dim3(256), 0, st, p, (const u32*)items, (G1X29Raw*)partials, 2u, 1u, MSM_FEW_SMALL);
+        hipLaunchKernelGGL(k_msm_fold_few, dim3(gx32, (unsigned)nc), dim3(256), 0, st, p, (const u32*)items, (G1X29Raw*)partials, 5u, MSM_FEW_SMALL,
+                           MSM_MEDIUM);
+        hipLaunchKernelGGL(k_msm_heavy_few, dim3(p.B / 256 < 64u ? (p.B / 256 ? p.B / 256 : 1u) : 64u, (unsigned)nc), dim3(256), 0, st, p,
+                           (const u32*)items, (G1X29Raw*)partials);
+    } else {
     hipLaunchKernelGGL(k_msm_bucket_sum, dim3((unsigned)nc, pz_div_up(p.B, 256)), dim3(256), 0, st, p, (const u32*)items,
                        (const u32*)fold, (const u32*)fold_cnt, (G1X29Raw*)partials);
     // heavy buckets are few per column in a column batch, but a single large MSM makes every bucket heavy:
@@ -1021,6 +1303,7 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
                        (const u32*)heavy_cnt, (G1X29Raw*)partials);
     hipLaunchKernelGGL(k_msm_medium_sum, dim3(hx, (unsigned)nc), dim3(256), 0, st, p, (const u32*)items, (const u32*)heavy,
                        (const u32*)heavy_cnt, (G1X29Raw*)partials);
+    }
     if (nc <= MSM_SLICE_MAX_COLS) {
         // few columns: bit-sliced parallel reduction (depth ~ log2 B + log2 c point additions)
         const unsigned nblk = pz_div_up(p.B, 256 * SLICE_PER_THREAD);
