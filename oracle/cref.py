@@ -51,6 +51,10 @@ def lib():
         _lib.ora_fq_mul.argtypes = [U64P, U64P, U64P]
         _lib.ora_fr_scale.argtypes = [U64P, C.c_size_t, U64P]
         _lib.ora_fr_distribute_powers.argtypes = [U64P, C.c_size_t, U64P]
+        _lib.ora_check_gates.argtypes = [U64P, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_size_t)]
+        _lib.ora_check_gates.restype = C.c_size_t
+        _lib.ora_check_range.argtypes = [U64P, C.c_size_t, C.c_uint32, C.POINTER(C.c_size_t)]
+        _lib.ora_check_range.restype = C.c_size_t
     return _lib
 
 
@@ -207,3 +211,23 @@ def paillier_enc(Ln: int, n: int, g: int, m: int, r: int) -> int:
                                 _p(int_to_limbs(r, Ln)), _p(out))
     assert rc == 0, rc
     return limbs_to_int(out)
+
+
+# ------------------------------------------------------------------ MockProver analogue on whole cell streams
+def check_gates(cells_mont, sel) -> tuple:
+    """cells: (n,4) Montgomery Fr in stream order; sel: (n,) uint8 selector (1 where a gate window [a,b,c,d] starts).
+    -> (number of windows with a + b*c != d, offset of the first one or n)"""
+    c = _c(cells_mont).reshape(-1, 4)
+    s = np.ascontiguousarray(sel, dtype=np.uint8)
+    assert s.shape[0] == c.shape[0]
+    first = C.c_size_t(0)
+    bad = lib().ora_check_gates(_p(c), s.ctypes.data_as(C.POINTER(C.c_uint8)), c.shape[0], C.byref(first))
+    return int(bad), int(first.value)
+
+
+def check_range(cells_mont, bits: int) -> tuple:
+    """-> (number of cells that are not canonical integers below 2^bits, offset of the first one or n)"""
+    c = _c(cells_mont).reshape(-1, 4)
+    first = C.c_size_t(0)
+    bad = lib().ora_check_range(_p(c), c.shape[0], bits, C.byref(first))
+    return int(bad), int(first.value)

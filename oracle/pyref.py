@@ -1070,6 +1070,246 @@ def gate_offsets_circuit(kind: str, enc_bits: int, limb_bits: int, lb: int, n_st
     return gates, off
 
 
+def gate_mask_circuit(kind: str, enc_bits: int, limb_bits: int, lb: int, n_steps_g: int = 0, n_steps_r: int = 0):
+    """gate_offsets_circuit as a numpy uint8 selector over the whole advice stream (1 where a gate window starts), built
+    from per-operation masks -- the mul_mod block's mask is tiled, so the 4e8-cell stream of a 2048-bit key costs no Python
+    loop.  -> (mask, stream length)"""
+    import numpy as np
+
+    Ln = enc_bits // limb_bits
+    L = 2 * Ln
+
+    def mask(part):
+        g, n = part
+        m = np.zeros(n, dtype=np.uint8)
+        m[np.asarray(g, dtype=np.int64)] = 1
+        return m
+
+    parts = [mask(gate_offsets_assign(Ln, limb_bits, lb))] * 4
+    parts.append(mask(gate_offsets_square(Ln)))
+    parts.append(mask(gate_offsets_refresh(refresh_aux(limb_bits, Ln, Ln), limb_bits, lb)))
+    parts.append(np.zeros(1, dtype=np.uint8))
+    mm = mask(gate_offsets_mul_mod(L, lb, limb_bits))
+    if kind == "encrypt":
+        for ns in (n_steps_g, n_steps_r):
+            parts.append(np.zeros(2, dtype=np.uint8))
+            parts.append(np.tile(mm, ns))
+    parts.append(mm)
+    parts.append(mask(gate_offsets_assign(L, limb_bits, lb)))
+    parts.append(mask(gate_offsets_assert_equal(L)))
+    out = np.concatenate(parts)
+    return out, out.shape[0]
+
+
+# ----------------------------------------------------------------------------------------
+# Copy constraints (the other half of MockProver's check): which cells of the stream must hold the SAME value because the
+# chip passes one assigned cell to several places.  expand_circuit_cells_wired walks the drivers exactly like
+# expand_circuit_cells, but every cell that is a copy names the cell it copies; the result is the value stream (must equal
+# expand_circuit_cells') and the list of (source cell, copy cell) pairs:
+#   * range_check: the recomposed accumulator equals the checked cell; the `rem` row re-uses the last digit
+#   * square / mul_no_carry: every (x_j, y_{i-j}) operand cell copies the operand's limb (or the zero cell for extended limbs)
+#   * refresh: div_mod_unsafe's dividend copies the limb it splits; carried remainders copy theirs
+#   * mul_mod: operands a / b copy the limbs of the value they are (previous remainders, g / r limbs extended with the zero
+#     cell: extend_limbs, paillier.rs:49,53; the constant 1); the re-assigned n copies the refreshed n^2 limbs (paillier.rs:45);
+#     qn + r and r < n re-use the q, n, r cells
+#   * assert_equal_fresh (bench.rs:74): x / y of every is_equal copy the circuit's result limbs / the assigned res limbs
+# Dependency-defined wiring [D] like the cell patterns themselves: what is checked is that the GPU-written stream has equal
+# values wherever this restatement's circuit would need them equal.
+# ----------------------------------------------------------------------------------------
+def expand_circuit_cells_wired(kind: str, n: int, g: int, x: int, y: int, res: int, enc_bits: int, limb_bits: int, lb: int):
+    """-> (advice values, [(src index, copy index)], satisfied bit)"""
+    Ln = enc_bits // limb_bits
+    L = 2 * Ln
+    base = 1 << limb_bits
+    adv: List[int] = []
+    pairs: List[Tuple[int, int]] = []
+
+    def put(v, src=None):
+        adv.append(v % FR_R)
+        if src is not None:
+            pairs.append((src, len(adv) - 1))
+        return len(adv) - 1
+
+    def range_check(xv, xcell, bits):
+        """-> the cell that holds the checked value afterwards (the recomposed accumulator; xcell itself for one digit)"""
+        k = -(-bits // lb)
+        rem = bits % lb
+        mask = (1 << lb) - 1
+        digs = [(xv >> (lb * i)) & mask for i in range(k)]
+        last_cell = xcell          # k == 1: the checked cell itself is looked up
+        holder = xcell
+        if k > 1:
+            c0 = put(digs[0])
+            acc = digs[0]
+            acc_cell = c0
+            for gi in range(1, k):
+                acc += digs[gi] << (lb * gi)
+                last_cell = put(digs[gi])
+                put(1 << (lb * gi))
+                acc_cell = put(acc)
+            if xcell is not None:
+                pairs.append((xcell, acc_cell))
+            holder = acc_cell
+        last = digs[-1]
+        if rem == 1:
+            put(0); put(last, last_cell); put(last, last_cell); put(last)
+        elif rem > 1:
+            put(0); put(last, last_cell); put(1 << (lb - rem)); put(last << (lb - rem))
+        return holder
+
+    def assign(v, nl):
+        limbs = decompose_biguint(v, nl, limb_bits)
+        cells = [put(l) for l in limbs]
+        for l, c in zip(limbs, cells):
+            range_check(l, c, limb_bits)
+        return list(zip(limbs, cells))
+
+    def mul_cells(xs, ys, D):
+        """xs / ys: [(value, cell)] ; shorter operands are extended with the load_zero cell this call pushes first"""
+        zc = put(0)
+        xe = list(xs) + [(0, zc)] * (D - len(xs))
+        ye = list(ys) + [(0, zc)] * (D - len(ys))
+        prod = []
+        for i in range(D):
+            put(0)
+            s = 0
+            cell = None
+            for j in range(i + 1):
+                s += xe[j][0] * ye[i - j][0]
+                put(xe[j][0], xe[j][1])
+                put(ye[i - j][0], ye[i - j][1])
+                cell = put(s)
+            prod.append((s, cell))
+        return prod
+
+    def is_equal(xv, xc, yv, yc):
+        d = (xv - yv) % FR_R
+        put(d); put(yv, yc); put(1); put(xv, xc)
+        z, bit = _is_zero_cells(d)
+        for v in z:
+            put(v)
+        return bit
+
+    def div_mod(v, vcell):
+        qd, rd = v >> limb_bits, v & (base - 1)
+        prod = qd * base
+        c_qd = put(qd); c_rd = put(rd); put(0); put(qd, c_qd); put(base); c_pr = put(prod)
+        put(v - prod); put(prod, c_pr); put(1); put(v, vcell)
+        is_equal(rd, c_rd, v - prod, None)
+        return (qd, c_qd), (rd, c_rd)
+
+    def mul_mod(a, b, nfresh):
+        """a, b: [(limb, cell)] x L; nfresh: the refreshed n^2 limbs [(limb, cell)] -> r as [(limb, cell)]"""
+        av, bv = get_biguint([t[0] for t in a], limb_bits), get_biguint([t[0] for t in b], limb_bits)
+        n2 = get_biguint([t[0] for t in nfresh], limb_bits)
+        q, r = divmod(av * bv, n2)
+        ql, nl_, rl = assign(q, L), assign(n2, L), assign(r, L)
+        for (v, c), (_, src) in zip(nl_, nfresh):
+            pairs.append((src, c))
+        D = 2 * L - 1
+        p_ab = mul_cells(a, b, D)
+        p_qn = mul_cells(ql, nl_, D)
+        qnr = list(p_qn)
+        for i in range(L):
+            put(p_qn[i][0], p_qn[i][1]); put(1); put(rl[i][0], rl[i][1])
+            qnr[i] = (p_qn[i][0] + rl[i][0], put(p_qn[i][0] + rl[i][0]))
+        m = base - 1
+        MAX = L * m * m + m
+        cb = (2 * MAX).bit_length() - limb_bits
+        put(0); put(1)
+        carry, accx, eq_bit = (0, None), (0, None), 1
+        for i in range(D):
+            diff = p_ab[i][0] - qnr[i][0]
+            c_diff = put(diff); put(qnr[i][0], qnr[i][1]); put(1); put(p_ab[i][0], p_ab[i][1])
+            s = diff + carry[0] + MAX
+            put(diff, c_diff); put(carry[0], carry[1]); put(1); put(diff + carry[0]); put(MAX); put(1); c_s = put(s)
+            new_carry, cmod = div_mod(s, c_s)
+            t = accx[0] + MAX
+            put(accx[0], accx[1]); put(1); put(MAX); c_t = put(t)
+            q_acc, mod_acc = div_mod(t, c_t)
+            e = is_equal(cmod[0], cmod[1], mod_acc[0], mod_acc[1])
+            put(0); put(eq_bit); put(e); put(eq_bit & e)
+            eq_bit &= e
+            accx = q_acc
+            if i < D - 1:
+                range_check(new_carry[0], new_carry[1], cb)
+            else:
+                e = is_equal(new_carry[0], new_carry[1], accx[0], accx[1])
+                put(0); put(eq_bit); put(e); put(eq_bit & e)
+                eq_bit &= e
+            carry = new_carry
+        borrow = (0, None)
+        for i in range(L):
+            nb = nl_[i][0] + borrow[0]
+            put(nl_[i][0], nl_[i][1]); put(1); put(borrow[0], borrow[1]); put(nb)
+            shift = rl[i][0] - nb + base
+            lt = 1 if rl[i][0] < nb else 0
+            out = shift & (base - 1)
+            put(shift); c_lt = put(lt); c_out = put(out)
+            put(rl[i][0], rl[i][1]); put(lt, c_lt); put(base); put(rl[i][0] + lt * base)
+            range_check(out, c_out, limb_bits)
+            borrow = (lt, c_lt)
+        put(borrow[0], borrow[1])
+        return rl
+
+    n_c, g_c, x_c, y_c = assign(n, Ln), assign(g, Ln), assign(x, Ln), assign(y, Ln)
+    prod = mul_cells(n_c, n_c, 2 * Ln - 1)
+    # refresh
+    inc = refresh_aux(limb_bits, Ln, Ln)
+    put(0)
+    cur = list(prod) + [(0, None)] * (len(inc) - len(prod))
+    for i in range(len(inc)):
+        limb = cur[i]
+        for j in range(inc[i] + 1):
+            qd, rd = div_mod(limb[0], limb[1])
+            if j == 0:
+                cur[i] = rd
+            else:
+                tgt = cur[i + j]
+                put(tgt[0], tgt[1]); put(1); put(rd[0], rd[1])
+                cur[i + j] = (tgt[0] + rd[0], put(tgt[0] + rd[0]))
+            limb = qd
+    # the refreshed limbs: a limb no cell was written for is the constant zero, its range check stands alone
+    fresh = []
+    for v, c in cur:
+        holder = range_check(v, c, limb_bits)
+        fresh.append((v, c if c is not None else holder))
+    zero = put(0)                      # ctx.load_zero() (paillier.rs:47 / 77)
+    ext = lambda limbs: list(limbs) + [(0, zero)] * (L - len(limbs))
+    if kind == "encrypt":
+        # pow_mod_fixed_exp: assign_constant(1), load_zero, then the steps in pow_mod_fixed_exp_trace's order; a step's
+        # operands are the limbs of earlier remainders (or of the base / the constant 1)
+        def pow_mod_traced(base_limbs, e):
+            one = put(1)
+            z2 = put(0)
+            acc = [(1, one)] + [(0, z2)] * (L - 1)
+            _, steps = pow_mod_fixed_exp_trace(get_biguint([t[0] for t in base_limbs], limb_bits), e, n * n)
+            vals = {get_biguint([t[0] for t in base_limbs], limb_bits): base_limbs, 1: acc}
+            last = acc
+            for (a_, b_, q_, r_) in steps:
+                ra = mul_mod(vals[a_], vals[b_], fresh)
+                vals[r_] = ra
+                last = ra
+            return vals, steps
+        vals_g, steps_g = pow_mod_traced(ext(g_c), x)
+        gm_val = pow(g, x, n * n)
+        gm = vals_g[gm_val] if steps_g else vals_g[1]
+        vals_r, steps_r = pow_mod_traced(ext(y_c), n)
+        rn_val = pow(y, n, n * n)
+        rn = vals_r[rn_val]
+        c_limbs = mul_mod(gm, rn, fresh)
+    else:
+        c_limbs = mul_mod(ext(x_c), ext(y_c), fresh)
+    res_c = assign(res, L)
+    put(0); put(1)
+    eq = 1
+    for (cv, cc), (rv, rc) in zip(c_limbs, res_c):
+        e = is_equal(cv, cc, rv, rc)
+        put(0); put(eq); put(e); put(eq & e)
+        eq &= e
+    return adv, pairs, eq
+
+
 # ----------------------------------------------------------------------------------------
 # SHPLONK multi-point opening (halo2 multiopen::shplonk::prover; SURVEY.md section 8f rank 3).  Restated from the published
 # protocol as halo2 implements it (dependency, tag [D]); pinned by the opening identity the two output polynomials satisfy

@@ -694,3 +694,40 @@ int ora_num_threads(void) {
     return 1;
 #endif
 }
+
+/* ---------------------------------------------------------------- MockProver analogue on a whole cell stream
+ * halo2-lib has ONE gate, q * (a + b*c - d) = 0 on four vertically consecutive cells.  cells: n
+ * Montgomery Fr elements in stream order; sel[i] != 0 where the selector is enabled (the window starts at cell i; i + 3 < n).
+ * Returns the number of windows whose identity fails, *first_bad = the first such offset (n if none).  Montgomery forms:
+ * mont(b) * mont(c) = mont(bc), so the identity is checked in the Montgomery domain as it stands.
+ * (reference: base_test().expect_satisfied(true) -> MockProver, /root/reference/src/paillier.rs:167-171) */
+size_t ora_check_gates(const u64 *cells, const uint8_t *sel, size_t n, size_t *first_bad) {
+    size_t bad = 0, first = n;
+#pragma omp parallel for schedule(static) reduction(+ : bad) reduction(min : first)
+    for (size_t i = 0; i < n; ++i) {
+        if (!sel[i]) continue;
+        if (i + 3 >= n) { bad++; if (i < first) first = i; continue; }
+        const fe *a = (const fe *)(cells + 4 * i), *b = a + 1, *c = a + 2, *d = a + 3;
+        fe t, u;
+        fe_mul(&t, b, c, &FR);
+        fe_add(&u, a, &t, &FR);
+        fe_sub(&t, &u, d, &FR);
+        if (!fe_is_zero(&t)) { bad++; if (i < first) first = i; }
+    }
+    if (first_bad) *first_bad = first;
+    return bad;
+}
+/* lookup-advice cells (range-check digits) must be canonical integers below 2^bits: the table the reference's RangeChip
+ * looks them up in is [0, 2^lookup_bits).  Returns the number of cells outside it. */
+size_t ora_check_range(const u64 *cells, size_t n, uint32_t bits, size_t *first_bad) {
+    size_t bad = 0, first = n;
+#pragma omp parallel for schedule(static) reduction(+ : bad) reduction(min : first)
+    for (size_t i = 0; i < n; ++i) {
+        fe v;
+        fe_from_mont(&v, (const fe *)(cells + 4 * i), &FR);
+        int ok = v.l[1] == 0 && v.l[2] == 0 && v.l[3] == 0 && (bits >= 64 || (v.l[0] >> bits) == 0);
+        if (!ok) { bad++; if (i < first) first = i; }
+    }
+    if (first_bad) *first_bad = first;
+    return bad;
+}
