@@ -141,21 +141,51 @@ class ProofWorkload:
             self.engw.set_stream(self.stream_w.cuda_stream)
             self.ready_ev = [torch.cuda.Event() for _ in range(2)]
             self.free_ev = [torch.cuda.Event() for _ in range(2)]
+            self.ntt_free_ev = [torch.cuda.Event() for _ in range(2)]
+        self.own_ntt = os.environ.get("PZ_BENCH_OWN_NTT", "1") == "1"   # K2 on the proof's own K4 columns (0: pool only, as in round 2)
         self.fused_ntt = os.environ.get("PZ_BENCH_FUSED_NTT", "0") == "1"   # measured: not faster
         self.digit_adds = 0  # filled by count_digit_adds() after a warm-up step
         gen = torch.Generator(device=dev)
         gen.manual_seed(seed)
         self.gen = gen
-        # the Lagrange-basis SRS g_lagrange[i] = [L_i(s)]G of ParamsKZG::setup for a seeded toxic scalar (what
-        # commit_lagrange multiplies the advice columns with), derived on the device
+        # The SRS as the reference gets it (bench.rs:161-171 -> gen_srs): a `params/kzg_bn254_{k}.srs` file.  The file is made here
+        # the way gen_srs makes it (ParamsKZG::setup with a seeded scalar -> monomial bases g[i] = [s^i]G, on the device), then
+        # READ BACK through paillier_halo2_amd/srs.py, validated on the device (pz_g1_check_dev = read_raw's is_on_curve) and its
+        # Lagrange bases derived from the monomial ones by the G1 inverse FFT (pz_srs_lagrange_from_monomial_dev): the toxic
+        # scalar is not used after the file exists.
         import random as _random
+        import tempfile
 
+        from paillier_halo2_amd import srs as pzsrs
+
+        t_srs = time.perf_counter()
         s_toxic = _random.Random(seed ^ 0x535253).randrange(2, consts.FR_R)
+        d_g = torch.zeros((self.n, 8), dtype=torch.int64, device=dev)
+        eng.srs_setup_g1_dev(k, consts.fr_mont_limbs(s_toxic), consts.fr_mont_limbs(consts.fr_omega(k)), d_g.data_ptr(), 0)
+        eng.sync()
+        del s_toxic
+        pdir = os.path.join(tempfile.gettempdir(), "pz_params_%d" % os.getpid())
+        os.makedirs(pdir, exist_ok=True)
+        ppath = os.path.join(pdir, "kzg_bn254_%d.srs" % k)
+        g_host = d_g.cpu().numpy().view(np.uint64)
+        pzsrs.write_params_kzg(ppath, k, g_host, np.zeros_like(g_host))   # the Lagrange section is re-derived below, not trusted
+        del d_g, g_host
+        t_file = time.perf_counter()
+        params = pzsrs.read_params_kzg(ppath, expect_k=k)
+        d_g = torch.from_numpy(np.array(params.g, dtype=np.uint64).view(np.int64)).to(dev)
+        assert eng.g1_check_dev(d_g.data_ptr(), self.n) == 0, "SRS point not on the curve"
         d_b = torch.zeros((self.n, 8), dtype=torch.int64, device=dev)
-        eng.srs_setup_g1_dev(k, consts.fr_mont_limbs(s_toxic), consts.fr_mont_limbs(consts.fr_omega(k)), 0, d_b.data_ptr())
+        eng.srs_lagrange_from_monomial_dev(k, consts.fr_mont_limbs(pow(consts.fr_omega(k), -1, consts.FR_R)),
+                                           consts.fr_mont_limbs(pow(self.n, -1, consts.FR_R)), d_g.data_ptr(), d_b.data_ptr())
         eng.sync()
         self.bases = eng.load_bases_dev(d_b.data_ptr(), self.n)
-        del d_b
+        self.srs_ms = {"setup_and_write_file": (t_file - t_srs) * 1e3, "read_check_lagrange_table": (time.perf_counter() - t_file) * 1e3}
+        del d_b, d_g, params
+        try:
+            os.unlink(ppath)
+            os.rmdir(pdir)
+        except OSError:
+            pass
         # column pools (values synthetic, Montgomery form): witness-like / lookup digits / full width
         self.pool = pool
         self.col_f = self._rand_fr(pool * self.n).view(pool, self.n, 4)
@@ -220,6 +250,8 @@ class ProofWorkload:
         sh = self.shape
         if self.pipeline:
             self.stream_w.wait_event(self.free_ev[slot])  # the previous consumer of this slot has finished reading it
+            if self.stream_n is not None:
+                self.stream_w.wait_event(self.ntt_free_ev[slot])   # ... and so has the transform stream
         nn, g, m, r = self.inputs
         skip = os.environ.get("PZ_BENCH_SKIP", "")   # debug only ("k3" / "k4"): see consume()
         self._produced = getattr(self, "_produced", 0) + 1
@@ -274,22 +306,50 @@ class ProofWorkload:
         if ws > 1:
             pzd.gather_commitments(t, self.dist, self.d_out_full[: hi - lo], self.counts["msm_full"], rk, ws)
         if not msm_only and "ntt" not in skip:
-            self.consume_ntt()
+            self.consume_ntt(slot)
         if tail:
             self.tail_run(slot)
         if self.pipeline:
             self.free_ev[slot].record(t.cuda.current_stream())
 
-    def consume_ntt(self):
+    def consume_ntt(self, slot=0):
         eng, n, k, sh = self.engn, self.n, self.k, self.shape
+        t = self.torch
         # K2: Lagrange -> coeff (iNTT 2^k) -> extended coset: 4 interleaved coset NTTs with the 1/n divisor folded into
-        # their pre-scale tables (pz_ntt_fr_extend_dev == zero-extend, distribute_powers, best_fft(omega_ext))
+        # their pre-scale tables (pz_ntt_fr_extend_dev == zero-extend, distribute_powers, best_fft(omega_ext)).
+        # The proof's OWN advice and lookup columns (K4's output, which the commitment stream reads at the same time) are
+        # copied batch by batch into the transform buffer -- the coefficient form is a separate allocation in a prover too --
+        # and transformed there; the remaining polynomials of a proof (permuted lookup columns, lookup and permutation
+        # products: A + 4 Lk + P in all) come from the resident pool of uniformly random field elements.
         from paillier_halo2_amd import dist as pzd
 
         p_lo, p_hi = pzd.column_range(self.counts["polys"], *self.shard)   # column-parallel mode: this rank's polynomials
         done = 0
         nb = self.ntt_batch
         pool_n = self.col_f if self.stream_n is None else self.col_n
+        own = [(self.d_adv[slot], self.adv_cols), (self.d_lk[slot], self.lk_cols)] if (self.own_ntt and self.scale == 1.0 and self.shard == (0, 1)) else []
+        ctx_stream = t.cuda.stream(self.stream_n) if self.stream_n is not None else _null()
+        if self.stream_n is not None and self.pipeline:
+            self.stream_n.wait_event(self.ready_ev[slot])     # the columns K4 wrote
+        for buf, ncols in own:
+            cols = buf.view(ncols, n, 4)
+            c0 = 0
+            while c0 < ncols and done < p_hi - p_lo:
+                nc = min(nb, ncols - c0, p_hi - p_lo - done)
+                work = pool_n[:nc]
+                with ctx_stream:
+                    work.copy_(cols[c0:c0 + nc])
+                eng.ntt_dev(work.data_ptr(), nc, 4 * n, self.omega_inv, k, None, None)
+                eng.ntt_extend_dev(work.data_ptr(), nc, 4 * n, self.d_ext.data_ptr(), 4 * self.ext_n, k, sh.ext_k - k,
+                                   self.omega_n, self.coset_gens, self.n_inv)
+                c0 += nc
+                done += nc
+        if own and self.stream_n is not None and self.pipeline:
+            self.ntt_free_ev[slot].record(self.stream_n)      # the witness slot has been read by this stream
+        if own:
+            # the pool rows used as work space hold coefficients now: refill is not needed, the transforms' cost does not depend
+            # on the values (any canonical field elements)
+            pass
         while done < p_hi - p_lo:
             nc = min(nb, p_hi - p_lo - done)
             # in place on the resident pool columns (as a prover consumes its own columns): they stay uniformly
@@ -306,6 +366,46 @@ class ProofWorkload:
                 eng.ntt_extend_dev(src.data_ptr(), nc, 4 * n, self.d_ext.data_ptr(), 4 * self.ext_n, k, sh.ext_k - k,
                                    self.omega_n, self.coset_gens, self.n_inv)
             done += nc
+
+    # ---- keygen (bench.rs:174-175 prints vk / pk time): commitments, coefficient and extended-coset forms of the fixed columns
+    # (one selector per advice column, the lookup table, a constants column) and of the permutation polynomials, 256 columns at
+    # a time through pz_permutation_sigma_dev + pz_keygen_columns_dev.  Column CONTENTS are stand-ins (0/1 selector patterns, the
+    # identity permutation: the copy-constraint cycles are the dependency's circuit structure); the work does not depend on them
+    # beyond selectors being short scalars and sigma values full-width ones.  Run once per key, outside the per-proof loop.
+    def keygen_vk_pk(self):
+        eng, t, n, k, sh = self.eng, self.torch, self.n, self.k, self.shape
+        dev = self.d_ext.device
+        nb = 256
+        log_e = sh.ext_k - k
+        d_cols = t.zeros((nb, n, 4), dtype=t.int64, device=dev)
+        d_ext = t.zeros((nb, n << log_e, 4), dtype=t.int64, device=dev)
+        d_com = t.zeros((nb, 12), dtype=t.int64, device=dev)
+        sel = t.zeros((n, 4), dtype=t.int64, device=dev)
+        sel[::3, 0] = 1
+        eng.fr_convert_dev(sel.data_ptr(), n, True)
+        map_col = t.arange(nb, dtype=t.int32, device=dev).repeat_interleave(n).contiguous()
+        map_row = t.arange(n, dtype=t.int32, device=dev).repeat(nb).contiguous()
+        delta = consts_mod().fr_mont_limbs(pow(consts_mod().FR_GENERATOR, 1 << 28, consts_mod().FR_R))
+        n_fixed, n_sigma = sh.advice_cols + 2, sh.advice_cols + sh.lookup_cols + 1
+        t.cuda.synchronize()
+        t0 = time.perf_counter()
+        for total, is_sigma in ((n_fixed, False), (n_sigma, True)):
+            done = 0
+            while done < total:
+                nc = min(nb, total - done)
+                if is_sigma:
+                    eng.permutation_sigma_dev(map_col.data_ptr(), map_row.data_ptr(), nc, k, self.omega_n, delta, d_cols.data_ptr(), 4 * n)
+                else:
+                    d_cols[:nc] = sel
+                eng.keygen_columns_dev(self.bases, d_cols.data_ptr(), nc, 4 * n, k, log_e, self.omega_n, self.omega_inv, self.n_inv,
+                                       self.coset_gens, d_com.data_ptr(), d_ext.data_ptr(), 4 * (n << log_e))
+                done += nc
+        eng.sync()
+        t.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+        return {"vk_pk_ms": ms, "fixed_columns": n_fixed, "permutation_columns": n_sigma,
+                "note": "keygen_vk + keygen_pk on the device for this circuit's column counts (selector-like fixed columns, identity permutation): "
+                        "commitment + coefficient form + extended-coset form of every column, 256 columns per call; once per key, not in `value`"}
 
     # ---- the prover steps that follow the hot path: permutation and lookup grand
     # products, evaluate_h, evaluations at the challenge point and opening quotients.  Inputs: the permutation products
@@ -429,6 +529,16 @@ class ProofWorkload:
 
     def tail_evals(self):
         eng, T, n = self.eng, self._tail, self.n
+        # a prover draws a fresh challenge x per proof: new points, hence new power tables, every call (the library's table cache
+        # does not help and must not stall: pz_get_pow_table reuses the evicted table's buffer)
+        from paillier_halo2_amd import consts
+
+        self._eval_round = getattr(self, "_eval_round", 0) + 1
+        x0 = pow(consts.FR_GENERATOR, 19 + 7 * self._eval_round, consts.FR_R)
+        w = consts.fr_omega(self.k)
+        pts = [x0, x0 * w % consts.FR_R, x0 * pow(w, 2, consts.FR_R) % consts.FR_R, x0 * pow(w, 3, consts.FR_R) % consts.FR_R,
+               x0 * pow(w, -1, consts.FR_R) % consts.FR_R, x0 * pow(w, n - 11, consts.FR_R) % consts.FR_R]
+        T["sh_points"] = np.stack([consts.fr_mont_limbs(p_) for p_ in pts])
         # every committed polynomial at its rotation set, one pass over the coefficients per polynomial (pz_poly_eval_multi_dev):
         # (count, points) classes as in halo2's evals phase; together T["n_evals"] point evaluations
         for cnt, pts in T["eval_classes"]:
@@ -503,6 +613,12 @@ class ProofWorkload:
 def env_switches():
     """every PZ_* / GPU_MAX_HW_QUEUES environment switch in effect, for the JSON line"""
     return {k: v for k, v in sorted(os.environ.items()) if k.startswith("PZ_") or k == "GPU_MAX_HW_QUEUES"}
+
+
+def consts_mod():
+    from paillier_halo2_amd import consts
+
+    return consts
 
 
 class _null:
@@ -609,6 +725,49 @@ def dropin_host_pointer_path(wl, torch, log, sample=256):
                     "binding and is not counted" % (n_wit, wl.counts["msm_full"], wl.counts["polys"], k, sh.ext_k)}
 
 
+def dropin_device_resident(wl, args, log):
+    """The SAME hot path driven from plain C++ through the C ABI alone -- paillier_halo2_amd/host/prove_c2.cpp: pz_dev_alloc /
+    pz_upload, three contexts ordered by pz_ctx_wait, no torch and no HIP call in the host -- i.e. what the reference's Rust
+    prover patched at points C and D of INTEGRATION.md reaches.  Run as a child process after this process's own timed loops
+    (the GPU is idle then); same counts, call sizes and pools as ProofWorkload."""
+    import struct
+    import subprocess
+    import tempfile
+
+    from paillier_halo2_amd import consts
+
+    exe = os.path.join(ROOT, "tests", "cpp", "prove_c2")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "prove_c2"], stdout=subprocess.DEVNULL)
+    import random as _random
+
+    s_toxic = _random.Random(args.seed ^ 0x535253).randrange(2, consts.FR_R)
+    sh = wl.shape
+    nn = consts.limbs_to_int(wl.inputs[0]) if hasattr(consts, "limbs_to_int") else sum(int(v) << (64 * i) for i, v in enumerate(wl.inputs[0]))
+    words = [0x325A50, wl.enc_bits, wl.k, sh.lookup_bits, wl.n_steps, wl.counts["msm_full"], wl.counts["polys"], wl.pool, wl.ntt_batch,
+             args.steps, args.warmup, sh.ext_k - wl.k, args.seed]
+    arrs = [np.asarray(a, dtype=np.uint64) for a in wl.inputs] + [wl.circ_inputs[4 * wl.Ln:].astype(np.uint64),
+                                                                   consts.int_to_limbs(nn * nn, wl.L)]
+    arrs += [consts.fr_mont_limbs(s_toxic), wl.omega_n, wl.omega_inv, wl.n_inv, wl.coset_gens.reshape(-1)]
+    blob = struct.pack("<%dQ" % len(words), *words) + b"".join(np.ascontiguousarray(a, dtype="<u8").tobytes() for a in arrs)
+    with tempfile.NamedTemporaryFile(suffix=".job", delete=False) as f:
+        f.write(blob)
+        path = f.name
+    try:
+        env = dict(os.environ)
+        env.pop("LD_PRELOAD", None)
+        p = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=env)
+    finally:
+        os.unlink(path)
+    if p.returncode != 0:
+        return {"error": (p.stderr or p.stdout)[-400:]}
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    out["note"] = ("paillier_halo2_amd/host/prove_c2.cpp: the hot path of one proof per step from plain C++ over include/pz.h only (device "
+                   "memory through pz_dev_alloc / pz_upload, contexts ordered by pz_ctx_wait; no torch, no HIP in the host), same work "
+                   "per step as `value`; the binding INTEGRATION.md section 5a shows for the reference's Rust side")
+    return out
+
+
 def _free_port():
     import socket
 
@@ -681,7 +840,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c2u", "c3", "msm22", "stub"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2u", "c3", "c5", "msm22", "stub"],
                     help="c2: encrypt proof hot path (headline); c2u: the same key size through the uniform-shape circuit (g^m over all message bits in circuit, SURVEY 8f rank 4); c3: homomorphic-add circuit at --k 15; msm22: one sharded MSM")
     ap.add_argument("--k", type=int, default=17)
     ap.add_argument("--enc-bits", type=int, default=2048)
@@ -735,7 +894,9 @@ def main():
     eng = pz.Engine(local)
     eng.bind_torch_stream()  # a real stream, current for torch too: the event waits of the pipeline order against it
     # multiplier issue peak of this device, measured live (8 independent mads per lane and iteration)
-    mad_peak = max(8192 * 256 * 1024 * 8 / (eng.ubench_mad_indep(8192, 1024) * 1e-3) / 1e12 for _ in range(3))
+    from paillier_halo2_amd import probe   # libpz_probe.so: measurement only, outside the product ABI
+
+    mad_peak = max(8192 * 256 * 1024 * 8 / (probe.ubench_mad_indep(local, 8192, 1024) * 1e-3) / 1e12 for _ in range(3))
 
     def barrier():
         torch.cuda.synchronize()
@@ -764,6 +925,11 @@ def main():
     t0 = time.time()
     if args.workload == "c3" and args.k == 17:
         args.k = 15
+    if args.workload == "c5":   # BASELINE config c5: 3072-bit n, k = 19, 64 proofs over 8 GPUs = 8 independent proofs per GPU (replicas)
+        args.enc_bits, args.k = 3072, 19
+        if "--steps" not in sys.argv:
+            args.steps = 8
+        args.workload = "c2"
     colpar = args.parallel == "columns"
     wl = ProofWorkload(eng, torch, args.enc_bits, args.k, seed=args.seed + (0 if colpar else rank), scale=args.scale,
                        pool=int(os.environ.get("PZ_BENCH_POOL", "256")),   # columns per full-width commitment call (tuning only)
@@ -840,6 +1006,13 @@ def main():
             dropin = dropin_host_pointer_path(wl, torch, log)
         except Exception as ex:
             dropin = {"error": repr(ex)}
+    dropin_dev = None
+    if rank == 0 and world == 1 and args.scale == 1.0 and not args.no_dropin and args.workload == "c2" and wl.pipeline and wl.stream_n is not None:
+        try:
+            torch.cuda.synchronize()
+            dropin_dev = dropin_device_resident(wl, args, log)
+        except Exception as ex:
+            dropin_dev = {"error": repr(ex)}
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -849,6 +1022,12 @@ def main():
             dist.destroy_process_group()
         return
     sh, cnt = wl.shape, wl.counts
+    keygen = None
+    if args.scale == 1.0 and world == 1 and not args.no_tail:
+        try:
+            keygen = wl.keygen_vk_pk()
+        except Exception as ex:
+            keygen = {"error": repr(ex)}
     proofs = args.steps * (1 if colpar else world)
     value = proofs / dt
     # roofline of the dominant kernel (k_msm_accumulate): algorithmic bytes per launch / avg launch time.
@@ -901,7 +1080,7 @@ def main():
         },
         # the roofline that actually binds this kernel: multiplier-instruction issue (v_mad_u64_u32 / v_mul_lo_u32).  One mixed
         # addition = 8 products x 180 + 2 squares x 135 multiplier instructions of the 29-bit field (fp29.cuh); peak = the
-        # independent-multiplicand mad issue rate measured live by pz_ubench_mad_indep
+        # independent-multiplicand mad issue rate measured live by libpz_probe.so's pzp_ubench_mad_indep
         "roofline_int": {
             "bound": "v_mad_u64_u32 issue", "kernel": "k_msm_accumulate",
             "achieved": (wl.digit_adds * args.steps * MULT_PER_MADD / (acc_ms * 1e-3) / 1e12) if (acc_ms > 0 and wl.digit_adds) else None,
@@ -921,12 +1100,21 @@ def main():
     # (PZ_BENCH_SKIP, --scale) marks the line as not comparable
     out["config"]["env_switches"] = env_switches()
     out["comparable"] = bool(args.scale == 1.0 and not os.environ.get("PZ_BENCH_SKIP"))
+    out["srs_ms"] = wl.srs_ms
+    out["config"]["srs"] = "params file written as gen_srs does (ParamsKZG::setup), read back by paillier_halo2_amd/srs.py, points checked on the device, Lagrange bases by the G1 inverse FFT (no toxic scalar)"
+    out["config"]["ntt_inputs"] = ("the proof's own advice and lookup columns (copied into the transform buffer) + pool polynomials for the rest" if wl.own_ntt else "pool polynomials")
+    if keygen is not None:
+        out["keygen"] = keygen
     if tail is not None:
         out["next_rows_ms_per_proof"] = tail
     if body is not None:
         out["with_next_rows"] = body
     if dropin is not None:
         out["dropin_host_pointer"] = dropin
+    if dropin_dev is not None:
+        out["dropin_device_resident"] = dropin_dev
+        if dropin_dev.get("value"):
+            out["dropin_device_resident"]["ratio_to_value"] = dropin_dev["value"] / value
     if not args.no_cpu_baseline and args.scale == 1.0 and world == 1:   # rank 0 at N = 1 only
         try:
             out["cpu_baseline"] = cpu_baseline(sh, wl.n_steps, args.enc_bits, args.k, log)

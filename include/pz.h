@@ -49,7 +49,8 @@ enum pz_status {
     PZ_ERR_ZERO_MODULUS = -5, /* mul_mod / pow_mod with modulus 0 (reference: BigUint % 0 panics, paillier.rs:91) */
     PZ_ERR_RANGE = -6,        /* quotient does not fit the limb count the circuit assigns it (unsatisfiable in the reference) */
     PZ_ERR_UNSUPPORTED = -7,  /* n_devices != 1, limb count not a supported size ...         */
-    PZ_ERR_CAPACITY = -8      /* caller-provided output capacity too small                  */
+    PZ_ERR_CAPACITY = -8,     /* caller-provided output capacity too small                  */
+    PZ_ERR_MESSAGE_RANGE = -9 /* uniform-shape circuit: a message does not fit the m_bits the circuit decomposes */
 };
 
 /* ---------------------------------------------------------------------------------------------
@@ -64,8 +65,31 @@ const char* pz_last_hip_error(const pz_ctx* ctx);
 /* stream used by the _dev entry points (NULL = the context's own stream). */
 int pz_set_stream(pz_ctx* ctx, void* hip_stream);
 int pz_sync(pz_ctx* ctx);
-/* number of entry points exported; lets a binding check it was built against this header */
+/* explicit ABI version, bumped whenever an entry point below is added, removed or changes meaning (measurement probes are
+ * not part of this ABI: they live in libpz_probe.so).  A binding compares it with the PZ_ABI_VERSION it was built against. */
+#define PZ_ABI_VERSION 3
 int pz_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * device memory -- for a host that owns no HIP runtime of its own (the reference's Rust prover behind this FFI; the C++
+ * driver in paillier_halo2_amd/host/prove_c2.cpp).  The `_dev` entry points take these pointers as they are, so a proof's
+ * columns can stay in HBM from K4 through K1 and K2 (patch points C / D of INTEGRATION.md: bench.rs:161-171's create_proof).
+ * ------------------------------------------------------------------------------------------- */
+int pz_dev_alloc(pz_ctx* ctx, size_t bytes, void** d_out);
+/* waits for the context's queued work, then frees */
+int pz_dev_free(pz_ctx* ctx, void* d);
+/* host -> device on the context's stream; returns when the host buffer may be reused */
+int pz_upload(pz_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+/* device -> host on the context's stream; returns when the data has arrived (everything queued before it has run) */
+int pz_download(pz_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+/* asynchronous fill on the context's stream */
+int pz_dev_memset(pz_ctx* ctx, void* d_dst, int byte_value, size_t bytes);
+/* asynchronous device -> device copy on the context's stream (e.g. a column's Lagrange values into the buffer its coefficient
+ * form is computed in) */
+int pz_dev_copy(pz_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
+/* order two contexts of one device: everything queued on `producer`'s stream so far happens before whatever `waiter` queues
+ * from now on (an event wait, no host synchronisation) */
+int pz_ctx_wait(pz_ctx* waiter, pz_ctx* producer);
 
 /* ---------------------------------------------------------------------------------------------
  * K1 -- G1 multi-scalar multiplication.  Replaces halo2curves `best_multiexp(coeffs, bases)`
@@ -180,7 +204,7 @@ int pz_paillier_encrypt_dev(pz_ctx* ctx, uint32_t limbs_n, size_t batch, const u
 /* Uniform-shape variant (NOT the reference's circuit): g^m as BigUintChip::pow_mod over exactly
  * m_bits in-circuit exponent bits -- per bit the step (acc, sq) [kept only if the bit is set: select] then the step (sq, sq)
  * -- so n_steps_g = 2 * m_bits for every message and one vk / pk serves every proof of a key.  r^n and the final mul_mod as
- * above.  PZ_ERR_RANGE if a message does not fit m_bits.  Same buffer conventions as pz_paillier_encrypt[_dev]. */
+ * above.  PZ_ERR_MESSAGE_RANGE if a message does not fit m_bits.  Same buffer conventions as pz_paillier_encrypt[_dev]. */
 int pz_paillier_encrypt_uniform(pz_ctx* ctx, uint32_t limbs_n, size_t batch, uint32_t m_bits, const uint64_t* n, const uint64_t* g,
                                 const uint64_t* m, const uint64_t* r, uint64_t* steps_out, size_t steps_cap, uint32_t* n_steps_g,
                                 uint32_t* n_steps_r, uint64_t* c_out);
@@ -384,7 +408,7 @@ int pz_shplonk_finish_dev(pz_ctx* ctx, pz_shplonk* state, const uint64_t u[4], c
 int pz_shplonk_free(pz_ctx* ctx, pz_shplonk* state);
 
 /* ---------------------------------------------------------------------------------------------
- * measurement helpers (used by bench.py; not part of the reference surface)
+ * measurement helpers (used by bench.py; not part of the reference surface).  Issue-rate microbenchmarks: libpz_probe.so.
  * ------------------------------------------------------------------------------------------- */
 /* HIP-event timing of the dominant kernel on the context's stream: accumulated since the last
  * reset, for kernel class `which` (0 = MSM bucket accumulation, 1 = NTT passes, 2 = modexp trace,
@@ -393,22 +417,6 @@ int pz_shplonk_free(pz_ctx* ctx, pz_shplonk* state);
 int pz_timing_enable(pz_ctx* ctx, int on);
 int pz_timing_reset(pz_ctx* ctx);
 int pz_timing_get(pz_ctx* ctx, int which, double* total_ms, uint64_t* launches);
-/* integer-multiply issue-rate microbenchmark: runs `iters` dependent-free v_mad_u64_u32 per lane
- * on `blocks` x 256 threads, returns elapsed ms (device time) */
-int pz_ubench_mad(pz_ctx* ctx, uint32_t blocks, uint32_t iters, double* ms);
-/* the same with multiplicands that do not depend on the accumulators (8 mads per iteration): the issue rate of the mads of a
- * reduced-radix field product, the peak `roofline_int` is priced against */
-int pz_ubench_mad_indep(pz_ctx* ctx, uint32_t blocks, uint32_t iters, double* ms);
-/* Fq Montgomery multiplications per second microbenchmark (chains of `iters` per lane) */
-int pz_ubench_fqmul(pz_ctx* ctx, uint32_t blocks, uint32_t iters, double* ms);
-/* the same chain with an alternative field product: variant 0 = the production fp_mul,
- * 1 = its round-1 form without the two wait states behind a single-product carry (timing only), 2 = a 9 x 29-bit
- * reduced-radix product whose mads cannot overflow (no v_addc at all; 171 instead of 136 multiplier instructions) */
-int pz_ubench_fqmul_variant(pz_ctx* ctx, int variant, uint32_t blocks, uint32_t iters, double* ms);
-/* one product of variant 2, for its correctness check: a, b 256-bit integers below 2p (host, 4 x u64);
- * out = a * b * 2^-261 mod p as an integer below 2p */
-int pz_fq_mul29(pz_ctx* ctx, const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
-
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(CSRC, "libpz_hip.so")
+PROBE_SO_PATH = os.path.join(CSRC, "libpz_probe.so")   # measurement probes, not part of the product ABI (probe.py)
 
 U64P = C.POINTER(C.c_uint64)
 U32P = C.POINTER(C.c_uint32)
@@ -27,6 +28,13 @@ SIGNATURES = {
     "pz_set_stream": (C.c_int, [VP, VP]),
     "pz_sync": (C.c_int, [VP]),
     "pz_abi_version": (C.c_int, []),
+    "pz_dev_alloc": (C.c_int, [VP, C.c_size_t, C.POINTER(VP)]),
+    "pz_dev_free": (C.c_int, [VP, VP]),
+    "pz_upload": (C.c_int, [VP, VP, VP, C.c_size_t]),
+    "pz_download": (C.c_int, [VP, VP, VP, C.c_size_t]),
+    "pz_dev_memset": (C.c_int, [VP, VP, C.c_int, C.c_size_t]),
+    "pz_dev_copy": (C.c_int, [VP, VP, VP, C.c_size_t]),
+    "pz_ctx_wait": (C.c_int, [VP, VP]),
     "pz_srs_load_g1": (C.c_int, [VP, C.c_uint32, VP, C.c_int, C.POINTER(VP)]),
     "pz_bases_load_g1": (C.c_int, [VP, VP, C.c_size_t, C.c_int, C.c_uint32, C.POINTER(VP)]),
     "pz_bases_free": (C.c_int, [VP, VP]),
@@ -95,11 +103,6 @@ SIGNATURES = {
     "pz_timing_enable": (C.c_int, [VP, C.c_int]),
     "pz_timing_reset": (C.c_int, [VP]),
     "pz_timing_get": (C.c_int, [VP, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
-    "pz_ubench_mad": (C.c_int, [VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
-    "pz_ubench_mad_indep": (C.c_int, [VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
-    "pz_ubench_fqmul": (C.c_int, [VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
-    "pz_ubench_fqmul_variant": (C.c_int, [VP, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
-    "pz_fq_mul29": (C.c_int, [VP, VP, VP, VP]),
 }
 
 _lib = None
@@ -159,3 +162,4 @@ PZ_ERR_ZERO_MODULUS = -5
 PZ_ERR_RANGE = -6
 PZ_ERR_UNSUPPORTED = -7
 PZ_ERR_CAPACITY = -8
+PZ_ERR_MESSAGE_RANGE = -9

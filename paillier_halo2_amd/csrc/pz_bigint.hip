@@ -673,7 +673,7 @@ static int encrypt_impl(pz_ctx* ctx, uint32_t Ln, size_t batch, const uint64_t* 
         nr[i] = count(n + i * Ln);
         if (uniform_m_bits) {   // the message must fit the bits the circuit decomposes
             for (uint32_t b = uniform_m_bits; b < 64 * Ln; ++b)
-                if ((m[i * Ln + (b >> 6)] >> (b & 63)) & 1) return PZ_ERR_RANGE;
+                if ((m[i * Ln + (b >> 6)] >> (b & 63)) & 1) return PZ_ERR_MESSAGE_RANGE;
         }
         if (steps_out && (size_t)ng[i] + nr[i] + 1 > steps_cap) return PZ_ERR_CAPACITY;
     }

@@ -1,8 +1,6 @@
-// pz_core.hip -- context, workspaces, cached power tables, timing and the two issue-rate
-// microbenchmarks of libpz_hip.so.  gfx950 only.
-#define PZ_FP_MUL_VARIANTS 1
+// pz_core.hip -- context, device memory, workspaces, cached power tables and timing of libpz_hip.so.  gfx950 only.
+// (the issue-rate microbenchmarks live in probe/pz_probe.hip -> libpz_probe.so, outside the product ABI)
 #include "fp.cuh"
-#include "fp29_probe.cuh"
 #include "fp29.cuh"
 #include "pz_internal.h"
 
@@ -30,115 +28,12 @@ __global__ void k_pow_table(Fr base, Fr init, Fr* table, size_t n, unsigned ch) 
     }
 }
 
-// issue-rate probes --------------------------------------------------------------------------
-__global__ void k_ubench_mad(u64* out, unsigned iters) {
-    u32 a = threadIdx.x * 2654435761u + 12345u, b = blockIdx.x * 40503u + 7u;
-    u64 x0 = a, x1 = b, x2 = a ^ b, x3 = a + b, x4 = a * 3, x5 = b * 5, x6 = a - b, x7 = ~a;
-    for (unsigned i = 0; i < iters; ++i) {
-        // 8 independent accumulators: measures issue throughput, not dependent latency
-        x0 = (u64)a * (u32)x0 + x0;
-        x1 = (u64)b * (u32)x1 + x1;
-        x2 = (u64)a * (u32)x2 + x2;
-        x3 = (u64)b * (u32)x3 + x3;
-        x4 = (u64)a * (u32)x4 + x4;
-        x5 = (u64)b * (u32)x5 + x5;
-        x6 = (u64)a * (u32)x6 + x6;
-        x7 = (u64)b * (u32)x7 + x7;
-    }
-    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7;
-}
-
-// the same with multiplicands that do NOT depend on the accumulators (what a column of a field product looks like: only the
-// 64-bit addend chains): the issue rate the 29-bit kernels actually see
-__global__ void k_ubench_mad_indep(u64* out, unsigned iters) {
-    u32 a = threadIdx.x * 2654435761u + 12345u, b = blockIdx.x * 40503u + 7u, c = a ^ 0x9e3779b9u, d = b + 0x7f4a7c15u;
-    u64 x0 = a, x1 = b, x2 = a ^ b, x3 = a + b, x4 = a * 3, x5 = b * 5, x6 = a - b, x7 = ~a;
-    for (unsigned i = 0; i < iters; ++i) {
-        asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_mad_u64_u32 %1, vcc, %9, %10, %1\n\tv_mad_u64_u32 %2, vcc, %10, %11, %2\n\t"
-                     "v_mad_u64_u32 %3, vcc, %8, %11, %3\n\tv_mad_u64_u32 %4, vcc, %8, %10, %4\n\tv_mad_u64_u32 %5, vcc, %9, %11, %5\n\t"
-                     "v_mad_u64_u32 %6, vcc, %8, %8, %6\n\tv_mad_u64_u32 %7, vcc, %9, %9, %7"
-                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
-                     : "v"(a), "v"(b), "v"(c), "v"(d)
-                     : "vcc");
-    }
-    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7;
-}
-
-__global__ void k_ubench_fqmul(Fq* out, unsigned iters) {
-    Fq x = fp_one<FqTag>(), y = fp_one<FqTag>();
-    x.v[0] ^= threadIdx.x;
-    y.v[1] ^= blockIdx.x;
-    for (unsigned i = 0; i < iters; ++i) {
-        x = fp_mul(x, y);
-        y = fp_mul(y, x);
-    }
-    fp_store(out + (size_t)blockIdx.x * blockDim.x + threadIdx.x, fp_add(x, y));
-}
-
-// the same chain with another product: 1 = round 1's back-to-back mad/addc pairs (no wait states -- timing only,
-// its results are not trusted), 2 = the 9 x 29-bit no-carry product of fp29_probe.cuh
-__global__ void k_ubench_fqmul_nowait(Fq* out, unsigned iters) {
-    Fq x = fp_one<FqTag>(), y = fp_one<FqTag>();
-    x.v[0] ^= threadIdx.x;
-    y.v[1] ^= blockIdx.x;
-    for (unsigned i = 0; i < iters; ++i) {
-        x = fp_mul_nowait(x, y);
-        y = fp_mul_nowait(y, x);
-    }
-    fp_store(out + (size_t)blockIdx.x * blockDim.x + threadIdx.x, fp_add(x, y));
-}
-__global__ void k_ubench_fqmul29(Fq* out, unsigned iters) {
-    Fq x0 = fp_one<FqTag>(), y0 = fp_one<FqTag>();
-    x0.v[0] ^= threadIdx.x;
-    y0.v[1] ^= blockIdx.x;
-    Fq29 x = fq29_from_words(x0.v), y = fq29_from_words(y0.v);
-    for (unsigned i = 0; i < iters; ++i) {
-        x = fq29_mul(x, y);
-        y = fq29_mul(y, x);
-    }
-    Fq r;
-    fq29_to_words(x, r.v);
-    Fq r2;
-    fq29_to_words(y, r2.v);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) r.v[k] ^= r2.v[k];
-    uint4* q = reinterpret_cast<uint4*>(out + (size_t)blockIdx.x * blockDim.x + threadIdx.x);
-    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
-    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
-}
-// variants 3 / 4: the production 29-bit product / square of fp29.cuh (asm columns)
-template <int SQR> __global__ void k_ubench_f29(Fq* out, unsigned iters) {
-    Fq x0 = fp_one<FqTag>(), y0 = fp_one<FqTag>();
-    x0.v[0] ^= threadIdx.x;
-    y0.v[1] ^= blockIdx.x;
-    F29<FqTag> x = f29_from_fp(x0), y = f29_from_fp(y0);
-    for (unsigned i = 0; i < iters; ++i) {
-        if (SQR) {
-            x = f29_sqr(y);
-            y = f29_sqr(x);
-        } else {
-            x = f29_mul(x, y);
-            y = f29_mul(y, x);
-        }
-    }
-    f29_store<1>(out + (size_t)blockIdx.x * blockDim.x + threadIdx.x, f29_mul(x, y));
-}
-// one product of the probe, for its correctness check: out = a * b * 2^-261 mod p as a 256-bit integer below 2p
-__global__ void k_fq_mul29(const u32* a, const u32* b, u32* out) {
-    u32 aw[8], bw[8], rw[8];
-    for (int k = 0; k < 8; ++k) {
-        aw[k] = a[k];
-        bw[k] = b[k];
-    }
-    Fq29 r = fq29_mul(fq29_from_words(aw), fq29_from_words(bw));
-    fq29_to_words(r, rw);
-    for (int k = 0; k < 8; ++k) out[k] = rw[k];
-}
-
 // ------------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------------
-extern "C" int pz_abi_version(void) { return 1; }
+// explicit ABI version: bumped whenever an entry point of include/pz.h is added, removed or changes meaning (1 = rounds 1-2;
+// 3 = round 3: device-memory entry points added, measurement probes moved out to libpz_probe.so)
+extern "C" int pz_abi_version(void) { return PZ_ABI_VERSION; }
 
 extern "C" const char* pz_strerror(int s) {
     switch (s) {
@@ -151,6 +46,7 @@ extern "C" const char* pz_strerror(int s) {
         case PZ_ERR_RANGE: return "quotient does not fit the assigned limb count";
         case PZ_ERR_UNSUPPORTED: return "unsupported configuration";
         case PZ_ERR_CAPACITY: return "output capacity too small";
+        case PZ_ERR_MESSAGE_RANGE: return "message does not fit the exponent bits of the uniform-shape circuit";
         default: return "unknown pz_status";
     }
 }
@@ -197,6 +93,10 @@ extern "C" int pz_free(pz_ctx* ctx) {
         }
     for (auto& e : ctx->io_ev)
         if (e) (void)hipEventDestroy(e);
+    for (int k = 0; k < 4; ++k) {
+        if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
+        if (ctx->stage_h[k]) (void)hipHostFree(ctx->stage_h[k]);
+    }
     if (ctx->io_h2d) (void)hipStreamDestroy(ctx->io_h2d);
     if (ctx->io_d2h) (void)hipStreamDestroy(ctx->io_d2h);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -219,6 +119,91 @@ extern "C" int pz_set_stream(pz_ctx* ctx, void* s) {
         if (e != hipSuccess) return pz_hip_fail(ctx, e, "pz_set_stream: order the new stream after the old one");
         ctx->stream = ns;
     }
+    return PZ_OK;
+}
+
+
+// ---- device memory for hosts that own no HIP runtime of their own (a Rust prover behind the FFI; tests/cpp) ------------
+// Plain hipMalloc'd buffers; the `_dev` entry points take them as they are.  Transfers are ordered on the context's stream:
+// pz_upload returns once the host buffer may be reused, pz_download once the data has arrived.
+extern "C" int pz_dev_alloc(pz_ctx* ctx, size_t bytes, void** d_out) {
+    if (!ctx || !d_out) return PZ_ERR_INVALID;
+    *d_out = nullptr;
+    if (!bytes) return PZ_OK;
+    PZ_ENTER(ctx);
+    HIPCHK(ctx, hipMalloc(d_out, bytes));
+    return PZ_OK;
+}
+extern "C" int pz_dev_free(pz_ctx* ctx, void* d) {
+    if (!ctx) return PZ_ERR_INVALID;
+    if (!d) return PZ_OK;
+    PZ_ENTER(ctx);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // kernels queued by this context may still use it
+    HIPCHK(ctx, hipFree(d));
+    return PZ_OK;
+}
+extern "C" int pz_upload(pz_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+    if (!ctx || (bytes && (!d_dst || !src))) return PZ_ERR_INVALID;
+    if (!bytes) return PZ_OK;
+    PZ_ENTER(ctx);
+    HIPCHK(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PZ_OK;
+}
+extern "C" int pz_download(pz_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
+    if (!ctx || (bytes && (!dst || !d_src))) return PZ_ERR_INVALID;
+    if (!bytes) return PZ_OK;
+    PZ_ENTER(ctx);
+    HIPCHK(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PZ_OK;
+}
+extern "C" int pz_dev_memset(pz_ctx* ctx, void* d_dst, int byte_value, size_t bytes) {
+    if (!ctx || (bytes && !d_dst)) return PZ_ERR_INVALID;
+    if (!bytes) return PZ_OK;
+    PZ_ENTER(ctx);
+    HIPCHK(ctx, hipMemsetAsync(d_dst, byte_value, bytes, ctx->stream));
+    return PZ_OK;
+}
+extern "C" int pz_dev_copy(pz_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
+    if (!ctx || (bytes && (!d_dst || !d_src))) return PZ_ERR_INVALID;
+    if (!bytes) return PZ_OK;
+    PZ_ENTER(ctx);
+    HIPCHK(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return PZ_OK;
+}
+// everything queued on `producer`'s stream so far happens before whatever `waiter` queues from now on (an event, no host
+// synchronisation): how a host with several contexts -- witness / commitments / transforms, each with its own stream -- orders a
+// buffer one context writes and another reads
+extern "C" int pz_ctx_wait(pz_ctx* waiter, pz_ctx* producer) {
+    if (!waiter || !producer) return PZ_ERR_INVALID;
+    if (waiter == producer) return PZ_OK;
+    if (waiter->device != producer->device) return PZ_ERR_UNSUPPORTED;
+    std::lock_guard<std::recursive_mutex> l1(producer->mu);
+    PZ_ENTER(waiter);
+    hipEvent_t ev;
+    HIPCHK(waiter, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, producer->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(waiter->stream, ev, 0);
+    (void)hipEventDestroy(ev);
+    if (e != hipSuccess) return pz_hip_fail(waiter, e, "pz_ctx_wait");
+    return PZ_OK;
+}
+
+int pz_upload_small_async(pz_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+    const unsigned k = ctx->stage_next++ & 3u;
+    if (ctx->stage_ev[k]) HIPCHK(ctx, hipEventSynchronize(ctx->stage_ev[k]));   // the copy queued from this slot four calls ago
+    else HIPCHK(ctx, hipEventCreateWithFlags(&ctx->stage_ev[k], hipEventDisableTiming));
+    if (ctx->stage_cap[k] < bytes) {
+        if (ctx->stage_h[k]) HIPCHK(ctx, hipHostFree(ctx->stage_h[k]));
+        ctx->stage_h[k] = nullptr;
+        ctx->stage_cap[k] = 0;
+        HIPCHK(ctx, hipHostMalloc(&ctx->stage_h[k], bytes + 256, hipHostMallocDefault));
+        ctx->stage_cap[k] = bytes + 256;
+    }
+    memcpy(ctx->stage_h[k], src, bytes);
+    HIPCHK(ctx, hipMemcpyAsync(d_dst, ctx->stage_h[k], bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->stage_ev[k], ctx->stream));
     return PZ_OK;
 }
 
@@ -266,12 +251,23 @@ int pz_get_pow_table(pz_ctx* ctx, const uint64_t base[4], size_t n, void** d_out
             *d_out = t.d;
             return PZ_OK;
         }
-    if (ctx->pow_tables.size() >= 48) {  // evict the least recently used table (kernels still reading it: drain first)
+    void* reuse = nullptr;
+    size_t reuse_cap = 0;
+    if (ctx->pow_tables.size() >= 48) {
+        // evict the least recently used table.  Its buffer is handed to the new table when it is large enough: the kernel
+        // that fills it runs on the context's stream, BEHIND every kernel still reading the old contents, so no host
+        // synchronisation and no free / malloc pair (a prover draws fresh challenge points every proof: six new 2^k-entry
+        // tables per proof went through hipStreamSynchronize + hipFree + hipMalloc here)
         size_t lru = 0;
         for (size_t k = 1; k < ctx->pow_tables.size(); ++k)
             if (ctx->pow_tables[k].stamp < ctx->pow_tables[lru].stamp) lru = k;
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        HIPCHK(ctx, hipFree(ctx->pow_tables[lru].d));
+        if (ctx->pow_tables[lru].cap >= n) {
+            reuse = ctx->pow_tables[lru].d;
+            reuse_cap = ctx->pow_tables[lru].cap;
+        } else {
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            HIPCHK(ctx, hipFree(ctx->pow_tables[lru].d));
+        }
         ctx->pow_tables.erase(ctx->pow_tables.begin() + lru);
     }
     pz_pow_table t;
@@ -279,7 +275,13 @@ int pz_get_pow_table(pz_ctx* ctx, const uint64_t base[4], size_t n, void** d_out
     memcpy(t.base, base, 32);
     memcpy(t.init, init, 32);
     t.n = n;
-    HIPCHK(ctx, hipMalloc(&t.d, n * 32));
+    if (reuse) {
+        t.d = reuse;
+        t.cap = reuse_cap;
+    } else {
+        HIPCHK(ctx, hipMalloc(&t.d, n * 32));
+        t.cap = n;
+    }
     Fr b, i0;
     memcpy(b.v, base, 32);
     memcpy(i0.v, init, 32);
@@ -351,67 +353,3 @@ extern "C" int pz_timing_get(pz_ctx* ctx, int which, double* total_ms, uint64_t*
     return PZ_OK;
 }
 
-// ---- microbenchmarks ---------------------------------------------------------------------------
-template <class K, class... A>
-static int timed_launch(pz_ctx* ctx, double* ms, K kern, dim3 g, dim3 b, A... args) {
-    hipEvent_t e0, e1;
-    HIPCHK(ctx, hipEventCreate(&e0));
-    HIPCHK(ctx, hipEventCreate(&e1));
-    hipLaunchKernelGGL(kern, g, b, 0, ctx->stream, args...);  // warm
-    HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
-    hipLaunchKernelGGL(kern, g, b, 0, ctx->stream, args...);
-    HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
-    HIPCHK(ctx, hipEventSynchronize(e1));
-    float f = 0;
-    HIPCHK(ctx, hipEventElapsedTime(&f, e0, e1));
-    *ms = f;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    return PZ_OK;
-}
-
-extern "C" int pz_ubench_mad(pz_ctx* ctx, uint32_t blocks, uint32_t iters, double* ms) {
-    if (!ctx || !ms || !blocks) return PZ_ERR_INVALID;
-    PZ_ENTER(ctx);
-    void* d;
-    PZCHK(pz_ws_get(ctx, WS_MISC, (size_t)blocks * 256 * 32, &d));
-    return timed_launch(ctx, ms, k_ubench_mad, dim3(blocks), dim3(256), (u64*)d, (unsigned)iters);
-}
-extern "C" int pz_ubench_mad_indep(pz_ctx* ctx, uint32_t blocks, uint32_t iters, double* ms) {
-    if (!ctx || !ms || !blocks) return PZ_ERR_INVALID;
-    PZ_ENTER(ctx);
-    void* d;
-    PZCHK(pz_ws_get(ctx, WS_MISC, (size_t)blocks * 256 * 32, &d));
-    return timed_launch(ctx, ms, k_ubench_mad_indep, dim3(blocks), dim3(256), (u64*)d, (unsigned)iters);
-}
-extern "C" int pz_ubench_fqmul_variant(pz_ctx* ctx, int variant, uint32_t blocks, uint32_t iters, double* ms) {
-    if (!ctx || !ms || !blocks || variant < 0 || variant > 4) return PZ_ERR_INVALID;
-    PZ_ENTER(ctx);
-    void* d;
-    PZCHK(pz_ws_get(ctx, WS_MISC, (size_t)blocks * 256 * 32, &d));
-    if (variant == 1) return timed_launch(ctx, ms, k_ubench_fqmul_nowait, dim3(blocks), dim3(256), (Fq*)d, (unsigned)iters);
-    if (variant == 3) return timed_launch(ctx, ms, k_ubench_f29<0>, dim3(blocks), dim3(256), (Fq*)d, (unsigned)iters);
-    if (variant == 4) return timed_launch(ctx, ms, k_ubench_f29<1>, dim3(blocks), dim3(256), (Fq*)d, (unsigned)iters);
-    if (variant == 2) return timed_launch(ctx, ms, k_ubench_fqmul29, dim3(blocks), dim3(256), (Fq*)d, (unsigned)iters);
-    return timed_launch(ctx, ms, k_ubench_fqmul, dim3(blocks), dim3(256), (Fq*)d, (unsigned)iters);
-}
-extern "C" int pz_fq_mul29(pz_ctx* ctx, const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
-    if (!ctx || !a || !b || !out) return PZ_ERR_INVALID;
-    PZ_ENTER(ctx);
-    void* d;
-    PZCHK(pz_ws_get(ctx, WS_MISC, 96, &d));
-    HIPCHK(ctx, hipMemcpyAsync(d, a, 32, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync((char*)d + 32, b, 32, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_fq_mul29, dim3(1), dim3(1), 0, ctx->stream, (const u32*)d, (const u32*)d + 8, (u32*)d + 16);
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(out, (char*)d + 64, 32, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return PZ_OK;
-}
-extern "C" int pz_ubench_fqmul(pz_ctx* ctx, uint32_t blocks, uint32_t iters, double* ms) {
-    if (!ctx || !ms || !blocks) return PZ_ERR_INVALID;
-    PZ_ENTER(ctx);
-    void* d;
-    PZCHK(pz_ws_get(ctx, WS_MISC, (size_t)blocks * 256 * 32, &d));
-    return timed_launch(ctx, ms, k_ubench_fqmul, dim3(blocks), dim3(256), (Fq*)d, (unsigned)iters);
-}

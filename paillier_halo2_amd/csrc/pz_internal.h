@@ -17,7 +17,8 @@ struct pz_pow_table {   // cached table init * base^i, i < n  (twiddles omega^i,
     uint64_t base[4];
     uint64_t init[4];
     size_t n;
-    void* d;            // n x 32 B
+    size_t cap;         // entries the buffer holds (>= n: an evicted table's buffer is reused)
+    void* d;            // cap x 32 B
     uint64_t stamp;     // last use (LRU: per-proof challenge points would otherwise grow the cache without bound)
 };
 
@@ -60,6 +61,12 @@ struct pz_ctx {
     // of the next / previous column group run beside the kernels of the current one (pz_io_init creates them on first use)
     hipStream_t io_h2d = nullptr, io_d2h = nullptr;
     hipEvent_t io_ev[PZ_IO_EVENTS] = {};
+    // small pinned staging blocks for host arguments of asynchronous entry points (pz_upload_small_async): a ring of four, a
+    // slot is reused only after the copy recorded on it has completed
+    void* stage_h[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t stage_cap[4] = {0, 0, 0, 0};
+    hipEvent_t stage_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned stage_next = 0;
     std::recursive_mutex mu;   // one context is serialised internally: entry points may be called from any thread
 };
 
@@ -109,6 +116,9 @@ struct pz_timer {
 };
 
 const uint64_t* pz_fr_one261();   // Montgomery one times 32: first entry of a power table kept in the 2^261 domain (fp29.cuh)
-int pz_io_init(pz_ctx* ctx);   // streams + events of the host-pointer pipelines; orders io_h2d after ctx->stream
+int pz_io_init(pz_ctx* ctx);
+// asynchronous host -> device copy of a SMALL host argument (pageable memory the caller may free on return): staged through a
+// pinned block of the context (ring of four; a block is reused only after the copy queued from it has completed)
+int pz_upload_small_async(pz_ctx* ctx, void* d_dst, const void* src, size_t bytes);   // streams + events of the host-pointer pipelines; orders io_h2d after ctx->stream
 
 static inline unsigned pz_div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

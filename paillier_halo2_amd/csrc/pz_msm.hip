@@ -1373,7 +1373,7 @@ extern "C" int pz_msm_g1_dev(pz_ctx* ctx, const pz_bases* bases, const uint64_t*
     const size_t digits = n * (size_t)(win_hi - win_lo);
     const unsigned chunk = msm_chunk_for(n_cols, digits);
     const size_t per_col = digits * 4 + (digits / chunk) * (sizeof(G1X29Raw) + 8) +
-                           (size_t)(1u << (bases->c - 1)) * (180 + 4 * (size_t)pz_div_up(n, (size_t)SORT_THREADS * msm_spt_for(n_cols, n)));
+                           (size_t)(1u << (bases->c - 1)) * (180 + 4 * (size_t)pz_div_up(n, (size_t)SORT_THREADS * msm_spt_for(1, n)));   // spt of the smallest group (a halved group recomputes it): an upper bound on the slices
     // group size: sized for 288 GB of HBM -- by default up to 48 GiB of sort / partial-sum workspace per launch
     // sequence (PZ_MSM_WS_GIB overrides), so the latency-bound tree levels are paid once per ~2000 columns
     size_t ws_budget = pz_msm_ws_gib() << 30;

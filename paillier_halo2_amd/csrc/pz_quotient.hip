@@ -419,8 +419,9 @@ __global__ __launch_bounds__(256) void k_kd_carry(Fr* __restrict__ L, size_t n_c
         carry = fp_add(t, fp_mul(xk, carry));
     }
 }
-__global__ __launch_bounds__(256) void k_kd_apply(const Fr* __restrict__ a, size_t cs, size_t n, Fr x,
-                                                  const Fr* __restrict__ L, size_t n_chunks, Fr* __restrict__ q, size_t qs) {
+// a and q may alias (SHPLONK divides in place): neither is __restrict__, and every coefficient is read before its slot is written
+__global__ __launch_bounds__(256) void k_kd_apply(const Fr* a, size_t cs, size_t n, Fr x,
+                                                  const Fr* __restrict__ L, size_t n_chunks, Fr* q, size_t qs) {
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     const Fr* p = a + (size_t)blockIdx.y * cs;

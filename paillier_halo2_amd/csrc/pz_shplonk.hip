@@ -16,6 +16,8 @@
 #include <vector>
 
 #include "fp.cuh"
+#include <memory>
+
 #include "pz_internal.h"
 
 #define SH_MAX_PTS 8u     // points per rotation set
@@ -194,7 +196,8 @@ extern "C" int pz_shplonk_begin_dev(pz_ctx* ctx, size_t n, uint32_t n_sets, cons
     for (size_t j = 0; j < tot_polys; ++j)
         if (!d_polys[j]) return PZ_ERR_INVALID;
     PZ_ENTER(ctx);
-    pz_shplonk* st = new pz_shplonk();
+    std::unique_ptr<pz_shplonk> owner(new pz_shplonk());   // released into *state only on success: no early return leaks it
+    pz_shplonk* st = owner.get();
     st->n = n;
     st->n_sets = n_sets;
     st->n_t = n_points_total;
@@ -210,10 +213,7 @@ extern "C" int pz_shplonk_begin_dev(pz_ctx* ctx, size_t n, uint32_t n_sets, cons
     {
         int rc = pz_ws_get(ctx, WS_SH_SMALL, b_end + 64, &st->d_small);
         if (rc == PZ_OK) rc = pz_ws_get(ctx, WS_SH_C, (size_t)n_sets * n * 32, &st->d_C);
-        if (rc != PZ_OK) {
-            delete st;
-            return rc;
-        }
+        if (rc != PZ_OK) return rc;
     }
     st->off_T = o_T; st->off_R = o_R; st->off_out = o_out;
     char* sm = (char*)st->d_small;
@@ -264,12 +264,15 @@ extern "C" int pz_shplonk_begin_dev(pz_ctx* ctx, size_t n, uint32_t n_sets, cons
         hipLaunchKernelGGL(k_sh_horner, dim3(gb), dim3(256), 0, s, (Fr*)d_h, N, fr_host(v), n, kk == n_sets - 1 ? 1 : 0);
     }
     HIPCHK(ctx, hipGetLastError());
-    *state = st;
+    *state = owner.release();
     return PZ_OK;
 }
 
-extern "C" int pz_shplonk_finish_dev(pz_ctx* ctx, pz_shplonk* st, const uint64_t u[4], const uint64_t* d_h, uint64_t* d_h2) {
-    if (!ctx || !st || !u || !d_h || !d_h2) return PZ_ERR_INVALID;
+extern "C" int pz_shplonk_finish_dev(pz_ctx* ctx, pz_shplonk* st_in, const uint64_t u[4], const uint64_t* d_h, uint64_t* d_h2) {
+    if (!ctx || !st_in) return PZ_ERR_INVALID;
+    std::unique_ptr<pz_shplonk> owner(st_in);   // pz.h: finish frees the state -- on every path, errors included
+    pz_shplonk* st = owner.get();
+    if (!u || !d_h || !d_h2) return PZ_ERR_INVALID;
     PZ_ENTER(ctx);
     const size_t n = st->n;
     hipStream_t s = ctx->stream;
@@ -294,5 +297,5 @@ extern "C" int pz_shplonk_finish_dev(pz_ctx* ctx, pz_shplonk* st, const uint64_t
     PZCHK(pz_poly_div_linear_dev(ctx, d_h2, 1, 4 * n, n, u, d_h2, 4 * n));
     hipLaunchKernelGGL(k_sh_scale, dim3(gb), dim3(256), 0, s, (Fr*)d_h2, n, fsm + st->off_out + st->n_sets + 2);
     HIPCHK(ctx, hipGetLastError());
-    return pz_shplonk_free(ctx, st);
+    return PZ_OK;   // `owner` frees the state
 }

@@ -1043,7 +1043,9 @@ extern "C" int pz_circuit_expand_dev(pz_ctx* ctx, int kind, uint32_t limbs_n, ui
     const size_t in_words = 4 * (size_t)C.words_n + C.e.L64;
     void* d_in;
     PZCHK(pz_ws_get(ctx, WS_MISC, in_words * 8 + 64, &d_in));
-    HIPCHK(ctx, hipMemcpyAsync(d_in, inputs, in_words * 8, hipMemcpyHostToDevice, ctx->stream));
+    // `inputs` is the caller's (pageable) memory and may go away when this returns: the few hundred bytes go through a pinned
+    // staging block of the context, so the copy is truly asynchronous and reads nothing of the caller's afterwards
+    PZCHK(pz_upload_small_async(ctx, d_in, inputs, in_words * 8));
     pz_timer tm(ctx, PZ_T_EXPAND);
     const size_t rec = 4 * (size_t)C.e.L64;   // words per step record
     const size_t runs[3] = {kind != 1 ? n_steps_g : 0, kind != 1 ? n_steps_r : 0, 1};

@@ -73,12 +73,13 @@ def sharded_msm(torch, dist, rank: int, world: int, n_units: int,
 
 
 def hip_fold_fn(eng, torch):
-    """the fixed-order EC fold on the device (pz_g1_sum_dev), into a resident 96-byte result"""
+    """the fixed-order EC fold on the device (pz_g1_sum_dev).  The kernel writes a resident 96-byte buffer; what is returned is a
+    copy of it (a device-to-device copy on the same stream), so a caller may keep one MSM's result across the next call"""
     d_res = torch.zeros(12, dtype=torch.int64, device="cuda")
 
     def fn(parts):
         eng.g1_sum_dev(parts.data_ptr(), parts.shape[0], d_res.data_ptr())
-        return d_res
+        return d_res.clone()
 
     return fn
 

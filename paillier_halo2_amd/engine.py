@@ -507,31 +507,33 @@ class Engine:
         self._chk(self.L.pz_timing_get(self.ctx, which, C.byref(ms), C.byref(n)), "pz_timing_get")
         return ms.value, n.value
 
-    def ubench_mad(self, blocks: int, iters: int) -> float:
-        ms = C.c_double()
-        self._chk(self.L.pz_ubench_mad(self.ctx, blocks, iters, C.byref(ms)), "pz_ubench_mad")
-        return ms.value
+    # ------------------------------------------------------------------ device memory / context ordering (plain-pointer hosts)
+    def dev_alloc(self, nbytes: int) -> int:
+        d = VP()
+        self._chk(self.L.pz_dev_alloc(self.ctx, nbytes, C.byref(d)), "pz_dev_alloc")
+        return d.value or 0
 
-    def ubench_mad_indep(self, blocks: int, iters: int) -> float:
-        ms = C.c_double()
-        self._chk(self.L.pz_ubench_mad_indep(self.ctx, blocks, iters, C.byref(ms)), "pz_ubench_mad_indep")
-        return ms.value
+    def dev_free(self, d: int):
+        self._chk(self.L.pz_dev_free(self.ctx, VP(d)), "pz_dev_free")
 
-    def ubench_fqmul(self, blocks: int, iters: int) -> float:
-        ms = C.c_double()
-        self._chk(self.L.pz_ubench_fqmul(self.ctx, blocks, iters, C.byref(ms)), "pz_ubench_fqmul")
-        return ms.value
+    def upload(self, d_dst: int, arr):
+        a = np.ascontiguousarray(arr)
+        self._chk(self.L.pz_upload(self.ctx, VP(d_dst), VP(a.ctypes.data), a.nbytes), "pz_upload")
 
-    def ubench_fqmul_variant(self, variant: int, blocks: int, iters: int) -> float:
-        ms = C.c_double()
-        self._chk(self.L.pz_ubench_fqmul_variant(self.ctx, variant, blocks, iters, C.byref(ms)), "pz_ubench_fqmul_variant")
-        return ms.value
-
-    def fq_mul29(self, a, b) -> np.ndarray:
-        a, b = _np(a).reshape(4), _np(b).reshape(4)
-        out = np.zeros(4, dtype=np.uint64)
-        self._chk(self.L.pz_fq_mul29(self.ctx, _ptr(a), _ptr(b), _ptr(out)), "pz_fq_mul29")
+    def download(self, d_src: int, shape, dtype=np.uint64) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        self._chk(self.L.pz_download(self.ctx, VP(out.ctypes.data), VP(d_src), out.nbytes), "pz_download")
         return out
+
+    def dev_memset(self, d: int, value: int, nbytes: int):
+        self._chk(self.L.pz_dev_memset(self.ctx, VP(d), value, nbytes), "pz_dev_memset")
+
+    def dev_copy(self, d_dst: int, d_src: int, nbytes: int):
+        self._chk(self.L.pz_dev_copy(self.ctx, VP(d_dst), VP(d_src), nbytes), "pz_dev_copy")
+
+    def wait_for(self, other: "Engine"):
+        """everything `other` has queued so far happens before what this engine queues from now on"""
+        self._chk(self.L.pz_ctx_wait(self.ctx, other.ctx), "pz_ctx_wait")
 
 
 T_MSM_ACC, T_NTT, T_TRACE, T_EXPAND, T_MSM_ALL, T_MSM_SORT, T_MSM_TREE = 0, 1, 2, 3, 4, 5, 6

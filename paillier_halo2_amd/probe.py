@@ -1,0 +1,58 @@
+"""ctypes loader of csrc/libpz_probe.so: issue-rate microbenchmarks and alternative field products (measurement only).
+Not part of the product ABI (include/pz.h); bench.py uses mad_indep for the live multiplier-issue peak, profiles/probes/ the rest."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+_probe = None
+
+
+def lib():
+    global _probe
+    if _probe is None:
+        if not os.path.exists(_lib.PROBE_SO_PATH):
+            raise RuntimeError(f"{_lib.PROBE_SO_PATH} is missing: build it with `make -C paillier_halo2_amd/csrc`")
+        _lib.lib()   # the product library first: torch's HIP runtime is then the one already mapped (see _lib.lib)
+        l = C.CDLL(_lib.PROBE_SO_PATH)
+        for name, args in (("pzp_ubench_mad", [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
+                           ("pzp_ubench_mad_indep", [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
+                           ("pzp_ubench_fqmul_variant", [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
+                           ("pzp_fq_mul29", [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])):
+            fn = getattr(l, name)
+            fn.restype = C.c_int
+            fn.argtypes = args
+        _probe = l
+    return _probe
+
+
+def _ms(fn, *args) -> float:
+    ms = C.c_double()
+    if fn(*args, C.byref(ms)) != 0:
+        raise RuntimeError("probe launch failed")
+    return ms.value
+
+
+def ubench_mad(device: int, blocks: int, iters: int) -> float:
+    return _ms(lib().pzp_ubench_mad, device, blocks, iters)
+
+
+def ubench_mad_indep(device: int, blocks: int, iters: int) -> float:
+    return _ms(lib().pzp_ubench_mad_indep, device, blocks, iters)
+
+
+def ubench_fqmul_variant(device: int, variant: int, blocks: int, iters: int) -> float:
+    return _ms(lib().pzp_ubench_fqmul_variant, device, variant, blocks, iters)
+
+
+def fq_mul29(device: int, a, b) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(4)
+    b = np.ascontiguousarray(b, dtype=np.uint64).reshape(4)
+    out = np.zeros(4, dtype=np.uint64)
+    if lib().pzp_fq_mul29(device, a.ctypes.data, b.ctypes.data, out.ctypes.data) != 0:
+        raise RuntimeError("probe launch failed")
+    return out

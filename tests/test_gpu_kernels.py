@@ -337,13 +337,48 @@ def test_encrypt_batch_full_2048(eng, cref):
 
 
 def test_ubench_reports(eng):
-    ms = eng.ubench_mad(2048, 4096)
+    """the measurement probes (libpz_probe.so, outside the product ABI) launch and report"""
+    from paillier_halo2_amd import probe
+
+    ms = probe.ubench_mad(eng.device, 2048, 4096)
     mads = 2048 * 256 * 4096 * 8
     print("\n[ubench] v_mad_u64_u32: %.3f ms, %.2f Tmad/s" % (ms, mads / ms / 1e9))
-    ms = eng.ubench_fqmul(2048, 512)
+    ms = probe.ubench_fqmul_variant(eng.device, 0, 2048, 512)
     muls = 2048 * 256 * 512 * 2
     print("[ubench] Fq mont mul: %.3f ms, %.2f Gmul/s" % (ms, muls / ms / 1e6))
     assert ms > 0
+
+
+def test_device_memory_entry_points(eng, cref):
+    """pz_dev_alloc / pz_upload / pz_download / pz_dev_memset / pz_ctx_wait: a host without its own HIP runtime drives the
+    `_dev` entry points through them (here an NTT round trip and a second context ordered after the first)"""
+    import paillier_halo2_amd as pz
+
+    log_n = 12
+    n = 1 << log_n
+    rng = random.Random(4242)
+    a = cref.fr_ints_to_mont([rng.randrange(P.FR_R) for _ in range(n)])
+    w = cref.fr_ints_to_mont([P.fr_omega(log_n)])[0]
+    d = eng.dev_alloc(n * 32)
+    assert d
+    eng.upload(d, a)
+    eng.ntt_dev(d, 1, 4 * n, w, log_n, None, None)
+    got = eng.download(d, (n, 4))
+    assert np.array_equal(got, cref.ntt_fr(a, w, log_n))
+    # a second context reads what the first one produced: pz_ctx_wait orders the two streams on the device
+    other = pz.Engine(eng.device)
+    eng.upload(d, a)
+    eng.ntt_dev(d, 1, 4 * n, w, log_n, None, None)
+    other.wait_for(eng)
+    w_inv = cref.fr_ints_to_mont([pow(P.fr_omega(log_n), -1, P.FR_R)])[0]
+    n_inv = cref.fr_ints_to_mont([pow(n, -1, P.FR_R)])[0]
+    other.ntt_dev(d, 1, 4 * n, w_inv, log_n, None, n_inv)
+    assert np.array_equal(other.download(d, (n, 4)), a)
+    eng.dev_memset(d, 0, n * 32)
+    assert not eng.download(d, (n, 4)).any()
+    other.close()
+    eng.dev_free(d)
+    eng.dev_free(0)
 
 
 # ------------------------------------------------------------------------------------------ K4
@@ -783,16 +818,18 @@ def test_external_kats(eng, cref):
 def test_fp_mul_variants_probe(eng, cref):
     """the 9 x 29-bit no-carry product (measurement probe) computes a*b*2^-261 mod p, and the
     issue-rate microbenchmark reports all three variants"""
+    from paillier_halo2_amd import probe
+
     rng = random.Random(29)
     inv = pow(1 << 261, -1, P.FQ_P)
     for _ in range(20):
         a, b = rng.randrange(2 * P.FQ_P), rng.randrange(2 * P.FQ_P)
-        got = cref.limbs_to_int(eng.fq_mul29(cref.int_to_limbs(a, 4), cref.int_to_limbs(b, 4)))
+        got = cref.limbs_to_int(probe.fq_mul29(eng.device, cref.int_to_limbs(a, 4), cref.int_to_limbs(b, 4)))
         assert got < 2 * P.FQ_P and got % P.FQ_P == a * b * inv % P.FQ_P
     blocks, iters = 256 * 16, 256
     rates = {}
     for variant, name in ((0, "fp_mul"), (1, "fp_mul_nowait"), (2, "fq29_mul")):
-        ms = min(eng.ubench_fqmul_variant(variant, blocks, iters) for _ in range(3))
+        ms = min(probe.ubench_fqmul_variant(eng.device, variant, blocks, iters) for _ in range(3))
         rates[name] = blocks * 256 * iters * 2 / (ms * 1e-3) / 1e9
     print("Fq products per second (G/s):", {k: round(v, 1) for k, v in rates.items()})
     assert all(v > 10 for v in rates.values())
@@ -965,7 +1002,7 @@ def test_uniform_shape_encrypt_batch(eng, cref):
         assert got == want, i
     with pytest.raises(pz._lib.PzError) as ei:
         eng.paillier_encrypt_uniform(Ln, m_bits, arr([n]), arr([g]), arr([1 << m_bits]), arr([rs[0]]))
-    assert ei.value.status == pz._lib.PZ_ERR_RANGE
+    assert ei.value.status == pz._lib.PZ_ERR_MESSAGE_RANGE
     # 2048-bit key, full-width message bits: values only (no trace), batch of 3
     Ln, bits = 32, 2048
     n, g, _, _ = P.synth_paillier_inputs(bits, 0x5047)
