@@ -671,6 +671,9 @@ def cpu_baseline(shape, n_steps, enc_bits, k, log):
                  + shape.polys * (t_ntt + t_ntt_ext) + n_steps * t_step)
     return {
         "value": 1.0 / per_proof, "unit": "proofs/s", "cores": int(cores), "kind": "port",
+        "per_kernel_ms": {"msm_2pow%d_full_width" % k: t_msm_full * 1e3, "msm_2pow%d_witness_like" % k: t_msm_wit * 1e3,
+                          "ntt_2pow%d" % k: t_ntt * 1e3, "ntt_2pow%d" % (k + 2): t_ntt_ext * 1e3, "mul_mod_step_us_single_thread": t_step * 1e6},
+        "threads_note": "OpenMP threads = the cgroup's CPU quota of this box (oracle/pz_oracle.c::ora_num_threads), not the visible CPU count",
         "sample": ("oracle/pz_oracle.c (C restatement of best_multiexp / best_fft / mul_mod, OpenMP): 2x MSM 2^%d full-width "
                    "(%.3fs each), 2x MSM 2^%d witness-like (%.3fs), 2x NTT 2^%d (%.4fs), 1x NTT 2^%d (%.4fs), %d mul_mod "
                    "steps single-thread (%.1f us each); extrapolated with the per-proof counts in config"

@@ -29,6 +29,7 @@
  */
 #include <stdint.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 #include <math.h>
 #ifdef _OPENMP
@@ -58,6 +59,8 @@ static const field_t FR = {
     0xc2e1f593efffffffULL,
     {0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL},
     {0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL}};
+
+int ora_num_threads(void);
 
 /* ---------------------------------------------------------------- field arithmetic */
 static inline int fe_is_zero(const fe *a) { return (a->l[0] | a->l[1] | a->l[2] | a->l[3]) == 0; }
@@ -401,20 +404,46 @@ static inline unsigned get_at(unsigned segment, unsigned c, const u64 k[4]) {
     return (unsigned)(v & ((1ULL << c) - 1));
 }
 
+/* One thread's share, as halo2curves' multiexp_serial: window bits c ~ ln(n), windows from the top, bucket running sums.  Two
+ * standard refinements of the same algorithm keep this CPU baseline honest ("signed-digit Pippenger with a
+ * per-thread window choice"): digits are recoded to (-2^(c-1), 2^(c-1)] with a carry into the next window, so a window has
+ * 2^(c-1) buckets (a negative digit adds the negated point), and c is taken one larger than ln(n) since buckets cost half.
+ * The VALUE is the same group element; Jacobian representatives are never compared (tests normalise). */
 static void multiexp_serial(const fe *coeffs_canon, const aff_t *bases, size_t n, jac_t *acc) {
     unsigned c;
     if (n < 4) c = 1;
     else if (n < 32) c = 3;
-    else c = (unsigned)ceil(log((double)n));
-    unsigned segments = 256 / c + 1;
-    size_t nb = ((size_t)1 << c) - 1;
+    else c = (unsigned)ceil(log((double)n)) + 1;
+    if (c > 16) c = 16;
+    unsigned segments = 256 / c + 2;                 /* + 1 for the final carry */
+    size_t nb = (size_t)1 << (c - 1);
     jac_t *buckets = (jac_t *)malloc(sizeof(jac_t) * nb);
+    /* signed digits of every scalar, window-major would cost n * segments bytes * 2: recode on the fly per window instead,
+     * carrying per scalar in a byte array (the carry into window s depends only on windows below s: walk windows bottom-up
+     * once to record the carries) */
+    unsigned char *carry_in = (unsigned char *)calloc(n * (size_t)segments, 1);
+    for (size_t i = 0; i < n; ++i) {
+        unsigned carry = 0;
+        for (unsigned seg = 0; seg < segments; ++seg) {
+            carry_in[(size_t)seg * n + i] = (unsigned char)carry;
+            unsigned d = get_at(seg, c, coeffs_canon[i].l) + carry;
+            carry = d > (1u << (c - 1)) ? 1u : 0u;
+        }
+    }
     for (unsigned seg = segments; seg-- > 0;) {
         for (unsigned i = 0; i < c; ++i) jac_double(acc, acc);
         for (size_t b = 0; b < nb; ++b) jac_set_inf(&buckets[b]);
         for (size_t i = 0; i < n; ++i) {
-            unsigned d = get_at(seg, c, coeffs_canon[i].l);
-            if (d) jac_add_mixed(&buckets[d - 1], &buckets[d - 1], &bases[i]);
+            unsigned d = get_at(seg, c, coeffs_canon[i].l) + carry_in[(size_t)seg * n + i];
+            if (!d) continue;
+            if (d > (1u << (c - 1))) {               /* digit d - 2^c < 0: add -P to bucket 2^c - d */
+                if (d == (1u << c)) continue;        /* 2^c - 2^c = 0 with a carry out: nothing in this window */
+                aff_t neg = bases[i];
+                if (!aff_is_inf(&neg)) fe_neg(&neg.y, &neg.y, &FQ);
+                jac_add_mixed(&buckets[(1u << c) - d - 1], &buckets[(1u << c) - d - 1], &neg);
+            } else {
+                jac_add_mixed(&buckets[d - 1], &buckets[d - 1], &bases[i]);
+            }
         }
         jac_t run;
         jac_set_inf(&run);
@@ -423,6 +452,7 @@ static void multiexp_serial(const fe *coeffs_canon, const aff_t *bases, size_t n
             jac_add(acc, acc, &run);
         }
     }
+    free(carry_in);
     free(buckets);
 }
 
@@ -434,7 +464,7 @@ int ora_msm_g1(const u64 *scalars, const u64 *bases, size_t n, int threads, u64 
     fe *canon = (fe *)malloc(sizeof(fe) * n);
     if (!canon) return -1;
 #ifdef _OPENMP
-    if (threads <= 0) threads = omp_get_max_threads();
+    if (threads <= 0) threads = ora_num_threads();
 #else
     threads = 1;
 #endif
@@ -468,34 +498,79 @@ static inline size_t bitrev(size_t k, unsigned l) {
     return r;
 }
 
+/* The butterflies are exactly best_fft's serial layers (bit reversal, then log_n radix-2 DIT layers over a twiddle table
+ * omega^i); only the ORDER differs between threads: the first log_n - log_t layers never leave a contiguous block of n / 2^log_t
+ * elements, so each thread runs them on its own blocks without a barrier (cache-resident), and only the last log_t layers are
+ * swept by all threads together -- halo2curves' best_fft splits the same way (recursive halves per thread).  The field
+ * operations are associative-free (each element's value is the same function of the inputs in any order): results are
+ * bit-identical to the serial layers. */
 int ora_ntt_fr(u64 *a_, const u64 omega_[4], uint32_t log_n, int threads) {
     fe *a = (fe *)a_;
     size_t n = (size_t)1 << log_n;
     const field_t *F = &FR;
 #ifdef _OPENMP
-    if (threads <= 0) threads = omp_get_max_threads();
+    if (threads <= 0) threads = ora_num_threads();
 #else
     threads = 1;
 #endif
-    for (size_t k = 0; k < n; ++k) {
-        size_t rk = bitrev(k, log_n);
-        if (k < rk) { fe t = a[k]; a[k] = a[rk]; a[rk] = t; }
+    if (n < 4096) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(static) if (threads > 1)
+    for (long k = 0; k < (long)n; ++k) {
+        size_t rk = bitrev((size_t)k, log_n);
+        if ((size_t)k < rk) { fe t = a[k]; a[k] = a[rk]; a[rk] = t; }
     }
     if (log_n == 0) return 0;
     size_t half = n / 2;
     fe *tw = (fe *)malloc(sizeof(fe) * half);
     if (!tw) return -1;
-    fe w;
-    memcpy(w.l, F->r1, 32);
-    for (size_t i = 0; i < half; ++i) {
-        tw[i] = w;
-        fe_mul(&w, &w, (const fe *)omega_, F);
+    {   /* omega^i, i < n/2: blocks of 1024 started by square-and-multiply, then successive products */
+        const size_t TB = 1024;
+        size_t nblk = (half + TB - 1) / TB;
+#pragma omp parallel for num_threads(threads) schedule(static) if (threads > 1)
+        for (long b = 0; b < (long)nblk; ++b) {
+            size_t lo = (size_t)b * TB, hi = lo + TB < half ? lo + TB : half;
+            u64 e[4] = {(u64)lo, 0, 0, 0};
+            fe w;
+            fe_pow(&w, (const fe *)omega_, e, F);
+            for (size_t i = lo; i < hi; ++i) {
+                tw[i] = w;
+                fe_mul(&w, &w, (const fe *)omega_, F);
+            }
+        }
     }
-    size_t chunk = 2, tchunk = half;
-    for (uint32_t layer = 0; layer < log_n; ++layer) {
+    /* blocks of 2^log_b elements per task for the barrier-free layers */
+    uint32_t log_b = log_n;
+    if (threads > 1) {
+        uint32_t log_t = 0;
+        while ((1u << log_t) < (unsigned)threads * 4u) ++log_t;   /* a few blocks per thread */
+        log_b = log_n > log_t ? log_n - log_t : 0;
+        if (log_b > 14) log_b = 14;                               /* 512 KiB of elements: stays in a core's L2 */
+    }
+    size_t nb = n >> log_b, bsz = (size_t)1 << log_b;
+#pragma omp parallel for num_threads(threads) schedule(static) if (threads > 1)
+    for (long b = 0; b < (long)nb; ++b) {
+        fe *base = a + (size_t)b * bsz;
+        size_t chunk = 2, tchunk = half;
+        for (uint32_t layer = 0; layer < log_b; ++layer) {
+            size_t hc = chunk / 2;
+            for (size_t blk = 0; blk < bsz; blk += chunk)
+                for (size_t i = 0; i < hc; ++i) {
+                    fe *lo = base + blk + i, *hi = lo + hc;
+                    fe t;
+                    if (i == 0) t = *hi; else fe_mul(&t, hi, &tw[i * tchunk], F);
+                    fe u = *lo;
+                    fe_add(lo, &u, &t, F);
+                    fe_sub(hi, &u, &t, F);
+                }
+            chunk *= 2;
+            tchunk /= 2;
+        }
+    }
+    size_t chunk = (size_t)2 << log_b, tchunk = half >> log_b;
+    for (uint32_t layer = log_b; layer < log_n; ++layer) {
         size_t hc = chunk / 2;
         size_t nblk = n / chunk;
-#pragma omp parallel for num_threads(threads) schedule(static) if (n >= 4096)
+#pragma omp parallel for num_threads(threads) schedule(static) if (threads > 1)
         for (long bj = 0; bj < (long)(nblk * hc); ++bj) {
             size_t blk = (size_t)bj / hc, i = (size_t)bj % hc;
             fe *lo = a + blk * chunk + i;
@@ -687,9 +762,36 @@ int ora_paillier_enc(uint32_t Ln, const u64 *n, const u64 *g, const u64 *m, cons
     return rc;
 }
 
+/* threads worth starting: the OpenMP default, capped by the CPU quota of the cgroup (a GPU box shows 256 logical CPUs and grants
+ * 16: 256 threads on a 16-CPU quota spend their time throttled at the barriers) */
 int ora_num_threads(void) {
 #ifdef _OPENMP
-    return omp_get_max_threads();
+    static int cached = 0;
+    if (cached) return cached;
+    int t = omp_get_max_threads();
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        char q[64];
+        long period = 0;
+        if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            long quota = atol(q);
+            int cpus = (int)((quota + period - 1) / period);
+            if (cpus >= 1 && cpus < t) t = cpus;
+        }
+        fclose(f);
+    } else if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"))) {
+        long quota = -1, period = 100000;
+        if (fscanf(f, "%ld", &quota) != 1) quota = -1;
+        fclose(f);
+        FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+        if (g) { if (fscanf(g, "%ld", &period) != 1) period = 100000; fclose(g); }
+        if (quota > 0 && period > 0) {
+            int cpus = (int)((quota + period - 1) / period);
+            if (cpus >= 1 && cpus < t) t = cpus;
+        }
+    }
+    cached = t < 1 ? 1 : t;
+    return cached;
 #else
     return 1;
 #endif
