@@ -318,8 +318,8 @@ class ProofWorkload:
         # K2: Lagrange -> coeff (iNTT 2^k) -> extended coset: 4 interleaved coset NTTs with the 1/n divisor folded into
         # their pre-scale tables (pz_ntt_fr_extend_dev == zero-extend, distribute_powers, best_fft(omega_ext)).
         # The proof's OWN advice and lookup columns (K4's output, which the commitment stream reads at the same time) are
-        # copied batch by batch into the transform buffer -- the coefficient form is a separate allocation in a prover too --
-        # and transformed there; the remaining polynomials of a proof (permuted lookup columns, lookup and permutation
+        # transformed batch by batch OUT OF PLACE into the transform buffer (pz_ntt_fr_to_dev) -- the coefficient form is a
+        # separate allocation in a prover too; the remaining polynomials of a proof (permuted lookup columns, lookup and permutation
         # products: A + 4 Lk + P in all) come from the resident pool of uniformly random field elements.
         from paillier_halo2_amd import dist as pzd
 
@@ -328,7 +328,6 @@ class ProofWorkload:
         nb = self.ntt_batch
         pool_n = self.col_f if self.stream_n is None else self.col_n
         own = [(self.d_adv[slot], self.adv_cols), (self.d_lk[slot], self.lk_cols)] if (self.own_ntt and self.scale == 1.0 and self.shard == (0, 1)) else []
-        ctx_stream = t.cuda.stream(self.stream_n) if self.stream_n is not None else _null()
         if self.stream_n is not None and self.pipeline:
             self.stream_n.wait_event(self.ready_ev[slot])     # the columns K4 wrote
         for buf, ncols in own:
@@ -337,9 +336,8 @@ class ProofWorkload:
             while c0 < ncols and done < p_hi - p_lo:
                 nc = min(nb, ncols - c0, p_hi - p_lo - done)
                 work = pool_n[:nc]
-                with ctx_stream:
-                    work.copy_(cols[c0:c0 + nc])
-                eng.ntt_dev(work.data_ptr(), nc, 4 * n, self.omega_inv, k, None, None)
+                # lagrange_to_coeff out of place: the Lagrange values stay where the commitment stream reads them
+                eng.ntt_to_dev(cols[c0].data_ptr(), 4 * n, work.data_ptr(), 4 * n, nc, self.omega_inv, k, None, None)
                 eng.ntt_extend_dev(work.data_ptr(), nc, 4 * n, self.d_ext.data_ptr(), 4 * self.ext_n, k, sh.ext_k - k,
                                    self.omega_n, self.coset_gens, self.n_inv)
                 c0 += nc
@@ -1105,7 +1103,7 @@ def main():
     out["comparable"] = bool(args.scale == 1.0 and not os.environ.get("PZ_BENCH_SKIP"))
     out["srs_ms"] = wl.srs_ms
     out["config"]["srs"] = "params file written as gen_srs does (ParamsKZG::setup), read back by paillier_halo2_amd/srs.py, points checked on the device, Lagrange bases by the G1 inverse FFT (no toxic scalar)"
-    out["config"]["ntt_inputs"] = ("the proof's own advice and lookup columns (copied into the transform buffer) + pool polynomials for the rest" if wl.own_ntt else "pool polynomials")
+    out["config"]["ntt_inputs"] = ("the proof's own advice and lookup columns (transformed out of place into the coefficient buffer) + pool polynomials for the rest" if wl.own_ntt else "pool polynomials")
     if keygen is not None:
         out["keygen"] = keygen
     if tail is not None:

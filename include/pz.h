@@ -151,6 +151,11 @@ int pz_ntt_fr_batch(pz_ctx* ctx, uint64_t* const* cols, size_t n_cols, const uin
  *   post_scale  : a[k] *= s   after  the transform (the 1/n `ifft_divisor`)            */
 int pz_ntt_fr_dev(pz_ctx* ctx, uint64_t* d_a, size_t n_cols, size_t col_stride, const uint64_t omega[4],
                   uint32_t log_n, const uint64_t* pre_coset_g, const uint64_t* post_scale);
+/* the same out of place: column j is read at d_in + j*in_stride and its transform written at d_out + j*out_stride (d_in is not
+ * modified; d_out == d_in with equal strides is pz_ntt_fr_dev).  lagrange_to_coeff of a committed column: the Lagrange values
+ * stay where the commitment kernel reads them, the coefficient form gets its own buffer. */
+int pz_ntt_fr_to_dev(pz_ctx* ctx, const uint64_t* d_in, size_t in_stride, uint64_t* d_out, size_t out_stride, size_t n_cols,
+                     const uint64_t omega[4], uint32_t log_n, const uint64_t* pre_coset_g, const uint64_t* post_scale);
 
 /* coeff_to_extended in one call (n = 2^log_n coefficients per column -> 2^log_e * n evaluations on the coset):
  *   d_ext[col][2^log_e * q + r] = sum_i d_coeff[col][i] * scale * coset_gens[r]^i * omega_n^(i q)

@@ -50,6 +50,7 @@ SIGNATURES = {
     "pz_ntt_fr": (C.c_int, [VP, VP, VP, C.c_uint32]),
     "pz_ntt_fr_batch": (C.c_int, [VP, C.POINTER(VP), C.c_size_t, VP, C.c_uint32]),
     "pz_ntt_fr_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, VP, C.c_uint32, VP, VP]),
+    "pz_ntt_fr_to_dev": (C.c_int, [VP, VP, C.c_size_t, VP, C.c_size_t, C.c_size_t, VP, C.c_uint32, VP, VP]),
     "pz_ntt_fr_extend_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, VP, C.c_size_t, C.c_uint32, C.c_uint32, VP, VP, VP]),
     "pz_ntt_fr_coeff_extend_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, VP, C.c_size_t, C.c_uint32, C.c_uint32, VP, VP, VP,
                                              VP]),

@@ -438,13 +438,20 @@ static int launch_final(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t os
 
 extern "C" int pz_ntt_fr_dev(pz_ctx* ctx, uint64_t* d_a, size_t n_cols, size_t col_stride, const uint64_t omega[4],
                              uint32_t log_n, const uint64_t* pre_coset_g, const uint64_t* post_scale) {
-    if (!ctx || !omega || (n_cols && !d_a) || log_n > 27) return PZ_ERR_INVALID;
+    return pz_ntt_fr_to_dev(ctx, d_a, col_stride, d_a, col_stride, n_cols, omega, log_n, pre_coset_g, post_scale);
+}
+
+// out of place: the first pass reads d_in, the last one writes d_out (the same passes; in place when the two are equal)
+extern "C" int pz_ntt_fr_to_dev(pz_ctx* ctx, const uint64_t* d_in, size_t in_stride, uint64_t* d_out, size_t out_stride, size_t n_cols,
+                                const uint64_t omega[4], uint32_t log_n, const uint64_t* pre_coset_g, const uint64_t* post_scale) {
+    if (!ctx || !omega || (n_cols && (!d_in || !d_out)) || log_n > 27) return PZ_ERR_INVALID;
     if (n_cols == 0) return PZ_OK;
     const size_t n = (size_t)1 << log_n;
-    if (col_stride % 4 || col_stride < 4 * n) return PZ_ERR_INVALID;
+    if (in_stride % 4 || in_stride < 4 * n || out_stride % 4 || out_stride < 4 * n) return PZ_ERR_INVALID;
     PZ_ENTER(ctx);
-    const size_t cs = col_stride / 4;  // column stride in elements
-    Fr* a = reinterpret_cast<Fr*>(d_a);
+    const size_t cs = out_stride / 4, is_ = in_stride / 4;  // column strides in elements
+    Fr* a = reinterpret_cast<Fr*>(d_out);
+    const Fr* ain = reinterpret_cast<const Fr*>(d_in);
     void* twv = nullptr;
     PZCHK(pz_get_pow_table(ctx, omega, n, &twv, one261()));   // omega^i * 2^261
     const Fr* tw = (const Fr*)twv;
@@ -476,15 +483,16 @@ extern "C" int pz_ntt_fr_dev(pz_ctx* ctx, uint64_t* d_a, size_t n_cols, size_t c
     for (size_t c0 = 0; c0 < n_cols; c0 += group) {
         size_t nc = n_cols - c0 < group ? n_cols - c0 : group;
         Fr* ac = a + c0 * cs;
+        const Fr* ic = ain + c0 * is_;
         if (npass == 1) {
             NttPass p{};
             p.logR = log_n; p.lo = 1; p.hi = 1; p.tw_mul = 0; p.n = n; p.T = 1; p.n1 = 1; p.n2 = 1;
-            PZCHK(launch_final(ctx, ac, ac, cs, cs, nc, p, tw, pre, post_scale));
+            PZCHK(launch_final(ctx, ic, ac, is_, cs, nc, p, tw, pre, post_scale));
         } else if (npass == 2) {
             size_t n1 = (size_t)1 << lg[0], n2 = (size_t)1 << lg[1];
             NttPass pa{};
             pa.logR = lg[0]; pa.lo = n2; pa.hi = 1; pa.tw_mul = 1; pa.n = n; pa.T = pick_tile(n2, lg[0]);
-            PZCHK(launch_strided(ctx, ac, tmp, cs, n, nc, pa, tw, pre));
+            PZCHK(launch_strided(ctx, ic, tmp, is_, n, nc, pa, tw, pre));
             // tmp columns are packed with stride n
             NttPass pc{};
             pc.logR = lg[1]; pc.lo = 1; pc.hi = n1; pc.n = n; pc.n1 = n1; pc.n2 = 1; pc.T = pick_tile(n1, lg[1]);
@@ -493,7 +501,7 @@ extern "C" int pz_ntt_fr_dev(pz_ctx* ctx, uint64_t* d_a, size_t n_cols, size_t c
             size_t n1 = (size_t)1 << lg[0], n2 = (size_t)1 << lg[1], n3 = (size_t)1 << lg[2];
             NttPass pa{};
             pa.logR = lg[0]; pa.lo = n2 * n3; pa.hi = 1; pa.tw_mul = 1; pa.n = n; pa.T = pick_tile(n2 * n3, lg[0]);
-            PZCHK(launch_strided(ctx, ac, tmp, cs, n, nc, pa, tw, pre));
+            PZCHK(launch_strided(ctx, ic, tmp, is_, n, nc, pa, tw, pre));
             NttPass pb{};
             pb.logR = lg[1]; pb.lo = n3; pb.hi = n1; pb.tw_mul = n1; pb.n = n; pb.T = pick_tile(n3, lg[1]);
             PZCHK(launch_strided(ctx, tmp, tmp, n, n, nc, pb, tw, nullptr));

@@ -187,6 +187,16 @@ class Engine:
         w = _np(omega).reshape(4)
         self._chk(self.L.pz_ntt_fr_batch(self.ctx, arr, len(cols), _ptr(w), log_n), "pz_ntt_fr_batch")
 
+    def ntt_to_dev(self, d_in: int, in_stride_u64: int, d_out: int, out_stride_u64: int, n_cols: int, omega, log_n: int,
+                   pre_coset_g=None, post_scale=None):
+        """out of place: reads d_in, writes d_out (pz_ntt_fr_to_dev)"""
+        w = _np(omega).reshape(4)
+        g = _np(pre_coset_g).reshape(4) if pre_coset_g is not None else None
+        s = _np(post_scale).reshape(4) if post_scale is not None else None
+        self._chk(self.L.pz_ntt_fr_to_dev(self.ctx, VP(d_in), in_stride_u64, VP(d_out), out_stride_u64, n_cols, _ptr(w), log_n,
+                                          _ptr(g) if g is not None else VP(), _ptr(s) if s is not None else VP()),
+                  "pz_ntt_fr_to_dev")
+
     def ntt_dev(self, d_a: int, n_cols: int, col_stride_u64: int, omega, log_n: int, pre_coset_g=None,
                 post_scale=None):
         w = _np(omega).reshape(4)

@@ -142,8 +142,8 @@ int main(int argc, char** argv) {
             CK(pz_msm_g1_dev(ctx, bases, (const uint64_t*)d_pool_f, nc, n, 4 * n, 0, nwin, (uint64_t*)d_out_full + done * 12));
             done += nc;
         }
-        // K2: first the proof's own advice / lookup columns (copied batch by batch into the transform buffer: the coefficient form
-        // is its own allocation in a prover too), then the pool polynomials of the later phases
+        // K2: first the proof's own advice / lookup columns (lagrange_to_coeff out of place into the transform buffer: the
+        // coefficient form is its own allocation in a prover too), then the pool polynomials of the later phases
         size_t done = 0;
         const void* own[2] = {d_adv[slot], d_lk[slot]};
         const size_t own_cols[2] = {adv_cols, lk_cols};
@@ -151,8 +151,8 @@ int main(int argc, char** argv) {
             for (size_t c0 = 0; c0 < own_cols[b] && done < J.polys;) {
                 size_t nc = own_cols[b] - c0 < J.ntt_batch ? own_cols[b] - c0 : J.ntt_batch;
                 if (nc > J.polys - done) nc = J.polys - done;
-                CK(pz_dev_copy(ctxn, d_pool_n, (const char*)own[b] + c0 * n * 32, nc * n * 32));
-                CK(pz_ntt_fr_dev(ctxn, (uint64_t*)d_pool_n, nc, 4 * n, J.omega_inv, (uint32_t)J.k, nullptr, nullptr));
+                CK(pz_ntt_fr_to_dev(ctxn, (const uint64_t*)own[b] + c0 * n * 4, 4 * n, (uint64_t*)d_pool_n, 4 * n, nc, J.omega_inv, (uint32_t)J.k,
+                                    nullptr, nullptr));
                 CK(pz_ntt_fr_extend_dev(ctxn, (const uint64_t*)d_pool_n, nc, 4 * n, (uint64_t*)d_ext, 4 * n * E, (uint32_t)J.k, (uint32_t)J.log_e,
                                         J.omega, J.gens.data(), J.n_inv));
                 c0 += nc;

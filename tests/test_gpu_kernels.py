@@ -1149,3 +1149,29 @@ def test_msm_oom_halving_path(cref):
     assert np.array_equal(got, want)
     tb.free()
     e2.close()
+
+
+@pytest.mark.parametrize("log_n", [6, 12, 17, 19])
+def test_ntt_out_of_place(eng, cref, log_n):
+    """pz_ntt_fr_to_dev == pz_ntt_fr_dev on a copy, and leaves its input untouched (1, 2 and 3 pass sizes; strided columns)"""
+    import torch
+
+    n, ncols = 1 << log_n, 3
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(log_n)
+    x = torch.randint(0, 1 << 62, (ncols, n + 8, 4), dtype=torch.int64, device="cuda", generator=gen)
+    x[:, :, 3] &= 0x0FFFFFFFFFFFFFFF
+    keep = x.clone()
+    out = torch.zeros((ncols, n, 4), dtype=torch.int64, device="cuda")
+    w = cref.fr_ints_to_mont([P.fr_omega(log_n)])[0]
+    sc = cref.fr_ints_to_mont([pow(n, -1, P.FR_R)])[0]
+    eng.ntt_to_dev(x.data_ptr(), 4 * (n + 8), out.data_ptr(), 4 * n, ncols, w, log_n, None, sc)
+    eng.sync()
+    assert torch.equal(x, keep)
+    ref = x[:, :n].contiguous()
+    eng.ntt_dev(ref.data_ptr(), ncols, 4 * n, w, log_n, None, sc)
+    eng.sync()
+    assert torch.equal(out, ref)
+    if log_n <= 12:
+        a = x[1, :n].cpu().numpy().view(np.uint64)
+        assert np.array_equal(out[1].cpu().numpy().view(np.uint64), cref.fr_scale(cref.ntt_fr(a, w, log_n), sc))
