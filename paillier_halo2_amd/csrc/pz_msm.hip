@@ -19,6 +19,7 @@
 // traffic is 96 B per (scalar, base) pair; bench.py reports both fractions.
 #include "ec.cuh"
 #include "ec29.cuh"
+#include "ec29_quad.cuh"
 #include <stdlib.h>
 
 #include "pz_internal.h"
@@ -27,7 +28,6 @@
 #define MSM_CHUNK_MAX 256u  // chosen per launch sequence by msm_chunk_for)
 #define MSM_HEAVY 24u       // buckets with more chunks than this are folded by a whole workgroup
 #define MSM_MEDIUM 1024u    // ... up to this many chunks by a 32-lane group (k_msm_medium_sum), more by a whole workgroup
-#define SLICE_PER_THREAD 4u
 #define MSM_SLICE_MAX_COLS 8u   // up to this many columns per launch sequence take the bit-sliced reduction (latency), more the radix-16 tree (throughput)
 
 struct MsmP {
@@ -806,6 +806,21 @@ __global__ __launch_bounds__(256) void k_msm_fold_few(MsmP p, const u32* __restr
         }
         if (!__syncthreads_or(m != 0)) continue;   // nothing to fold in this round (block-uniform)
         G1X29Raw* pc = partials + col * p.max_items + first;
+        if (logG == 2) {
+            // a quad per bucket: its four lanes walk the partial sums TOGETHER, each addition split over them (ec29_quad.cuh:
+            // 4 product latencies per addition instead of 14); the next partial is in flight while the current one is added
+            if (m) {
+                G1X29 acc = x29_load_raw(pc);
+                G1X29 nxt = x29_load_raw(pc + 1);
+                for (u32 t = 1; t < m; ++t) {
+                    const G1X29 cur = nxt;
+                    if (t + 1 < m) nxt = x29_load_raw(pc + t + 1);
+                    x29_add_quad(acc, cur);
+                }
+                if (l == 0) x29_store_raw(pc, acc);
+            }
+            continue;
+        }
         G1X29 acc = x29_inf();
         for (u32 t = l; t < m; t += G) {
             G1X29 o = x29_load_raw(pc + t);
@@ -980,19 +995,23 @@ __global__ __launch_bounds__(128) void k_msm_combine(unsigned n_in, unsigned m, 
 //   k_msm_slice_reduce  : the B/256 partials of (column, bit j) -> T_j (LDS tree)
 //   k_msm_slice_horner  : U = T_0 + 2 T_1, ...; then pairs of pairs with 2, 4, 8 doublings: one workgroup per column
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lds_tree_sum(G1X29Raw* s_pt, unsigned nthreads) {   // nthreads a power of two <= 256
-    for (unsigned off = nthreads >> 1; off > 0; off >>= 1) {
+// sum of the first n entries of s_pt (n a power of two <= 256, 256 threads) into s_pt[0]: pairwise tree, every addition done by a
+// QUAD (ec29_quad.cuh) -- 64 additions per round, ~4 product latencies each
+__device__ __forceinline__ void lds_tree_sum_quad(G1X29Raw* s_pt, unsigned n) {
+    const unsigned quad = threadIdx.x >> 2;
+    for (unsigned off = n >> 1; off > 0; off >>= 1) {
         __syncthreads();
-        if (threadIdx.x < off) {
-            G1X29 a = x29_load_raw(&s_pt[threadIdx.x]);
-            G1X29 o = x29_load_raw(&s_pt[threadIdx.x + off]);
-            x29_add(a, o);
-            x29_store_raw(&s_pt[threadIdx.x], a);
+        for (unsigned node = quad; node < off; node += 64) {   // the same trip count for the four lanes of a quad
+            G1X29 a = x29_load_raw(&s_pt[node]);
+            const G1X29 o = x29_load_raw(&s_pt[node + off]);
+            x29_add_quad(a, o);
+            if ((threadIdx.x & 3u) == 0) x29_store_raw(&s_pt[node], a);
         }
     }
     __syncthreads();
 }
 
+// one bucket per thread: the partial sum of the buckets of this 256-bucket block whose weight has bit j
 __global__ __launch_bounds__(256) void k_msm_slice_partial(MsmP p, const u32* __restrict__ items,
                                                            const G1X29Raw* __restrict__ partials, unsigned nblk,
                                                            G1X29Raw* __restrict__ slice_part) {
@@ -1001,15 +1020,13 @@ __global__ __launch_bounds__(256) void k_msm_slice_partial(MsmP p, const u32* __
     const unsigned j = blockIdx.y;
     const u32* it = items + col * (p.B + 1);
     G1X29 v = x29_inf();
-    for (unsigned q = 0; q < SLICE_PER_THREAD; ++q) {   // a few buckets per lane, then the tree
-        const unsigned b = (blockIdx.x * SLICE_PER_THREAD + q) * 256 + threadIdx.x;
-        if (b < p.B && (((b + 1) >> j) & 1u) && it[b + 1] > it[b]) {
-            G1X29 o = x29_load_raw(partials + col * p.max_items + it[b]);
-            x29_add(v, o);
-        }
+    const unsigned b = blockIdx.x * 256 + threadIdx.x;
+    if (b < p.B && (((b + 1) >> j) & 1u)) {
+        const u32 a = it[b], z = it[b + 1];
+        if (z > a) v = x29_load_raw(partials + col * p.max_items + a);
     }
     x29_store_raw(&s_pt[threadIdx.x], v);
-    lds_tree_sum(s_pt, 256);
+    lds_tree_sum_quad(s_pt, 256);
     if (threadIdx.x == 0) slice_part[(col * p.c + j) * nblk + blockIdx.x] = s_pt[0];
 }
 
@@ -1025,11 +1042,13 @@ __global__ __launch_bounds__(256) void k_msm_slice_reduce(MsmP p, unsigned nblk,
         x29_add(acc, o);
     }
     x29_store_raw(&s_pt[threadIdx.x], acc);
-    lds_tree_sum(s_pt, 256);
+    unsigned n = 1;
+    while (n < nblk && n < 256) n <<= 1;   // only the levels that hold something
+    lds_tree_sum_quad(s_pt, n);
     if (threadIdx.x == 0) slices[col * 16 + j] = s_pt[0];
 }
 
-// sum_j 2^j T_j for c <= 16 slices: four pairwise levels, level l combining neighbours with 2^l doublings
+// sum_j 2^j T_j for c <= 16 slices: four pairwise levels, level l combining neighbours with 2^l doublings; every pair is a quad's
 __global__ __launch_bounds__(64) void k_msm_slice_horner(MsmP p, const G1X29Raw* __restrict__ slices, G1Jac* __restrict__ out) {
     __shared__ G1X29Raw s_pt[16];
     const size_t col = blockIdx.x;
@@ -1037,16 +1056,17 @@ __global__ __launch_bounds__(64) void k_msm_slice_horner(MsmP p, const G1X29Raw*
         G1X29 v = threadIdx.x < p.c ? x29_load_raw(slices + col * 16 + threadIdx.x) : x29_inf();
         x29_store_raw(&s_pt[threadIdx.x], v);
     }
+    const unsigned quad = threadIdx.x >> 2;
     for (unsigned l = 0; l < 4; ++l) {
         __syncthreads();
         const unsigned stride = 1u << l;
-        if (threadIdx.x < (8u >> l)) {
-            const unsigned i = threadIdx.x * 2 * stride;
+        if (quad < (8u >> l)) {
+            const unsigned i = quad * 2 * stride;
             G1X29 hi = x29_load_raw(&s_pt[i + stride]);
-            for (unsigned k = 0; k < stride; ++k) hi = x29_dbl(hi);
+            for (unsigned k = 0; k < stride; ++k) hi = x29_dbl_quad(hi);
             G1X29 lo = x29_load_raw(&s_pt[i]);
-            x29_add(lo, hi);
-            x29_store_raw(&s_pt[i], lo);
+            x29_add_quad(lo, hi);
+            if ((threadIdx.x & 3u) == 0) x29_store_raw(&s_pt[i], lo);
         }
     }
     __syncthreads();
@@ -1306,7 +1326,7 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     }
     if (nc <= MSM_SLICE_MAX_COLS) {
         // few columns: bit-sliced parallel reduction (depth ~ log2 B + log2 c point additions)
-        const unsigned nblk = pz_div_up(p.B, 256 * SLICE_PER_THREAD);
+        const unsigned nblk = pz_div_up(p.B, 256);
         void *sp, *sl;
         PZCHK(pz_ws_get(ctx, WS_NODES_A, nc * (size_t)p.c * nblk * sizeof(G1X29Raw), &sp));
         PZCHK(pz_ws_get(ctx, WS_NODES_B, nc * 16 * sizeof(G1X29Raw), &sl));
