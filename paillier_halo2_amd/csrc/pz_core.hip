@@ -28,6 +28,15 @@ __global__ void k_pow_table(Fr base, Fr init, Fr* table, size_t n, unsigned ch) 
     }
 }
 
+// 256-bit integers -> 9 x 29-bit limbs (the form the K2 kernels multiply by: no unpack per use)
+__global__ void k_raw29(const Fr* __restrict__ src, u32* __restrict__ dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const F29<FrTag> x = f29_load<FrTag>(src + i);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) dst[9 * i + j] = x.v[j];
+}
+
 // ------------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------------
@@ -82,8 +91,10 @@ extern "C" int pz_free(pz_ctx* ctx) {
     (void)hipDeviceSynchronize();
     for (auto& w : ctx->ws)
         if (w.d) (void)hipFree(w.d);
-    for (auto& t : ctx->pow_tables)
+    for (auto& t : ctx->pow_tables) {
         if (t.d) (void)hipFree(t.d);
+        if (t.d_raw) (void)hipFree(t.d_raw);
+    }
     for (auto& t : ctx->ext_tables)
         if (t.d) (void)hipFree(t.d);
     for (auto& v : ctx->ev)
@@ -252,6 +263,7 @@ int pz_get_pow_table(pz_ctx* ctx, const uint64_t base[4], size_t n, void** d_out
             return PZ_OK;
         }
     void* reuse = nullptr;
+    void* reuse_raw = nullptr;
     size_t reuse_cap = 0;
     if (ctx->pow_tables.size() >= 48) {
         // evict the least recently used table.  Its buffer is handed to the new table when it is large enough: the kernel
@@ -264,9 +276,11 @@ int pz_get_pow_table(pz_ctx* ctx, const uint64_t base[4], size_t n, void** d_out
         if (ctx->pow_tables[lru].cap >= n) {
             reuse = ctx->pow_tables[lru].d;
             reuse_cap = ctx->pow_tables[lru].cap;
+            reuse_raw = ctx->pow_tables[lru].d_raw;   // same capacity: rebuilt on demand (in stream order)
         } else {
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
             HIPCHK(ctx, hipFree(ctx->pow_tables[lru].d));
+            if (ctx->pow_tables[lru].d_raw) HIPCHK(ctx, hipFree(ctx->pow_tables[lru].d_raw));
         }
         ctx->pow_tables.erase(ctx->pow_tables.begin() + lru);
     }
@@ -278,6 +292,8 @@ int pz_get_pow_table(pz_ctx* ctx, const uint64_t base[4], size_t n, void** d_out
     if (reuse) {
         t.d = reuse;
         t.cap = reuse_cap;
+        t.d_raw = reuse_raw;
+        t.raw_valid = false;
     } else {
         HIPCHK(ctx, hipMalloc(&t.d, n * 32));
         t.cap = n;
@@ -292,6 +308,32 @@ int pz_get_pow_table(pz_ctx* ctx, const uint64_t base[4], size_t n, void** d_out
     ctx->pow_tables.push_back(t);
     *d_out = t.d;
     return PZ_OK;
+}
+
+int pz_raw29_convert(pz_ctx* ctx, const void* d_src_fr, void* d_dst_u32, size_t count) {
+    if (!count) return PZ_OK;
+    hipLaunchKernelGGL(k_raw29, dim3(pz_div_up(count, 256)), dim3(256), 0, ctx->stream, (const Fr*)d_src_fr, (u32*)d_dst_u32, count);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}
+
+int pz_get_pow_table_raw(pz_ctx* ctx, const uint64_t base[4], size_t n, void** d_raw_out, const uint64_t* init) {
+    void* d;
+    PZCHK(pz_get_pow_table(ctx, base, n, &d, init));
+    for (auto& t : ctx->pow_tables)
+        if (t.d == d) {
+            if (!t.d_raw) {
+                HIPCHK(ctx, hipMalloc(&t.d_raw, t.cap * 36));
+                t.raw_valid = false;
+            }
+            if (!t.raw_valid) {
+                PZCHK(pz_raw29_convert(ctx, t.d, t.d_raw, t.n));
+                t.raw_valid = true;
+            }
+            *d_raw_out = t.d_raw;
+            return PZ_OK;
+        }
+    return PZ_ERR_INVALID;
 }
 
 // ---- timing ------------------------------------------------------------------------------------

@@ -19,12 +19,14 @@ struct pz_pow_table {   // cached table init * base^i, i < n  (twiddles omega^i,
     size_t n;
     size_t cap;         // entries the buffer holds (>= n: an evicted table's buffer is reused)
     void* d;            // cap x 32 B
+    void* d_raw = nullptr;   // the same entries as 9 x 29-bit limbs (36 B each), built on demand for the K2 kernels (no unpack per use)
+    bool raw_valid = false;
     uint64_t stamp;     // last use (LRU: per-proof challenge points would otherwise grow the cache without bound)
 };
 
 struct pz_ext_table {   // packed [2^e][n] pre-scale tables of pz_ntt_fr_extend_dev, keyed by its parameters
     std::vector<uint64_t> key;
-    void* d;
+    void* d;       // 9 x 29-bit limbs per entry (36 B): [2^e][n][9] u32
 };
 
 struct pz_wsbuf {
@@ -104,6 +106,10 @@ static inline int pz_hip_fail(pz_ctx* ctx, hipError_t e, const char* what) {
 int pz_ws_get(pz_ctx* ctx, int slot, size_t bytes, void** out);
 // cached base^i table (device, Fr Montgomery)
 int pz_get_pow_table(pz_ctx* ctx, const uint64_t base[4], size_t n, void** d_out, const uint64_t* init = nullptr);
+// the same table as raw 9 x 29-bit limbs per entry (n x 9 u32), cached beside it
+int pz_get_pow_table_raw(pz_ctx* ctx, const uint64_t base[4], size_t n, void** d_raw_out, const uint64_t* init = nullptr);
+// dst[9 i + j] = limb j (29 bits; the top limb takes the rest) of the 256-bit integer src[i]: asynchronous on the context's stream
+int pz_raw29_convert(pz_ctx* ctx, const void* d_src_fr, void* d_dst_u32, size_t count);
 
 // timing scopes: record an event pair around a kernel-class region on ctx->stream
 struct pz_timer {

@@ -86,6 +86,30 @@ __device__ __forceinline__ void lds29_put(u32* sm, unsigned e, const Fr29& a) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) p[i] = a.v[i];
 }
+// entry idx of a raw table (9 x 29-bit limbs per entry, 36 B: pz_get_pow_table_raw): no unpacking
+__device__ __forceinline__ Fr29 raw9_get(const u32* __restrict__ tab, size_t idx) {
+    Fr29 r;
+    const u32* p = tab + idx * 9u;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.v[i] = p[i];
+    return r;
+}
+struct Raw9 {
+    u32 v[9];
+};
+__device__ __forceinline__ Raw9 raw9_load(const u32* __restrict__ tab, size_t idx) {
+    Raw9 r;
+    const u32* p = tab + idx * 9u;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.v[i] = p[i];
+    return r;
+}
+__device__ __forceinline__ Fr29 raw9_fr(const Raw9& x) {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.v[i] = x.v[i];
+    return r;
+}
 // radix-2 butterfly on carried inputs (u any value, v the already multiplied, tight operand below 2p)
 __device__ __forceinline__ void bf29(const Fr29& u, const Fr29& v, Fr29& sum, Fr29& diff) {
     sum = f29_add(u, v);
@@ -98,7 +122,7 @@ __device__ __forceinline__ void bf29(const Fr29& u, const Fr29& v, Fr29& sum, Fr
 // once per stage.  Stages 0+1 cost one product per group (their other twiddles are 1).  An odd logR ends with one
 // plain radix-2 stage.  element (j, t) lives at tile index j*sr + t*st.  Input must be stored bit-reversed in j.
 __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, unsigned sr, unsigned st, bool t_fastest,
-                                          const Fr* __restrict__ tw, size_t n_) {
+                                          const u32* __restrict__ tw, size_t n_) {
     const unsigned n = (unsigned)n_;   // n <= 2^27: twiddle indices fit 32 bits
     const unsigned R = 1u << logR;
     const unsigned logT = 31u - (unsigned)__builtin_clz(T);
@@ -126,13 +150,13 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
                 // parallel carry round each
                 a0 = f29_carry(a0);
                 a2 = f29_carry(a2);
-                const Fr29 w = f29_load<FrTag>(tw + pos * (n >> (s + 1)));
+                const Fr29 w = raw9_get(tw, pos * (n >> (s + 1)));
                 a1 = f29_mul(a1, w);
                 a3 = f29_mul(a3, w);
                 bf29(a0, a1, b0, b1);
                 bf29(a2, a3, b2, b3);
-                b2 = f29_mul(b2, f29_load<FrTag>(tw + pos * (n >> (s + 2))));
-                b3 = f29_mul(b3, f29_load<FrTag>(tw + (pos + h) * (n >> (s + 2))));
+                b2 = f29_mul(b2, raw9_get(tw, pos * (n >> (s + 2))));
+                b3 = f29_mul(b3, raw9_get(tw, (pos + h) * (n >> (s + 2))));
                 bf29(b0, b2, o0, o2);
             } else {
                 // stages 0 + 1: operands straight from the load (tight, value < 2p); the first layer's twiddles and the
@@ -141,7 +165,7 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
                 b1 = f29_sub<2, 29>(a0, a1);
                 b2 = f29_add(a2, a3);          // un-multiplied: limbs < 2^30, value < 4p -> subtrahend of f29_sub<4, 30>
                 b3 = f29_sub<2, 29>(a2, a3);
-                b3 = f29_mul(b3, f29_load<FrTag>(tw + (pos + h) * (n >> (s + 2))));
+                b3 = f29_mul(b3, raw9_get(tw, (pos + h) * (n >> (s + 2))));
                 o0 = f29_add(b0, b2);
                 o2 = f29_sub<4, 30>(b0, b2);
             }
@@ -174,7 +198,7 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
             Fr29 o0, o1;
             if (s) {
                 u = f29_carry(u);
-                v = f29_mul(v, f29_load<FrTag>(tw + pos * (n >> (s + 1))));
+                v = f29_mul(v, raw9_get(tw, pos * (n >> (s + 1))));
                 bf29(u, v, o0, o1);
             } else {  // a single stage (logR == 1): operands straight from the load (tight, < 2p)
                 o0 = f29_add(u, v);
@@ -190,8 +214,8 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
 // strided pass.  grid.x = hi * (lo / T), grid.y = column.  tw, pre: 261-domain tables
 template <bool PRE>
 __global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, size_t in_stride, size_t out_stride,
-                                                       NttPass p, const Fr* __restrict__ tw,
-                                                       const Fr* __restrict__ pre0, unsigned n_r, size_t pre_r_stride,
+                                                       NttPass p, const u32* __restrict__ tw,
+                                                       const u32* __restrict__ pre0, unsigned n_r, size_t pre_r_stride,
                                                        size_t out_r_stride) {
     u32* sm = reinterpret_cast<u32*>(pz_smem);
     const unsigned R = 1u << p.logR, T = p.T;
@@ -211,24 +235,25 @@ __global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, si
     // (one per coset) into n_r outputs; the tile is re-read from L2, not from HBM, and one launch does the work of n_r
     Fr* const dst0 = dst;
     for (unsigned rr = 0; rr < n_r; ++rr) {
-    const Fr* __restrict__ pre = pre0 + (size_t)rr * pre_r_stride;
+    const u32* __restrict__ pre = pre0 + (size_t)rr * pre_r_stride * 9u;
     dst = dst0 + (size_t)rr * out_r_stride;
     if (rr) __syncthreads();   // the previous coset's stores have read the tile
     for (unsigned i0 = 0; i0 < nelem; i0 += NTT_LB * 256u) {
-        Fr raw[NTT_LB], praw[NTT_LB];
+        Fr raw[NTT_LB];
+        Raw9 praw[NTT_LB];
 #pragma unroll
         for (unsigned k = 0; k < NTT_LB; ++k) {
             const unsigned idx = (i0 + k * 256u + threadIdx.x) & (nelem - 1);   // lanes past the tile re-read one of its elements: no branch around the loads
             const size_t g = base + (size_t)(idx >> logT) * p.lo + (idx & (T - 1));
             raw[k] = fp_load<FrTag>(src + g);
-            if (PRE) praw[k] = fp_load<FrTag>(pre + g);
+            if (PRE) praw[k] = raw9_load(pre, g);
         }
 #pragma unroll
         for (unsigned k = 0; k < NTT_LB; ++k) {
             const unsigned idx = i0 + k * 256u + threadIdx.x;
             if (idx < nelem) {
                 Fr29 x = f29_from_fp(raw[k]);
-                if (PRE) x = f29_mul(x, f29_from_fp(praw[k]));
+                if (PRE) x = f29_mul(x, raw9_fr(praw[k]));
                 lds29_put(sm, bitrev32(idx >> logT, p.logR) * T + (idx & (T - 1)), x);
             }
         }
@@ -236,11 +261,11 @@ __global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, si
     __syncthreads();
     lds_dit29(sm, p.logR, T, T, 1, true, tw, p.n);
     for (unsigned i0 = 0; i0 < nelem; i0 += NTT_LB * 256u) {
-        Fr traw[NTT_LB];
+        Raw9 traw[NTT_LB];
 #pragma unroll
         for (unsigned k = 0; k < NTT_LB; ++k) {
             const unsigned idx = (i0 + k * 256u + threadIdx.x) & (nelem - 1);
-            traw[k] = fp_load<FrTag>(tw + p.tw_mul * (lt * T + (idx & (T - 1))) * (idx >> logT));  // exponent < n by construction
+            traw[k] = raw9_load(tw, p.tw_mul * (lt * T + (idx & (T - 1))) * (idx >> logT));  // exponent < n by construction
         }
 #pragma unroll
         for (unsigned k = 0; k < NTT_LB; ++k) {
@@ -248,7 +273,7 @@ __global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, si
             if (idx < nelem) {
                 const unsigned kk = idx >> logT, t = idx & (T - 1);
                 // always through the product (tw[0] = 1): the result is below 2p whatever the stages accumulated
-                const Fr29 x = f29_mul(lds29_get(sm, kk * T + t), f29_from_fp(traw[k]));
+                const Fr29 x = f29_mul(lds29_get(sm, kk * T + t), raw9_fr(traw[k]));
                 ntt_store<false, 1>(dst + base + (size_t)kk * p.lo + t, x);
             }
         }
@@ -259,7 +284,7 @@ __global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, si
 // final pass.  grid.x = n2 * (n1 / T), grid.y = column
 template <bool PRE>
 __global__ __launch_bounds__(256) void k_ntt_final29(const Fr* in, Fr* out, size_t in_stride, size_t out_stride,
-                                                     NttPass p, const Fr* __restrict__ tw, const Fr* __restrict__ pre,
+                                                     NttPass p, const u32* __restrict__ tw, const u32* __restrict__ pre,
                                                      Fr post, int has_post) {
     u32* sm = reinterpret_cast<u32*>(pz_smem);
     const unsigned R = 1u << p.logR, T = p.T;
@@ -271,20 +296,21 @@ __global__ __launch_bounds__(256) void k_ntt_final29(const Fr* in, Fr* out, size
     Fr* dst = out + by * out_stride;
     const unsigned nelem = R * T;
     for (unsigned i0 = 0; i0 < nelem; i0 += NTT_LB * 256u) {
-        Fr raw[NTT_LB], praw[NTT_LB];
+        Fr raw[NTT_LB];
+        Raw9 praw[NTT_LB];
 #pragma unroll
         for (unsigned k = 0; k < NTT_LB; ++k) {
             const unsigned idx = (i0 + k * 256u + threadIdx.x) & (nelem - 1);
             const size_t g = ((k1_0 + (idx >> p.logR)) * p.n2 + k2) * R + (idx & (R - 1));
             raw[k] = fp_load<FrTag>(src + g);
-            if (PRE) praw[k] = fp_load<FrTag>(pre + g);
+            if (PRE) praw[k] = raw9_load(pre, g);
         }
 #pragma unroll
         for (unsigned k = 0; k < NTT_LB; ++k) {
             const unsigned idx = i0 + k * 256u + threadIdx.x;
             if (idx < nelem) {
                 Fr29 x = f29_from_fp(raw[k]);
-                if (PRE) x = f29_mul(x, f29_from_fp(praw[k]));
+                if (PRE) x = f29_mul(x, raw9_fr(praw[k]));
                 lds29_put(sm, (idx >> p.logR) * R + bitrev32(idx & (R - 1), p.logR), x);
             }
         }
@@ -308,7 +334,7 @@ __global__ __launch_bounds__(256) void k_ntt_final29(const Fr* in, Fr* out, size
 template <bool PRE>
 __global__ __launch_bounds__(256) void k_ntt_final_ext29(const Fr* in, Fr* out, size_t in_stride, size_t in_r_stride,
                                                          size_t out_stride, NttPass p, unsigned log_e,
-                                                         const Fr* __restrict__ tw, const Fr* __restrict__ pre,
+                                                         const u32* __restrict__ tw, const u32* __restrict__ pre,
                                                          size_t pre_r_stride) {
     u32* sm = reinterpret_cast<u32*>(pz_smem);
     const unsigned R = 1u << p.logR, T = p.T, E = 1u << log_e;
@@ -320,14 +346,15 @@ __global__ __launch_bounds__(256) void k_ntt_final_ext29(const Fr* in, Fr* out, 
     Fr* dst = out + by * out_stride;
     const unsigned nelem = R * T * E;
     for (unsigned i0 = 0; i0 < nelem; i0 += NTT_LB * 256u) {
-        Fr raw[NTT_LB], praw[NTT_LB];
+        Fr raw[NTT_LB];
+        Raw9 praw[NTT_LB];
 #pragma unroll
         for (unsigned k = 0; k < NTT_LB; ++k) {
             const unsigned idx = (i0 + k * 256u + threadIdx.x) & (nelem - 1);
             const unsigned j = idx & (R - 1), rr = (idx >> p.logR) & (T - 1), r = idx >> (p.logR + logT);
             const size_t g = ((k1_0 + rr) * p.n2 + k2) * R + j;
             raw[k] = fp_load<FrTag>(src + (size_t)r * in_r_stride + g);
-            if (PRE) praw[k] = fp_load<FrTag>(pre + (size_t)r * pre_r_stride + g);
+            if (PRE) praw[k] = raw9_load(pre, (size_t)r * pre_r_stride + g);
         }
 #pragma unroll
         for (unsigned k = 0; k < NTT_LB; ++k) {
@@ -335,7 +362,7 @@ __global__ __launch_bounds__(256) void k_ntt_final_ext29(const Fr* in, Fr* out, 
             if (idx < nelem) {
                 const unsigned j = idx & (R - 1), rr = (idx >> p.logR) & (T - 1), r = idx >> (p.logR + logT);
                 Fr29 x = f29_from_fp(raw[k]);
-                if (PRE) x = f29_mul(x, f29_from_fp(praw[k]));
+                if (PRE) x = f29_mul(x, raw9_fr(praw[k]));
                 lds29_put(sm, (r * T + rr) * R + bitrev32(j, p.logR), x);
             }
         }
@@ -407,7 +434,7 @@ static const uint64_t* one261() {
 const uint64_t* pz_fr_one261() { return one261(); }   // for the other translation units' 261-domain power tables
 
 static int launch_strided(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t os, size_t ncols, NttPass p,
-                          const Fr* tw, const Fr* pre, unsigned n_r = 1, size_t pre_r_stride = 0, size_t out_r_stride = 0) {
+                          const u32* tw, const u32* pre, unsigned n_r = 1, size_t pre_r_stride = 0, size_t out_r_stride = 0) {
     size_t blocks = p.hi * (p.lo / p.T);
     size_t lds = ntt29_lds_bytes(((size_t)1 << p.logR) * p.T);
     p.swap = (ncols > 1 && blocks <= 65535) ? 1u : 0u;
@@ -418,7 +445,7 @@ static int launch_strided(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t 
     return PZ_OK;
 }
 static int launch_final(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t os, size_t ncols, NttPass p,
-                        const Fr* tw, const Fr* pre, const uint64_t* post_scale) {
+                        const u32* tw, const u32* pre, const uint64_t* post_scale) {
     size_t blocks = p.n2 * (p.n1 / p.T);
     size_t lds = ntt29_lds_bytes(((size_t)1 << p.logR) * p.T);
     Fr post;
@@ -453,11 +480,11 @@ extern "C" int pz_ntt_fr_to_dev(pz_ctx* ctx, const uint64_t* d_in, size_t in_str
     Fr* a = reinterpret_cast<Fr*>(d_out);
     const Fr* ain = reinterpret_cast<const Fr*>(d_in);
     void* twv = nullptr;
-    PZCHK(pz_get_pow_table(ctx, omega, n, &twv, one261()));   // omega^i * 2^261
-    const Fr* tw = (const Fr*)twv;
+    PZCHK(pz_get_pow_table_raw(ctx, omega, n, &twv, one261()));   // omega^i * 2^261 as 9 x 29-bit limbs
+    const u32* tw = (const u32*)twv;
     void* prev = nullptr;
-    if (pre_coset_g) PZCHK(pz_get_pow_table(ctx, pre_coset_g, n, &prev, one261()));
-    const Fr* pre = (const Fr*)prev;
+    if (pre_coset_g) PZCHK(pz_get_pow_table_raw(ctx, pre_coset_g, n, &prev, one261()));
+    const u32* pre = (const u32*)prev;
 
     const unsigned npass = log_n <= 9 ? 1 : (log_n <= 18 ? 2 : 3);
     unsigned lg[3] = {0, 0, 0};
@@ -529,11 +556,11 @@ static int get_ext_pre_tables(pz_ctx* ctx, const uint64_t* coset_gens, size_t E,
     if (scale) fr_times32(scale, init);
     else memcpy(init, one261(), 32);
     void* prev = nullptr;
-    HIPCHK(ctx, hipMalloc(&prev, E * n * 32));
+    HIPCHK(ctx, hipMalloc(&prev, E * n * 36));   // raw 9 x 29-bit limbs per entry
     for (size_t r = 0; r < E; ++r) {
         void* t;
         PZCHK(pz_get_pow_table(ctx, coset_gens + 4 * r, n, &t, init));
-        HIPCHK(ctx, hipMemcpyAsync((char*)prev + r * n * 32, t, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+        PZCHK(pz_raw29_convert(ctx, t, (char*)prev + r * n * 36, n));
     }
     ctx->ext_tables.push_back(pz_ext_table{key, prev});
     *out = prev;
@@ -554,11 +581,11 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
     PZ_ENTER(ctx);
     const size_t is = in_stride / 4, os = out_stride / 4;
     void* twv = nullptr;
-    PZCHK(pz_get_pow_table(ctx, omega_n, n, &twv, one261()));
-    const Fr* tw = (const Fr*)twv;
+    PZCHK(pz_get_pow_table_raw(ctx, omega_n, n, &twv, one261()));
+    const u32* tw = (const u32*)twv;
     void* prev = nullptr;
     PZCHK(get_ext_pre_tables(ctx, coset_gens, E, log_n, scale, &prev));
-    const Fr* pre = (const Fr*)prev;
+    const u32* pre = (const u32*)prev;
     const Fr* cin = (const Fr*)d_coeff;
     Fr* eout = (Fr*)d_ext;
     const unsigned npass = log_n <= 9 ? 1 : (log_n <= 18 ? 2 : 3);
@@ -605,7 +632,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
             const size_t lds = ntt29_lds_bytes(((size_t)1 << lg[2]) * T * E);
             pc.swap = (nc > 1 && n2 * (n1 / T) <= 65535) ? 1u : 0u;
             hipLaunchKernelGGL(k_ntt_final_ext29<false>, pc.swap ? dim3((unsigned)nc, (unsigned)(n2 * (n1 / T))) : dim3((unsigned)(n2 * (n1 / T)), (unsigned)nc), dim3(256), lds, ctx->stream, tmp,
-                               eout + c0 * os, n, nc * n, os, pc, log_e, tw, (const Fr*)nullptr, (size_t)0);
+                               eout + c0 * os, n, nc * n, os, pc, log_e, tw, (const u32*)nullptr, (size_t)0);
         } else {
             unsigned lg0 = (log_n + 1) / 2, lg1 = log_n - lg0;
             const size_t n1 = (size_t)1 << lg0, n2 = (size_t)1 << lg1;
@@ -623,7 +650,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
             const size_t lds = ntt29_lds_bytes(((size_t)1 << lg1) * T * E);
             pc.swap = nc > 1 ? 1u : 0u;
             hipLaunchKernelGGL(k_ntt_final_ext29<false>, pc.swap ? dim3((unsigned)nc, (unsigned)(n1 / T)) : dim3((unsigned)(n1 / T), (unsigned)nc), dim3(256), lds, ctx->stream, tmp,
-                               eout + c0 * os, n, nc * n, os, pc, log_e, tw, (const Fr*)nullptr, (size_t)0);
+                               eout + c0 * os, n, nc * n, os, pc, log_e, tw, (const u32*)nullptr, (size_t)0);
         }
         HIPCHK(ctx, hipGetLastError());
     }
