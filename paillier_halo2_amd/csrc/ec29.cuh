@@ -91,7 +91,8 @@ __device__ __forceinline__ void x29_add_affine(G1X29& acc, const G1A29& q) {
     const Fq29 U2 = f29_mul(q.x, acc.zz);
     const Fq29 S2 = f29_mul(q.y, acc.zzz);
     const Fq29 P = f29_carry(f29_sub<8, 30>(U2, acc.x));    // value < 10p
-    const Fq29 R = f29_carry(f29_sub<4, 31>(S2, acc.y));    // value < 6p
+    const Fq29 nY = f29_neg<4, 31>(acc.y);                  // 4p - Y1: limbs < 2^31.4, value < 4p
+    const Fq29 R = f29_carry(f29_add(S2, nY));              // S2 - Y1 + 4p, value < 6p
     if (f29_is_zero(P)) {
         acc = x29_add_affine_special(q, f29_is_zero(R));
         return;
@@ -100,8 +101,11 @@ __device__ __forceinline__ void x29_add_affine(G1X29& acc, const G1A29& q) {
     const Fq29 PPP = f29_mul(P, PP);
     const Fq29 Q = f29_mul(acc.x, PP);
     const Fq29 X3 = f29_carry(f29_sub<4, 31>(f29_sqr(R), f29_add2(PPP, Q)));   // R^2 - PPP - 2Q, value < 5.3p
-    const Fq29 t = f29_sub<8, 30>(Q, X3);
-    const Fq29 Y3 = f29_sub<2, 29>(f29_mul(R, t), f29_mul(acc.y, PPP));        // value < 3.4p, limbs < 2^30.6
+    const Fq29 t = f29_sub<8, 30>(Q, X3);                                      // limbs < 2^31, value < 9.1p
+    // Y3 = R t - Y1 PPP as ONE Montgomery reduction of R t + (4p - Y1) PPP (f29_mul2): the column bound needs the negated Y1
+    // carried (9 (2^29+8) 2^31 + 9 (2^29+8) 2^29 + 2^59.8 < 2^63.6); 27 carry instructions for ~118 of a second reduction and
+    // the limb-wise subtraction.  Value < (55 + 4.4) p^2 / (169 p) + p < 1.4p, limbs tight.
+    const Fq29 Y3 = f29_mul2(R, t, f29_carry(nY), PPP);
     acc.x = X3;
     acc.y = Y3;
     acc.zz = f29_mul(acc.zz, PP);
@@ -124,7 +128,8 @@ __device__ __forceinline__ void x29_add(G1X29& acc, const G1X29& q) {
     const Fq29 S1 = f29_mul(acc.y, q.zzz);
     const Fq29 S2 = f29_mul(q.y, acc.zzz);
     const Fq29 P = f29_carry(f29_sub<2, 29>(U2, U1));
-    const Fq29 R = f29_carry(f29_sub<2, 29>(S2, S1));
+    const Fq29 nS1 = f29_neg<2, 29>(S1);                    // 2p - S1: limbs < 2^30, value < 2p
+    const Fq29 R = f29_carry(f29_add(S2, nS1));
     if (f29_is_zero(P)) {
         acc = x29_add_special(acc, f29_is_zero(R));
         return;
@@ -134,7 +139,8 @@ __device__ __forceinline__ void x29_add(G1X29& acc, const G1X29& q) {
     const Fq29 Q = f29_mul(U1, PP);
     const Fq29 X3 = f29_carry(f29_sub<4, 31>(f29_sqr(R), f29_add2(PPP, Q)));
     const Fq29 t = f29_sub<8, 30>(Q, X3);
-    const Fq29 Y3 = f29_sub<2, 29>(f29_mul(R, t), f29_mul(S1, PPP));
+    // one reduction for R t - S1 PPP (see x29_add_affine): 9 (2^29+8) 2^31 + 9 2^30 2^29 + 2^59.8 < 2^63.9, no carry needed
+    const Fq29 Y3 = f29_mul2(R, t, nS1, PPP);
     acc.x = X3;
     acc.y = Y3;
     acc.zz = f29_mul(f29_mul(acc.zz, q.zz), PP);

@@ -357,6 +357,136 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_msm_scan(const u32* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// pass 3 in two steps -- an A/B variant (PZ_MSM_SCATTER=two), NOT the default.  k_msm_scatter keeps 2^15 write frontiers per
+// workgroup open (one per bucket): 2 MB per workgroup, 64 MB per XCD against a 4 MB L2, so nearly every 4-byte entry leaves
+// the L2 as its own partial line -- 12.7 GB written per 256-column launch for 2.1 GB of entries
+// (profiles/r02_pmc_fetch_write_bench.txt).  An MSD split keeps the frontiers inside the L2:
+//   k_msm_scatter_coarse : the slice's digits go to the region of their COARSE bucket group (bucket >> 7: 256 frontiers per
+//                          workgroup) of a staging list, as (bucket & 127) << 25 | sign << 24 | table index
+//   k_msm_scatter_fine   : a workgroup per (coarse group, column) sorts the group's entries (32 KB at the production shape)
+//                          inside LDS, cursors for the 128 buckets in LDS, and writes whole lines
+// Same sorted entry list up to the order inside a bucket, which no consumer depends on.
+// Measured (profiles/r03_ab_scatter_two_pass.txt, 256 + 512 columns of 2^17 per launch pair): coarse 2.03 ms + fine 2.02 ms
+// against 4.31 ms for the single pass -- the coarse step's 537 M scattered 4-byte stores are bound by the L2's request rate
+// (~2 ms), not by bytes, and staging it through LDS as well would need sub-slice rounds -- while k_msm_accumulate runs 1.7 %
+// (0.4 ms) slower on the list this order produces.  Net loss, so the single pass stays the default.
+// ------------------------------------------------------------------------------------------------
+#define SORT_FINE_LOG 7u
+#define SORT_FINE (1u << SORT_FINE_LOG)
+#define SORT_COARSE_MAX (SORT_MAXB >> SORT_FINE_LOG)
+__global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter_coarse(const Fr* __restrict__ scalars, size_t col_stride, MsmP p,
+                                                                     const u32* __restrict__ slice_hist, unsigned n_slices,
+                                                                     const u32* __restrict__ offs, u32* __restrict__ staged,
+                                                                     size_t n_cols) {
+    __shared__ u32 cb[SORT_COARSE_MAX];
+    size_t col;
+    unsigned slice;
+    if (!sort_block_coords(n_slices, n_cols, slice, col)) return;
+    const u32* in = slice_hist + (col * n_slices + slice) * (size_t)p.B;
+    const u32* o = offs + col * (p.B + 1);
+    const unsigned n_coarse = p.B >> SORT_FINE_LOG;
+    for (unsigned c = threadIdx.x; c < n_coarse; c += SORT_THREADS) cb[c] = o[c << SORT_FINE_LOG];
+    __syncthreads();
+    // + the entries earlier slices put into the group: a wave sums 64 consecutive buckets (half a group) per step
+    for (unsigned b0 = (threadIdx.x & ~63u); b0 < p.B; b0 += 4 * SORT_THREADS) {
+        u32 v[4];
+#pragma unroll
+        for (unsigned k = 0; k < 4; ++k) {
+            const unsigned b = b0 + k * SORT_THREADS + (threadIdx.x & 63u);
+            v[k] = b < p.B ? in[b] : 0u;
+        }
+#pragma unroll
+        for (unsigned k = 0; k < 4; ++k) {
+            u32 t = v[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+            const unsigned b = b0 + k * SORT_THREADS;
+            if ((threadIdx.x & 63u) == 0 && b < p.B && t) atomicAdd(&cb[b >> SORT_FINE_LOG], t);
+        }
+    }
+    __syncthreads();
+    u32* e = staged + col * p.cap;
+    const size_t base = (size_t)slice * SORT_THREADS * p.spt;
+    for (unsigned t = 0; t < p.spt; ++t) {
+        const size_t i = base + (size_t)t * SORT_THREADS + threadIdx.x;
+        if (i >= p.n) break;
+        u32 s[8];
+        const bool neg = scalar_prepare(fp_load<FrTag>(scalars + col * col_stride + i), s);
+        u32 any = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) any |= s[k];
+        if (!any) continue;
+        unsigned carry = 0;
+        if (p.c == 16) {
+#pragma unroll
+            for (unsigned w = 0; w < 16; ++w) {
+                if (w < p.win_hi) {
+                    const unsigned d0 = ((s[w >> 1] >> (16 * (w & 1))) & 0xffffu) + carry;
+                    carry = d0 > 0x8000u ? 1u : 0u;
+                    const unsigned mag = carry ? 0x10000u - d0 : d0;
+                    if (w >= p.win_lo && mag != 0) {
+                        const unsigned b = mag - 1;
+                        const u32 pos = atomicAdd(&cb[b >> SORT_FINE_LOG], 1u);
+                        const bool sgn = neg != (carry != 0);
+                        e[pos] = (u32)((size_t)w * p.n_table + i) | (sgn ? 0x01000000u : 0u) | ((b & (SORT_FINE - 1)) << 25);
+                    }
+                }
+            }
+        } else {
+            for (unsigned w = 0; w < p.win_hi; ++w) {
+                int d = next_digit(s, w, p.c, carry);
+                if (w >= p.win_lo && d != 0) {
+                    const unsigned b = (d < 0 ? -d : d) - 1;
+                    const u32 pos = atomicAdd(&cb[b >> SORT_FINE_LOG], 1u);
+                    const bool sgn = neg != (d < 0);
+                    e[pos] = (u32)((size_t)w * p.n_table + i) | (sgn ? 0x01000000u : 0u) | ((b & (SORT_FINE - 1)) << 25);
+                }
+            }
+        }
+    }
+}
+
+// Scattered 4-byte stores are bound by the L2's request rate, not by bytes (537 M stores of a 256-column launch: ~2 ms at best,
+// measured 3.5 ms), so a group that fits the staging array is sorted INSIDE LDS and leaves as whole lines; a larger group
+// (skewed columns) takes the direct path.
+#define FINE_LDS_ENTRIES 12288u   // 48 KB: three workgroups per CU
+#define FINE_THREADS 512u        // x 8 loads in flight per thread: ~48 KB outstanding per CU
+__global__ __launch_bounds__(FINE_THREADS) void k_msm_scatter_fine(MsmP p, const u32* __restrict__ offs, const u32* __restrict__ staged,
+                                                          u32* __restrict__ entries) {
+    __shared__ u32 cur[SORT_FINE + 1];
+    __shared__ u32 buf[FINE_LDS_ENTRIES];
+    const size_t col = blockIdx.y;
+    const u32* o = offs + col * (p.B + 1) + ((size_t)blockIdx.x << SORT_FINE_LOG);
+    if (threadIdx.x <= SORT_FINE) cur[threadIdx.x] = o[threadIdx.x];
+    __syncthreads();
+    const u32 lo = cur[0], hi = cur[SORT_FINE];   // the group's region; cur[SORT_FINE] is never advanced
+    __syncthreads();
+    const u32* src = staged + col * p.cap;
+    u32* dst = entries + col * p.cap;
+    const bool in_lds = hi - lo <= FINE_LDS_ENTRIES;
+    for (u32 j0 = lo + threadIdx.x; j0 < hi; j0 += 8 * FINE_THREADS) {
+        u32 v[8];
+#pragma unroll
+        for (unsigned k = 0; k < 8; ++k) {
+            const u32 j = j0 + k * FINE_THREADS;
+            v[k] = j < hi ? src[j] : 0xffffffffu;
+        }
+#pragma unroll
+        for (unsigned k = 0; k < 8; ++k) {
+            if (j0 + k * FINE_THREADS < hi) {
+                const u32 pos = atomicAdd(&cur[v[k] >> 25], 1u);
+                const u32 e = (v[k] & 0x00ffffffu) | ((v[k] & 0x01000000u) << 7);
+                if (in_lds) buf[pos - lo] = e;
+                else dst[pos] = e;
+            }
+        }
+    }
+    if (!in_lds) return;
+    __syncthreads();
+    for (u32 j = threadIdx.x; j < hi - lo; j += FINE_THREADS) dst[lo + j] = buf[j];
+}
+
 // the size-ordered work item list of k_msm_accumulate: item_order[rank] = work item, item_bucket[rank] = its bucket.
 // grid (B / 256, columns): a thread per bucket; buckets with many chunks are shared by the whole workgroup afterwards
 __global__ __launch_bounds__(256) void k_msm_items(MsmP p, const u32* __restrict__ offs, const u32* __restrict__ items,
@@ -913,6 +1043,63 @@ __global__ __launch_bounds__(128) void k_msm_reduce_l1(MsmP p, unsigned m, const
     x29_store_raw(&o->S, run);
 }
 
+// The same two kernels with every addition done by a QUAD (ec29_quad.cuh): a lane-serial walk is a chain of 2m dependent
+// additions of 14 dependent products each, and with 168 VGPRs only 2-3 such chains share a SIMD (~50 % of the issue rate, DESIGN.md
+// section 10); a quad's addition is 4 products deep.  Measured on 256 + 512 columns of 2^17 (profiles/r03_ab_tree_quad_vs_lane.txt):
+// the combine levels (few nodes: latency-bound) go 470 -> 240 us per launch with quads; level 1 (8 waves/SIMD of nodes: already
+// throughput-bound, and the lane walk skips empty buckets and the infinity cases) goes 2.23 -> 3.48 ms.  So the default is lane
+// level 1 + quad combines; PZ_MSM_TREE=lane / =quad select all-lane / all-quad (A/B).
+__global__ __launch_bounds__(256) void k_msm_reduce_l1_quad(MsmP p, unsigned m, const u32* __restrict__ items,
+                                                            const G1X29Raw* __restrict__ partials, MsmNode* __restrict__ nodes) {
+    const size_t col = blockIdx.y;
+    const unsigned t = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;   // node = quad
+    const unsigned nn = p.B / m;
+    if (t >= nn) return;                                               // whole quads leave together
+    const u32* it = items + col * (p.B + 1);
+    const G1X29Raw* pc = partials + col * p.max_items;
+    G1X29 run = x29_inf(), acc = x29_inf();
+    for (unsigned j = m; j-- > 0;) {
+        const unsigned b = t * m + j;
+        const u32 a = it[b], z = it[b + 1];
+        if (z > a) {  // merged: the bucket's sum sits in its first partial (replicated test: the quad branches together)
+            const G1X29 v = x29_load_raw(pc + a);
+            x29_add_quad(run, v);
+        }
+        x29_add_quad(acc, run);
+    }
+    if ((threadIdx.x & 3u) == 0) {
+        MsmNode* o = nodes + col * nn + t;
+        x29_store_raw(&o->V, acc);
+        x29_store_raw(&o->S, run);
+    }
+}
+__global__ __launch_bounds__(256) void k_msm_combine_quad(unsigned n_in, unsigned m, unsigned log_w,
+                                                          const MsmNode* __restrict__ in, MsmNode* __restrict__ out) {
+    const size_t col = blockIdx.y;
+    const unsigned t = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const unsigned n_out = n_in / m;
+    if (t >= n_out) return;
+    const MsmNode* c = in + col * n_in + (size_t)t * m;
+    G1X29 run = x29_inf(), acc = x29_inf();
+    for (unsigned k = m; k-- > 1;) {
+        const G1X29 s = x29_load_raw(&c[k].S);
+        x29_add_quad(run, s);
+        x29_add_quad(acc, run);
+    }
+    for (unsigned k = 0; k < log_w; ++k) acc = x29_dbl_quad(acc);
+    const G1X29 s0 = x29_load_raw(&c[0].S);
+    x29_add_quad(run, s0);
+    for (unsigned k = 0; k < m; ++k) {
+        const G1X29 v = x29_load_raw(&c[k].V);
+        x29_add_quad(acc, v);
+    }
+    if ((threadIdx.x & 3u) == 0) {
+        MsmNode* o = out + col * n_out + t;
+        x29_store_raw(&o->V, acc);
+        x29_store_raw(&o->S, run);
+    }
+}
+
 // A/B variant of level 1 (BASELINE north_star: "LDS-staged Pippenger buckets and wavefront-level bucket reduction"): a
 // WAVE owns a tile of 64 consecutive buckets staged in LDS and reduces it with cross-lane scans -- suffix sums
 // R_k = sum_{j >= k} B_j by 6 Hillis-Steele steps, then V = sum_k R_k by a 6-step tree -- instead of one lane walking 16
@@ -1269,7 +1456,17 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     PZCHK(pz_ws_get(ctx, WS_OFFS, nc * (p.B + 1) * 4, &offs));
     PZCHK(pz_ws_get(ctx, WS_ITEMS, nc * (p.B + 1) * 4, &items));
     PZCHK(pz_ws_get(ctx, WS_ENTRIES, nc * p.cap * 4 + 16, &entries));
-    PZCHK(pz_ws_get(ctx, WS_PARTIALS, nc * p.max_items * sizeof(G1X29Raw), &partials));
+    // PZ_MSM_SCATTER=two selects the two-step scatter (A/B; measured slower end to end, see the kernels' comment)
+    static int scatter_two = -1;
+    if (scatter_two < 0) {
+        const char* e = getenv("PZ_MSM_SCATTER");
+        scatter_two = (e && !strcmp(e, "two")) ? 1 : 0;
+    }
+    const bool two_pass = scatter_two && p.B >= 2 * SORT_FINE && (size_t)p.nwin * p.n_table <= ((size_t)1 << 24);
+    {
+        const size_t part_bytes = nc * p.max_items * sizeof(G1X29Raw), stage_bytes = two_pass ? nc * p.cap * 4 + 16 : 0;
+        PZCHK(pz_ws_get(ctx, WS_PARTIALS, part_bytes > stage_bytes ? part_bytes : stage_bytes, &partials));
+    }
     // radix of the reduction tree
     const unsigned m1 = p.B >= 16 ? 16 : p.B;
     unsigned n_nodes = p.B / m1;
@@ -1293,8 +1490,15 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
             hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)nc), dim3(SCAN_THREADS), 0, st, (const u32*)totals, p, (u32*)offs, (u32*)items,
                                (u32*)heavy, heavy_cnt, (u32*)fold, fold_cnt, (u32*)nullptr, (u32*)nullptr, item_order, item_bucket);
         }
-        hipLaunchKernelGGL(k_msm_scatter, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (const u32*)hist, n_slices,
-                           (const u32*)offs, (u32*)entries, nc);
+        if (two_pass) {
+            // the staging list lives in the partial sums' buffer: k_msm_accumulate writes those after the list is consumed
+            hipLaunchKernelGGL(k_msm_scatter_coarse, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (const u32*)hist, n_slices,
+                               (const u32*)offs, (u32*)partials, nc);
+            hipLaunchKernelGGL(k_msm_scatter_fine, dim3(p.B >> SORT_FINE_LOG, (unsigned)nc), dim3(FINE_THREADS), 0, st, p, (const u32*)offs,
+                               (const u32*)partials, (u32*)entries);
+        } else
+            hipLaunchKernelGGL(k_msm_scatter, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (const u32*)hist, n_slices,
+                               (const u32*)offs, (u32*)entries, nc);
     }
     {
         pz_timer tacc(ctx, PZ_T_MSM_ACC);
@@ -1337,10 +1541,13 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
         HIPCHK(ctx, hipGetLastError());
         return PZ_OK;
     }
-    static int reduce_wave = -1;
+    static int reduce_wave = -1, tree_quad = 1, l1_quad = 0;
     if (reduce_wave < 0) {
         const char* e = getenv("PZ_MSM_REDUCE");
         reduce_wave = (e && !strcmp(e, "wave")) ? 1 : 0;
+        const char* e2 = getenv("PZ_MSM_TREE");
+        tree_quad = (e2 && !strcmp(e2, "lane")) ? 0 : 1;
+        l1_quad = (e2 && !strcmp(e2, "quad")) ? 1 : 0;
     }
     unsigned m1_used = m1;
     if (reduce_wave && p.B >= 64) {   // A/B variant: wave-level scan over LDS-staged tiles of 64 buckets
@@ -1348,7 +1555,10 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
         n_nodes = p.B / 64;
         hipLaunchKernelGGL(k_msm_reduce_wave, dim3(pz_div_up(n_nodes, 4), (unsigned)nc), dim3(256), 0, st, p, (const u32*)items,
                            (const G1X29Raw*)partials, (MsmNode*)na);
-    } else
+    } else if (l1_quad)
+        hipLaunchKernelGGL(k_msm_reduce_l1_quad, dim3(pz_div_up((size_t)n_nodes * 4, 256), (unsigned)nc), dim3(256), 0, st, p, m1,
+                           (const u32*)items, (const G1X29Raw*)partials, (MsmNode*)na);
+    else
         hipLaunchKernelGGL(k_msm_reduce_l1, dim3(pz_div_up(n_nodes, 128), (unsigned)nc), dim3(128), 0, st, p, m1,
                            (const u32*)items, (const G1X29Raw*)partials, (MsmNode*)na);
     MsmNode* cur = (MsmNode*)na;
@@ -1357,8 +1567,12 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     for (unsigned t = m1_used; t > 1; t >>= 1) ++log_w;
     while (n_nodes > 1) {
         unsigned m = n_nodes >= 16 ? 16 : n_nodes;
-        hipLaunchKernelGGL(k_msm_combine, dim3(pz_div_up(n_nodes / m, 128), (unsigned)nc), dim3(128), 0, st, n_nodes, m,
-                           log_w, (const MsmNode*)cur, nxt);
+        if (tree_quad)
+            hipLaunchKernelGGL(k_msm_combine_quad, dim3(pz_div_up((size_t)(n_nodes / m) * 4, 256), (unsigned)nc), dim3(256), 0, st, n_nodes, m,
+                               log_w, (const MsmNode*)cur, nxt);
+        else
+            hipLaunchKernelGGL(k_msm_combine, dim3(pz_div_up(n_nodes / m, 128), (unsigned)nc), dim3(128), 0, st, n_nodes, m,
+                               log_w, (const MsmNode*)cur, nxt);
         n_nodes /= m;
         for (unsigned t = m; t > 1; t >>= 1) ++log_w;
         MsmNode* tmp = cur;
@@ -1392,7 +1606,8 @@ extern "C" int pz_msm_g1_dev(pz_ctx* ctx, const pz_bases* bases, const uint64_t*
     // column groups: bound the sorted-entry workspace (4 B per digit) to ~1 GiB, grid.y to 65535
     const size_t digits = n * (size_t)(win_hi - win_lo);
     const unsigned chunk = msm_chunk_for(n_cols, digits);
-    const size_t per_col = digits * 4 + (digits / chunk) * (sizeof(G1X29Raw) + 8) +
+    const size_t part_col = (digits / chunk) * sizeof(G1X29Raw);   // shared with the two-pass scatter's staging list (4 B per digit)
+    const size_t per_col = digits * 4 + (part_col > digits * 4 ? part_col : digits * 4) + (digits / chunk) * 8 +
                            (size_t)(1u << (bases->c - 1)) * (180 + 4 * (size_t)pz_div_up(n, (size_t)SORT_THREADS * msm_spt_for(1, n)));   // spt of the smallest group (a halved group recomputes it): an upper bound on the slices
     // group size: sized for 288 GB of HBM -- by default up to 48 GiB of sort / partial-sum workspace per launch
     // sequence (PZ_MSM_WS_GIB overrides), so the latency-bound tree levels are paid once per ~2000 columns

@@ -1175,3 +1175,47 @@ def test_ntt_out_of_place(eng, cref, log_n):
     if log_n <= 12:
         a = x[1, :n].cpu().numpy().view(np.uint64)
         assert np.array_equal(out[1].cpu().numpy().view(np.uint64), cref.fr_scale(cref.ntt_fr(a, w, log_n), sc))
+
+
+_AB_ARMS_SCRIPT = r"""
+import sys, random
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, sys.argv[1] + "/tests")
+import paillier_halo2_amd as pz
+from oracle import cref, pyref as P
+cref.build()
+eng = pz.Engine(0)
+rng = random.Random(77)
+n = 1 << 11
+s, t = rng.randrange(1, P.FR_R), rng.randrange(1, P.FR_R)
+bases = cref.walk_bases(n, s, t)
+for c in (9, 16):
+    tb = eng.load_bases(bases, window_bits=c)
+    cols = [[rng.randrange(P.FR_R) for _ in range(n)] for _ in range(3)] + [P.witness_like_scalars(n, 5), [rng.getrandbits(1) for _ in range(n)]]
+    # few columns (bit-sliced reduction) and a column batch (radix-16 tree): 12 columns > MSM_SLICE_MAX_COLS
+    batch = [cref.fr_ints_to_mont(x) for x in cols] * 3
+    out = eng.msm_batch(tb, batch[:12])
+    for j in range(12):
+        got = cref.affine_mont_to_ints(eng.g1_normalize(out[j]))[0]
+        assert tuple(got) == tuple(P.msm_walk_expected(cols[j % 5], s, t)), (c, j)
+    one = eng.msm(tb, batch[3])
+    assert tuple(cref.affine_mont_to_ints(eng.g1_normalize(one))[0]) == tuple(P.msm_walk_expected(cols[3], s, t)), c
+    tb.free()
+print("arms-ok")
+"""
+
+
+@pytest.mark.parametrize("env", [{"PZ_MSM_SCATTER": "two"}, {"PZ_MSM_TREE": "lane"}, {"PZ_MSM_TREE": "quad"}, {"PZ_MSM_REDUCE": "wave"}])
+def test_msm_ab_arms(env):
+    """the A/B arms of K1 that an environment switch selects (read once per process): two-step scatter, lane / quad tree kernels,
+    wave-parallel level 1 -- same results as the defaults (walk bases: expected values from scalar arithmetic)"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", _AB_ARMS_SCRIPT, root], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "arms-ok" in r.stdout, (env, r.stdout[-2000:], r.stderr[-2000:])
