@@ -233,6 +233,24 @@ template <class T> __device__ __forceinline__ F29<T> f29_unpack(const u32 w[8]) 
     }
     return r;
 }
+// the limbs of x * 2^5 (x a 256-bit integer: the value stays below 2^261, NOT reduced -- up to 32 x): limb i = bits
+// [29 i - 5, 29 i + 24) of x.  What it is for: memory holds field elements as x * 2^256 (the ABI's Montgomery form) while
+// f29_mul divides by 2^261, so a product of two LOADED values needs one of them as x * 2^261 = (x * 2^256) * 2^5 to land in
+// the 256-domain again; unpacking with the shift built in costs the same 17 instructions as f29_unpack.
+template <class T> __device__ __forceinline__ F29<T> f29_unpack_shl5(const u32 w[8]) {
+    F29<T> r;
+    r.v[0] = (w[0] << 5) & F29_MASK;
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        const int bit = 29 * i - 5, j = bit >> 5, o = bit & 31;
+        u32 x;
+        if (o == 0) x = w[j];
+        else if (j + 1 < 8) x = __builtin_amdgcn_alignbit(w[j + 1], w[j], o);
+        else x = w[j] >> o;
+        r.v[i] = i < 8 ? (x & F29_MASK) : x;
+    }
+    return r;
+}
 // strict limbs, value < 2^256
 template <class T> __device__ __forceinline__ void f29_pack(const F29<T>& a, u32 w[8]) {
 #pragma unroll
@@ -244,6 +262,8 @@ template <class T> __device__ __forceinline__ void f29_pack(const F29<T>& a, u32
 }
 template <class T> __device__ __forceinline__ F29<T> f29_from_fp(const Fp<T>& x) { return f29_unpack<T>(x.v); }
 template <class T> __device__ __forceinline__ F29<T> f29_load(const void* p) { return f29_from_fp(fp_load<T>(p)); }
+template <class T> __device__ __forceinline__ F29<T> f29_from_fp_shl5(const Fp<T>& x) { return f29_unpack_shl5<T>(x.v); }
+template <class T> __device__ __forceinline__ F29<T> f29_load_shl5(const void* p) { return f29_from_fp_shl5(fp_load<T>(p)); }
 // store the canonical representative as a 256-bit integer (value below 2^(J+1) p)
 template <unsigned J, class T> __device__ __forceinline__ void f29_store(void* p, const F29<T>& x) {
     const F29<T> c = f29_canon<J>(x);

@@ -90,10 +90,41 @@ def emit_mul2(out, name):
     out.append("    return r;\n}")
 
 
+def emit_dot(out, name, terms):
+    """sum_{t < terms} a[t] * b[t] / R' with ONE reduction (dot products: evaluation at a point, linear combinations).  Legal when
+    9 * sum_t (max a[t] limb * max b[t] limb) + 2^59.8 < 2^64 -- e.g. four tight x tight terms; result tight,
+    value < sum(va * vb) / (169 p) + p"""
+    out.append("template <class T> __device__ __forceinline__ F29<T> %s(const F29<T> (&a)[%d], const F29<T> (&b)[%d]) {" % (name, terms, terms))
+    out.append("    u64 acc = 0;\n    u32 m0, m1, m2, m3, m4, m5, m6, m7, m8;\n    F29<T> r;")
+
+    def pairs(t, k):
+        return [("a[%d].v[%d]" % (t, i), "v", "b[%d].v[%d]" % (t, k - i), "v") for i in range(max(0, k - (N - 1)), min(k, N - 1) + 1)]
+
+    for k in range(N):
+        for t in range(terms):
+            out.append(mads(pairs(t, k)))
+        mp = [("m%d" % i, "v", "P29<T>::P(%d)" % (k - i), "s") for i in range(k)]
+        if mp:
+            out.append(mads(mp))
+        out.append("    m%d = ((u32)acc * P29<T>::INV) & F29_MASK;" % k)
+        out.append(mads([("m%d" % k, "v", "P29<T>::P(0)", "s")]))
+        out.append("    acc >>= 29;")
+    for k in range(N, 2 * N - 1):
+        for t in range(terms):
+            out.append(mads(pairs(t, k)))
+        out.append(mads([("m%d" % i, "v", "P29<T>::P(%d)" % (k - i), "s") for i in range(k - (N - 1), N)]))
+        out.append("    r.v[%d] = (u32)acc & F29_MASK;" % (k - N))
+        out.append("    acc >>= 29;")
+    out.append("    r.v[8] = (u32)acc;")
+    out.append("    return r;\n}")
+
+
 out = ["// GENERATED by gen_fp29.py -- do not edit.  Included by fp29.cuh."]
 emit_mul(out, "f29_mul", False)
 out.append("")
 emit_mul(out, "f29_sqr", True)
 out.append("")
 emit_mul2(out, "f29_mul2")
+out.append("")
+emit_dot(out, "f29_dot4", 4)
 print("\n".join(out))

@@ -17,7 +17,7 @@
 //
 // All of it is elementwise / scan work on 32-byte field elements: HBM-bound at >= 8 columns per pass, otherwise
 // bound by the field products (3-5 per element).
-#include "fp.cuh"
+#include "fp29.cuh"
 #include "pz_internal.h"
 
 static inline Fr fp_one_host() {  // Montgomery one of Fr (R mod r)
@@ -32,29 +32,58 @@ static inline Fr fr_from_u64(const uint64_t x[4]) {
     return r;
 }
 
+// ---- the 29-bit field for the row kernels (fp29.cuh)
+typedef F29<FrTag> Fr29;
+// a challenge (x * 2^256, canonical) as x * 2^261: the operand that keeps a product with a 256-domain value in the 256-domain
+__device__ __forceinline__ Fr29 fr29_c261(const Fr& c) { return f29_to_261(f29_from_fp(c)); }
+// 1 in the 256-domain
+__device__ __forceinline__ Fr29 fr29_one256() {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.v[i] = P29<FrTag>::R256(i);
+    return r;
+}
+
+// beta, gamma, delta of a permutation argument as the row kernels use them -- out[0] = beta * 2^266 (beta times a 256-domain value
+// lands in the 261-domain), out[1] = gamma * 2^261, out[2] = delta * 2^261, nine raw limbs each -- computed ONCE per call: with
+// two columns per set a thread of k_perm_terms_sets has ten products of real work, and five more per thread for the constants
+// made the kernel 1.5x slower than on 32-bit limbs
+__global__ void k_perm_consts(Fr beta, Fr gamma, Fr delta, u32* __restrict__ out) {
+    if (blockIdx.x || threadIdx.x) return;
+    f29_store_raw(out, f29_to_261(fr29_c261(beta)));
+    f29_store_raw(out + 9, fr29_c261(gamma));
+    f29_store_raw(out + 18, fr29_c261(delta));
+}
+
 // ---------------------------------------------------------------------------------------------- batch inversion
 // thread t owns elements t, t+T, t+2T, ... (coalesced across the wave for every j)
+// 29-bit field: the running products are kept in the 256-domain (acc * shl5(v)); the scratch array takes them packed but not
+// canonical (a product is tight and below 2p < 2^256: no conditional subtraction on the way out).  f29_inv works in the
+// 261-domain: fed acc * 2^256 it returns acc^-1 * 2^266, and one product by 1 * 2^256 brings that to acc^-1 * 2^261 -- the domain
+// in which inv * scratch lands in the 256-domain and inv * shl5(v) stays where it is.
 __global__ __launch_bounds__(256) void k_batch_invert(Fr* __restrict__ a, Fr* __restrict__ scratch, size_t n, size_t T,
                                                       unsigned K) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
-    Fr acc = fp_one<FrTag>();
+    Fr29 acc = fr29_one256();
     for (unsigned j = 0; j < K; ++j) {
         const size_t i = t + (size_t)j * T;
         if (i >= n) break;
-        Fr v = fp_load<FrTag>(a + i);
+        const Fr v = fp_load<FrTag>(a + i);
         if (fp_is_zero(v)) continue;
-        fp_store(scratch + i, acc);
-        acc = fp_mul(acc, v);
+        Fr w;
+        f29_pack(acc, w.v);
+        fp_store(scratch + i, w);
+        acc = f29_mul(acc, f29_from_fp_shl5(v));
     }
-    Fr inv = fp_inv(acc);  // acc is a product of non-zero elements (or 1)
+    Fr29 inv = f29_mul(f29_inv(acc), fr29_one256());  // acc is a product of non-zero elements (or 1)
     for (unsigned j = K; j-- > 0;) {
         const size_t i = t + (size_t)j * T;
         if (i >= n) continue;
-        Fr v = fp_load<FrTag>(a + i);
+        const Fr v = fp_load<FrTag>(a + i);
         if (fp_is_zero(v)) continue;
-        fp_store(a + i, fp_mul(inv, fp_load<FrTag>(scratch + i)));
-        inv = fp_mul(inv, v);
+        f29_store<1>(a + i, f29_mul(inv, f29_load<FrTag>(scratch + i)));
+        inv = f29_mul(inv, f29_from_fp_shl5(v));
     }
 }
 
@@ -62,9 +91,11 @@ int pz_batch_invert_internal(pz_ctx* ctx, Fr* d_a, size_t n) {
     if (!n) return PZ_OK;
     void* scr;
     PZCHK(pz_ws_get(ctx, WS_BIG_A, n * 32, &scr));
-    // one inversion (~380 products) per K elements: K = 64 once there is enough work to keep >= 2^14 threads
+    // one inversion (~380 products, every lane of the wave its own) per K elements against 3 products per element: K = 64 once
+    // there are 2^14 threads, up to 512 while 2^18 threads (four waves per SIMD) remain
     unsigned K = 8;
     while (K < 64 && n / (K * 2) >= 16384) K *= 2;
+    while (K < 512 && n / (K * 2) >= 262144) K *= 2;
     const size_t T = pz_div_up(n, K);
     hipLaunchKernelGGL(k_batch_invert, dim3(pz_div_up(T, 256)), dim3(256), 0, ctx->stream, d_a, (Fr*)scr, n, T, K);
     HIPCHK(ctx, hipGetLastError());
@@ -158,22 +189,26 @@ extern "C" int pz_fr_prefix_product_dev(pz_ctx* ctx, const uint64_t* d_a, size_t
 }
 
 // ---------------------------------------------------------------------------------------------- permutation product
+// (29-bit field; domains as in k_quotient_permutation: v, gamma, beta * sigma and beta * delta^j * w^i carry 2^261, the running
+// products 2^256)
 __global__ __launch_bounds__(256) void k_perm_terms(const Fr* __restrict__ cols, size_t cs, const Fr* __restrict__ sigma,
                                                     size_t ss, unsigned m, size_t n, const Fr* __restrict__ wpow, Fr beta,
                                                     Fr gamma, Fr delta0, Fr delta, Fr* __restrict__ num,
                                                     Fr* __restrict__ den) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fr nm = fp_one<FrTag>(), dn = fp_one<FrTag>();
-    Fr bd = fp_mul(fp_mul(beta, delta0), fp_load<FrTag>(wpow + i));  // beta * delta^j0 * w^i, times delta per column
+    const Fr29 g = fr29_c261(gamma), d = fr29_c261(delta), beta266 = f29_to_261(fr29_c261(beta));
+    Fr29 nm = fr29_one256(), dn = nm;
+    Fr29 bd = f29_mul(f29_mul(beta266, f29_from_fp(delta0)), f29_load_shl5<FrTag>(wpow + i));  // beta * delta^j0 * w^i, times delta per column
     for (unsigned j = 0; j < m; ++j) {
-        Fr v = fp_add(fp_load<FrTag>(cols + (size_t)j * cs + i), gamma);
-        nm = fp_mul(nm, fp_add(v, bd));
-        dn = fp_mul(dn, fp_add(v, fp_mul(beta, fp_load<FrTag>(sigma + (size_t)j * ss + i))));
-        bd = fp_mul(bd, delta);
+        const Fr29 v = f29_add(f29_load_shl5<FrTag>(cols + (size_t)j * cs + i), g);
+        const Fr29 sg = f29_load<FrTag>(sigma + (size_t)j * ss + i);
+        nm = f29_mul(nm, f29_add(v, bd));
+        dn = f29_mul(dn, f29_add(v, f29_mul(beta266, sg)));
+        bd = f29_mul(bd, d);
     }
-    fp_store(num + i, nm);
-    fp_store(den + i, dn);
+    f29_store<1>(num + i, nm);
+    f29_store<1>(den + i, dn);
 }
 __global__ __launch_bounds__(256) void k_fr_mul_inplace(Fr* __restrict__ a, const Fr* __restrict__ b, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -210,21 +245,28 @@ extern "C" int pz_permutation_product_dev(pz_ctx* ctx, const uint64_t* d_cols, s
 // (one batched inversion, one batched scan) and chained afterwards by a scalar per set.
 __global__ __launch_bounds__(256) void k_perm_terms_sets(const Fr* __restrict__ cols, size_t cs, const Fr* __restrict__ sigma,
                                                          size_t ss, unsigned m, unsigned chunk_len, size_t n,
-                                                         const Fr* __restrict__ wpow, const Fr* __restrict__ dpow, Fr beta,
-                                                         Fr gamma, Fr delta, Fr* __restrict__ num, Fr* __restrict__ den) {
+                                                         const Fr* __restrict__ wpow, const Fr* __restrict__ dpow,
+                                                         const u32* __restrict__ rc, Fr* __restrict__ num, Fr* __restrict__ den) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned set = blockIdx.y, c0 = set * chunk_len;
-    Fr nm = fp_one<FrTag>(), dn = fp_one<FrTag>();
-    Fr bd = fp_mul(fp_mul(beta, fp_load<FrTag>(dpow + c0)), fp_load<FrTag>(wpow + i));
+    const Fr29 beta266 = f29_load_raw<FrTag>(rc), g = f29_load_raw<FrTag>(rc + 9), d = f29_load_raw<FrTag>(rc + 18);   // k_perm_consts
+    Fr29 nm = fr29_one256(), dn = nm;
+    Fr29 bd = f29_mul(f29_mul(beta266, f29_load<FrTag>(dpow + c0)), f29_load_shl5<FrTag>(wpow + i));
+    // the next column's value and sigma are requested before the current column's products start
+    Fr v_n = fp_load<FrTag>(cols + (size_t)c0 * cs + i), s_n = fp_load<FrTag>(sigma + (size_t)c0 * ss + i);
     for (unsigned c = c0; c < c0 + chunk_len && c < m; ++c) {
-        Fr v = fp_add(fp_load<FrTag>(cols + (size_t)c * cs + i), gamma);
-        nm = fp_mul(nm, fp_add(v, bd));
-        dn = fp_mul(dn, fp_add(v, fp_mul(beta, fp_load<FrTag>(sigma + (size_t)c * ss + i))));
-        bd = fp_mul(bd, delta);
+        const Fr29 v = f29_add(f29_from_fp_shl5(v_n), g);
+        const Fr29 sg = f29_from_fp(s_n);
+        const unsigned cn = (c + 1 < c0 + chunk_len && c + 1 < m) ? c + 1 : c;
+        v_n = fp_load<FrTag>(cols + (size_t)cn * cs + i);
+        s_n = fp_load<FrTag>(sigma + (size_t)cn * ss + i);
+        nm = f29_mul(nm, f29_add(v, bd));
+        dn = f29_mul(dn, f29_add(v, f29_mul(beta266, sg)));
+        bd = f29_mul(bd, d);
     }
-    fp_store(num + (size_t)set * n + i, nm);
-    fp_store(den + (size_t)set * n + i, dn);
+    f29_store<1>(num + (size_t)set * n + i, nm);
+    f29_store<1>(den + (size_t)set * n + i, dn);
 }
 __global__ void k_perm_chain(const Fr* __restrict__ z, size_t zs, unsigned n_sets, size_t u, Fr* __restrict__ mult) {
     if (blockIdx.x || threadIdx.x) return;
@@ -258,11 +300,15 @@ extern "C" int pz_permutation_product_sets_dev(pz_ctx* ctx, const uint64_t* d_co
     PZCHK(pz_get_pow_table(ctx, delta, m, &dp));
     PZCHK(pz_ws_get(ctx, WS_BIG_C, 2 * n_sets * n * 32, &ws));
     PZCHK(pz_ws_get(ctx, WS_MISC, n_sets * 32, &mu));
+    void* rc;
+    PZCHK(pz_ws_get(ctx, WS_ROWC, 27 * 4, &rc));
     Fr* num = (Fr*)ws;
     Fr* den = num + n_sets * n;
+    hipLaunchKernelGGL(k_perm_consts, dim3(1), dim3(64), 0, ctx->stream, fr_from_u64(beta), fr_from_u64(gamma), fr_from_u64(delta),
+                       (u32*)rc);
     hipLaunchKernelGGL(k_perm_terms_sets, dim3(pz_div_up(n, 256), (unsigned)n_sets), dim3(256), 0, ctx->stream,
                        (const Fr*)d_cols, col_stride / 4, (const Fr*)d_sigma, sigma_stride / 4, (unsigned)m, (unsigned)chunk_len, n,
-                       (const Fr*)wp, (const Fr*)dp, fr_from_u64(beta), fr_from_u64(gamma), fr_from_u64(delta), num, den);
+                       (const Fr*)wp, (const Fr*)dp, (const u32*)rc, num, den);
     HIPCHK(ctx, hipGetLastError());
     PZCHK(pz_batch_invert_internal(ctx, den, n_sets * n));
     hipLaunchKernelGGL(k_fr_mul_inplace, dim3(pz_div_up(n_sets * n, 256)), dim3(256), 0, ctx->stream, num, (const Fr*)den,
@@ -280,21 +326,24 @@ extern "C" int pz_permutation_product_sets_dev(pz_ctx* ctx, const uint64_t* d_co
 }
 
 // ---------------------------------------------------------------------------------------------- gate part of evaluate_h
+// 29-bit field: a1 * shl5(a2) stays in the 256-domain, and acc * y + e * shl5(sel) is one reduction (f29_mul2) -- two reductions
+// per column where the 32-bit-limb version paid three full products.  e = a0 + a1 a2 - a3 + 2p: limbs < 2^31, value < 4.2p.
 __global__ __launch_bounds__(256) void k_quotient_gate(const Fr* __restrict__ adv, size_t as, const Fr* __restrict__ sel,
                                                        size_t ss, unsigned n_cols, size_t N, unsigned step, Fr y,
                                                        Fr* __restrict__ h) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const size_t i1 = (i + step) & (N - 1), i2 = (i + 2 * (size_t)step) & (N - 1), i3 = (i + 3 * (size_t)step) & (N - 1);
-    Fr acc = fp_load<FrTag>(h + i);
+    const Fr29 y261 = fr29_c261(y);
+    Fr29 acc = f29_load<FrTag>(h + i);
     for (unsigned j = 0; j < n_cols; ++j) {
         const Fr* a = adv + (size_t)j * as;
-        Fr e = fp_sub(fp_add(fp_load<FrTag>(a + i), fp_mul(fp_load<FrTag>(a + i1), fp_load<FrTag>(a + i2))),
-                      fp_load<FrTag>(a + i3));
-        e = fp_mul(e, fp_load<FrTag>(sel + (size_t)j * ss + i));
-        acc = fp_add(fp_mul(acc, y), e);
+        const Fr29 a0 = f29_load<FrTag>(a + i), a1 = f29_load<FrTag>(a + i1), a3 = f29_load<FrTag>(a + i3);
+        const Fr29 a2 = f29_load_shl5<FrTag>(a + i2), sl = f29_load_shl5<FrTag>(sel + (size_t)j * ss + i);
+        const Fr29 e = f29_sub<2, 29>(f29_add(a0, f29_mul(a1, a2)), a3);
+        acc = f29_mul2(acc, y261, e, sl);
     }
-    fp_store(h + i, acc);
+    f29_store<1>(h + i, acc);
 }
 
 extern "C" int pz_quotient_gate_dev(pz_ctx* ctx, const uint64_t* d_adv_ext, size_t adv_stride, const uint64_t* d_sel_ext,
@@ -468,44 +517,52 @@ struct PermQ {
     unsigned n_sets, chunk_len, m_total, step, last_rot;
     Fr beta, gamma, delta, x0, w_ext, y;
 };
+// On the 29-bit field (fp29.cuh): ~210 instructions per product instead of ~380 on saturated 32-bit limbs.  Domains: memory
+// holds x * 2^256; f29_mul divides by 2^261, so in every product exactly one operand carries the extra 2^5 -- a challenge
+// converted once per thread (c261), or a loaded value unpacked through f29_load_shl5.  acc * y + term * l is one reduction
+// (f29_mul2).  Limb / value bounds: products are tight (< 2^29, value < 2p); sums of up to three tight values and
+// f29_sub<2, 29> results stay below 2^31, a legal operand against a tight one.
 __global__ __launch_bounds__(256) void k_quotient_permutation(PermQ q, Fr* __restrict__ h) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= q.N) return;
     const size_t mask = q.N - 1;
     const size_t i_next = (i + q.step) & mask;
     const size_t i_last = (i + q.N - (size_t)q.last_rot * q.step) & mask;
-    const Fr one = fp_one<FrTag>();
-    const Fr l0 = fp_load<FrTag>(q.l0 + i), ll = fp_load<FrTag>(q.llast + i), la = fp_load<FrTag>(q.lactive + i);
-    Fr acc = fp_load<FrTag>(h + i);
-    const Fr z_first = fp_load<FrTag>(q.z + i);
-    acc = fp_add(fp_mul(acc, q.y), fp_mul(fp_sub(one, z_first), l0));
-    const Fr z_lastset = fp_load<FrTag>(q.z + (size_t)(q.n_sets - 1) * q.zs + i);
-    acc = fp_add(fp_mul(acc, q.y), fp_mul(fp_sub(fp_sqr(z_lastset), z_lastset), ll));
+    const Fr29 one = fr29_one256();
+    const Fr29 y = fr29_c261(q.y), gamma = fr29_c261(q.gamma), delta = fr29_c261(q.delta);
+    const Fr29 beta261 = fr29_c261(q.beta), beta266 = f29_to_261(beta261);
+    const Fr29 l0 = f29_load_shl5<FrTag>(q.l0 + i), ll = f29_load_shl5<FrTag>(q.llast + i), la = f29_load_shl5<FrTag>(q.lactive + i);
+    Fr29 acc = f29_load<FrTag>(h + i);
+    const Fr29 z_first = f29_load<FrTag>(q.z + i);
+    acc = f29_mul2(acc, y, f29_sub<2, 29>(one, z_first), l0);
+    const Fr zl = fp_load<FrTag>(q.z + (size_t)(q.n_sets - 1) * q.zs + i);
+    const Fr29 z_lastset = f29_from_fp(zl);
+    acc = f29_mul2(acc, y, f29_sub<2, 29>(f29_mul(z_lastset, f29_from_fp_shl5(zl)), z_lastset), ll);
     for (unsigned j = 1; j < q.n_sets; ++j) {
-        Fr d = fp_sub(fp_load<FrTag>(q.z + (size_t)j * q.zs + i), fp_load<FrTag>(q.z + (size_t)(j - 1) * q.zs + i_last));
-        acc = fp_add(fp_mul(acc, q.y), fp_mul(d, l0));
+        const Fr29 d = f29_sub<2, 29>(f29_load<FrTag>(q.z + (size_t)j * q.zs + i), f29_load<FrTag>(q.z + (size_t)(j - 1) * q.zs + i_last));
+        acc = f29_mul2(acc, y, d, l0);
     }
-    // beta * X_i, X_i = x0 * w_ext^i from the cached power table (square-and-multiply over the bits of i cost a wave
-    // 2 log2(N) products per row and call: both arms of every bit)
-    Fr cur = fp_mul(q.beta, fp_load<FrTag>(q.xpow + i));
+    // beta * X_i (261-domain), X_i = x0 * w_ext^i from the cached power table
+    Fr29 cur = f29_mul(beta266, f29_load<FrTag>(q.xpow + i));
     unsigned c = 0;
     // the next column's value and sigma are requested before the current column's four products start
     Fr v_n = fp_load<FrTag>(q.cols + i), s_n = fp_load<FrTag>(q.sigma + i);
     for (unsigned j = 0; j < q.n_sets; ++j) {
-        Fr left = fp_load<FrTag>(q.z + (size_t)j * q.zs + i_next);
-        Fr right = fp_load<FrTag>(q.z + (size_t)j * q.zs + i);
+        Fr29 left = f29_load<FrTag>(q.z + (size_t)j * q.zs + i_next);
+        Fr29 right = f29_load<FrTag>(q.z + (size_t)j * q.zs + i);
         for (unsigned t = 0; t < q.chunk_len && c < q.m_total; ++t, ++c) {
-            const Fr v = fp_add(v_n, q.gamma), sg = s_n;
+            const Fr29 v = f29_add(f29_from_fp_shl5(v_n), gamma);   // (v + gamma) * 2^261
+            const Fr29 sg = f29_from_fp(s_n);
             const unsigned cn = c + 1 < q.m_total ? c + 1 : c;
             v_n = fp_load<FrTag>(q.cols + (size_t)cn * q.cs + i);
             s_n = fp_load<FrTag>(q.sigma + (size_t)cn * q.ss + i);
-            left = fp_mul(left, fp_add(v, fp_mul(q.beta, sg)));
-            right = fp_mul(right, fp_add(v, cur));
-            cur = fp_mul(cur, q.delta);
+            left = f29_mul(left, f29_add(v, f29_mul(beta266, sg)));
+            right = f29_mul(right, f29_add(v, cur));
+            cur = f29_mul(cur, delta);
         }
-        acc = fp_add(fp_mul(acc, q.y), fp_mul(fp_sub(left, right), la));
+        acc = f29_mul2(acc, y, f29_sub<2, 29>(left, right), la);
     }
-    fp_store(h + i, acc);
+    f29_store<1>(h + i, acc);
 }
 
 extern "C" int pz_quotient_permutation_dev(pz_ctx* ctx, const uint64_t* d_cols_ext, size_t col_stride,

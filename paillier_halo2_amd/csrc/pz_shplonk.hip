@@ -15,7 +15,7 @@
 // single lane on the device too -- no field arithmetic runs on the host.
 #include <vector>
 
-#include "fp.cuh"
+#include "fp29.cuh"
 #include <memory>
 
 #include "pz_internal.h"
@@ -38,16 +38,26 @@ struct pz_shplonk {
 // (every advice column of the proof): grid.y cuts them into chunks of SH_FOLD_CHUNK so the dependent load -> product -> add
 // chain of a lane is 32 long, not 6000 (the loop is latency-bound on the loads); k_sh_fold_sum adds the chunks' partials.
 #define SH_FOLD_CHUNK 32u
+// On the 29-bit field: the polynomial value is unpacked as v * 2^5 (f29_load_shl5) so that v * ypow stays in the ABI's domain, and
+// four terms share one Montgomery reduction (f29_dot4).  ypow[0] = 1 is multiplied like any other power (exact).
 __global__ __launch_bounds__(256) void k_sh_fold(const u64* __restrict__ plist, unsigned np, const Fr* __restrict__ ypow, size_t n,
                                                  Fr* __restrict__ part) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned j0 = blockIdx.y * SH_FOLD_CHUNK, j1 = j0 + SH_FOLD_CHUNK < np ? j0 + SH_FOLD_CHUNK : np;
-    Fr acc = fp_load<FrTag>(reinterpret_cast<const Fr*>(plist[j0]) + i);
-    if (j0) acc = fp_mul(acc, fp_load<FrTag>(ypow + j0));
-    for (unsigned j = j0 + 1; j < j1; ++j)
-        acc = fp_add(acc, fp_mul(fp_load<FrTag>(reinterpret_cast<const Fr*>(plist[j]) + i), fp_load<FrTag>(ypow + j)));
-    fp_store(part + (size_t)blockIdx.y * n + i, acc);
+    F29<FrTag> acc = f29_zero<FrTag>();
+    for (unsigned j = j0; j < j1; j += 4) {
+        F29<FrTag> v[4], y[4];
+#pragma unroll
+        for (unsigned k = 0; k < 4; ++k) {
+            const bool in = j + k < j1;
+            const unsigned jj = in ? j + k : j;
+            v[k] = in ? f29_load_shl5<FrTag>(reinterpret_cast<const Fr*>(plist[jj]) + i) : f29_zero<FrTag>();
+            y[k] = f29_load<FrTag>(ypow + jj);
+        }
+        acc = f29_carry(f29_add(acc, f29_dot4(v, y)));   // each term < 1.8p, tight; at most SH_FOLD_CHUNK / 4 = 8 of them
+    }
+    f29_store<3>(part + (size_t)blockIdx.y * n + i, acc);
 }
 __global__ __launch_bounds__(256) void k_sh_fold_sum(const Fr* __restrict__ part, unsigned n_chunks, size_t n, Fr* __restrict__ C) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
