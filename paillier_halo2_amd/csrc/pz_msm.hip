@@ -236,8 +236,7 @@ __global__ __launch_bounds__(256) void k_msm_totals(u32* __restrict__ slice_hist
 __global__ __launch_bounds__(SCAN_THREADS) void k_msm_scan(const u32* __restrict__ hist, MsmP p, u32* __restrict__ offs,
                                                   u32* __restrict__ items, u32* __restrict__ heavy,
                                                   u32* __restrict__ heavy_cnt, u32* __restrict__ fold_order,
-                                                  u32* __restrict__ fold_cnt, u32* __restrict__ pos_hi,
-                                                  u32* __restrict__ pos_lo, u32* __restrict__ item_order,
+                                                  u32* __restrict__ fold_cnt, u32* __restrict__ item_order,
                                                   u32* __restrict__ item_bucket) {
     __shared__ u32 s_cnt[SCAN_THREADS], s_itm[SCAN_THREADS];
     __shared__ u32 s_heavy;
@@ -334,15 +333,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_msm_scan(const u32* __restrict
             if (ch > 1 && ch <= MSM_HEAVY) fold_order[col * p.B + s_base[ch] + atomicAdd(&s_bin[ch], 1u)] = b;
             if (ch) {
                 // where this bucket's work items go in the size-ordered list: its `rem` chunks of q + 1 entries and its
-                // ch - rem chunks of q entries (k_msm_items writes the list: half a million scattered stores for one
-                // 2^19-point column are too many for the single workgroup this kernel is)
+                // ch - rem chunks of q entries (one workgroup per column is parallel enough in a column batch; few columns
+                // take k_msm_items_few instead of this kernel)
                 const u32 q = v / ch, rem = v % ch;
                 const u32 ph = rem ? s_obase[q + 1] + atomicAdd(&s_obin[q + 1], rem) : 0u;
                 const u32 pl = s_obase[q] + atomicAdd(&s_obin[q], ch - rem);
-                if (pos_hi) {   // few columns: the list is written by k_msm_items
-                    pos_hi[col * p.B + b] = ph;
-                    pos_lo[col * p.B + b] = pl;
-                } else {        // column batches: one workgroup per column is parallel enough, write it here
+                {
                     const u32 item0 = m - ch;
                     u32* ord = item_order + col * p.max_items;
                     u32* obk = item_bucket + col * p.max_items;
@@ -485,47 +481,6 @@ __global__ __launch_bounds__(FINE_THREADS) void k_msm_scatter_fine(MsmP p, const
     if (!in_lds) return;
     __syncthreads();
     for (u32 j = threadIdx.x; j < hi - lo; j += FINE_THREADS) dst[lo + j] = buf[j];
-}
-
-// the size-ordered work item list of k_msm_accumulate: item_order[rank] = work item, item_bucket[rank] = its bucket.
-// grid (B / 256, columns): a thread per bucket; buckets with many chunks are shared by the whole workgroup afterwards
-__global__ __launch_bounds__(256) void k_msm_items(MsmP p, const u32* __restrict__ offs, const u32* __restrict__ items,
-                                                   const u32* __restrict__ pos_hi, const u32* __restrict__ pos_lo,
-                                                   u32* __restrict__ item_order, u32* __restrict__ item_bucket) {
-    __shared__ u32 s_big[256];
-    __shared__ u32 s_nbig;
-    if (threadIdx.x == 0) s_nbig = 0;
-    __syncthreads();
-    const size_t col = blockIdx.y;
-    const u32* o = offs + col * (p.B + 1);
-    const u32* it = items + col * (p.B + 1);
-    u32* ord = item_order + col * p.max_items;
-    u32* obk = item_bucket + col * p.max_items;
-    const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < p.B) {
-        const u32 ch = it[b + 1] - it[b];
-        if (ch > ITEMS_SOLO) s_big[atomicAdd(&s_nbig, 1u)] = b;
-        else if (ch) {
-            const u32 v = o[b + 1] - o[b], rem = v % ch, item0 = it[b];
-            const u32 ph = pos_hi[col * p.B + b], pl = pos_lo[col * p.B + b];
-            for (u32 j = 0; j < ch; ++j) {
-                const u32 pos = j < rem ? ph + j : pl + j - rem;
-                ord[pos] = item0 + j;
-                obk[pos] = b;
-            }
-        }
-    }
-    __syncthreads();
-    for (unsigned k = 0; k < s_nbig; ++k) {
-        const unsigned bb = s_big[k];
-        const u32 ch = it[bb + 1] - it[bb], v = o[bb + 1] - o[bb], rem = v % ch, item0 = it[bb];
-        const u32 ph = pos_hi[col * p.B + bb], pl = pos_lo[col * p.B + bb];
-        for (u32 j = threadIdx.x; j < ch; j += blockDim.x) {
-            const u32 pos = j < rem ? ph + j : pl + j - rem;
-            ord[pos] = item0 + j;
-            obk[pos] = bb;
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1439,7 +1394,7 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     const unsigned n_slices = pz_div_up(n, (size_t)SORT_THREADS * p.spt);
     PZCHK(pz_ws_get(ctx, WS_HIST, nc * (size_t)n_slices * p.B * 4, &hist));
     PZCHK(pz_ws_get(ctx, WS_CURSOR, nc * (size_t)(p.B + 1) * 4, &heavy));
-    // few columns: k_msm_scan (one workgroup per column) leaves the work item list to k_msm_items
+    // few columns: k_msm_totals_few / k_msm_items_few instead of k_msm_totals / k_msm_scan (one workgroup per column)
     const bool split_items = nc <= MSM_SLICE_MAX_COLS;
     const unsigned nblk_few = pz_div_up(p.B, 256);
     // bucket totals | (few columns) per 256-bucket block: entry sums, item sums, items by chunk size
@@ -1488,7 +1443,7 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
             hipLaunchKernelGGL(k_msm_totals, dim3(pz_div_up(p.B, 256), (unsigned)nc), dim3(256), 0, st, (u32*)hist, n_slices, p,
                                (u32*)totals);
             hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)nc), dim3(SCAN_THREADS), 0, st, (const u32*)totals, p, (u32*)offs, (u32*)items,
-                               (u32*)heavy, heavy_cnt, (u32*)fold, fold_cnt, (u32*)nullptr, (u32*)nullptr, item_order, item_bucket);
+                               (u32*)heavy, heavy_cnt, (u32*)fold, fold_cnt, item_order, item_bucket);
         }
         if (two_pass) {
             // the staging list lives in the partial sums' buffer: k_msm_accumulate writes those after the list is consumed

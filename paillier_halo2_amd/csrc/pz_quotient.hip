@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_batch_invert(Fr* __restrict__ a, Fr* __
         if (i >= n) continue;
         const Fr v = fp_load<FrTag>(a + i);
         if (fp_is_zero(v)) continue;
-        f29_store<1>(a + i, f29_mul(inv, f29_load<FrTag>(scratch + i)));
+        f29_store_product(a + i, f29_mul(inv, f29_load<FrTag>(scratch + i)));
         inv = f29_mul(inv, f29_from_fp_shl5(v));
     }
 }
@@ -112,26 +112,45 @@ extern "C" int pz_fr_batch_invert_dev(pz_ctx* ctx, uint64_t* d_a, size_t n) {
 #define PP_K 16u
 // (batched over grid.y = column.)  phase 1: per-thread run products, block-level exclusive scan;
 // excl[t] = product of the block's earlier runs
+// (29-bit field: the run product stays in the 256-domain through shl5-unpacked factors; the workgroup scan runs in the
+// 261-domain, where products of two scanned values are closed, on raw limbs in LDS; `excl` keeps that domain -- packed, not
+// canonical -- so that block prefix (256-domain) x excl lands in the 256-domain in k_pp_apply)
 __global__ __launch_bounds__(256) void k_pp_local(const Fr* __restrict__ a, size_t as, size_t n, Fr* __restrict__ excl,
                                                   Fr* __restrict__ block_tot, unsigned nb) {
-    __shared__ Fr s[256];
+    __shared__ u32 s[9 * 256];   // limb-major: s[limb * 256 + thread]
     a += (size_t)blockIdx.y * as;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t lo = t * PP_K;
-    Fr p = fp_one<FrTag>();
+    Fr29 p = fr29_one256();
     for (unsigned j = 0; j < PP_K; ++j)
-        if (lo + j < n) p = fp_mul(p, fp_load<FrTag>(a + lo + j));
-    s[threadIdx.x] = p;
+        if (lo + j < n) p = f29_mul(p, f29_load_shl5<FrTag>(a + lo + j));
+    p = f29_to_261(p);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s[i * 256 + threadIdx.x] = p.v[i];
     __syncthreads();
     for (unsigned off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scan
-        Fr v = s[threadIdx.x];
-        Fr u = threadIdx.x >= off ? s[threadIdx.x - off] : fp_one<FrTag>();
+        Fr29 u;
+        if (threadIdx.x >= off) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) u.v[i] = s[i * 256 + threadIdx.x - off];
+        }
         __syncthreads();
-        if (threadIdx.x >= off) s[threadIdx.x] = fp_mul(u, v);
+        if (threadIdx.x >= off) {
+            p = f29_mul(u, p);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) s[i * 256 + threadIdx.x] = p.v[i];
+        }
         __syncthreads();
     }
-    fp_store(excl + (size_t)blockIdx.y * nb * 256 + t, threadIdx.x ? s[threadIdx.x - 1] : fp_one<FrTag>());
-    if (threadIdx.x == 255) fp_store(block_tot + (size_t)blockIdx.y * nb + blockIdx.x, s[255]);
+    Fr29 e = f29_one<FrTag>();
+    if (threadIdx.x) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) e.v[i] = s[i * 256 + threadIdx.x - 1];
+    }
+    Fr w;
+    f29_pack(e, w.v);   // strict limbs, below 2p
+    fp_store(excl + (size_t)blockIdx.y * nb * 256 + t, w);
+    if (threadIdx.x == 255) f29_store_product(block_tot + (size_t)blockIdx.y * nb + blockIdx.x, f29_to_256(p));
 }
 // phase 2: exclusive scan of each column's block totals, seeded with z0 (a few dozen entries: one lane per column)
 __global__ void k_pp_blocks(Fr* __restrict__ block_tot, unsigned nb, size_t n_cols, Fr z0) {
@@ -153,12 +172,12 @@ __global__ __launch_bounds__(256) void k_pp_apply(const Fr* __restrict__ a, size
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t lo = t * PP_K;
     if (lo >= n) return;
-    Fr cur = fp_mul(fp_load<FrTag>(block_tot + (size_t)blockIdx.y * nb + blockIdx.x),
-                    fp_load<FrTag>(excl + (size_t)blockIdx.y * nb * 256 + t));
+    Fr29 cur = f29_mul(f29_load<FrTag>(block_tot + (size_t)blockIdx.y * nb + blockIdx.x),
+                       f29_load<FrTag>(excl + (size_t)blockIdx.y * nb * 256 + t));
     for (unsigned j = 0; j < PP_K && lo + j < n; ++j) {
-        Fr v = fp_load<FrTag>(a + lo + j);  // read before the store: z may alias a
-        fp_store(z + lo + j, cur);
-        cur = fp_mul(cur, v);
+        const Fr v = fp_load<FrTag>(a + lo + j);  // read before the store: z may alias a
+        f29_store_product(z + lo + j, cur);
+        cur = f29_mul(cur, f29_from_fp_shl5(v));
     }
 }
 
@@ -207,8 +226,8 @@ __global__ __launch_bounds__(256) void k_perm_terms(const Fr* __restrict__ cols,
         dn = f29_mul(dn, f29_add(v, f29_mul(beta266, sg)));
         bd = f29_mul(bd, d);
     }
-    f29_store<1>(num + i, nm);
-    f29_store<1>(den + i, dn);
+    f29_store<0>(num + i, nm);   // one256 when m == 0, a product otherwise: strict limbs either way, but keep the general store
+    f29_store<0>(den + i, dn);
 }
 __global__ __launch_bounds__(256) void k_fr_mul_inplace(Fr* __restrict__ a, const Fr* __restrict__ b, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -265,8 +284,8 @@ __global__ __launch_bounds__(256) void k_perm_terms_sets(const Fr* __restrict__ 
         dn = f29_mul(dn, f29_add(v, f29_mul(beta266, sg)));
         bd = f29_mul(bd, d);
     }
-    f29_store<1>(num + (size_t)set * n + i, nm);
-    f29_store<1>(den + (size_t)set * n + i, dn);
+    f29_store_product(num + (size_t)set * n + i, nm);   // one256 (an empty set) or a product: strict limbs, below 2p
+    f29_store_product(den + (size_t)set * n + i, dn);
 }
 __global__ void k_perm_chain(const Fr* __restrict__ z, size_t zs, unsigned n_sets, size_t u, Fr* __restrict__ mult) {
     if (blockIdx.x || threadIdx.x) return;
@@ -343,7 +362,7 @@ __global__ __launch_bounds__(256) void k_quotient_gate(const Fr* __restrict__ ad
         const Fr29 e = f29_sub<2, 29>(f29_add(a0, f29_mul(a1, a2)), a3);
         acc = f29_mul2(acc, y261, e, sl);
     }
-    f29_store<1>(h + i, acc);
+    f29_store<0>(h + i, acc);
 }
 
 extern "C" int pz_quotient_gate_dev(pz_ctx* ctx, const uint64_t* d_adv_ext, size_t adv_stride, const uint64_t* d_sel_ext,
@@ -562,7 +581,7 @@ __global__ __launch_bounds__(256) void k_quotient_permutation(PermQ q, Fr* __res
         }
         acc = f29_mul2(acc, y, f29_sub<2, 29>(left, right), la);
     }
-    f29_store<1>(h + i, acc);
+    f29_store<0>(h + i, acc);
 }
 
 extern "C" int pz_quotient_permutation_dev(pz_ctx* ctx, const uint64_t* d_cols_ext, size_t col_stride,
@@ -609,30 +628,37 @@ struct LookQ {
     unsigned n_lookups, step;
     Fr beta, gamma, y;
 };
+// (29-bit field, domains as in k_quotient_permutation: beta, gamma, y and the l_* rows carry 2^261; every line of the argument is
+// one f29_mul2 with acc * y)
 __global__ __launch_bounds__(256) void k_quotient_lookup(LookQ q, Fr* __restrict__ h) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= q.N) return;
     const size_t mask = q.N - 1;
     const size_t i_next = (i + q.step) & mask, i_prev = (i + q.N - q.step) & mask;
-    const Fr one = fp_one<FrTag>();
-    const Fr l0 = fp_load<FrTag>(q.l0 + i), ll = fp_load<FrTag>(q.llast + i), la = fp_load<FrTag>(q.lactive + i);
-    const Fr sg = fp_add(fp_load<FrTag>(q.s + i), q.gamma);
-    Fr acc = fp_load<FrTag>(h + i);
+    const Fr29 one = fr29_one256();
+    const Fr29 y = fr29_c261(q.y), beta = fr29_c261(q.beta), gamma = fr29_c261(q.gamma);
+    const Fr29 l0 = f29_load_shl5<FrTag>(q.l0 + i), ll = f29_load_shl5<FrTag>(q.llast + i), la = f29_load_shl5<FrTag>(q.lactive + i);
+    const Fr29 sg = f29_add(f29_load_shl5<FrTag>(q.s + i), gamma);   // (s + gamma) 2^261
+    Fr29 acc = f29_load<FrTag>(h + i);
     for (unsigned k = 0; k < q.n_lookups; ++k) {
-        const Fr z = fp_load<FrTag>(q.z + (size_t)k * q.zs + i), zn = fp_load<FrTag>(q.z + (size_t)k * q.zs + i_next);
-        const Fr ap = fp_load<FrTag>(q.ap + (size_t)k * q.aps + i), sp = fp_load<FrTag>(q.sp + (size_t)k * q.sps + i);
-        const Fr a = fp_load<FrTag>(q.a + (size_t)k * q.as + i);
-        acc = fp_add(fp_mul(acc, q.y), fp_mul(fp_sub(one, z), l0));
-        acc = fp_add(fp_mul(acc, q.y), fp_mul(fp_sub(fp_sqr(z), z), ll));
-        const Fr lhs = fp_mul(zn, fp_mul(fp_add(ap, q.beta), fp_add(sp, q.gamma)));
-        const Fr rhs = fp_mul(z, fp_mul(fp_add(a, q.beta), sg));
-        acc = fp_add(fp_mul(acc, q.y), fp_mul(fp_sub(lhs, rhs), la));
-        const Fr ams = fp_sub(ap, sp);
-        acc = fp_add(fp_mul(acc, q.y), fp_mul(ams, l0));
-        const Fr dprev = fp_sub(ap, fp_load<FrTag>(q.ap + (size_t)k * q.aps + i_prev));
-        acc = fp_add(fp_mul(acc, q.y), fp_mul(fp_mul(ams, dprev), la));
+        const Fr zf = fp_load<FrTag>(q.z + (size_t)k * q.zs + i);
+        const Fr29 z = f29_from_fp(zf), zn = f29_load<FrTag>(q.z + (size_t)k * q.zs + i_next);
+        const Fr apf = fp_load<FrTag>(q.ap + (size_t)k * q.aps + i), spf = fp_load<FrTag>(q.sp + (size_t)k * q.sps + i);
+        const Fr29 ap = f29_from_fp(apf), sp = f29_from_fp(spf);
+        acc = f29_mul2(acc, y, f29_sub<2, 29>(one, z), l0);
+        acc = f29_mul2(acc, y, f29_sub<2, 29>(f29_mul(z, f29_from_fp_shl5(zf)), z), ll);
+        // (a' + beta)(s' + gamma) and (a + beta)(s + gamma): both factors carry 2^261, so does the product (loose x loose limbs:
+        // 9 * 2^30 * 2^30 + 2^59.8 < 2^64; value < 8p), and z * that is back in the 256-domain
+        const Fr29 f1 = f29_mul(f29_add(f29_from_fp_shl5(apf), beta), f29_add(f29_from_fp_shl5(spf), gamma));
+        const Fr29 f2 = f29_mul(f29_add(f29_load_shl5<FrTag>(q.a + (size_t)k * q.as + i), beta), sg);
+        acc = f29_mul2(acc, y, f29_sub<2, 29>(f29_mul(zn, f1), f29_mul(z, f2)), la);
+        const Fr29 ams = f29_carry(f29_sub<2, 29>(ap, sp));   // a' - s' + 2p, limbs < 2^29 + 8
+        acc = f29_mul2(acc, y, ams, l0);
+        // (a' - a'(w^-1 X)) * 2^261 from the shl5 images (values below 32p each; + 64p keeps every limb and the value positive)
+        const Fr29 dprev = f29_sub<64, 29>(f29_from_fp_shl5(apf), f29_load_shl5<FrTag>(q.ap + (size_t)k * q.aps + i_prev));
+        acc = f29_mul2(acc, y, f29_mul(ams, dprev), la);
     }
-    fp_store(h + i, acc);
+    f29_store<0>(h + i, acc);
 }
 
 extern "C" int pz_quotient_lookup_dev(pz_ctx* ctx, const uint64_t* d_input_ext, size_t input_stride, const uint64_t* d_table_ext,
