@@ -43,7 +43,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
-MULT_PER_MADD = 8 * 180.0 + 2 * 135.0   # v_mad_u64_u32 + v_mul_lo_u32 per XYZZ mixed addition on the 29-bit field
+MULT_PER_MADD = 6 * 180.0 + 2 * 135.0 + 252.0   # v_mad_u64_u32 + v_mul_lo_u32 per XYZZ mixed addition on the 29-bit field: 6 products, 2 squares,
+                                                # and Y3 = R t - Y1 PPP as two products under ONE reduction (f29_mul2: 243 + 9); 1710 before round 3
 
 
 def synth_inputs(enc_bits: int, seed: int):
@@ -1042,7 +1043,7 @@ def main():
     # so the per-launch figure of the committed rocprofv3 --pmc passes of this same command is reported
     traffic, traffic_src = None, None
     try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
         if args.scale == 1.0 and (args.enc_bits, args.k) == (2048, 17):
             traffic = pj["k_msm_accumulate"]["fetch_bytes_per_launch_raw"] + pj["k_msm_accumulate"]["write_bytes_per_launch"]
             traffic_src = pj["source"]
