@@ -177,3 +177,47 @@ extern "C" int pzp_fq_mul29(int device, const uint64_t a[4], const uint64_t b[4]
     if (hipMemcpy(out, (char*)d + 64, 32, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return 0;
 }
+
+// ---- element-wise checks of the 29-bit field's building blocks on RAW limb inputs (loose limbs allowed: the tests feed the
+// documented operand bounds, where a column of the product scan is closest to 2^64).  in: [count][k][9] words, out: [count][9].
+//   op 0: f29_mul(a, b)   1: f29_sqr(a)   2: f29_mul2(a, b, c, d)   3: f29_dot4(a0..a3, b0..b3) (k = 8: a0 b0 a1 b1 ..)
+//   op 4: f29_unpack_shl5 of an 8-word integer (k = 1, the ninth word ignored)   5: f29_canon<4> of a loose value (k = 1)
+//   op 6: the canonical 8-word image f29_store_product writes for a strict value below 2p (k = 1; out words 0..7)
+template <class T> __global__ void k_f29_ops(int op, const u32* __restrict__ in, unsigned k, size_t count, u32* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    F29<T> x[8];
+    for (unsigned j = 0; j < k && j < 8; ++j) x[j] = f29_load_raw<T>(in + (i * k + j) * 9);
+    F29<T> r = f29_zero<T>();
+    if (op == 0) r = f29_mul(x[0], x[1]);
+    else if (op == 1) r = f29_sqr(x[0]);
+    else if (op == 2) r = f29_mul2(x[0], x[1], x[2], x[3]);
+    else if (op == 3) {
+        const F29<T> a[4] = {x[0], x[2], x[4], x[6]}, b[4] = {x[1], x[3], x[5], x[7]};
+        r = f29_dot4(a, b);
+    } else if (op == 4) {
+        r = f29_unpack_shl5<T>(x[0].v);
+    } else if (op == 5) {
+        r = f29_canon<4>(x[0]);
+    } else if (op == 6) {
+        alignas(16) u32 w[8];
+        f29_store_product(w, x[0]);
+        for (int j = 0; j < 8; ++j) r.v[j] = w[j];
+        r.v[8] = 0;
+    }
+    f29_store_raw(out + i * 9, r);
+}
+extern "C" int pzp_f29_ops(int device, int field, int op, const uint32_t* in, uint32_t k, size_t count, uint32_t* out) {
+    if (!in || !out || !count || k == 0 || k > 8 || op < 0 || op > 6 || (field != 0 && field != 1)) return -1;
+    const size_t in_b = count * k * 36, out_b = count * 36;
+    void* d = probe_buf(device, in_b + out_b);
+    if (!d) return -1;
+    if (hipMemcpy(d, in, in_b, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    u32* d_out = (u32*)((char*)d + in_b);
+    const dim3 g((unsigned)((count + 63) / 64)), b(64);
+    if (field == 0) hipLaunchKernelGGL(k_f29_ops<FqTag>, g, b, 0, 0, op, (const u32*)d, (unsigned)k, count, d_out);
+    else hipLaunchKernelGGL(k_f29_ops<FrTag>, g, b, 0, 0, op, (const u32*)d, (unsigned)k, count, d_out);
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpy(out, d_out, out_b, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return 0;
+}

@@ -22,7 +22,8 @@ def lib():
         for name, args in (("pzp_ubench_mad", [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
                            ("pzp_ubench_mad_indep", [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
                            ("pzp_ubench_fqmul_variant", [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
-                           ("pzp_fq_mul29", [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])):
+                           ("pzp_fq_mul29", [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+                           ("pzp_f29_ops", [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_size_t, C.c_void_p])):
             fn = getattr(l, name)
             fn.restype = C.c_int
             fn.argtypes = args
@@ -54,5 +55,20 @@ def fq_mul29(device: int, a, b) -> np.ndarray:
     b = np.ascontiguousarray(b, dtype=np.uint64).reshape(4)
     out = np.zeros(4, dtype=np.uint64)
     if lib().pzp_fq_mul29(device, a.ctypes.data, b.ctypes.data, out.ctypes.data) != 0:
+        raise RuntimeError("probe launch failed")
+    return out
+
+
+F29_OPS = {"mul": (0, 2), "sqr": (1, 1), "mul2": (2, 4), "dot4": (3, 8), "unpack_shl5": (4, 1), "canon4": (5, 1), "store_product": (6, 1)}
+
+
+def f29_ops(device: int, field: str, op: str, limbs) -> np.ndarray:
+    """element-wise check entry of the 29-bit field's building blocks (csrc/fp29.cuh) on RAW limb operands:
+    limbs [count][k][9] uint32 (loose limbs allowed) -> [count][9]; field 'fq' | 'fr'; op a key of F29_OPS"""
+    code, k = F29_OPS[op]
+    a = np.ascontiguousarray(limbs, dtype=np.uint32)
+    assert a.ndim == 3 and a.shape[1] == k and a.shape[2] == 9, a.shape
+    out = np.zeros((a.shape[0], 9), dtype=np.uint32)
+    if lib().pzp_f29_ops(device, 0 if field == "fq" else 1, code, a.ctypes.data, k, a.shape[0], out.ctypes.data) != 0:
         raise RuntimeError("probe launch failed")
     return out

@@ -1230,3 +1230,87 @@ def test_msm_ab_arms(env):
     e.update(env)
     r = subprocess.run([sys.executable, "-c", _AB_ARMS_SCRIPT, root], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "arms-ok" in r.stdout, (env, r.stdout[-2000:], r.stderr[-2000:])
+
+
+# ------------------------------------------------------------------------------------------ the 29-bit field's building blocks
+def _limbs_val(l):
+    return sum(int(x) << (29 * i) for i, x in enumerate(l))
+
+
+def _rand_limbs(rng, limb_max, value_max):
+    """nine limbs each up to limb_max (half of the samples AT limb_max in every low limb), the value kept below value_max
+    through the top limb"""
+    low = [limb_max if rng.random() < 0.5 else rng.randrange(limb_max + 1) for _ in range(8)]
+    if rng.random() < 0.25:
+        low = [limb_max] * 8
+    rest = value_max - 1 - _limbs_val(low)
+    assert rest >= 0
+    top = min(rest >> 232, limb_max, (1 << 32) - 1)
+    top = top if rng.random() < 0.5 else rng.randrange(top + 1)
+    return low + [top]
+
+
+@pytest.mark.parametrize("field", ["fq", "fr"])
+def test_f29_building_blocks_at_their_operand_bounds(eng, field):
+    """f29_mul / f29_sqr / f29_mul2 / f29_dot4 on RAW limb operands at the bounds their callers document (fp29.cuh, ec29.cuh,
+    pz_quotient.hip): a column of the product scan is a 64-bit accumulator with no carry-out, so an operand pattern beyond the
+    analysed bound would wrap silently -- here every low limb sits AT the bound in a quarter of the samples.  Checked: the
+    result is congruent to sum(a_i b_i) / 2^261, has strict 29-bit limbs and stays below sum(va vb) / 2^261 + p.
+    Also f29_unpack_shl5 (limbs of 32 x), f29_canon<4> and f29_store_product against Python integers."""
+    from paillier_halo2_amd import probe
+
+    p = P.FQ_P if field == "fq" else P.FR_R
+    rinv = pow(1 << 261, -1, p)
+    rng = random.Random(2929 + (field == "fr"))
+    T, T8 = (1 << 29) - 1, (1 << 29) + 7   # tight; tight after one parallel carry round
+    cases = {
+        # op: list of per-term ((limb bound a, value bound a), (limb bound b, value bound b))
+        "mul": [[((T8, 10 * p), ((1 << 31) - 1, 10 * p))],                       # R x t of the mixed addition
+                [((int(1.23 * 2 ** 30), 36 * p), (int(1.23 * 2 ** 30), 36 * p))],  # loose x loose (lookup quotient: (a'+beta)(s'+gamma))
+                [((T, 2 * p), (3 << 29, 40 * p))]],                              # running product x (v + beta sigma + gamma)
+        "sqr": [[((T8, 10 * p), None)], [(((1 << 30) + 16, 8 * p), None)]],      # P^2, R^2; U^2 of the doubling (U = 2Y)
+        "mul2": [[((T8, 6 * p), ((1 << 31) - 1, 10 * p)), ((T8, 4 * p), (T, 2 * p))],          # Y3 of x29_add_affine
+                 [((T8, 4 * p), ((1 << 31) - 1, 10 * p)), (((1 << 30) - 1, 2 * p), (T, 2 * p))],   # Y3 of x29_add
+                 [((T, 2 * p), (T, 2 * p)), (((1 << 31) - 1, 5 * p), (T, 32 * p))],          # acc y + e sel (gate), + (..) l (permutation)
+                 [((T, 2 * p), (T, 2 * p)), ((3 << 29, 4 * p), (T, 32 * p))]],
+        "dot4": [[((T, 32 * p), (T, 2 * p))] * 4],
+    }
+    for op, variants in cases.items():
+        for terms in variants:
+            count = 512
+            rows, expect, vbound = [], [], []
+            for _ in range(count):
+                ops, acc, vb = [], 0, 0
+                for (la, va), second in terms:
+                    a = _rand_limbs(rng, la, va)
+                    b = a if second is None else _rand_limbs(rng, second[0], second[1])
+                    ops.append(a)
+                    if second is not None:
+                        ops.append(b)
+                    acc += _limbs_val(a) * _limbs_val(b)
+                    vb += _limbs_val(a) * _limbs_val(b)
+                rows.append(ops)
+                expect.append(acc * rinv % p)
+                vbound.append((vb >> 261) + p + 1)
+            got = probe.f29_ops(eng.device, field, op, np.array(rows, dtype=np.uint32))
+            for i in range(count):
+                assert all(int(x) < (1 << 29) for x in got[i]), (op, terms, i, "limbs not strict")
+                v = _limbs_val(got[i])
+                assert v % p == expect[i], (op, terms, i)
+                assert v < vbound[i], (op, terms, i, "value bound")
+    # shl5 unpack: the limbs of 32 x for any 256-bit x
+    xs = [rng.getrandbits(256) for _ in range(256)] + [0, 1, (1 << 256) - 1, p - 1]
+    rows = [[[(x >> (32 * j)) & 0xFFFFFFFF for j in range(8)] + [0]] for x in xs]
+    got = probe.f29_ops(eng.device, field, "unpack_shl5", np.array(rows, dtype=np.uint32))
+    for x, g in zip(xs, got):
+        assert all(int(l) < (1 << 29) for l in g) and _limbs_val(g) == 32 * x
+    # canon<4> (any value below 32p, loose limbs) and the product store (strict limbs, below 2p)
+    rows = [[_rand_limbs(rng, (1 << 31) + (1 << 29), 32 * p)] for _ in range(512)]
+    got = probe.f29_ops(eng.device, field, "canon4", np.array(rows, dtype=np.uint32))
+    for r, g in zip(rows, got):
+        assert _limbs_val(g) == _limbs_val(r[0]) % p and all(int(l) < (1 << 29) for l in g)
+    vals = [rng.randrange(2 * p) for _ in range(512)] + [0, p - 1, p, p + 1, 2 * p - 1]
+    rows = [[[(v >> (29 * j)) & T for j in range(8)] + [v >> 232]] for v in vals]
+    got = probe.f29_ops(eng.device, field, "store_product", np.array(rows, dtype=np.uint32))
+    for v, g in zip(vals, got):
+        assert sum(int(w) << (32 * j) for j, w in enumerate(g[:8])) == v % p
