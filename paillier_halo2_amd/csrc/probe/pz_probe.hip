@@ -183,7 +183,11 @@ extern "C" int pzp_fq_mul29(int device, const uint64_t a[4], const uint64_t b[4]
 //   op 0: f29_mul(a, b)   1: f29_sqr(a)   2: f29_mul2(a, b, c, d)   3: f29_dot4(a0..a3, b0..b3) (k = 8: a0 b0 a1 b1 ..)
 //   op 4: f29_unpack_shl5 of an 8-word integer (k = 1, the ninth word ignored)   5: f29_canon<4> of a loose value (k = 1)
 //   op 6: the canonical 8-word image f29_store_product writes for a strict value below 2p (k = 1; out words 0..7)
+//   op 7: f29_canon_q of a loose value below 32p (k = 1), the quotient table in LDS as the transforms' last pass keeps it
 template <class T> __global__ void k_f29_ops(int op, const u32* __restrict__ in, unsigned k, size_t count, u32* __restrict__ out) {
+    __shared__ u32 qtab[F29_QTAB_WORDS];
+    f29_qtab_fill<T>(qtab);
+    __syncthreads();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     F29<T> x[8];
@@ -204,11 +208,13 @@ template <class T> __global__ void k_f29_ops(int op, const u32* __restrict__ in,
         f29_store_product(w, x[0]);
         for (int j = 0; j < 8; ++j) r.v[j] = w[j];
         r.v[8] = 0;
+    } else if (op == 7) {
+        r = f29_canon_q(x[0], qtab);
     }
     f29_store_raw(out + i * 9, r);
 }
 extern "C" int pzp_f29_ops(int device, int field, int op, const uint32_t* in, uint32_t k, size_t count, uint32_t* out) {
-    if (!in || !out || !count || k == 0 || k > 8 || op < 0 || op > 6 || (field != 0 && field != 1)) return -1;
+    if (!in || !out || !count || k == 0 || k > 8 || op < 0 || op > 7 || (field != 0 && field != 1)) return -1;
     const size_t in_b = count * k * 36, out_b = count * 36;
     void* d = probe_buf(device, in_b + out_b);
     if (!d) return -1;

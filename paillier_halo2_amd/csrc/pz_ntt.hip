@@ -70,6 +70,19 @@ template <bool CANON, unsigned J> __device__ __forceinline__ void ntt_store(Fp<F
     }
 }
 
+// the last pass's store of a value that has no product in front of it (uncarried limbs, below 32p: the inter-pass product left
+// it below 2p and every pair of stages adds at most 4p): canonical through the quotient estimate (fp29.cuh::f29_canon_q)
+__device__ __forceinline__ void ntt_store_q(Fp<FrTag>* p, const F29<FrTag>& x, const u32* __restrict__ qtab) {
+    const F29<FrTag> c = f29_canon_q(x, qtab);
+    u32 w[8];
+    f29_pack(c, w);
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+// words of an LDS tile of `elems` elements (pad element per 32 + one): the quotient table of the final kernels sits behind it
+__device__ __host__ __forceinline__ unsigned ntt29_lds_words(unsigned elems) { return (elems + (elems >> 5) + 1u) * 9u; }
+
 // tile index -> LDS word offset: 9 words per element and ONE PAD ELEMENT PER 32, which spreads the power-of-two
 // element strides of the bit-reversed fill and of the first pair of stages over all banks (without it 69 % of the
 // LDS cycles of these kernels were bank conflicts: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/)
@@ -316,14 +329,16 @@ __global__ __launch_bounds__(256) void k_ntt_final29(const Fr* in, Fr* out, size
         }
     }
     __syncthreads();
+    u32* qtab = sm + ntt29_lds_words(nelem);   // behind the tile: q * p rows of the quotient-estimate canonicalisation
+    if (!has_post) f29_qtab_fill<FrTag>(qtab);   // (filled before the stages' last barrier: visible to the stores below)
     lds_dit29(sm, p.logR, T, 1, R, false, tw, p.n);
     const Fr29 post29 = f29_from_fp(post);
     for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
         unsigned k = idx >> logT, r = idx & (T - 1);
         Fr29 x = lds29_get(sm, r * R + k);
         Fr* o = dst + (k1_0 + r) + p.n1 * k2 + p.hi * (size_t)k;
-        if (has_post) ntt_store<true, 1>(o, f29_mul(x, post29));
-        else ntt_store<true, 4>(o, x);
+        if (has_post) f29_store_product(o, f29_mul(x, post29));   // a product: strict limbs, below 2p
+        else ntt_store_q(o, x, qtab);
     }
 }
 
@@ -368,11 +383,13 @@ __global__ __launch_bounds__(256) void k_ntt_final_ext29(const Fr* in, Fr* out, 
         }
     }
     __syncthreads();
+    u32* qtab = sm + ntt29_lds_words(nelem);
+    f29_qtab_fill<FrTag>(qtab);
     lds_dit29(sm, p.logR, T * E, 1, R, false, tw, p.n);
     for (unsigned idx = threadIdx.x; idx < R * T * E; idx += blockDim.x) {
         const unsigned r = idx & (E - 1), rr = (idx >> log_e) & (T - 1), k = idx >> (log_e + logT);
         const Fr29 x = lds29_get(sm, (r * T + rr) * R + k);
-        ntt_store<true, 4>(dst + (((k1_0 + rr) + p.n1 * k2 + p.hi * (size_t)k) << log_e) + r, x);
+        ntt_store_q(dst + (((k1_0 + rr) + p.n1 * k2 + p.hi * (size_t)k) << log_e) + r, x, qtab);
     }
 }
 
@@ -447,7 +464,7 @@ static int launch_strided(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t 
 static int launch_final(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t os, size_t ncols, NttPass p,
                         const u32* tw, const u32* pre, const uint64_t* post_scale) {
     size_t blocks = p.n2 * (p.n1 / p.T);
-    size_t lds = ntt29_lds_bytes(((size_t)1 << p.logR) * p.T);
+    size_t lds = ntt29_lds_bytes(((size_t)1 << p.logR) * p.T) + F29_QTAB_WORDS * 4;
     Fr post;
     memset(&post, 0, sizeof post);
     if (post_scale) {   // into the 261-domain
@@ -605,7 +622,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
         if (npass == 1) {
             NttPass p{};
             p.logR = log_n; p.lo = 1; p.hi = 1; p.n = n; p.T = 1; p.n1 = 1; p.n2 = 1;
-            const size_t lds = ntt29_lds_bytes(((size_t)1 << p.logR) * p.T * E);
+            const size_t lds = ntt29_lds_bytes(((size_t)1 << p.logR) * p.T * E) + F29_QTAB_WORDS * 4;
             p.swap = 0;
             hipLaunchKernelGGL(k_ntt_final_ext29<true>, dim3(1, (unsigned)nc), dim3(256), lds, ctx->stream, cin + c0 * is,
                                eout + c0 * os, is, (size_t)0, os, p, log_e, tw, pre, n);
@@ -629,7 +646,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
             unsigned T = 8;
             while (T > 1 && (((size_t)32 << lg[2]) * T * E > ntt_tile_budget() || T > n1)) T >>= 1;
             pc.T = T;
-            const size_t lds = ntt29_lds_bytes(((size_t)1 << lg[2]) * T * E);
+            const size_t lds = ntt29_lds_bytes(((size_t)1 << lg[2]) * T * E) + F29_QTAB_WORDS * 4;
             pc.swap = (nc > 1 && n2 * (n1 / T) <= 65535) ? 1u : 0u;
             hipLaunchKernelGGL(k_ntt_final_ext29<false>, pc.swap ? dim3((unsigned)nc, (unsigned)(n2 * (n1 / T))) : dim3((unsigned)(n2 * (n1 / T)), (unsigned)nc), dim3(256), lds, ctx->stream, tmp,
                                eout + c0 * os, n, nc * n, os, pc, log_e, tw, (const u32*)nullptr, (size_t)0);
@@ -647,7 +664,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
             unsigned T = 8;
             while (T > 1 && (((size_t)32 << lg1) * T * E > ntt_tile_budget() || T > n1)) T >>= 1;
             pc.T = T;
-            const size_t lds = ntt29_lds_bytes(((size_t)1 << lg1) * T * E);
+            const size_t lds = ntt29_lds_bytes(((size_t)1 << lg1) * T * E) + F29_QTAB_WORDS * 4;
             pc.swap = nc > 1 ? 1u : 0u;
             hipLaunchKernelGGL(k_ntt_final_ext29<false>, pc.swap ? dim3((unsigned)nc, (unsigned)(n1 / T)) : dim3((unsigned)(n1 / T), (unsigned)nc), dim3(256), lds, ctx->stream, tmp,
                                eout + c0 * os, n, nc * n, os, pc, log_e, tw, (const u32*)nullptr, (size_t)0);

@@ -1309,6 +1309,12 @@ def test_f29_building_blocks_at_their_operand_bounds(eng, field):
     got = probe.f29_ops(eng.device, field, "canon4", np.array(rows, dtype=np.uint32))
     for r, g in zip(rows, got):
         assert _limbs_val(g) == _limbs_val(r[0]) % p and all(int(l) < (1 << 29) for l in g)
+    # the quotient-estimate canonicalisation of the transforms' last pass: random loose values and the edges k p - 1, k p, k p + 1
+    edge = [k * p + d for k in range(0, 32) for d in (-1, 0, 1) if 0 <= k * p + d < 32 * p] + [32 * p - 1]
+    rows += [[[(v >> (29 * j)) & T for j in range(8)] + [v >> 232]] for v in edge]
+    got = probe.f29_ops(eng.device, field, "canon_q", np.array(rows, dtype=np.uint32))
+    for r, g in zip(rows, got):
+        assert _limbs_val(g) == _limbs_val(r[0]) % p and all(int(l) < (1 << 29) for l in g), ("canon_q", _limbs_val(r[0]) // p)
     vals = [rng.randrange(2 * p) for _ in range(512)] + [0, p - 1, p, p + 1, 2 * p - 1]
     rows = [[[(v >> (29 * j)) & T for j in range(8)] + [v >> 232]] for v in vals]
     got = probe.f29_ops(eng.device, field, "store_product", np.array(rows, dtype=np.uint32))
