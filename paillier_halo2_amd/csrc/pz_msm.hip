@@ -1133,8 +1133,8 @@ __global__ __launch_bounds__(128) void k_msm_combine(unsigned n_in, unsigned m, 
 // its size).  Bit-sliced instead:  sum_b w_b B_b = sum_j 2^j T_j  with  T_j = sum of the buckets whose weight w_b = b + 1
 // has bit j set -- c subset sums, each a fully parallel tree reduction (depth log2 B additions instead of ~150), then
 // a pairwise Horner fold of the c slices (depth log2 c).
-//   k_msm_slice_partial : block of 256 buckets x bit j  -> one partial (LDS tree)
-//   k_msm_slice_reduce  : the B/256 partials of (column, bit j) -> T_j (LDS tree)
+//   k_msm_slice_partial : block of 256 weights -> its subset sums for the low eight bits + its plain sum (LDS trees)
+//   k_msm_slice_reduce  : the blocks' sums of (column, bit j) -> T_j (LDS tree)
 //   k_msm_slice_horner  : U = T_0 + 2 T_1, ...; then pairs of pairs with 2, 4, 8 doublings: one workgroup per column
 // ------------------------------------------------------------------------------------------------
 // sum of the first n entries of s_pt (n a power of two <= 256, 256 threads) into s_pt[0]: pairwise tree, every addition done by a
@@ -1153,39 +1153,69 @@ __device__ __forceinline__ void lds_tree_sum_quad(G1X29Raw* s_pt, unsigned n) {
     __syncthreads();
 }
 
-// one bucket per thread: the partial sum of the buckets of this 256-bucket block whose weight has bit j
+// Blocks are cut by WEIGHT, w = 256 blk + t (w = 0 has no bucket; bucket b has weight b + 1), so that the bits of w split
+// cleanly: bits 0..7 are bits of t -- within a block exactly half of the t have bit y -- and bits >= 8 are bits of blk -- a
+// block is in such a slice with ALL its buckets or with none.  Per block therefore NINE half-size subset sums of 128 leaves:
+//   slot y < 8: the block's buckets whose t has bit y;  slot 8: those whose t has bit 7 CLEAR
+// (slot 7 + slot 8 = the block's plain sum, which serves every high bit): 9 * 127 additions instead of 16 * 255, and with
+// 18 KB of LDS per workgroup all blocks x slots of a column are resident at once (one round instead of 1161 / 1024).
+#define SLICE_SLOTS 9u
 __global__ __launch_bounds__(256) void k_msm_slice_partial(MsmP p, const u32* __restrict__ items,
                                                            const G1X29Raw* __restrict__ partials, unsigned nblk,
                                                            G1X29Raw* __restrict__ slice_part) {
-    __shared__ G1X29Raw s_pt[256];
+    __shared__ G1X29Raw s_pt[128];
     const size_t col = blockIdx.z;
-    const unsigned j = blockIdx.y;
+    const unsigned y = blockIdx.y, blk = blockIdx.x;
     const u32* it = items + col * (p.B + 1);
-    G1X29 v = x29_inf();
-    const unsigned b = blockIdx.x * 256 + threadIdx.x;
-    if (b < p.B && (((b + 1) >> j) & 1u)) {
-        const u32 a = it[b], z = it[b + 1];
-        if (z > a) v = x29_load_raw(partials + col * p.max_items + a);
+    if (threadIdx.x < 128) {
+        const unsigned i = threadIdx.x, yy = y < 8 ? y : 7u;
+        // the i-th t with bit yy set (slots 0..7) or clear (slot 8)
+        const unsigned t = ((i >> yy) << (yy + 1)) | (y < 8 ? (1u << yy) : 0u) | (i & ((1u << yy) - 1u));
+        const unsigned w = blk * 256u + t;
+        G1X29 v = x29_inf();
+        if (w >= 1 && w <= p.B) {
+            const u32 a = it[w - 1], z = it[w];
+            if (z > a) v = x29_load_raw(partials + col * p.max_items + a);
+        }
+        x29_store_raw(&s_pt[i], v);
     }
-    x29_store_raw(&s_pt[threadIdx.x], v);
-    lds_tree_sum_quad(s_pt, 256);
-    if (threadIdx.x == 0) slice_part[(col * p.c + j) * nblk + blockIdx.x] = s_pt[0];
+    lds_tree_sum_quad(s_pt, 128);
+    if (threadIdx.x == 0) slice_part[(col * SLICE_SLOTS + y) * nblk + blk] = s_pt[0];
 }
 
+// T_j of one column: bit j < 8 -> the blocks' slot-j sums; bit j >= 8 -> slots 7 and 8 (together a block's plain sum) of the
+// blocks whose index has bit j - 8: at most 2 * 64 values for B <= 2^15, a tree of 128
 __global__ __launch_bounds__(256) void k_msm_slice_reduce(MsmP p, unsigned nblk, const G1X29Raw* __restrict__ slice_part,
                                                           G1X29Raw* __restrict__ slices) {
     __shared__ G1X29Raw s_pt[256];
     const size_t col = blockIdx.y;
     const unsigned j = blockIdx.x;
-    const G1X29Raw* in = slice_part + (col * p.c + j) * nblk;
+    const G1X29Raw* base = slice_part + col * SLICE_SLOTS * (size_t)nblk;
     G1X29 acc = x29_inf();
-    for (unsigned t = threadIdx.x; t < nblk; t += 256) {
-        G1X29 o = x29_load_raw(in + t);
-        x29_add(acc, o);
+    unsigned count;
+    if (j < 8) {
+        count = nblk;
+        for (unsigned t = threadIdx.x; t < nblk; t += 256) {
+            G1X29 o = x29_load_raw(base + (size_t)j * nblk + t);
+            x29_add(acc, o);
+        }
+    } else {
+        const unsigned s_ = j - 8;
+        // blocks with bit s_ of their index: the k-th is k with a one inserted at bit s_; two values (slots 7, 8) per block
+        const unsigned n_sel = (nblk + (1u << s_)) >> (s_ + 1) << s_;   // upper bound on such blocks below nblk (exact or + partial run)
+        count = 2 * n_sel;
+        for (unsigned t = threadIdx.x; t < count; t += 256) {
+            const unsigned k = t >> 1;
+            const unsigned blk = ((k >> s_) << (s_ + 1)) | (1u << s_) | (k & ((1u << s_) - 1u));
+            if (blk < nblk) {
+                G1X29 o = x29_load_raw(base + (size_t)(7 + (t & 1u)) * nblk + blk);
+                x29_add(acc, o);
+            }
+        }
     }
     x29_store_raw(&s_pt[threadIdx.x], acc);
     unsigned n = 1;
-    while (n < nblk && n < 256) n <<= 1;   // only the levels that hold something
+    while (n < count && n < 256) n <<= 1;   // only the levels that hold something
     lds_tree_sum_quad(s_pt, n);
     if (threadIdx.x == 0) slices[col * 16 + j] = s_pt[0];
 }
@@ -1367,11 +1397,14 @@ static unsigned msm_chunk_for(size_t n_cols, size_t digits_per_col) {
 }
 
 // Scalars per thread of the sort passes.  A slice costs its workgroup ~0.4 MB of fixed traffic (zeroing / loading / storing
-// the 2^15 bucket counters), so slices are as large as SORT_PER_THREAD allows -- unless that leaves fewer workgroups than
-// CUs: a single 2^19-point column in 64 slices kept 3/4 of the chip idle through both passes.
+// the 2^15 bucket counters), so slices are as large as SORT_PER_THREAD allows -- unless that leaves too few workgroups: a single
+// 2^19-point column in 64 slices kept 3/4 of the chip idle through both passes.  How few is too few was measured on that
+// column (a rank's share of c4; hist + totals + scatter): 512 workgroups 206 us, 256: 178, 128: 163 -- the fixed traffic of the
+// extra slices costs more than the idle CUs.  Column batches have thousands of slices either way.
 static unsigned msm_spt_for(size_t n_cols, size_t n) {
+    const size_t min_wg = n_cols <= MSM_SLICE_MAX_COLS ? 128 : 512;
     unsigned spt = SORT_PER_THREAD;
-    while (spt > 1 && n_cols * pz_div_up(n, (size_t)SORT_THREADS * spt) < 512) spt >>= 1;
+    while (spt > 1 && n_cols * pz_div_up(n, (size_t)SORT_THREADS * spt) < min_wg) spt >>= 1;
     return spt;
 }
 
@@ -1485,11 +1518,11 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     }
     if (nc <= MSM_SLICE_MAX_COLS) {
         // few columns: bit-sliced parallel reduction (depth ~ log2 B + log2 c point additions)
-        const unsigned nblk = pz_div_up(p.B, 256);
+        const unsigned nblk = (p.B >> 8) + 1;   // blocks by weight: w = 256 blk + t, 1 <= w <= B
         void *sp, *sl;
-        PZCHK(pz_ws_get(ctx, WS_NODES_A, nc * (size_t)p.c * nblk * sizeof(G1X29Raw), &sp));
+        PZCHK(pz_ws_get(ctx, WS_NODES_A, nc * (size_t)SLICE_SLOTS * nblk * sizeof(G1X29Raw), &sp));
         PZCHK(pz_ws_get(ctx, WS_NODES_B, nc * 16 * sizeof(G1X29Raw), &sl));
-        hipLaunchKernelGGL(k_msm_slice_partial, dim3(nblk, p.c, (unsigned)nc), dim3(256), 0, st, p, (const u32*)items,
+        hipLaunchKernelGGL(k_msm_slice_partial, dim3(nblk, SLICE_SLOTS, (unsigned)nc), dim3(256), 0, st, p, (const u32*)items,
                            (const G1X29Raw*)partials, nblk, (G1X29Raw*)sp);
         hipLaunchKernelGGL(k_msm_slice_reduce, dim3(p.c, (unsigned)nc), dim3(256), 0, st, p, nblk, (const G1X29Raw*)sp, (G1X29Raw*)sl);
         hipLaunchKernelGGL(k_msm_slice_horner, dim3((unsigned)nc), dim3(64), 0, st, p, (const G1X29Raw*)sl, d_out);
