@@ -371,25 +371,40 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_msm_scan(const u32* __restrict
 #define SORT_FINE_LOG 7u
 #define SORT_FINE (1u << SORT_FINE_LOG)
 #define SORT_COARSE_MAX (SORT_MAXB >> SORT_FINE_LOG)
-__global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter_coarse(const Fr* __restrict__ scalars, size_t col_stride, MsmP p,
-                                                                     const u32* __restrict__ slice_hist, unsigned n_slices,
-                                                                     const u32* __restrict__ offs, u32* __restrict__ staged,
-                                                                     size_t n_cols) {
-    __shared__ u32 cb[SORT_COARSE_MAX];
+// The coarse step is LDS-staged as well: a 256-thread workgroup takes its slice in rounds of 256 scalars (<= 4096 entries),
+// counting-sorts the round's entries by coarse group inside LDS and writes them out in slot order -- consecutive lanes hit
+// consecutive addresses inside a group's run (~16 entries = 64 B on average), so a wave's store instruction touches a handful
+// of lines instead of 64.  Three barriers per round; window width 16 only (the digits of a scalar are kept in registers).
+#define COARSE_THREADS 256u
+#define COARSE_ROUND (COARSE_THREADS * 16u)
+__global__ __launch_bounds__(COARSE_THREADS) void k_msm_scatter_coarse(const Fr* __restrict__ scalars, size_t col_stride, MsmP p,
+                                                                       const u32* __restrict__ slice_hist, unsigned n_slices,
+                                                                       const u32* __restrict__ offs, u32* __restrict__ staged,
+                                                                       size_t n_cols) {
+    __shared__ u32 cb[SORT_COARSE_MAX];      // global cursor of every coarse group (position in the column's staging list)
+    __shared__ u32 cnt[SORT_COARSE_MAX];     // entries of this round per group
+    __shared__ u32 lbase[SORT_COARSE_MAX];   // first LDS slot of the group in this round
+    __shared__ u32 gb[SORT_COARSE_MAX];      // global position of LDS slot 0 if it belonged to the group: cursor - lbase
+    __shared__ u32 stage[COARSE_ROUND];
+    __shared__ unsigned char sbin[COARSE_ROUND];
+    __shared__ u32 s_total;
     size_t col;
     unsigned slice;
     if (!sort_block_coords(n_slices, n_cols, slice, col)) return;
     const u32* in = slice_hist + (col * n_slices + slice) * (size_t)p.B;
     const u32* o = offs + col * (p.B + 1);
-    const unsigned n_coarse = p.B >> SORT_FINE_LOG;
-    for (unsigned c = threadIdx.x; c < n_coarse; c += SORT_THREADS) cb[c] = o[c << SORT_FINE_LOG];
+    const unsigned n_coarse = p.B >> SORT_FINE_LOG;   // <= 256
+    if (threadIdx.x < SORT_COARSE_MAX) {
+        cb[threadIdx.x] = threadIdx.x < n_coarse ? o[threadIdx.x << SORT_FINE_LOG] : 0u;
+        cnt[threadIdx.x] = 0;
+    }
     __syncthreads();
     // + the entries earlier slices put into the group: a wave sums 64 consecutive buckets (half a group) per step
-    for (unsigned b0 = (threadIdx.x & ~63u); b0 < p.B; b0 += 4 * SORT_THREADS) {
+    for (unsigned b0 = (threadIdx.x & ~63u); b0 < p.B; b0 += 4 * COARSE_THREADS) {
         u32 v[4];
 #pragma unroll
         for (unsigned k = 0; k < 4; ++k) {
-            const unsigned b = b0 + k * SORT_THREADS + (threadIdx.x & 63u);
+            const unsigned b = b0 + k * COARSE_THREADS + (threadIdx.x & 63u);
             v[k] = b < p.B ? in[b] : 0u;
         }
 #pragma unroll
@@ -397,24 +412,25 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter_coarse(const Fr* _
             u32 t = v[k];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
-            const unsigned b = b0 + k * SORT_THREADS;
+            const unsigned b = b0 + k * COARSE_THREADS;
             if ((threadIdx.x & 63u) == 0 && b < p.B && t) atomicAdd(&cb[b >> SORT_FINE_LOG], t);
         }
     }
     __syncthreads();
     u32* e = staged + col * p.cap;
     const size_t base = (size_t)slice * SORT_THREADS * p.spt;
-    for (unsigned t = 0; t < p.spt; ++t) {
-        const size_t i = base + (size_t)t * SORT_THREADS + threadIdx.x;
-        if (i >= p.n) break;
-        u32 s[8];
-        const bool neg = scalar_prepare(fp_load<FrTag>(scalars + col * col_stride + i), s);
-        u32 any = 0;
+    const unsigned rounds = SORT_THREADS * p.spt / COARSE_THREADS;
+    for (unsigned rd = 0; rd < rounds; ++rd) {
+        const size_t i = base + (size_t)rd * COARSE_THREADS + threadIdx.x;
+        if (base + (size_t)rd * COARSE_THREADS >= p.n) break;   // uniform: the whole round lies beyond the column
+        // ---- phase 1: digits of this thread's scalar, rank of each inside its group (LDS counters)
+        u32 ev[16], rb[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) any |= s[k];
-        if (!any) continue;
-        unsigned carry = 0;
-        if (p.c == 16) {
+        for (unsigned w = 0; w < 16; ++w) rb[w] = 0xffffffffu;
+        if (i < p.n) {
+            u32 s[8];
+            const bool neg = scalar_prepare(fp_load<FrTag>(scalars + col * col_stride + i), s);
+            unsigned carry = 0;
 #pragma unroll
             for (unsigned w = 0; w < 16; ++w) {
                 if (w < p.win_hi) {
@@ -422,24 +438,52 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter_coarse(const Fr* _
                     carry = d0 > 0x8000u ? 1u : 0u;
                     const unsigned mag = carry ? 0x10000u - d0 : d0;
                     if (w >= p.win_lo && mag != 0) {
-                        const unsigned b = mag - 1;
-                        const u32 pos = atomicAdd(&cb[b >> SORT_FINE_LOG], 1u);
+                        const unsigned bkt = mag - 1, grp = bkt >> SORT_FINE_LOG;
                         const bool sgn = neg != (carry != 0);
-                        e[pos] = (u32)((size_t)w * p.n_table + i) | (sgn ? 0x01000000u : 0u) | ((b & (SORT_FINE - 1)) << 25);
+                        ev[w] = (u32)((size_t)w * p.n_table + i) | (sgn ? 0x01000000u : 0u) | ((bkt & (SORT_FINE - 1)) << 25);
+                        rb[w] = atomicAdd(&cnt[grp], 1u) | (grp << 16);
                     }
                 }
             }
-        } else {
-            for (unsigned w = 0; w < p.win_hi; ++w) {
-                int d = next_digit(s, w, p.c, carry);
-                if (w >= p.win_lo && d != 0) {
-                    const unsigned b = (d < 0 ? -d : d) - 1;
-                    const u32 pos = atomicAdd(&cb[b >> SORT_FINE_LOG], 1u);
-                    const bool sgn = neg != (d < 0);
-                    e[pos] = (u32)((size_t)w * p.n_table + i) | (sgn ? 0x01000000u : 0u) | ((b & (SORT_FINE - 1)) << 25);
-                }
+        }
+        __syncthreads();
+        // ---- phase 2: exclusive scan of the 256 counters by the first wave
+        if (threadIdx.x < 64) {
+            const unsigned c0 = cnt[4 * threadIdx.x], c1 = cnt[4 * threadIdx.x + 1], c2 = cnt[4 * threadIdx.x + 2], c3 = cnt[4 * threadIdx.x + 3];
+            const unsigned sum = c0 + c1 + c2 + c3;
+            unsigned incl = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned t = __shfl_up(incl, off, 64);
+                if ((int)threadIdx.x >= off) incl += t;
+            }
+            const unsigned excl = incl - sum;
+            lbase[4 * threadIdx.x] = excl;
+            lbase[4 * threadIdx.x + 1] = excl + c0;
+            lbase[4 * threadIdx.x + 2] = excl + c0 + c1;
+            lbase[4 * threadIdx.x + 3] = excl + c0 + c1 + c2;
+            if (threadIdx.x == 63) s_total = incl;
+        }
+        __syncthreads();
+        // ---- phase 3: cursors, placement into the staging array
+        {
+            const unsigned g = cb[threadIdx.x], c = cnt[threadIdx.x];
+            gb[threadIdx.x] = g - lbase[threadIdx.x];
+            cb[threadIdx.x] = g + c;
+            cnt[threadIdx.x] = 0;
+        }
+#pragma unroll
+        for (unsigned w = 0; w < 16; ++w) {
+            if (rb[w] != 0xffffffffu) {
+                const unsigned grp = rb[w] >> 16, slot = lbase[grp] + (rb[w] & 0xffffu);
+                stage[slot] = ev[w];
+                sbin[slot] = (unsigned char)grp;
             }
         }
+        __syncthreads();
+        // ---- phase 4: out in slot order (coalesced inside every group's run)
+        const unsigned total = s_total;
+        for (unsigned sl = threadIdx.x; sl < total; sl += COARSE_THREADS) e[gb[sbin[sl]] + sl] = stage[sl];
     }
 }
 
@@ -1450,7 +1494,7 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
         const char* e = getenv("PZ_MSM_SCATTER");
         scatter_two = (e && !strcmp(e, "two")) ? 1 : 0;
     }
-    const bool two_pass = scatter_two && p.B >= 2 * SORT_FINE && (size_t)p.nwin * p.n_table <= ((size_t)1 << 24);
+    const bool two_pass = scatter_two && p.c == 16 && (size_t)p.nwin * p.n_table <= ((size_t)1 << 24);
     {
         const size_t part_bytes = nc * p.max_items * sizeof(G1X29Raw), stage_bytes = two_pass ? nc * p.cap * 4 + 16 : 0;
         PZCHK(pz_ws_get(ctx, WS_PARTIALS, part_bytes > stage_bytes ? part_bytes : stage_bytes, &partials));
@@ -1480,7 +1524,7 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
         }
         if (two_pass) {
             // the staging list lives in the partial sums' buffer: k_msm_accumulate writes those after the list is consumed
-            hipLaunchKernelGGL(k_msm_scatter_coarse, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (const u32*)hist, n_slices,
+            hipLaunchKernelGGL(k_msm_scatter_coarse, gs, dim3(COARSE_THREADS), 0, st, d_scalars, cs, p, (const u32*)hist, n_slices,
                                (const u32*)offs, (u32*)partials, nc);
             hipLaunchKernelGGL(k_msm_scatter_fine, dim3(p.B >> SORT_FINE_LOG, (unsigned)nc), dim3(FINE_THREADS), 0, st, p, (const u32*)offs,
                                (const u32*)partials, (u32*)entries);
