@@ -43,6 +43,16 @@ struct MsmP {
     unsigned spt;      // scalars per thread of the sort passes: a slice is SORT_THREADS * spt scalars (msm_spt_for)
 };
 
+// Which scatter runs is decided ON THE DEVICE from the launch's number of non-zero digits (summed by the scan kernels): the
+// two-step (coarse + fine, LDS-staged) scatter wins on dense columns -- full-width scalars: 2.6 ms against 6.4 per 256 columns,
+// and the accumulation likes its order -- and loses on sparse ones (witness columns: 5.1 ms against 2.2 per 512), and the host
+// does not know which kind a launch holds.  All three kernels are launched; the ones not chosen leave at once.
+struct ScatterSel {
+    const unsigned long long* total;   // non-zero digits of the launch (all columns)
+    unsigned long long thr;            // dense if *total >= thr
+};
+__device__ __forceinline__ bool scatter_dense(const ScatterSel& s) { return *s.total >= s.thr; }
+
 __device__ __forceinline__ u32 sel8(const u32 s[8], unsigned i) {
     u32 r = s[0];
 #pragma unroll
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_msm_scan(const u32* __restrict
                                                   u32* __restrict__ items, u32* __restrict__ heavy,
                                                   u32* __restrict__ heavy_cnt, u32* __restrict__ fold_order,
                                                   u32* __restrict__ fold_cnt, u32* __restrict__ item_order,
-                                                  u32* __restrict__ item_bucket) {
+                                                  u32* __restrict__ item_bucket, unsigned long long* __restrict__ digits_total) {
     __shared__ u32 s_cnt[SCAN_THREADS], s_itm[SCAN_THREADS];
     __shared__ u32 s_heavy;
     __shared__ u32 s_bin[MSM_HEAVY + 1], s_base[MSM_HEAVY + 1];
@@ -295,6 +305,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_msm_scan(const u32* __restrict
         if (threadIdx.x == SCAN_THREADS - 1) {
             o[p.B] = bc + ic;
             it[p.B] = bm + im;
+            atomicAdd(digits_total, (unsigned long long)(bc + ic));
         }
     }
     if (threadIdx.x == 0) {
@@ -380,7 +391,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_msm_scan(const u32* __restrict
 __global__ __launch_bounds__(COARSE_THREADS) void k_msm_scatter_coarse(const Fr* __restrict__ scalars, size_t col_stride, MsmP p,
                                                                        const u32* __restrict__ slice_hist, unsigned n_slices,
                                                                        const u32* __restrict__ offs, u32* __restrict__ staged,
-                                                                       size_t n_cols) {
+                                                                       size_t n_cols, ScatterSel sel) {
+    if (!scatter_dense(sel)) return;
     __shared__ u32 cb[SORT_COARSE_MAX];      // global cursor of every coarse group (position in the column's staging list)
     __shared__ u32 cnt[SORT_COARSE_MAX];     // entries of this round per group
     __shared__ u32 lbase[SORT_COARSE_MAX];   // first LDS slot of the group in this round
@@ -420,16 +432,21 @@ __global__ __launch_bounds__(COARSE_THREADS) void k_msm_scatter_coarse(const Fr*
     u32* e = staged + col * p.cap;
     const size_t base = (size_t)slice * SORT_THREADS * p.spt;
     const unsigned rounds = SORT_THREADS * p.spt / COARSE_THREADS;
+    // the next round's scalar is requested before this round's stores go out (its latency would otherwise be exposed in every
+    // one of the 4 * spt rounds)
+    Fr nxt = fp_zero<FrTag>();
+    if (base + threadIdx.x < p.n) nxt = fp_load<FrTag>(scalars + col * col_stride + base + threadIdx.x);
     for (unsigned rd = 0; rd < rounds; ++rd) {
         const size_t i = base + (size_t)rd * COARSE_THREADS + threadIdx.x;
         if (base + (size_t)rd * COARSE_THREADS >= p.n) break;   // uniform: the whole round lies beyond the column
+        const Fr cur_scalar = nxt;
         // ---- phase 1: digits of this thread's scalar, rank of each inside its group (LDS counters)
         u32 ev[16], rb[16];
 #pragma unroll
         for (unsigned w = 0; w < 16; ++w) rb[w] = 0xffffffffu;
         if (i < p.n) {
             u32 s[8];
-            const bool neg = scalar_prepare(fp_load<FrTag>(scalars + col * col_stride + i), s);
+            const bool neg = scalar_prepare(cur_scalar, s);
             unsigned carry = 0;
 #pragma unroll
             for (unsigned w = 0; w < 16; ++w) {
@@ -482,6 +499,10 @@ __global__ __launch_bounds__(COARSE_THREADS) void k_msm_scatter_coarse(const Fr*
         }
         __syncthreads();
         // ---- phase 4: out in slot order (coalesced inside every group's run)
+        {
+            const size_t in_ = i + COARSE_THREADS;
+            if (rd + 1 < rounds && in_ < p.n) nxt = fp_load<FrTag>(scalars + col * col_stride + in_);
+        }
         const unsigned total = s_total;
         for (unsigned sl = threadIdx.x; sl < total; sl += COARSE_THREADS) e[gb[sbin[sl]] + sl] = stage[sl];
     }
@@ -493,7 +514,8 @@ __global__ __launch_bounds__(COARSE_THREADS) void k_msm_scatter_coarse(const Fr*
 #define FINE_LDS_ENTRIES 12288u   // 48 KB: three workgroups per CU
 #define FINE_THREADS 512u        // x 8 loads in flight per thread: ~48 KB outstanding per CU
 __global__ __launch_bounds__(FINE_THREADS) void k_msm_scatter_fine(MsmP p, const u32* __restrict__ offs, const u32* __restrict__ staged,
-                                                          u32* __restrict__ entries) {
+                                                          u32* __restrict__ entries, ScatterSel sel) {
+    if (!scatter_dense(sel)) return;
     __shared__ u32 cur[SORT_FINE + 1];
     __shared__ u32 buf[FINE_LDS_ENTRIES];
     const size_t col = blockIdx.y;
@@ -597,7 +619,8 @@ __global__ __launch_bounds__(256) void k_msm_totals_few(u32* __restrict__ slice_
 __global__ __launch_bounds__(256) void k_msm_items_few(MsmP p, const u32* __restrict__ totals, const u32* __restrict__ blk_cnt,
                                                        const u32* __restrict__ blk_itm, const u32* __restrict__ blk_bins,
                                                        u32* __restrict__ offs, u32* __restrict__ items,
-                                                       u32* __restrict__ item_order, u32* __restrict__ item_bucket) {
+                                                       u32* __restrict__ item_order, u32* __restrict__ item_bucket,
+                                                       unsigned long long* __restrict__ digits_total) {
     __shared__ u32 s_pos[FEW_BINS], s_tot[FEW_BINS], s_rank[FEW_BINS];
     __shared__ u32 s_tmp[4], s_wc[4], s_wm[4];
     __shared__ u32 s_big[256];
@@ -669,6 +692,7 @@ __global__ __launch_bounds__(256) void k_msm_items_few(MsmP p, const u32* __rest
         if (b == p.B - 1) {
             o[p.B] = o_b + v;
             it[p.B] = it_b + ch;
+            atomicAdd(digits_total, (unsigned long long)(o_b + v));
         }
     }
     u32* ord = item_order + col * p.max_items;
@@ -708,7 +732,9 @@ __global__ __launch_bounds__(256) void k_msm_items_few(MsmP p, const u32* __rest
 
 __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restrict__ scalars, size_t col_stride, MsmP p,
                                                               const u32* __restrict__ slice_hist, unsigned n_slices,
-                                                              const u32* __restrict__ offs, u32* __restrict__ entries, size_t n_cols) {
+                                                              const u32* __restrict__ offs, u32* __restrict__ entries, size_t n_cols,
+                                                              ScatterSel sel) {
+    if (scatter_dense(sel)) return;   // the two-step kernels take this launch
     __shared__ u32 h[SORT_MAXB];
     size_t col;
     unsigned slice;
@@ -1488,13 +1514,13 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     PZCHK(pz_ws_get(ctx, WS_OFFS, nc * (p.B + 1) * 4, &offs));
     PZCHK(pz_ws_get(ctx, WS_ITEMS, nc * (p.B + 1) * 4, &items));
     PZCHK(pz_ws_get(ctx, WS_ENTRIES, nc * p.cap * 4 + 16, &entries));
-    // PZ_MSM_SCATTER=two selects the two-step scatter (A/B; measured slower end to end, see the kernels' comment)
-    static int scatter_two = -1;
-    if (scatter_two < 0) {
+    // PZ_MSM_SCATTER=one / two force the single-pass / the two-step scatter (A/B); default: chosen on the device per launch
+    static int scatter_mode = -1;   // 0 auto, 1 one, 2 two
+    if (scatter_mode < 0) {
         const char* e = getenv("PZ_MSM_SCATTER");
-        scatter_two = (e && !strcmp(e, "two")) ? 1 : 0;
+        scatter_mode = (e && !strcmp(e, "one")) ? 1 : (e && !strcmp(e, "two")) ? 2 : 0;
     }
-    const bool two_pass = scatter_two && p.c == 16 && (size_t)p.nwin * p.n_table <= ((size_t)1 << 24);
+    const bool two_pass = scatter_mode != 1 && p.c == 16 && (size_t)p.nwin * p.n_table <= ((size_t)1 << 24);   // the staged entry holds a 24-bit table index
     {
         const size_t part_bytes = nc * p.max_items * sizeof(G1X29Raw), stage_bytes = two_pass ? nc * p.cap * 4 + 16 : 0;
         PZCHK(pz_ws_get(ctx, WS_PARTIALS, part_bytes > stage_bytes ? part_bytes : stage_bytes, &partials));
@@ -1507,6 +1533,9 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     hipStream_t st = ctx->stream;
     pz_timer tall(ctx, PZ_T_MSM_ALL);
     dim3 gs(sort_grid(n_slices, nc));
+    void* dsel;
+    PZCHK(pz_ws_get(ctx, WS_SEL, 8, &dsel));
+    HIPCHK(ctx, hipMemsetAsync(dsel, 0, 8, st));
     {
         pz_timer tsort(ctx, PZ_T_MSM_SORT);
         hipLaunchKernelGGL(k_msm_hist, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (u32*)hist, n_slices, nc);
@@ -1515,22 +1544,28 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
             hipLaunchKernelGGL(k_msm_totals_few, dim3(nblk_few, (unsigned)nc), dim3(256), 0, st, (u32*)hist, n_slices, p, (u32*)totals,
                                blk_cnt, blk_itm, blk_bins);
             hipLaunchKernelGGL(k_msm_items_few, dim3(nblk_few, (unsigned)nc), dim3(256), 0, st, p, (const u32*)totals, (const u32*)blk_cnt,
-                               (const u32*)blk_itm, (const u32*)blk_bins, (u32*)offs, (u32*)items, item_order, item_bucket);
+                               (const u32*)blk_itm, (const u32*)blk_bins, (u32*)offs, (u32*)items, item_order, item_bucket,
+                               (unsigned long long*)dsel);
         } else {
             hipLaunchKernelGGL(k_msm_totals, dim3(pz_div_up(p.B, 256), (unsigned)nc), dim3(256), 0, st, (u32*)hist, n_slices, p,
                                (u32*)totals);
             hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)nc), dim3(SCAN_THREADS), 0, st, (const u32*)totals, p, (u32*)offs, (u32*)items,
-                               (u32*)heavy, heavy_cnt, (u32*)fold, fold_cnt, item_order, item_bucket);
+                               (u32*)heavy, heavy_cnt, (u32*)fold, fold_cnt, item_order, item_bucket, (unsigned long long*)dsel);
         }
+        // dense launch (>= 0.4 of the digits non-zero: full-width scalars) -> two-step; sparse (witness columns) -> single pass
+        ScatterSel sel;
+        sel.total = (const unsigned long long*)dsel;
+        sel.thr = !two_pass ? ~0ull : scatter_mode == 2 ? 0ull : (unsigned long long)(0.4 * (double)nc * (double)p.cap);
         if (two_pass) {
             // the staging list lives in the partial sums' buffer: k_msm_accumulate writes those after the list is consumed
             hipLaunchKernelGGL(k_msm_scatter_coarse, gs, dim3(COARSE_THREADS), 0, st, d_scalars, cs, p, (const u32*)hist, n_slices,
-                               (const u32*)offs, (u32*)partials, nc);
+                               (const u32*)offs, (u32*)partials, nc, sel);
             hipLaunchKernelGGL(k_msm_scatter_fine, dim3(p.B >> SORT_FINE_LOG, (unsigned)nc), dim3(FINE_THREADS), 0, st, p, (const u32*)offs,
-                               (const u32*)partials, (u32*)entries);
-        } else
+                               (const u32*)partials, (u32*)entries, sel);
+        }
+        if (scatter_mode != 2 || !two_pass)
             hipLaunchKernelGGL(k_msm_scatter, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (const u32*)hist, n_slices,
-                               (const u32*)offs, (u32*)entries, nc);
+                               (const u32*)offs, (u32*)entries, nc, sel);
     }
     {
         pz_timer tacc(ctx, PZ_T_MSM_ACC);

@@ -1217,7 +1217,7 @@ print("arms-ok")
 """
 
 
-@pytest.mark.parametrize("env", [{"PZ_MSM_SCATTER": "two"}, {"PZ_MSM_TREE": "lane"}, {"PZ_MSM_TREE": "quad"}, {"PZ_MSM_REDUCE": "wave"}])
+@pytest.mark.parametrize("env", [{"PZ_MSM_SCATTER": "two"}, {"PZ_MSM_SCATTER": "one"}, {"PZ_MSM_TREE": "lane"}, {"PZ_MSM_TREE": "quad"}, {"PZ_MSM_REDUCE": "wave"}])
 def test_msm_ab_arms(env):
     """the A/B arms of K1 that an environment switch selects (read once per process): two-step scatter, lane / quad tree kernels,
     wave-parallel level 1 -- same results as the defaults (walk bases: expected values from scalar arithmetic)"""
