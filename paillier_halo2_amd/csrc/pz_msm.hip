@@ -1520,7 +1520,10 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
         const char* e = getenv("PZ_MSM_SCATTER");
         scatter_mode = (e && !strcmp(e, "one")) ? 1 : (e && !strcmp(e, "two")) ? 2 : 0;
     }
-    const bool two_pass = scatter_mode != 1 && p.c == 16 && (size_t)p.nwin * p.n_table <= ((size_t)1 << 24);   // the staged entry holds a 24-bit table index
+    // the staged entry holds a 24-bit table index; a few columns have too few slices for the 256-thread coarse step (a rank's
+    // 2^19-point share of c4: 110 + 41 us against 111 for the single pass) unless forced
+    const bool two_pass = scatter_mode != 1 && p.c == 16 && (size_t)p.nwin * p.n_table <= ((size_t)1 << 24) &&
+                          (nc > MSM_SLICE_MAX_COLS || scatter_mode == 2);
     {
         const size_t part_bytes = nc * p.max_items * sizeof(G1X29Raw), stage_bytes = two_pass ? nc * p.cap * 4 + 16 : 0;
         PZCHK(pz_ws_get(ctx, WS_PARTIALS, part_bytes > stage_bytes ? part_bytes : stage_bytes, &partials));
