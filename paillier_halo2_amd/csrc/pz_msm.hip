@@ -365,19 +365,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_msm_scan(const u32* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// pass 3 in two steps -- an A/B variant (PZ_MSM_SCATTER=two), NOT the default.  k_msm_scatter keeps 2^15 write frontiers per
-// workgroup open (one per bucket): 2 MB per workgroup, 64 MB per XCD against a 4 MB L2, so nearly every 4-byte entry leaves
-// the L2 as its own partial line -- 12.7 GB written per 256-column launch for 2.1 GB of entries
-// (profiles/r02_pmc_fetch_write_bench.txt).  An MSD split keeps the frontiers inside the L2:
-//   k_msm_scatter_coarse : the slice's digits go to the region of their COARSE bucket group (bucket >> 7: 256 frontiers per
-//                          workgroup) of a staging list, as (bucket & 127) << 25 | sign << 24 | table index
+// pass 3 in two steps: the scatter of DENSE column batches (ScatterSel above; PZ_MSM_SCATTER=one / two force a variant).
+// k_msm_scatter keeps 2^15 write frontiers per workgroup open (one per bucket): 2 MB per workgroup, 64 MB per XCD against a
+// 4 MB L2, so nearly every 4-byte entry leaves the L2 as its own partial line -- 12.7 GB written per 256-column launch for
+// 2.1 GB of entries (profiles/r02_pmc_fetch_write_bench.txt) -- and, the harder floor, 537 M scattered stores cost ~2 ms of
+// L2 request rate whatever their bytes.  An MSD split with BOTH steps sorted inside LDS writes runs instead of single entries:
+//   k_msm_scatter_coarse : the slice's digits go to the region of their COARSE bucket group (bucket >> 7) of a staging list,
+//                          as (bucket & 127) << 25 | sign << 24 | table index
 //   k_msm_scatter_fine   : a workgroup per (coarse group, column) sorts the group's entries (32 KB at the production shape)
 //                          inside LDS, cursors for the 128 buckets in LDS, and writes whole lines
 // Same sorted entry list up to the order inside a bucket, which no consumer depends on.
-// Measured (profiles/r03_ab_scatter_two_pass.txt, 256 + 512 columns of 2^17 per launch pair): coarse 2.03 ms + fine 2.02 ms
-// against 4.31 ms for the single pass -- the coarse step's 537 M scattered 4-byte stores are bound by the L2's request rate
-// (~2 ms), not by bytes, and staging it through LDS as well would need sub-slice rounds -- while k_msm_accumulate runs 1.7 %
-// (0.4 ms) slower on the list this order produces.  Net loss, so the single pass stays the default.
+// Measured per launch (profiles/r03_ab_scatter_two_pass.txt): 256 full-width columns of 2^17: 1.76 + 0.75 ms against 6.43 for the
+// single pass (and k_msm_accumulate 0.45 ms faster on this order); 512 witness-like columns: 1.72 + 3.38 against 2.20 -- the
+// coarse step costs its rounds whatever the density and the fine step's workgroups find a tenth of the entries.  Hence the
+// choice per launch, on the device.
 // ------------------------------------------------------------------------------------------------
 #define SORT_FINE_LOG 7u
 #define SORT_FINE (1u << SORT_FINE_LOG)
