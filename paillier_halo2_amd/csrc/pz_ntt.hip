@@ -134,8 +134,11 @@ __device__ __forceinline__ void bf29(const Fr29& u, const Fr29& v, Fr29& sum, Fr
 // four products as two radix-2 layers) and the tile crosses LDS and a barrier once per pair of stages instead of
 // once per stage.  Stages 0+1 cost one product per group (their other twiddles are 1).  An odd logR ends with one
 // plain radix-2 stage.  element (j, t) lives at tile index j*sr + t*st.  Input must be stored bit-reversed in j.
+// stw != nullptr: the stage twiddles come from a per-transform table instead of the omega table -- entry (2^s - 1) + pos of
+// stage s holds K_s * omega^(pos * n / 2^(s+1)) with a constant K_s per stage (the coset shift of the extended transform's first
+// pass absorbed into the stages, see get_ext_abs_tables): every stage then has real twiddles, stages 0 + 1 included.
 __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, unsigned sr, unsigned st, bool t_fastest,
-                                          const u32* __restrict__ tw, size_t n_) {
+                                          const u32* __restrict__ tw, size_t n_, const u32* __restrict__ stw = nullptr) {
     const unsigned n = (unsigned)n_;   // n <= 2^27: twiddle indices fit 32 bits
     const unsigned R = 1u << logR;
     const unsigned logT = 31u - (unsigned)__builtin_clz(T);
@@ -157,19 +160,19 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
             const unsigned e0 = base * sr + t * st, dh = h * sr;
             Fr29 a0 = lds29_get(sm, e0), a1 = lds29_get(sm, e0 + dh), a2 = lds29_get(sm, e0 + 2 * dh), a3 = lds29_get(sm, e0 + 3 * dh);
             Fr29 b0, b1, b2, b3, o0, o1, o2, o3;
-            if (s) {  // kernel-uniform branch
+            if (s || stw) {  // kernel-uniform branch
                 // tile elements arrive with limbs < 2^31.3 (uncarried outputs of the previous pair of stages): legal as
                 // they are for the operands that get multiplied (a1, a3); the two that are only added (a0, a2) take one
                 // parallel carry round each
                 a0 = f29_carry(a0);
                 a2 = f29_carry(a2);
-                const Fr29 w = raw9_get(tw, pos * (n >> (s + 1)));
+                const Fr29 w = stw ? raw9_get(stw, (h - 1u) + pos) : raw9_get(tw, pos * (n >> (s + 1)));
                 a1 = f29_mul(a1, w);
                 a3 = f29_mul(a3, w);
                 bf29(a0, a1, b0, b1);
                 bf29(a2, a3, b2, b3);
-                b2 = f29_mul(b2, raw9_get(tw, pos * (n >> (s + 2))));
-                b3 = f29_mul(b3, raw9_get(tw, (pos + h) * (n >> (s + 2))));
+                b2 = f29_mul(b2, stw ? raw9_get(stw, (2u * h - 1u) + pos) : raw9_get(tw, pos * (n >> (s + 2))));
+                b3 = f29_mul(b3, stw ? raw9_get(stw, (2u * h - 1u) + pos + h) : raw9_get(tw, (pos + h) * (n >> (s + 2))));
                 bf29(b0, b2, o0, o2);
             } else {
                 // stages 0 + 1: operands straight from the load (tight, value < 2p); the first layer's twiddles and the
@@ -209,9 +212,9 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
             Fr29 u = lds29_get(sm, e0);
             Fr29 v = lds29_get(sm, e1);
             Fr29 o0, o1;
-            if (s) {
+            if (s || stw) {
                 u = f29_carry(u);
-                v = f29_mul(v, raw9_get(tw, pos * (n >> (s + 1))));
+                v = f29_mul(v, stw ? raw9_get(stw, (half - 1u) + pos) : raw9_get(tw, pos * (n >> (s + 1))));
                 bf29(u, v, o0, o1);
             } else {  // a single stage (logR == 1): operands straight from the load (tight, < 2p)
                 o0 = f29_add(u, v);
@@ -225,11 +228,14 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
 }
 
 // strided pass.  grid.x = hi * (lo / T), grid.y = column.  tw, pre: 261-domain tables
-template <bool PRE>
+// PRE: 0 none; 1 every loaded element times a pre-scale table entry; 2 the coset shift ABSORBED (extended transform's first
+// pass): no product at the load, stage twiddles from stw0 (per coset, (1 << logR) entries apart), and pre0 holds the fused
+// inter-pass table c^col * omega^(col * k) indexed [k * lo + col] instead of the pre-scale table
+template <int PRE>
 __global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, size_t in_stride, size_t out_stride,
                                                        NttPass p, const u32* __restrict__ tw,
                                                        const u32* __restrict__ pre0, unsigned n_r, size_t pre_r_stride,
-                                                       size_t out_r_stride) {
+                                                       size_t out_r_stride, const u32* __restrict__ stw0) {
     u32* sm = reinterpret_cast<u32*>(pz_smem);
     const unsigned R = 1u << p.logR, T = p.T;
     const unsigned logT = 31u - (unsigned)__builtin_clz(T);
@@ -259,26 +265,27 @@ __global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, si
             const unsigned idx = (i0 + k * 256u + threadIdx.x) & (nelem - 1);   // lanes past the tile re-read one of its elements: no branch around the loads
             const size_t g = base + (size_t)(idx >> logT) * p.lo + (idx & (T - 1));
             raw[k] = fp_load<FrTag>(src + g);
-            if (PRE) praw[k] = raw9_load(pre, g);
+            if (PRE == 1) praw[k] = raw9_load(pre, g);
         }
 #pragma unroll
         for (unsigned k = 0; k < NTT_LB; ++k) {
             const unsigned idx = i0 + k * 256u + threadIdx.x;
             if (idx < nelem) {
                 Fr29 x = f29_from_fp(raw[k]);
-                if (PRE) x = f29_mul(x, raw9_fr(praw[k]));
+                if (PRE == 1) x = f29_mul(x, raw9_fr(praw[k]));
                 lds29_put(sm, bitrev32(idx >> logT, p.logR) * T + (idx & (T - 1)), x);
             }
         }
     }
     __syncthreads();
-    lds_dit29(sm, p.logR, T, T, 1, true, tw, p.n);
+    lds_dit29(sm, p.logR, T, T, 1, true, tw, p.n, PRE == 2 ? stw0 + (size_t)rr * R * 9u : nullptr);
     for (unsigned i0 = 0; i0 < nelem; i0 += NTT_LB * 256u) {
         Raw9 traw[NTT_LB];
 #pragma unroll
         for (unsigned k = 0; k < NTT_LB; ++k) {
             const unsigned idx = (i0 + k * 256u + threadIdx.x) & (nelem - 1);
-            traw[k] = raw9_load(tw, p.tw_mul * (lt * T + (idx & (T - 1))) * (idx >> logT));  // exponent < n by construction
+            if (PRE == 2) traw[k] = raw9_load(pre, (size_t)(idx >> logT) * p.lo + (lt * T + (idx & (T - 1))));
+            else traw[k] = raw9_load(tw, p.tw_mul * (lt * T + (idx & (T - 1))) * (idx >> logT));  // exponent < n by construction
         }
 #pragma unroll
         for (unsigned k = 0; k < NTT_LB; ++k) {
@@ -451,13 +458,15 @@ static const uint64_t* one261() {
 const uint64_t* pz_fr_one261() { return one261(); }   // for the other translation units' 261-domain power tables
 
 static int launch_strided(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t os, size_t ncols, NttPass p,
-                          const u32* tw, const u32* pre, unsigned n_r = 1, size_t pre_r_stride = 0, size_t out_r_stride = 0) {
+                          const u32* tw, const u32* pre, unsigned n_r = 1, size_t pre_r_stride = 0, size_t out_r_stride = 0,
+                          const u32* stw = nullptr) {
     size_t blocks = p.hi * (p.lo / p.T);
     size_t lds = ntt29_lds_bytes(((size_t)1 << p.logR) * p.T);
     p.swap = (ncols > 1 && blocks <= 65535) ? 1u : 0u;
     const dim3 grid = p.swap ? dim3((unsigned)ncols, (unsigned)blocks) : dim3((unsigned)blocks, (unsigned)ncols);
-    if (pre) hipLaunchKernelGGL(k_ntt_strided29<true>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, n_r, pre_r_stride, out_r_stride);
-    else hipLaunchKernelGGL(k_ntt_strided29<false>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, n_r, pre_r_stride, out_r_stride);
+    if (stw) hipLaunchKernelGGL(k_ntt_strided29<2>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, n_r, pre_r_stride, out_r_stride, stw);
+    else if (pre) hipLaunchKernelGGL(k_ntt_strided29<1>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, n_r, pre_r_stride, out_r_stride, stw);
+    else hipLaunchKernelGGL(k_ntt_strided29<0>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, n_r, pre_r_stride, out_r_stride, stw);
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
 }
@@ -587,6 +596,66 @@ static int get_ext_pre_tables(pz_ctx* ctx, const uint64_t* coset_gens, size_t E,
 // coeff_to_extended in one call: d_ext[col][2^e * q + r] = sum_i d_coeff[col][i] * scale * (gens[r])^i * omega_n^(i q)
 // with gens[r] = g * omega_ext^r supplied by the caller (2^log_e x 4 limbs, host), omega_n = omega_ext^(2^log_e).
 // Saves the zero-fill, the copy and two butterfly layers of the generic zero-extended transform.
+// ---- the coset shift of the extended transform ABSORBED into its first pass (no pre-scale product).
+// The 4-step first pass is, for every column col < lo, the R-point DFT over j1 of a[j1 * lo + col] * c^(j1 * lo + col).  The factor
+// c^col is constant inside the DFT: it moves into the inter-pass twiddle, E[k * lo + col] = c^col * omega^(col * k) (* scale).
+// The factor (c^lo)^j1 turns the DFT into an evaluation on the coset c^lo * <omega_R>, and a radix-2 DIT does that with every
+// stage's twiddles times a constant: stage s (blocks of 2^s joined into 2^(s+1)) uses K_s * omega^(pos * n / 2^(s+1)),
+// K_s = c^(n / 2^(s+1)).  Stages 0 + 1 lose their trivial twiddles (0.75 products per element more), the pre-scale goes
+// (1 product per element less).  Both tables in the 261-domain as raw limbs; S[(2^s - 1) + pos], R entries apart per coset.
+__global__ void k_ext_epilogue_table(const Fr* __restrict__ cpow, const u32* __restrict__ tw, size_t lo, size_t n, u32* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t k = i / lo, col = i % lo;
+    const Fr29 x = f29_mul(f29_load<FrTag>(cpow + col), raw9_get(tw, col * k));   // col * k < lo * R = n
+    f29_store_raw(out + i * 9, x);
+}
+__global__ void k_ext_stage_table(Fr c, const u32* __restrict__ tw, size_t n, unsigned logR, u32* __restrict__ out) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x, R = 1u << logR;
+    if (t + 1 >= R) return;
+    const unsigned s = 31u - (unsigned)__builtin_clz(t + 1), pos = t + 1 - (1u << s);
+    // K_s = c^(n >> (s + 1)): a power of two, by squarings in the 261-domain
+    Fr29 K = f29_to_261(f29_from_fp(c));
+    for (size_t e = n >> (s + 1); e > 1; e >>= 1) K = f29_sqr(K);
+    const Fr29 x = f29_mul(K, raw9_get(tw, (size_t)pos * (n >> (s + 1))));
+    f29_store_raw(out + (size_t)t * 9, x);
+}
+// out_ep: [E][n][9], out_stw: [E][R][9]
+static int get_ext_abs_tables(pz_ctx* ctx, const uint64_t* coset_gens, size_t E, uint32_t log_n, unsigned logR, const uint64_t* scale,
+                              const u32* tw, const u32** out_ep, const u32** out_stw) {
+    const size_t n = (size_t)1 << log_n, R = (size_t)1 << logR, lo = n >> logR;
+    std::vector<uint64_t> key(coset_gens, coset_gens + 4 * E);
+    key.push_back(log_n);
+    key.push_back(0xab50000ull + logR);   // distinguishes these tables from the pre-scale ones of the same cosets
+    if (scale) key.insert(key.end(), scale, scale + 4);
+    for (auto& c : ctx->ext_tables)
+        if (c.key == key) {
+            *out_ep = (const u32*)c.d;
+            *out_stw = (const u32*)c.d + E * n * 9;
+            return PZ_OK;
+        }
+    uint64_t init[4];
+    if (scale) fr_times32(scale, init);
+    else memcpy(init, one261(), 32);
+    void* d = nullptr;
+    HIPCHK(ctx, hipMalloc(&d, (E * n + E * R) * 36));
+    u32* ep = (u32*)d;
+    u32* stw = ep + E * n * 9;
+    for (size_t r = 0; r < E; ++r) {
+        void* cp;
+        PZCHK(pz_get_pow_table(ctx, coset_gens + 4 * r, lo, &cp, init));   // c^col * scale, 261-domain
+        hipLaunchKernelGGL(k_ext_epilogue_table, dim3(pz_div_up(n, 256)), dim3(256), 0, ctx->stream, (const Fr*)cp, tw, lo, n, ep + r * n * 9);
+        Fr c;
+        memcpy(c.v, coset_gens + 4 * r, 32);
+        hipLaunchKernelGGL(k_ext_stage_table, dim3(pz_div_up(R, 256)), dim3(256), 0, ctx->stream, c, tw, n, logR, stw + r * R * 9);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    ctx->ext_tables.push_back(pz_ext_table{key, d});
+    *out_ep = ep;
+    *out_stw = stw;
+    return PZ_OK;
+}
+
 extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t n_cols, size_t in_stride, uint64_t* d_ext,
                                     size_t out_stride, uint32_t log_n, uint32_t log_e, const uint64_t omega_n[4],
                                     const uint64_t* coset_gens, const uint64_t* scale) {
@@ -600,9 +669,23 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
     void* twv = nullptr;
     PZCHK(pz_get_pow_table_raw(ctx, omega_n, n, &twv, one261()));
     const u32* tw = (const u32*)twv;
-    void* prev = nullptr;
-    PZCHK(get_ext_pre_tables(ctx, coset_gens, E, log_n, scale, &prev));
-    const u32* pre = (const u32*)prev;
+    const unsigned npass_ = log_n <= 9 ? 1 : (log_n <= 18 ? 2 : 3);
+    // PZ_NTT_COSET=pre keeps the pre-scale product of the first pass (A/B); default: the coset shift absorbed into its twiddles
+    static int coset_pre = -1;
+    if (coset_pre < 0) {
+        const char* e = getenv("PZ_NTT_COSET");
+        coset_pre = (e && !strcmp(e, "pre")) ? 1 : 0;
+    }
+    const bool absorbed = npass_ > 1 && !coset_pre;
+    const unsigned logR_a = npass_ == 2 ? (log_n + 1) / 2 : (log_n + 2) / 3;   // size of the first pass (lg0 / lg[0] below)
+    const u32 *pre = nullptr, *stw = nullptr;
+    if (absorbed) {
+        PZCHK(get_ext_abs_tables(ctx, coset_gens, E, log_n, logR_a, scale, tw, &pre, &stw));
+    } else {
+        void* prev = nullptr;
+        PZCHK(get_ext_pre_tables(ctx, coset_gens, E, log_n, scale, &prev));
+        pre = (const u32*)prev;
+    }
     const Fr* cin = (const Fr*)d_coeff;
     Fr* eout = (Fr*)d_ext;
     const unsigned npass = log_n <= 9 ? 1 : (log_n <= 18 ? 2 : 3);
@@ -639,7 +722,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
             NttPass pb{};
             pb.logR = lg[1]; pb.lo = n3; pb.hi = n1; pb.tw_mul = n1; pb.n = n; pb.T = pick_tile(n3, lg[1]);
             // tmp layout [r][col][n]: all cosets of the first pass in one launch, then the E * nc intermediate columns together
-            PZCHK(launch_strided(ctx, cin + c0 * is, tmp, is, n, nc, pa, tw, pre, (unsigned)E, n, nc * n));
+            PZCHK(launch_strided(ctx, cin + c0 * is, tmp, is, n, nc, pa, tw, pre, (unsigned)E, n, nc * n, stw));
             PZCHK(launch_strided(ctx, tmp, tmp, n, n, E * nc, pb, tw, nullptr));
             NttPass pc{};
             pc.logR = lg[2]; pc.lo = 1; pc.hi = n1 * n2; pc.n = n; pc.n1 = n1; pc.n2 = n2;
@@ -656,7 +739,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
             NttPass pa{};
             pa.logR = lg0; pa.lo = n2; pa.hi = 1; pa.tw_mul = 1; pa.n = n; pa.T = pick_tile(n2, lg0);
             // all cosets in one launch: tmp layout [r][col][n]
-            PZCHK(launch_strided(ctx, cin + c0 * is, tmp, is, n, nc, pa, tw, pre, (unsigned)E, n, nc * n));
+            PZCHK(launch_strided(ctx, cin + c0 * is, tmp, is, n, nc, pa, tw, pre, (unsigned)E, n, nc * n, stw));
             NttPass pc{};
             pc.logR = lg1; pc.lo = 1; pc.hi = n1; pc.n = n; pc.n1 = n1; pc.n2 = 1;
             // 32 KiB of LDS per block (4 blocks per CU): with 2^e = 4 interleaved outputs a single row already

@@ -1337,3 +1337,51 @@ def test_f29_building_blocks_at_their_operand_bounds(eng, field):
     got = probe.f29_ops(eng.device, field, "store_product", np.array(rows, dtype=np.uint32))
     for v, g in zip(vals, got):
         assert sum(int(w) << (32 * j) for j, w in enumerate(g[:8])) == v % p
+
+
+_NTT_ARM_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, sys.argv[1] + "/tests")
+import torch
+import paillier_halo2_amd as pz
+from oracle import cref, pyref as P
+cref.build()
+eng = pz.Engine(0)
+eng.bind_torch_stream()
+for log_n, log_e in ((10, 2), (13, 1), (17, 2)):
+    rng = np.random.default_rng(31 + log_n)
+    n, E, ncols = 1 << log_n, 1 << log_e, 2
+    coeff = rng.integers(0, 1 << 62, size=(ncols, n, 4), dtype=np.uint64)
+    coeff[:, :, 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
+    w_ext = P.fr_omega(log_n + log_e)
+    w_n = pow(w_ext, E, P.FR_R)
+    g = 7
+    gens = np.stack([cref.fr_ints_to_mont([g * pow(w_ext, r, P.FR_R) % P.FR_R])[0] for r in range(E)])
+    d_c = torch.from_numpy(coeff.astype(np.int64)).cuda()
+    d_e = torch.zeros((ncols, n * E, 4), dtype=torch.int64, device="cuda")
+    eng.ntt_extend_dev(d_c.data_ptr(), ncols, 4 * n, d_e.data_ptr(), 4 * n * E, log_n, log_e, cref.fr_ints_to_mont([w_n])[0], gens, None)
+    eng.sync()
+    got = d_e.cpu().numpy().astype(np.uint64)
+    for j in range(ncols):
+        ext = np.zeros((n * E, 4), dtype=np.uint64)
+        ext[:n] = coeff[j]
+        want = cref.ntt_fr(cref.fr_distribute_powers(ext, cref.fr_ints_to_mont([g])[0]), cref.fr_ints_to_mont([w_ext])[0], log_n + log_e)
+        assert np.array_equal(got[j], want), (log_n, log_e, j)
+print("ntt-arm-ok")
+"""
+
+
+def test_ntt_ab_arm_pre_scale():
+    """PZ_NTT_COSET=pre: the extended transform's first pass with its pre-scale product (the arm the default -- coset shift absorbed
+    into the stage twiddles -- is A/B'd against), same results as the oracle, with and without a scale"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e["PZ_NTT_COSET"] = "pre"
+    r = subprocess.run([sys.executable, "-c", _NTT_ARM_SCRIPT, root], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ntt-arm-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
