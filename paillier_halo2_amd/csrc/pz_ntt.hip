@@ -235,7 +235,8 @@ template <int PRE>
 __global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, size_t in_stride, size_t out_stride,
                                                        NttPass p, const u32* __restrict__ tw,
                                                        const u32* __restrict__ pre0, unsigned n_r, size_t pre_r_stride,
-                                                       size_t out_r_stride, const u32* __restrict__ stw0) {
+                                                       size_t out_r_stride, const u32* __restrict__ stw0,
+                                                       const u32* __restrict__ tw_ep) {   // tw_ep: the omega table of the inter-pass product (may carry a scale)
     u32* sm = reinterpret_cast<u32*>(pz_smem);
     const unsigned R = 1u << p.logR, T = p.T;
     const unsigned logT = 31u - (unsigned)__builtin_clz(T);
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, si
         for (unsigned k = 0; k < NTT_LB; ++k) {
             const unsigned idx = (i0 + k * 256u + threadIdx.x) & (nelem - 1);
             if (PRE == 2) traw[k] = raw9_load(pre, (size_t)(idx >> logT) * p.lo + (lt * T + (idx & (T - 1))));
-            else traw[k] = raw9_load(tw, p.tw_mul * (lt * T + (idx & (T - 1))) * (idx >> logT));  // exponent < n by construction
+            else traw[k] = raw9_load(tw_ep, p.tw_mul * (lt * T + (idx & (T - 1))) * (idx >> logT));  // exponent < n by construction
         }
 #pragma unroll
         for (unsigned k = 0; k < NTT_LB; ++k) {
@@ -459,14 +460,15 @@ const uint64_t* pz_fr_one261() { return one261(); }   // for the other translati
 
 static int launch_strided(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t os, size_t ncols, NttPass p,
                           const u32* tw, const u32* pre, unsigned n_r = 1, size_t pre_r_stride = 0, size_t out_r_stride = 0,
-                          const u32* stw = nullptr) {
+                          const u32* stw = nullptr, const u32* tw_ep = nullptr) {
+    if (!tw_ep) tw_ep = tw;
     size_t blocks = p.hi * (p.lo / p.T);
     size_t lds = ntt29_lds_bytes(((size_t)1 << p.logR) * p.T);
     p.swap = (ncols > 1 && blocks <= 65535) ? 1u : 0u;
     const dim3 grid = p.swap ? dim3((unsigned)ncols, (unsigned)blocks) : dim3((unsigned)blocks, (unsigned)ncols);
-    if (stw) hipLaunchKernelGGL(k_ntt_strided29<2>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, n_r, pre_r_stride, out_r_stride, stw);
-    else if (pre) hipLaunchKernelGGL(k_ntt_strided29<1>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, n_r, pre_r_stride, out_r_stride, stw);
-    else hipLaunchKernelGGL(k_ntt_strided29<0>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, n_r, pre_r_stride, out_r_stride, stw);
+    if (stw) hipLaunchKernelGGL(k_ntt_strided29<2>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, n_r, pre_r_stride, out_r_stride, stw, tw_ep);
+    else if (pre) hipLaunchKernelGGL(k_ntt_strided29<1>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, n_r, pre_r_stride, out_r_stride, stw, tw_ep);
+    else hipLaunchKernelGGL(k_ntt_strided29<0>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, n_r, pre_r_stride, out_r_stride, stw, tw_ep);
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
 }
@@ -513,6 +515,17 @@ extern "C" int pz_ntt_fr_to_dev(pz_ctx* ctx, const uint64_t* d_in, size_t in_str
     const u32* pre = (const u32*)prev;
 
     const unsigned npass = log_n <= 9 ? 1 : (log_n <= 18 ? 2 : 3);
+    // a post-scale (the 1/n of an inverse transform) rides on the first pass's inter-pass product -- its omega table taken with
+    // the scale as first entry -- instead of costing the last pass a product per element
+    const u32* tw_ep = nullptr;
+    if (post_scale && npass > 1) {
+        uint64_t init[4];
+        fr_times32(post_scale, init);
+        void* t;
+        PZCHK(pz_get_pow_table_raw(ctx, omega, n, &t, init));
+        tw_ep = (const u32*)t;
+        post_scale = nullptr;
+    }
     unsigned lg[3] = {0, 0, 0};
     {
         unsigned rem = log_n;
@@ -545,7 +558,7 @@ extern "C" int pz_ntt_fr_to_dev(pz_ctx* ctx, const uint64_t* d_in, size_t in_str
             size_t n1 = (size_t)1 << lg[0], n2 = (size_t)1 << lg[1];
             NttPass pa{};
             pa.logR = lg[0]; pa.lo = n2; pa.hi = 1; pa.tw_mul = 1; pa.n = n; pa.T = pick_tile(n2, lg[0]);
-            PZCHK(launch_strided(ctx, ic, tmp, is_, n, nc, pa, tw, pre));
+            PZCHK(launch_strided(ctx, ic, tmp, is_, n, nc, pa, tw, pre, 1, 0, 0, nullptr, tw_ep));
             // tmp columns are packed with stride n
             NttPass pc{};
             pc.logR = lg[1]; pc.lo = 1; pc.hi = n1; pc.n = n; pc.n1 = n1; pc.n2 = 1; pc.T = pick_tile(n1, lg[1]);
@@ -554,7 +567,7 @@ extern "C" int pz_ntt_fr_to_dev(pz_ctx* ctx, const uint64_t* d_in, size_t in_str
             size_t n1 = (size_t)1 << lg[0], n2 = (size_t)1 << lg[1], n3 = (size_t)1 << lg[2];
             NttPass pa{};
             pa.logR = lg[0]; pa.lo = n2 * n3; pa.hi = 1; pa.tw_mul = 1; pa.n = n; pa.T = pick_tile(n2 * n3, lg[0]);
-            PZCHK(launch_strided(ctx, ic, tmp, is_, n, nc, pa, tw, pre));
+            PZCHK(launch_strided(ctx, ic, tmp, is_, n, nc, pa, tw, pre, 1, 0, 0, nullptr, tw_ep));
             NttPass pb{};
             pb.logR = lg[1]; pb.lo = n3; pb.hi = n1; pb.tw_mul = n1; pb.n = n; pb.T = pick_tile(n3, lg[1]);
             PZCHK(launch_strided(ctx, tmp, tmp, n, n, nc, pb, tw, nullptr));
