@@ -338,9 +338,10 @@ class ProofWorkload:
                 nc = min(nb, ncols - c0, p_hi - p_lo - done)
                 work = pool_n[:nc]
                 # lagrange_to_coeff out of place: the Lagrange values stay where the commitment stream reads them
-                eng.ntt_to_dev(cols[c0].data_ptr(), 4 * n, work.data_ptr(), 4 * n, nc, self.omega_inv, k, None, None)
+                # (with its 1/n, as halo2's ifft has it: the coefficients are the real ones; the scale rides on an inter-pass product)
+                eng.ntt_to_dev(cols[c0].data_ptr(), 4 * n, work.data_ptr(), 4 * n, nc, self.omega_inv, k, None, self.n_inv)
                 eng.ntt_extend_dev(work.data_ptr(), nc, 4 * n, self.d_ext.data_ptr(), 4 * self.ext_n, k, sh.ext_k - k,
-                                   self.omega_n, self.coset_gens, self.n_inv)
+                                   self.omega_n, self.coset_gens, None)
                 c0 += nc
                 done += nc
         if own and self.stream_n is not None and self.pipeline:
@@ -361,9 +362,9 @@ class ProofWorkload:
                 eng.ntt_coeff_extend_dev(src.data_ptr(), nc, 4 * n, self.d_ext.data_ptr(), 4 * self.ext_n, k, sh.ext_k - k,
                                          self.omega_n, self.omega_inv, self.n_inv, self.coset_gens)
             else:
-                eng.ntt_dev(src.data_ptr(), nc, 4 * n, self.omega_inv, k, None, None)
+                eng.ntt_dev(src.data_ptr(), nc, 4 * n, self.omega_inv, k, None, self.n_inv)
                 eng.ntt_extend_dev(src.data_ptr(), nc, 4 * n, self.d_ext.data_ptr(), 4 * self.ext_n, k, sh.ext_k - k,
-                                   self.omega_n, self.coset_gens, self.n_inv)
+                                   self.omega_n, self.coset_gens, None)
             done += nc
 
     # ---- keygen (bench.rs:174-175 prints vk / pk time): commitments, coefficient and extended-coset forms of the fixed columns

@@ -152,9 +152,9 @@ int main(int argc, char** argv) {
                 size_t nc = own_cols[b] - c0 < J.ntt_batch ? own_cols[b] - c0 : J.ntt_batch;
                 if (nc > J.polys - done) nc = J.polys - done;
                 CK(pz_ntt_fr_to_dev(ctxn, (const uint64_t*)own[b] + c0 * n * 4, 4 * n, (uint64_t*)d_pool_n, 4 * n, nc, J.omega_inv, (uint32_t)J.k,
-                                    nullptr, nullptr));
+                                    nullptr, J.n_inv));   // lagrange_to_coeff: the 1/n belongs to the inverse transform (and costs nothing there)
                 CK(pz_ntt_fr_extend_dev(ctxn, (const uint64_t*)d_pool_n, nc, 4 * n, (uint64_t*)d_ext, 4 * n * E, (uint32_t)J.k, (uint32_t)J.log_e,
-                                        J.omega, J.gens.data(), J.n_inv));
+                                        J.omega, J.gens.data(), nullptr));
                 c0 += nc;
                 done += nc;
             }
@@ -163,9 +163,9 @@ int main(int argc, char** argv) {
             size_t off = done % J.pool;
             if (off + nc > J.pool) off = 0;
             uint64_t* src = (uint64_t*)d_pool_n + off * n * 4;
-            CK(pz_ntt_fr_dev(ctxn, src, nc, 4 * n, J.omega_inv, (uint32_t)J.k, nullptr, nullptr));
+            CK(pz_ntt_fr_dev(ctxn, src, nc, 4 * n, J.omega_inv, (uint32_t)J.k, nullptr, J.n_inv));
             CK(pz_ntt_fr_extend_dev(ctxn, src, nc, 4 * n, (uint64_t*)d_ext, 4 * n * E, (uint32_t)J.k, (uint32_t)J.log_e, J.omega, J.gens.data(),
-                                    J.n_inv));
+                                    nullptr));
             done += nc;
         }
     };
