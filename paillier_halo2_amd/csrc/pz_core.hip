@@ -190,8 +190,10 @@ extern "C" int pz_ctx_wait(pz_ctx* waiter, pz_ctx* producer) {
     if (!waiter || !producer) return PZ_ERR_INVALID;
     if (waiter == producer) return PZ_OK;
     if (waiter->device != producer->device) return PZ_ERR_UNSUPPORTED;
-    std::lock_guard<std::recursive_mutex> l1(producer->mu);
-    PZ_ENTER(waiter);
+    // both contexts' mutexes, taken by std::scoped_lock's deadlock-avoiding algorithm: one thread per context issuing
+    // pz_ctx_wait(a, b) and pz_ctx_wait(b, a) at the same time must not take them in opposite orders
+    std::scoped_lock<std::recursive_mutex, std::recursive_mutex> both(waiter->mu, producer->mu);
+    HIPCHK(waiter, hipSetDevice(waiter->device));
     hipEvent_t ev;
     HIPCHK(waiter, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     hipError_t e = hipEventRecord(ev, producer->stream);

@@ -336,9 +336,9 @@ __global__ __launch_bounds__(256) void k_ntt_final29(const Fr* in, Fr* out, size
             }
         }
     }
-    __syncthreads();
     u32* qtab = sm + ntt29_lds_words(nelem);   // behind the tile: q * p rows of the quotient-estimate canonicalisation
-    if (!has_post) f29_qtab_fill<FrTag>(qtab);   // (filled before the stages' last barrier: visible to the stores below)
+    if (!has_post) f29_qtab_fill<FrTag>(qtab);   // before the barrier that publishes the tile: lds_dit29 has none when logR == 0
+    __syncthreads();
     lds_dit29(sm, p.logR, T, 1, R, false, tw, p.n);
     const Fr29 post29 = f29_from_fp(post);
     for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
@@ -390,9 +390,9 @@ __global__ __launch_bounds__(256) void k_ntt_final_ext29(const Fr* in, Fr* out, 
             }
         }
     }
-    __syncthreads();
     u32* qtab = sm + ntt29_lds_words(nelem);
-    f29_qtab_fill<FrTag>(qtab);
+    f29_qtab_fill<FrTag>(qtab);   // before the barrier that publishes the tile (see k_ntt_final29)
+    __syncthreads();
     lds_dit29(sm, p.logR, T * E, 1, R, false, tw, p.n);
     for (unsigned idx = threadIdx.x; idx < R * T * E; idx += blockDim.x) {
         const unsigned r = idx & (E - 1), rr = (idx >> log_e) & (T - 1), k = idx >> (log_e + logT);
@@ -635,11 +635,12 @@ __global__ void k_ext_stage_table(Fr c, const u32* __restrict__ tw, size_t n, un
 }
 // out_ep: [E][n][9], out_stw: [E][R][9]
 static int get_ext_abs_tables(pz_ctx* ctx, const uint64_t* coset_gens, size_t E, uint32_t log_n, unsigned logR, const uint64_t* scale,
-                              const u32* tw, const u32** out_ep, const u32** out_stw) {
+                              const uint64_t omega_n[4], const u32* tw, const u32** out_ep, const u32** out_stw) {
     const size_t n = (size_t)1 << log_n, R = (size_t)1 << logR, lo = n >> logR;
     std::vector<uint64_t> key(coset_gens, coset_gens + 4 * E);
     key.push_back(log_n);
     key.push_back(0xab50000ull + logR);   // distinguishes these tables from the pre-scale ones of the same cosets
+    key.insert(key.end(), omega_n, omega_n + 4);   // both tables are built from omega_n's powers (`tw`): part of the key
     if (scale) key.insert(key.end(), scale, scale + 4);
     for (auto& c : ctx->ext_tables)
         if (c.key == key) {
@@ -693,7 +694,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
     const unsigned logR_a = npass_ == 2 ? (log_n + 1) / 2 : (log_n + 2) / 3;   // size of the first pass (lg0 / lg[0] below)
     const u32 *pre = nullptr, *stw = nullptr;
     if (absorbed) {
-        PZCHK(get_ext_abs_tables(ctx, coset_gens, E, log_n, logR_a, scale, tw, &pre, &stw));
+        PZCHK(get_ext_abs_tables(ctx, coset_gens, E, log_n, logR_a, scale, omega_n, tw, &pre, &stw));
     } else {
         void* prev = nullptr;
         PZCHK(get_ext_pre_tables(ctx, coset_gens, E, log_n, scale, &prev));
