@@ -64,6 +64,30 @@ def synth_inputs(enc_bits: int, seed: int):
     return n, n + 1, rng.randrange(0, n), rng.randrange(1, n)
 
 
+def _same_shape_message(m: int, rng) -> int:
+    """another message with m's bit length and popcount (so the circuit of paillier.rs:50-55 keeps its shape): a few
+    (set bit, clear bit) pairs below the top bit swapped"""
+    top = m.bit_length() - 1
+    ones = [i for i in range(top) if (m >> i) & 1]
+    zeros = [i for i in range(top) if not (m >> i) & 1]
+    if not ones or not zeros:
+        return m
+    for _ in range(min(64, len(ones), len(zeros))):
+        i, j = rng.choice(ones), rng.choice(zeros)
+        if (m >> i) & 1 and not (m >> j) & 1:
+            m ^= (1 << i) | (1 << j)
+    return m
+
+
+def fnv1a64(data: bytes) -> int:
+    """FNV-1a over bytes, eight at a time as little-endian words (the same walk as host/prove_c2.cpp's)"""
+    h = 0xCBF29CE484222325
+    a = np.frombuffer(data, dtype="<u8")
+    for w in a.tolist():
+        h = ((h ^ w) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
 class ProofWorkload:
     """device-resident state of the c2 hot path on one GPU"""
 
@@ -81,6 +105,7 @@ class ProofWorkload:
         nn, g, m, r = synth_inputs(enc_bits, seed)
         self.circuit = circuit
         self.inputs = tuple(consts.int_to_limbs(x, self.Ln) for x in (nn, g, m, r))
+        self._ints = (nn, g, m, r)
         if circuit == "encrypt":
             n_steps = m.bit_length() + bin(m).count("1") + nn.bit_length() + bin(nn).count("1") + 1
         elif circuit == "encrypt_uniform":   # g^m over enc_bits in-circuit bits, two mul_mods per bit
@@ -101,6 +126,31 @@ class ProofWorkload:
         else:
             res_limbs = eng.mul_mod(self.L, consts.int_to_limbs(m, self.L), consts.int_to_limbs(r, self.L), consts.int_to_limbs(nn * nn, self.L))[1]
         self.circ_inputs = np.concatenate([consts.int_to_limbs(x, self.Ln) for x in (nn, g, m, r)] + [np.asarray(res_limbs, dtype=np.uint64)])
+        # THREE (message, randomness) pairs of the same key go round the TWO witness slots, step i proving pair i % 3: a slot
+        # overwritten too early or read too early then holds another message's cells and the check after the timed loop
+        # (verify_pipelined) sees it -- with one message every slot would hold the same values whatever the order of the streams.
+        # The pairs share the circuit's SHAPE (paillier.rs:50-55 bakes the message's bits into it): same bit length and
+        # popcount of m, hence the same step count, columns and proving key
+        self.variants = [dict(inputs=self.inputs, circ_inputs=self.circ_inputs, add_ops=getattr(self, "add_ops", None), ints=(nn, g, m, r))]
+        import random as _rnd
+
+        vr = _rnd.Random(seed ^ 0x766172)
+        for _ in range(2):
+            if circuit == "add":
+                m2, r2 = vr.randrange(0, nn), vr.randrange(1, nn)
+            else:
+                m2, r2 = _same_shape_message(m, vr), vr.randrange(1, nn)
+            inp = tuple(consts.int_to_limbs(x, self.Ln) for x in (nn, g, m2, r2))
+            if circuit != "add":
+                res2 = eng.paillier_encrypt(self.Ln, *inp, want_steps=False)[0][0]
+                ops = None
+            else:
+                ops = tuple(consts.int_to_limbs(x, self.L) for x in (m2, r2, nn * nn))
+                res2 = eng.mul_mod(self.L, ops[0], ops[1], ops[2])[1]
+            ci = np.concatenate(list(inp) + [np.asarray(res2, dtype=np.uint64)])
+            self.variants.append(dict(inputs=inp, circ_inputs=ci, add_ops=ops, ints=(nn, g, m2, r2)))
+        self._steps_done = 0
+        self.drop_edge = os.environ.get("PZ_BENCH_DROP_EDGE", "")   # negative test of verify_pipelined only: "ready" / "ntt_ready" (a consumer does not wait for K4) / "free" (the producer does not wait for its slot's readers)
         sh = self.shape
         sc = lambda x: max(1, int(round(x * scale)))
         self.counts = dict(msm_full=sc(sh.msm_full), polys=sc(sh.polys))
@@ -180,6 +230,7 @@ class ProofWorkload:
                                            consts.fr_mont_limbs(pow(self.n, -1, consts.FR_R)), d_g.data_ptr(), d_b.data_ptr())
         eng.sync()
         self.bases = eng.load_bases_dev(d_b.data_ptr(), self.n)
+        self.lagrange_host = d_b.cpu().numpy().astype(np.uint64)   # 64 B x 2^k: what the checker commits the sampled columns against
         self.srs_ms = {"setup_and_write_file": (t_file - t_srs) * 1e3, "read_check_lagrange_table": (time.perf_counter() - t_file) * 1e3}
         del d_b, d_g, params
         try:
@@ -246,14 +297,20 @@ class ProofWorkload:
         return self.digit_adds
 
     # ---- one pass of the hot path = produce(slot) [K3 + K4] then consume(slot) [K1 + K2]
-    def produce(self, slot):
-        eng, t = self.engw, self.torch
+    def produce(self, slot, variant=0, eng=None, events=True):
+        """K3 + K4 of message `variant` into witness slot `slot` (on the witness context / stream; `eng` + events=False: on
+        that context with no event traffic -- the serial reference of verify_pipelined)"""
+        t = self.torch
+        eng = eng or self.engw
+        events = events and self.pipeline
         sh = self.shape
-        if self.pipeline:
-            self.stream_w.wait_event(self.free_ev[slot])  # the previous consumer of this slot has finished reading it
-            if self.stream_n is not None:
-                self.stream_w.wait_event(self.ntt_free_ev[slot])   # ... and so has the transform stream
-        nn, g, m, r = self.inputs
+        if events:
+            if self.drop_edge != "free":
+                self.stream_w.wait_event(self.free_ev[slot])  # the previous consumer of this slot has finished reading it
+                if self.stream_n is not None:
+                    self.stream_w.wait_event(self.ntt_free_ev[slot])   # ... and so has the transform stream
+        var = self.variants[variant]
+        nn, g, m, r = var["inputs"]
         skip = os.environ.get("PZ_BENCH_SKIP", "")   # debug only ("k3" / "k4"): see consume()
         self._produced = getattr(self, "_produced", 0) + 1
         if self._produced <= 2:
@@ -265,36 +322,39 @@ class ProofWorkload:
         elif self.circuit == "encrypt_uniform":
             eng.paillier_encrypt_uniform_dev(self.Ln, self.enc_bits, nn, g, m, r, self.d_steps[slot].data_ptr(), self.n_steps)
         else:
-            a, b, mod = self.add_ops
+            a, b, mod = var["add_ops"]
             q, rem = eng.mul_mod(self.L, a, b, mod)
-            with (t.cuda.stream(self.stream_w) if self.pipeline else _null()):
+            with (t.cuda.stream(self.stream_w) if (self.pipeline and eng is self.engw) else _null()):
                 self.d_steps[slot].copy_(t.from_numpy(np.stack([a, b, q, rem]).astype(np.int64)).view(1, 4, self.L))
         # K4: expand the whole operation tape into the advice / lookup cell streams (the circuit's columns)
         if "k4" not in skip:
-            eng.circuit_expand_dev(self.kind, self.Ln, 64, sh.lookup_bits, self.circ_inputs, self.d_steps[slot].data_ptr(), self.ng, self.nr,
+            eng.circuit_expand_dev(self.kind, self.Ln, 64, sh.lookup_bits, var["circ_inputs"], self.d_steps[slot].data_ptr(), self.ng, self.nr,
                                    self.d_mod.data_ptr(), self.d_adv[slot].data_ptr(), self.d_lk[slot].data_ptr(), self.rows, self.n)
-        if self.pipeline:
+        if events:
             self.ready_ev[slot].record(self.stream_w)
 
-    def consume(self, slot, msm_only=False, tail=False):
+    def consume(self, slot, msm_only=False, tail=False, keep=None):
+        """keep: a dict from new_keep() -- the commitments go to its buffers instead of the shared ones and the transforms of
+        its sampled columns are copied out (verify_pipelined); the launches and the event edges are the timed loop's"""
         eng, t = self.eng, self.torch
         n, k, sh = self.n, self.k, self.shape
-        if self.pipeline:
+        if self.pipeline and self.drop_edge != "ready":
             t.cuda.current_stream().wait_event(self.ready_ev[slot])
         from paillier_halo2_amd import dist as pzd
 
         rk, ws = self.shard
         skip = os.environ.get("PZ_BENCH_SKIP", "")   # debug only ("msm" / "ntt"): time one half of the hot path alone
         # K1: commitments -- every advice and lookup-advice column (real witness cells) ...
-        for buf, ncols in (() if "msm" in skip else ((self.d_adv[slot], self.adv_cols), (self.d_lk[slot], self.lk_cols))):
+        for which, (buf, ncols) in enumerate(() if "msm" in skip else ((self.d_adv[slot], self.adv_cols), (self.d_lk[slot], self.lk_cols))):
             if self.scale != 1.0:
                 ncols = max(1, int(round(ncols * self.scale)))
             lo, hi = pzd.column_range(ncols, rk, ws)   # column-parallel mode: this rank's columns of the shared proof
+            d_o = self.d_out_adv if keep is None else keep["lk" if which else "adv"]
             if hi > lo:
                 eng.msm_dev(self.bases, buf.data_ptr() + lo * self.n * 32, hi - lo, self.n, 4 * self.n,
-                            self.d_out_adv.data_ptr())
-            if ws > 1:
-                pzd.gather_commitments(t, self.dist, self.d_out_adv[: hi - lo], ncols, rk, ws)
+                            d_o.data_ptr())
+            if self.dist is not None:   # column-parallel mode (a process group of one rank runs the collective too: --force-dist)
+                pzd.gather_commitments(t, self.dist, d_o[: hi - lo], ncols, rk, ws)
         # ... and the full-width MSMs of the later prover phases (permuted lookup columns, grand products,
         # quotient pieces, openings): uniformly random scalars
         lo, hi = pzd.column_range(self.counts["msm_full"], rk, ws)
@@ -302,18 +362,18 @@ class ProofWorkload:
         while done < hi:
             nc = min(self.pool, hi - done)
             e_ = self.engn if (os.environ.get("PZ_BENCH_MSM2") == "1" and (done // self.pool) & 1) else eng   # experiment
-            e_.msm_dev(self.bases, self.col_f.data_ptr(), nc, n, 4 * n, self.d_out_full[done - lo].data_ptr())
+            e_.msm_dev(self.bases, self.col_f.data_ptr(), nc, n, 4 * n, (self.d_out_full if keep is None else keep["full"])[done - lo].data_ptr())
             done += nc
-        if ws > 1:
-            pzd.gather_commitments(t, self.dist, self.d_out_full[: hi - lo], self.counts["msm_full"], rk, ws)
+        if self.dist is not None:
+            pzd.gather_commitments(t, self.dist, (self.d_out_full if keep is None else keep["full"])[: hi - lo], self.counts["msm_full"], rk, ws)
         if not msm_only and "ntt" not in skip:
-            self.consume_ntt(slot)
+            self.consume_ntt(slot, keep=keep)
         if tail:
             self.tail_run(slot)
         if self.pipeline:
             self.free_ev[slot].record(t.cuda.current_stream())
 
-    def consume_ntt(self, slot=0):
+    def consume_ntt(self, slot=0, keep=None):
         eng, n, k, sh = self.engn, self.n, self.k, self.shape
         t = self.torch
         # K2: Lagrange -> coeff (iNTT 2^k) -> extended coset: 4 interleaved coset NTTs with the 1/n divisor folded into
@@ -329,9 +389,9 @@ class ProofWorkload:
         nb = self.ntt_batch
         pool_n = self.col_f if self.stream_n is None else self.col_n
         own = [(self.d_adv[slot], self.adv_cols), (self.d_lk[slot], self.lk_cols)] if (self.own_ntt and self.scale == 1.0 and self.shard == (0, 1)) else []
-        if self.stream_n is not None and self.pipeline:
+        if self.stream_n is not None and self.pipeline and self.drop_edge != "ntt_ready":
             self.stream_n.wait_event(self.ready_ev[slot])     # the columns K4 wrote
-        for buf, ncols in own:
+        for which, (buf, ncols) in enumerate(own):
             cols = buf.view(ncols, n, 4)
             c0 = 0
             while c0 < ncols and done < p_hi - p_lo:
@@ -342,6 +402,12 @@ class ProofWorkload:
                 eng.ntt_to_dev(cols[c0].data_ptr(), 4 * n, work.data_ptr(), 4 * n, nc, self.omega_inv, k, None, self.n_inv)
                 eng.ntt_extend_dev(work.data_ptr(), nc, 4 * n, self.d_ext.data_ptr(), 4 * self.ext_n, k, sh.ext_k - k,
                                    self.omega_n, self.coset_gens, None)
+                if keep is not None:   # sampled columns of this batch: coefficient and extended forms copied out on the transform stream
+                    with (t.cuda.stream(self.stream_n) if self.stream_n is not None else _null()):
+                        for j, (w_, c_) in enumerate(keep["samples"]):
+                            if w_ == which and c0 <= c_ < c0 + nc:
+                                keep["coef"][j].copy_(work[c_ - c0])
+                                keep["ext"][j].copy_(self.d_ext[c_ - c0])
                 c0 += nc
                 done += nc
         if own and self.stream_n is not None and self.pipeline:
@@ -589,25 +655,114 @@ class ProofWorkload:
                        "and blinding randomness are not included")
         return out
 
-    def run(self, steps, with_tail=False):
+    def run(self, steps, with_tail=False, keep=None):
         """exactly `steps` passes of the hot path (with_tail: each followed by the prover steps after it); with
         PZ_BENCH_PIPELINE the witness of pass i+1 overlaps the commitments / NTTs of pass i (every pass still does all of
         its work inside the timed region)"""
         if steps <= 0:
             return
+        base, nv = self._steps_done, len(self.variants)
+        self._steps_done += steps
         if not self.pipeline:
-            for _ in range(steps):
-                self.produce(0)
-                self.consume(0, tail=with_tail)
+            for i in range(steps):
+                self.produce(0, (base + i) % nv)
+                self.consume(0, tail=with_tail, keep=keep[i] if keep else None)
             return
-        self.produce(0)
+        self.produce(0, base % nv)
         for i in range(steps):
-            self.consume(i & 1, tail=with_tail)   # asynchronous: returns once the launches are queued
+            self.consume(i & 1, tail=with_tail, keep=keep[i] if keep else None)   # asynchronous: returns once the launches are queued
             if i + 1 < steps:
-                self.produce((i + 1) & 1)    # its trace call blocks the host while the GPU works on both streams
+                self.produce((i + 1) & 1, (base + i + 1) % nv)    # its trace call blocks the host while the GPU works on both streams
 
     def step(self):
         self.run(1)
+
+    # ---- what the timed loop computes, checked: VERDICT r03 item 1 / ADVICE r03 #2.  The timed loop is a two-slot, three-stream,
+    # three-context pipeline ordered by events; the at-size parity tests run the same kernels serially.  After the timed loop,
+    # untimed: `steps` more PIPELINED steps (same launches, same event edges; only the output pointers differ and sampled
+    # transforms are copied out) whose every advice / lookup commitment and sampled coefficient / extended columns are compared
+    # with a SERIAL recomputation of the same message on one context and one stream, synchronised between stages.
+    def new_keep(self):
+        t = self.torch
+        z = lambda *shape: t.zeros(shape, dtype=t.int64, device="cuda")
+        a, l = self.adv_cols, self.lk_cols
+        samples = sorted({(0, 0), (0, a // 2), (0, a - 1), (1, 0), (1, l - 1)})
+        return dict(adv=z(a, 12), lk=z(max(1, l), 12), full=z(self.counts["msm_full"], 12), samples=samples,
+                    coef=z(len(samples), self.n, 4), ext=z(len(samples), self.ext_n, 4))
+
+    def serial_reference(self, variant):
+        """the same message on ONE context / ONE stream (the commitment context), a synchronisation after every stage; also
+        keeps the cells of the sampled columns (for the oracle comparison of the cpu_baseline leg)"""
+        eng, t, n, k, sh = self.eng, self.torch, self.n, self.k, self.shape
+        t.cuda.synchronize()
+        self.produce(0, variant, eng=eng, events=False)
+        eng.sync()
+        ref = self.new_keep()
+        eng.msm_dev(self.bases, self.d_adv[0].data_ptr(), self.adv_cols, n, 4 * n, ref["adv"].data_ptr())
+        eng.sync()
+        if self.lk_cols:
+            eng.msm_dev(self.bases, self.d_lk[0].data_ptr(), self.lk_cols, n, 4 * n, ref["lk"].data_ptr())
+            eng.sync()
+        done = 0
+        while done < self.counts["msm_full"]:
+            nc = min(self.pool, self.counts["msm_full"] - done)
+            eng.msm_dev(self.bases, self.col_f.data_ptr(), nc, n, 4 * n, ref["full"][done].data_ptr())
+            eng.sync()
+            done += nc
+        ref["cells"] = []
+        for j, (w_, c_) in enumerate(ref["samples"]):
+            col = (self.d_lk[0] if w_ else self.d_adv[0]).view(-1, n, 4)[c_]
+            ref["cells"].append(col.clone())
+            eng.ntt_to_dev(col.data_ptr(), 4 * n, ref["coef"][j].data_ptr(), 4 * n, 1, self.omega_inv, k, None, self.n_inv)
+            eng.sync()
+            eng.ntt_extend_dev(ref["coef"][j].data_ptr(), 1, 4 * n, ref["ext"][j].data_ptr(), 4 * self.ext_n, k, sh.ext_k - k,
+                               self.omega_n, self.coset_gens, None)
+            eng.sync()
+        return ref
+
+    def verify_pipelined(self, steps=4):
+        t, eng = self.torch, self.eng
+        if not (self.scale == 1.0 and self.shard == (0, 1) and self.own_ntt):
+            return {"verified": None, "note": "not run: scaled / column-parallel / pool-only transforms"}
+        nv = len(self.variants)
+        keeps = [self.new_keep() for _ in range(steps)]
+        base = self._steps_done
+        err = None
+        self.run(steps, keep=keeps)
+        t.cuda.synchronize()
+        for e_ in {id(x): x for x in (self.eng, self.engw, self.engn)}.values():
+            try:
+                e_.sync()      # PZ_ERR_ASYNC: a sort kernel saw its scalars change under it
+            except Exception as ex:
+                err = repr(ex)
+        aff = lambda x: eng.g1_normalize(x.cpu().numpy().astype(np.uint64))
+        refs, bad, n_com, n_ntt, hashes = {}, [], 0, 0, {}
+        for i in range(steps):
+            v = (base + i) % nv
+            if v not in refs:
+                refs[v] = self.serial_reference(v)
+                refs[v]["aff"] = {kk: aff(refs[v][kk]) for kk in ("adv", "lk", "full")}
+            ref, kp = refs[v], keeps[i]
+            got = {kk: aff(kp[kk]) for kk in ("adv", "lk", "full")}
+            for kk in ("adv", "lk", "full"):
+                ne = np.nonzero((got[kk] != ref["aff"][kk]).any(axis=1))[0]
+                n_com += got[kk].shape[0]
+                if ne.size:
+                    bad.append({"step": i, "message": v, "what": kk + " commitments", "columns_differing": int(ne.size), "first": int(ne[0])})
+            for j, (w_, c_) in enumerate(kp["samples"]):
+                for form in ("coef", "ext"):
+                    n_ntt += 1
+                    if not t.equal(kp[form][j], ref[form][j]):
+                        bad.append({"step": i, "message": v, "what": "%s form of %s column %d" % (form, "lookup" if w_ else "advice", c_)})
+            hashes[v] = "%016x" % fnv1a64(np.ascontiguousarray(np.concatenate([got["adv"], got["lk"][: self.lk_cols]])).tobytes())
+        self._verify_refs = refs
+        ok = not bad and err is None
+        return {"verified": ok, "pipelined_steps_checked": steps, "messages": nv, "commitments_compared": n_com, "transforms_compared": n_ntt,
+                "mismatches": bad[:8], "async_error": err, "commitment_hash_by_message": {str(k_): h_ for k_, h_ in sorted(hashes.items())},
+                "dropped_edge": self.drop_edge or None,
+                "note": "untimed, after the timed loop: pipelined steps (the timed loop's launches and event edges; three messages of one shape "
+                        "through the two witness slots) against a serial one-context one-stream recomputation of each message: every advice / lookup / "
+                        "full-width commitment (affine form) and the coefficient + extended forms of sampled columns, bit for bit"}
 
 
 def env_switches():
@@ -681,6 +836,56 @@ def cpu_baseline(shape, n_steps, enc_bits, k, log):
     }
 
 
+def oracle_check(wl, log):
+    """checker only (part of the cpu_baseline leg, the one place bench.py may touch oracle/): the sampled columns of the serial
+    reference verify_pipelined compared the pipelined steps with -- K4 cells, K1 commitment, K2 coefficient and extended forms of
+    one message -- against the oracle chain (Python trace -> Python cells -> C best_multiexp / best_fft)."""
+    from oracle import cref
+    from oracle import pyref as P
+
+    t0 = time.time()
+    refs = getattr(wl, "_verify_refs", None)
+    if not refs:
+        return {"ok": None, "note": "no serial reference kept"}
+    v = sorted(refs)[-1]
+    ref = refs[v]
+    nn, g, m, r = wl.variants[v]["ints"]
+    res = P.paillier_enc_native(nn, g, m, r)
+    n, rows, k, sh = wl.n, wl.rows, wl.k, wl.shape
+    assert wl.variants[v]["circ_inputs"][4 * wl.Ln:].tolist() == cref.int_to_limbs(res, wl.L).tolist(), "ciphertext of the witness vs paillier_enc_native"
+    win = lambda j, tot: (j * rows, min((j + 1) * rows, tot))
+    sa = [c_ for w_, c_ in ref["samples"] if w_ == 0]
+    sl = [c_ for w_, c_ in ref["samples"] if w_ == 1]
+    tot_a, tot_l, cells_a, cells_l = P.encrypt_circuit_cells_windows(nn, g, m, r, res, wl.enc_bits, 64, sh.lookup_bits,
+                                                                     [win(j, wl.circ_adv) for j in sa], [win(j, wl.circ_lk) for j in sl])
+    assert (tot_a, tot_l) == (wl.circ_adv, wl.circ_lk)
+    bases = wl.lagrange_host
+    mont = lambda x: cref.fr_ints_to_mont([x % P.FR_R])[0]
+    w_inv, n_inv = pow(P.fr_omega(k), -1, P.FR_R), pow(n, -1, P.FR_R)
+    log_e = sh.ext_k - k
+    bad = []
+    want_cells = {(0, c_): col for c_, col in zip(sa, cells_a)}
+    want_cells.update({(1, c_): col for c_, col in zip(sl, cells_l)})
+    for j, key in enumerate(ref["samples"]):
+        col = want_cells[key]
+        col_m = cref.fr_ints_to_mont(col + [0] * (n - len(col)))
+        if not np.array_equal(ref["cells"][j].cpu().numpy().astype(np.uint64), col_m):
+            bad.append(("cells", key))
+        got_c = wl.eng.g1_normalize(ref["lk" if key[0] else "adv"][key[1]].cpu().numpy().astype(np.uint64).reshape(1, 12))[0]
+        if not np.array_equal(got_c, cref.g1_normalize(cref.msm_g1(col_m, bases))):
+            bad.append(("commitment", key))
+        coeff = cref.fr_scale(cref.ntt_fr(col_m, mont(w_inv), k), mont(n_inv))
+        if not np.array_equal(ref["coef"][j].cpu().numpy().astype(np.uint64), coeff):
+            bad.append(("coefficients", key))
+        ext_in = np.zeros((n << log_e, 4), dtype=np.uint64)
+        ext_in[:n] = cref.fr_distribute_powers(coeff, mont(P.FR_GENERATOR))
+        if not np.array_equal(ref["ext"][j].cpu().numpy().astype(np.uint64), cref.ntt_fr(ext_in, mont(P.fr_omega(sh.ext_k)), sh.ext_k)):
+            bad.append(("extended", key))
+    return {"ok": not bad, "message": v, "columns": [list(x) for x in ref["samples"]], "mismatches": [list(map(str, b)) for b in bad],
+            "seconds": time.time() - t0,
+            "note": "serial reference of message %d vs the oracle chain: cells, commitment, coefficient form and extended-coset form of %d sampled columns" % (v, len(ref["samples"]))}
+
+
 def dropin_host_pointer_path(wl, torch, log, sample=256):
     """What a reference prover patched as INTEGRATION.md sections 2-3 describe would get WITHOUT restructuring its data flow:
     best_multiexp -> pz_msm_g1_batch and best_fft -> pz_ntt_fr_batch with HOST pointers (pinned memory here), i.e. every
@@ -728,7 +933,7 @@ def dropin_host_pointer_path(wl, torch, log, sample=256):
                     "binding and is not counted" % (n_wit, wl.counts["msm_full"], wl.counts["polys"], k, sh.ext_k)}
 
 
-def dropin_device_resident(wl, args, log):
+def dropin_device_resident(wl, args, log, env_extra=None, replicas=1):
     """The SAME hot path driven from plain C++ through the C ABI alone -- paillier_halo2_amd/host/prove_c2.cpp: pz_dev_alloc /
     pz_upload, three contexts ordered by pz_ctx_wait, no torch and no HIP call in the host -- i.e. what the reference's Rust
     prover patched at points C and D of INTEGRATION.md reaches.  Run as a child process after this process's own timed loops
@@ -752,6 +957,10 @@ def dropin_device_resident(wl, args, log):
     arrs = [np.asarray(a, dtype=np.uint64) for a in wl.inputs] + [wl.circ_inputs[4 * wl.Ln:].astype(np.uint64),
                                                                    consts.int_to_limbs(nn * nn, wl.L)]
     arrs += [consts.fr_mont_limbs(s_toxic), wl.omega_n, wl.omega_inv, wl.n_inv, wl.coset_gens.reshape(-1)]
+    # the other messages of the same shape (step i proves message i % 3, as in ProofWorkload.run): m | r | res each
+    arrs.append(np.array([len(wl.variants) - 1], dtype=np.uint64))
+    for var in wl.variants[1:]:
+        arrs += [np.asarray(var["inputs"][2], dtype=np.uint64), np.asarray(var["inputs"][3], dtype=np.uint64), var["circ_inputs"][4 * wl.Ln:].astype(np.uint64)]
     blob = struct.pack("<%dQ" % len(words), *words) + b"".join(np.ascontiguousarray(a, dtype="<u8").tobytes() for a in arrs)
     with tempfile.NamedTemporaryFile(suffix=".job", delete=False) as f:
         f.write(blob)
@@ -759,7 +968,8 @@ def dropin_device_resident(wl, args, log):
     try:
         env = dict(os.environ)
         env.pop("LD_PRELOAD", None)
-        p = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=env)
+        env.update(env_extra or {})
+        p = subprocess.run([exe, path] + ([str(replicas)] if replicas > 1 else []), capture_output=True, text=True, timeout=900, env=env)
     finally:
         os.unlink(path)
     if p.returncode != 0:
@@ -866,13 +1076,17 @@ def main():
     ap.add_argument("--no-body", action="store_true", help="skip the second timed loop (hot path + the prover steps after it)")
     ap.add_argument("--emulate-world", type=int, default=0, help="msm22 workload on ONE GPU: run each of W ranks' shares in turn, "
                     "print per-share stage times and the predicted W-GPU efficiency for both splits")
+    ap.add_argument("--no-verify", action="store_true", help="skip the output check of the pipelined step after the timed loop (the line then says verified: null)")
     ap.add_argument("--no-tail", action="store_true", help="skip the (untimed) measurement of the prover steps after the hot path")
+    ap.add_argument("--force-dist", action="store_true", help="with --gpus 1: still start through torch.distributed.run, create the process group "
+                    "(backend nccl = RCCL) and run every collective of the N > 1 path on the one rank (all_gather_into_tensor + device fold of msm22, "
+                    "the commitment all-gather of --parallel columns, the barriers and the MAX all-reduce of the timing)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo only with --workload stub)")
     args = ap.parse_args()
 
     # typed as `python bench.py --gpus N` (not pre-launched by torch.distributed.run): become the launcher.  Nothing above
     # this line has touched the GPU (numpy only), and the ranks are CHILD processes -- never an exec of this one
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
     if args.workload == "stub":
         return stub_workload(args)
@@ -973,6 +1187,14 @@ def main():
         iso_ms, iso_n = eng.timing_get(E.T_MSM_ACC)
     for e_ in engines:
         e_.timing_enable(False)
+    # what the timed loop computed, checked (untimed): pipelined steps against a serial recomputation
+    verification = None
+    if not args.no_verify and rank == 0:
+        try:
+            verification = wl.verify_pipelined()
+            log("verify_pipelined: %s" % {k_: v_ for k_, v_ in verification.items() if k_ not in ("note",)})
+        except Exception as ex:
+            verification = {"verified": False, "error": repr(ex)}
     tail = None
     body = None
     if args.scale == 1.0 and not args.no_tail:
@@ -1102,7 +1324,13 @@ def main():
     # every PZ_* switch set for this run is echoed; anything that removes or resizes work inside the timed region
     # (PZ_BENCH_SKIP, --scale) marks the line as not comparable
     out["config"]["env_switches"] = env_switches()
-    out["comparable"] = bool(args.scale == 1.0 and not os.environ.get("PZ_BENCH_SKIP"))
+    out["comparable"] = bool(args.scale == 1.0 and not os.environ.get("PZ_BENCH_SKIP") and not os.environ.get("PZ_BENCH_DROP_EDGE"))
+    # `verified`: the pipelined step's outputs equal a serial recomputation's (verify_pipelined); a failed check voids the line
+    out["verified"] = verification.get("verified") if verification else None
+    if verification is not None:
+        out["verification"] = verification
+        if verification.get("verified") is False:
+            out["comparable"] = False
     out["srs_ms"] = wl.srs_ms
     out["config"]["srs"] = "params file written as gen_srs does (ParamsKZG::setup), read back by paillier_halo2_amd/srs.py, points checked on the device, Lagrange bases by the G1 inverse FFT (no toxic scalar)"
     out["config"]["ntt_inputs"] = ("the proof's own advice and lookup columns (transformed out of place into the coefficient buffer) + pool polynomials for the rest" if wl.own_ntt else "pool polynomials")
@@ -1118,11 +1346,28 @@ def main():
         out["dropin_device_resident"] = dropin_dev
         if dropin_dev.get("value"):
             out["dropin_device_resident"]["ratio_to_value"] = dropin_dev["value"] / value
+        # the C++ caller's commitments are the Python path's: the per-message hashes of the two verification runs agree
+        if verification and verification.get("commitment_hash_by_message") and dropin_dev.get("commitment_hash_by_message"):
+            mine, theirs = verification["commitment_hash_by_message"], dropin_dev["commitment_hash_by_message"]
+            common = sorted(set(mine) & set(theirs))
+            dropin_dev["commitments_equal_python_path"] = bool(common) and all(mine[c_] == theirs[c_] for c_ in common)
+            if dropin_dev.get("verified") is False or not dropin_dev["commitments_equal_python_path"]:
+                out["comparable"] = False
     if not args.no_cpu_baseline and args.scale == 1.0 and world == 1:   # rank 0 at N = 1 only
         try:
             out["cpu_baseline"] = cpu_baseline(sh, wl.n_steps, args.enc_bits, args.k, log)
         except Exception as ex:  # the checker must never take the bench line down
             out["cpu_baseline"] = {"value": None, "error": repr(ex)}
+        # the same leg holds the checker: the serial reference of verify_pipelined against the oracle chain
+        if verification and verification.get("verified") and wl.circuit == "encrypt":
+            try:
+                vo = oracle_check(wl, log)
+                out["verification"]["vs_oracle"] = vo
+                if not vo.get("ok"):
+                    out["verified"] = out["verification"]["verified"] = False
+                    out["comparable"] = False
+            except Exception as ex:
+                out["verification"]["vs_oracle"] = {"ok": None, "error": repr(ex)}
     if out["roofline_int"]["achieved"]:
         out["roofline_int"]["frac"] = out["roofline_int"]["achieved"] / out["roofline_int"]["peak"]
         if out["roofline_int"]["achieved_alone"]:

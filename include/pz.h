@@ -50,7 +50,10 @@ enum pz_status {
     PZ_ERR_RANGE = -6,        /* quotient does not fit the limb count the circuit assigns it (unsatisfiable in the reference) */
     PZ_ERR_UNSUPPORTED = -7,  /* n_devices != 1, limb count not a supported size ...         */
     PZ_ERR_CAPACITY = -8,     /* caller-provided output capacity too small                  */
-    PZ_ERR_MESSAGE_RANGE = -9 /* uniform-shape circuit: a message does not fit the m_bits the circuit decomposes */
+    PZ_ERR_MESSAGE_RANGE = -9,/* uniform-shape circuit: a message does not fit the m_bits the circuit decomposes */
+    PZ_ERR_ASYNC = -10        /* reported by a synchronising entry point (pz_sync, pz_download, the host-pointer MSM calls): an
+                                 earlier asynchronous pz_msm_g1* call found its scalars changed while it ran; its outputs are
+                                 invalid (no out-of-bounds access took place: positions are checked on the device) */
 };
 
 /* ---------------------------------------------------------------------------------------------
@@ -67,7 +70,7 @@ int pz_set_stream(pz_ctx* ctx, void* hip_stream);
 int pz_sync(pz_ctx* ctx);
 /* explicit ABI version, bumped whenever an entry point below is added, removed or changes meaning (measurement probes are
  * not part of this ABI: they live in libpz_probe.so).  A binding compares it with the PZ_ABI_VERSION it was built against. */
-#define PZ_ABI_VERSION 3
+#define PZ_ABI_VERSION 4
 int pz_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------

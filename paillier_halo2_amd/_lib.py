@@ -164,3 +164,4 @@ PZ_ERR_RANGE = -6
 PZ_ERR_UNSUPPORTED = -7
 PZ_ERR_CAPACITY = -8
 PZ_ERR_MESSAGE_RANGE = -9
+PZ_ERR_ASYNC = -10

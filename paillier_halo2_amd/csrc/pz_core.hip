@@ -56,6 +56,7 @@ extern "C" const char* pz_strerror(int s) {
         case PZ_ERR_UNSUPPORTED: return "unsupported configuration";
         case PZ_ERR_CAPACITY: return "output capacity too small";
         case PZ_ERR_MESSAGE_RANGE: return "message does not fit the exponent bits of the uniform-shape circuit";
+        case PZ_ERR_ASYNC: return "an asynchronous call found its inputs changed while it ran (or an internal invariant broken); its results are invalid";
         default: return "unknown pz_status";
     }
 }
@@ -108,6 +109,7 @@ extern "C" int pz_free(pz_ctx* ctx) {
         if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
         if (ctx->stage_h[k]) (void)hipHostFree(ctx->stage_h[k]);
     }
+    if (ctx->async_err_h) (void)hipHostFree((void*)ctx->async_err_h);
     if (ctx->io_h2d) (void)hipStreamDestroy(ctx->io_h2d);
     if (ctx->io_d2h) (void)hipStreamDestroy(ctx->io_d2h);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -167,7 +169,7 @@ extern "C" int pz_download(pz_ctx* ctx, void* dst, const void* d_src, size_t byt
     PZ_ENTER(ctx);
     HIPCHK(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return PZ_OK;
+    return pz_check_async(ctx);
 }
 extern "C" int pz_dev_memset(pz_ctx* ctx, void* d_dst, int byte_value, size_t bytes) {
     if (!ctx || (bytes && !d_dst)) return PZ_ERR_INVALID;
@@ -235,7 +237,30 @@ extern "C" int pz_sync(pz_ctx* ctx) {
     if (!ctx) return PZ_ERR_INVALID;
     PZ_ENTER(ctx);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return pz_check_async(ctx);
+}
+
+int pz_async_err_init(pz_ctx* ctx) {
+    if (ctx->async_err_h) return PZ_OK;
+    void *h = nullptr, *d = nullptr;
+    HIPCHK(ctx, hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    *(volatile unsigned*)h = 0;
+    hipError_t e = hipHostGetDevicePointer(&d, h, 0);
+    if (e != hipSuccess) {
+        (void)hipHostFree(h);
+        return pz_hip_fail(ctx, e, "hipHostGetDevicePointer(async error flag)");
+    }
+    ctx->async_err_h = (volatile unsigned*)h;
+    ctx->async_err_d = (volatile unsigned*)d;
     return PZ_OK;
+}
+
+int pz_check_async(pz_ctx* ctx) {
+    if (!ctx->async_err_h || !*ctx->async_err_h) return PZ_OK;
+    *ctx->async_err_h = 0;
+    snprintf(ctx->hip_err, sizeof ctx->hip_err, "a sort kernel of pz_msm_g1* found an entry position outside its list: the scalars "
+             "changed between the call's two passes over them (they must stay untouched until the context is synchronised)");
+    return PZ_ERR_ASYNC;
 }
 
 int pz_ws_get(pz_ctx* ctx, int slot, size_t bytes, void** out) {

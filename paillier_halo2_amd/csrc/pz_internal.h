@@ -69,6 +69,10 @@ struct pz_ctx {
     size_t stage_cap[4] = {0, 0, 0, 0};
     hipEvent_t stage_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned stage_next = 0;
+    // asynchronous-failure flag: one word of pinned host memory a kernel sets when it finds an internal invariant broken (the
+    // scatter kernels' position checks, pz_msm.hip); read and cleared by pz_check_async after a synchronisation
+    volatile unsigned* async_err_h = nullptr;
+    volatile unsigned* async_err_d = nullptr;   // the same word as the device addresses it
     std::recursive_mutex mu;   // one context is serialised internally: entry points may be called from any thread
 };
 
@@ -121,6 +125,8 @@ struct pz_timer {
     ~pz_timer();
 };
 
+int pz_async_err_init(pz_ctx* ctx);    // allocates the flag on first use
+int pz_check_async(pz_ctx* ctx);       // after a stream synchronisation: PZ_ERR_ASYNC (and the flag cleared) if a kernel raised it
 const uint64_t* pz_fr_one261();   // Montgomery one times 32: first entry of a power table kept in the 2^261 domain (fp29.cuh)
 int pz_io_init(pz_ctx* ctx);
 // asynchronous host -> device copy of a SMALL host argument (pageable memory the caller may free on return): staged through a

@@ -50,7 +50,18 @@ struct MsmP {
 struct ScatterSel {
     const unsigned long long* total;   // non-zero digits of the launch (all columns)
     unsigned long long thr;            // dense if *total >= thr
+    volatile unsigned* err;            // set when a sorted-entry position lies outside its list (see scatter_bad): pinned HOST memory
 };
+// Every position the scatter kernels store to is DERIVED from the histogram pass's counts (bucket offsets + earlier slices'
+// counts + a rank), so it is only as good as the agreement between the two passes over the scalars: a caller that overwrites
+// the scalars while the call is in flight (the ABI's `_dev` calls are asynchronous), or a defect in a cursor computation, turns
+// into stores past the end of the list -- round 3's one memory-access fault was exactly that, an experimental coarse step whose
+// cursors over-counted.  Positions are therefore checked against the list they belong to before the
+// store (one compare per entry beside an LDS atomic and a 4-byte store), a violation raises a flag in pinned host memory (a plain
+// store over the fabric on the error path only: nothing is copied or polled otherwise) and surfaces as PZ_ERR_ASYNC at the
+// context's next synchronising entry point; k_msm_accumulate clamps the table row it gathers, so a list with holes cannot send
+// a gather outside the table either.
+__device__ __noinline__ void scatter_bad(const ScatterSel& s) { *s.err = 1u; }
 __device__ __forceinline__ bool scatter_dense(const ScatterSel& s) { return *s.total >= s.thr; }
 
 __device__ __forceinline__ u32 sel8(const u32 s[8], unsigned i) {
@@ -389,6 +400,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_msm_scan(const u32* __restrict
 // of lines instead of 64.  Three barriers per round; window width 16 only (the digits of a scalar are kept in registers).
 #define COARSE_THREADS 256u
 #define COARSE_ROUND (COARSE_THREADS * 16u)
+// invariants the kernel's packed words rely on: a round holds at most 16 digits of each of its 256 scalars, so a group's count
+// in a round (the low half of rb[]) is <= COARSE_ROUND = 4096 < 2^16 and a slot index < COARSE_ROUND always; the group id (high half
+// of rb[], the byte in sbin[]) is < SORT_COARSE_MAX = 256; phase 3 hands one counter to each of the COARSE_THREADS threads
+static_assert(COARSE_ROUND <= 65536u && SORT_COARSE_MAX <= 256u && SORT_COARSE_MAX == COARSE_THREADS, "k_msm_scatter_coarse packing");
 __global__ __launch_bounds__(COARSE_THREADS) void k_msm_scatter_coarse(const Fr* __restrict__ scalars, size_t col_stride, MsmP p,
                                                                        const u32* __restrict__ slice_hist, unsigned n_slices,
                                                                        const u32* __restrict__ offs, u32* __restrict__ staged,
@@ -505,7 +520,11 @@ __global__ __launch_bounds__(COARSE_THREADS) void k_msm_scatter_coarse(const Fr*
             if (rd + 1 < rounds && in_ < p.n) nxt = fp_load<FrTag>(scalars + col * col_stride + in_);
         }
         const unsigned total = s_total;
-        for (unsigned sl = threadIdx.x; sl < total; sl += COARSE_THREADS) e[gb[sbin[sl]] + sl] = stage[sl];
+        for (unsigned sl = threadIdx.x; sl < total; sl += COARSE_THREADS) {
+            const u32 pos = gb[sbin[sl]] + sl;
+            if (pos < p.cap) e[pos] = stage[sl];
+            else scatter_bad(sel);
+        }
     }
 }
 
@@ -540,7 +559,8 @@ __global__ __launch_bounds__(FINE_THREADS) void k_msm_scatter_fine(MsmP p, const
             if (j0 + k * FINE_THREADS < hi) {
                 const u32 pos = atomicAdd(&cur[v[k] >> 25], 1u);
                 const u32 e = (v[k] & 0x00ffffffu) | ((v[k] & 0x01000000u) << 7);
-                if (in_lds) buf[pos - lo] = e;
+                if (pos >= hi) scatter_bad(sel);   // beyond the group's region (pos >= lo always: cursors start at bucket offsets)
+                else if (in_lds) buf[pos - lo] = e;
                 else dst[pos] = e;
             }
         }
@@ -781,7 +801,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restri
                     if (w >= p.win_lo && mag != 0) {
                         const u32 pos = atomicAdd(&h[mag - 1], 1u);
                         const bool sgn = neg != (carry != 0);
-                        e[pos] = (u32)((size_t)w * p.n_table + i) | (sgn ? 0x80000000u : 0u);
+                        if (pos < p.cap) e[pos] = (u32)((size_t)w * p.n_table + i) | (sgn ? 0x80000000u : 0u);
+                        else scatter_bad(sel);
                     }
                 }
             }
@@ -792,7 +813,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restri
                     const unsigned b = (d < 0 ? -d : d) - 1;
                     const u32 pos = atomicAdd(&h[b], 1u);
                     const bool sgn = neg != (d < 0);
-                    e[pos] = (u32)((size_t)w * p.n_table + i) | (sgn ? 0x80000000u : 0u);
+                    if (pos < p.cap) e[pos] = (u32)((size_t)w * p.n_table + i) | (sgn ? 0x80000000u : 0u);
+                    else scatter_bad(sel);
                 }
             }
         }
@@ -824,10 +846,12 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const G1Aff64* __restric
     const u32 start = o[b] + j * q + (j < rem ? j : rem);
     const u32 end = start + q + (j < rem ? 1u : 0u);
     const u32* e = entries + col * p.cap;
+    const u32 last_row = (u32)((size_t)p.nwin * p.n_table - 1);   // the gather never leaves the table, whatever the list holds
     G1X29 acc = x29_inf();
     for (u32 k = start; k < end; ++k) {
         u32 ent = e[k];
-        G1A29 q = a29_load64(table + (ent & 0x7fffffffu));
+        const u32 row = ent & 0x7fffffffu;
+        G1A29 q = a29_load64(table + (row < last_row ? row : last_row));
         if ((ent & 0x80000000u) && !a29_is_inf(q)) q.y = a29_neg_y(q.y);
         x29_add_affine(acc, q);
     }
@@ -1540,6 +1564,7 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
     void* dsel;
     PZCHK(pz_ws_get(ctx, WS_SEL, 8, &dsel));
     HIPCHK(ctx, hipMemsetAsync(dsel, 0, 8, st));
+    PZCHK(pz_async_err_init(ctx));
     {
         pz_timer tsort(ctx, PZ_T_MSM_SORT);
         hipLaunchKernelGGL(k_msm_hist, gs, dim3(SORT_THREADS), 0, st, d_scalars, cs, p, (u32*)hist, n_slices, nc);
@@ -1560,6 +1585,7 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
         ScatterSel sel;
         sel.total = (const unsigned long long*)dsel;
         sel.thr = !two_pass ? ~0ull : scatter_mode == 2 ? 0ull : (unsigned long long)(0.4 * (double)nc * (double)p.cap);
+        sel.err = ctx->async_err_d;
         if (two_pass) {
             // the staging list lives in the partial sums' buffer: k_msm_accumulate writes those after the list is consumed
             hipLaunchKernelGGL(k_msm_scatter_coarse, gs, dim3(COARSE_THREADS), 0, st, d_scalars, cs, p, (const u32*)hist, n_slices,
@@ -1763,6 +1789,7 @@ extern "C" int pz_msm_g1_batch(pz_ctx* ctx, const pz_bases* bases, const uint64_
     // the host buffers belong to the caller again when this returns, whatever happened
     hipError_t e1 = hipStreamSynchronize(ctx->io_h2d), e2 = hipStreamSynchronize(ctx->stream);
     if (rc == PZ_OK && (e1 != hipSuccess || e2 != hipSuccess)) rc = pz_hip_fail(ctx, e1 != hipSuccess ? e1 : e2, "pz_msm_g1_batch: synchronize");
+    if (rc == PZ_OK) rc = pz_check_async(ctx);
     return rc;
 }
 

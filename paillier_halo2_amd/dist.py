@@ -41,7 +41,7 @@ def gather_commitments(torch, dist, share, n_cols: int, rank: int, world: int):
     total (474 KB for a c2 proof) -- latency-bound on xGMI, like the 96-byte exchange of the sharded MSM."""
     lo, hi = column_range(n_cols, rank, world)
     assert share.shape[0] == hi - lo
-    if dist is None or world == 1:
+    if dist is None:     # no process group; a group of ONE rank still runs its collective (bench.py --force-dist: the RCCL path on one GPU)
         return share
     per = -(-n_cols // world)
     pad = torch.zeros((per, share.shape[1]), dtype=share.dtype, device=share.device)
@@ -65,7 +65,7 @@ def sharded_msm(torch, dist, rank: int, world: int, n_units: int,
     touches the host (the all-gather lands in a device tensor, the fold is one small kernel)."""
     lo, hi = window_range(n_units, rank, world)
     part = partial_fn(lo, hi).reshape(12).contiguous()
-    if dist is None or world == 1:
+    if dist is None:     # no process group (a group of one rank still all-gathers: the same calls an 8-rank run makes)
         return fold_fn(part.reshape(1, 12))
     parts = torch.empty(world * 12, dtype=part.dtype, device=part.device)
     dist.all_gather_into_tensor(parts, part)

@@ -10,12 +10,21 @@
 //   [0] magic 0x325a50  [1] enc_bits  [2] k  [3] lookup_bits  [4] n_steps  [5] msm_full  [6] polys  [7] pool  [8] ntt_batch
 //   [9] steps  [10] warmup  [11] log_e  [12] seed
 //   then n | g | m | r (Ln words each), res | n^2 (2 Ln words each), s_toxic, omega_n, omega_n_inv, n_inv (4 words each,
-//   Montgomery), coset_gens (2^log_e x 4 words)
+//   Montgomery), coset_gens (2^log_e x 4 words), then [n_extra] and per extra message of the SAME circuit shape: m | r (Ln
+//   words each), res (2 Ln words)
+// Step i proves message i % (1 + n_extra) in witness slot i & 1, as bench.py does.  After the timed loop, untimed, a few more
+// PIPELINED steps keep their outputs and are compared with a SERIAL recomputation (one context, synchronised after every call):
+// every advice / lookup commitment in affine form and the coefficient + extended forms of sampled columns, bit for bit; the line
+// says "verified" and carries a hash of each message's commitments that bench.py compares with its own.
 #include <chrono>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pz.h"
@@ -34,6 +43,7 @@ struct Job {
     std::vector<uint64_t> n, g, m, r, res, n2;
     uint64_t s_toxic[4], omega[4], omega_inv[4], n_inv[4];
     std::vector<uint64_t> gens;
+    std::vector<std::vector<uint64_t>> vm, vr, vres;   // messages of the same shape: [0] = m, r, res above
 };
 
 static Job read_job(const char* path) {
@@ -56,11 +66,27 @@ static Job read_job(const char* path) {
     memcpy(j.omega_inv, &w[p], 32); p += 4;
     memcpy(j.n_inv, &w[p], 32); p += 4;
     take(j.gens, 4u << j.log_e);
+    j.vm.push_back(j.m); j.vr.push_back(j.r); j.vres.push_back(j.res);
+    if (p < w.size()) {
+        const size_t extra = w[p++];
+        for (size_t e = 0; e < extra; ++e) {
+            std::vector<uint64_t> a, b, c;
+            take(a, Ln); take(b, Ln); take(c, 2 * Ln);
+            j.vm.push_back(a); j.vr.push_back(b); j.vres.push_back(c);
+        }
+    }
     if (p != w.size()) { fprintf(stderr, "job file length\n"); exit(2); }
     return j;
 }
 
 // pool of uniformly random field elements below 2^252 (valid Montgomery representatives), like bench.py's _rand_fr
+// FNV-1a over little-endian 64-bit words (the same walk as bench.py's fnv1a64)
+static uint64_t fnv1a64(const uint64_t* w, size_t n_words) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (size_t i = 0; i < n_words; ++i) h = (h ^ w[i]) * 0x100000001B3ull;
+    return h;
+}
+
 static void fill_pool(pz_ctx* ctx, void* d, size_t elems, uint64_t seed) {
     const size_t chunk = (size_t)1 << 22;
     std::vector<uint64_t> h(chunk * 4);
@@ -75,16 +101,34 @@ static void fill_pool(pz_ctx* ctx, void* d, size_t elems, uint64_t seed) {
     }
 }
 
-int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: prove_c2 <job file>\n"); return 2; }
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);   // more than four streams in this process (INTEGRATION.md section 2)
-    const Job J = read_job(argv[1]);
+// all replicas enter the timed region together (and leave the warm-up together): N provers on N devices -- or, on a one-GPU box,
+// N provers time-slicing device 0 -- are timed as ONE job
+struct Gate {
+    std::mutex m;
+    std::condition_variable cv;
+    size_t n, waiting = 0, round = 0;
+    explicit Gate(size_t n_) : n(n_) {}
+    void wait() {
+        std::unique_lock<std::mutex> l(m);
+        const size_t r = round;
+        if (++waiting == n) { waiting = 0; ++round; cv.notify_all(); }
+        else cv.wait(l, [&] { return round != r; });
+    }
+};
+
+struct Result {
+    double value = 0, dt = 0;
+    bool verified = false;
+    std::string json;
+};
+
+// one prover: three contexts on `device`, the two-slot pipeline, J.steps timed steps, then the verification
+static void prove(const Job& J, int device, Gate& gate, Result& out) {
     const size_t Ln = J.enc_bits / 64, L = 2 * Ln, n = (size_t)1 << J.k, rows = n - 10, E = (size_t)1 << J.log_e;
-    if (pz_abi_version() != PZ_ABI_VERSION) { fprintf(stderr, "ABI version mismatch\n"); return 2; }
     pz_ctx *ctx, *ctxw, *ctxn;   // commitments / witness / transforms
-    CK(pz_init(1, nullptr, &ctx));
-    CK(pz_init(1, nullptr, &ctxw));
-    CK(pz_init(1, nullptr, &ctxn));
+    CK(pz_init(1, &device, &ctx));
+    CK(pz_init(1, &device, &ctxw));
+    CK(pz_init(1, &device, &ctxn));
     // circuit shape
     size_t adv_cells, lk_cells;
     uint32_t ng = 0, nr = 0;
@@ -94,8 +138,8 @@ int main(int argc, char** argv) {
     std::vector<uint64_t> c_out(L);
     CK(pz_paillier_encrypt_dev(ctxw, (uint32_t)Ln, 1, J.n.data(), J.g.data(), J.m.data(), J.r.data(), (uint64_t*)d_steps[0], J.n_steps, &ng,
                                &nr, c_out.data()));
-    if (memcmp(c_out.data(), J.res.data(), L * 8) != 0) { fprintf(stderr, "ciphertext mismatch\n"); return 2; }
-    if ((size_t)ng + nr + 1 != J.n_steps) { fprintf(stderr, "step count mismatch\n"); return 2; }
+    if (memcmp(c_out.data(), J.res.data(), L * 8) != 0) { fprintf(stderr, "ciphertext mismatch\n"); exit(2); }
+    if ((size_t)ng + nr + 1 != J.n_steps) { fprintf(stderr, "step count mismatch\n"); exit(2); }
     CK(pz_circuit_cells(0, (uint32_t)Ln, 64, (uint32_t)J.lb, ng, nr, &adv_cells, &lk_cells));
     const size_t adv_cols = (adv_cells + rows - 1) / rows, lk_cols = (lk_cells + rows - 1) / rows;
     void *d_adv[2], *d_lk[2], *d_mod, *d_out_adv, *d_out_full, *d_lagr, *d_pool_f, *d_pool_n, *d_ext;
@@ -125,18 +169,38 @@ int main(int argc, char** argv) {
     fill_pool(ctxn, d_pool_n, J.pool * n, J.seed + 1);
     const size_t ext_cols = J.ntt_batch > 64 ? J.ntt_batch : 64;
     CK(pz_dev_alloc(ctxn, ext_cols * n * E * 32, &d_ext));
-    std::vector<uint64_t> inputs;
-    for (const auto* v : {&J.n, &J.g, &J.m, &J.r, &J.res}) inputs.insert(inputs.end(), v->begin(), v->end());
+    const size_t NV = J.vm.size();
+    std::vector<std::vector<uint64_t>> inputs(NV);
+    for (size_t v = 0; v < NV; ++v)
+        for (const auto* x : {&J.n, &J.g, &J.vm[v], &J.vr[v], &J.vres[v]}) inputs[v].insert(inputs[v].end(), x->begin(), x->end());
+    // what a verification step keeps: commitments of its own, sampled columns' coefficient and extended forms
+    struct Keep {
+        void *adv = nullptr, *lk = nullptr, *coef = nullptr, *ext = nullptr;
+    };
+    const size_t samp_buf[5] = {0, 0, 0, 1, 1};
+    const size_t samp_col[5] = {0, adv_cols / 2, adv_cols - 1, 0, lk_cols ? lk_cols - 1 : 0};
+    const size_t NS = lk_cols ? 5 : 3;
+    auto new_keep = [&](pz_ctx* c) {
+        Keep k;
+        CK(pz_dev_alloc(c, adv_cols * 96, &k.adv));
+        CK(pz_dev_alloc(c, (lk_cols ? lk_cols : 1) * 96, &k.lk));
+        CK(pz_dev_alloc(c, NS * n * 32, &k.coef));
+        CK(pz_dev_alloc(c, NS * n * E * 32, &k.ext));
+        return k;
+    };
 
-    auto produce = [&](int slot) {   // K3 + K4 on the witness context
-        CK(pz_paillier_encrypt_dev(ctxw, (uint32_t)Ln, 1, J.n.data(), J.g.data(), J.m.data(), J.r.data(), (uint64_t*)d_steps[slot], J.n_steps,
+    // K3 + K4 of message v into witness slot `slot`, on context c (the witness context in the pipeline)
+    auto produce_on = [&](pz_ctx* c, int slot, size_t v) {
+        CK(pz_paillier_encrypt_dev(c, (uint32_t)Ln, 1, J.n.data(), J.g.data(), J.vm[v].data(), J.vr[v].data(), (uint64_t*)d_steps[slot], J.n_steps,
                                    &ng, &nr, c_out.data()));
-        CK(pz_circuit_expand_dev(ctxw, 0, (uint32_t)Ln, 64, (uint32_t)J.lb, inputs.data(), (const uint64_t*)d_steps[slot], ng, nr,
+        if (memcmp(c_out.data(), J.vres[v].data(), L * 8) != 0) { fprintf(stderr, "ciphertext mismatch (message %zu)\n", v); exit(2); }
+        CK(pz_circuit_expand_dev(c, 0, (uint32_t)Ln, 64, (uint32_t)J.lb, inputs[v].data(), (const uint64_t*)d_steps[slot], ng, nr,
                                  (const uint64_t*)d_mod, (uint64_t*)d_adv[slot], (uint64_t*)d_lk[slot], rows, n));
     };
-    auto consume = [&](int slot) {   // K1 on the commitment context, K2 on the transform context
-        CK(pz_msm_g1_dev(ctx, bases, (const uint64_t*)d_adv[slot], adv_cols, n, 4 * n, 0, nwin, (uint64_t*)d_out_adv));
-        CK(pz_msm_g1_dev(ctx, bases, (const uint64_t*)d_lk[slot], lk_cols, n, 4 * n, 0, nwin, (uint64_t*)d_out_adv));
+    auto produce = [&](int slot, size_t v) { produce_on(ctxw, slot, v); };
+    auto consume = [&](int slot, const Keep* keep) {   // K1 on the commitment context, K2 on the transform context
+        CK(pz_msm_g1_dev(ctx, bases, (const uint64_t*)d_adv[slot], adv_cols, n, 4 * n, 0, nwin, (uint64_t*)(keep ? keep->adv : d_out_adv)));
+        CK(pz_msm_g1_dev(ctx, bases, (const uint64_t*)d_lk[slot], lk_cols, n, 4 * n, 0, nwin, (uint64_t*)(keep ? keep->lk : d_out_adv)));
         for (size_t done = 0; done < J.msm_full;) {
             const size_t nc = J.msm_full - done < J.pool ? J.msm_full - done : J.pool;
             CK(pz_msm_g1_dev(ctx, bases, (const uint64_t*)d_pool_f, nc, n, 4 * n, 0, nwin, (uint64_t*)d_out_full + done * 12));
@@ -155,6 +219,12 @@ int main(int argc, char** argv) {
                                     nullptr, J.n_inv));   // lagrange_to_coeff: the 1/n belongs to the inverse transform (and costs nothing there)
                 CK(pz_ntt_fr_extend_dev(ctxn, (const uint64_t*)d_pool_n, nc, 4 * n, (uint64_t*)d_ext, 4 * n * E, (uint32_t)J.k, (uint32_t)J.log_e,
                                         J.omega, J.gens.data(), nullptr));
+                if (keep)   // sampled columns of this batch, copied out behind the transforms (same context, same stream)
+                    for (size_t s_ = 0; s_ < NS; ++s_)
+                        if (samp_buf[s_] == (size_t)b && samp_col[s_] >= c0 && samp_col[s_] < c0 + nc) {
+                            CK(pz_dev_copy(ctxn, (char*)keep->coef + s_ * n * 32, (const char*)d_pool_n + (samp_col[s_] - c0) * n * 32, n * 32));
+                            CK(pz_dev_copy(ctxn, (char*)keep->ext + s_ * n * E * 32, (const char*)d_ext + (samp_col[s_] - c0) * n * E * 32, n * E * 32));
+                        }
                 c0 += nc;
                 done += nc;
             }
@@ -169,35 +239,159 @@ int main(int argc, char** argv) {
             done += nc;
         }
     };
-    auto run = [&](size_t steps) {
+    size_t steps_done = 0;
+    const char* drop = getenv("PZ_PROVE_DROP_EDGE");   // negative test of the verification only: "ready" / "free"
+    const bool drop_ready = drop && !strcmp(drop, "ready"), drop_free = drop && !strcmp(drop, "free");
+    auto run = [&](size_t steps, const std::vector<Keep>* keeps) {
         if (!steps) return;
-        produce(0);
+        const size_t base = steps_done;
+        steps_done += steps;
+        produce(0, base % NV);
         for (size_t i = 0; i < steps; ++i) {
-            CK(pz_ctx_wait(ctxw, ctx));    // the witness of proof i+1 may overwrite its slot once proof i-1's commitments ...
-            CK(pz_ctx_wait(ctxw, ctxn));   // ... and transforms have read it
-            CK(pz_ctx_wait(ctx, ctxw));    // proof i's commitments and transforms read the columns K4 wrote
-            CK(pz_ctx_wait(ctxn, ctxw));
-            consume((int)(i & 1));
-            if (i + 1 < steps) produce((int)((i + 1) & 1));
+            if (!drop_free) {
+                CK(pz_ctx_wait(ctxw, ctx));    // the witness of proof i+1 may overwrite its slot once proof i-1's commitments ...
+                CK(pz_ctx_wait(ctxw, ctxn));   // ... and transforms have read it
+            }
+            if (!drop_ready) {
+                CK(pz_ctx_wait(ctx, ctxw));    // proof i's commitments and transforms read the columns K4 wrote
+                CK(pz_ctx_wait(ctxn, ctxw));
+            }
+            consume((int)(i & 1), keeps ? &(*keeps)[i] : nullptr);
+            if (i + 1 < steps) produce((int)((i + 1) & 1), (base + i + 1) % NV);
         }
     };
     auto sync_all = [&]() { CK(pz_sync(ctxw)); CK(pz_sync(ctx)); CK(pz_sync(ctxn)); };
-    run(J.warmup);
+    run(J.warmup, nullptr);
     sync_all();
+    gate.wait();
     const auto t0 = std::chrono::steady_clock::now();
-    run(J.steps);
+    run(J.steps, nullptr);
     sync_all();
+    gate.wait();   // the job ends when its slowest replica does
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+
+    // ---- verification (untimed): VSTEPS more pipelined steps keeping their outputs, against a serial recomputation
+    const size_t VSTEPS = 4;
+    std::vector<Keep> keeps;
+    for (size_t i = 0; i < VSTEPS; ++i) keeps.push_back(new_keep(ctx));
+    const size_t vbase = steps_done;
+    run(VSTEPS, &keeps);
+    sync_all();
+    bool verified = true;
+    char mismatch[256] = "";
+    auto fail = [&](size_t step, size_t v, const char* what, size_t idx) {
+        if (verified) snprintf(mismatch, sizeof mismatch, "step %zu (message %zu): %s %zu", step, v, what, idx);
+        verified = false;
+    };
+    auto affine = [&](const void* d_jac, size_t cnt) {
+        std::vector<uint64_t> jac(cnt * 12), aff(cnt * 8);
+        if (!cnt) return aff;
+        CK(pz_download(ctx, jac.data(), d_jac, cnt * 96));
+        CK(pz_g1_normalize(ctx, jac.data(), cnt, aff.data()));
+        return aff;
+    };
+    std::vector<Keep> refs(NV);
+    std::vector<std::vector<uint64_t>> ref_adv(NV), ref_lk(NV);
+    std::vector<bool> have(NV, false);
+    std::vector<uint64_t> hashes(NV, 0);
+    std::vector<uint64_t> ha, hb;
+    for (size_t i = 0; i < VSTEPS; ++i) {
+        const size_t v = (vbase + i) % NV;
+        if (!have[v]) {   // serial: ONE context, a synchronisation after every call
+            have[v] = true;
+            refs[v] = new_keep(ctx);
+            produce_on(ctx, 0, v);
+            CK(pz_sync(ctx));
+            CK(pz_msm_g1_dev(ctx, bases, (const uint64_t*)d_adv[0], adv_cols, n, 4 * n, 0, nwin, (uint64_t*)refs[v].adv));
+            CK(pz_sync(ctx));
+            CK(pz_msm_g1_dev(ctx, bases, (const uint64_t*)d_lk[0], lk_cols, n, 4 * n, 0, nwin, (uint64_t*)refs[v].lk));
+            CK(pz_sync(ctx));
+            for (size_t s_ = 0; s_ < NS; ++s_) {
+                const uint64_t* col = (const uint64_t*)(samp_buf[s_] ? d_lk[0] : d_adv[0]) + samp_col[s_] * n * 4;
+                uint64_t* cf = (uint64_t*)refs[v].coef + s_ * n * 4;
+                CK(pz_ntt_fr_to_dev(ctx, col, 4 * n, cf, 4 * n, 1, J.omega_inv, (uint32_t)J.k, nullptr, J.n_inv));
+                CK(pz_sync(ctx));
+                CK(pz_ntt_fr_extend_dev(ctx, cf, 1, 4 * n, (uint64_t*)refs[v].ext + s_ * n * E * 4, 4 * n * E, (uint32_t)J.k, (uint32_t)J.log_e, J.omega,
+                                        J.gens.data(), nullptr));
+                CK(pz_sync(ctx));
+            }
+            ref_adv[v] = affine(refs[v].adv, adv_cols);
+            ref_lk[v] = affine(refs[v].lk, lk_cols);
+            std::vector<uint64_t> both(ref_adv[v]);
+            both.insert(both.end(), ref_lk[v].begin(), ref_lk[v].end());
+            hashes[v] = fnv1a64(both.data(), both.size());
+        }
+        const std::vector<uint64_t> ga = affine(keeps[i].adv, adv_cols), gl = affine(keeps[i].lk, lk_cols);
+        for (size_t c = 0; c < adv_cols; ++c)
+            if (memcmp(&ga[c * 8], &ref_adv[v][c * 8], 64)) { fail(i, v, "advice commitment", c); break; }
+        for (size_t c = 0; c < lk_cols; ++c)
+            if (memcmp(&gl[c * 8], &ref_lk[v][c * 8], 64)) { fail(i, v, "lookup commitment", c); break; }
+        for (size_t s_ = 0; s_ < NS; ++s_) {
+            ha.resize(n * E * 4); hb.resize(n * E * 4);
+            CK(pz_download(ctx, ha.data(), (const char*)keeps[i].coef + s_ * n * 32, n * 32));
+            CK(pz_download(ctx, hb.data(), (const char*)refs[v].coef + s_ * n * 32, n * 32));
+            if (memcmp(ha.data(), hb.data(), n * 32)) fail(i, v, "coefficient form of sample", s_);
+            CK(pz_download(ctx, ha.data(), (const char*)keeps[i].ext + s_ * n * E * 32, n * E * 32));
+            CK(pz_download(ctx, hb.data(), (const char*)refs[v].ext + s_ * n * E * 32, n * E * 32));
+            if (memcmp(ha.data(), hb.data(), n * E * 32)) fail(i, v, "extended form of sample", s_);
+        }
+    }
     // one commitment back to the host: the data a transcript would absorb
     std::vector<uint64_t> first(12);
     CK(pz_download(ctx, first.data(), d_out_adv, 96));
-    printf("{\"value\": %.6f, \"unit\": \"proofs/s\", \"steps\": %zu, \"warmup\": %zu, \"ms_per_step\": %.3f, \"advice_cols\": %zu, "
-           "\"lookup_cols\": %zu, \"msm_full\": %zu, \"polys\": %zu, \"mul_mod_steps\": %zu, \"first_commitment_x_limb0\": %llu}\n",
+    char buf[2048];
+    int len = snprintf(buf, sizeof buf,
+           "{\"value\": %.6f, \"unit\": \"proofs/s\", \"steps\": %zu, \"warmup\": %zu, \"ms_per_step\": %.3f, \"advice_cols\": %zu, "
+           "\"lookup_cols\": %zu, \"msm_full\": %zu, \"polys\": %zu, \"mul_mod_steps\": %zu, \"first_commitment_x_limb0\": %llu, \"device\": %d, "
+           "\"verified\": %s, \"pipelined_steps_checked\": %zu, \"messages\": %zu, \"mismatch\": \"%s\", \"commitment_hash_by_message\": {",
            J.steps / dt, (size_t)J.steps, (size_t)J.warmup, dt / J.steps * 1e3, adv_cols, lk_cols, (size_t)J.msm_full, (size_t)J.polys,
-           (size_t)J.n_steps, (unsigned long long)first[0]);
+           (size_t)J.n_steps, (unsigned long long)first[0], device, verified ? "true" : "false", VSTEPS, NV, mismatch);
+    bool first_h = true;
+    for (size_t v = 0; v < NV; ++v)
+        if (have[v]) {
+            len += snprintf(buf + len, sizeof buf - len, "%s\"%zu\": \"%016llx\"", first_h ? "" : ", ", v, (unsigned long long)hashes[v]);
+            first_h = false;
+        }
+    snprintf(buf + len, sizeof buf - len, "}}");
+    out.json = buf;
+    out.value = J.steps / dt;
+    out.dt = dt;
+    out.verified = verified;
     pz_bases_free(ctx, bases);
     pz_free(ctxn);
     pz_free(ctxw);
     pz_free(ctx);
+}
+
+// usage: prove_c2 <job file> [replicas] [dev0,dev1,...]
+//   replicas > 1: config c5 / the weak-scaling headline from plain C++ -- N independent provers (one host thread each, its own three
+//   contexts) on the listed devices (cycled: a one-GPU box runs them all on device 0), entering the timed region together; the line
+//   carries the aggregate proofs/s and every replica's own line.  Replicas are proofs of the same job: their commitment hashes agree.
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: prove_c2 <job file> [replicas] [devices]\n"); return 2; }
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);   // more than four streams in this process (INTEGRATION.md section 2)
+    const Job J = read_job(argv[1]);
+    if (pz_abi_version() != PZ_ABI_VERSION) { fprintf(stderr, "ABI version mismatch\n"); return 2; }
+    const size_t replicas = argc > 2 ? (size_t)atoi(argv[2]) : 1;
+    std::vector<int> devs;
+    if (argc > 3) for (char* t = strtok(argv[3], ","); t; t = strtok(nullptr, ",")) devs.push_back(atoi(t));
+    if (devs.empty()) devs.push_back(0);
+    if (replicas < 1 || replicas > 64) { fprintf(stderr, "bad replica count\n"); return 2; }
+    Gate gate(replicas);
+    std::vector<Result> res(replicas);
+    std::vector<std::thread> th;
+    for (size_t r = 0; r < replicas; ++r) th.emplace_back([&, r] { prove(J, devs[r % devs.size()], gate, res[r]); });
+    for (auto& t : th) t.join();
+    if (replicas == 1) {
+        printf("%s\n", res[0].json.c_str());
+        return 0;
+    }
+    double dt = 0;
+    bool all = true;
+    for (auto& r : res) { dt = r.dt > dt ? r.dt : dt; all = all && r.verified; }
+    printf("{\"value\": %.6f, \"unit\": \"proofs/s\", \"replicas\": %zu, \"devices\": %zu, \"steps\": %zu, \"ms_per_step\": %.3f, \"verified\": %s, "
+           "\"per_replica\": [", replicas * J.steps / dt, replicas, devs.size(), (size_t)J.steps, dt / J.steps * 1e3, all ? "true" : "false");
+    for (size_t r = 0; r < replicas; ++r) printf("%s%s", r ? ", " : "", res[r].json.c_str());
+    printf("]}\n");
     return 0;
 }

@@ -54,3 +54,11 @@ def test_single_rank_without_launcher():
     assert p.returncode == 0, p.stderr[-2000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1
+
+
+def test_force_dist_single_rank_creates_the_group():
+    """--gpus 1 --force-dist: one rank, still through the launcher and a process group (what the GPU test runs with backend nccl)"""
+    p = _run(["--gpus", "1", "--force-dist", "--steps", "2", "--warmup", "0", "--workload", "stub", "--backend", "gloo"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["backend"] == "gloo"
