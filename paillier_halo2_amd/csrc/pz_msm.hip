@@ -1093,36 +1093,11 @@ __global__ __launch_bounds__(128) void k_msm_reduce_l1(MsmP p, unsigned m, const
     x29_store_raw(&o->S, run);
 }
 
-// The same two kernels with every addition done by a QUAD (ec29_quad.cuh): a lane-serial walk is a chain of 2m dependent
-// additions of 14 dependent products each, and with 168 VGPRs only 2-3 such chains share a SIMD (~50 % of the issue rate, DESIGN.md
-// section 10); a quad's addition is 4 products deep.  Measured on 256 + 512 columns of 2^17 (profiles/r03_ab_tree_quad_vs_lane.txt):
-// the combine levels (few nodes: latency-bound) go 470 -> 240 us per launch with quads; level 1 (8 waves/SIMD of nodes: already
-// throughput-bound, and the lane walk skips empty buckets and the infinity cases) goes 2.23 -> 3.48 ms.  So the default is lane
-// level 1 + quad combines; PZ_MSM_TREE=lane / =quad select all-lane / all-quad (A/B).
-__global__ __launch_bounds__(256) void k_msm_reduce_l1_quad(MsmP p, unsigned m, const u32* __restrict__ items,
-                                                            const G1X29Raw* __restrict__ partials, MsmNode* __restrict__ nodes) {
-    const size_t col = blockIdx.y;
-    const unsigned t = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;   // node = quad
-    const unsigned nn = p.B / m;
-    if (t >= nn) return;                                               // whole quads leave together
-    const u32* it = items + col * (p.B + 1);
-    const G1X29Raw* pc = partials + col * p.max_items;
-    G1X29 run = x29_inf(), acc = x29_inf();
-    for (unsigned j = m; j-- > 0;) {
-        const unsigned b = t * m + j;
-        const u32 a = it[b], z = it[b + 1];
-        if (z > a) {  // merged: the bucket's sum sits in its first partial (replicated test: the quad branches together)
-            const G1X29 v = x29_load_raw(pc + a);
-            x29_add_quad(run, v);
-        }
-        x29_add_quad(acc, run);
-    }
-    if ((threadIdx.x & 3u) == 0) {
-        MsmNode* o = nodes + col * nn + t;
-        x29_store_raw(&o->V, acc);
-        x29_store_raw(&o->S, run);
-    }
-}
+// Upper levels with every addition done by a QUAD of lanes (ec29_quad.cuh): a lane-serial combine is a chain of ~50 dependent
+// additions of 14 dependent products each on a handful of nodes -- latency-bound -- and a quad's addition is 4 products deep:
+// 470 -> 240 us per launch (profiles/r03_ab_tree_quad_vs_lane.txt).  Level 1 stays lane-serial (k_msm_reduce_l1: 8 waves per SIMD
+// of nodes, throughput-bound, skips empty buckets: 2.23 ms against 3.48 with quads).  The arms that lost those A/Bs -- quad level 1,
+// lane combine, the wave-scan level 1 of north_star's wording -- are kept as source under profiles/probes/r03_retired_arms/.
 __global__ __launch_bounds__(256) void k_msm_combine_quad(unsigned n_in, unsigned m, unsigned log_w,
                                                           const MsmNode* __restrict__ in, MsmNode* __restrict__ out) {
     const size_t col = blockIdx.y;
@@ -1148,78 +1123,6 @@ __global__ __launch_bounds__(256) void k_msm_combine_quad(unsigned n_in, unsigne
         x29_store_raw(&o->V, acc);
         x29_store_raw(&o->S, run);
     }
-}
-
-// A/B variant of level 1 (BASELINE north_star: "LDS-staged Pippenger buckets and wavefront-level bucket reduction"): a
-// WAVE owns a tile of 64 consecutive buckets staged in LDS and reduces it with cross-lane scans -- suffix sums
-// R_k = sum_{j >= k} B_j by 6 Hillis-Steele steps, then V = sum_k R_k by a 6-step tree -- instead of one lane walking 16
-// buckets.  Depth 12 point additions instead of 32, but 64 x 12 lane-additions per 64 buckets instead of 128: the
-// throughput comparison is in DESIGN.md section 6.1 (selected by PZ_MSM_REDUCE=wave, never the default).
-__global__ __launch_bounds__(256) void k_msm_reduce_wave(MsmP p, const u32* __restrict__ items,
-                                                         const G1X29Raw* __restrict__ partials, MsmNode* __restrict__ nodes) {
-    __shared__ G1X29Raw s_pt[256];
-    const size_t col = blockIdx.y;
-    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned tile = blockIdx.x * 4 + wave, nn = p.B / 64;
-    G1X29Raw* sp = s_pt + wave * 64;
-    const u32* it = items + col * (p.B + 1);
-    G1X29 v = x29_inf();
-    if (tile < nn) {
-        const unsigned b = tile * 64 + lane;
-        if (it[b + 1] > it[b]) v = x29_load_raw(partials + col * p.max_items + it[b]);
-    }
-    // suffix scan: R_k = sum_{j >= k} B_j
-    for (unsigned off = 1; off < 64; off <<= 1) {
-        x29_store_raw(&sp[lane], v);
-        __syncthreads();
-        if (lane + off < 64) {
-            G1X29 o = x29_load_raw(&sp[lane + off]);
-            x29_add(v, o);
-        }
-        __syncthreads();
-    }
-    const G1X29 S = v;   // lane 0 holds the tile's plain sum
-    // V = sum_k R_k  (= sum_k (k + 1) B_k)
-    for (unsigned off = 32; off > 0; off >>= 1) {
-        x29_store_raw(&sp[lane], v);
-        __syncthreads();
-        if (lane < off) {
-            G1X29 o = x29_load_raw(&sp[lane + off]);
-            x29_add(v, o);
-        }
-        __syncthreads();
-    }
-    if (tile < nn && lane == 0) {
-        MsmNode* o = nodes + col * nn + tile;
-        x29_store_raw(&o->V, v);
-        x29_store_raw(&o->S, S);
-    }
-}
-
-// upper levels: m children of span w buckets each -> V = sum V_k + w * sum k*S_k, S = sum S_k
-__global__ __launch_bounds__(128) void k_msm_combine(unsigned n_in, unsigned m, unsigned log_w,
-                                                     const MsmNode* __restrict__ in, MsmNode* __restrict__ out) {
-    const size_t col = blockIdx.y;
-    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned n_out = n_in / m;
-    if (t >= n_out) return;
-    const MsmNode* c = in + col * n_in + (size_t)t * m;
-    G1X29 run = x29_inf(), acc = x29_inf();
-    for (unsigned k = m; k-- > 1;) {
-        G1X29 s = x29_load_raw(&c[k].S);
-        x29_add(run, s);
-        x29_add(acc, run);
-    }
-    for (unsigned k = 0; k < log_w; ++k) acc = x29_dbl(acc);
-    G1X29 s0 = x29_load_raw(&c[0].S);
-    x29_add(run, s0);
-    for (unsigned k = 0; k < m; ++k) {
-        G1X29 v = x29_load_raw(&c[k].V);
-        x29_add(acc, v);
-    }
-    MsmNode* o = out + col * n_out + t;
-    x29_store_raw(&o->V, acc);
-    x29_store_raw(&o->S, run);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1638,38 +1541,17 @@ static int msm_group(pz_ctx* ctx, const pz_bases* bases, const Fr* d_scalars, si
         HIPCHK(ctx, hipGetLastError());
         return PZ_OK;
     }
-    static int reduce_wave = -1, tree_quad = 1, l1_quad = 0;
-    if (reduce_wave < 0) {
-        const char* e = getenv("PZ_MSM_REDUCE");
-        reduce_wave = (e && !strcmp(e, "wave")) ? 1 : 0;
-        const char* e2 = getenv("PZ_MSM_TREE");
-        tree_quad = (e2 && !strcmp(e2, "lane")) ? 0 : 1;
-        l1_quad = (e2 && !strcmp(e2, "quad")) ? 1 : 0;
-    }
-    unsigned m1_used = m1;
-    if (reduce_wave && p.B >= 64) {   // A/B variant: wave-level scan over LDS-staged tiles of 64 buckets
-        m1_used = 64;
-        n_nodes = p.B / 64;
-        hipLaunchKernelGGL(k_msm_reduce_wave, dim3(pz_div_up(n_nodes, 4), (unsigned)nc), dim3(256), 0, st, p, (const u32*)items,
-                           (const G1X29Raw*)partials, (MsmNode*)na);
-    } else if (l1_quad)
-        hipLaunchKernelGGL(k_msm_reduce_l1_quad, dim3(pz_div_up((size_t)n_nodes * 4, 256), (unsigned)nc), dim3(256), 0, st, p, m1,
-                           (const u32*)items, (const G1X29Raw*)partials, (MsmNode*)na);
-    else
-        hipLaunchKernelGGL(k_msm_reduce_l1, dim3(pz_div_up(n_nodes, 128), (unsigned)nc), dim3(128), 0, st, p, m1,
-                           (const u32*)items, (const G1X29Raw*)partials, (MsmNode*)na);
+    hipLaunchKernelGGL(k_msm_reduce_l1, dim3(pz_div_up(n_nodes, 128), (unsigned)nc), dim3(128), 0, st, p, m1,
+                       (const u32*)items, (const G1X29Raw*)partials, (MsmNode*)na);
+    const unsigned m1_used = m1;
     MsmNode* cur = (MsmNode*)na;
     MsmNode* nxt = (MsmNode*)nb;
     unsigned log_w = 0;
     for (unsigned t = m1_used; t > 1; t >>= 1) ++log_w;
     while (n_nodes > 1) {
         unsigned m = n_nodes >= 16 ? 16 : n_nodes;
-        if (tree_quad)
-            hipLaunchKernelGGL(k_msm_combine_quad, dim3(pz_div_up((size_t)(n_nodes / m) * 4, 256), (unsigned)nc), dim3(256), 0, st, n_nodes, m,
-                               log_w, (const MsmNode*)cur, nxt);
-        else
-            hipLaunchKernelGGL(k_msm_combine, dim3(pz_div_up(n_nodes / m, 128), (unsigned)nc), dim3(128), 0, st, n_nodes, m,
-                               log_w, (const MsmNode*)cur, nxt);
+        hipLaunchKernelGGL(k_msm_combine_quad, dim3(pz_div_up((size_t)(n_nodes / m) * 4, 256), (unsigned)nc), dim3(256), 0, st, n_nodes, m,
+                           log_w, (const MsmNode*)cur, nxt);
         n_nodes /= m;
         for (unsigned t = m; t > 1; t >>= 1) ++log_w;
         MsmNode* tmp = cur;

@@ -684,13 +684,9 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
     PZCHK(pz_get_pow_table_raw(ctx, omega_n, n, &twv, one261()));
     const u32* tw = (const u32*)twv;
     const unsigned npass_ = log_n <= 9 ? 1 : (log_n <= 18 ? 2 : 3);
-    // PZ_NTT_COSET=pre keeps the pre-scale product of the first pass (A/B); default: the coset shift absorbed into its twiddles
-    static int coset_pre = -1;
-    if (coset_pre < 0) {
-        const char* e = getenv("PZ_NTT_COSET");
-        coset_pre = (e && !strcmp(e, "pre")) ? 1 : 0;
-    }
-    const bool absorbed = npass_ > 1 && !coset_pre;
+    // several passes: the coset shift is absorbed into the first pass's twiddles (get_ext_abs_tables); a single-pass transform
+    // (log_n <= 9) keeps the pre-scale product (round 3's A/B switch PZ_NTT_COSET=pre is gone: -2.1 us per polynomial)
+    const bool absorbed = npass_ > 1;
     const unsigned logR_a = npass_ == 2 ? (log_n + 1) / 2 : (log_n + 2) / 3;   // size of the first pass (lg0 / lg[0] below)
     const u32 *pre = nullptr, *stw = nullptr;
     if (absorbed) {
