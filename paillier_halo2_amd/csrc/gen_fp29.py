@@ -24,10 +24,14 @@ def mads(pairs):
     return '    asm("%s"\n        : "+v"(acc)\n        : %s\n        : "vcc");' % ('\\n\\t'.join(lines), ', '.join(ops))
 
 
-def emit_mul(out, name, square):
+def emit_mul(out, name, square, b_scalar=False):
+    """b_scalar: b is a wave-uniform constant given as nine SGPR-resident limbs (const u32 (&b)[9], e.g. a kernel argument): every
+    a_i * b_j mad reads ONE scalar operand, and the nine VGPRs a per-lane copy of the constant would occupy are free"""
     if square:
         out.append("template <class T> __device__ __forceinline__ F29<T> %s(const F29<T>& a) {" % name)
         out.append("    u32 d[9];   // doubled limbs for the cross terms\n#pragma unroll\n    for (int i = 0; i < 9; ++i) d[i] = a.v[i] << 1;")
+    elif b_scalar:
+        out.append("template <class T> __device__ __forceinline__ F29<T> %s(const F29<T>& a, const u32 (&b)[9]) {" % name)
     else:
         out.append("template <class T> __device__ __forceinline__ F29<T> %s(const F29<T>& a, const F29<T>& b) {" % name)
     out.append("    u64 acc = 0;\n    u32 m0, m1, m2, m3, m4, m5, m6, m7, m8;\n    F29<T> r;")
@@ -36,7 +40,7 @@ def emit_mul(out, name, square):
         ps = []
         if not square:
             for i in range(max(0, k - (N - 1)), min(k, N - 1) + 1):
-                ps.append(("a.v[%d]" % i, "v", "b.v[%d]" % (k - i), "v"))
+                ps.append(("a.v[%d]" % i, "v", ("b[%d]" if b_scalar else "b.v[%d]") % (k - i), "s" if b_scalar else "v"))
         else:
             lo = max(0, k - (N - 1))
             for i in range(lo, (k + 1) // 2):      # i < k - i
@@ -62,13 +66,19 @@ def emit_mul(out, name, square):
     out.append("    return r;\n}")
 
 
-def emit_mul2(out, name):
+def emit_mul2(out, name, b_scalar=False):
     """(a*b + c*d) / R' with ONE reduction: both products' columns go into the same accumulator.  Legal when
-    9*(max a limb * max b limb + max c limb * max d limb) + 2^59.8 < 2^64; result tight, value < (va*vb + vc*vd)/(169 p) + p"""
-    out.append("template <class T> __device__ __forceinline__ F29<T> %s(const F29<T>& a, const F29<T>& b, const F29<T>& c, const F29<T>& d) {" % name)
+    9*(max a limb * max b limb + max c limb * max d limb) + 2^59.8 < 2^64; result tight, value < (va*vb + vc*vd)/(169 p) + p.
+    b_scalar: b is a wave-uniform constant in SGPRs (see emit_mul)"""
+    if b_scalar:
+        out.append("template <class T> __device__ __forceinline__ F29<T> %s(const F29<T>& a, const u32 (&b)[9], const F29<T>& c, const F29<T>& d) {" % name)
+    else:
+        out.append("template <class T> __device__ __forceinline__ F29<T> %s(const F29<T>& a, const F29<T>& b, const F29<T>& c, const F29<T>& d) {" % name)
     out.append("    u64 acc = 0;\n    u32 m0, m1, m2, m3, m4, m5, m6, m7, m8;\n    F29<T> r;")
 
     def pairs(x, y, k):
+        if b_scalar and y == "b":
+            return [("%s.v[%d]" % (x, i), "v", "b[%d]" % (k - i), "s") for i in range(max(0, k - (N - 1)), min(k, N - 1) + 1)]
         return [("%s.v[%d]" % (x, i), "v", "%s.v[%d]" % (y, k - i), "v") for i in range(max(0, k - (N - 1)), min(k, N - 1) + 1)]
 
     for k in range(N):
@@ -127,4 +137,8 @@ out.append("")
 emit_mul2(out, "f29_mul2")
 out.append("")
 emit_dot(out, "f29_dot4", 4)
+out.append("")
+emit_mul(out, "f29_mul_s", False, b_scalar=True)
+out.append("")
+emit_mul2(out, "f29_mul2_s", b_scalar=True)
 print("\n".join(out))

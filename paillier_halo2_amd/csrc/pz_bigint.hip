@@ -11,10 +11,16 @@
 // column array shifts one lane down; carries are kept as per-column counters and resolved once
 // per product with a ballot-based carry look-ahead (64-bit scalar add of generate/propagate
 // masks).  Reduction is Barrett with a normalised modulus, so the exact quotient falls out; the
-// reciprocal is computed on the device once per modulus by restoring division.  A workgroup is
-// two waves: wave 0 runs the squaring chain, wave 1 the multiply chain (needed only on set
-// exponent bits), synchronised once per exponent bit.
-// Latency-bound by construction (serial dependency between steps); see DESIGN.md section 5.
+// reciprocal is computed on the device once per modulus by restoring division.
+// The modexp chain (k_pow_mod_chain) is latency-bound by construction -- every step depends on the one before -- and one
+// wavefront is ISSUE-bound inside a product (one VALU instruction per ~4.5 cycles: 64 outer limbs x ~22 instructions), so a
+// product is worked by a TEAM of four wavefronts, one per SIMD of the CU: wave w takes the outer limbs [16w, 16w + 16) of a
+// against all of b, the four partial products meet in LDS (one workgroup barrier per product, double-buffered) and every wave of
+// the team sums them, so all four hold the full result and the O(n) parts of a step (shifts, additions, comparisons) simply run
+// redundantly.  A chain is TWO workgroups (two CUs: with both on one CU their waves halve each other's issue slots): the SQUARER
+// runs sq <- sq^2 for every exponent bit, never waits, and publishes every square through global memory (a release counter); the
+// MULTIPLIER consumes the squares of the set bits (acc <- acc * sq_i) as they appear.  Squarers have the lower workgroup ids, so
+// they are resident before any multiplier starts to wait.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -215,6 +221,213 @@ template <int E> __device__ __noinline__ void ld_mul(LD<E>& lo, LD<E>& hi, const
     (void)ld_add(hi, cv, sh, false);
 }
 
+// ---- the same product by a team of TEAM wavefronts (k_pow_mod_chain).  P_w = sum_{i in slice w} a_i * b * 2^(64 (i - i0_w)), i0_w =
+// w * C / TEAM: C / TEAM low limbs (emitted one per outer iteration) + C high limbs (the column array once its deferred carries are
+// resolved) -- exactly ld_mul's loop over a quarter of the outer limbs.  X = sum_w 2^(64 i0_w) P_w: the low limbs are disjoint
+// (limb m belongs to slice m / (C / TEAM)); high limb t of P_w has weight i0_w + C / TEAM + t.
+#define K3_TEAM 4
+template <int E> struct TeamBuf {         // one buffer of a team's exchange area (two per team: double-buffered)
+    u64 lo[64 * E];                       // emitted low limbs, by absolute limb index
+    u64 sink[64 + 64 / K3_TEAM];          // where lanes 1..63 drop their copy of the per-iteration store (no exec-mask juggling)
+    u64 hi[K3_TEAM][64 * E];              // resolved high limbs of every wave's partial product
+};
+template <int E> struct TeamCtx {
+    TeamBuf<E>* buf;    // this team's two buffers
+    unsigned w;         // this wave's index in the team
+    unsigned parity;    // which buffer the next product uses (advanced by every call, identically in all waves of the team)
+#ifdef PZ_K3_PROF
+    unsigned long long t_loop = 0, t_res = 0, t_bar = 0, t_comb = 0, n_mul = 0;
+#endif
+};
+#ifdef PZ_K3_PROF
+#define K3_T0() const unsigned long long t0_ = clock64()
+#define K3_T(acc, prev) const unsigned long long acc##_now = clock64(); T.acc += acc##_now - prev
+#else
+#define K3_T0()
+#define K3_T(acc, prev)
+#endif
+// (forceinline, like mul_mod below: a TeamCtx / BarrettCtx whose address reaches a real call lives in scratch memory, and every
+// T.parity / B.mu access of the callee becomes a private-memory round trip -- ~2000 clock units per product were exactly that)
+template <int E> __device__ __forceinline__ void ld_mul_team(TeamCtx<E>& T, LD<E>& lo, LD<E>& hi, const LD<E> a, const LD<E> b) {
+    constexpr unsigned C = 64 * E, SL = 64 / K3_TEAM;   // SL outer lanes (SL * E limbs) per wave
+    u64 col[E];
+    u32 cc[E];
+    LD<E> plo;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        col[e] = 0;
+        cc[e] = 0;
+        plo.v[e] = 0;
+    }
+    const unsigned lane = lane_id();
+    const unsigned j0 = T.w * SL;
+    K3_T0();
+    TeamBuf<E>& B = T.buf[T.parity & 1u];
+    T.parity ^= 1u;
+    if constexpr (E == 1) {
+        // The same systolic step on 32-bit words with explicit carries: hipcc's code for the u64 version below is ~38 VALU instructions
+        // per outer limb (64-bit additions as v_lshl_add_u64 at ~9.5 cycles, carries by 64-bit compares); this one is 5 mads + 2 DPP
+        // moves + 2 readlanes + 6 carry instructions.  Column of this lane: (c1:c0) + c2 * 2^64; the finished low limb of every
+        // iteration is lane 0's column, stored straight into the team's exchange area.
+        const u32 b0 = (u32)b.v[0], b1 = (u32)(b.v[0] >> 32);
+        const u32 a_lo = (u32)a.v[0], a_hi = (u32)(a.v[0] >> 32);
+        // (1) the SL products A_jj * b of this wave's outer limbs: four mads each, independent of the column chain and of each other,
+        // so they issue back to back (a mad's result is ~20 cycles away: chained through the column they made the loop latency-bound)
+        u32 p0[SL], p1[SL], p2[SL], p3[SL];
+        const u32 one = 1u;
+#pragma unroll
+        for (unsigned jl = 0; jl < SL; ++jl) {
+            const unsigned jj = j0 + jl;
+            const u32 A0 = __builtin_amdgcn_readlane(a_lo, jj), A1 = __builtin_amdgcn_readlane(a_hi, jj);
+            u64 xx = 0;
+            asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(xx) : "s"(A0), "v"(b0) : "vcc");
+            u64 y = xx >> 32;
+            asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(y) : "s"(A0), "v"(b1) : "vcc");
+            u64 z = (u32)y;
+            asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(z) : "s"(A1), "v"(b0) : "vcc");
+            u64 w = y >> 32;
+            asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w) : "s"(A1), "v"(b1) : "vcc");
+            const u32 zh = (u32)(z >> 32);
+            asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w) : "v"(zh), "v"(one) : "vcc");   // A * b < 2^128: no carry out
+            p0[jl] = (u32)xx;
+            p1[jl] = (u32)z;
+            p2[jl] = (u32)w;
+            p3[jl] = (u32)(w >> 32);
+        }
+        // (2) the column chain: additions only
+        u32 c0 = 0, c1 = 0, c2 = 0;
+        volatile u64* lo_dst = lane == 0 ? &B.lo[j0] : &B.sink[lane];   // one ds_write_b64 with an immediate offset per iteration
+#pragma unroll
+        for (unsigned jl = 0; jl < SL; ++jl) {
+            asm("v_add_co_u32 %0, vcc, %0, %3\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %4, vcc\n\ts_nop 1\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc"
+                : "+v"(c0), "+v"(c1), "+v"(c2) : "v"(p0[jl]), "v"(p1[jl]) : "vcc");
+            lo_dst[jl] = ((u64)c1 << 32) | c0;     // lane 0: the finished low limb of this outer limb; other lanes: into the sink
+            // shift one limb down: new column = column of lane + 1 (without its overflow count) + high half of the product + this
+            // lane's overflow count
+            u32 t0 = dpp_down1(c0), t1 = dpp_down1(c1), k = 0;
+            asm("v_add_co_u32 %0, vcc, %0, %3\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %4, vcc\n\ts_nop 1\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc"
+                : "+v"(t0), "+v"(t1), "+v"(k) : "v"(p2[jl]), "v"(p3[jl]) : "vcc");
+            asm("v_add_co_u32 %0, vcc, %0, %3\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\ts_nop 1\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc"
+                : "+v"(t0), "+v"(t1), "+v"(k) : "v"(c2) : "vcc");
+            c0 = t0;
+            c1 = t1;
+            c2 = k;
+        }
+        const u64 x = ((u64)c1 << 32) | c0;
+        col[0] = x;
+        cc[0] = c2;
+    } else {
+#ifndef PZ_K3_TEAM_UNROLL
+#define PZ_K3_TEAM_UNROLL 16
+#endif
+#pragma unroll PZ_K3_TEAM_UNROLL
+    for (unsigned jl = 0; jl < SL; ++jl) {
+        const unsigned jj = j0 + jl;    // wave-uniform: v_readlane takes it from an SGPR
+#pragma unroll
+        for (int ee = 0; ee < E; ++ee) {
+            const u64 A = bcast64(a.v[ee], jj);
+            u64 pend = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                u64 ph, pl;
+                mul64(A, b.v[e], ph, pl);
+                u64 t = col[e] + pl;
+                cc[e] += t < pl;
+                col[e] = t;
+                if (e + 1 < E) {
+                    u64 t2 = col[e + 1] + ph;
+                    cc[e + 1] += t2 < ph;
+                    col[e + 1] = t2;
+                } else {
+                    pend = ph;
+                }
+            }
+            const u64 emit = bcast64(col[0], 0);
+            if (lane == jj) plo.v[ee] = emit;
+            const u64 n0 = shfl_down1(col[0]);
+            u64 ncol[E];
+            u32 ncc[E];
+#pragma unroll
+            for (int e = 0; e + 1 < E; ++e) {
+                u64 t = col[e + 1] + cc[e];
+                ncc[e] = (t < col[e + 1]);
+                ncol[e] = t;
+            }
+            {
+                u64 t = n0 + pend;
+                u32 k = (t < pend);
+                u64 t2 = t + cc[E - 1];
+                k += t2 < t;
+                ncol[E - 1] = t2;
+                ncc[E - 1] = k;
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                col[e] = ncol[e];
+                cc[e] = ncc[e];
+            }
+        }
+    }
+    }
+    K3_T(t_loop, t0_);
+    // this wave's high limbs: col + (cc shifted up by one limb); cannot carry out (P_w < 2^(64 (C + SL E)))
+    LD<E> cv, sh, ph_;
+#pragma unroll
+    for (int e = 0; e < E; ++e) cv.v[e] = col[e];
+    sh.v[0] = shfl_up1((u64)cc[E - 1]);
+#pragma unroll
+    for (int e = 1; e < E; ++e) sh.v[e] = cc[e - 1];
+    (void)ld_add(ph_, cv, sh, false);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (E > 1 && lane >= j0 && lane < j0 + SL) B.lo[lane * E + e] = plo.v[e];   // (E == 1: stored inside the loop)
+        B.hi[T.w][lane * E + e] = ph_.v[e];
+    }
+    K3_T(t_res, t_loop_now);
+    __syncthreads();   // the team is the workgroup
+    K3_T(t_bar, t_res_now);
+    // every wave sums the partials: limb m = lane * E + e of the low half, m + C of the high half; carries are counted per limb
+    // (at most TEAM per limb) and resolved by two look-ahead additions
+    LD<E> s_lo, s_hi, c_lo, c_hi;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const unsigned m = lane * E + e;
+        u64 sl = B.lo[m], cl = 0, sh_ = 0, ch = 0;
+#pragma unroll
+        for (unsigned w = 0; w < K3_TEAM; ++w) {
+            const unsigned off = (w + 1) * SL * E;   // weight of that partial's first high limb
+            if (m >= off) {               // low half: t = m - off < C always
+                const u64 v = B.hi[w][m - off];
+                sl += v;
+                cl += sl < v;
+            }
+            if (m + C - off < C) {        // high half: t = m + C - off
+                const u64 v = B.hi[w][m + C - off];
+                sh_ += v;
+                ch += sh_ < v;
+            }
+        }
+        s_lo.v[e] = sl; c_lo.v[e] = cl; s_hi.v[e] = sh_; c_hi.v[e] = ch;
+    }
+    // X = S + (carry counts shifted up one limb): low half, then the high half with the low half's carry out
+    LD<E> k_lo, k_hi;
+    const u64 top_cnt = bcast64(c_lo.v[E - 1], 63);    // count of the low half's top limb moves into the high half's limb 0
+    k_lo.v[0] = shfl_up1(c_lo.v[E - 1]);
+    k_hi.v[0] = shfl_up1(c_hi.v[E - 1]);
+    if (lane == 0) k_hi.v[0] = top_cnt;
+#pragma unroll
+    for (int e = 1; e < E; ++e) {
+        k_lo.v[e] = c_lo.v[e - 1];
+        k_hi.v[e] = c_hi.v[e - 1];
+    }
+    const bool co = ld_add(lo, s_lo, k_lo, false);
+    (void)ld_add(hi, s_hi, k_hi, co);
+    K3_T(t_comb, t_bar_now);
+#ifdef PZ_K3_PROF
+    T.n_mul++;
+#endif
+}
+
 // per-wave LDS scratch: 4*64*E u64 (a 2C-limb value twice)
 template <int E> struct BarrettCtx {
     LD<E> M;      // modulus << s (top bit of the capacity set)
@@ -230,6 +443,21 @@ __device__ __forceinline__ bool shl_2c(const BarrettCtx<E>& B, LD<E>& ylo, LD<E>
     constexpr unsigned C = 64 * E;
     const unsigned ls = B.s >> 6, bs = B.s & 63;
     const unsigned lane = lane_id();
+    if (E == 1 && ls == 0) {
+        // a shift below one limb (a modulus that nearly fills the capacity: n^2 of a full-size key): neighbours by DPP, no LDS round trip
+        if (bs == 0) {
+            ylo = xlo;
+            yhi = xhi;
+            return false;
+        }
+        const u64 pl = shfl_up1(xlo.v[0]);
+        u64 ph = shfl_up1(xhi.v[0]);
+        const u64 top_lo = bcast64(xlo.v[0], 63), top_hi = bcast64(xhi.v[0], 63);
+        if (lane == 0) ph = top_lo;
+        ylo.v[0] = (xlo.v[0] << bs) | (pl >> (64 - bs));
+        yhi.v[0] = (xhi.v[0] << bs) | (ph >> (64 - bs));
+        return (top_hi >> (64 - bs)) != 0;
+    }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         B.sm[lane * E + e] = xlo.v[e];
@@ -260,6 +488,12 @@ template <int E> __device__ __forceinline__ LD<E> shr_c(const BarrettCtx<E>& B, 
     constexpr unsigned C = 64 * E;
     const unsigned ls = B.s >> 6, bs = B.s & 63;
     const unsigned lane = lane_id();
+    if (E == 1 && ls == 0) {   // see shl_2c
+        if (bs == 0) return x;
+        LD<E> y;
+        y.v[0] = (x.v[0] >> bs) | (shfl_down1(x.v[0]) << (64 - bs));
+        return y;
+    }
 #pragma unroll
     for (int e = 0; e < E; ++e) B.sm[lane * E + e] = x.v[e];
     __builtin_amdgcn_wave_barrier();
@@ -310,7 +544,7 @@ template <int E> __device__ __forceinline__ unsigned ld_bitlen(const LD<E>& a) {
 }
 
 // Barrett constants for modulus m (must be non-zero): returns false if m == 0
-template <int E> __device__ __noinline__ bool barrett_setup(BarrettCtx<E>& B, const LD<E> m) {
+template <int E> __device__ __forceinline__ bool barrett_setup(BarrettCtx<E>& B, const LD<E> m) {   // (inlined: B stays in registers)
     constexpr unsigned N = 64 * 64 * E;
     const unsigned bl = ld_bitlen(m);
     if (bl == 0) return false;
@@ -351,24 +585,54 @@ template <int E> __device__ __noinline__ bool barrett_setup(BarrettCtx<E>& B, co
 
 enum { ST_OK = 0, ST_RANGE = 1, ST_ZERO_MOD = 2, ST_INTERNAL = 4 };
 
+// the product routine of a mul_mod: one wave on its own (k_mul_mod) or a team of waves (k_pow_mod_chain)
+template <int E> struct SoloMul {
+    __device__ __forceinline__ void operator()(LD<E>& lo, LD<E>& hi, const LD<E>& a, const LD<E>& b) { ld_mul(lo, hi, a, b); }
+};
+template <int E> struct TeamMul {
+    TeamCtx<E>* T;
+    __device__ __forceinline__ void operator()(LD<E>& lo, LD<E>& hi, const LD<E>& a, const LD<E>& b) { ld_mul_team(*T, lo, hi, a, b); }
+};
+#ifdef PZ_K3_PROF
+__device__ unsigned long long g_k3_phase[16];
+#define K3_STAMP(i)                                                             \
+    do {                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                      \
+        const unsigned long long now_ = clock64();                              \
+        __builtin_amdgcn_sched_barrier(0);                                      \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_k3_phase[i] += now_ - last_; \
+        last_ = now_;                                                           \
+    } while (0)
+#define K3_STAMP0() unsigned long long last_ = clock64()
+#else
+#define K3_STAMP(i)
+#define K3_STAMP0()
+#endif
 // (q, r) = divmod(a*b, modulus).  Returns status bits.
-template <int E>
-__device__ __noinline__ unsigned mul_mod(const BarrettCtx<E>& B, LD<E>& q, LD<E>& r, const LD<E> a, const LD<E> b) {
+template <int E, class Mul>
+__device__ __forceinline__ unsigned mul_mod(const BarrettCtx<E>& B, LD<E>& q, LD<E>& r, const LD<E> a, const LD<E> b, Mul ld_mul) {
     unsigned st = ST_OK;
+    K3_STAMP0();
     LD<E> xlo, xhi;
     ld_mul(xlo, xhi, a, b);
+    K3_STAMP(0);
     LD<E> ylo, yhi;
     if (shl_2c(B, ylo, yhi, xlo, xhi)) st |= ST_RANGE;  // quotient cannot fit the capacity
+    K3_STAMP(1);
     // qhat = yhi + hi(yhi * mu)
     LD<E> plo, phi;
     ld_mul(plo, phi, yhi, B.mu);
+    K3_STAMP(2);
     LD<E> qh;
     if (ld_add(qh, yhi, phi, false)) st |= ST_RANGE;
+    K3_STAMP(3);
     // r' = y - qhat*M'  (low capacity limbs + one limb above)
     LD<E> zlo, zhi;
     ld_mul(zlo, zhi, qh, B.M);
+    K3_STAMP(4);
     LD<E> rr;
     const bool b0 = ld_sub(rr, ylo, zlo);
+    K3_STAMP(5);
     u64 top = bcast64(yhi.v[0], 0) - bcast64(zhi.v[0], 0) - (b0 ? 1ull : 0ull);
     for (int it = 0; it < 8; ++it) {
         LD<E> d;
@@ -380,9 +644,11 @@ __device__ __noinline__ unsigned mul_mod(const BarrettCtx<E>& B, LD<E>& q, LD<E>
         LD<E> z = ld_zero<E>();
         if (ld_add(qh, qh, z, true)) st |= ST_RANGE;
     }
+    K3_STAMP(6);
     r = shr_c(B, rr);
     q = qh;
     if (ld_exceeds(q, B.limbs)) st |= ST_RANGE;
+    K3_STAMP(7);
     return st;
 }
 
@@ -403,14 +669,26 @@ struct ChainDesc {
     u32 steps_cap;
     u32 uniform_bits;    // != 0: pow_mod with the exponent's bits IN the circuit: exactly this many
                          // bits, per bit the step (acc, sq) then the step (sq, sq); acc takes the product only if the bit is set
+    u64* sq_buf;         // hand-off from the squarer to the multiplier: square i at sq_buf + i * L (max exponent bits x L limbs)
+    u32* ready;          // number of squares published so far (zeroed by the host before the launch)
 };
 
-template <int E> __global__ __launch_bounds__(128) void k_pow_mod_chain(const ChainDesc* __restrict__ descs) {
+template <int E> __global__ __launch_bounds__(64 * K3_TEAM) void k_pow_mod_chain(const ChainDesc* __restrict__ descs, unsigned n_chains) {
     constexpr unsigned C = 64 * E;
-    __shared__ u64 s_scratch[2][2 * C];   // per-wave shift scratch
-    __shared__ u64 s_cur[2][C];           // squaring chain hand-off, double buffered
-    const ChainDesc D = descs[blockIdx.x];
+    __shared__ u64 s_scratch[K3_TEAM][2 * C];   // per-wave shift scratch
+    __shared__ TeamBuf<E> s_team[2];            // [parity]
+    const bool squarer = blockIdx.x < n_chains;     // workgroups [0, n): squarers; [n, 2n): multipliers of the same chains
+    const ChainDesc D = descs[squarer ? blockIdx.x : blockIdx.x - n_chains];
+#ifdef PZ_K3_PROF
+    const unsigned long long k_t0 = clock64();
+#endif
     const unsigned wave = threadIdx.x >> 6;
+    TeamCtx<E> T;
+    T.buf = s_team;
+    T.w = wave;
+    T.parity = 0;
+    TeamMul<E> tmul{&T};
+    const bool writer = wave == 0;   // the four waves of the team hold the same values: one of them writes
     BarrettCtx<E> B;
     B.sm = s_scratch[wave];
     B.limbs = D.L;
@@ -419,7 +697,7 @@ template <int E> __global__ __launch_bounds__(128) void k_pow_mod_chain(const Ch
     LD<E> m = ld_load<E>(D.modulus, D.limbs_mod);
     if (D.square_modulus) {
         LD<E> lo, hi;
-        ld_mul(lo, hi, m, m);
+        tmul(lo, hi, m, m);
         m = lo;
     }
     const bool mod_ok = barrett_setup(B, m);
@@ -441,18 +719,18 @@ template <int E> __global__ __launch_bounds__(128) void k_pow_mod_chain(const Ch
     if (mod_ok) {
         for (unsigned i = 0; i < nbits; ++i) {
             const bool bit = (i >> 6) < D.exp_limbs && ((D.exp[i >> 6] >> (i & 63)) & 1);
-            if (wave == 0) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) s_cur[i & 1][lane_id() * E + e] = sq.v[e];
-            }
-            __syncthreads();
             // reference schedule (pow_mod_fixed_exp): squaring step, then the multiply step on set bits;
             // uniform schedule (pow_mod): multiply step for EVERY bit, then the squaring step
             const unsigned sq_slot = uni ? step_idx + 1 : step_idx, mul_slot = uni ? step_idx : step_idx + 1;
-            if (wave == 0) {
+            if (squarer) {
+                if (writer) {   // publish sq_i: the limbs, then the counter (release: the multiplier's acquire load orders its reads)
+                    ld_store(D.sq_buf + (size_t)i * D.L, sq, D.L);
+                    __threadfence();
+                    if (lane_id() == 0) __hip_atomic_store(D.ready, i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 LD<E> q, r;
-                st |= mul_mod(B, q, r, sq, sq);
-                if (D.steps && sq_slot < D.steps_cap) {
+                st |= mul_mod(B, q, r, sq, sq, tmul);
+                if (writer && D.steps && sq_slot < D.steps_cap) {
                     u64* o = D.steps + (size_t)sq_slot * 4 * D.L;
                     ld_store(o, sq, D.L);
                     ld_store(o + D.L, sq, D.L);
@@ -461,12 +739,18 @@ template <int E> __global__ __launch_bounds__(128) void k_pow_mod_chain(const Ch
                 }
                 sq = r;
             } else if (bit || uni) {
+                // wait for square i (every wave polls for itself: no workgroup barrier on this path); the squarer never waits for
+                // anyone and was dispatched first, so the wait is bounded by its progress
+                while (__hip_atomic_load(D.ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) <= i) __builtin_amdgcn_s_sleep(2);
                 LD<E> cur;
 #pragma unroll
-                for (int e = 0; e < E; ++e) cur.v[e] = s_cur[i & 1][lane_id() * E + e];
+                for (int e = 0; e < E; ++e) {
+                    const unsigned idx = lane_id() * E + e;
+                    cur.v[e] = idx < D.L ? __hip_atomic_load(D.sq_buf + (size_t)i * D.L + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                }
                 LD<E> q, r;
-                st |= mul_mod(B, q, r, acc, cur);
-                if (D.steps && mul_slot < D.steps_cap) {
+                st |= mul_mod(B, q, r, acc, cur, tmul);
+                if (writer && D.steps && mul_slot < D.steps_cap) {
                     u64* o = D.steps + (size_t)mul_slot * 4 * D.L;
                     ld_store(o, acc, D.L);
                     ld_store(o + D.L, cur, D.L);
@@ -479,11 +763,22 @@ template <int E> __global__ __launch_bounds__(128) void k_pow_mod_chain(const Ch
         }
     }
     if (D.steps && step_idx > D.steps_cap) st |= ST_INTERNAL;
-    if (wave == 1) {
+    if (!squarer && writer) {
         ld_store(D.result, acc, D.L);
         if (D.n_steps && lane_id() == 0) *D.n_steps = step_idx;
     }
     if (st && lane_id() == 0) atomicOr(D.status, st);
+#ifdef PZ_K3_PROF
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        printf("K3 phases (cycles per step, squarer wg 0): mul1 %llu shl %llu mul2 %llu add %llu mul3 %llu sub %llu fixup %llu shr %llu | whole kernel %llu per bit\n",
+               g_k3_phase[0] / nbits, g_k3_phase[1] / nbits, g_k3_phase[2] / nbits, g_k3_phase[3] / nbits, g_k3_phase[4] / nbits, g_k3_phase[5] / nbits,
+               g_k3_phase[6] / nbits, g_k3_phase[7] / nbits, (unsigned long long)(clock64() - k_t0) / nbits);
+        for (int i = 0; i < 16; ++i) g_k3_phase[i] = 0;
+    }
+    if (lane_id() == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == n_chains))
+        printf("K3 prof wg %u: products %llu; cycles per product: loop %llu, resolve+lds %llu, barrier %llu, combine %llu; total cycles %llu\n", blockIdx.x,
+               T.n_mul, T.t_loop / T.n_mul, T.t_res / T.n_mul, T.t_bar / T.n_mul, T.t_comb / T.n_mul, (unsigned long long)(clock64() - k_t0));
+#endif
 }
 
 struct MulDesc {
@@ -515,7 +810,7 @@ template <int E> __global__ __launch_bounds__(64) void k_mul_mod(const MulDesc* 
     }
     LD<E> a = ld_load<E>(D.a, D.limbs_a), b = ld_load<E>(D.b, D.limbs_b);
     LD<E> q, r;
-    st |= mul_mod(B, q, r, a, b);
+    st |= mul_mod(B, q, r, a, b, SoloMul<E>());
     if (D.q) ld_store(D.q, q, D.L);
     if (D.r) ld_store(D.r, r, D.L);
     if (D.step) {
@@ -540,9 +835,24 @@ static int status_to_rc(pz_ctx* ctx, u32 st) {
     return PZ_OK;
 }
 
+// per chain: the hand-off area of its two workgroups -- `bits` squares of L limbs + the progress counter (zeroed here, in stream order)
+static size_t chain_handoff_bytes(unsigned bits, unsigned L) { return (size_t)bits * L * 8 + 256; }
+static int chain_handoff_alloc(pz_ctx* ctx, size_t n_chains, unsigned bits, unsigned L, char** base) {
+    void* d;
+    PZCHK(pz_ws_get(ctx, WS_K3, n_chains * chain_handoff_bytes(bits, L), &d));
+    *base = (char*)d;
+    for (size_t i = 0; i < n_chains; ++i)
+        HIPCHK(ctx, hipMemsetAsync(*base + i * chain_handoff_bytes(bits, L) + (size_t)bits * L * 8, 0, 4, ctx->stream));
+    return PZ_OK;
+}
+static void chain_handoff_set(ChainDesc& d, char* base, size_t i, unsigned bits, unsigned L) {
+    d.sq_buf = (u64*)(base + i * chain_handoff_bytes(bits, L));
+    d.ready = (u32*)(base + i * chain_handoff_bytes(bits, L) + (size_t)bits * L * 8);
+}
 static int launch_chains(pz_ctx* ctx, const ChainDesc* d_descs, size_t n, unsigned L) {
-    if (L <= 64) hipLaunchKernelGGL(k_pow_mod_chain<1>, dim3((unsigned)n), dim3(128), 0, ctx->stream, d_descs);
-    else hipLaunchKernelGGL(k_pow_mod_chain<2>, dim3((unsigned)n), dim3(128), 0, ctx->stream, d_descs);
+    // grid: n squarers, then n multipliers (dispatch order = id order: a squarer is resident before its multiplier can wait for it)
+    if (L <= 64) hipLaunchKernelGGL(k_pow_mod_chain<1>, dim3((unsigned)(2 * n)), dim3(64 * K3_TEAM), 0, ctx->stream, d_descs, (unsigned)n);
+    else hipLaunchKernelGGL(k_pow_mod_chain<2>, dim3((unsigned)(2 * n)), dim3(64 * K3_TEAM), 0, ctx->stream, d_descs, (unsigned)n);
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
 }
@@ -632,6 +942,11 @@ extern "C" int pz_paillier_trace(pz_ctx* ctx, uint32_t limbs_n2, const uint64_t*
     h.L = L;
     h.square_modulus = 0;
     h.steps_cap = (u32)need;
+    {
+        char* hb;
+        PZCHK(chain_handoff_alloc(ctx, 1, 64 * exp_limbs, L, &hb));
+        chain_handoff_set(h, hb, 0, 64 * exp_limbs, L);
+    }
     HIPCHK(ctx, hipMemcpyAsync(d_desc, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
     {
         pz_timer tm(ctx, PZ_T_TRACE);
@@ -709,6 +1024,8 @@ static int encrypt_impl(pz_ctx* ctx, uint32_t Ln, size_t batch, const uint64_t* 
     HIPCHK(ctx, hipMemsetAsync(d_status, 0, 4, ctx->stream));
     std::vector<ChainDesc> ch(2 * batch);
     std::vector<MulDesc> mu(batch);
+    char* hb;
+    PZCHK(chain_handoff_alloc(ctx, 2 * batch, 64 * Ln, L, &hb));
     for (size_t i = 0; i < batch; ++i) {
         u64* st_i = d_steps ? d_steps + i * steps_cap * 4 * L : nullptr;
         ChainDesc& a = ch[2 * i];
@@ -735,6 +1052,8 @@ static int encrypt_impl(pz_ctx* ctx, uint32_t Ln, size_t batch, const uint64_t* 
         b.steps = st_i ? st_i + (size_t)ng[i] * 4 * L : nullptr;
         b.result = d_rn + i * L;
         b.steps_cap = nr[i];
+        chain_handoff_set(a, hb, 2 * i, 64 * Ln, L);
+        chain_handoff_set(b, hb, 2 * i + 1, 64 * Ln, L);
         MulDesc& f = mu[i];
         f = MulDesc{};
         f.a = d_gm + i * L;

@@ -17,7 +17,7 @@
 #include "fp.cuh"
 #include "pz_internal.h"
 
-int pz_batch_invert_internal(pz_ctx* ctx, Fr* d_a, size_t n);
+int pz_batch_invert_internal(pz_ctx* ctx, Fr* d_a, size_t n, Fr* d_mul_io);
 int pz_prefix_product_batch_internal(pz_ctx* ctx, const Fr* d_a, size_t a_stride, size_t n_cols, size_t n, Fr z0, Fr* d_z,
                                      size_t z_stride);
 
@@ -173,10 +173,6 @@ __global__ __launch_bounds__(256) void k_lk_terms(const Fr* __restrict__ A, size
     fp_store(num + k * n + i, fp_mul(fp_add(fp_load<FrTag>(A + k * as + i), beta), fp_add(fp_load<FrTag>(S + i), gamma)));
     fp_store(den + k * n + i, fp_mul(fp_add(fp_load<FrTag>(Ap + k * aps + i), beta), fp_add(fp_load<FrTag>(Sp + k * sps + i), gamma)));
 }
-__global__ __launch_bounds__(256) void k_lk_mul(Fr* __restrict__ a, const Fr* __restrict__ b, size_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) fp_store(a + i, fp_mul(fp_load<FrTag>(a + i), fp_load<FrTag>(b + i)));
-}
 
 extern "C" int pz_lookup_product_dev(pz_ctx* ctx, const uint64_t* d_inputs, size_t input_stride, const uint64_t* d_table,
                                      const uint64_t* d_perm_inputs, size_t perm_input_stride, const uint64_t* d_perm_tables,
@@ -201,8 +197,6 @@ extern "C" int pz_lookup_product_dev(pz_ctx* ctx, const uint64_t* d_inputs, size
                        input_stride / 4, (const Fr*)d_table, (const Fr*)d_perm_inputs, perm_input_stride / 4,
                        (const Fr*)d_perm_tables, perm_table_stride / 4, n, b, g, num, den);
     HIPCHK(ctx, hipGetLastError());
-    PZCHK(pz_batch_invert_internal(ctx, den, n_lookups * n));
-    hipLaunchKernelGGL(k_lk_mul, dim3(pz_div_up(n_lookups * n, 256)), dim3(256), 0, ctx->stream, num, (const Fr*)den, n_lookups * n);
-    HIPCHK(ctx, hipGetLastError());
+    PZCHK(pz_batch_invert_internal(ctx, den, n_lookups * n, num));   // num <- num / den
     return pz_prefix_product_batch_internal(ctx, num, n, n_lookups, n, z, (Fr*)d_z, z_stride / 4);
 }

@@ -44,15 +44,99 @@ __device__ __forceinline__ Fr29 fr29_one256() {
     return r;
 }
 
-// beta, gamma, delta of a permutation argument as the row kernels use them -- out[0] = beta * 2^266 (beta times a 256-domain value
-// lands in the 261-domain), out[1] = gamma * 2^261, out[2] = delta * 2^261, nine raw limbs each -- computed ONCE per call: with
-// two columns per set a thread of k_perm_terms_sets has ten products of real work, and five more per thread for the constants
-// made the kernel 1.5x slower than on 32-bit limbs
-__global__ void k_perm_consts(Fr beta, Fr gamma, Fr delta, u32* __restrict__ out) {
-    if (blockIdx.x || threadIdx.x) return;
-    f29_store_raw(out, f29_to_261(fr29_c261(beta)));
-    f29_store_raw(out + 9, fr29_c261(gamma));
-    f29_store_raw(out + 18, fr29_c261(delta));
+// ---- wave-uniform constants in SGPRs.  A challenge is the same for every lane; converted on the HOST into the nine 29-bit limbs
+// the kernels multiply by (c * 2^(256 + k) mod r: k = 5 for the 261-domain image of a 256-domain value, k = 10 for beta, whose
+// product with a plain 256-domain value must land in the 261-domain) and passed BY VALUE as a kernel argument, it lives in SGPRs:
+// f29_mul_s / f29_mul2_s read it as the scalar operand of every mad, and the nine VGPRs per constant a per-lane copy took are
+// free -- k_quotient_permutation carried five such copies (45 of its 158 VGPRs: the difference between 3 and 4 waves per SIMD).
+struct S29 {
+    u32 v[9];
+};
+static S29 host_fr_shl(const uint64_t c[4], unsigned k) {   // canonical c (Montgomery form, below r) -> limbs of c * 2^k mod r
+    static const uint64_t R[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+    uint64_t x[4] = {c[0], c[1], c[2], c[3]};
+    for (unsigned t = 0; t < k; ++t) {
+        for (int i = 3; i > 0; --i) x[i] = (x[i] << 1) | (x[i - 1] >> 63);   // x < r < 2^254: no bit is lost
+        x[0] <<= 1;
+        bool ge = true;
+        for (int i = 3; i >= 0; --i)
+            if (x[i] != R[i]) { ge = x[i] > R[i]; break; }
+        if (ge) {
+            unsigned __int128 br = 0;
+            for (int i = 0; i < 4; ++i) {
+                const unsigned __int128 d = (unsigned __int128)x[i] - R[i] - br;
+                x[i] = (uint64_t)d;
+                br = (d >> 64) & 1;
+            }
+        }
+    }
+    S29 r;
+    for (int i = 0; i < 9; ++i) {
+        const unsigned bit = 29u * i, j = bit >> 6, o = bit & 63;
+        uint64_t w = x[j] >> o;
+        if (o > 35 && j + 1 < 4) w |= x[j + 1] << (64 - o);
+        r.v[i] = (u32)(w & (i < 8 ? 0x1fffffffull : 0xffffffffull));
+    }
+    return r;
+}
+// host Montgomery product of two canonical Fr elements (4 x u64, R = 2^256): a handful of calls per entry point (challenge powers)
+static void host_fr_mul(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
+    static const uint64_t R[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+    const uint64_t INV = 0xc2e1f593efffffffULL;   // -r^-1 mod 2^64
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+        unsigned __int128 c = 0;
+        for (int j = 0; j < 4; ++j) {
+            c += (unsigned __int128)a[j] * b[i] + t[j];
+            t[j] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[4] = (uint64_t)c;
+        t[5] = (uint64_t)(c >> 64);
+        const uint64_t m = t[0] * INV;
+        c = ((unsigned __int128)m * R[0] + t[0]) >> 64;
+        for (int j = 1; j < 4; ++j) {
+            c += (unsigned __int128)m * R[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[3] = (uint64_t)c;
+        t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    bool ge = t[4] != 0;
+    if (!ge) {
+        ge = true;
+        for (int i = 3; i >= 0; --i)
+            if (t[i] != R[i]) { ge = t[i] > R[i]; break; }
+    }
+    if (ge) {
+        unsigned __int128 br = 0;
+        for (int i = 0; i < 4; ++i) {
+            const unsigned __int128 d = (unsigned __int128)t[i] - R[i] - br;
+            t[i] = (uint64_t)d;
+            br = (d >> 64) & 1;
+        }
+    }
+    memcpy(out, t, 32);
+}
+static void host_fr_pow(const uint64_t a[4], unsigned e, uint64_t out[4]) {   // a^e, Montgomery form in and out
+    static const uint64_t ONE[4] = {0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL};
+    uint64_t acc[4], sq[4];
+    memcpy(acc, ONE, 32);
+    memcpy(sq, a, 32);
+    for (; e; e >>= 1) {
+        if (e & 1) host_fr_mul(acc, sq, acc);
+        host_fr_mul(sq, sq, sq);
+    }
+    memcpy(out, acc, 32);
+}
+__device__ __forceinline__ Fr29 f29_add_s(const Fr29& a, const u32 (&b)[9]) {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.v[i] = a.v[i] + b[i];
+    return r;
 }
 
 // ---------------------------------------------------------------------------------------------- batch inversion
@@ -61,8 +145,10 @@ __global__ void k_perm_consts(Fr beta, Fr gamma, Fr delta, u32* __restrict__ out
 // canonical (a product is tight and below 2p < 2^256: no conditional subtraction on the way out).  f29_inv works in the
 // 261-domain: fed acc * 2^256 it returns acc^-1 * 2^266, and one product by 1 * 2^256 brings that to acc^-1 * 2^261 -- the domain
 // in which inv * scratch lands in the 256-domain and inv * shl5(v) stays where it is.
+// mul_io != nullptr: the inverses are not stored; mul_io[i] <- mul_io[i] / a[i] instead (zeros of a leave mul_io[i] alone), a stays as
+// it was -- the numerator / denominator quotient of the grand-product arguments without a pass of its own
 __global__ __launch_bounds__(256) void k_batch_invert(Fr* __restrict__ a, Fr* __restrict__ scratch, size_t n, size_t T,
-                                                      unsigned K) {
+                                                      unsigned K, Fr* __restrict__ mul_io) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     Fr29 acc = fr29_one256();
@@ -82,12 +168,14 @@ __global__ __launch_bounds__(256) void k_batch_invert(Fr* __restrict__ a, Fr* __
         if (i >= n) continue;
         const Fr v = fp_load<FrTag>(a + i);
         if (fp_is_zero(v)) continue;
-        f29_store_product(a + i, f29_mul(inv, f29_load<FrTag>(scratch + i)));
+        const Fr29 ai = f29_mul(inv, f29_load<FrTag>(scratch + i));   // 1 / a[i], 256-domain
+        if (mul_io) f29_store_product(mul_io + i, f29_mul(ai, f29_load_shl5<FrTag>(mul_io + i)));
+        else f29_store_product(a + i, ai);
         inv = f29_mul(inv, f29_from_fp_shl5(v));
     }
 }
 
-int pz_batch_invert_internal(pz_ctx* ctx, Fr* d_a, size_t n) {
+int pz_batch_invert_internal(pz_ctx* ctx, Fr* d_a, size_t n, Fr* d_mul_io) {
     if (!n) return PZ_OK;
     void* scr;
     PZCHK(pz_ws_get(ctx, WS_BIG_A, n * 32, &scr));
@@ -97,7 +185,7 @@ int pz_batch_invert_internal(pz_ctx* ctx, Fr* d_a, size_t n) {
     while (K < 64 && n / (K * 2) >= 16384) K *= 2;
     while (K < 512 && n / (K * 2) >= 262144) K *= 2;
     const size_t T = pz_div_up(n, K);
-    hipLaunchKernelGGL(k_batch_invert, dim3(pz_div_up(T, 256)), dim3(256), 0, ctx->stream, d_a, (Fr*)scr, n, T, K);
+    hipLaunchKernelGGL(k_batch_invert, dim3(pz_div_up(T, 256)), dim3(256), 0, ctx->stream, d_a, (Fr*)scr, n, T, K, d_mul_io);
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
 }
@@ -105,7 +193,7 @@ int pz_batch_invert_internal(pz_ctx* ctx, Fr* d_a, size_t n) {
 extern "C" int pz_fr_batch_invert_dev(pz_ctx* ctx, uint64_t* d_a, size_t n) {
     if (!ctx || (n && !d_a)) return PZ_ERR_INVALID;
     PZ_ENTER(ctx);
-    return pz_batch_invert_internal(ctx, (Fr*)d_a, n);
+    return pz_batch_invert_internal(ctx, (Fr*)d_a, n, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------- prefix product
@@ -229,10 +317,6 @@ __global__ __launch_bounds__(256) void k_perm_terms(const Fr* __restrict__ cols,
     f29_store<0>(num + i, nm);   // one256 when m == 0, a product otherwise: strict limbs either way, but keep the general store
     f29_store<0>(den + i, dn);
 }
-__global__ __launch_bounds__(256) void k_fr_mul_inplace(Fr* __restrict__ a, const Fr* __restrict__ b, size_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) fp_store(a + i, fp_mul(fp_load<FrTag>(a + i), fp_load<FrTag>(b + i)));
-}
 
 extern "C" int pz_permutation_product_dev(pz_ctx* ctx, const uint64_t* d_cols, size_t col_stride, const uint64_t* d_sigma,
                                           size_t sigma_stride, size_t m, uint32_t log_n, const uint64_t omega[4],
@@ -253,9 +337,7 @@ extern "C" int pz_permutation_product_dev(pz_ctx* ctx, const uint64_t* d_cols, s
                        (const Fr*)d_sigma, sigma_stride / 4, (unsigned)m, n, (const Fr*)wp, fr_from_u64(beta), fr_from_u64(gamma),
                        fr_from_u64(delta_start), fr_from_u64(delta), num, den);
     HIPCHK(ctx, hipGetLastError());
-    PZCHK(pz_batch_invert_internal(ctx, den, n));
-    hipLaunchKernelGGL(k_fr_mul_inplace, dim3(pz_div_up(n, 256)), dim3(256), 0, ctx->stream, num, (const Fr*)den, n);
-    HIPCHK(ctx, hipGetLastError());
+    PZCHK(pz_batch_invert_internal(ctx, den, n, num));   // num <- num / den
     return pz_prefix_product_internal(ctx, num, n, fr_from_u64(z0), (Fr*)d_z);
 }
 
@@ -265,32 +347,49 @@ extern "C" int pz_permutation_product_dev(pz_ctx* ctx, const uint64_t* d_cols, s
 __global__ __launch_bounds__(256) void k_perm_terms_sets(const Fr* __restrict__ cols, size_t cs, const Fr* __restrict__ sigma,
                                                          size_t ss, unsigned m, unsigned chunk_len, size_t n,
                                                          const Fr* __restrict__ wpow, const Fr* __restrict__ dpow,
-                                                         const u32* __restrict__ rc, Fr* __restrict__ num, Fr* __restrict__ den) {
+                                                         S29 beta266, S29 g, S29 d, Fr* __restrict__ num, Fr* __restrict__ den) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned set = blockIdx.y, c0 = set * chunk_len;
-    const Fr29 beta266 = f29_load_raw<FrTag>(rc), g = f29_load_raw<FrTag>(rc + 9), d = f29_load_raw<FrTag>(rc + 18);   // k_perm_consts
     Fr29 nm = fr29_one256(), dn = nm;
-    Fr29 bd = f29_mul(f29_mul(beta266, f29_load<FrTag>(dpow + c0)), f29_load_shl5<FrTag>(wpow + i));
+    Fr29 bd = f29_mul(f29_mul_s(f29_load<FrTag>(dpow + c0), beta266.v), f29_load_shl5<FrTag>(wpow + i));
     // the next column's value and sigma are requested before the current column's products start
     Fr v_n = fp_load<FrTag>(cols + (size_t)c0 * cs + i), s_n = fp_load<FrTag>(sigma + (size_t)c0 * ss + i);
     for (unsigned c = c0; c < c0 + chunk_len && c < m; ++c) {
-        const Fr29 v = f29_add(f29_from_fp_shl5(v_n), g);
+        const Fr29 v = f29_add_s(f29_from_fp_shl5(v_n), g.v);
         const Fr29 sg = f29_from_fp(s_n);
         const unsigned cn = (c + 1 < c0 + chunk_len && c + 1 < m) ? c + 1 : c;
         v_n = fp_load<FrTag>(cols + (size_t)cn * cs + i);
         s_n = fp_load<FrTag>(sigma + (size_t)cn * ss + i);
         nm = f29_mul(nm, f29_add(v, bd));
-        dn = f29_mul(dn, f29_add(v, f29_mul(beta266, sg)));
-        bd = f29_mul(bd, d);
+        dn = f29_mul(dn, f29_add(v, f29_mul_s(sg, beta266.v)));
+        bd = f29_mul_s(bd, d.v);
     }
     f29_store_product(num + (size_t)set * n + i, nm);   // one256 (an empty set) or a product: strict limbs, below 2p
     f29_store_product(den + (size_t)set * n + i, dn);
 }
-__global__ void k_perm_chain(const Fr* __restrict__ z, size_t zs, unsigned n_sets, size_t u, Fr* __restrict__ mult) {
-    if (blockIdx.x || threadIdx.x) return;
-    Fr c = fp_one<FrTag>();
-    for (unsigned j = 0; j < n_sets; ++j) {
+// mult[j] = prod_{t < j} z_t[u]: the exclusive prefix product over the sets that chains them (z_j starts where z_{j-1} stood at row
+// u).  One workgroup: thread runs over consecutive sets, a Hillis-Steele scan over the 256 run products (a single lane walking
+// 128 dependent products took 145 us per call, 13 calls per proof)
+__global__ __launch_bounds__(256) void k_perm_chain(const Fr* __restrict__ z, size_t zs, unsigned n_sets, size_t u, Fr* __restrict__ mult) {
+    __shared__ Fr s_p[256];
+    const unsigned per = (n_sets + 255u) / 256u, lo = threadIdx.x * per, hi = lo + per < n_sets ? lo + per : n_sets;
+    Fr p = fp_one<FrTag>();
+    for (unsigned j = lo; j < hi; ++j) p = fp_mul(p, fp_load<FrTag>(z + (size_t)j * zs + u));
+    s_p[threadIdx.x] = p;
+    __syncthreads();
+    for (unsigned off = 1; off < 256; off <<= 1) {
+        Fr v = fp_one<FrTag>();
+        if (threadIdx.x >= off) v = s_p[threadIdx.x - off];
+        __syncthreads();
+        if (threadIdx.x >= off) {
+            p = fp_mul(v, p);
+            s_p[threadIdx.x] = p;
+        }
+        __syncthreads();
+    }
+    Fr c = threadIdx.x ? s_p[threadIdx.x - 1] : fp_one<FrTag>();
+    for (unsigned j = lo; j < hi; ++j) {
         fp_store(mult + j, c);
         c = fp_mul(c, fp_load<FrTag>(z + (size_t)j * zs + u));
     }
@@ -319,23 +418,16 @@ extern "C" int pz_permutation_product_sets_dev(pz_ctx* ctx, const uint64_t* d_co
     PZCHK(pz_get_pow_table(ctx, delta, m, &dp));
     PZCHK(pz_ws_get(ctx, WS_BIG_C, 2 * n_sets * n * 32, &ws));
     PZCHK(pz_ws_get(ctx, WS_MISC, n_sets * 32, &mu));
-    void* rc;
-    PZCHK(pz_ws_get(ctx, WS_ROWC, 27 * 4, &rc));
     Fr* num = (Fr*)ws;
     Fr* den = num + n_sets * n;
-    hipLaunchKernelGGL(k_perm_consts, dim3(1), dim3(64), 0, ctx->stream, fr_from_u64(beta), fr_from_u64(gamma), fr_from_u64(delta),
-                       (u32*)rc);
     hipLaunchKernelGGL(k_perm_terms_sets, dim3(pz_div_up(n, 256), (unsigned)n_sets), dim3(256), 0, ctx->stream,
                        (const Fr*)d_cols, col_stride / 4, (const Fr*)d_sigma, sigma_stride / 4, (unsigned)m, (unsigned)chunk_len, n,
-                       (const Fr*)wp, (const Fr*)dp, (const u32*)rc, num, den);
+                       (const Fr*)wp, (const Fr*)dp, host_fr_shl(beta, 10), host_fr_shl(gamma, 5), host_fr_shl(delta, 5), num, den);
     HIPCHK(ctx, hipGetLastError());
-    PZCHK(pz_batch_invert_internal(ctx, den, n_sets * n));
-    hipLaunchKernelGGL(k_fr_mul_inplace, dim3(pz_div_up(n_sets * n, 256)), dim3(256), 0, ctx->stream, num, (const Fr*)den,
-                       n_sets * n);
-    HIPCHK(ctx, hipGetLastError());
+    PZCHK(pz_batch_invert_internal(ctx, den, n_sets * n, num));   // num <- num / den
     PZCHK(pz_prefix_product_batch_internal(ctx, num, n, n_sets, n, fp_one_host(), (Fr*)d_z, z_stride / 4));
     if (n_sets > 1) {
-        hipLaunchKernelGGL(k_perm_chain, dim3(1), dim3(64), 0, ctx->stream, (const Fr*)d_z, z_stride / 4, (unsigned)n_sets,
+        hipLaunchKernelGGL(k_perm_chain, dim3(1), dim3(256), 0, ctx->stream, (const Fr*)d_z, z_stride / 4, (unsigned)n_sets,
                            usable_rows, (Fr*)mu);
         hipLaunchKernelGGL(k_scale_sets, dim3(pz_div_up(n, 256), (unsigned)n_sets), dim3(256), 0, ctx->stream, (Fr*)d_z,
                            z_stride / 4, n, (const Fr*)mu);
@@ -348,19 +440,18 @@ extern "C" int pz_permutation_product_sets_dev(pz_ctx* ctx, const uint64_t* d_co
 // 29-bit field: a1 * shl5(a2) stays in the 256-domain, and acc * y + e * shl5(sel) is one reduction (f29_mul2) -- two reductions
 // per column where the 32-bit-limb version paid three full products.  e = a0 + a1 a2 - a3 + 2p: limbs < 2^31, value < 4.2p.
 __global__ __launch_bounds__(256) void k_quotient_gate(const Fr* __restrict__ adv, size_t as, const Fr* __restrict__ sel,
-                                                       size_t ss, unsigned n_cols, size_t N, unsigned step, Fr y,
+                                                       size_t ss, unsigned n_cols, size_t N, unsigned step, S29 y261,
                                                        Fr* __restrict__ h) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const size_t i1 = (i + step) & (N - 1), i2 = (i + 2 * (size_t)step) & (N - 1), i3 = (i + 3 * (size_t)step) & (N - 1);
-    const Fr29 y261 = fr29_c261(y);
     Fr29 acc = f29_load<FrTag>(h + i);
     for (unsigned j = 0; j < n_cols; ++j) {
         const Fr* a = adv + (size_t)j * as;
         const Fr29 a0 = f29_load<FrTag>(a + i), a1 = f29_load<FrTag>(a + i1), a3 = f29_load<FrTag>(a + i3);
         const Fr29 a2 = f29_load_shl5<FrTag>(a + i2), sl = f29_load_shl5<FrTag>(sel + (size_t)j * ss + i);
         const Fr29 e = f29_sub<2, 29>(f29_add(a0, f29_mul(a1, a2)), a3);
-        acc = f29_mul2(acc, y261, e, sl);
+        acc = f29_mul2_s(acc, y261.v, e, sl);
     }
     f29_store<0>(h + i, acc);
 }
@@ -377,7 +468,7 @@ extern "C" int pz_quotient_gate_dev(pz_ctx* ctx, const uint64_t* d_adv_ext, size
     PZ_ENTER(ctx);
     hipLaunchKernelGGL(k_quotient_gate, dim3(pz_div_up(N, 256)), dim3(256), 0, ctx->stream, (const Fr*)d_adv_ext,
                        adv_stride / 4, (const Fr*)d_sel_ext, sel_stride / 4, (unsigned)n_cols, N, (unsigned)rot_step,
-                       fr_from_u64(y), (Fr*)d_h);
+                       host_fr_shl(y, 5), (Fr*)d_h);
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
 }
@@ -534,7 +625,8 @@ struct PermQ {
     const Fr *cols, *sigma, *z, *l0, *llast, *lactive, *xpow;
     size_t cs, ss, zs, N;
     unsigned n_sets, chunk_len, m_total, step, last_rot;
-    Fr beta, gamma, delta, x0, w_ext, y;
+    S29 y, gamma, delta, beta266;   // challenges as SGPR-resident limbs (host_fr_shl): y, gamma, delta times 2^261, beta times 2^266
+    S29 y_chain, y_sets;            // y^(n_sets - 1) and y^n_sets times 2^261: the Horner steps of a whole GROUP of lines
 };
 // On the 29-bit field (fp29.cuh): ~210 instructions per product instead of ~380 on saturated 32-bit limbs.  Domains: memory
 // holds x * 2^256; f29_mul divides by 2^261, so in every product exactly one operand carries the extra 2^5 -- a challenge
@@ -547,40 +639,53 @@ __global__ __launch_bounds__(256) void k_quotient_permutation(PermQ q, Fr* __res
     const size_t mask = q.N - 1;
     const size_t i_next = (i + q.step) & mask;
     const size_t i_last = (i + q.N - (size_t)q.last_rot * q.step) & mask;
-    const Fr29 one = fr29_one256();
-    const Fr29 y = fr29_c261(q.y), gamma = fr29_c261(q.gamma), delta = fr29_c261(q.delta);
-    const Fr29 beta261 = fr29_c261(q.beta), beta266 = f29_to_261(beta261);
-    const Fr29 l0 = f29_load_shl5<FrTag>(q.l0 + i), ll = f29_load_shl5<FrTag>(q.llast + i), la = f29_load_shl5<FrTag>(q.lactive + i);
     Fr29 acc = f29_load<FrTag>(h + i);
-    const Fr29 z_first = f29_load<FrTag>(q.z + i);
-    acc = f29_mul2(acc, y, f29_sub<2, 29>(one, z_first), l0);
-    const Fr zl = fp_load<FrTag>(q.z + (size_t)(q.n_sets - 1) * q.zs + i);
-    const Fr29 z_lastset = f29_from_fp(zl);
-    acc = f29_mul2(acc, y, f29_sub<2, 29>(f29_mul(z_lastset, f29_from_fp_shl5(zl)), z_lastset), ll);
-    for (unsigned j = 1; j < q.n_sets; ++j) {
-        const Fr29 d = f29_sub<2, 29>(f29_load<FrTag>(q.z + (size_t)j * q.zs + i), f29_load<FrTag>(q.z + (size_t)(j - 1) * q.zs + i_last));
-        acc = f29_mul2(acc, y, d, l0);
+    {   // the boundary lines: l0 and l_last rows are live only here
+        const Fr29 one = fr29_one256();
+        const Fr29 l0 = f29_load_shl5<FrTag>(q.l0 + i);
+        const Fr29 z_first = f29_load<FrTag>(q.z + i);
+        acc = f29_mul2_s(acc, q.y.v, f29_sub<2, 29>(one, z_first), l0);
+        {
+            const Fr29 ll = f29_load_shl5<FrTag>(q.llast + i);
+            const Fr zl = fp_load<FrTag>(q.z + (size_t)(q.n_sets - 1) * q.zs + i);
+            const Fr29 z_lastset = f29_from_fp(zl);
+            acc = f29_mul2_s(acc, q.y.v, f29_sub<2, 29>(f29_mul(z_lastset, f29_from_fp_shl5(zl)), z_lastset), ll);
+        }
+        // the n_sets - 1 chaining lines share their factor l0: sum_j y^(S-1-j) l0 d_j = l0 * (Horner of the d_j in y), so the group
+        // costs one plain product per line and ONE two-term reduction, instead of a two-term reduction per line (same field value,
+        // hence the same canonical h)
+        if (q.n_sets > 1) {
+            Fr29 t0 = f29_sub<2, 29>(f29_load<FrTag>(q.z + q.zs + i), f29_load<FrTag>(q.z + i_last));
+            for (unsigned j = 2; j < q.n_sets; ++j) {
+                const Fr29 d = f29_sub<2, 29>(f29_load<FrTag>(q.z + (size_t)j * q.zs + i), f29_load<FrTag>(q.z + (size_t)(j - 1) * q.zs + i_last));
+                t0 = f29_add(f29_mul_s(t0, q.y.v), d);   // tight + (< 2^31): a legal operand of the next product
+            }
+            acc = f29_mul2_s(acc, q.y_chain.v, t0, l0);
+        }
     }
     // beta * X_i (261-domain), X_i = x0 * w_ext^i from the cached power table
-    Fr29 cur = f29_mul(beta266, f29_load<FrTag>(q.xpow + i));
+    Fr29 cur = f29_mul_s(f29_load<FrTag>(q.xpow + i), q.beta266.v);
     unsigned c = 0;
     // the next column's value and sigma are requested before the current column's four products start
     Fr v_n = fp_load<FrTag>(q.cols + i), s_n = fp_load<FrTag>(q.sigma + i);
+    Fr29 hs;   // Horner in y of the sets' (left - right): the factor l_active is applied once to the whole group
     for (unsigned j = 0; j < q.n_sets; ++j) {
         Fr29 left = f29_load<FrTag>(q.z + (size_t)j * q.zs + i_next);
         Fr29 right = f29_load<FrTag>(q.z + (size_t)j * q.zs + i);
         for (unsigned t = 0; t < q.chunk_len && c < q.m_total; ++t, ++c) {
-            const Fr29 v = f29_add(f29_from_fp_shl5(v_n), gamma);   // (v + gamma) * 2^261
+            const Fr29 v = f29_add_s(f29_from_fp_shl5(v_n), q.gamma.v);   // (v + gamma) * 2^261
             const Fr29 sg = f29_from_fp(s_n);
             const unsigned cn = c + 1 < q.m_total ? c + 1 : c;
             v_n = fp_load<FrTag>(q.cols + (size_t)cn * q.cs + i);
             s_n = fp_load<FrTag>(q.sigma + (size_t)cn * q.ss + i);
-            left = f29_mul(left, f29_add(v, f29_mul(beta266, sg)));
+            left = f29_mul(left, f29_add(v, f29_mul_s(sg, q.beta266.v)));
             right = f29_mul(right, f29_add(v, cur));
-            cur = f29_mul(cur, delta);
+            cur = f29_mul_s(cur, q.delta.v);
         }
-        acc = f29_mul2(acc, y, f29_sub<2, 29>(left, right), la);
+        const Fr29 diff = f29_sub<2, 29>(left, right);
+        hs = j ? f29_add(f29_mul_s(hs, q.y.v), diff) : diff;
     }
+    acc = f29_mul2_s(acc, q.y_sets.v, hs, f29_load_shl5<FrTag>(q.lactive + i));
     f29_store<0>(h + i, acc);
 }
 
@@ -607,8 +712,12 @@ extern "C" int pz_quotient_permutation_dev(pz_ctx* ctx, const uint64_t* d_cols_e
     q.l0 = (const Fr*)d_l0; q.llast = (const Fr*)d_l_last; q.lactive = (const Fr*)d_l_active;
     q.cs = col_stride / 4; q.ss = sigma_stride / 4; q.zs = z_stride / 4; q.N = N;
     q.n_sets = n_sets; q.chunk_len = chunk_len; q.m_total = m_total; q.step = rot_step; q.last_rot = last_rotation;
-    q.beta = fr_from_u64(beta); q.gamma = fr_from_u64(gamma); q.delta = fr_from_u64(delta);
-    q.x0 = fr_from_u64(coset_g); q.w_ext = fr_from_u64(omega_ext); q.y = fr_from_u64(y);
+    q.beta266 = host_fr_shl(beta, 10); q.gamma = host_fr_shl(gamma, 5); q.delta = host_fr_shl(delta, 5); q.y = host_fr_shl(y, 5);
+    uint64_t yp[4];
+    host_fr_pow(y, n_sets - 1, yp);
+    q.y_chain = host_fr_shl(yp, 5);
+    host_fr_mul(yp, y, yp);
+    q.y_sets = host_fr_shl(yp, 5);
     void* xp;
     PZCHK(pz_get_pow_table(ctx, omega_ext, N, &xp, coset_g));   // X_i = coset_g * omega_ext^i, cached across calls
     q.xpow = (const Fr*)xp;
@@ -626,7 +735,7 @@ struct LookQ {
     const Fr *a, *s, *ap, *sp, *z, *l0, *llast, *lactive;
     size_t as, aps, sps, zs, N;
     unsigned n_lookups, step;
-    Fr beta, gamma, y;
+    S29 beta, gamma, y;   // times 2^261, SGPR-resident limbs (host_fr_shl)
 };
 // (29-bit field, domains as in k_quotient_permutation: beta, gamma, y and the l_* rows carry 2^261; every line of the argument is
 // one f29_mul2 with acc * y)
@@ -636,27 +745,26 @@ __global__ __launch_bounds__(256) void k_quotient_lookup(LookQ q, Fr* __restrict
     const size_t mask = q.N - 1;
     const size_t i_next = (i + q.step) & mask, i_prev = (i + q.N - q.step) & mask;
     const Fr29 one = fr29_one256();
-    const Fr29 y = fr29_c261(q.y), beta = fr29_c261(q.beta), gamma = fr29_c261(q.gamma);
     const Fr29 l0 = f29_load_shl5<FrTag>(q.l0 + i), ll = f29_load_shl5<FrTag>(q.llast + i), la = f29_load_shl5<FrTag>(q.lactive + i);
-    const Fr29 sg = f29_add(f29_load_shl5<FrTag>(q.s + i), gamma);   // (s + gamma) 2^261
+    const Fr29 sg = f29_add_s(f29_load_shl5<FrTag>(q.s + i), q.gamma.v);   // (s + gamma) 2^261
     Fr29 acc = f29_load<FrTag>(h + i);
     for (unsigned k = 0; k < q.n_lookups; ++k) {
         const Fr zf = fp_load<FrTag>(q.z + (size_t)k * q.zs + i);
         const Fr29 z = f29_from_fp(zf), zn = f29_load<FrTag>(q.z + (size_t)k * q.zs + i_next);
         const Fr apf = fp_load<FrTag>(q.ap + (size_t)k * q.aps + i), spf = fp_load<FrTag>(q.sp + (size_t)k * q.sps + i);
         const Fr29 ap = f29_from_fp(apf), sp = f29_from_fp(spf);
-        acc = f29_mul2(acc, y, f29_sub<2, 29>(one, z), l0);
-        acc = f29_mul2(acc, y, f29_sub<2, 29>(f29_mul(z, f29_from_fp_shl5(zf)), z), ll);
+        acc = f29_mul2_s(acc, q.y.v, f29_sub<2, 29>(one, z), l0);
+        acc = f29_mul2_s(acc, q.y.v, f29_sub<2, 29>(f29_mul(z, f29_from_fp_shl5(zf)), z), ll);
         // (a' + beta)(s' + gamma) and (a + beta)(s + gamma): both factors carry 2^261, so does the product (loose x loose limbs:
         // 9 * 2^30 * 2^30 + 2^59.8 < 2^64; value < 8p), and z * that is back in the 256-domain
-        const Fr29 f1 = f29_mul(f29_add(f29_from_fp_shl5(apf), beta), f29_add(f29_from_fp_shl5(spf), gamma));
-        const Fr29 f2 = f29_mul(f29_add(f29_load_shl5<FrTag>(q.a + (size_t)k * q.as + i), beta), sg);
-        acc = f29_mul2(acc, y, f29_sub<2, 29>(f29_mul(zn, f1), f29_mul(z, f2)), la);
+        const Fr29 f1 = f29_mul(f29_add_s(f29_from_fp_shl5(apf), q.beta.v), f29_add_s(f29_from_fp_shl5(spf), q.gamma.v));
+        const Fr29 f2 = f29_mul(f29_add_s(f29_load_shl5<FrTag>(q.a + (size_t)k * q.as + i), q.beta.v), sg);
+        acc = f29_mul2_s(acc, q.y.v, f29_sub<2, 29>(f29_mul(zn, f1), f29_mul(z, f2)), la);
         const Fr29 ams = f29_carry(f29_sub<2, 29>(ap, sp));   // a' - s' + 2p, limbs < 2^29 + 8
-        acc = f29_mul2(acc, y, ams, l0);
+        acc = f29_mul2_s(acc, q.y.v, ams, l0);
         // (a' - a'(w^-1 X)) * 2^261 from the shl5 images (values below 32p each; + 64p keeps every limb and the value positive)
         const Fr29 dprev = f29_sub<64, 29>(f29_from_fp_shl5(apf), f29_load_shl5<FrTag>(q.ap + (size_t)k * q.aps + i_prev));
-        acc = f29_mul2(acc, y, f29_mul(ams, dprev), la);
+        acc = f29_mul2_s(acc, q.y.v, f29_mul(ams, dprev), la);
     }
     f29_store<0>(h + i, acc);
 }
@@ -683,7 +791,7 @@ extern "C" int pz_quotient_lookup_dev(pz_ctx* ctx, const uint64_t* d_input_ext, 
     q.l0 = (const Fr*)d_l0; q.llast = (const Fr*)d_l_last; q.lactive = (const Fr*)d_l_active;
     q.as = input_stride / 4; q.aps = perm_input_stride / 4; q.sps = perm_table_stride / 4; q.zs = z_stride / 4; q.N = N;
     q.n_lookups = n_lookups; q.step = rot_step;
-    q.beta = fr_from_u64(beta); q.gamma = fr_from_u64(gamma); q.y = fr_from_u64(y);
+    q.beta = host_fr_shl(beta, 5); q.gamma = host_fr_shl(gamma, 5); q.y = host_fr_shl(y, 5);
     hipLaunchKernelGGL(k_quotient_lookup, dim3(pz_div_up(N, 256)), dim3(256), 0, ctx->stream, q, (Fr*)d_h);
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
