@@ -229,7 +229,8 @@ template <int E> __device__ __noinline__ void ld_mul(LD<E>& lo, LD<E>& hi, const
 template <int E> struct TeamBuf {         // one buffer of a team's exchange area (two per team: double-buffered)
     u64 lo[64 * E];                       // emitted low limbs, by absolute limb index
     u64 sink[64 + 64 / K3_TEAM];          // where lanes 1..63 drop their copy of the per-iteration store (no exec-mask juggling)
-    u64 hi[K3_TEAM][64 * E];              // resolved high limbs of every wave's partial product
+    u64 row[K3_TEAM][2 * 64 * E];         // wave w's resolved high limbs AT THEIR WEIGHT: [(w + 1) C / TEAM, ... + C); the rest of a row
+                                          // is zero from the kernel's start and never written, so the sum below reads unconditionally
 };
 template <int E> struct TeamCtx {
     TeamBuf<E>* buf;    // this team's two buffers
@@ -294,20 +295,22 @@ template <int E> __device__ __forceinline__ void ld_mul_team(TeamCtx<E>& T, LD<E
             p2[jl] = (u32)w;
             p3[jl] = (u32)(w >> 32);
         }
-        // (2) the column chain: additions only
+        // (2) the column chain: additions only.  (No wait states between v_add_co / v_addc: the carry through VCC is interlocked in
+        // hardware -- a build with `s_nop 1` after every carry producer, as hipcc pads its own code on gfx950, gives identical
+        // traces and 12 % more time per step: a lone wave pays a full issue slot for every s_nop)
         u32 c0 = 0, c1 = 0, c2 = 0;
         volatile u64* lo_dst = lane == 0 ? &B.lo[j0] : &B.sink[lane];   // one ds_write_b64 with an immediate offset per iteration
 #pragma unroll
         for (unsigned jl = 0; jl < SL; ++jl) {
-            asm("v_add_co_u32 %0, vcc, %0, %3\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %4, vcc\n\ts_nop 1\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc"
+            asm("v_add_co_u32 %0, vcc, %0, %3\n\tv_addc_co_u32 %1, vcc, %1, %4, vcc\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc"
                 : "+v"(c0), "+v"(c1), "+v"(c2) : "v"(p0[jl]), "v"(p1[jl]) : "vcc");
             lo_dst[jl] = ((u64)c1 << 32) | c0;     // lane 0: the finished low limb of this outer limb; other lanes: into the sink
             // shift one limb down: new column = column of lane + 1 (without its overflow count) + high half of the product + this
             // lane's overflow count
             u32 t0 = dpp_down1(c0), t1 = dpp_down1(c1), k = 0;
-            asm("v_add_co_u32 %0, vcc, %0, %3\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %4, vcc\n\ts_nop 1\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc"
+            asm("v_add_co_u32 %0, vcc, %0, %3\n\tv_addc_co_u32 %1, vcc, %1, %4, vcc\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc"
                 : "+v"(t0), "+v"(t1), "+v"(k) : "v"(p2[jl]), "v"(p3[jl]) : "vcc");
-            asm("v_add_co_u32 %0, vcc, %0, %3\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\ts_nop 1\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc"
+            asm("v_add_co_u32 %0, vcc, %0, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc"
                 : "+v"(t0), "+v"(t1), "+v"(k) : "v"(c2) : "vcc");
             c0 = t0;
             c1 = t1;
@@ -381,33 +384,39 @@ template <int E> __device__ __forceinline__ void ld_mul_team(TeamCtx<E>& T, LD<E
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         if (E > 1 && lane >= j0 && lane < j0 + SL) B.lo[lane * E + e] = plo.v[e];   // (E == 1: stored inside the loop)
-        B.hi[T.w][lane * E + e] = ph_.v[e];
+        B.row[T.w][(T.w + 1) * SL * E + lane * E + e] = ph_.v[e];
     }
     K3_T(t_res, t_loop_now);
     __syncthreads();   // the team is the workgroup
     K3_T(t_bar, t_res_now);
-    // every wave sums the partials: limb m = lane * E + e of the low half, m + C of the high half; carries are counted per limb
-    // (at most TEAM per limb) and resolved by two look-ahead additions
+    // every wave sums the partials: limb m = lane * E + e of the low half, m + C of the high half.  The 64-bit terms are added as two
+    // 32-bit digits into 64-bit accumulators (a mad by one: no carry out to catch, one issue slot per digit), then the digits are
+    // put back together: limb + an overflow count below 2^3, resolved by two look-ahead additions
     LD<E> s_lo, s_hi, c_lo, c_hi;
+    const u32 one_ = 1u;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const unsigned m = lane * E + e;
-        u64 sl = B.lo[m], cl = 0, sh_ = 0, ch = 0;
 #pragma unroll
-        for (unsigned w = 0; w < K3_TEAM; ++w) {
-            const unsigned off = (w + 1) * SL * E;   // weight of that partial's first high limb
-            if (m >= off) {               // low half: t = m - off < C always
-                const u64 v = B.hi[w][m - off];
-                sl += v;
-                cl += sl < v;
+        for (int half = 0; half < 2; ++half) {
+            u64 d0 = 0, d1 = 0;
+            if (half == 0) {
+                const u64 v = B.lo[m];
+                d0 = (u32)v;
+                d1 = v >> 32;
             }
-            if (m + C - off < C) {        // high half: t = m + C - off
-                const u64 v = B.hi[w][m + C - off];
-                sh_ += v;
-                ch += sh_ < v;
+#pragma unroll
+            for (unsigned w = 0; w < K3_TEAM; ++w) {
+                const u64 v = B.row[w][half * C + m];
+                const u32 v0 = (u32)v, v1 = (u32)(v >> 32);
+                asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(d0) : "v"(v0), "v"(one_) : "vcc");
+                asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(d1) : "v"(v1), "v"(one_) : "vcc");
             }
+            const u64 mid = (d0 >> 32) + (u32)d1;
+            const u64 limb = (u64)(u32)d0 | (mid << 32), cnt = (mid >> 32) + (d1 >> 32);
+            if (half == 0) { s_lo.v[e] = limb; c_lo.v[e] = cnt; }
+            else { s_hi.v[e] = limb; c_hi.v[e] = cnt; }
         }
-        s_lo.v[e] = sl; c_lo.v[e] = cl; s_hi.v[e] = sh_; c_hi.v[e] = ch;
     }
     // X = S + (carry counts shifted up one limb): low half, then the high half with the low half's carry out
     LD<E> k_lo, k_hi;
@@ -694,6 +703,11 @@ template <int E> __global__ __launch_bounds__(64 * K3_TEAM) void k_pow_mod_chain
     B.limbs = D.L;
     B.s = 0;
     unsigned st = ST_OK;
+    {   // the exchange rows are zero outside the ranges the products write (TeamBuf::row)
+        u64* z = (u64*)s_team;
+        for (unsigned t = threadIdx.x; t < sizeof(s_team) / 8; t += blockDim.x) z[t] = 0;
+        __syncthreads();
+    }
     LD<E> m = ld_load<E>(D.modulus, D.limbs_mod);
     if (D.square_modulus) {
         LD<E> lo, hi;
@@ -723,13 +737,23 @@ template <int E> __global__ __launch_bounds__(64 * K3_TEAM) void k_pow_mod_chain
             // uniform schedule (pow_mod): multiply step for EVERY bit, then the squaring step
             const unsigned sq_slot = uni ? step_idx + 1 : step_idx, mul_slot = uni ? step_idx : step_idx + 1;
             if (squarer) {
-                if (writer) {   // publish sq_i: the limbs, then the counter (release: the multiplier's acquire load orders its reads)
-                    ld_store(D.sq_buf + (size_t)i * D.L, sq, D.L);
-                    __threadfence();
-                    if (lane_id() == 0) __hip_atomic_store(D.ready, i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                // publish sq_i without a fence on the critical path (a __threadfence here -- L2 write-back + wait for every store in
+                // flight, the trace records included -- cost ~2 us per step): the limbs leave as agent-scope stores BEFORE the step,
+                // the counter follows AFTER it, behind a wait that finds them long acknowledged.  The multiplier reads both with
+                // agent-scope loads, the limbs only after it has seen the counter.
+                if (writer) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const unsigned idx = lane_id() * E + e;
+                        if (idx < D.L) __hip_atomic_store(D.sq_buf + (size_t)i * D.L + idx, sq.v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
                 LD<E> q, r;
                 st |= mul_mod(B, q, r, sq, sq, tmul);
+                if (writer) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane_id() == 0) __hip_atomic_store(D.ready, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 if (writer && D.steps && sq_slot < D.steps_cap) {
                     u64* o = D.steps + (size_t)sq_slot * 4 * D.L;
                     ld_store(o, sq, D.L);
@@ -741,7 +765,8 @@ template <int E> __global__ __launch_bounds__(64 * K3_TEAM) void k_pow_mod_chain
             } else if (bit || uni) {
                 // wait for square i (every wave polls for itself: no workgroup barrier on this path); the squarer never waits for
                 // anyone and was dispatched first, so the wait is bounded by its progress
-                while (__hip_atomic_load(D.ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) <= i) __builtin_amdgcn_s_sleep(2);
+                while (__hip_atomic_load(D.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= i) __builtin_amdgcn_s_sleep(2);
+                asm volatile("" ::: "memory");   // the limb loads below stay below the counter's
                 LD<E> cur;
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
