@@ -112,7 +112,10 @@ __global__ __launch_bounds__(256) void k_poly_eval_partial_multi(const Fr* __res
     const size_t col = blockIdx.y;
     const Fr* c = coeffs + col * col_stride;
     const Fr* xp[4] = {xp0, xp1, xp2, xp3};
-    const size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * EVAL_CH;
+    // a thread's EVAL_CH coefficients lie 256 apart, so a wave's load is 64 consecutive 32-byte elements (any four terms may share a
+    // reduction: the sum does not care which).  With 16 CONSECUTIVE coefficients per thread every lane of a load sat in its own
+    // 512-byte segment and the lines were fetched again for each of their four quarters.
+    const size_t base = (size_t)blockIdx.x * 256 * EVAL_CH + threadIdx.x;
     // products on the 9 x 29-bit field (fp29.cuh): the power tables are kept in the 2^261 domain, so coefficient (2^256
     // domain) x table entry stays in the ABI's domain.  Four terms share ONE Montgomery reduction (f29_dot4: 4 x 81 + 90
     // multiplier instructions instead of 4 x 171); the EVAL_CH / 4 results are added limb-wise (limbs < 4 * 2^29, values < 8p)
@@ -121,15 +124,19 @@ __global__ __launch_bounds__(256) void k_poly_eval_partial_multi(const Fr* __res
     for (unsigned q = 0; q < P; ++q) acc[q] = f29_zero<FrTag>();
 #pragma unroll 2
     for (unsigned t = 0; t < EVAL_CH; t += 4) {
-        if (base + t >= n) break;
+        if (base + (size_t)t * 256 >= n) break;
         F29<FrTag> v[4];
+        size_t idx[4];
 #pragma unroll
-        for (unsigned k = 0; k < 4; ++k) v[k] = base + t + k < n ? f29_load<FrTag>(c + base + t + k) : f29_zero<FrTag>();
+        for (unsigned k = 0; k < 4; ++k) {
+            idx[k] = base + (size_t)(t + k) * 256;
+            v[k] = idx[k] < n ? f29_load<FrTag>(c + idx[k]) : f29_zero<FrTag>();
+        }
 #pragma unroll
         for (unsigned q = 0; q < P; ++q) {
             F29<FrTag> x[4];
 #pragma unroll
-            for (unsigned k = 0; k < 4; ++k) x[k] = f29_load<FrTag>(xp[q] + (base + t + k < n ? base + t + k : n - 1));
+            for (unsigned k = 0; k < 4; ++k) x[k] = f29_load<FrTag>(xp[q] + (idx[k] < n ? idx[k] : n - 1));
             acc[q] = f29_add(acc[q], f29_dot4(v, x));
         }
     }
