@@ -633,60 +633,92 @@ struct PermQ {
 // converted once per thread (c261), or a loaded value unpacked through f29_load_shl5.  acc * y + term * l is one reduction
 // (f29_mul2).  Limb / value bounds: products are tight (< 2^29, value < 2p); sums of up to three tight values and
 // f29_sub<2, 29> results stay below 2^31, a legal operand against a tight one.
+// A thread takes the TWO rows i and i + N/2: X_{i + N/2} = -X_i on the extended coset (w_ext^(N/2) = -1), so the identity term
+// beta * delta^c * X of the second row is the first row's negated and the product cur * delta per column is paid once for the pair
+// (3.5 instead of 4 products per row and column; the kernel is at its VALU floor -- profiles/r04_pmc_tail_sq_counters.txt -- so only
+// fewer products shorten it).
 __global__ __launch_bounds__(256) void k_quotient_permutation(PermQ q, Fr* __restrict__ h) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= q.N) return;
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t half = q.N >> 1;
+    if (i0 >= half) return;
     const size_t mask = q.N - 1;
-    const size_t i_next = (i + q.step) & mask;
-    const size_t i_last = (i + q.N - (size_t)q.last_rot * q.step) & mask;
-    Fr29 acc = f29_load<FrTag>(h + i);
-    {   // the boundary lines: l0 and l_last rows are live only here
+    size_t row[2], i_next[2], i_last[2];
+    Fr29 acc[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        row[r] = i0 + (r ? half : 0);
+        i_next[r] = (row[r] + q.step) & mask;
+        i_last[r] = (row[r] + q.N - (size_t)q.last_rot * q.step) & mask;
+        acc[r] = f29_load<FrTag>(h + row[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {   // the boundary lines: l0 and l_last rows are live only here
+        const size_t i = row[r];
         const Fr29 one = fr29_one256();
         const Fr29 l0 = f29_load_shl5<FrTag>(q.l0 + i);
         const Fr29 z_first = f29_load<FrTag>(q.z + i);
-        acc = f29_mul2_s(acc, q.y.v, f29_sub<2, 29>(one, z_first), l0);
+        acc[r] = f29_mul2_s(acc[r], q.y.v, f29_sub<2, 29>(one, z_first), l0);
         {
             const Fr29 ll = f29_load_shl5<FrTag>(q.llast + i);
             const Fr zl = fp_load<FrTag>(q.z + (size_t)(q.n_sets - 1) * q.zs + i);
             const Fr29 z_lastset = f29_from_fp(zl);
-            acc = f29_mul2_s(acc, q.y.v, f29_sub<2, 29>(f29_mul(z_lastset, f29_from_fp_shl5(zl)), z_lastset), ll);
+            acc[r] = f29_mul2_s(acc[r], q.y.v, f29_sub<2, 29>(f29_mul(z_lastset, f29_from_fp_shl5(zl)), z_lastset), ll);
         }
         // the n_sets - 1 chaining lines share their factor l0: sum_j y^(S-1-j) l0 d_j = l0 * (Horner of the d_j in y), so the group
         // costs one plain product per line and ONE two-term reduction, instead of a two-term reduction per line (same field value,
         // hence the same canonical h)
         if (q.n_sets > 1) {
-            Fr29 t0 = f29_sub<2, 29>(f29_load<FrTag>(q.z + q.zs + i), f29_load<FrTag>(q.z + i_last));
+            Fr29 t0 = f29_sub<2, 29>(f29_load<FrTag>(q.z + q.zs + i), f29_load<FrTag>(q.z + i_last[r]));
             for (unsigned j = 2; j < q.n_sets; ++j) {
-                const Fr29 d = f29_sub<2, 29>(f29_load<FrTag>(q.z + (size_t)j * q.zs + i), f29_load<FrTag>(q.z + (size_t)(j - 1) * q.zs + i_last));
+                const Fr29 d = f29_sub<2, 29>(f29_load<FrTag>(q.z + (size_t)j * q.zs + i), f29_load<FrTag>(q.z + (size_t)(j - 1) * q.zs + i_last[r]));
                 t0 = f29_add(f29_mul_s(t0, q.y.v), d);   // tight + (< 2^31): a legal operand of the next product
             }
-            acc = f29_mul2_s(acc, q.y_chain.v, t0, l0);
+            acc[r] = f29_mul2_s(acc[r], q.y_chain.v, t0, l0);
         }
     }
-    // beta * X_i (261-domain), X_i = x0 * w_ext^i from the cached power table
-    Fr29 cur = f29_mul_s(f29_load<FrTag>(q.xpow + i), q.beta266.v);
+    // beta * X_i (261-domain), X_i = x0 * w_ext^i from the cached power table; the second row's is its negative
+    Fr29 cur = f29_mul_s(f29_load<FrTag>(q.xpow + i0), q.beta266.v);
     unsigned c = 0;
-    // the next column's value and sigma are requested before the current column's four products start
-    Fr v_n = fp_load<FrTag>(q.cols + i), s_n = fp_load<FrTag>(q.sigma + i);
-    Fr29 hs;   // Horner in y of the sets' (left - right): the factor l_active is applied once to the whole group
+    // the next column's values and sigmas are requested before the current column's products start
+    Fr v_n[2], s_n[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        v_n[r] = fp_load<FrTag>(q.cols + row[r]);
+        s_n[r] = fp_load<FrTag>(q.sigma + row[r]);
+    }
+    Fr29 hs[2];   // Horner in y of the sets' (left - right): the factor l_active is applied once to the whole group
     for (unsigned j = 0; j < q.n_sets; ++j) {
-        Fr29 left = f29_load<FrTag>(q.z + (size_t)j * q.zs + i_next);
-        Fr29 right = f29_load<FrTag>(q.z + (size_t)j * q.zs + i);
+        Fr29 left[2], right[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            left[r] = f29_load<FrTag>(q.z + (size_t)j * q.zs + i_next[r]);
+            right[r] = f29_load<FrTag>(q.z + (size_t)j * q.zs + row[r]);
+        }
         for (unsigned t = 0; t < q.chunk_len && c < q.m_total; ++t, ++c) {
-            const Fr29 v = f29_add_s(f29_from_fp_shl5(v_n), q.gamma.v);   // (v + gamma) * 2^261
-            const Fr29 sg = f29_from_fp(s_n);
             const unsigned cn = c + 1 < q.m_total ? c + 1 : c;
-            v_n = fp_load<FrTag>(q.cols + (size_t)cn * q.cs + i);
-            s_n = fp_load<FrTag>(q.sigma + (size_t)cn * q.ss + i);
-            left = f29_mul(left, f29_add(v, f29_mul_s(sg, q.beta266.v)));
-            right = f29_mul(right, f29_add(v, cur));
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const Fr29 v = f29_add_s(f29_from_fp_shl5(v_n[r]), q.gamma.v);   // (v + gamma) * 2^261
+                const Fr29 sg = f29_from_fp(s_n[r]);
+                v_n[r] = fp_load<FrTag>(q.cols + (size_t)cn * q.cs + row[r]);
+                s_n[r] = fp_load<FrTag>(q.sigma + (size_t)cn * q.ss + row[r]);
+                left[r] = f29_mul(left[r], f29_add(v, f29_mul_s(sg, q.beta266.v)));
+                // v + beta delta^c X: row 0 adds cur, row 1 (X negated) subtracts it (cur is a product: tight, below 2p)
+                right[r] = f29_mul(right[r], r ? f29_sub<2, 29>(v, cur) : f29_add(v, cur));
+            }
             cur = f29_mul_s(cur, q.delta.v);
         }
-        const Fr29 diff = f29_sub<2, 29>(left, right);
-        hs = j ? f29_add(f29_mul_s(hs, q.y.v), diff) : diff;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const Fr29 diff = f29_sub<2, 29>(left[r], right[r]);
+            hs[r] = j ? f29_add(f29_mul_s(hs[r], q.y.v), diff) : diff;
+        }
     }
-    acc = f29_mul2_s(acc, q.y_sets.v, hs, f29_load_shl5<FrTag>(q.lactive + i));
-    f29_store<0>(h + i, acc);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        acc[r] = f29_mul2_s(acc[r], q.y_sets.v, hs[r], f29_load_shl5<FrTag>(q.lactive + row[r]));
+        f29_store<0>(h + row[r], acc[r]);
+    }
 }
 
 extern "C" int pz_quotient_permutation_dev(pz_ctx* ctx, const uint64_t* d_cols_ext, size_t col_stride,
@@ -700,7 +732,7 @@ extern "C" int pz_quotient_permutation_dev(pz_ctx* ctx, const uint64_t* d_cols_e
     if (!ctx || !d_cols_ext || !d_sigma_ext || !d_z_ext || !d_l0 || !d_l_last || !d_l_active || !beta || !gamma || !delta ||
         !coset_g || !omega_ext || !y || !d_h)
         return PZ_ERR_INVALID;
-    if (log_ext > 28 || n_sets == 0 || chunk_len == 0 || m_total == 0 || col_stride % 4 || sigma_stride % 4 || z_stride % 4)
+    if (log_ext > 28 || log_ext == 0 || n_sets == 0 || chunk_len == 0 || m_total == 0 || col_stride % 4 || sigma_stride % 4 || z_stride % 4)
         return PZ_ERR_INVALID;
     const size_t N = (size_t)1 << log_ext;
     if ((size_t)n_sets * chunk_len < m_total || (size_t)(n_sets - 1) * chunk_len >= m_total) return PZ_ERR_INVALID;
@@ -721,7 +753,7 @@ extern "C" int pz_quotient_permutation_dev(pz_ctx* ctx, const uint64_t* d_cols_e
     void* xp;
     PZCHK(pz_get_pow_table(ctx, omega_ext, N, &xp, coset_g));   // X_i = coset_g * omega_ext^i, cached across calls
     q.xpow = (const Fr*)xp;
-    hipLaunchKernelGGL(k_quotient_permutation, dim3(pz_div_up(N, 256)), dim3(256), 0, ctx->stream, q, (Fr*)d_h);
+    hipLaunchKernelGGL(k_quotient_permutation, dim3(pz_div_up(N / 2, 256)), dim3(256), 0, ctx->stream, q, (Fr*)d_h);   // a thread per row PAIR
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
 }
