@@ -1,7 +1,7 @@
 // msm_sharded.cpp -- config c4 from plain C++ over the C ABI (include/pz.h): ONE large G1 multi-scalar multiplication sharded over
 // N contexts, one host thread per context -- what a Rust host without torch builds from N pz_ctx (one per device id),
 // pz_msm_g1_dev(win_lo, win_hi) on its window range (north_star's split) or on its point range (SURVEY 8e's alternative), a
-// 96-byte download per rank and pz_g1_sum in rank order (INTEGRATION.md section 6).  No torch, no RCCL, no HIP call of its own:
+// 96-byte download per rank and pz_g1_sum in rank order (INTEGRATION.md section 5b).  No torch, no RCCL, no HIP call of its own:
 // inside one process the "exchange" is N x 96 bytes through host memory; across processes the same 96 bytes travel by the host's
 // own transport (or torch.distributed, paillier_halo2_amd/dist.py).
 //
