@@ -798,6 +798,23 @@ class _null:
         return False
 
 
+class _stdout_to_stderr:
+    """file descriptor 1 points at stderr inside the block: RCCL prints a version banner to the C stdout when its first communicator
+    comes up, and this program's stdout carries ONE JSON line"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *a):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def cpu_baseline(shape, n_steps, enc_bits, k, log):
     """The C restatement (oracle/pz_oracle.c, kind 'port') timed on this host's cores on a bounded
     sample of the same workload, extrapolated with the per-proof counts of `shape`."""
@@ -1121,7 +1138,9 @@ def main():
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)  # launched by torch.distributed.run
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend or "nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        with _stdout_to_stderr():
+            dist.init_process_group(args.backend or "nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.barrier()   # the communicator comes up here (and says so), not inside a timed region
     log = (lambda s: print("[bench] " + s, file=sys.stderr, flush=True)) if rank == 0 else (lambda s: None)
 
     eng = pz.Engine(local)
