@@ -345,7 +345,7 @@ class ProofWorkload:
         rk, ws = self.shard
         skip = os.environ.get("PZ_BENCH_SKIP", "")   # debug only ("msm" / "ntt"): time one half of the hot path alone
         # K1: commitments -- every advice and lookup-advice column (real witness cells) ...
-        for which, (buf, ncols) in enumerate(() if "msm" in skip else ((self.d_adv[slot], self.adv_cols), (self.d_lk[slot], self.lk_cols))):
+        for which, (buf, ncols) in enumerate(() if ("msm" in skip or "wit" in skip) else ((self.d_adv[slot], self.adv_cols), (self.d_lk[slot], self.lk_cols))):
             if self.scale != 1.0:
                 ncols = max(1, int(round(ncols * self.scale)))
             lo, hi = pzd.column_range(ncols, rk, ws)   # column-parallel mode: this rank's columns of the shared proof
