@@ -64,6 +64,12 @@ def test_pipelined_step_equals_serial_and_oracle(c2, cref):
     assert v["pipelined_steps_checked"] == 4 and v["messages"] == 3
     assert v["commitments_compared"] == 4 * (3033 + 84 + wl.counts["msm_full"]) and v["transforms_compared"] == 4 * 5 * 2
     assert len(set(v["commitment_hash_by_message"].values())) == 3     # three different witnesses went through the two slots
+    # ... and they are the commitments every box and every caller has produced for this seed (tests/golden/c2_commitment_hashes.json)
+    import json
+
+    with open(os.path.join(ROOT, "tests", "golden", "c2_commitment_hashes.json")) as f:
+        gold = json.load(f)
+    assert gold["seed"] == "0x5043" and v["commitment_hash_by_message"] == gold["commitment_hash_by_message"]
     vo = bench.oracle_check(wl, lambda s: None)
     assert vo["ok"] is True, vo
 
