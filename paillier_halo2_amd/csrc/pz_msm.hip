@@ -20,6 +20,7 @@
 #include "ec.cuh"
 #include "ec29.cuh"
 #include "ec29_quad.cuh"
+#include <math.h>
 #include <stdlib.h>
 
 #include "pz_internal.h"
@@ -1381,13 +1382,26 @@ extern "C" int pz_bases_info(const pz_bases* b, size_t* n_points, uint32_t* wind
 // Work items are handed to lanes in chunk-size order, so a wave's lanes run equal trip counts whatever the
 // chunk bound is; the bound only has to leave enough items to fill the chip (>= ~2^18 lanes per launch)
 // and keep a single skewed bucket from serialising.  Larger chunks mean fewer partial sums to write and fold.
-static unsigned msm_chunk_for(size_t n_cols, size_t digits_per_col) {
+static unsigned msm_chunk_for(size_t n_cols, size_t digits_per_col, unsigned window_bits) {
     static int env = -1;
     if (env < 0) {
         const char* e = getenv("PZ_MSM_CHUNK");
         env = e ? atoi(e) : 0;
     }
     if (env >= (int)MSM_CHUNK_MIN && env <= (int)MSM_CHUNK_MAX) return (unsigned)env;
+    if (n_cols <= MSM_SLICE_MAX_COLS) {
+        // one large MSM (or a rank's share of it): every bucket holds many entries, and the chunk trades the accumulation's load
+        // balance (flat below a knee, rising above it) against the partial sums the folds must add up (falling with the chunk).
+        // Measured optimum ([r4], bench.py --workload msm22 --emulate-world 8 with PZ_MSM_CHUNK): 96 at 2048 entries per bucket (one
+        // 2^22-point MSM: 6.33 ms against 6.93 with the 2^18-lane rule's 256), 24-28 at 256 per bucket (a 2^19-point share: 1.00 ms
+        // against 1.01) -- chunk = 0.79 * (entries per bucket)^0.63 passes through both
+        const double per_bucket = (double)digits_per_col / (double)((size_t)1 << (window_bits - 1));
+        double ch = 0.79 * pow(per_bucket, 0.63);
+        // in steps of 32 (16 below 24): the window split's shares measured 15 % slower at 24 / 26 than at 32
+        unsigned c32 = ch < 24.0 ? MSM_CHUNK_MIN : 32u * (unsigned)((ch + 16.0) / 32.0);
+        if (c32 > MSM_CHUNK_MAX) c32 = MSM_CHUNK_MAX;
+        return c32;
+    }
     const size_t want = (n_cols * digits_per_col) >> 18;   // >= 2^18 lanes: four waves per SIMD
     unsigned chunk = MSM_CHUNK_MIN;
     while (chunk < MSM_CHUNK_MAX && chunk * 2 <= want) chunk *= 2;
@@ -1584,7 +1598,7 @@ extern "C" int pz_msm_g1_dev(pz_ctx* ctx, const pz_bases* bases, const uint64_t*
     const size_t cs = col_stride / 4;
     // column groups: bound the sorted-entry workspace (4 B per digit) to ~1 GiB, grid.y to 65535
     const size_t digits = n * (size_t)(win_hi - win_lo);
-    const unsigned chunk = msm_chunk_for(n_cols, digits);
+    const unsigned chunk = msm_chunk_for(n_cols, digits, bases->c);
     const size_t part_col = (digits / chunk) * sizeof(G1X29Raw);   // shared with the two-pass scatter's staging list (4 B per digit)
     const size_t per_col = digits * 4 + (part_col > digits * 4 ? part_col : digits * 4) + (digits / chunk) * 8 +
                            (size_t)(1u << (bases->c - 1)) * (180 + 4 * (size_t)pz_div_up(n, (size_t)SORT_THREADS * msm_spt_for(1, n)));   // spt of the smallest group (a halved group recomputes it): an upper bound on the slices
