@@ -700,7 +700,7 @@ class ProofWorkload:
         t = self.torch
         z = lambda *shape: t.zeros(shape, dtype=t.int64, device="cuda")
         a, l = self.adv_cols, self.lk_cols
-        samples = sorted({(0, 0), (0, a // 2), (0, a - 1), (1, 0), (1, l - 1)})
+        samples = sorted({(0, 0), (0, a // 2), (0, a - 1)} | ({(1, 0), (1, l - 1)} if l else set()))
         return dict(adv=z(a, 12), lk=z(max(1, l), 12), full=z(self.counts["msm_full"], 12), samples=samples,
                     coef=z(len(samples), self.n, 4), ext=z(len(samples), self.ext_n, 4))
 
