@@ -130,6 +130,17 @@ int pz_g1_sum(pz_ctx* ctx, const uint64_t* jac /* n x 12 */, size_t n, uint64_t 
 /* device form: d_jac (n x 12) and d_out_jac (12) are device pointers; asynchronous on the context's stream.  d_out_jac
  * must not alias d_jac.  Used after the all-gather of the sharded MSM: every rank folds the same points in rank order. */
 int pz_g1_sum_dev(pz_ctx* ctx, const uint64_t* d_jac, size_t n, uint64_t* d_out_jac);
+/* ONE multi-scalar multiplication over n_ctx contexts -- one per GPU of a node (several on one device work too) -- in one call:
+ * north_star's "disjoint Pippenger windows of one large MSM sharded across the GPUs, partial sums folded" for a single-process host.
+ *   split_points == 0: context r accumulates windows [r W / n_ctx, (r + 1) W / n_ctx) of ALL n_per_ctx[r] (== n) scalars; it holds all
+ *                      scalars (d_scalars[r]) and a table of all bases (bases[r], the same window width everywhere);
+ *   split_points != 0: context r takes its own point range: d_scalars[r] holds its n_per_ctx[r] scalars, bases[r] its n_per_ctx[r]
+ *                      bases (SURVEY 8e's alternative: 1 / n_ctx of the table memory and scalar reads per GPU).
+ * Every context's share is queued on its own stream (the call does not serialise them), the 96-byte partial points are then read
+ * back in rank order and folded on ctxs[0] in that fixed order.  Blocks until out_jac is there.  d_scalars[r] / bases[r] belong to
+ * ctxs[r]'s device.  Across PROCESSES (one per GPU) the same is pz_msm_g1_dev + an exchange of the partials + pz_g1_sum[_dev]. */
+int pz_msm_g1_multi(pz_ctx* const* ctxs, const pz_bases* const* bases, const uint64_t* const* d_scalars, const size_t* n_per_ctx,
+                    size_t n_ctx, int split_points, uint64_t out_jac[12]);
 /* Jacobian -> affine for n points (host in/out): `batch_normalize`. */
 int pz_g1_normalize(pz_ctx* ctx, const uint64_t* jac /* n x 12 */, size_t n, uint64_t* aff /* n x 8 */);
 /* out[i] = [scalars[i]] * G1 generator, affine; scalars are Fr Montgomery (host in/out).  This is

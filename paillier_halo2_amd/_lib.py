@@ -44,6 +44,7 @@ SIGNATURES = {
     "pz_msm_g1_dev": (C.c_int, [VP, VP, VP, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, VP]),
     "pz_g1_sum": (C.c_int, [VP, VP, C.c_size_t, VP]),
     "pz_g1_sum_dev": (C.c_int, [VP, VP, C.c_size_t, VP]),
+    "pz_msm_g1_multi": (C.c_int, [VP, VP, VP, VP, C.c_size_t, C.c_int, VP]),
     "pz_g1_normalize": (C.c_int, [VP, VP, C.c_size_t, VP]),
     "pz_g1_fixed_base_mul": (C.c_int, [VP, VP, C.c_size_t, VP]),
     "pz_g1_fixed_base_mul_dev": (C.c_int, [VP, VP, C.c_size_t, VP]),

@@ -41,7 +41,8 @@ __global__ void k_raw29(const Fr* __restrict__ src, u32* __restrict__ dst, size_
 // host
 // ------------------------------------------------------------------------------------------------
 // explicit ABI version: bumped whenever an entry point of include/pz.h is added, removed or changes meaning (1 = rounds 1-2;
-// 3 = round 3: device-memory entry points added, measurement probes moved out to libpz_probe.so)
+// 3 = round 3: device-memory entry points added, measurement probes moved out to libpz_probe.so; 4 = round 4: PZ_ERR_ASYNC,
+// pz_msm_g1_multi)
 extern "C" int pz_abi_version(void) { return PZ_ABI_VERSION; }
 
 extern "C" const char* pz_strerror(int s) {

@@ -35,7 +35,7 @@ struct pz_wsbuf {
 };
 
 enum { WS_HIST = 0, WS_OFFS, WS_CURSOR, WS_ITEMS, WS_ENTRIES, WS_PARTIALS, WS_NODES_A, WS_NODES_B, WS_NTT_TMP,
-       WS_IO_A, WS_IO_B, WS_IO_C, WS_BIG_A, WS_BIG_B, WS_BIG_C, WS_MISC, WS_TOTALS, WS_ORDER, WS_SH_C, WS_SH_SMALL, WS_ROWC, WS_SEL, WS_K3, WS_COUNT };
+       WS_IO_A, WS_IO_B, WS_IO_C, WS_BIG_A, WS_BIG_B, WS_BIG_C, WS_MISC, WS_TOTALS, WS_ORDER, WS_SH_C, WS_SH_SMALL, WS_ROWC, WS_SEL, WS_K3, WS_MULTI, WS_COUNT };
 
 struct pz_event_pair {
     hipEvent_t a, b;

@@ -1709,6 +1709,38 @@ extern "C" int pz_g1_sum(pz_ctx* ctx, const uint64_t* jac, size_t n, uint64_t ou
 }
 
 // device-resident form: the fold of the all-gathered per-rank partial points, no host hop (n is the world size)
+// One MSM over several contexts (devices) from ONE host thread: pz_msm_g1_dev only queues work, so the shares run side by side on
+// their devices; the downloads (one synchronisation per context, in rank order) and the fold follow.
+extern "C" int pz_msm_g1_multi(pz_ctx* const* ctxs, const pz_bases* const* bases, const uint64_t* const* d_scalars, const size_t* n_per_ctx,
+                               size_t n_ctx, int split_points, uint64_t out_jac[12]) {
+    if (!ctxs || !bases || !d_scalars || !n_per_ctx || !out_jac || n_ctx == 0 || n_ctx > 1024) return PZ_ERR_INVALID;
+    for (size_t r = 0; r < n_ctx; ++r) {
+        if (!ctxs[r] || (n_per_ctx[r] && (!bases[r] || !d_scalars[r]))) return PZ_ERR_INVALID;
+        if (n_per_ctx[r] && bases[r]->device != ctxs[r]->device) return PZ_ERR_INVALID;
+        if (!split_points && (n_per_ctx[r] != n_per_ctx[0] || !bases[r] || bases[r]->nwin != bases[0]->nwin || bases[r]->c != bases[0]->c))
+            return PZ_ERR_INVALID;   // the window split needs every context to hold the same scalars and the same table shape
+    }
+    std::vector<uint64_t> parts(n_ctx * 12, 0);
+    std::vector<void*> d_part(n_ctx, nullptr);
+    for (size_t r = 0; r < n_ctx; ++r) {
+        pz_ctx* c = ctxs[r];
+        PZ_ENTER(c);   // (recursive: the entry points below take it again)
+        PZCHK(pz_ws_get(c, WS_MULTI, 96, &d_part[r]));
+        uint32_t lo = 0, hi = n_per_ctx[r] ? bases[r]->nwin : 0;
+        if (!split_points && n_per_ctx[r]) {
+            lo = (uint32_t)(r * bases[r]->nwin / n_ctx);
+            hi = (uint32_t)((r + 1) * bases[r]->nwin / n_ctx);
+        }
+        if (n_per_ctx[r] == 0 || lo == hi) {
+            HIPCHK(c, hipMemsetAsync(d_part[r], 0, 96, c->stream));   // Jacobian identity (z = 0): an empty share
+            continue;
+        }
+        PZCHK(pz_msm_g1_dev(c, bases[r], d_scalars[r], 1, n_per_ctx[r], 4 * n_per_ctx[r], lo, hi, (uint64_t*)d_part[r]));
+    }
+    for (size_t r = 0; r < n_ctx; ++r) PZCHK(pz_download(ctxs[r], &parts[12 * r], d_part[r], 96));   // rank order == the fixed fold order
+    return pz_g1_sum(ctxs[0], parts.data(), n_ctx, out_jac);
+}
+
 extern "C" int pz_g1_sum_dev(pz_ctx* ctx, const uint64_t* d_jac, size_t n, uint64_t* d_out_jac) {
     if (!ctx || !d_out_jac || (n && !d_jac)) return PZ_ERR_INVALID;
     PZ_ENTER(ctx);

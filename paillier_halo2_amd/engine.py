@@ -142,6 +142,21 @@ class Engine:
         self._chk(self.L.pz_msm_g1_dev(self.ctx, bases.handle, VP(d_scalars), n_cols, n, col_stride_u64, win_lo,
                                        win_hi, VP(d_out)), "pz_msm_g1_dev")
 
+    @staticmethod
+    def msm_multi(engines: Sequence["Engine"], bases: Sequence[Bases], d_scalars: Sequence[int], n_per_ctx: Sequence[int],
+                  split_points: bool) -> np.ndarray:
+        """pz_msm_g1_multi: ONE MSM over several contexts (one per GPU; several on one device for rehearsal).  d_scalars: device
+        pointers, one per context.  Returns the Jacobian point (12,)."""
+        k = len(engines)
+        assert len(bases) == len(d_scalars) == len(n_per_ctx) == k and k > 0
+        ctxs = (VP * k)(*[e.ctx for e in engines])
+        bs = (VP * k)(*[(b.handle if b is not None else VP()) for b in bases])
+        sc = (VP * k)(*[VP(p) for p in d_scalars])
+        ns = (C.c_size_t * k)(*n_per_ctx)
+        out = np.zeros(12, dtype=np.uint64)
+        engines[0]._chk(engines[0].L.pz_msm_g1_multi(ctxs, bs, sc, ns, k, int(split_points), _ptr(out)), "pz_msm_g1_multi")
+        return out
+
     def g1_sum(self, jac) -> np.ndarray:
         j = _np(jac, 12)
         out = np.zeros(12, dtype=np.uint64)

@@ -163,13 +163,34 @@ int main(int argc, char** argv) {
         if (it) t_shares += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     CK(pz_g1_normalize(c0, folded, 1, folded_aff));
+    // ---- the same in ONE call of the ABI (pz_msm_g1_multi: the shares queued from this thread, partials folded inside)
+    uint64_t multi[12], multi_aff[8];
+    double t_multi = 0;
+    {
+        std::vector<pz_ctx*> cs(world);
+        std::vector<const pz_bases*> bs(world);
+        std::vector<const uint64_t*> ss(world);
+        std::vector<size_t> ns(world);
+        for (size_t r = 0; r < world; ++r) {
+            cs[r] = ranks[r].ctx;
+            bs[r] = ranks[r].bases;
+            ss[r] = (const uint64_t*)ranks[r].d_scalars;
+            ns[r] = by_points ? ranks[r].hi - ranks[r].lo : n;
+        }
+        for (size_t it = 0; it < steps + 1; ++it) {
+            const auto t0 = std::chrono::steady_clock::now();
+            CK(pz_msm_g1_multi(cs.data(), bs.data(), ss.data(), ns.data(), world, by_points ? 1 : 0, multi));
+            if (it) t_multi += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+        CK(pz_g1_normalize(c0, multi, 1, multi_aff));
+    }
     char hx[4][65];
     hex256(whole_aff, hx[0]); hex256(whole_aff + 4, hx[1]); hex256(folded_aff, hx[2]); hex256(folded_aff + 4, hx[3]);
-    printf("{\"log_n\": %u, \"contexts\": %zu, \"split\": \"%s\", \"window_bits\": %u, \"n_windows\": %u, \"devices\": %zu, \"equal\": %s, "
-           "\"whole_ms\": %.4f, \"sharded_ms\": %.4f, \"s_lo\": \"%llu\", \"t_lo\": \"%llu\", \"seed\": \"%llu\", "
+    printf("{\"log_n\": %u, \"contexts\": %zu, \"split\": \"%s\", \"window_bits\": %u, \"n_windows\": %u, \"devices\": %zu, \"equal\": %s, \"multi_call_equal\": %s, "
+           "\"whole_ms\": %.4f, \"sharded_ms\": %.4f, \"multi_call_ms\": %.4f, \"s_lo\": \"%llu\", \"t_lo\": \"%llu\", \"seed\": \"%llu\", "
            "\"whole_affine_mont\": [\"%s\", \"%s\"], \"sharded_affine_mont\": [\"%s\", \"%s\"]}\n",
            log_n, world, by_points ? "points" : "windows", cbits, nwin, devs.size(), memcmp(whole_aff, folded_aff, 64) ? "false" : "true",
-           t_whole / steps * 1e3, t_shares / steps * 1e3, (unsigned long long)s_lo, (unsigned long long)t_lo, (unsigned long long)seed, hx[0], hx[1], hx[2],
+           memcmp(whole_aff, multi_aff, 64) ? "false" : "true", t_whole / steps * 1e3, t_shares / steps * 1e3, t_multi / steps * 1e3, (unsigned long long)s_lo, (unsigned long long)t_lo, (unsigned long long)seed, hx[0], hx[1], hx[2],
            hx[3]);
     for (auto& R : ranks) {
         if (R.bases) pz_bases_free(R.ctx, R.bases);
@@ -179,5 +200,5 @@ int main(int argc, char** argv) {
     pz_bases_free(c0, b0);
     for (void* d : {d_dl, d_b, d_s, d_o}) CK(pz_dev_free(c0, d));
     pz_free(c0);
-    return memcmp(whole_aff, folded_aff, 64) ? 1 : 0;
+    return (memcmp(whole_aff, folded_aff, 64) || memcmp(whole_aff, multi_aff, 64)) ? 1 : 0;
 }

@@ -345,3 +345,45 @@ def test_c3_msm_2pow15_vs_oracle(eng, cref):
     for j, col in enumerate(cols):
         assert np.array_equal(eng.g1_normalize(out[j])[0], cref.g1_normalize(cref.msm_g1(col, bases))), j
     tb.free()
+
+
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_msm_multi_contexts_one_call(cref, world):
+    """pz_msm_g1_multi: one 2^20-point MSM over `world` contexts (all on this one device: the entry point does not care) in ONE call
+    of the C ABI -- window split and point split -- equals the single-context MSM and the closed form; empty shares (more contexts
+    than windows would give) are identities"""
+    import torch
+
+    import paillier_halo2_amd as pz
+
+    log_n = 20
+    n = 1 << log_n
+    s, t = (0x19D << 236) + 0x55AA, 0x1234567890ABCDEF1
+    engs = [pz.Engine(0) for _ in range(world)]
+    engs[0].bind_torch_stream()
+    try:
+        d_b = _walk_bases_dev(engs[0], torch, n, s, t)
+        sc = canon_rand_scalars(n, 2020 + world)
+        want = P.g1_mul(P.G1_GEN, walk_dlog_sum(sc, s, t))
+        d_s = torch.from_numpy(sc.view(np.int64)).cuda()
+        engs[0].fr_convert_dev(d_s.data_ptr(), n, True)
+        engs[0].sync()
+        torch.cuda.synchronize()
+        # north_star's split: every context a table of all bases, its window range
+        tabs = [e.load_bases_dev(d_b.data_ptr(), n) for e in engs]
+        got = pz.Engine.msm_multi(engs, tabs, [d_s.data_ptr()] * world, [n] * world, split_points=False)
+        assert _aff(cref, engs[0], got) == want, ("window split", world)
+        for tb in tabs:
+            tb.free()
+        # point ranges: every context a table of its own bases
+        from paillier_halo2_amd import dist as pzd
+
+        rng = [pzd.point_range(n, r, world) for r in range(world)]
+        tabs = [engs[r].load_bases_dev(d_b.data_ptr() + lo * 64, hi - lo) for r, (lo, hi) in enumerate(rng)]
+        got = pz.Engine.msm_multi(engs, tabs, [d_s.data_ptr() + lo * 32 for lo, _ in rng], [hi - lo for lo, hi in rng], split_points=True)
+        assert _aff(cref, engs[0], got) == want, ("point split", world)
+        for tb in tabs:
+            tb.free()
+    finally:
+        for e in engs:
+            e.close()

@@ -57,7 +57,7 @@ def test_cpp_sharded_msm_contexts(log_n, world, split):
     p = subprocess.run([exe, str(log_n), str(world), split, str(seed), "2"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
-    assert out["equal"] is True and out["contexts"] == world and out["split"] == split
+    assert out["equal"] is True and out["multi_call_equal"] is True and out["contexts"] == world and out["split"] == split
     assert out["whole_affine_mont"] == out["sharded_affine_mont"]
     # the closed form: sum_i c_i (s + i t) with the program's inputs
     n = 1 << log_n
