@@ -765,7 +765,15 @@ template <int E> __global__ __launch_bounds__(64 * K3_TEAM) void k_pow_mod_chain
             } else if (bit || uni) {
                 // wait for square i (every wave polls for itself: no workgroup barrier on this path); the squarer never waits for
                 // anyone and was dispatched first, so the wait is bounded by its progress
-                while (__hip_atomic_load(D.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= i) __builtin_amdgcn_s_sleep(2);
+                // (bounded: ~2^27 polls of >= 100 ns are tens of seconds, far beyond any chain -- a wave must have an exit it reaches
+                // whatever happens to the other workgroup; the step then runs on stale limbs and the status says so)
+                for (unsigned spins = 0; __hip_atomic_load(D.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= i; ++spins) {
+                    if (spins > (1u << 27)) {
+                        st |= ST_INTERNAL;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
                 asm volatile("" ::: "memory");   // the limb loads below stay below the counter's
                 LD<E> cur;
 #pragma unroll
