@@ -815,9 +815,11 @@ class _stdout_to_stderr:
         return False
 
 
-def cpu_baseline(shape, n_steps, enc_bits, k, log):
+def cpu_baseline(shape, n_steps, enc_bits, k, log, check_wl=None):
     """The C restatement (oracle/pz_oracle.c, kind 'port') timed on this host's cores on a bounded
-    sample of the same workload, extrapolated with the per-proof counts of `shape`."""
+    sample of the same workload, extrapolated with the per-proof counts of `shape`.  This leg is the ONE place of bench.py that
+    touches oracle/: besides the timing it runs the checker (`oracle_check`) on the serial reference verify_pipelined kept in
+    `check_wl` -- as the checker, never as the thing measured."""
     import random
 
     from oracle import cref
@@ -855,7 +857,14 @@ def cpu_baseline(shape, n_steps, enc_bits, k, log):
     t_step = (time.time() - t) / max(1, len(steps))
     per_proof = (shape.msm_full * t_msm_full + (shape.msm_witness + shape.msm_lookup) * t_msm_wit
                  + shape.polys * (t_ntt + t_ntt_ext) + n_steps * t_step)
+    checker = None
+    if check_wl is not None:
+        try:
+            checker = oracle_check(check_wl, log)
+        except Exception as ex:
+            checker = {"ok": None, "error": repr(ex)}
     return {
+        "checker": checker,
         "value": 1.0 / per_proof, "unit": "proofs/s", "cores": int(cores), "kind": "port",
         "per_kernel_ms": {"msm_2pow%d_full_width" % k: t_msm_full * 1e3, "msm_2pow%d_witness_like" % k: t_msm_wit * 1e3,
                           "ntt_2pow%d" % k: t_ntt * 1e3, "ntt_2pow%d" % (k + 2): t_ntt_ext * 1e3, "mul_mod_step_us_single_thread": t_step * 1e6},
@@ -1415,20 +1424,18 @@ def main():
             if dropin_dev.get("verified") is False or not dropin_dev["commitments_equal_python_path"]:
                 out["comparable"] = False
     if not args.no_cpu_baseline and args.scale == 1.0 and world == 1:   # rank 0 at N = 1 only
+        want_check = bool(verification and verification.get("verified") and wl.circuit == "encrypt")
         try:
-            out["cpu_baseline"] = cpu_baseline(sh, wl.n_steps, args.enc_bits, args.k, log)
+            out["cpu_baseline"] = cpu_baseline(sh, wl.n_steps, args.enc_bits, args.k, log, check_wl=wl if want_check else None)
         except Exception as ex:  # the checker must never take the bench line down
             out["cpu_baseline"] = {"value": None, "error": repr(ex)}
-        # the same leg holds the checker: the serial reference of verify_pipelined against the oracle chain
-        if verification and verification.get("verified") and wl.circuit == "encrypt":
-            try:
-                vo = oracle_check(wl, log)
-                out["verification"]["vs_oracle"] = vo
-                if not vo.get("ok"):
-                    out["verified"] = out["verification"]["verified"] = False
-                    out["comparable"] = False
-            except Exception as ex:
-                out["verification"]["vs_oracle"] = {"ok": None, "error": repr(ex)}
+        # the leg's checker result belongs to the verification: the serial reference of verify_pipelined against the oracle chain
+        vo = out["cpu_baseline"].pop("checker", None)
+        if vo is not None:
+            out["verification"]["vs_oracle"] = vo
+            if vo.get("ok") is False:
+                out["verified"] = out["verification"]["verified"] = False
+                out["comparable"] = False
     if out["roofline_int"]["achieved"]:
         out["roofline_int"]["frac"] = out["roofline_int"]["achieved"] / out["roofline_int"]["peak"]
         if out["roofline_int"]["achieved_alone"]:
