@@ -132,6 +132,46 @@ static void host_fr_pow(const uint64_t a[4], unsigned e, uint64_t out[4]) {   //
     }
     memcpy(out, acc, 32);
 }
+// CPU-only consistency check of the three host helpers above (no device call; outside the pz_ ABI: tests/test_host_logic.py calls it
+// through ctypes): powers of two computed by doubling (host_fr_shl), by Montgomery products (host_fr_mul) and by square-and-
+// multiply (host_fr_pow) must coincide, limb for limb.  Returns 0, or the number of the first check that failed.
+extern "C" int pzx_host_selftest(void) {
+    static const uint64_t ONE[4] = {0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL};
+    auto limbs_of = [](const uint64_t x[4]) { return host_fr_shl(x, 0); };
+    auto same = [](const S29& a, const S29& b) { return memcmp(a.v, b.v, sizeof a.v) == 0; };
+    uint64_t two[4], acc[4], pw[4];
+    {   // 2 in Montgomery form = ONE + ONE mod r, built from the limbs of ONE doubled once
+        const S29 d = host_fr_shl(ONE, 1);
+        unsigned __int128 carry = 0;
+        memset(two, 0, sizeof two);
+        for (int i = 0; i < 9; ++i) {   // limbs -> 4 x u64
+            const unsigned bit = 29u * i, j = bit >> 6, o = bit & 63;
+            two[j] |= (uint64_t)d.v[i] << o;
+            if (o > 35 && j + 1 < 4) two[j + 1] |= (uint64_t)d.v[i] >> (64 - o);
+        }
+        (void)carry;
+    }
+    if (!same(limbs_of(two), host_fr_shl(ONE, 1))) return 1;
+    host_fr_mul(ONE, ONE, acc);
+    if (memcmp(acc, ONE, 32)) return 2;                       // 1 * 1 = 1
+    memcpy(acc, ONE, 32);
+    for (unsigned k = 1; k <= 300; ++k) {                     // 2^k three ways (k beyond 254: the reductions are exercised)
+        host_fr_mul(acc, two, acc);
+        if (!same(limbs_of(acc), host_fr_shl(ONE, k))) return 100 + (int)k;
+        if (k % 37 == 0 || k == 300) {
+            host_fr_pow(two, k, pw);
+            if (memcmp(pw, acc, 32)) return 1000 + (int)k;
+        }
+    }
+    return 0;
+}
+// the helpers themselves for the CPU tests (compared there with Python integers)
+extern "C" void pzx_host_fr_mul(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) { host_fr_mul(a, b, out); }
+extern "C" void pzx_host_fr_pow(const uint64_t a[4], unsigned e, uint64_t out[4]) { host_fr_pow(a, e, out); }
+extern "C" void pzx_host_fr_shl(const uint64_t c[4], unsigned k, uint32_t out[9]) {
+    const S29 r = host_fr_shl(c, k);
+    memcpy(out, r.v, sizeof r.v);
+}
 __device__ __forceinline__ Fr29 f29_add_s(const Fr29& a, const u32 (&b)[9]) {
     Fr29 r;
 #pragma unroll

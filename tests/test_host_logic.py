@@ -88,3 +88,42 @@ def test_params_kzg_file_roundtrip_and_malformed(tmp_path):
         srs.read_params_kzg(p)
     with pytest.raises(ValueError):
         srs.write_params_kzg(p, k, g[:3], gl)
+
+
+def test_host_field_helpers_of_the_row_kernels():
+    """CPU: the host-side Fr arithmetic that turns challenges into the SGPR-resident limbs of the quotient kernels
+    (pz_quotient.hip: host_fr_mul / host_fr_pow / host_fr_shl, exported for tests as pzx_*) against Python integers"""
+    import ctypes
+    import random
+
+    import numpy as np
+
+    import paillier_halo2_amd as pz
+    from paillier_halo2_amd import consts
+
+    pz.build()
+    L = ctypes.CDLL(pz.SO_PATH)
+    assert L.pzx_host_selftest() == 0
+    r, R = consts.FR_R, 1 << 256
+    rng = random.Random(41)
+    u64x4 = lambda x: np.array([(x >> (64 * i)) & (2 ** 64 - 1) for i in range(4)], dtype=np.uint64)
+    val = lambda a: sum(int(v) << (64 * i) for i, v in enumerate(a))
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for _ in range(50):
+        x, y = rng.randrange(r), rng.randrange(r)
+        a, b, out = u64x4(x * R % r), u64x4(y * R % r), np.zeros(4, dtype=np.uint64)
+        L.pzx_host_fr_mul(P(a), P(b), P(out))
+        assert val(out) == x * y * R % r                       # Montgomery product, canonical
+        e = rng.randrange(0, 5000)
+        L.pzx_host_fr_pow(P(a), ctypes.c_uint(e), P(out))
+        assert val(out) == pow(x, e, r) * R % r
+        k = rng.choice([0, 1, 5, 10, 29, 64])
+        limbs = np.zeros(9, dtype=np.uint32)
+        L.pzx_host_fr_shl(P(a), ctypes.c_uint(k), P(limbs))
+        assert sum(int(v) << (29 * i) for i, v in enumerate(limbs)) == (x * R << k) % r
+        assert all(int(v) < (1 << 29) for v in limbs[:8])
+    # edge values: 0, 1, r - 1
+    for x in (0, 1, r - 1):
+        a, out = u64x4(x * R % r), np.zeros(4, dtype=np.uint64)
+        L.pzx_host_fr_mul(P(a), P(a), P(out))
+        assert val(out) == x * x * R % r
