@@ -280,6 +280,23 @@ def test_pow_mod_trace_vs_oracle(eng, cref):
                 assert [cref.limbs_to_int(st[i]) for i in range(4)] == [a, b, q, r]
 
 
+@pytest.mark.parametrize("L", [64, 96])
+def test_pow_mod_trace_extreme_limbs(eng, cref, L):
+    """the team product's carry chains at their worst (round 4: hand-written v_add_co / v_addc chains without wait states, digit-wise
+    sums of the partial products): moduli and bases whose limbs are all ones / alternate all-ones and zero, exponents with every
+    bit set -- every step's (a, b, q, r) against Python integers, for both capacities (E = 1 and E = 2)"""
+    full = (1 << (64 * L)) - 1
+    alt = int("".join("ffffffffffffffff0000000000000000" for _ in range(L // 2)), 16)
+    el = 1
+    for mod, base in ((full, full - 1), (full - (1 << 64) + 2, full - 5), (alt | 1 | (1 << (64 * L - 1)), alt), ((1 << (64 * L - 1)) + 1, full >> 1)):
+        for e in ((1 << 24) - 1, (1 << 20) | 1):
+            res, steps, ns = eng.paillier_trace(L, cref.int_to_limbs(mod, L), cref.int_to_limbs(base % mod, L), cref.int_to_limbs(e, el), el)
+            acc, psteps = P.pow_mod_fixed_exp_trace(base % mod, e, mod)
+            assert cref.limbs_to_int(res) == acc and ns == len(psteps)
+            for k, (st, (a, b, q, r)) in enumerate(zip(steps, psteps)):
+                assert [cref.limbs_to_int(st[i]) for i in range(4)] == [a, b, q, r], (hex(mod)[:20], e, k)
+
+
 def test_encrypt_golden(eng, cref):
     """PaillierChip::encrypt witness (paillier.rs:32-60): value == paillier_enc_native and the step
     trace matches the fixture digest, for the reference's 128-bit shape and the 2048/3072-bit keys."""
