@@ -374,7 +374,9 @@ int pz_quotient_gate_dev(pz_ctx* ctx, const uint64_t* d_adv_ext, size_t adv_stri
  * chunk_len, all arrays on the extended domain of 2^log_ext points X_i = coset_g * omega_ext^i, one domain row =
  * rot_step indices, last_rotation = blinding_factors + 1 rows.  In halo2's order, each folded as h = h*y + term:
  *   l0 (1 - z_0);  l_last (z_last^2 - z_last);  for j > 0: l0 (z_j - z_{j-1}(omega^-last_rotation X));
- *   for every set: l_active ( z_j(omega X) prod_c (v_c + beta sigma_c + gamma) - z_j(X) prod_c (v_c + delta^c beta X + gamma) ). */
+ *   for every set: l_active ( z_j(omega X) prod_c (v_c + beta sigma_c + gamma) - z_j(X) prod_c (v_c + delta^c beta X + gamma) ).
+ * omega_ext must be a PRIMITIVE 2^log_ext-th root of unity (log_ext >= 1): rows i and i + 2^(log_ext-1) are evaluated together and
+ * share the identity term through X_{i + N/2} = -X_i.  All challenges canonical (below r), Montgomery form. */
 int pz_quotient_permutation_dev(pz_ctx* ctx, const uint64_t* d_cols_ext, size_t col_stride, const uint64_t* d_sigma_ext,
                                 size_t sigma_stride, const uint64_t* d_z_ext, size_t z_stride, uint32_t n_sets,
                                 uint32_t chunk_len, uint32_t m_total, uint32_t log_ext, uint32_t rot_step,
