@@ -54,6 +54,16 @@ enum pz_status {
     PZ_ERR_ASYNC = -10        /* reported by a synchronising entry point (pz_sync, pz_download, the host-pointer MSM calls): an
                                  earlier asynchronous pz_msm_g1* call found its scalars changed while it ran; its outputs are
                                  invalid (no out-of-bounds access took place: positions are checked on the device) */
+    ,
+    PZ_ERR_INTERNAL = -11     /* a device-side wait ran into its bound.  Only source today: K3 (pz_paillier_trace / pz_paillier_encrypt*):
+                                 a chain is worked by two workgroups, and a multiplier workgroup waits for each square its squarer
+                                 publishes; that wait is bounded (2^27 polls, tens of seconds) so that every wave has an exit whatever
+                                 happens to the other workgroup.  For the caller: the call has returned cleanly, c_out / result /
+                                 n_steps of the affected chains were NOT written and their step records are incomplete -- discard all
+                                 outputs of the call; the context and its device memory are intact and the same call may simply be
+                                 repeated.  It does not occur in normal operation (roles are handed out by arrival, so a multiplier's
+                                 squarer has always started before it; see csrc/pz_bigint.hip k_pow_mod_chain); it is the defined
+                                 outcome if the device stops scheduling a started workgroup. */
 };
 
 /* ---------------------------------------------------------------------------------------------
@@ -70,7 +80,7 @@ int pz_set_stream(pz_ctx* ctx, void* hip_stream);
 int pz_sync(pz_ctx* ctx);
 /* explicit ABI version, bumped whenever an entry point below is added, removed or changes meaning (measurement probes are
  * not part of this ABI: they live in libpz_probe.so).  A binding compares it with the PZ_ABI_VERSION it was built against. */
-#define PZ_ABI_VERSION 4
+#define PZ_ABI_VERSION 5
 int pz_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -270,6 +280,24 @@ int pz_circuit_expand_dev(pz_ctx* ctx, int kind, uint32_t limbs_n, uint32_t limb
                           const uint64_t* inputs, const uint64_t* d_steps, size_t n_steps_g, size_t n_steps_r,
                           const uint64_t* d_modulus, uint64_t* d_advice, uint64_t* d_lookup, size_t rows, size_t col_stride);
 
+/* The same stream with the ADVICE cells in halo2-lib's break-point column layout -- what the dependency's assign_with_constraints
+ * [D] does with the Context's cell list when it fills the basic-gate columns (reached from bench.rs:161-171 through keygen /
+ * create_proof -> synthesize): a 4-cell gate never straddles two columns; the column ends where one would, and the cell it ends
+ * with is written AGAIN as row 0 of the next column (the two copies are tied by an equality constraint of the circuit).
+ *   pz_circuit_break_points (host, no device work): from the selector mask of the stream (gate_mask[i] != 0 where a gate window
+ *   starts at cell i) and max_rows (usable rows of a column) -> starts[j] = the stream index of column j's row 0, j < *n_cols, and
+ *   starts[*n_cols] = n_cells.  starts_out may be NULL (count only); PZ_ERR_CAPACITY if capacity < *n_cols + 1; PZ_ERR_UNSUPPORTED if
+ *   two gates overlap by other than three cells at a break (the dependency asserts the same).
+ *   pz_circuit_expand_cols_dev: as pz_circuit_expand_dev, the advice stream placed by d_col_starts (DEVICE array of n_adv_cols + 1
+ *   entries as above), columns col_stride elements apart; the lookup stream is cut plainly into columns of lookup_rows cells.
+ *   Column j's rows above starts[j + 1] - starts[j] are not written. */
+int pz_circuit_break_points(const uint8_t* gate_mask, size_t n_cells, size_t max_rows, uint64_t* starts_out, size_t capacity,
+                            size_t* n_cols);
+int pz_circuit_expand_cols_dev(pz_ctx* ctx, int kind, uint32_t limbs_n, uint32_t limb_bits, uint32_t lookup_bits,
+                               const uint64_t* inputs, const uint64_t* d_steps, size_t n_steps_g, size_t n_steps_r,
+                               const uint64_t* d_modulus, uint64_t* d_advice, uint64_t* d_lookup, const uint64_t* d_col_starts,
+                               size_t n_adv_cols, size_t max_rows, size_t lookup_rows, size_t col_stride);
+
 /* RefreshAux::new(limb_bits, l, r).increased_limbs_vec (paillier.rs:40-44): the number of further limbs each product limb's
  * maximal value spills into; *n_out entries (= the refreshed integer's limb count) are written. */
 int pz_refresh_aux(uint32_t limb_bits, uint32_t num_limbs_l, uint32_t num_limbs_r, uint8_t* increased_limbs,
@@ -326,7 +354,10 @@ int pz_poly_eval_multi_dev(pz_ctx* ctx, const uint64_t* d_coeffs, size_t n_cols,
 
 /* The prover steps between the commitments and the NTTs (in the reference all of
  * them run inside create_proof, reached from /root/reference/src/bench.rs:161-171).  Device pointers throughout, field
- * elements Fr Montgomery, strides in uint64_t units; challenges / constants are host pointers to one element. */
+ * elements Fr Montgomery, strides in uint64_t units; challenges / constants are host pointers to one element.
+ * Precondition checked on entry: the challenges beta, gamma, delta, y handed to pz_permutation_product_sets_dev and the three
+ * pz_quotient_*_dev functions must be canonical (below r) -- they are converted on the host into the limb form the kernels
+ * keep in scalar registers; a non-canonical word returns PZ_ERR_INVALID (it is not reduced). */
 /* halo2 BatchInvert: d_a[i] <- 1 / d_a[i] in place, zeros stay zero. */
 int pz_fr_batch_invert_dev(pz_ctx* ctx, uint64_t* d_a, size_t n);
 /* running product: d_z[0] = z0, d_z[i+1] = d_z[i] * d_a[i] for i < n-1 (n outputs; d_z may alias d_a). */
@@ -384,6 +415,19 @@ int pz_quotient_permutation_dev(pz_ctx* ctx, const uint64_t* d_cols_ext, size_t 
                                 const uint64_t* d_l_active, const uint64_t beta[4], const uint64_t gamma[4],
                                 const uint64_t delta[4], const uint64_t coset_g[4], const uint64_t omega_ext[4],
                                 const uint64_t y[4], uint64_t* d_h);
+/* the same for a RANGE of sets, so that the prover can stream tiles of extended columns through it (evaluate_h never needs all
+ * columns on the extended domain at once): this call adds the product lines of sets [set_lo, set_lo + n_sets) of n_sets_total;
+ * d_cols_ext / d_sigma_ext point at the call's first column (= column set_lo * chunk_len of the argument) and m_cols counts the call's
+ * columns (n_sets * chunk_len, fewer only when the call ends with the argument's last set); d_z_ext holds ALL n_sets_total products.
+ * head != 0: the boundary and chaining lines (l0 (1 - z_0), l_last (z_last^2 - z_last), l0 (z_j - z_{j-1}(omega^-last X))) are added
+ * first -- pass it with the first range only.  Calls in increasing set order give the value of one pz_quotient_permutation_dev. */
+int pz_quotient_permutation_part_dev(pz_ctx* ctx, const uint64_t* d_cols_ext, size_t col_stride, const uint64_t* d_sigma_ext,
+                                     size_t sigma_stride, const uint64_t* d_z_ext, size_t z_stride, uint32_t n_sets_total,
+                                     uint32_t set_lo, uint32_t n_sets, uint32_t chunk_len, uint32_t m_cols, int head, uint32_t log_ext,
+                                     uint32_t rot_step, uint32_t last_rotation, const uint64_t* d_l0, const uint64_t* d_l_last,
+                                     const uint64_t* d_l_active, const uint64_t beta[4], const uint64_t gamma[4],
+                                     const uint64_t delta[4], const uint64_t coset_g[4], const uint64_t omega_ext[4],
+                                     const uint64_t y[4], uint64_t* d_h);
 /* evaluate_h, lookup arguments (n_lookups of them against one table column), per lookup in halo2's order:
  *   l0 (1 - z);  l_last (z^2 - z);  l_active ( z(omega X)(a' + beta)(s' + gamma) - z(X)(a + beta)(s + gamma) );
  *   l0 (a' - s');  l_active (a' - s')(a' - a'(omega^-1 X)). */

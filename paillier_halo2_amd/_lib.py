@@ -72,6 +72,9 @@ SIGNATURES = {
                                    C.POINTER(C.c_size_t)]),
     "pz_circuit_expand_dev": (C.c_int, [VP, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, VP, VP, C.c_size_t, C.c_size_t, VP, VP, VP,
                                         C.c_size_t, C.c_size_t]),
+    "pz_circuit_break_points": (C.c_int, [VP, C.c_size_t, C.c_size_t, VP, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "pz_circuit_expand_cols_dev": (C.c_int, [VP, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, VP, VP, C.c_size_t, C.c_size_t, VP, VP, VP,
+                                             VP, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]),
     "pz_srs_setup_g1_dev": (C.c_int, [VP, C.c_uint32, VP, VP, VP, VP]),
     "pz_srs_lagrange_from_monomial_dev": (C.c_int, [VP, C.c_uint32, VP, VP, VP, VP]),
     "pz_permutation_sigma_dev": (C.c_int, [VP, VP, VP, C.c_size_t, C.c_uint32, VP, VP, VP, C.c_size_t]),
@@ -92,6 +95,9 @@ SIGNATURES = {
     "pz_quotient_permutation_dev": (C.c_int, [VP, VP, C.c_size_t, VP, C.c_size_t, VP, C.c_size_t, C.c_uint32, C.c_uint32,
                                               C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, VP, VP, VP, VP, VP, VP, VP, VP,
                                               VP, VP]),
+    "pz_quotient_permutation_part_dev": (C.c_int, [VP, VP, C.c_size_t, VP, C.c_size_t, VP, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                   C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, VP, VP, VP, VP, VP,
+                                                   VP, VP, VP, VP, VP]),
     "pz_quotient_lookup_dev": (C.c_int, [VP, VP, C.c_size_t, VP, VP, C.c_size_t, VP, C.c_size_t, VP, C.c_size_t, C.c_uint32,
                                          C.c_uint32, C.c_uint32, VP, VP, VP, VP, VP, VP, VP]),
     "pz_quotient_finish_dev": (C.c_int, [VP, VP, C.c_uint32, C.c_uint32, VP, VP]),
@@ -166,3 +172,4 @@ PZ_ERR_UNSUPPORTED = -7
 PZ_ERR_CAPACITY = -8
 PZ_ERR_MESSAGE_RANGE = -9
 PZ_ERR_ASYNC = -10
+PZ_ERR_INTERNAL = -11

@@ -249,6 +249,18 @@ template <int E> struct TeamCtx {
 #endif
 // (forceinline, like mul_mod below: a TeamCtx / BarrettCtx whose address reaches a real call lives in scratch memory, and every
 // T.parity / B.mu access of the callee becomes a private-memory round trip -- ~2000 clock units per product were exactly that)
+// Wait states inside the hand-written multi-instruction asm blocks.  gfx940 / gfx950 require two wait states between a VALU
+// instruction that writes an SGPR or VCC (v_readlane, v_add_co / v_addc_co carry-out) and a VALU instruction that reads it (LLVM's
+// GCNHazardRecognizer: VALUWriteSGPRVALURead, the `s_nop 1` hipcc pads its own carry chains with on this target).  The recogniser
+// does not look inside asm strings, so the blocks carry the `s_nop 1` themselves.  Measured round 4: identical traces without them on
+// every box (the carry looked interlocked) and 12 % less time per step -- an empirical observation for a lone wave per SIMD, not an
+// ISA guarantee, and in the pipelined prover K3 shares its CUs with K1 / K2 waves.  -DPZ_K3_NO_WAITSTATES builds the nop-free chain
+// for measurement only.
+#ifdef PZ_K3_NO_WAITSTATES
+#define K3_WS ""
+#else
+#define K3_WS "s_nop 1\n\t"
+#endif
 template <int E> __device__ __forceinline__ void ld_mul_team(TeamCtx<E>& T, LD<E>& lo, LD<E>& hi, const LD<E> a, const LD<E> b) {
     constexpr unsigned C = 64 * E, SL = 64 / K3_TEAM;   // SL outer lanes (SL * E limbs) per wave
     u64 col[E];
@@ -281,11 +293,11 @@ template <int E> __device__ __forceinline__ void ld_mul_team(TeamCtx<E>& T, LD<E
             const unsigned jj = j0 + jl;
             const u32 A0 = __builtin_amdgcn_readlane(a_lo, jj), A1 = __builtin_amdgcn_readlane(a_hi, jj);
             u64 xx = 0;
-            asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(xx) : "s"(A0), "v"(b0) : "vcc");
+            asm(K3_WS "v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(xx) : "s"(A0), "v"(b0) : "vcc");   // A0 / A1 come from v_readlane
             u64 y = xx >> 32;
             asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(y) : "s"(A0), "v"(b1) : "vcc");
             u64 z = (u32)y;
-            asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(z) : "s"(A1), "v"(b0) : "vcc");
+            asm(K3_WS "v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(z) : "s"(A1), "v"(b0) : "vcc");
             u64 w = y >> 32;
             asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w) : "s"(A1), "v"(b1) : "vcc");
             const u32 zh = (u32)(z >> 32);
@@ -295,22 +307,20 @@ template <int E> __device__ __forceinline__ void ld_mul_team(TeamCtx<E>& T, LD<E
             p2[jl] = (u32)w;
             p3[jl] = (u32)(w >> 32);
         }
-        // (2) the column chain: additions only.  (No wait states between v_add_co / v_addc: the carry through VCC is interlocked in
-        // hardware -- a build with `s_nop 1` after every carry producer, as hipcc pads its own code on gfx950, gives identical
-        // traces and 12 % more time per step: a lone wave pays a full issue slot for every s_nop)
+        // (2) the column chain: additions only, every carry consumer behind its two wait states (K3_WS above)
         u32 c0 = 0, c1 = 0, c2 = 0;
         volatile u64* lo_dst = lane == 0 ? &B.lo[j0] : &B.sink[lane];   // one ds_write_b64 with an immediate offset per iteration
 #pragma unroll
         for (unsigned jl = 0; jl < SL; ++jl) {
-            asm("v_add_co_u32 %0, vcc, %0, %3\n\tv_addc_co_u32 %1, vcc, %1, %4, vcc\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc"
+            asm("v_add_co_u32 %0, vcc, %0, %3\n\t" K3_WS "v_addc_co_u32 %1, vcc, %1, %4, vcc\n\t" K3_WS "v_addc_co_u32 %2, vcc, 0, %2, vcc"
                 : "+v"(c0), "+v"(c1), "+v"(c2) : "v"(p0[jl]), "v"(p1[jl]) : "vcc");
             lo_dst[jl] = ((u64)c1 << 32) | c0;     // lane 0: the finished low limb of this outer limb; other lanes: into the sink
             // shift one limb down: new column = column of lane + 1 (without its overflow count) + high half of the product + this
             // lane's overflow count
             u32 t0 = dpp_down1(c0), t1 = dpp_down1(c1), k = 0;
-            asm("v_add_co_u32 %0, vcc, %0, %3\n\tv_addc_co_u32 %1, vcc, %1, %4, vcc\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc"
+            asm("v_add_co_u32 %0, vcc, %0, %3\n\t" K3_WS "v_addc_co_u32 %1, vcc, %1, %4, vcc\n\t" K3_WS "v_addc_co_u32 %2, vcc, 0, %2, vcc"
                 : "+v"(t0), "+v"(t1), "+v"(k) : "v"(p2[jl]), "v"(p3[jl]) : "vcc");
-            asm("v_add_co_u32 %0, vcc, %0, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc"
+            asm("v_add_co_u32 %0, vcc, %0, %3\n\t" K3_WS "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t" K3_WS "v_addc_co_u32 %2, vcc, 0, %2, vcc"
                 : "+v"(t0), "+v"(t1), "+v"(k) : "v"(c2) : "vcc");
             c0 = t0;
             c1 = t1;
@@ -592,7 +602,7 @@ template <int E> __device__ __forceinline__ bool barrett_setup(BarrettCtx<E>& B,
     return true;
 }
 
-enum { ST_OK = 0, ST_RANGE = 1, ST_ZERO_MOD = 2, ST_INTERNAL = 4 };
+enum { ST_OK = 0, ST_RANGE = 1, ST_ZERO_MOD = 2, ST_INTERNAL = 4, ST_TIMEOUT = 8 };
 
 // the product routine of a mul_mod: one wave on its own (k_mul_mod) or a team of waves (k_pow_mod_chain)
 template <int E> struct SoloMul {
@@ -680,14 +690,29 @@ struct ChainDesc {
                          // bits, per bit the step (acc, sq) then the step (sq, sq); acc takes the product only if the bit is set
     u64* sq_buf;         // hand-off from the squarer to the multiplier: square i at sq_buf + i * L (max exponent bits x L limbs)
     u32* ready;          // number of squares published so far (zeroed by the host before the launch)
+    u32 spin_limit;      // polls a multiplier wave makes for one square before it gives up (ST_TIMEOUT); K3_SPIN_LIMIT unless a test lowers it
+    u32 test_no_publish; // test hook (PZ_K3_TEST_NO_PUBLISH): the squarer never advances `ready`, so the bounded wait is exercised
 };
+#define K3_SPIN_LIMIT (1u << 27)   // x >= 100 ns per poll: tens of seconds, far beyond any chain
 
-template <int E> __global__ __launch_bounds__(64 * K3_TEAM) void k_pow_mod_chain(const ChainDesc* __restrict__ descs, unsigned n_chains) {
+template <int E> __global__ __launch_bounds__(64 * K3_TEAM) void k_pow_mod_chain(const ChainDesc* __restrict__ descs, unsigned n_chains,
+                                                                                    u32* __restrict__ ticket) {
     constexpr unsigned C = 64 * E;
     __shared__ u64 s_scratch[K3_TEAM][2 * C];   // per-wave shift scratch
     __shared__ TeamBuf<E> s_team[2];            // [parity]
-    const bool squarer = blockIdx.x < n_chains;     // workgroups [0, n): squarers; [n, 2n): multipliers of the same chains
-    const ChainDesc D = descs[squarer ? blockIdx.x : blockIdx.x - n_chains];
+    __shared__ unsigned s_role, s_dead_step;
+    // Roles by ARRIVAL, not by workgroup id: the first n workgroups that start running are the squarers of chains 0..n-1, the next n the
+    // multipliers.  A multiplier only ever waits for the squarer of its chain, whose ticket is lower, i.e. which has already started
+    // (and a squarer waits for nobody), so forward progress needs nothing from the dispatcher but that a workgroup which has started
+    // keeps running -- no assumption on the order in which workgroup ids are dispatched, or on how many are resident.
+    if (threadIdx.x == 0) {
+        s_role = atomicAdd(ticket, 1u);
+        s_dead_step = 0;
+    }
+    __syncthreads();
+    const unsigned role = s_role;
+    const bool squarer = role < n_chains;
+    const ChainDesc D = descs[squarer ? role : role - n_chains];
 #ifdef PZ_K3_PROF
     const unsigned long long k_t0 = clock64();
 #endif
@@ -750,9 +775,14 @@ template <int E> __global__ __launch_bounds__(64 * K3_TEAM) void k_pow_mod_chain
                 }
                 LD<E> q, r;
                 st |= mul_mod(B, q, r, sq, sq, tmul);
-                if (writer) {
+                if (writer && !D.test_no_publish) {
+#ifdef PZ_K3_RELEASE
+                    // measurement arm: the textbook publish (release = L2 write-back of everything dirty + wait, then the store)
+                    if (lane_id() == 0) __hip_atomic_store(D.ready, i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (lane_id() == 0) __hip_atomic_store(D.ready, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
                 }
                 if (writer && D.steps && sq_slot < D.steps_cap) {
                     u64* o = D.steps + (size_t)sq_slot * 4 * D.L;
@@ -768,13 +798,16 @@ template <int E> __global__ __launch_bounds__(64 * K3_TEAM) void k_pow_mod_chain
                 // (bounded: ~2^27 polls of >= 100 ns are tens of seconds, far beyond any chain -- a wave must have an exit it reaches
                 // whatever happens to the other workgroup; the step then runs on stale limbs and the status says so)
                 for (unsigned spins = 0; __hip_atomic_load(D.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= i; ++spins) {
-                    if (spins > (1u << 27)) {
-                        st |= ST_INTERNAL;
+                    if (spins > D.spin_limit) {
+                        st |= ST_TIMEOUT;
+                        s_dead_step = i + 1;   // every wave of the team gives up at the END of this step (see below): same value from all
                         break;
                     }
                     __builtin_amdgcn_s_sleep(2);
                 }
-                asm volatile("" ::: "memory");   // the limb loads below stay below the counter's
+                // acquire at agent scope: orders the limb loads below after the counter's (the compiler and the hardware both), and
+                // invalidates what this CU may hold of the hand-off lines
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 LD<E> cur;
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
@@ -791,12 +824,19 @@ template <int E> __global__ __launch_bounds__(64 * K3_TEAM) void k_pow_mod_chain
                     ld_store(o + 3 * D.L, r, D.L);
                 }
                 if (bit) acc = r;   // select(bit, muled, acc)
+                // a wave whose wait ran out has said so BEFORE this step's product barriers; every wave reads the flag after them,
+                // so the whole team leaves at the same step (a wave leaving alone would hang the others at the next barrier)
+                const unsigned dead = *(volatile unsigned*)&s_dead_step;
+                if (dead != 0 && dead <= i + 1) {
+                    st |= ST_TIMEOUT;
+                    break;
+                }
             }
             step_idx += (bit || uni) ? 2 : 1;
         }
     }
-    if (D.steps && step_idx > D.steps_cap) st |= ST_INTERNAL;
-    if (!squarer && writer) {
+    if (D.steps && step_idx > D.steps_cap && !(st & ST_TIMEOUT)) st |= ST_INTERNAL;
+    if (!squarer && writer && !(st & ST_TIMEOUT)) {   // after a timeout neither the result nor the step count is written
         ld_store(D.result, acc, D.L);
         if (D.n_steps && lane_id() == 0) *D.n_steps = step_idx;
     }
@@ -859,6 +899,10 @@ template <int E> __global__ __launch_bounds__(64) void k_mul_mod(const MulDesc* 
 // host
 // ------------------------------------------------------------------------------------------------
 static int status_to_rc(pz_ctx* ctx, u32 st) {
+    if (st & ST_TIMEOUT) {
+        snprintf(ctx->hip_err, sizeof ctx->hip_err, "big-integer kernel: a multiplier workgroup's bounded wait for its squarer ran out (status %u)", st);
+        return PZ_ERR_INTERNAL;
+    }
     if (st & ST_ZERO_MOD) return PZ_ERR_ZERO_MODULUS;
     if (st & ST_RANGE) return PZ_ERR_RANGE;
     if (st & ST_INTERNAL) {
@@ -868,25 +912,55 @@ static int status_to_rc(pz_ctx* ctx, u32 st) {
     return PZ_OK;
 }
 
-// per chain: the hand-off area of its two workgroups -- `bits` squares of L limbs + the progress counter (zeroed here, in stream order)
-static size_t chain_handoff_bytes(unsigned bits, unsigned L) { return (size_t)bits * L * 8 + 256; }
-static int chain_handoff_alloc(pz_ctx* ctx, size_t n_chains, unsigned bits, unsigned L, char** base) {
+// The hand-off area of a launch: per chain `bits` squares of L limbs; then ONE block of counters for the whole call, cleared by a single
+// memset in stream order -- per launch a role ticket, per chain the number of squares published (a 64-byte line each: a counter is polled
+// by the four waves of one multiplier while its squarer writes it; neighbours in one line would share that traffic).
+// The squares of a batch are bounded: at most K3_HANDOFF_CAP bytes of them exist at a time, larger batches run as several launches
+// one after the other on the stream (the multiplier consumes squares strictly in order, but a ring with a consumer counter would make
+// the squarer wait for a workgroup that may not have started: that is the one dependency the role tickets exclude).
+#define K3_HANDOFF_CAP ((size_t)1 << 30)
+static size_t chain_squares_bytes(unsigned bits, unsigned L) { return (size_t)bits * L * 8; }
+static unsigned env_u32(const char* name, unsigned dflt) {
+    const char* v = getenv(name);
+    return v && *v ? (unsigned)strtoul(v, nullptr, 0) : dflt;
+}
+static size_t chains_per_launch(unsigned bits, unsigned L, size_t n_chains) {
+    const size_t cap_kib = env_u32("PZ_K3_HANDOFF_CAP_KIB", 0);   // test hook: a small cap splits a small batch into several launches
+    size_t per = (cap_kib ? cap_kib << 10 : K3_HANDOFF_CAP) / chain_squares_bytes(bits, L);
+    per = per < 2 ? 2 : per & ~(size_t)1;   // the two chains of an instance stay in one launch
+    return per < n_chains ? per : n_chains;
+}
+struct ChainHandoff {
+    char* squares;     // chains_per_launch x chain_squares_bytes, reused by every launch of the call
+    char* counters;    // n_launches tickets, then n_chains ready counters, 64 bytes apart
+    size_t per_launch, n_launches;
+};
+static int chain_handoff_alloc(pz_ctx* ctx, size_t n_chains, unsigned bits, unsigned L, ChainHandoff* h) {
+    h->per_launch = chains_per_launch(bits, L, n_chains);
+    h->n_launches = (n_chains + h->per_launch - 1) / h->per_launch;
+    const size_t sq = h->per_launch * chain_squares_bytes(bits, L), cnt = (h->n_launches + n_chains) * 64;
     void* d;
-    PZCHK(pz_ws_get(ctx, WS_K3, n_chains * chain_handoff_bytes(bits, L), &d));
-    *base = (char*)d;
-    for (size_t i = 0; i < n_chains; ++i)
-        HIPCHK(ctx, hipMemsetAsync(*base + i * chain_handoff_bytes(bits, L) + (size_t)bits * L * 8, 0, 4, ctx->stream));
+    PZCHK(pz_ws_get(ctx, WS_K3, sq + cnt + 256, &d));
+    h->squares = (char*)d;
+    h->counters = (char*)d + ((sq + 255) & ~(size_t)255);
+    HIPCHK(ctx, hipMemsetAsync(h->counters, 0, cnt, ctx->stream));
     return PZ_OK;
 }
-static void chain_handoff_set(ChainDesc& d, char* base, size_t i, unsigned bits, unsigned L) {
-    d.sq_buf = (u64*)(base + i * chain_handoff_bytes(bits, L));
-    d.ready = (u32*)(base + i * chain_handoff_bytes(bits, L) + (size_t)bits * L * 8);
+static void chain_handoff_set(ChainDesc& d, const ChainHandoff& h, size_t i, unsigned bits, unsigned L) {
+    d.sq_buf = (u64*)(h.squares + (i % h.per_launch) * chain_squares_bytes(bits, L));
+    d.ready = (u32*)(h.counters + (h.n_launches + i) * 64);
+    d.spin_limit = env_u32("PZ_K3_SPIN_LIMIT", K3_SPIN_LIMIT);        // test hooks: tests/test_gpu_kernels.py::test_k3_bounded_wait
+    d.test_no_publish = env_u32("PZ_K3_TEST_NO_PUBLISH", 0);
 }
-static int launch_chains(pz_ctx* ctx, const ChainDesc* d_descs, size_t n, unsigned L) {
-    // grid: n squarers, then n multipliers (dispatch order = id order: a squarer is resident before its multiplier can wait for it)
-    if (L <= 64) hipLaunchKernelGGL(k_pow_mod_chain<1>, dim3((unsigned)(2 * n)), dim3(64 * K3_TEAM), 0, ctx->stream, d_descs, (unsigned)n);
-    else hipLaunchKernelGGL(k_pow_mod_chain<2>, dim3((unsigned)(2 * n)), dim3(64 * K3_TEAM), 0, ctx->stream, d_descs, (unsigned)n);
-    HIPCHK(ctx, hipGetLastError());
+static int launch_chains(pz_ctx* ctx, const ChainDesc* d_descs, size_t n, unsigned L, const ChainHandoff& h) {
+    // per launch: 2 m workgroups for m chains; who squares and who multiplies is decided by arrival (k_pow_mod_chain)
+    for (size_t l = 0, off = 0; off < n; ++l, off += h.per_launch) {
+        const size_t m = n - off < h.per_launch ? n - off : h.per_launch;
+        u32* ticket = (u32*)(h.counters + l * 64);
+        if (L <= 64) hipLaunchKernelGGL(k_pow_mod_chain<1>, dim3((unsigned)(2 * m)), dim3(64 * K3_TEAM), 0, ctx->stream, d_descs + off, (unsigned)m, ticket);
+        else hipLaunchKernelGGL(k_pow_mod_chain<2>, dim3((unsigned)(2 * m)), dim3(64 * K3_TEAM), 0, ctx->stream, d_descs + off, (unsigned)m, ticket);
+        HIPCHK(ctx, hipGetLastError());
+    }
     return PZ_OK;
 }
 static int launch_muls(pz_ctx* ctx, const MulDesc* d_descs, size_t n, unsigned L) {
@@ -975,15 +1049,13 @@ extern "C" int pz_paillier_trace(pz_ctx* ctx, uint32_t limbs_n2, const uint64_t*
     h.L = L;
     h.square_modulus = 0;
     h.steps_cap = (u32)need;
-    {
-        char* hb;
-        PZCHK(chain_handoff_alloc(ctx, 1, 64 * exp_limbs, L, &hb));
-        chain_handoff_set(h, hb, 0, 64 * exp_limbs, L);
-    }
+    ChainHandoff hb;
+    PZCHK(chain_handoff_alloc(ctx, 1, 64 * exp_limbs, L, &hb));
+    chain_handoff_set(h, hb, 0, 64 * exp_limbs, L);
     HIPCHK(ctx, hipMemcpyAsync(d_desc, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
     {
         pz_timer tm(ctx, PZ_T_TRACE);
-        PZCHK(launch_chains(ctx, d_desc, 1, L));
+        PZCHK(launch_chains(ctx, d_desc, 1, L, hb));
     }
     u32 st[2] = {0, 0};
     HIPCHK(ctx, hipMemcpyAsync(result, p + 2 * lb + eb, lb, hipMemcpyDeviceToHost, ctx->stream));
@@ -1057,7 +1129,7 @@ static int encrypt_impl(pz_ctx* ctx, uint32_t Ln, size_t batch, const uint64_t* 
     HIPCHK(ctx, hipMemsetAsync(d_status, 0, 4, ctx->stream));
     std::vector<ChainDesc> ch(2 * batch);
     std::vector<MulDesc> mu(batch);
-    char* hb;
+    ChainHandoff hb;
     PZCHK(chain_handoff_alloc(ctx, 2 * batch, 64 * Ln, L, &hb));
     for (size_t i = 0; i < batch; ++i) {
         u64* st_i = d_steps ? d_steps + i * steps_cap * 4 * L : nullptr;
@@ -1107,7 +1179,7 @@ static int encrypt_impl(pz_ctx* ctx, uint32_t Ln, size_t batch, const uint64_t* 
     HIPCHK(ctx, hipMemcpyAsync(d_mu, mu.data(), mu.size() * sizeof(MulDesc), hipMemcpyHostToDevice, ctx->stream));
     {
         pz_timer tm(ctx, PZ_T_TRACE);
-        PZCHK(launch_chains(ctx, d_ch, 2 * batch, L));
+        PZCHK(launch_chains(ctx, d_ch, 2 * batch, L, hb));
         PZCHK(launch_muls(ctx, d_mu, batch, L));
     }
     u32 st = 0;

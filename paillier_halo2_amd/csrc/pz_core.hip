@@ -42,7 +42,7 @@ __global__ void k_raw29(const Fr* __restrict__ src, u32* __restrict__ dst, size_
 // ------------------------------------------------------------------------------------------------
 // explicit ABI version: bumped whenever an entry point of include/pz.h is added, removed or changes meaning (1 = rounds 1-2;
 // 3 = round 3: device-memory entry points added, measurement probes moved out to libpz_probe.so; 4 = round 4: PZ_ERR_ASYNC,
-// pz_msm_g1_multi)
+// pz_msm_g1_multi; 5 = round 5: PZ_ERR_INTERNAL, the break-point column layout and the connected-proof entry points)
 extern "C" int pz_abi_version(void) { return PZ_ABI_VERSION; }
 
 extern "C" const char* pz_strerror(int s) {
@@ -58,6 +58,7 @@ extern "C" const char* pz_strerror(int s) {
         case PZ_ERR_CAPACITY: return "output capacity too small";
         case PZ_ERR_MESSAGE_RANGE: return "message does not fit the exponent bits of the uniform-shape circuit";
         case PZ_ERR_ASYNC: return "an asynchronous call found its inputs changed while it ran (or an internal invariant broken); its results are invalid";
+        case PZ_ERR_INTERNAL: return "a bounded device-side wait ran out; the call's outputs are invalid, the context is intact";
         default: return "unknown pz_status";
     }
 }

@@ -52,6 +52,12 @@ __device__ __forceinline__ Fr29 fr29_one256() {
 struct S29 {
     u32 v[9];
 };
+static bool host_fr_canonical(const uint64_t c[4]) {   // c < r: what host_fr_shl (and every kernel that takes its limbs) assumes
+    static const uint64_t R[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+    for (int i = 3; i >= 0; --i)
+        if (c[i] != R[i]) return c[i] < R[i];
+    return false;
+}
 static S29 host_fr_shl(const uint64_t c[4], unsigned k) {   // canonical c (Montgomery form, below r) -> limbs of c * 2^k mod r
     static const uint64_t R[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
     uint64_t x[4] = {c[0], c[1], c[2], c[3]};
@@ -185,7 +191,7 @@ __device__ __forceinline__ Fr29 f29_add_s(const Fr29& a, const u32 (&b)[9]) {
 // canonical (a product is tight and below 2p < 2^256: no conditional subtraction on the way out).  f29_inv works in the
 // 261-domain: fed acc * 2^256 it returns acc^-1 * 2^266, and one product by 1 * 2^256 brings that to acc^-1 * 2^261 -- the domain
 // in which inv * scratch lands in the 256-domain and inv * shl5(v) stays where it is.
-// mul_io != nullptr: the inverses are not stored; mul_io[i] <- mul_io[i] / a[i] instead (zeros of a leave mul_io[i] alone), a stays as
+// mul_io != nullptr: the inverses are not stored; mul_io[i] <- mul_io[i] / a[i] instead (mul_io[i] <- 0 where a[i] = 0: the inverse of zero is zero), a stays as
 // it was -- the numerator / denominator quotient of the grand-product arguments without a pass of its own
 __global__ __launch_bounds__(256) void k_batch_invert(Fr* __restrict__ a, Fr* __restrict__ scratch, size_t n, size_t T,
                                                       unsigned K, Fr* __restrict__ mul_io) {
@@ -207,7 +213,12 @@ __global__ __launch_bounds__(256) void k_batch_invert(Fr* __restrict__ a, Fr* __
         const size_t i = t + (size_t)j * T;
         if (i >= n) continue;
         const Fr v = fp_load<FrTag>(a + i);
-        if (fp_is_zero(v)) continue;
+        if (fp_is_zero(v)) {
+            // a zero denominator inverts to zero (ff::BatchInvert skips it and leaves 0), so the quotient the fused path forms is 0
+            // -- what batch_invert followed by the multiplication gave before the two were fused, and what the reference computes
+            if (mul_io) fp_store(mul_io + i, fp_zero<FrTag>());
+            continue;
+        }
         const Fr29 ai = f29_mul(inv, f29_load<FrTag>(scratch + i));   // 1 / a[i], 256-domain
         if (mul_io) f29_store_product(mul_io + i, f29_mul(ai, f29_load_shl5<FrTag>(mul_io + i)));
         else f29_store_product(a + i, ai);
@@ -452,6 +463,7 @@ extern "C" int pz_permutation_product_sets_dev(pz_ctx* ctx, const uint64_t* d_co
     const size_t n_sets = (m + chunk_len - 1) / chunk_len;
     if (col_stride % 4 || sigma_stride % 4 || z_stride % 4 || usable_rows >= n || n_sets > 65535 || m > 0xffffffu) return PZ_ERR_INVALID;
     if ((m > 1 && (col_stride < 4 * n || sigma_stride < 4 * n)) || (n_sets > 1 && z_stride < 4 * n)) return PZ_ERR_INVALID;
+    if (!host_fr_canonical(beta) || !host_fr_canonical(gamma) || !host_fr_canonical(delta)) return PZ_ERR_INVALID;   // pz.h: challenges below r
     PZ_ENTER(ctx);
     void *wp, *dp, *ws, *mu;
     PZCHK(pz_get_pow_table(ctx, omega, n, &wp));
@@ -504,6 +516,7 @@ extern "C" int pz_quotient_gate_dev(pz_ctx* ctx, const uint64_t* d_adv_ext, size
     const size_t N = (size_t)1 << log_ext;
     if (rot_step == 0 || rot_step >= N) return PZ_ERR_INVALID;
     if (n_cols > 1 && (adv_stride < 4 * N || sel_stride < 4 * N)) return PZ_ERR_INVALID;
+    if (!host_fr_canonical(y)) return PZ_ERR_INVALID;
     if (n_cols == 0) return PZ_OK;
     PZ_ENTER(ctx);
     hipLaunchKernelGGL(k_quotient_gate, dim3(pz_div_up(N, 256)), dim3(256), 0, ctx->stream, (const Fr*)d_adv_ext,
@@ -665,8 +678,13 @@ struct PermQ {
     const Fr *cols, *sigma, *z, *l0, *llast, *lactive, *xpow;
     size_t cs, ss, zs, N;
     unsigned n_sets, chunk_len, m_total, step, last_rot;
+    // a call may cover only the sets [set_lo, set_lo + n_sets) of n_sets_total (pz_quotient_permutation_part_dev: the prover streams
+    // 64-column tiles through the extension and this kernel): z always holds ALL sets' products (row stride zs), cols / sigma start
+    // at the call's first column, m_total counts the call's columns; head != 0 adds the boundary and chaining lines (first call only)
+    unsigned set_lo, n_sets_total, head;
     S29 y, gamma, delta, beta266;   // challenges as SGPR-resident limbs (host_fr_shl): y, gamma, delta times 2^261, beta times 2^266
-    S29 y_chain, y_sets;            // y^(n_sets - 1) and y^n_sets times 2^261: the Horner steps of a whole GROUP of lines
+    S29 bx266;                      // beta * delta^(index of the call's first column) times 2^266: the identity term's start
+    S29 y_chain, y_sets;            // y^(n_sets_total - 1) and y^n_sets times 2^261: the Horner steps of a whole GROUP of lines
 };
 // On the 29-bit field (fp29.cuh): ~210 instructions per product instead of ~380 on saturated 32-bit limbs.  Domains: memory
 // holds x * 2^256; f29_mul divides by 2^261, so in every product exactly one operand carries the extra 2^5 -- a challenge
@@ -692,7 +710,7 @@ __global__ __launch_bounds__(256) void k_quotient_permutation(PermQ q, Fr* __res
         acc[r] = f29_load<FrTag>(h + row[r]);
     }
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {   // the boundary lines: l0 and l_last rows are live only here
+    for (int r = 0; r < 2 && q.head; ++r) {   // the boundary lines: l0 and l_last rows are live only here
         const size_t i = row[r];
         const Fr29 one = fr29_one256();
         const Fr29 l0 = f29_load_shl5<FrTag>(q.l0 + i);
@@ -700,16 +718,16 @@ __global__ __launch_bounds__(256) void k_quotient_permutation(PermQ q, Fr* __res
         acc[r] = f29_mul2_s(acc[r], q.y.v, f29_sub<2, 29>(one, z_first), l0);
         {
             const Fr29 ll = f29_load_shl5<FrTag>(q.llast + i);
-            const Fr zl = fp_load<FrTag>(q.z + (size_t)(q.n_sets - 1) * q.zs + i);
+            const Fr zl = fp_load<FrTag>(q.z + (size_t)(q.n_sets_total - 1) * q.zs + i);
             const Fr29 z_lastset = f29_from_fp(zl);
             acc[r] = f29_mul2_s(acc[r], q.y.v, f29_sub<2, 29>(f29_mul(z_lastset, f29_from_fp_shl5(zl)), z_lastset), ll);
         }
         // the n_sets - 1 chaining lines share their factor l0: sum_j y^(S-1-j) l0 d_j = l0 * (Horner of the d_j in y), so the group
         // costs one plain product per line and ONE two-term reduction, instead of a two-term reduction per line (same field value,
         // hence the same canonical h)
-        if (q.n_sets > 1) {
+        if (q.n_sets_total > 1) {
             Fr29 t0 = f29_sub<2, 29>(f29_load<FrTag>(q.z + q.zs + i), f29_load<FrTag>(q.z + i_last[r]));
-            for (unsigned j = 2; j < q.n_sets; ++j) {
+            for (unsigned j = 2; j < q.n_sets_total; ++j) {
                 const Fr29 d = f29_sub<2, 29>(f29_load<FrTag>(q.z + (size_t)j * q.zs + i), f29_load<FrTag>(q.z + (size_t)(j - 1) * q.zs + i_last[r]));
                 t0 = f29_add(f29_mul_s(t0, q.y.v), d);   // tight + (< 2^31): a legal operand of the next product
             }
@@ -717,7 +735,7 @@ __global__ __launch_bounds__(256) void k_quotient_permutation(PermQ q, Fr* __res
         }
     }
     // beta * X_i (261-domain), X_i = x0 * w_ext^i from the cached power table; the second row's is its negative
-    Fr29 cur = f29_mul_s(f29_load<FrTag>(q.xpow + i0), q.beta266.v);
+    Fr29 cur = f29_mul_s(f29_load<FrTag>(q.xpow + i0), q.bx266.v);
     unsigned c = 0;
     // the next column's values and sigmas are requested before the current column's products start
     Fr v_n[2], s_n[2];
@@ -731,8 +749,8 @@ __global__ __launch_bounds__(256) void k_quotient_permutation(PermQ q, Fr* __res
         Fr29 left[2], right[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            left[r] = f29_load<FrTag>(q.z + (size_t)j * q.zs + i_next[r]);
-            right[r] = f29_load<FrTag>(q.z + (size_t)j * q.zs + row[r]);
+            left[r] = f29_load<FrTag>(q.z + (size_t)(q.set_lo + j) * q.zs + i_next[r]);
+            right[r] = f29_load<FrTag>(q.z + (size_t)(q.set_lo + j) * q.zs + row[r]);
         }
         for (unsigned t = 0; t < q.chunk_len && c < q.m_total; ++t, ++c) {
             const unsigned cn = c + 1 < q.m_total ? c + 1 : c;
@@ -761,6 +779,50 @@ __global__ __launch_bounds__(256) void k_quotient_permutation(PermQ q, Fr* __res
     }
 }
 
+extern "C" int pz_quotient_permutation_part_dev(pz_ctx* ctx, const uint64_t* d_cols_ext, size_t col_stride,
+                                                const uint64_t* d_sigma_ext, size_t sigma_stride, const uint64_t* d_z_ext,
+                                                size_t z_stride, uint32_t n_sets_total, uint32_t set_lo, uint32_t n_sets,
+                                                uint32_t chunk_len, uint32_t m_cols, int head, uint32_t log_ext, uint32_t rot_step,
+                                                uint32_t last_rotation, const uint64_t* d_l0, const uint64_t* d_l_last,
+                                                const uint64_t* d_l_active, const uint64_t beta[4], const uint64_t gamma[4],
+                                                const uint64_t delta[4], const uint64_t coset_g[4], const uint64_t omega_ext[4],
+                                                const uint64_t y[4], uint64_t* d_h) {
+    if (!ctx || !d_cols_ext || !d_sigma_ext || !d_z_ext || !d_l0 || !d_l_last || !d_l_active || !beta || !gamma || !delta ||
+        !coset_g || !omega_ext || !y || !d_h)
+        return PZ_ERR_INVALID;
+    if (log_ext > 28 || log_ext == 0 || n_sets == 0 || chunk_len == 0 || m_cols == 0 || col_stride % 4 || sigma_stride % 4 || z_stride % 4)
+        return PZ_ERR_INVALID;
+    if (n_sets_total == 0 || (size_t)set_lo + n_sets > n_sets_total) return PZ_ERR_INVALID;
+    const size_t N = (size_t)1 << log_ext;
+    // the call's columns fill its sets; only the LAST set of the whole argument may be short
+    if ((size_t)n_sets * chunk_len < m_cols || (size_t)(n_sets - 1) * chunk_len >= m_cols) return PZ_ERR_INVALID;
+    if (set_lo + n_sets < n_sets_total && (size_t)n_sets * chunk_len != m_cols) return PZ_ERR_INVALID;
+    if (rot_step == 0 || rot_step >= N || (size_t)last_rotation * rot_step >= N) return PZ_ERR_INVALID;
+    if ((m_cols > 1 && (col_stride < 4 * N || sigma_stride < 4 * N)) || (n_sets_total > 1 && z_stride < 4 * N)) return PZ_ERR_INVALID;
+    if (!host_fr_canonical(beta) || !host_fr_canonical(gamma) || !host_fr_canonical(delta) || !host_fr_canonical(y)) return PZ_ERR_INVALID;
+    PZ_ENTER(ctx);
+    PermQ q;
+    q.cols = (const Fr*)d_cols_ext; q.sigma = (const Fr*)d_sigma_ext; q.z = (const Fr*)d_z_ext;
+    q.l0 = (const Fr*)d_l0; q.llast = (const Fr*)d_l_last; q.lactive = (const Fr*)d_l_active;
+    q.cs = col_stride / 4; q.ss = sigma_stride / 4; q.zs = z_stride / 4; q.N = N;
+    q.n_sets = n_sets; q.chunk_len = chunk_len; q.m_total = m_cols; q.step = rot_step; q.last_rot = last_rotation;
+    q.set_lo = set_lo; q.n_sets_total = n_sets_total; q.head = head ? 1u : 0u;
+    q.beta266 = host_fr_shl(beta, 10); q.gamma = host_fr_shl(gamma, 5); q.delta = host_fr_shl(delta, 5); q.y = host_fr_shl(y, 5);
+    uint64_t yp[4], bx[4];
+    host_fr_pow(delta, set_lo * chunk_len, bx);       // delta^(first column of the call)
+    host_fr_mul(bx, beta, bx);
+    q.bx266 = host_fr_shl(bx, 10);
+    host_fr_pow(y, n_sets_total - 1, yp);
+    q.y_chain = host_fr_shl(yp, 5);
+    host_fr_pow(y, n_sets, yp);
+    q.y_sets = host_fr_shl(yp, 5);
+    void* xp;
+    PZCHK(pz_get_pow_table(ctx, omega_ext, N, &xp, coset_g));   // X_i = coset_g * omega_ext^i, cached across calls
+    q.xpow = (const Fr*)xp;
+    hipLaunchKernelGGL(k_quotient_permutation, dim3(pz_div_up(N / 2, 256)), dim3(256), 0, ctx->stream, q, (Fr*)d_h);   // a thread per row PAIR
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}
 extern "C" int pz_quotient_permutation_dev(pz_ctx* ctx, const uint64_t* d_cols_ext, size_t col_stride,
                                            const uint64_t* d_sigma_ext, size_t sigma_stride, const uint64_t* d_z_ext,
                                            size_t z_stride, uint32_t n_sets, uint32_t chunk_len, uint32_t m_total,
@@ -769,33 +831,9 @@ extern "C" int pz_quotient_permutation_dev(pz_ctx* ctx, const uint64_t* d_cols_e
                                            const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta[4],
                                            const uint64_t coset_g[4], const uint64_t omega_ext[4], const uint64_t y[4],
                                            uint64_t* d_h) {
-    if (!ctx || !d_cols_ext || !d_sigma_ext || !d_z_ext || !d_l0 || !d_l_last || !d_l_active || !beta || !gamma || !delta ||
-        !coset_g || !omega_ext || !y || !d_h)
-        return PZ_ERR_INVALID;
-    if (log_ext > 28 || log_ext == 0 || n_sets == 0 || chunk_len == 0 || m_total == 0 || col_stride % 4 || sigma_stride % 4 || z_stride % 4)
-        return PZ_ERR_INVALID;
-    const size_t N = (size_t)1 << log_ext;
-    if ((size_t)n_sets * chunk_len < m_total || (size_t)(n_sets - 1) * chunk_len >= m_total) return PZ_ERR_INVALID;
-    if (rot_step == 0 || rot_step >= N || (size_t)last_rotation * rot_step >= N) return PZ_ERR_INVALID;
-    if ((m_total > 1 && (col_stride < 4 * N || sigma_stride < 4 * N)) || (n_sets > 1 && z_stride < 4 * N)) return PZ_ERR_INVALID;
-    PZ_ENTER(ctx);
-    PermQ q;
-    q.cols = (const Fr*)d_cols_ext; q.sigma = (const Fr*)d_sigma_ext; q.z = (const Fr*)d_z_ext;
-    q.l0 = (const Fr*)d_l0; q.llast = (const Fr*)d_l_last; q.lactive = (const Fr*)d_l_active;
-    q.cs = col_stride / 4; q.ss = sigma_stride / 4; q.zs = z_stride / 4; q.N = N;
-    q.n_sets = n_sets; q.chunk_len = chunk_len; q.m_total = m_total; q.step = rot_step; q.last_rot = last_rotation;
-    q.beta266 = host_fr_shl(beta, 10); q.gamma = host_fr_shl(gamma, 5); q.delta = host_fr_shl(delta, 5); q.y = host_fr_shl(y, 5);
-    uint64_t yp[4];
-    host_fr_pow(y, n_sets - 1, yp);
-    q.y_chain = host_fr_shl(yp, 5);
-    host_fr_mul(yp, y, yp);
-    q.y_sets = host_fr_shl(yp, 5);
-    void* xp;
-    PZCHK(pz_get_pow_table(ctx, omega_ext, N, &xp, coset_g));   // X_i = coset_g * omega_ext^i, cached across calls
-    q.xpow = (const Fr*)xp;
-    hipLaunchKernelGGL(k_quotient_permutation, dim3(pz_div_up(N / 2, 256)), dim3(256), 0, ctx->stream, q, (Fr*)d_h);   // a thread per row PAIR
-    HIPCHK(ctx, hipGetLastError());
-    return PZ_OK;
+    return pz_quotient_permutation_part_dev(ctx, d_cols_ext, col_stride, d_sigma_ext, sigma_stride, d_z_ext, z_stride, n_sets, 0, n_sets,
+                                            chunk_len, m_total, 1, log_ext, rot_step, last_rotation, d_l0, d_l_last, d_l_active, beta, gamma,
+                                            delta, coset_g, omega_ext, y, d_h);
 }
 
 // ---------------------------------------------------------------------------------------------- evaluate_h: lookups
@@ -855,6 +893,7 @@ extern "C" int pz_quotient_lookup_dev(pz_ctx* ctx, const uint64_t* d_input_ext, 
     if (rot_step == 0 || rot_step >= N) return PZ_ERR_INVALID;
     if (n_lookups > 1 && (input_stride < 4 * N || perm_input_stride < 4 * N || perm_table_stride < 4 * N || z_stride < 4 * N))
         return PZ_ERR_INVALID;
+    if (!host_fr_canonical(beta) || !host_fr_canonical(gamma) || !host_fr_canonical(y)) return PZ_ERR_INVALID;
     if (n_lookups == 0) return PZ_OK;
     PZ_ENTER(ctx);
     LookQ q;

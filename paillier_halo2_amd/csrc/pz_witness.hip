@@ -164,23 +164,47 @@ __device__ __forceinline__ void limb_extract(const u64* __restrict__ words, unsi
 // Where a cell of the stream lives: the stream is cut into the circuit's columns of `rows` usable rows, and a column
 // may be stored with a larger stride (2^k: room for the blinding rows) -- cell c sits at c + (c / rows) * pad.
 // rows == 0: the stream is dense.
+// starts != nullptr: halo2-lib's BREAK-POINT layout of the advice stream (assign_with_constraints of the dependency, SURVEY tag [D]):
+// column j holds the cells starts[j] .. starts[j + 1] from row 0 on -- the cell a column ends with is ALSO row 0 of the next one
+// (a gate must not straddle two columns: the column breaks where a 4-cell gate would, and the shared cell carries the value
+// across, tied by a copy constraint).  starts[0] = 0, starts[n_cols] = the stream's length; a column takes at most rows + 1 cells
+// (rows = max_rows - 1 new ones), so c / rows never overshoots the column and the search walks forward from there.  pad = the
+// column stride in this mode.
 struct CellPtr {
     Fr* base;
     size_t idx, rows, pad;
+    const u64* starts;
+    unsigned ncols;
     __device__ __forceinline__ CellPtr operator+(size_t o) const {
         CellPtr r = *this;
         r.idx += o;
         return r;
     }
     __device__ __forceinline__ explicit operator bool() const { return base != nullptr; }
-    __device__ __forceinline__ Fr* addr() const {
-        if (!rows) return base + idx;
+    __device__ __forceinline__ size_t plain_col() const {
         // one division per cell: 32-bit whenever the stream has fewer than 2^32 cells (a 64-bit division is ~100 instructions)
-        const size_t col = ((idx | rows) >> 32) == 0 ? (size_t)((u32)idx / (u32)rows) : idx / rows;
-        return base + idx + col * pad;
+        return ((idx | rows) >> 32) == 0 ? (size_t)((u32)idx / (u32)rows) : idx / rows;
+    }
+    __device__ __forceinline__ Fr* addr() const {   // (dense / plain cut only)
+        if (!rows) return base + idx;
+        return base + idx + plain_col() * pad;
     }
 };
-__device__ __forceinline__ void fp_store(const CellPtr& p, const Fr& v) { fp_store(p.addr(), v); }
+__device__ __forceinline__ void fp_store(const CellPtr& p, const Fr& v) {
+    if (!p.starts) {
+        fp_store(p.addr(), v);
+        return;
+    }
+    size_t col = p.plain_col();
+    if (col >= p.ncols) col = p.ncols - 1;
+    while (col + 1 < p.ncols && p.starts[col + 1] <= p.idx) ++col;
+    const size_t row = p.idx - p.starts[col];
+    if (row < p.pad) fp_store(p.base + col * p.pad + row, v);            // (row < stride always for a table built by pz_circuit_break_points)
+    if (row == 0 && col > 0) {                                         // the previous column's last cell is this one too
+        const size_t prow = p.idx - p.starts[col - 1];
+        if (prow < p.pad) fp_store(p.base + (col - 1) * p.pad + prow, v);
+    }
+}
 
 struct ExpP {
     unsigned L, D, lb;
@@ -192,9 +216,17 @@ struct ExpP {
     u64 max_w[3];  // L*(2^W-1)^2 + (2^W-1)
     size_t cell0, lk0;        // stream index of this launch's first advice / lookup cell
     size_t rows, pad;         // column cut of the stream (CellPtr); 0, 0 = dense
+    const u64* bp_starts;     // != nullptr: the advice stream in break-point layout (CellPtr::starts); the lookup stream keeps the plain cut
+    size_t bp_div, bp_stride; // max_rows - 1, column stride
+    unsigned bp_ncols;
     size_t pair_stride, odd_off;   // != 0: steps come in pairs (uniform-shape circuit): step s sits at
                                    // cell0 + (s / 2) * pair_stride + (s & 1) * odd_off instead of cell0 + s * cells
 };
+
+__device__ __forceinline__ CellPtr adv_ptr(const ExpP& P, Fr* advice, size_t idx) {
+    if (P.bp_starts) return CellPtr{advice, idx, P.bp_div, P.bp_stride, P.bp_starts, P.bp_ncols};
+    return CellPtr{advice, idx, P.rows, P.pad, nullptr, 0};
+}
 
 // A cell's value as an integer: +-m, or the field inverse of that.  The helpers below pick the VALUE of a cell (cheap integer
 // selects, even when the lanes of a wave sit at different positions of a pattern) and the caller converts it to Montgomery
@@ -295,8 +327,8 @@ __global__ __launch_bounds__(EXP_THREADS) void k_witness_expand(ExpP P, const u6
     const bool wide = W > 64;
     const size_t step = blockIdx.x;
     const u64* st = steps + step * 4 * (size_t)P.L64;
-    const CellPtr adv{advice, P.cell0 + (P.pair_stride ? (step >> 1) * P.pair_stride + (step & 1) * P.odd_off : step * P.cells), P.rows, P.pad};
-    const CellPtr lk{lookup, P.lk0 + step * P.lookups, P.rows, P.pad};
+    const CellPtr adv = adv_ptr(P, advice, P.cell0 + (P.pair_stride ? (step >> 1) * P.pair_stride + (step & 1) * P.odd_off : step * P.cells));
+    const CellPtr lk{lookup, P.lk0 + step * P.lookups, P.rows, P.pad, nullptr, 0};
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const U192 MAXV = u_make(P.max_w[0], P.max_w[1], P.max_w[2]);
     const U192 BASE = u_shl(u_make(1), W);
@@ -683,7 +715,7 @@ struct CircP {
 __global__ __launch_bounds__(256) void k_circuit_misc(CircP C, const u64* __restrict__ inputs /* n | g | x | y | res */,
                                                       const u64* __restrict__ cval /* the circuit's result, L64 words */,
                                                       Fr* __restrict__ advice, Fr* __restrict__ lookup) {
-    const CellPtr adv{advice, 0, C.e.rows, C.e.pad}, lk{lookup, 0, C.e.rows, C.e.pad};
+    const CellPtr adv = adv_ptr(C.e, advice, 0), lk{lookup, 0, C.e.rows, C.e.pad, nullptr, 0};
     __shared__ u64 s_in[4][EXP_MAXL / 2 + 1][2];       // limbs of n, g, x, y
     __shared__ u64 s_res[CIRC_MAXF][2], s_c[CIRC_MAXF][2], s_fresh[CIRC_MAXF][2];
     __shared__ u64 s_sq[CIRC_MAXF][3];                 // limbs of n * n (unreduced convolution sums)
@@ -821,7 +853,7 @@ __global__ __launch_bounds__(256) void k_circuit_bits(ExpP P, unsigned Ln, unsig
     u64 lw[2];
     limb_extract(m_words, words_n, li, W, lw);
     const U192 x = u_make(lw[0], lw[1]);
-    const CellPtr a{advice, cell_base + (size_t)li * limb_stride, P.rows, P.pad};
+    const CellPtr a = adv_ptr(P, advice, cell_base + (size_t)li * limb_stride);
     const unsigned nip = 1 + 3 * (W - 1);
     for (unsigned t = threadIdx.x; t < nip + 4 * W; t += blockDim.x) {
         Fr v;
@@ -846,7 +878,7 @@ __global__ __launch_bounds__(256) void k_circuit_select(ExpP P, unsigned Ln, uns
     const unsigned bit = (unsigned)(u_lowbits(u_shr(u_make(lw[0], lw[1]), bi), 1).w[0]);
     const u64* st = steps + (size_t)(2 * i) * 4 * P.L64;    // the mul_mod(acc, sq) step: a = acc, r = muled
     // cells of this bit: after its limb's num_to_bits block and its mul_mod step
-    const CellPtr a{advice, cell_base + (size_t)li * limb_stride + nbits_cells + (size_t)bi * bit_stride + P.cells, P.rows, P.pad};
+    const CellPtr a = adv_ptr(P, advice, cell_base + (size_t)li * limb_stride + nbits_cells + (size_t)bi * bit_stride + P.cells);
     for (unsigned t = threadIdx.x; t < 8 * L; t += blockDim.x) {
         const unsigned limb = t / 8, p = t % 8;
         u64 aw[2], mw[2];
@@ -1028,10 +1060,44 @@ extern "C" int pz_circuit_cells(int kind, uint32_t limbs_n, uint32_t limb_bits, 
     return PZ_OK;
 }
 
-extern "C" int pz_circuit_expand_dev(pz_ctx* ctx, int kind, uint32_t limbs_n, uint32_t limb_bits, uint32_t lookup_bits,
-                                     const uint64_t* inputs, const uint64_t* d_steps, size_t n_steps_g, size_t n_steps_r,
-                                     const uint64_t* d_modulus, uint64_t* d_advice, uint64_t* d_lookup, size_t rows,
-                                     size_t col_stride) {
+// halo2-lib's column break rule (assign_with_constraints of the dependency [D]), from the selector mask of the advice stream: walking
+// the stream with row_offset r inside the current column, cell i is placed at (column, r); then, if (q[i] && r + 4 > max_rows) ||
+// r >= max_rows - 1, the column ends with this cell, the next column starts with a COPY of it at row 0 (tied by an equality
+// constraint) and -- if q[i] -- its gate is enabled there, not in the column it left.  starts[j] = the stream index of column j's row 0.
+extern "C" int pz_circuit_break_points(const uint8_t* gate_mask, size_t n_cells, size_t max_rows, uint64_t* starts_out, size_t capacity,
+                                       size_t* n_cols) {
+    if (!gate_mask || !n_cols || max_rows < 8) return PZ_ERR_INVALID;
+    size_t cols = 0, s = 0;
+    for (;;) {
+        if (starts_out) {
+            if (cols >= capacity) return PZ_ERR_CAPACITY;
+            starts_out[cols] = s;
+        }
+        ++cols;
+        // the column ends at the first i with (q[i] && i - s + 4 > max_rows) || i - s >= max_rows - 1
+        size_t end = s + max_rows - 1;
+        for (size_t i = s + max_rows - 3; i < s + max_rows - 1 && i < n_cells; ++i)
+            if (gate_mask[i]) {
+                // the dependency asserts that no gate started one or two cells earlier (overlaps are by exactly three cells)
+                if ((i >= 1 && gate_mask[i - 1] && i - 1 > s) || (i >= 2 && gate_mask[i - 2] && i - 2 > s)) return PZ_ERR_UNSUPPORTED;
+                end = i;
+                break;
+            }
+        if (end >= n_cells) break;     // the stream ends inside this column
+        s = end;
+    }
+    if (starts_out) {
+        if (cols >= capacity) return PZ_ERR_CAPACITY;
+        starts_out[cols] = n_cells;
+    }
+    *n_cols = cols;
+    return PZ_OK;
+}
+
+static int circuit_expand_impl(pz_ctx* ctx, int kind, uint32_t limbs_n, uint32_t limb_bits, uint32_t lookup_bits,
+                               const uint64_t* inputs, const uint64_t* d_steps, size_t n_steps_g, size_t n_steps_r,
+                               const uint64_t* d_modulus, uint64_t* d_advice, uint64_t* d_lookup, size_t rows, size_t col_stride,
+                               const uint64_t* d_col_starts, size_t n_adv_cols, size_t max_rows) {
     if (!ctx || !inputs || !d_steps || !d_modulus || !d_advice) return PZ_ERR_INVALID;
     if ((rows == 0) != (col_stride == 0) || col_stride < rows) return PZ_ERR_INVALID;
     CircP C;
@@ -1039,6 +1105,13 @@ extern "C" int pz_circuit_expand_dev(pz_ctx* ctx, int kind, uint32_t limbs_n, ui
     PZCHK(make_circuit_params(kind, limbs_n, limb_bits, lookup_bits, n_steps_g, n_steps_r, C, &a, &l, so));
     C.e.rows = rows;
     C.e.pad = col_stride - rows;
+    if (d_col_starts) {
+        if (n_adv_cols == 0 || n_adv_cols > 0xffffffffu || max_rows < 8 || max_rows > col_stride) return PZ_ERR_INVALID;
+        C.e.bp_starts = (const u64*)d_col_starts;
+        C.e.bp_ncols = (unsigned)n_adv_cols;
+        C.e.bp_div = max_rows - 1;
+        C.e.bp_stride = col_stride;
+    }
     PZ_ENTER(ctx);
     const size_t in_words = 4 * (size_t)C.words_n + C.e.L64;
     void* d_in;
@@ -1087,6 +1160,23 @@ extern "C" int pz_circuit_expand_dev(pz_ctx* ctx, int kind, uint32_t limbs_n, ui
                        (Fr*)d_lookup);
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
+}
+
+extern "C" int pz_circuit_expand_dev(pz_ctx* ctx, int kind, uint32_t limbs_n, uint32_t limb_bits, uint32_t lookup_bits,
+                                     const uint64_t* inputs, const uint64_t* d_steps, size_t n_steps_g, size_t n_steps_r,
+                                     const uint64_t* d_modulus, uint64_t* d_advice, uint64_t* d_lookup, size_t rows,
+                                     size_t col_stride) {
+    return circuit_expand_impl(ctx, kind, limbs_n, limb_bits, lookup_bits, inputs, d_steps, n_steps_g, n_steps_r, d_modulus, d_advice,
+                               d_lookup, rows, col_stride, nullptr, 0, 0);
+}
+extern "C" int pz_circuit_expand_cols_dev(pz_ctx* ctx, int kind, uint32_t limbs_n, uint32_t limb_bits, uint32_t lookup_bits,
+                                          const uint64_t* inputs, const uint64_t* d_steps, size_t n_steps_g, size_t n_steps_r,
+                                          const uint64_t* d_modulus, uint64_t* d_advice, uint64_t* d_lookup,
+                                          const uint64_t* d_col_starts, size_t n_adv_cols, size_t max_rows, size_t lookup_rows,
+                                          size_t col_stride) {
+    if (!d_col_starts || lookup_rows == 0 || lookup_rows > col_stride) return PZ_ERR_INVALID;
+    return circuit_expand_impl(ctx, kind, limbs_n, limb_bits, lookup_bits, inputs, d_steps, n_steps_g, n_steps_r, d_modulus, d_advice,
+                               d_lookup, lookup_rows, col_stride, d_col_starts, n_adv_cols, max_rows);
 }
 
 // host-pointer form (SURVEY.md section 8b `pz_witness_expand`): stages the trace up, expands on the device in groups

@@ -378,6 +378,16 @@ class Engine:
                                                n_steps_r, VP(d_modulus), VP(d_advice), VP(d_lookup), rows, col_stride),
                   "pz_circuit_expand_dev")
 
+    def circuit_expand_cols_dev(self, kind: int, limbs_n: int, limb_bits: int, lookup_bits: int, inputs, d_steps: int, n_steps_g: int,
+                                n_steps_r: int, d_modulus: int, d_advice: int, d_lookup: int, d_col_starts: int, n_adv_cols: int,
+                                max_rows: int, lookup_rows: int, col_stride: int):
+        """the whole circuit's cell stream with the advice cells in halo2-lib's break-point column layout (pz.h); d_col_starts: device
+        array of n_adv_cols + 1 uint64 from layout.break_points / pz_circuit_break_points"""
+        inp = np.ascontiguousarray(inputs, dtype=np.uint64).reshape(-1)
+        self._chk(self.L.pz_circuit_expand_cols_dev(self.ctx, kind, limbs_n, limb_bits, lookup_bits, _ptr(inp), VP(d_steps), n_steps_g,
+                                                    n_steps_r, VP(d_modulus), VP(d_advice), VP(d_lookup), VP(d_col_starts), n_adv_cols,
+                                                    max_rows, lookup_rows, col_stride), "pz_circuit_expand_cols_dev")
+
     # ------------------------------------------------------------------ "next" rows: SRS setup, evaluation at a point
     def srs_setup_g1_dev(self, k: int, s, omega, d_g: int = 0, d_g_lagrange: int = 0):
         self._chk(self.L.pz_srs_setup_g1_dev(self.ctx, k, _ptr(_np(s).reshape(4)), _ptr(_np(omega).reshape(4)), VP(d_g),
@@ -472,6 +482,17 @@ class Engine:
             chunk_len, m_total, log_ext, rot_step, last_rotation, VP(d_l0), VP(d_l_last), VP(d_l_active), self._fr1(beta),
             self._fr1(gamma), self._fr1(delta), self._fr1(coset_g), self._fr1(omega_ext), self._fr1(y), VP(d_h)),
             "pz_quotient_permutation_dev")
+
+    def quotient_permutation_part_dev(self, d_cols_ext: int, col_stride_u64: int, d_sigma_ext: int, sigma_stride_u64: int, d_z_ext: int,
+                                      z_stride_u64: int, n_sets_total: int, set_lo: int, n_sets: int, chunk_len: int, m_cols: int,
+                                      head: bool, log_ext: int, rot_step: int, last_rotation: int, d_l0: int, d_l_last: int,
+                                      d_l_active: int, beta, gamma, delta, coset_g, omega_ext, y, d_h: int):
+        """the permutation lines of evaluate_h for the sets [set_lo, set_lo + n_sets) (pz.h): tiles of extended columns in order"""
+        self._chk(self.L.pz_quotient_permutation_part_dev(
+            self.ctx, VP(d_cols_ext), col_stride_u64, VP(d_sigma_ext), sigma_stride_u64, VP(d_z_ext), z_stride_u64, n_sets_total, set_lo,
+            n_sets, chunk_len, m_cols, int(head), log_ext, rot_step, last_rotation, VP(d_l0), VP(d_l_last), VP(d_l_active),
+            self._fr1(beta), self._fr1(gamma), self._fr1(delta), self._fr1(coset_g), self._fr1(omega_ext), self._fr1(y), VP(d_h)),
+            "pz_quotient_permutation_part_dev")
 
     def quotient_lookup_dev(self, d_input_ext: int, input_stride_u64: int, d_table_ext: int, d_perm_input_ext: int,
                             perm_input_stride_u64: int, d_perm_table_ext: int, perm_table_stride_u64: int, d_z_ext: int,

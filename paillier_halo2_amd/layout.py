@@ -211,3 +211,26 @@ def encrypt_proof_shape(enc_bits: int, k: int, n_steps: int, limb_bits: int = 64
                       lookups_per_step=sc.lookup, advice_cols=A, lookup_cols=Lk, perm_cols=P, msm_witness=A,
                       msm_lookup=Lk, msm_full=3 * Lk + P + 1 + (max_degree - 1) + 2, polys=A + 4 * Lk + P,
                       ext_k=k + 2, advice_cells=cc.advice, lookup_cells=cc.lookup)
+
+
+def break_points(gate_mask, max_rows: int):
+    """halo2-lib's break-point column layout of an advice stream (pz.h pz_circuit_break_points; host logic inside the C ABI library,
+    no device needed): gate_mask = uint8 array, 1 where a gate window starts.  -> uint64 array of n_cols + 1 stream indices:
+    column j holds the cells starts[j] .. starts[j + 1] from row 0 on (the cell it ends with is also row 0 of column j + 1)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import _lib
+
+    m = np.ascontiguousarray(gate_mask, dtype=np.uint8)
+    L = _lib.lib()
+    nc = C.c_size_t()
+    rc = L.pz_circuit_break_points(C.c_void_p(m.ctypes.data), m.shape[0], max_rows, None, 0, C.byref(nc))
+    if rc != 0:
+        raise _lib.PzError(rc, "pz_circuit_break_points")
+    out = np.zeros(nc.value + 1, dtype=np.uint64)
+    rc = L.pz_circuit_break_points(C.c_void_p(m.ctypes.data), m.shape[0], max_rows, C.c_void_p(out.ctypes.data), out.shape[0], C.byref(nc))
+    if rc != 0:
+        raise _lib.PzError(rc, "pz_circuit_break_points")
+    return out

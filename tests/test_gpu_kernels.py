@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import pyref as P
-from tests.util import H, load_golden, steps_digest_arr
+from tests.util import H, load_golden, steps_digest_arr, steps_digest_ints
 
 pytestmark = pytest.mark.gpu
 
@@ -351,6 +351,74 @@ def test_encrypt_batch_full_2048(eng, cref):
         for k in list(range(0, tot, 97)) + [tot - 1]:
             a, b, q, rr = (cref.limbs_to_int(steps[i, k, j]) for j in range(4))
             assert a * b == q * n2 + rr and rr < n2
+
+
+def test_encrypt_batch_64_at_3072(eng, cref):
+    """BASELINE config c5's K3 launch shape: a batch of 64 encrypts at 3072 bits = 128 chains = 256 workgroups of 256 threads (round 4
+    never ran more than 5 instances).  Every value == paillier_enc_native; the whole step trace of three instances (first, middle,
+    last) against the oracle's trace digest; a*b == q*n^2 + r on sampled steps of every instance."""
+    Ln, L, B = 48, 96, 64
+    ins = [P.synth_paillier_inputs(3072, 0x5100 + i, standard_g=(i % 3 != 1)) for i in range(B)]
+    pack = lambda k: np.stack([cref.int_to_limbs(t[k], Ln) for t in ins])
+    c, steps, ng, nr = eng.paillier_encrypt(Ln, pack(0), pack(1), pack(2), pack(3))
+    for i, (n, g, m, r) in enumerate(ins):
+        assert cref.limbs_to_int(c[i]) == P.paillier_enc_native(n, g, m, r), i
+        assert (int(ng[i]), int(nr[i])) == (m.bit_length() + bin(m).count("1"), n.bit_length() + bin(n).count("1"))
+        tot, n2 = int(ng[i]) + int(nr[i]) + 1, n * n
+        for k in (0, tot // 3, int(ng[i]), tot - 2, tot - 1):
+            a, b, q, rr = (cref.limbs_to_int(steps[i, k, j]) for j in range(4))
+            assert a * b == q * n2 + rr and rr < n2, (i, k)
+    for i in (0, B // 2, B - 1):
+        n, g, m, r = ins[i]
+        _, sg, sr, fin = P.encrypt_trace(n, g, m, r)
+        tot = int(ng[i]) + int(nr[i]) + 1
+        assert steps_digest_arr(steps[i, :tot], L) == steps_digest_ints(sg + sr + [fin], L), i
+
+
+@pytest.mark.parametrize("cap_kib", [0, 256])
+def test_encrypt_batch_beyond_residency(eng, cref, monkeypatch, cap_kib):
+    """1600 encrypts of 128-bit keys in ONE call: 3200 chains = 6400 workgroups, many times what the chip holds at once -- the squarer /
+    multiplier roles are handed out by arrival, so no multiplier can be resident ahead of its squarer whatever the dispatch order.
+    cap_kib = 256: the hand-off area capped at 256 KiB (test hook) so the same batch runs as 50 launches sharing one squares buffer."""
+    if cap_kib:
+        monkeypatch.setenv("PZ_K3_HANDOFF_CAP_KIB", str(cap_kib))
+    Ln, B = 2, 1600
+    rng = random.Random(0x5200 + cap_kib)
+    ins = []
+    for i in range(B):
+        n = rng.getrandbits(128) | (1 << 127) | 1
+        ins.append((n, rng.randrange(1, n), rng.getrandbits(128 if i % 5 else 9) % n, rng.randrange(1, n)))
+    ins[7] = (ins[7][0], ins[7][1], 0, ins[7][3])          # m = 0: g^m = 1, no multiplier step at all
+    pack = lambda k: np.stack([cref.int_to_limbs(t[k], Ln) for t in ins])
+    c, steps, ng, nr = eng.paillier_encrypt(Ln, pack(0), pack(1), pack(2), pack(3))
+    for i, (n, g, m, r) in enumerate(ins):
+        assert cref.limbs_to_int(c[i]) == P.paillier_enc_native(n, g, m, r), i
+    for i in (0, 7, 799, B - 1):
+        n, g, m, r = ins[i]
+        _, sg, sr, fin = P.encrypt_trace(n, g, m, r)
+        tot = int(ng[i]) + int(nr[i]) + 1
+        assert tot == len(sg) + len(sr) + 1
+        assert steps_digest_arr(steps[i, :tot], 4) == steps_digest_ints(sg + sr + [fin], 4), i
+
+
+def test_k3_bounded_wait_reports_internal(eng, cref, monkeypatch):
+    """the multiplier's bounded wait (pz.h PZ_ERR_INTERNAL): with the squarer's counter never advanced (test hook) and the bound lowered,
+    the call returns PZ_ERR_INTERNAL instead of hanging, writes no result, and the same context then encrypts correctly"""
+    import paillier_halo2_amd as pz
+    from paillier_halo2_amd import _lib
+
+    Ln = 2
+    n, g, m, r = P.synth_paillier_inputs(128, 0x5300, standard_g=False)
+    arr = lambda x: cref.int_to_limbs(x, Ln)
+    monkeypatch.setenv("PZ_K3_TEST_NO_PUBLISH", "1")
+    monkeypatch.setenv("PZ_K3_SPIN_LIMIT", "3000")
+    with pytest.raises(pz.PzError) as ei:
+        eng.paillier_encrypt(Ln, arr(n), arr(g), arr(m), arr(r))
+    assert ei.value.status == _lib.PZ_ERR_INTERNAL
+    monkeypatch.delenv("PZ_K3_TEST_NO_PUBLISH")
+    monkeypatch.delenv("PZ_K3_SPIN_LIMIT")
+    c, _, _, _ = eng.paillier_encrypt(Ln, arr(n), arr(g), arr(m), arr(r))
+    assert cref.limbs_to_int(c[0]) == P.paillier_enc_native(n, g, m, r)
 
 
 def test_ubench_reports(eng):

@@ -395,6 +395,46 @@ def test_lookup_permute_and_product_vs_oracle(eng, cref, rows, bits, ncols):
         assert z[-1] * num % P.FR_R == z0 * den % P.FR_R, j
 
 
+def test_zero_denominator_and_noncanonical_challenge(eng, cref):
+    """(a) a planted zero denominator in the fused num / den path of the grand products: (A'[i] + beta) = 0 at one row -- halo2's
+    BatchInvert leaves the inverse of zero at zero, so the factor of that row is 0 (as the oracle's batch_invert gives), not the bare
+    numerator; (b) a challenge that is not canonical (>= r) is refused with PZ_ERR_INVALID by the entry points that convert their
+    challenges on the host (pz.h), not silently mis-reduced"""
+    import torch
+    import paillier_halo2_amd as pz
+    from paillier_halo2_amd import _lib
+
+    R = P.FR_R
+    rng = random.Random(4100)
+    n = 64
+    beta, gamma = rng.randrange(1, R), rng.randrange(1, R)
+    A = [rng.randrange(R) for _ in range(n)]
+    S = [rng.randrange(R) for _ in range(n)]
+    Ap = [rng.randrange(R) for _ in range(n)]
+    Sp = [rng.randrange(R) for _ in range(n)]
+    Ap[5] = (-beta) % R
+    d_A, d_S, d_Ap, d_Sp = (_dev(cref, x) for x in (A, S, Ap, Sp))
+    d_z = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    eng.lookup_product_dev(d_A.data_ptr(), 4 * n, d_S.data_ptr(), d_Ap.data_ptr(), 4 * n, d_Sp.data_ptr(), 4 * n, 1, n, _m(cref, beta),
+                           _m(cref, gamma), _m(cref, 1), d_z.data_ptr(), 4 * n)
+    eng.sync()
+    z = _ints(cref, d_z)
+    assert z == P.lookup_product(A, S, Ap, Sp, beta, gamma, 1)
+    assert z[5] != 0 and all(v == 0 for v in z[6:])
+    # (b)
+    bad = np.array([R & 0xFFFFFFFFFFFFFFFF, (R >> 64) & 0xFFFFFFFFFFFFFFFF, (R >> 128) & 0xFFFFFFFFFFFFFFFF, R >> 192], dtype=np.uint64)
+    N = 256
+    d_a = torch.zeros((N, 4), dtype=torch.int64, device="cuda")
+    d_h = torch.zeros((N, 4), dtype=torch.int64, device="cuda")
+    with pytest.raises(pz.PzError) as e:
+        eng.quotient_gate_dev(d_a.data_ptr(), 4 * N, d_a.data_ptr(), 4 * N, 1, 8, 4, bad, d_h.data_ptr())
+    assert e.value.status == _lib.PZ_ERR_INVALID
+    with pytest.raises(pz.PzError) as e:
+        eng.permutation_product_sets_dev(d_a.data_ptr(), 4 * N, d_a.data_ptr(), 4 * N, 1, 1, 8, N - 6, _m(cref, P.fr_omega(8)), bad,
+                                         _m(cref, gamma), _m(cref, 7), d_h.data_ptr(), 4 * N)
+    assert e.value.status == _lib.PZ_ERR_INVALID
+
+
 def test_lookup_permute_rejects_unsatisfiable_inputs(eng, cref):
     import torch
 
