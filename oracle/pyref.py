@@ -1116,13 +1116,25 @@ def gate_mask_circuit(kind: str, enc_bits: int, limb_bits: int, lb: int, n_steps
 # Dependency-defined wiring [D] like the cell patterns themselves: what is checked is that the GPU-written stream has equal
 # values wherever this restatement's circuit would need them equal.
 # ----------------------------------------------------------------------------------------
-def expand_circuit_cells_wired(kind: str, n: int, g: int, x: int, y: int, res: int, enc_bits: int, limb_bits: int, lb: int):
-    """-> (advice values, [(src index, copy index)], satisfied bit)"""
+def expand_circuit_cells_wired(kind: str, n: int, g: int, x: int, y: int, res: int, enc_bits: int, limb_bits: int, lb: int,
+                               full: bool = False):
+    """-> (advice values, [(src index, copy index)], satisfied bit); full=True: additionally the CONSTANT cells [(index, value)]
+    (halo2-lib assigns a constant as an advice cell tied to a cell of a fixed column: assign_raw_constants) and, for every cell of
+    the lookup stream in order, the index of the advice cell it copies (RangeChip pushes the cell to cells_to_lookup; the
+    lookup-advice column gets a copy tied by an equality constraint)"""
     Ln = enc_bits // limb_bits
     L = 2 * Ln
     base = 1 << limb_bits
     adv: List[int] = []
     pairs: List[Tuple[int, int]] = []
+    consts: List[Tuple[int, int]] = []
+    lk_src: List[int] = []
+
+    def putc(v):
+        """a constant cell"""
+        adv.append(v % FR_R)
+        consts.append((len(adv) - 1, v % FR_R))
+        return len(adv) - 1
 
     def put(v, src=None):
         adv.append(v % FR_R)
@@ -1140,21 +1152,26 @@ def expand_circuit_cells_wired(kind: str, n: int, g: int, x: int, y: int, res: i
         holder = xcell
         if k > 1:
             c0 = put(digs[0])
+            lk_src.append(c0)
             acc = digs[0]
             acc_cell = c0
             for gi in range(1, k):
                 acc += digs[gi] << (lb * gi)
                 last_cell = put(digs[gi])
-                put(1 << (lb * gi))
+                lk_src.append(last_cell)
+                putc(1 << (lb * gi))
                 acc_cell = put(acc)
             if xcell is not None:
                 pairs.append((xcell, acc_cell))
             holder = acc_cell
+        else:
+            assert xcell is not None
+            lk_src.append(xcell)
         last = digs[-1]
         if rem == 1:
-            put(0); put(last, last_cell); put(last, last_cell); put(last)
+            putc(0); put(last, last_cell); put(last, last_cell); put(last, last_cell)
         elif rem > 1:
-            put(0); put(last, last_cell); put(1 << (lb - rem)); put(last << (lb - rem))
+            putc(0); put(last, last_cell); putc(1 << (lb - rem)); lk_src.append(put(last << (lb - rem)))
         return holder
 
     def assign(v, nl):
@@ -1166,12 +1183,12 @@ def expand_circuit_cells_wired(kind: str, n: int, g: int, x: int, y: int, res: i
 
     def mul_cells(xs, ys, D):
         """xs / ys: [(value, cell)] ; shorter operands are extended with the load_zero cell this call pushes first"""
-        zc = put(0)
+        zc = putc(0)
         xe = list(xs) + [(0, zc)] * (D - len(xs))
         ye = list(ys) + [(0, zc)] * (D - len(ys))
         prod = []
         for i in range(D):
-            put(0)
+            putc(0)
             s = 0
             cell = None
             for j in range(i + 1):
@@ -1184,17 +1201,17 @@ def expand_circuit_cells_wired(kind: str, n: int, g: int, x: int, y: int, res: i
 
     def is_equal(xv, xc, yv, yc):
         d = (xv - yv) % FR_R
-        put(d); put(yv, yc); put(1); put(xv, xc)
+        c_d = put(d); put(yv, yc); putc(1); put(xv, xc)
         z, bit = _is_zero_cells(d)
-        for v in z:
-            put(v)
+        # is_zero(a): [is_zero, a, inv, 1 | 0, a, is_zero, 0]: is_zero + a * inv = 1 and 0 + a * is_zero = 0
+        c_z = put(z[0]); c_a = put(z[1], c_d); put(z[2]); putc(z[3]); putc(z[4]); put(z[5], c_a); put(z[6], c_z); putc(z[7])
         return bit
 
     def div_mod(v, vcell):
         qd, rd = v >> limb_bits, v & (base - 1)
         prod = qd * base
-        c_qd = put(qd); c_rd = put(rd); put(0); put(qd, c_qd); put(base); c_pr = put(prod)
-        put(v - prod); put(prod, c_pr); put(1); put(v, vcell)
+        c_qd = put(qd); c_rd = put(rd); putc(0); put(qd, c_qd); putc(base); c_pr = put(prod)
+        put(v - prod); put(prod, c_pr); putc(1); put(v, vcell)
         is_equal(rd, c_rd, v - prod, None)
         return (qd, c_qd), (rd, c_rd)
 
@@ -1211,42 +1228,43 @@ def expand_circuit_cells_wired(kind: str, n: int, g: int, x: int, y: int, res: i
         p_qn = mul_cells(ql, nl_, D)
         qnr = list(p_qn)
         for i in range(L):
-            put(p_qn[i][0], p_qn[i][1]); put(1); put(rl[i][0], rl[i][1])
+            put(p_qn[i][0], p_qn[i][1]); putc(1); put(rl[i][0], rl[i][1])
             qnr[i] = (p_qn[i][0] + rl[i][0], put(p_qn[i][0] + rl[i][0]))
         m = base - 1
         MAX = L * m * m + m
         cb = (2 * MAX).bit_length() - limb_bits
-        put(0); put(1)
-        carry, accx, eq_bit = (0, None), (0, None), 1
+        c_zero = putc(0); c_one = putc(1)
+        carry, accx, eq_bit = (0, c_zero), (0, c_zero), 1
+        eq_cell = c_one
         for i in range(D):
             diff = p_ab[i][0] - qnr[i][0]
-            c_diff = put(diff); put(qnr[i][0], qnr[i][1]); put(1); put(p_ab[i][0], p_ab[i][1])
+            c_diff = put(diff); put(qnr[i][0], qnr[i][1]); putc(1); put(p_ab[i][0], p_ab[i][1])
             s = diff + carry[0] + MAX
-            put(diff, c_diff); put(carry[0], carry[1]); put(1); put(diff + carry[0]); put(MAX); put(1); c_s = put(s)
+            put(diff, c_diff); put(carry[0], carry[1]); putc(1); put(diff + carry[0]); putc(MAX); putc(1); c_s = put(s)
             new_carry, cmod = div_mod(s, c_s)
             t = accx[0] + MAX
-            put(accx[0], accx[1]); put(1); put(MAX); c_t = put(t)
+            put(accx[0], accx[1]); putc(1); putc(MAX); c_t = put(t)
             q_acc, mod_acc = div_mod(t, c_t)
             e = is_equal(cmod[0], cmod[1], mod_acc[0], mod_acc[1])
-            put(0); put(eq_bit); put(e); put(eq_bit & e)
+            putc(0); put(eq_bit, eq_cell); put(e); eq_cell = put(eq_bit & e)
             eq_bit &= e
             accx = q_acc
             if i < D - 1:
                 range_check(new_carry[0], new_carry[1], cb)
             else:
                 e = is_equal(new_carry[0], new_carry[1], accx[0], accx[1])
-                put(0); put(eq_bit); put(e); put(eq_bit & e)
+                putc(0); put(eq_bit, eq_cell); put(e); eq_cell = put(eq_bit & e)
                 eq_bit &= e
             carry = new_carry
-        borrow = (0, None)
+        borrow = (0, c_zero)
         for i in range(L):
             nb = nl_[i][0] + borrow[0]
-            put(nl_[i][0], nl_[i][1]); put(1); put(borrow[0], borrow[1]); put(nb)
+            put(nl_[i][0], nl_[i][1]); putc(1); put(borrow[0], borrow[1]); put(nb)
             shift = rl[i][0] - nb + base
             lt = 1 if rl[i][0] < nb else 0
             out = shift & (base - 1)
             put(shift); c_lt = put(lt); c_out = put(out)
-            put(rl[i][0], rl[i][1]); put(lt, c_lt); put(base); put(rl[i][0] + lt * base)
+            put(rl[i][0], rl[i][1]); put(lt, c_lt); putc(base); put(rl[i][0] + lt * base)
             range_check(out, c_out, limb_bits)
             borrow = (lt, c_lt)
         put(borrow[0], borrow[1])
@@ -1256,7 +1274,7 @@ def expand_circuit_cells_wired(kind: str, n: int, g: int, x: int, y: int, res: i
     prod = mul_cells(n_c, n_c, 2 * Ln - 1)
     # refresh
     inc = refresh_aux(limb_bits, Ln, Ln)
-    put(0)
+    putc(0)
     cur = list(prod) + [(0, None)] * (len(inc) - len(prod))
     for i in range(len(inc)):
         limb = cur[i]
@@ -1266,7 +1284,7 @@ def expand_circuit_cells_wired(kind: str, n: int, g: int, x: int, y: int, res: i
                 cur[i] = rd
             else:
                 tgt = cur[i + j]
-                put(tgt[0], tgt[1]); put(1); put(rd[0], rd[1])
+                put(tgt[0], tgt[1]); putc(1); put(rd[0], rd[1])
                 cur[i + j] = (tgt[0] + rd[0], put(tgt[0] + rd[0]))
             limb = qd
     # the refreshed limbs: a limb no cell was written for is the constant zero, its range check stands alone
@@ -1274,14 +1292,14 @@ def expand_circuit_cells_wired(kind: str, n: int, g: int, x: int, y: int, res: i
     for v, c in cur:
         holder = range_check(v, c, limb_bits)
         fresh.append((v, c if c is not None else holder))
-    zero = put(0)                      # ctx.load_zero() (paillier.rs:47 / 77)
+    zero = putc(0)                     # ctx.load_zero() (paillier.rs:47 / 77)
     ext = lambda limbs: list(limbs) + [(0, zero)] * (L - len(limbs))
     if kind == "encrypt":
         # pow_mod_fixed_exp: assign_constant(1), load_zero, then the steps in pow_mod_fixed_exp_trace's order; a step's
         # operands are the limbs of earlier remainders (or of the base / the constant 1)
         def pow_mod_traced(base_limbs, e):
-            one = put(1)
-            z2 = put(0)
+            one = putc(1)
+            z2 = putc(0)
             acc = [(1, one)] + [(0, z2)] * (L - 1)
             _, steps = pow_mod_fixed_exp_trace(get_biguint([t[0] for t in base_limbs], limb_bits), e, n * n)
             vals = {get_biguint([t[0] for t in base_limbs], limb_bits): base_limbs, 1: acc}
@@ -1301,12 +1319,14 @@ def expand_circuit_cells_wired(kind: str, n: int, g: int, x: int, y: int, res: i
     else:
         c_limbs = mul_mod(ext(x_c), ext(y_c), fresh)
     res_c = assign(res, L)
-    put(0); put(1)
+    putc(0); eq_cell = putc(1)
     eq = 1
     for (cv, cc), (rv, rc) in zip(c_limbs, res_c):
         e = is_equal(cv, cc, rv, rc)
-        put(0); put(eq); put(e); put(eq & e)
+        putc(0); put(eq, eq_cell); put(e); eq_cell = put(eq & e)
         eq &= e
+    if full:
+        return {"advice": adv, "pairs": pairs, "consts": consts, "lookup_src": lk_src, "satisfied": eq, "result_cell": eq_cell}
     return adv, pairs, eq
 
 

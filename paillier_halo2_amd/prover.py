@@ -1,0 +1,372 @@
+"""The prover's phases composed in create_proof's order, on the device, over the C ABI (include/pz.h) only.
+
+The reference reaches halo2-axiom's `keygen_vk` / `keygen_pk` / `create_proof` through halo2-lib's tester
+(/root/reference/src/bench.rs:161-171: `bench_builder` -> keygen -> `gen_proof`); its circuit is halo2-lib's: one vertical gate
+q (a + b c - d) per basic-gate advice column, range-check lookups of lookup-enabled advice columns against one table column, a
+permutation over [advice | lookup advice | constants].  This module runs that flow as ONE dataflow -- every
+later phase consumes the earlier phases' outputs, nothing is synthetic:
+
+    keygen:        fixed columns (selectors, constants, table) and the sigma polynomials of the circuit's copy constraints:
+                   commitments, coefficient forms, extended-coset forms, all resident in HBM (pz_permutation_sigma_dev,
+                   pz_keygen_columns_dev)
+    create_proof:  1 advice + lookup-advice commitments (blinding rows filled)                        K1 pz_msm_g1_dev
+                   2 permute_expression_pair -> A', S' commitments                                    pz_lookup_permute_dev
+                   3 permutation products Z_j, lookup products Z commitments                          pz_permutation_product_sets_dev ...
+                   4 vanishing argument's random polynomial commitment
+                   5 every polynomial Lagrange -> coefficients (K2), then TILES of columns -> extended coset -> custom-gate and
+                     permutation lines of evaluate_h as each tile is produced; lookup lines; division by X^n - 1; extended -> coeff;
+                     h pieces committed                                                               pz_ntt_fr_*  pz_quotient_*
+                   6 evaluations at x and its rotations                                                pz_poly_eval_multi_dev
+                   7 SHPLONK over the real coefficient forms                                           pz_shplonk_*
+
+What stays outside: the transcript (challenges are INPUTS here: the caller hashes the commitments each phase
+hands back -- that is the host round trip between phases), the verifier / G2 side, and the circuit STRUCTURE itself (selector
+positions, copy constraints, break points: the dependency's keygen knows them; they are an input, `CircuitStructure`).
+
+Memory plan: the proving key's extended forms are RESIDENT (at config c2: 3033 selectors + 3118 sigma
+columns x 2^19 x 32 B = 103 GB of the 288 GB); the proof's own columns are extended tile by tile (`tile` columns at a time) and never
+exist on the extended domain all at once -- only the grand products Z (which the chaining lines read across sets) do.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import consts
+from .engine import Bases, Engine
+
+FR = consts.FR_R
+M = consts.fr_mont_limbs
+
+LOG_E = 2                      # cs.degree() = 4 for halo2-lib's gate + lookup -> quotient on the 4n coset, 3 pieces
+CHUNK = 2                      # permutation columns per grand product: degree - 2
+ZETA = pow(consts.FR_GENERATOR, (FR - 1) // 3, FR)          # the coset generator halo2's EvaluationDomain uses (g_coset)
+DELTA = pow(consts.FR_GENERATOR, 1 << consts.FR_S, FR)      # halo2curves Fr::DELTA
+
+
+@dataclass
+class CircuitStructure:
+    """what keygen derives from the circuit (INPUT; in the reference the dependency's synthesize / Assembly produce it)"""
+    k: int
+    lookup_bits: int
+    max_rows: int                  # rows of a column the circuit assigns (halo2-lib: 2^k - minimum_rows)
+    blinding_factors: int          # cs.blinding_factors(): 6 for halo2-lib's 4-rotation gate
+    selectors: np.ndarray          # uint8 [n_adv][2^k]
+    n_lk: int
+    constants: Sequence[int]       # the constants fixed column (row i), canonical integers
+    map_col: np.ndarray            # uint32 [m][2^k]: sigma as the (column, row) every cell maps to; m = n_adv + n_lk + 1
+    map_row: np.ndarray
+    table: Optional[Sequence[int]] = None      # default: 0 .. 2^lookup_bits - 1, then zeros
+
+    @property
+    def n_adv(self) -> int:
+        return int(self.selectors.shape[0])
+
+    @property
+    def m(self) -> int:
+        return self.n_adv + self.n_lk + 1
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def _zeros(*shape):
+    torch = _torch()
+    return torch.zeros(shape, dtype=torch.int64, device="cuda")
+
+
+def _ints_to_dev_mont(eng: Engine, vals: Sequence[int]):
+    """canonical integers -> Montgomery elements on the device (upload of raw limbs + pz_fr_convert_dev)"""
+    torch = _torch()
+    n = len(vals)
+    raw = np.zeros((n, 4), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        v %= FR
+        if v:
+            for j in range(4):
+                raw[i, j] = (v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+    t = torch.from_numpy(raw.view(np.int64)).cuda()
+    eng.fr_convert_dev(t.data_ptr(), n, True)
+    return t
+
+
+def _random_fr(gen, *shape):
+    """blinding values: uniform 252-bit integers taken as Montgomery representatives (all below r)"""
+    torch = _torch()
+    t = torch.randint(-(1 << 63), (1 << 63) - 1, (*shape, 4), dtype=torch.int64, device="cuda", generator=gen)
+    t[..., 3] &= 0x0FFFFFFFFFFFFFFF
+    return t
+
+
+@dataclass
+class Domain:
+    k: int
+    bf: int
+
+    def __post_init__(self):
+        self.n = 1 << self.k
+        self.N = self.n << LOG_E
+        self.E = 1 << LOG_E
+        self.usable = self.n - (self.bf + 1)
+        self.omega = consts.fr_omega(self.k)
+        self.omega_inv = pow(self.omega, -1, FR)
+        self.n_inv = pow(self.n, -1, FR)
+        self.omega_ext = consts.fr_omega(self.k + LOG_E)
+        self.omega_ext_inv = pow(self.omega_ext, -1, FR)
+        self.N_inv = pow(self.N, -1, FR)
+        self.coset_g = ZETA
+        self.gens = np.stack([M(self.coset_g * pow(self.omega_ext, r, FR) % FR) for r in range(self.E)])
+
+
+class ProvingKey:
+    """fixed + permutation polynomials in all three forms, resident in HBM; the SRS tables"""
+
+    def __init__(self, eng: Engine, st: CircuitStructure, bases_lagrange: Bases, bases_monomial: Bases):
+        torch = _torch()
+        self.eng, self.st = eng, st
+        self.dom = d = Domain(st.k, st.blinding_factors)
+        self.bases_lagrange, self.bases_monomial = bases_lagrange, bases_monomial
+        n, N, A, m = d.n, d.N, st.n_adv, st.m
+        assert st.max_rows <= d.usable and st.map_col.shape == (m, n) and st.selectors.shape == (A, n)
+        self.n_sets = -(-m // CHUNK)
+        one = torch.from_numpy(M(1).view(np.int64)).cuda()
+        # ---- fixed columns: [selectors | constants | table], Lagrange form
+        F = A + 2
+        fixed = _zeros(F, n, 4)
+        sel = torch.from_numpy(np.ascontiguousarray(st.selectors)).cuda()
+        fixed[:A] = torch.where(sel.bool().unsqueeze(-1), one, torch.zeros_like(one))
+        consts_col = list(st.constants) + [0] * (n - len(st.constants))
+        fixed[A] = _ints_to_dev_mont(eng, consts_col)
+        table = list(st.table) if st.table is not None else [i if i < (1 << st.lookup_bits) else 0 for i in range(n)]
+        fixed[A + 1] = _ints_to_dev_mont(eng, table)
+        self.const_lagrange = fixed[A].clone()
+        self.table_lagrange = fixed[A + 1].clone()
+        # ---- sigma polynomials from the copy-constraint map
+        d_mc = torch.from_numpy(st.map_col.astype(np.int32)).cuda()
+        d_mr = torch.from_numpy(st.map_row.astype(np.int32)).cuda()
+        sigma = _zeros(m, n, 4)
+        eng.permutation_sigma_dev(d_mc.data_ptr(), d_mr.data_ptr(), m, st.k, M(d.omega), M(DELTA), sigma.data_ptr(), 4 * n)
+        self.sigma_lagrange = sigma.clone()
+        # ---- keygen_vk + keygen_pk: commitments, coefficient forms (in place), extended forms
+        self.fixed_commit = _zeros(F, 12)
+        self.fixed_ext = _zeros(F, N, 4)
+        eng.keygen_columns_dev(bases_lagrange, fixed.data_ptr(), F, 4 * n, st.k, LOG_E, M(d.omega), M(d.omega_inv), M(d.n_inv), d.gens,
+                               self.fixed_commit.data_ptr(), self.fixed_ext.data_ptr(), 4 * N)
+        self.fixed_coeff = fixed
+        self.sigma_commit = _zeros(m, 12)
+        self.sigma_ext = _zeros(m, N, 4)
+        eng.keygen_columns_dev(bases_lagrange, sigma.data_ptr(), m, 4 * n, st.k, LOG_E, M(d.omega), M(d.omega_inv), M(d.n_inv), d.gens,
+                               self.sigma_commit.data_ptr(), self.sigma_ext.data_ptr(), 4 * N)
+        self.sigma_coeff = sigma
+        # ---- l_0, l_last, l_active on the extended coset
+        u = d.usable
+        lrows = _zeros(3, n, 4)
+        lrows[0, 0] = one
+        lrows[1, u] = one
+        lrows[2, :u] = one
+        eng.ntt_dev(lrows.data_ptr(), 3, 4 * n, M(d.omega_inv), st.k, None, M(d.n_inv))
+        self.l_ext = _zeros(3, N, 4)
+        eng.ntt_extend_dev(lrows.data_ptr(), 3, 4 * n, self.l_ext.data_ptr(), 4 * N, st.k, LOG_E, M(d.omega), d.gens, None)
+        eng.sync()
+
+    def vk_commitments(self) -> Dict[str, np.ndarray]:
+        e = self.eng
+        e.sync()
+        jac = lambda t: e.g1_normalize(t.cpu().numpy().view(np.uint64))
+        return {"fixed": jac(self.fixed_commit), "sigma": jac(self.sigma_commit)}
+
+
+def keygen(eng: Engine, st: CircuitStructure, bases_lagrange: Bases, bases_monomial: Bases) -> ProvingKey:
+    return ProvingKey(eng, st, bases_lagrange, bases_monomial)
+
+
+@dataclass
+class Challenges:
+    """the transcript's outputs (canonical integers): theta is unused by single-expression lookups but drawn all the same"""
+    theta: int
+    beta: int
+    gamma: int
+    y: int
+    x: int
+    sh_y: int      # SHPLONK's y, v, u
+    sh_v: int
+    sh_u: int
+
+
+@dataclass
+class Proof:
+    commitments: Dict[str, np.ndarray] = field(default_factory=dict)     # name -> affine points (count, 8), Montgomery
+    evals: Dict[str, np.ndarray] = field(default_factory=dict)           # name -> (count, n_points, 4), Montgomery
+    h_degree_ok: bool = False
+    h_top: Optional[np.ndarray] = None                                   # coefficients 3n-3 .. 4n-1 of the quotient (must be zero)
+
+
+def rotation_points(dom: Domain, x: int) -> List[int]:
+    """the six points of halo2-lib circuits' queries: x, wx, w^2 x, w^3 x (the gate's rotations), w^-(bf+1) x (x_last), w^-1 x"""
+    w = dom.omega
+    return [x % FR, x * w % FR, x * pow(w, 2, FR) % FR, x * pow(w, 3, FR) % FR, x * pow(w, -(dom.bf + 1), FR) % FR, x * pow(w, -1, FR) % FR]
+
+
+def query_layout(A: int, Lk: int, m: int, S: int):
+    """the multi-point opening's rotation sets: [(point indices into rotation_points, [(polynomial family, index), ...])], in the order
+    create_proof hands them to SHPLONK (a verifier must fold commitments and evaluations in the same order)"""
+    F = A + 2
+    sets = [([0], [("lookup_advice", i) for i in range(Lk)] + [("fixed", i) for i in range(F)] + [("sigma", i) for i in range(m)]
+             + [("perm_tables", i) for i in range(Lk)] + [("h", 0), ("random", 0)]),
+            ([0, 1, 2, 3], [("advice", i) for i in range(A)])]
+    if S > 1:
+        sets.append(([0, 1, 4], [("perm_z", i) for i in range(S - 1)]))
+    sets.append(([0, 1], [("perm_z", S - 1)] + [("lookup_z", i) for i in range(Lk)]))
+    sets.append(([0, 5], [("perm_inputs", i) for i in range(Lk)]))
+    return sets
+
+
+def create_proof(pk: ProvingKey, cols, ch: Challenges, seed: int = 0, tile: int = 64, hooks=None) -> Proof:
+    """cols: int64 CUDA tensor [m][2^k][4]: the advice columns then the lookup-advice columns as K4 wrote them (rows >= max_rows
+    zero); the last column (constants) and the blinding rows are filled here.  Runs on the engine's stream (bind_torch_stream).
+    hooks: optional dict of callables name -> f(tensor) applied to intermediate device buffers (the tests' tamper points)."""
+    torch = _torch()
+    eng, st, d = pk.eng, pk.st, pk.dom
+    n, N, k, u, bf = d.n, d.N, d.k, d.usable, d.bf
+    A, Lk, m, S = st.n_adv, st.n_lk, st.m, pk.n_sets
+    W = A + Lk
+    assert tile % CHUNK == 0 and tuple(cols.shape) == (m, n, 4)
+    hooks = hooks or {}
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    pr = Proof()
+    bl, bm = pk.bases_lagrange, pk.bases_monomial
+    beta, gamma, y = M(ch.beta), M(ch.gamma), M(ch.y)
+
+    def commit(bases, t, count, stride_u64):
+        out = _zeros(count, 12)
+        eng.msm_dev(bases, t.data_ptr(), count, n, stride_u64, out.data_ptr())
+        return out
+
+    # ---- 1. advice: blinding rows, commitments
+    cols[:W, u:] = _random_fr(gen, W, n - u)
+    cols[W] = pk.const_lagrange
+    if "advice" in hooks:
+        hooks["advice"](cols)
+    c_adv = commit(bl, cols, W, 4 * n)
+    # ---- 2. lookups: permuted input / table (one expression each side: theta does not enter)
+    Ap, Sp = _zeros(Lk, n, 4), _zeros(Lk, n, 4)
+    lk_in = cols[A:W]
+    eng.lookup_permute_dev(lk_in.data_ptr(), Lk, 4 * n, pk.table_lagrange.data_ptr(), u, st.lookup_bits, Ap.data_ptr(), Sp.data_ptr(), 4 * n)
+    if "permuted" in hooks:
+        hooks["permuted"](Ap, Sp)
+    Ap[:, u:] = _random_fr(gen, Lk, n - u)
+    Sp[:, u:] = _random_fr(gen, Lk, n - u)
+    c_ap, c_sp = commit(bl, Ap, Lk, 4 * n), commit(bl, Sp, Lk, 4 * n)
+    # ---- 3. grand products
+    Z = _zeros(S, n, 4)
+    eng.permutation_product_sets_dev(cols.data_ptr(), 4 * n, pk.sigma_lagrange.data_ptr(), 4 * n, m, CHUNK, k, u, M(d.omega), beta, gamma,
+                                     M(DELTA), Z.data_ptr(), 4 * n)
+    Z[:, u + 1:] = _random_fr(gen, S, n - u - 1)
+    Zl = _zeros(Lk, n, 4)
+    eng.lookup_product_dev(lk_in.data_ptr(), 4 * n, pk.table_lagrange.data_ptr(), Ap.data_ptr(), 4 * n, Sp.data_ptr(), 4 * n, Lk, n, beta,
+                           gamma, M(1), Zl.data_ptr(), 4 * n)
+    Zl[:, u + 1:] = _random_fr(gen, Lk, n - u - 1)
+    if "products" in hooks:
+        hooks["products"](Z, Zl)
+    c_z, c_zl = commit(bl, Z, S, 4 * n), commit(bl, Zl, Lk, 4 * n)
+    # ---- 4. the vanishing argument's random polynomial (coefficient form)
+    rnd = _random_fr(gen, 1, n)
+    c_rnd = commit(bm, rnd, 1, 4 * n)
+    # ---- 5. quotient.  Lagrange -> coefficients for everything the proof opens (in place: the Lagrange forms are done with)
+    for t, cnt in ((cols, m), (Ap, Lk), (Sp, Lk), (Z, S), (Zl, Lk)):
+        eng.ntt_dev(t.data_ptr(), cnt, 4 * n, M(d.omega_inv), k, None, M(d.n_inv))
+
+    def extend(src, cnt, dst):
+        eng.ntt_extend_dev(src.data_ptr(), cnt, 4 * n, dst.data_ptr(), 4 * N, k, LOG_E, M(d.omega), d.gens, None)
+
+    z_ext = _zeros(S, N, 4)                     # all sets: the chaining lines read z_{j-1} beside z_j
+    for s0 in range(0, S, tile):
+        extend(Z[s0:s0 + tile], min(tile, S - s0), z_ext[s0:s0 + tile])
+    hg, hp = _zeros(N, 4), _zeros(N, 4)         # gate lines / permutation lines, folded apart and joined below: one pass over the tiles
+    ext = _zeros(tile, N, 4)
+    l0, llast, lact = (pk.l_ext[i].data_ptr() for i in range(3))
+    for c0 in range(0, m, tile):
+        cnt = min(tile, m - c0)
+        extend(cols[c0:c0 + cnt], cnt, ext)
+        na = max(0, min(A, c0 + cnt) - c0)      # advice columns of this tile carry the custom gate
+        if na:
+            eng.quotient_gate_dev(ext.data_ptr(), 4 * N, pk.fixed_ext[c0].data_ptr(), 4 * N, na, k + LOG_E, d.E, y, hg.data_ptr())
+        set_lo, nsets = c0 // CHUNK, -(-cnt // CHUNK)
+        eng.quotient_permutation_part_dev(ext.data_ptr(), 4 * N, pk.sigma_ext[c0].data_ptr(), 4 * N, z_ext.data_ptr(), 4 * N, S, set_lo, nsets,
+                                          CHUNK, cnt, c0 == 0, k + LOG_E, d.E, bf + 1, l0, llast, lact, beta, gamma, M(DELTA), M(d.coset_g),
+                                          M(d.omega_ext), y, hp.data_ptr())
+    # h = hg * y^(permutation lines) + hp, then the lookup lines on top
+    n_perm_lines = 2 + (S - 1) + S
+    hh = torch.stack([hg, hp])
+    h = _zeros(N, 4)
+    eng.fr_lincomb_dev(hh.data_ptr(), 2, 4 * N, N, M(pow(ch.y, n_perm_lines, FR)), h.data_ptr())
+    for l0_ in range(0, Lk, tile):
+        cnt = min(tile, Lk - l0_)
+        e_in, e_ap, e_sp, e_zl = (_zeros(cnt, N, 4) for _ in range(4))
+        extend(cols[A + l0_:A + l0_ + cnt], cnt, e_in)
+        extend(Ap[l0_:l0_ + cnt], cnt, e_ap)
+        extend(Sp[l0_:l0_ + cnt], cnt, e_sp)
+        extend(Zl[l0_:l0_ + cnt], cnt, e_zl)
+        eng.quotient_lookup_dev(e_in.data_ptr(), 4 * N, pk.fixed_ext[A + 1].data_ptr(), e_ap.data_ptr(), 4 * N, e_sp.data_ptr(), 4 * N,
+                                e_zl.data_ptr(), 4 * N, cnt, k + LOG_E, d.E, l0, llast, lact, beta, gamma, y, h.data_ptr())
+    eng.quotient_finish_dev(h.data_ptr(), k, LOG_E, M(d.coset_g), M(d.omega_ext))
+    eng.ntt_dev(h.data_ptr(), 1, 4 * N, M(d.omega_ext_inv), k + LOG_E, None, M(d.N_inv))
+    eng.fr_distribute_powers_dev(h.data_ptr(), 1, 4 * N, N, M(pow(d.coset_g, -1, FR)))
+    pieces = h.view(d.E, n, 4)                  # h(X) = sum_i X^(n i) h_i(X); degree <= 3n - 4: piece 3 and the top of piece 2 vanish
+    c_h = commit(bm, pieces, d.E - 1, 4 * n)
+    # ---- 6. evaluations
+    xs = rotation_points(d, ch.x)
+    P = lambda idx: np.stack([M(xs[i]) for i in idx])
+
+    def evals(t, cnt, idx):
+        out = _zeros(cnt, len(idx), 4)
+        eng.poly_eval_multi_dev(t.data_ptr(), cnt, 4 * n, n, P(idx), out.data_ptr())
+        return out
+
+    xn = pow(ch.x, n, FR)
+    hcomb = _zeros(n, 4)                        # h_0 + x^n h_1 + x^2n h_2: what halo2 opens at x
+    for i in reversed(range(d.E - 1)):
+        eng.fr_lincomb_dev(pieces[i].data_ptr(), 1, 4 * n, n, M(xn), hcomb.data_ptr(), i != d.E - 2)
+    F = A + 2
+    e_adv = evals(cols, A, [0, 1, 2, 3])
+    e_lk = evals(cols[A:], Lk + 1, [0])         # lookup advice + the constants column (a fixed column, opened at x)
+    e_fix = evals(pk.fixed_coeff, F, [0])
+    e_sig = evals(pk.sigma_coeff, m, [0])
+    e_z = evals(Z, S, [0, 1, 4])
+    e_zl = evals(Zl, Lk, [0, 1])
+    e_ap = evals(Ap, Lk, [0, 5])
+    e_sp = evals(Sp, Lk, [0])
+    e_rnd = evals(rnd, 1, [0])
+    e_h = evals(hcomb.view(1, n, 4), 1, [0])
+    # ---- 7. SHPLONK
+    eng.sync()
+    host = lambda t: t.cpu().numpy().view(np.uint64)
+    polys = {"lookup_advice": cols[A:], "fixed": pk.fixed_coeff, "sigma": pk.sigma_coeff, "perm_tables": Sp, "h": hcomb.view(1, n, 4),
+             "random": rnd, "advice": cols, "perm_z": Z, "lookup_z": Zl, "perm_inputs": Ap}
+    ev = {"lookup_advice": host(e_lk), "fixed": host(e_fix), "sigma": host(e_sig), "perm_tables": host(e_sp), "h": host(e_h),
+          "random": host(e_rnd), "advice": host(e_adv), "perm_z": host(e_z), "lookup_z": host(e_zl), "perm_inputs": host(e_ap)}
+    sets = [([polys[f][i].data_ptr() for f, i in members], idx, np.stack([ev[f][i][:len(idx)] for f, i in members]))
+            for idx, members in query_layout(A, Lk, m, S)]
+    w1, w2 = _zeros(n, 4), _zeros(n, 4)
+    state = eng.shplonk_begin_dev(n, sets, np.stack([M(p) for p in xs]), M(ch.sh_y), M(ch.sh_v), w1.data_ptr())
+    c_w1 = commit(bm, w1.view(1, n, 4), 1, 4 * n)
+    eng.shplonk_finish_dev(state, M(ch.sh_u), w1.data_ptr(), w2.data_ptr())
+    c_w2 = commit(bm, w2.view(1, n, 4), 1, 4 * n)
+    eng.sync()
+    # ---- the proof
+    norm = lambda t: eng.g1_normalize(host(t))
+    pr.commitments = {"advice": norm(c_adv)[:A], "lookup_advice": norm(c_adv)[A:], "perm_inputs": norm(c_ap), "perm_tables": norm(c_sp),
+                      "perm_z": norm(c_z), "lookup_z": norm(c_zl), "random": norm(c_rnd), "h": norm(c_h), "w1": norm(c_w1), "w2": norm(c_w2)}
+    pr.evals = {"advice": host(e_adv), "lookup_advice": host(e_lk)[:Lk], "constants": host(e_lk)[Lk:], "fixed": host(e_fix),
+                "sigma": host(e_sig), "perm_z": host(e_z), "lookup_z": host(e_zl), "perm_inputs": host(e_ap), "perm_tables": host(e_sp),
+                "random": host(e_rnd), "h": host(e_h)}
+    top = host(h[3 * n - 3:])
+    pr.h_top = top
+    pr.h_degree_ok = not top.any()
+    return pr

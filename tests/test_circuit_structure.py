@@ -1,0 +1,67 @@
+"""CPU tests of the circuit-structure oracle (oracle/circuit.py) and the verifier restatement (oracle/verifier.py) the connected-proof
+GPU tests rely on: the column-form MockProver analogue accepts the honest witness of the reference's bench shape
+(/root/reference/src/bench.rs:139-140: 128-bit n, 64-bit limbs; k = 14, lookup_bits = 13) and rejects the reference's negative
+case (a wrong claimed result, bench.rs:68-74), the library's break-point rule equals the restated one, the permutation built from the
+equality constraints is a permutation whose cycles hold equal values."""
+import numpy as np
+
+from oracle import circuit as CQ
+from oracle import pyref as P
+from oracle import verifier as V
+
+R = P.FR_R
+
+
+def _build(k=14, lb=13, seed=0x5042, wrong=0):
+    n, g, m, r = P.synth_paillier_inputs(128, seed, standard_g=False)
+    res = P.paillier_enc_native(n, g, m, r) ^ wrong
+    return CQ.build("encrypt", n, g, m, r, res, 128, 64, lb, k), (n, g, m, r)
+
+
+def test_structure_is_satisfied_and_break_points_agree():
+    from paillier_halo2_amd import layout
+
+    st, (n, g, m, r) = _build()
+    assert st.satisfied == 1 and CQ.mock_prover(st) == []
+    ng, nr = m.bit_length() + bin(m).count("1"), n.bit_length() + bin(n).count("1")
+    mask, total = P.gate_mask_circuit("encrypt", 128, 64, 13, ng, nr)
+    assert total == st.n_cells
+    for max_rows in (st.max_rows, 1000, 4097):
+        assert layout.break_points(mask, max_rows).tolist() == CQ.break_points(mask, max_rows)
+    # no gate straddles a column; every column but the last ends with the cell the next one starts with
+    for j in range(st.n_adv):
+        rows = np.nonzero(st.selectors[j])[0]
+        assert rows.size and rows.max() + 3 < st.max_rows
+    # sigma is a permutation, and it only maps a cell to a cell with the same value
+    cols = CQ.perm_columns(st)
+    flat = st.map_col.astype(np.int64) * st.n + st.map_row
+    assert np.unique(flat).size == flat.size
+    moved = np.argwhere(flat != np.arange(flat.size).reshape(flat.shape))
+    assert moved.shape[0] > 100000
+    for c, rr in moved[:: max(1, moved.shape[0] // 5000)].tolist():
+        assert cols[c][rr] == cols[int(st.map_col[c, rr])][int(st.map_row[c, rr])]
+    # a tampered cell breaks its gate or its copies, nothing else
+    cols[2][500] = (cols[2][500] + 1) % R
+    bad = CQ.mock_prover(st, cols)
+    assert bad and all(b.startswith(("gate 2:", "copy")) for b in bad)
+
+
+def test_wrong_claimed_result_is_unsatisfied():
+    st, _ = _build(wrong=4)
+    bad = CQ.mock_prover(st)
+    assert st.satisfied == 0 and len(bad) == 1 and bad[0].startswith("copy")     # assert_equal_fresh's bit != the constant 1
+
+
+def test_lagrange_values_of_the_verifier():
+    k, bf = 5, 6
+    n = 1 << k
+    x = 0x1234567 % R
+    l0, llast, lblind = V.lagrange_at(k, bf, x)
+    w = P.fr_omega(k)
+    xn = pow(x, n, R)
+    li = [(xn - 1) * pow(w, i, R) % R * pow(n * (x - pow(w, i, R)) % R, -1, R) % R for i in range(n)]
+    assert sum(li) % R == 1                                    # the Lagrange basis sums to one
+    assert (l0, llast) == (li[0], li[n - bf - 1]) and lblind == sum(li[n - bf:]) % R
+    # l_i is the interpolation of the unit vector e_i
+    coeffs = P.intt([1 if i == 3 else 0 for i in range(n)], w)
+    assert P.poly_eval(coeffs, x) == li[3]

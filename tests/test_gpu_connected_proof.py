@@ -1,0 +1,215 @@
+"""ONE connected proof of the Paillier encrypt circuit at the reference's own bench shape (128-bit n, 64-bit limbs, k = 14,
+lookup_bits = 13: /root/reference/src/bench.rs:139-140,161-171), every phase on the device in create_proof's order
+(paillier_halo2_amd/prover.py), checked the way halo2's verifier would (oracle/verifier.py):
+
+  (i)   the quotient has degree <= 3n - 4 (the constraint numerator vanishes on the domain);
+  (ii)  h(x) (x^n - 1) equals the gate / permutation / lookup expression recomputed on the host from the EVALUATIONS only;
+  (iii) SHPLONK's final identity holds in the exponent against the proof's actual commitments (the test knows the toxic scalar);
+  (iv)  a tampered witness cell, a broken copy constraint, an out-of-table lookup value and a wrong claimed result each break (i) / (ii).
+
+The witness is K3 -> K4's own output in halo2-lib's break-point column layout; the circuit structure (selectors, copy constraints,
+constants, break points) is the keygen INPUT, built by oracle/circuit.py from the restated dependency patterns."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import circuit as CQ
+from oracle import pyref as P
+from oracle import verifier as V
+
+pytestmark = pytest.mark.gpu
+
+K, LB, BITS, W = 14, 13, 128, 64
+R = P.FR_R
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import paillier_halo2_amd as pz
+
+    e = pz.Engine(0)
+    e.bind_torch_stream()
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def world(eng, cref):
+    """inputs, structure, SRS (known toxic scalar), proving key, and a function that re-creates the K3 -> K4 witness columns"""
+    import torch
+    from paillier_halo2_amd import layout, prover
+
+    nn, g, m, r = P.synth_paillier_inputs(BITS, 0x5042, standard_g=False)
+    res = P.paillier_enc_native(nn, g, m, r)
+    st = CQ.build("encrypt", nn, g, m, r, res, BITS, W, LB, K)
+    assert CQ.mock_prover(st) == []
+    n = 1 << K
+    Ln = BITS // W
+    ng, nr = m.bit_length() + bin(m).count("1"), nn.bit_length() + bin(nn).count("1")
+    mask, total = P.gate_mask_circuit("encrypt", BITS, W, LB, ng, nr)
+    starts = layout.break_points(mask, st.max_rows)
+    assert starts.tolist() == st.starts           # the library's break rule == the oracle's restatement
+    d_starts = torch.from_numpy(starts.astype(np.int64)).cuda()
+    arr = lambda v, l: cref.int_to_limbs(v, l)
+
+    def witness(res_claimed=res):
+        steps_cap = ng + nr + 1
+        d_steps = torch.zeros((steps_cap, 4, 2 * Ln), dtype=torch.int64, device="cuda")
+        c, g_, r_ = eng.paillier_encrypt_dev(Ln, arr(nn, Ln), arr(g, Ln), arr(m, Ln), arr(r, Ln), d_steps.data_ptr(), steps_cap)
+        assert cref.limbs_to_int(c[0]) == res and (int(g_[0]), int(r_[0])) == (ng, nr)
+        d_mod = torch.from_numpy(arr(nn * nn, 2 * Ln).astype(np.int64)).cuda()
+        cols = torch.zeros((st.m, n, 4), dtype=torch.int64, device="cuda")
+        inputs = np.concatenate([arr(nn, Ln), arr(g, Ln), arr(m, Ln), arr(r, Ln), arr(res_claimed, 2 * Ln)])
+        eng.circuit_expand_cols_dev(0, Ln, W, LB, inputs, d_steps.data_ptr(), ng, nr, d_mod.data_ptr(), cols.data_ptr(),
+                                    cols[st.n_adv].data_ptr(), d_starts.data_ptr(), st.n_adv, st.max_rows, st.max_rows, n)
+        eng.sync()
+        return cols
+
+    rng = random.Random(0x5eed)
+    s_tox = rng.randrange(2, R)
+    F = lambda v: cref.fr_ints_to_mont([v % R])[0]
+    d_g = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    d_gl = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    eng.srs_setup_g1_dev(K, F(s_tox), F(P.fr_omega(K)), d_g.data_ptr(), d_gl.data_ptr())
+    eng.sync()
+    bl, bm = eng.load_bases_dev(d_gl.data_ptr(), n), eng.load_bases_dev(d_g.data_ptr(), n)
+    cs = prover.CircuitStructure(k=K, lookup_bits=LB, max_rows=st.max_rows, blinding_factors=st.blinding_factors, selectors=st.selectors,
+                                 n_lk=st.n_lk, constants=st.constants, map_col=st.map_col, map_row=st.map_row)
+    pk = prover.keygen(eng, cs, bl, bm)
+    ch = prover.Challenges(*(rng.randrange(2, R) for _ in range(8)))
+    yield dict(st=st, pk=pk, ch=ch, witness=witness, s_tox=s_tox, inputs=(nn, g, m, r, res))
+    bl.free()
+    bm.free()
+
+
+def _ints(cref, a):
+    """(count, points, 4) Montgomery words -> [[int]]"""
+    a = np.asarray(a, dtype=np.uint64)
+    flat = cref.fr_mont_to_ints(a.reshape(-1, 4))
+    p = a.shape[1]
+    return [flat[i * p:(i + 1) * p] for i in range(a.shape[0])]
+
+
+def _verify(cref, world, pr):
+    """-> (degree bound holds, identity at x holds, opening identity holds)"""
+    from paillier_halo2_amd import prover
+
+    st, pk, ch = world["st"], world["pk"], world["ch"]
+    ev = {k: _ints(cref, v) for k, v in pr.evals.items()}
+    want = V.expected_h(K, st.blinding_factors, st.n_adv, st.n_lk, prover.CHUNK, ev, ch.beta, ch.gamma, ch.y, ch.x, prover.DELTA)
+    ident = want == ev["h"][0][0]
+    # the verifier's h commitment: sum_i x^(n i) [h_i]
+    xn = pow(ch.x, 1 << K, R)
+    hc = cref.g1_normalize(cref.msm_g1(cref.fr_ints_to_mont([pow(xn, i, R) for i in range(3)]), pr.commitments["h"]))
+    vk = pk.vk_commitments()
+    com = dict(pr.commitments)
+    com.update(fixed=vk["fixed"], sigma=vk["sigma"], h=[hc])
+    lay = prover.query_layout(st.n_adv, st.n_lk, st.m, pk.n_sets)
+    pts = prover.rotation_points(pk.dom, ch.x)
+    opening = V.shplonk_check(cref, lay, pts, com, ev, ch.sh_y, ch.sh_v, ch.sh_u, pr.commitments["w1"][0], pr.commitments["w2"][0], world["s_tox"])
+    return pr.h_degree_ok, ident, opening
+
+
+def test_break_point_columns_equal_the_oracle_layout(eng, cref, world):
+    """K3 -> K4 in the break-point layout: every advice and lookup-advice column cell for cell against oracle/circuit.py"""
+    st = world["st"]
+    cols = world["witness"]().cpu().numpy().view(np.uint64)
+    for j in range(st.n_adv):
+        assert cref.fr_mont_to_ints(cols[j]) == st.adv_cols[j], j
+    for j in range(st.n_lk):
+        assert cref.fr_mont_to_ints(cols[st.n_adv + j]) == st.lk_cols[j], j
+    assert not cols[st.m - 1].any()
+
+
+def test_connected_proof_satisfies_the_verifier(eng, cref, world):
+    from paillier_halo2_amd import prover
+
+    pr = prover.create_proof(world["pk"], world["witness"](), world["ch"], seed=1, tile=8)     # 34 columns in five tiles
+    assert pr.h_top is not None and pr.h_top.shape[0] == (1 << K) + 3
+    deg, ident, opening = _verify(cref, world, pr)
+    assert deg, "quotient degree > 3n - 4"
+    assert ident, "h(x) (x^n - 1) != the constraint expression of the evaluations"
+    assert opening, "SHPLONK identity"
+    assert pr.commitments["h"].any() and pr.commitments["perm_z"].shape[0] == world["pk"].n_sets
+    # the tiling does not change the proof: one 64-column tile gives the same h and the same openings
+    pr2 = prover.create_proof(world["pk"], world["witness"](), world["ch"], seed=1, tile=64)
+    for kname in pr.commitments:
+        assert np.array_equal(pr.commitments[kname], pr2.commitments[kname]), kname
+    for kname in pr.evals:
+        assert np.array_equal(pr.evals[kname], pr2.evals[kname]), kname
+
+
+def _mont1(cref, v):
+    import torch
+
+    return torch.from_numpy(cref.fr_ints_to_mont([v % R])[0].astype(np.int64)).cuda()
+
+
+def test_tampered_witness_cell_breaks_the_identity(eng, cref, world):
+    from paillier_halo2_amd import prover
+
+    st = world["st"]
+    j = 3
+    r0 = int(np.nonzero(st.selectors[j])[0][100])
+
+    def tamper(cols):
+        cols[j, r0 + 3] = _mont1(cref, st.adv_cols[j][r0 + 3] + 1)      # the output cell of an enabled gate
+
+    pr = prover.create_proof(world["pk"], world["witness"](), world["ch"], seed=2, tile=8, hooks={"advice": tamper})
+    deg, ident, opening = _verify(cref, world, pr)
+    assert not deg and not ident
+    assert opening          # the openings themselves are still honest openings of what was committed
+
+
+def test_broken_copy_constraint_breaks_the_identity(eng, cref, world):
+    """a lookup-advice cell changed to ANOTHER value of the table: no gate touches it and the lookup still holds -- only the copy
+    constraint to the digit it copies is broken, and the permutation product no longer closes"""
+    from paillier_halo2_amd import prover
+
+    st = world["st"]
+    col, row = st.n_adv + 1, 777
+    old = st.lk_cols[1][row]
+
+    def tamper(cols):
+        cols[col, row] = _mont1(cref, (old + 1) % (1 << LB))
+
+    pr = prover.create_proof(world["pk"], world["witness"](), world["ch"], seed=3, tile=8, hooks={"advice": tamper})
+    deg, ident, _ = _verify(cref, world, pr)
+    assert not deg and not ident
+
+
+def test_out_of_table_lookup_value(eng, cref, world):
+    """(a) an out-of-range digit in a lookup-advice column: the prover stops where the reference's does (permute_expression_pair finds
+    no table row: PZ_ERR_RANGE); (b) past that point -- a permuted column that is not a permutation of its input -- the lookup
+    product does not telescope and the identity fails"""
+    import paillier_halo2_amd as pz
+    from paillier_halo2_amd import _lib, prover
+
+    st = world["st"]
+
+    def digit(cols):
+        cols[st.n_adv, 5] = _mont1(cref, 1 << LB)
+
+    with pytest.raises(pz.PzError) as e:
+        prover.create_proof(world["pk"], world["witness"](), world["ch"], seed=4, tile=8, hooks={"advice": digit})
+    assert e.value.status == _lib.PZ_ERR_RANGE
+
+    def permuted(Ap, Sp):
+        Ap[0, 9] = _mont1(cref, (1 << LB) + 5)
+        Sp[0, 9] = _mont1(cref, (1 << LB) + 5)
+
+    pr = prover.create_proof(world["pk"], world["witness"](), world["ch"], seed=4, tile=8, hooks={"permuted": permuted})
+    deg, ident, _ = _verify(cref, world, pr)
+    assert not deg and not ident
+
+
+def test_wrong_claimed_result_breaks_the_identity(eng, cref, world):
+    """bench.rs:68-74: the driver assigns the claimed ciphertext and asserts equality in-circuit; a wrong `res` expands (K4) to a
+    satisfied-gates witness whose assert_equal_fresh bit is 0 -- the copy constraint tying that bit to the constant 1 fails"""
+    from paillier_halo2_amd import prover
+
+    res = world["inputs"][4]
+    pr = prover.create_proof(world["pk"], world["witness"](res ^ 2), world["ch"], seed=5, tile=8)
+    deg, ident, _ = _verify(cref, world, pr)
+    assert not deg and not ident
