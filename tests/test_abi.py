@@ -40,6 +40,86 @@ def test_integration_doc_binds_every_entry_point():
     assert not missing, missing
 
 
+def _c_prototypes():
+    """include/pz.h -> {name: (return class, [parameter classes])}; classes: ptr, int, u32, u64, usize, f64"""
+    src = open(os.path.join(ROOT, "include", "pz.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith("#"))
+    src = re.sub(r"enum\s+pz_status\s*\{.*?\};", "", src, flags=re.S)
+    src = src.replace('extern "C" {', "")
+    out = {}
+    for stmt in src.split(";"):
+        st = stmt.strip()
+        m = re.search(r"((?:const\s+)?[A-Za-z_][A-Za-z0-9_]*\s*\**)\s*(pz_[a-z0-9_]+)\s*\((.*)\)\s*$", st, flags=re.S)
+        if not m or st.startswith("typedef"):
+            continue
+        ret, name, params = m.group(1), m.group(2), m.group(3)
+
+        def cls(decl):
+            d = " ".join(decl.split())
+            if "*" in d or "[" in d:
+                return "ptr"
+            base = re.sub(r"\bconst\b", "", d).split()
+            ty = base[0] if len(base) == 1 else " ".join(base[:-1])
+            return {"int": "int", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "double": "f64", "void": "void"}[ty]
+
+        ps = [] if params.strip() in ("", "void") else [cls(x) for x in params.split(",")]
+        out[name] = (cls(ret + " x") if "*" in ret else cls(ret + " x"), ps)
+    return out
+
+
+def _rust_bindings():
+    """INTEGRATION.md's extern "C" declarations -> the same shape"""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    out = {}
+    for m in re.finditer(r"pub fn (pz_[a-z0-9_]+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+))?;", text, flags=re.S):
+        name, params, ret = m.group(1), m.group(2), (m.group(3) or "void").strip()
+
+        def cls(ty):
+            ty = " ".join(ty.split())
+            if ty.startswith("*") or ty.startswith("Option<") or ty.startswith("&"):
+                return "ptr"
+            return {"c_int": "int", "i32": "int", "u32": "u32", "u64": "u64", "usize": "usize", "f64": "f64", "void": "void"}[ty]
+
+        ps = [cls(x.split(":", 1)[1]) for x in params.split(",") if x.strip()]
+        out.setdefault(name, (cls(ret), ps))
+    return out
+
+
+def test_bindings_match_the_header_parameter_by_parameter():
+    """the reference-side binding and the ctypes table against include/pz.h: parameter COUNT and the pointer / c_int /
+    u32 / u64 / usize / f64 class of every parameter and of the return value, for every entry point (names alone were checked before)"""
+    import ctypes as C
+
+    c = _c_prototypes()
+    names = declared_functions()
+    assert sorted(c) == names, sorted(set(names) ^ set(c))
+    rust = _rust_bindings()
+    mism = []
+    for n in names:
+        if n not in rust:
+            mism.append((n, "not bound"))
+        elif rust[n] != c[n]:
+            mism.append((n, c[n], rust[n]))
+    assert not mism, mism
+    # the ctypes signatures
+    def ct(t):
+        if t is None:
+            return "void"
+        if t in (C.c_void_p, C.c_char_p) or hasattr(t, "contents") or (isinstance(t, type) and issubclass(t, C._Pointer)):
+            return "ptr"
+        return {C.c_int: "int", C.c_uint32: "u32", C.c_uint64: "u64", C.c_size_t: "usize", C.c_double: "f64"}[t]
+
+    for n in names:
+        res, args = _lib.SIGNATURES[n]
+        got = (ct(res), [ct(a) for a in args])
+        want = c[n]
+        if C.sizeof(C.c_size_t) == C.sizeof(C.c_uint64):   # ctypes aliases c_size_t and c_uint64 on LP64
+            norm = lambda sig: (sig[0], ["u64" if x == "usize" else x for x in sig[1]])
+            got, want = norm(got), norm(want)
+        assert got == want, (n, want, got)
+
+
 def test_product_never_imports_oracle():
     """the product path must not import, link, dlopen or execute anything under oracle/"""
     pkg = os.path.join(ROOT, "paillier_halo2_amd")
