@@ -1,0 +1,159 @@
+"""bench.py's `with_next_rows` leg: ONE connected proof per step at the benchmark's configuration -- the whole create_proof dataflow
+of paillier_halo2_amd/prover.py on the proof's own data (reference: /root/reference/src/bench.rs:161-171, `gen_proof` after keygen):
+
+    K3 trace -> K4 cells in halo2-lib's break-point column layout -> advice commitments -> permuted lookup columns -> grand products
+    -> (challenge y) -> coefficient forms -> 64-column tiles extended and folded into the quotient as they are produced, against the
+    RESIDENT extended forms of the proving key (selectors + sigma: 103 GB at c2) -> h pieces -> evaluations -> SHPLONK,
+
+every phase closed by a synchronising download of its commitments into a hashing transcript (the host round trip a real transcript
+forces).  The circuit structure (selectors, copy constraints, break points) comes from paillier_halo2_amd/circuit_structure.py; the
+proving key is built once per (key, message-shape) by prover.keygen and timed separately.
+
+`verify()` runs in bench.py's cpu_baseline / checker leg (the one place that may touch oracle/): the quotient's degree bound, the
+verifier's identity h(x)(x^n - 1) == the constraint expression of the EVALUATIONS (oracle/verifier.py), and the multi-point opening's
+identity in the exponent against the proof's commitments (the bench's SRS is synthetic: its scalar is known to the checker).
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+
+
+class ConnectedWorkload:
+    def __init__(self, eng, torch, enc_bits: int, k: int, seed: int, lookup_bits=None, log=lambda s: None, tile: int = 64):
+        import random
+
+        import bench
+        from paillier_halo2_amd import circuit_structure as CS
+        from paillier_halo2_amd import consts, prover
+
+        self.eng, self.torch, self.log = eng, torch, log
+        self.enc_bits, self.k, self.n = enc_bits, k, 1 << k
+        self.lb = lookup_bits if lookup_bits is not None else k - 1
+        self.Ln = enc_bits // 64
+        self.L = 2 * self.Ln
+        nn, g, m, r = bench.synth_inputs(enc_bits, seed)
+        self.ints = (nn, g, m, r)
+        self.ng = m.bit_length() + bin(m).count("1")
+        self.nr = nn.bit_length() + bin(nn).count("1")
+        self.n_steps = self.ng + self.nr + 1
+        # one key serves the proofs of ONE message under different randomness: the message's bits are circuit structure
+        # (paillier.rs:50-55), r is not (r^n's exponent is the public n)
+        vr = random.Random(seed ^ 0x636F6E)
+        lim = lambda x: consts.int_to_limbs(x, self.Ln)
+        self.variants = [tuple(lim(x) for x in (nn, g, m, rr)) for rr in (r, vr.randrange(1, nn), vr.randrange(1, nn))]
+        # ---- circuit structure (what halo2's keygen extracts by synthesising the circuit once)
+        t0 = time.perf_counter()
+        sa = CS.stream_structure("encrypt", enc_bits, 64, self.lb, m, nn)
+        assert (sa.n_steps_g, sa.n_steps_r) == (self.ng, self.nr)
+        t1 = time.perf_counter()
+        self.cs, starts = CS.columns(sa, k, self.lb)
+        self.n_cells, self.n_lookups = sa.n_cells, int(sa.lookup_src.shape[0])
+        del sa
+        self.structure_ms = {"stream_walk_and_tiling": (t1 - t0) * 1e3, "columns_cycles_selectors": (time.perf_counter() - t1) * 1e3}
+        self.d_starts = torch.from_numpy(starts.astype(np.int64)).cuda()
+        self.A, self.Lk, self.m = self.cs.n_adv, self.cs.n_lk, self.cs.m
+        # ---- SRS: monomial and Lagrange bases from a seeded scalar (ParamsKZG::setup, as gen_srs does)
+        self.s_tox = random.Random(seed ^ 0x535253).randrange(2, consts.FR_R)
+        M = consts.fr_mont_limbs
+        d_g = torch.zeros((self.n, 8), dtype=torch.int64, device="cuda")
+        d_gl = torch.zeros((self.n, 8), dtype=torch.int64, device="cuda")
+        eng.srs_setup_g1_dev(k, M(self.s_tox), M(consts.fr_omega(k)), d_g.data_ptr(), d_gl.data_ptr())
+        eng.sync()
+        self.bl, self.bm = eng.load_bases_dev(d_gl.data_ptr(), self.n), eng.load_bases_dev(d_g.data_ptr(), self.n)
+        del d_g, d_gl
+        # ---- keygen_vk + keygen_pk: all three forms of the fixed and permutation polynomials, resident
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        self.pk = prover.keygen(eng, self.cs, self.bl, self.bm)
+        torch.cuda.synchronize()
+        self.keygen_ms = (time.perf_counter() - t2) * 1e3
+        torch.cuda.empty_cache()
+        self.ws = prover.Workspace(self.pk, tile)
+        self.cols = torch.zeros((self.m, self.n, 4), dtype=torch.int64, device="cuda")
+        self.d_steps = torch.zeros((self.n_steps, 4, self.L), dtype=torch.int64, device="cuda")
+        self.d_mod = torch.from_numpy(consts.int_to_limbs(nn * nn, self.L).astype(np.int64)).cuda()
+        self.timings = {}
+        self.last = None
+        self.done = 0
+        pk_bytes = sum(t.numel() * 8 for t in (self.pk.fixed_ext, self.pk.sigma_ext, self.pk.fixed_coeff, self.pk.sigma_coeff, self.pk.sigma_lagrange))
+        self.memory_gb = {"proving_key_resident": pk_bytes / 1e9, "of_which_extended_forms": (self.pk.fixed_ext.numel() + self.pk.sigma_ext.numel()) * 8 / 1e9,
+                          "grand_products_extended": self.ws.z_ext.numel() * 8 / 1e9, "witness_columns": self.cols.numel() * 8 / 1e9,
+                          "torch_allocated_after_setup": torch.cuda.memory_allocated() / 1e9}
+
+    def step(self, timed=True):
+        """one proof: witness, then create_proof with a fresh hashing transcript"""
+        from paillier_halo2_amd import prover
+
+        eng = self.eng
+        nn, g, m, r = self.variants[self.done % len(self.variants)]
+        t0 = time.perf_counter()
+        self.cols.zero_()
+        c, _, _ = eng.paillier_encrypt_dev(self.Ln, nn, g, m, r, self.d_steps.data_ptr(), self.n_steps)          # K3 (returns the ciphertext)
+        inputs = np.concatenate([nn, g, m, r, np.asarray(c[0], dtype=np.uint64)])
+        eng.circuit_expand_cols_dev(0, self.Ln, 64, self.lb, inputs, self.d_steps.data_ptr(), self.ng, self.nr, self.d_mod.data_ptr(),
+                                    self.cols.data_ptr(), self.cols[self.A].data_ptr(), self.d_starts.data_ptr(), self.A, self.cs.max_rows,
+                                    self.cs.max_rows, self.n)                                                     # K4, break-point layout
+        tr = prover.HashTranscript(b"pz-bench-%d" % self.done)
+        if timed:
+            eng.sync()
+            self.timings["witness"] = self.timings.get("witness", 0.0) + (time.perf_counter() - t0) * 1e3
+        pr = prover.create_proof(self.pk, self.cols, tr, seed=1000 + self.done, ws=self.ws, timings=self.timings if timed else None)
+        self.last = (pr, tr.challenges(), self.done % len(self.variants))
+        self.done += 1
+        return pr
+
+    def run(self, steps, timed=True):
+        for _ in range(steps):
+            self.step(timed)
+
+    def phase_ms(self, steps):
+        return {k_: v_ / max(1, steps) for k_, v_ in self.timings.items()}
+
+    def counts(self):
+        S = self.pk.n_sets
+        return {"advice_cols": self.A, "lookup_cols": self.Lk, "permutation_cols": self.m, "permutation_sets": S,
+                "advice_cells": self.n_cells, "lookup_cells": self.n_lookups,
+                "msm_witness": self.A + self.Lk, "msm_full": 3 * self.Lk + S + 1 + 3 + 2,
+                "ntt_polys": self.m + 3 * self.Lk + S, "polys_opened": 2 * self.m + self.A + 2 + 3 * self.Lk + S + 2 - 1}
+
+    def verify(self, cref):
+        """the checker leg (oracle/): the LAST timed proof against the verifier's arithmetic"""
+        from oracle import pyref as P
+        from oracle import verifier as V
+        from paillier_halo2_amd import prover
+
+        pr, ch, variant = self.last
+        R = P.FR_R
+        t0 = time.perf_counter()
+
+        def ints(a):
+            a = np.asarray(a, dtype=np.uint64)
+            flat = cref.fr_mont_to_ints(a.reshape(-1, 4))
+            p = a.shape[1]
+            return [flat[i * p:(i + 1) * p] for i in range(a.shape[0])]
+
+        ev = {k_: ints(v_) for k_, v_ in pr.evals.items()}
+        want = V.expected_h(self.k, self.cs.blinding_factors, self.A, self.Lk, prover.CHUNK, ev, ch.beta, ch.gamma, ch.y, ch.x, prover.DELTA)
+        ident = bool(want == ev["h"][0][0])
+        xn = pow(ch.x, self.n, R)
+        hc = cref.g1_normalize(cref.msm_g1(cref.fr_ints_to_mont([pow(xn, i, R) for i in range(3)]), pr.commitments["h"]))
+        vk = self.pk.vk_commitments()
+        com = dict(pr.commitments)
+        com.update(fixed=vk["fixed"], sigma=vk["sigma"], h=[hc])
+        lay = prover.query_layout(self.A, self.Lk, self.m, self.pk.n_sets)
+        pts = prover.rotation_points(self.pk.dom, ch.x)
+        opening = bool(V.shplonk_check(cref, lay, pts, com, ev, ch.sh_y, ch.sh_v, ch.sh_u, pr.commitments["w1"][0], pr.commitments["w2"][0], self.s_tox))
+        return {"verified": bool(pr.h_degree_ok and ident and opening), "quotient_degree_le_3n_minus_4": bool(pr.h_degree_ok),
+                "h_x_times_xn_minus_1_equals_expression_of_evaluations": ident, "shplonk_identity_on_the_proofs_commitments": opening,
+                "commitments": int(sum(v.shape[0] for v in pr.commitments.values())), "evaluations": int(sum(v.shape[0] * v.shape[1] for v in pr.evals.values())),
+                "checker_s": time.perf_counter() - t0}
+
+    def release(self):
+        for b in (self.bl, self.bm):
+            b.free()
+        for name in ("pk", "ws", "cols", "d_steps", "last"):
+            setattr(self, name, None)
+        self.torch.cuda.empty_cache()

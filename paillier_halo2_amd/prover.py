@@ -135,11 +135,15 @@ class ProvingKey:
         assert st.max_rows <= d.usable and st.map_col.shape == (m, n) and st.selectors.shape == (A, n)
         self.n_sets = -(-m // CHUNK)
         one = torch.from_numpy(M(1).view(np.int64)).cuda()
+        zero4 = torch.zeros_like(one)
+        GB = 256                                   # columns per keygen call (bounds the library's MSM / NTT workspaces)
         # ---- fixed columns: [selectors | constants | table], Lagrange form
         F = A + 2
         fixed = _zeros(F, n, 4)
-        sel = torch.from_numpy(np.ascontiguousarray(st.selectors)).cuda()
-        fixed[:A] = torch.where(sel.bool().unsqueeze(-1), one, torch.zeros_like(one))
+        for a0 in range(0, A, GB):
+            sel = torch.from_numpy(np.ascontiguousarray(st.selectors[a0:a0 + GB])).cuda()
+            fixed[a0:a0 + sel.shape[0]] = torch.where(sel.bool().unsqueeze(-1), one, zero4)
+            del sel
         consts_col = list(st.constants) + [0] * (n - len(st.constants))
         fixed[A] = _ints_to_dev_mont(eng, consts_col)
         table = list(st.table) if st.table is not None else [i if i < (1 << st.lookup_bits) else 0 for i in range(n)]
@@ -147,21 +151,26 @@ class ProvingKey:
         self.const_lagrange = fixed[A].clone()
         self.table_lagrange = fixed[A + 1].clone()
         # ---- sigma polynomials from the copy-constraint map
-        d_mc = torch.from_numpy(st.map_col.astype(np.int32)).cuda()
-        d_mr = torch.from_numpy(st.map_row.astype(np.int32)).cuda()
         sigma = _zeros(m, n, 4)
-        eng.permutation_sigma_dev(d_mc.data_ptr(), d_mr.data_ptr(), m, st.k, M(d.omega), M(DELTA), sigma.data_ptr(), 4 * n)
+        for c0 in range(0, m, GB):
+            cnt = min(GB, m - c0)
+            d_mc = torch.from_numpy(st.map_col[c0:c0 + cnt].astype(np.int32)).cuda()
+            d_mr = torch.from_numpy(st.map_row[c0:c0 + cnt].astype(np.int32)).cuda()
+            eng.permutation_sigma_dev(d_mc.data_ptr(), d_mr.data_ptr(), cnt, st.k, M(d.omega), M(DELTA), sigma[c0].data_ptr(), 4 * n)
+            eng.sync()
+            del d_mc, d_mr
         self.sigma_lagrange = sigma.clone()
         # ---- keygen_vk + keygen_pk: commitments, coefficient forms (in place), extended forms
         self.fixed_commit = _zeros(F, 12)
         self.fixed_ext = _zeros(F, N, 4)
-        eng.keygen_columns_dev(bases_lagrange, fixed.data_ptr(), F, 4 * n, st.k, LOG_E, M(d.omega), M(d.omega_inv), M(d.n_inv), d.gens,
-                               self.fixed_commit.data_ptr(), self.fixed_ext.data_ptr(), 4 * N)
-        self.fixed_coeff = fixed
         self.sigma_commit = _zeros(m, 12)
         self.sigma_ext = _zeros(m, N, 4)
-        eng.keygen_columns_dev(bases_lagrange, sigma.data_ptr(), m, 4 * n, st.k, LOG_E, M(d.omega), M(d.omega_inv), M(d.n_inv), d.gens,
-                               self.sigma_commit.data_ptr(), self.sigma_ext.data_ptr(), 4 * N)
+        for t_, cnt_all, com, ext in ((fixed, F, self.fixed_commit, self.fixed_ext), (sigma, m, self.sigma_commit, self.sigma_ext)):
+            for c0 in range(0, cnt_all, GB):
+                cnt = min(GB, cnt_all - c0)
+                eng.keygen_columns_dev(bases_lagrange, t_[c0].data_ptr(), cnt, 4 * n, st.k, LOG_E, M(d.omega), M(d.omega_inv), M(d.n_inv),
+                                       d.gens, com[c0].data_ptr(), ext[c0].data_ptr(), 4 * N)
+        self.fixed_coeff = fixed
         self.sigma_coeff = sigma
         # ---- l_0, l_last, l_active on the extended coset
         u = d.usable
@@ -198,6 +207,51 @@ class Challenges:
     sh_u: int
 
 
+class Transcript:
+    """fixed challenges (tests): nothing is hashed, the phases still hand their commitments over"""
+
+    def __init__(self, ch: Challenges):
+        self.ch = ch
+
+    def absorb_points(self, eng: Engine, *jac_tensors):
+        pass
+
+    def absorb_scalars(self, *host_arrays):
+        pass
+
+    def squeeze(self, name: str) -> int:
+        return getattr(self.ch, name)
+
+
+class HashTranscript(Transcript):
+    """a stand-in for halo2's Blake2b transcript with the same DATAFLOW: every phase's commitments are brought to the host in affine
+    form (a synchronising download: the prover cannot start the next phase before the challenge exists), hashed, and the challenge is
+    the digest reduced mod r.  Not halo2's byte format (the transcript is out of scope)."""
+
+    def __init__(self, seed: bytes = b"pz"):
+        import hashlib
+
+        self.h = hashlib.blake2b(seed, digest_size=64)
+        self.drawn: Dict[str, int] = {}
+
+    def absorb_points(self, eng: Engine, *jac_tensors):
+        for t in jac_tensors:
+            self.h.update(eng.g1_normalize(t.cpu().numpy().view(np.uint64)).tobytes())
+
+    def absorb_scalars(self, *host_arrays):
+        for a in host_arrays:
+            self.h.update(np.ascontiguousarray(a).tobytes())
+
+    def squeeze(self, name: str) -> int:
+        self.h.update(name.encode())
+        v = int.from_bytes(self.h.digest(), "little") % (FR - 2) + 2
+        self.drawn[name] = v
+        return v
+
+    def challenges(self) -> Challenges:
+        return Challenges(**self.drawn)
+
+
 @dataclass
 class Proof:
     commitments: Dict[str, np.ndarray] = field(default_factory=dict)     # name -> affine points (count, 8), Montgomery
@@ -226,36 +280,85 @@ def query_layout(A: int, Lk: int, m: int, S: int):
     return sets
 
 
-def create_proof(pk: ProvingKey, cols, ch: Challenges, seed: int = 0, tile: int = 64, hooks=None) -> Proof:
+class Workspace:
+    """the per-proof device buffers of create_proof, allocated once per proving key and reused by every proof (at config c2: the
+    grand products on the extended domain are 26 GB; everything else is a few GB)"""
+
+    def __init__(self, pk: ProvingKey, tile: int = 64):
+        d, st = pk.dom, pk.st
+        n, N, Lk, S = d.n, d.N, st.n_lk, pk.n_sets
+        assert tile % CHUNK == 0
+        self.tile = tile
+        self.Ap, self.Sp, self.Zl = _zeros(Lk, n, 4), _zeros(Lk, n, 4), _zeros(Lk, n, 4)
+        self.Z = _zeros(S, n, 4)
+        self.z_ext = _zeros(S, N, 4)
+        self.ext = _zeros(tile, N, 4)
+        lt = min(tile, Lk)
+        self.lk_ext = [_zeros(lt, N, 4) for _ in range(4)]
+        self.hh = _zeros(2, N, 4)
+        self.h = _zeros(N, 4)
+        self.rnd = _zeros(1, n, 4)
+        self.hcomb = _zeros(n, 4)
+        self.w1, self.w2 = _zeros(n, 4), _zeros(n, 4)
+
+
+def create_proof(pk: ProvingKey, cols, tr, seed: int = 0, tile: int = 64, hooks=None, ws: Optional[Workspace] = None,
+                 timings: Optional[Dict[str, float]] = None) -> Proof:
     """cols: int64 CUDA tensor [m][2^k][4]: the advice columns then the lookup-advice columns as K4 wrote them (rows >= max_rows
-    zero); the last column (constants) and the blinding rows are filled here.  Runs on the engine's stream (bind_torch_stream).
-    hooks: optional dict of callables name -> f(tensor) applied to intermediate device buffers (the tests' tamper points)."""
+    zero); the last column (constants) and the blinding rows are filled here; cols is consumed (it ends up in coefficient form).
+    tr: a Transcript (or plain Challenges).  Runs on the engine's stream (bind_torch_stream).
+    hooks: optional dict of callables name -> f(tensors) applied to intermediate device buffers (the tests' tamper points).
+    timings: if given, phase -> milliseconds of wall time (each phase ends with the transcript's synchronising download)."""
+    import time
+
     torch = _torch()
     eng, st, d = pk.eng, pk.st, pk.dom
     n, N, k, u, bf = d.n, d.N, d.k, d.usable, d.bf
     A, Lk, m, S = st.n_adv, st.n_lk, st.m, pk.n_sets
     W = A + Lk
-    assert tile % CHUNK == 0 and tuple(cols.shape) == (m, n, 4)
+    if isinstance(tr, Challenges):
+        tr = Transcript(tr)
+    if ws is None:
+        ws = Workspace(pk, tile)
+    tile = ws.tile
+    assert tuple(cols.shape) == (m, n, 4)
     hooks = hooks or {}
     gen = torch.Generator(device="cuda")
     gen.manual_seed(seed)
     pr = Proof()
     bl, bm = pk.bases_lagrange, pk.bases_monomial
-    beta, gamma, y = M(ch.beta), M(ch.gamma), M(ch.y)
+    t_last = [time.perf_counter()]
+
+    def phase(name):
+        if timings is not None:
+            eng.sync()
+            now = time.perf_counter()
+            timings[name] = timings.get(name, 0.0) + (now - t_last[0]) * 1e3
+            t_last[0] = now
 
     def commit(bases, t, count, stride_u64):
         out = _zeros(count, 12)
         eng.msm_dev(bases, t.data_ptr(), count, n, stride_u64, out.data_ptr())
         return out
 
-    # ---- 1. advice: blinding rows, commitments
+    def to_coeff(t, cnt):       # lagrange_to_coeff in place, `tile` columns per call (bounds the transform workspace)
+        for c0 in range(0, cnt, tile):
+            eng.ntt_dev(t[c0].data_ptr(), min(tile, cnt - c0), 4 * n, M(d.omega_inv), k, None, M(d.n_inv))
+
+    def extend(src, cnt, dst):
+        eng.ntt_extend_dev(src.data_ptr(), cnt, 4 * n, dst.data_ptr(), 4 * N, k, LOG_E, M(d.omega), d.gens, None)
+
+    # ---- 1. advice: blinding rows, commitments -> theta
     cols[:W, u:] = _random_fr(gen, W, n - u)
     cols[W] = pk.const_lagrange
     if "advice" in hooks:
         hooks["advice"](cols)
     c_adv = commit(bl, cols, W, 4 * n)
-    # ---- 2. lookups: permuted input / table (one expression each side: theta does not enter)
-    Ap, Sp = _zeros(Lk, n, 4), _zeros(Lk, n, 4)
+    tr.absorb_points(eng, c_adv)
+    tr.squeeze("theta")
+    phase("advice_commit")
+    # ---- 2. lookups: permuted input / table (one expression each side: theta does not enter) -> beta, gamma
+    Ap, Sp, Zl, Z = ws.Ap, ws.Sp, ws.Zl, ws.Z
     lk_in = cols[A:W]
     eng.lookup_permute_dev(lk_in.data_ptr(), Lk, 4 * n, pk.table_lagrange.data_ptr(), u, st.lookup_bits, Ap.data_ptr(), Sp.data_ptr(), 4 * n)
     if "permuted" in hooks:
@@ -263,33 +366,36 @@ def create_proof(pk: ProvingKey, cols, ch: Challenges, seed: int = 0, tile: int 
     Ap[:, u:] = _random_fr(gen, Lk, n - u)
     Sp[:, u:] = _random_fr(gen, Lk, n - u)
     c_ap, c_sp = commit(bl, Ap, Lk, 4 * n), commit(bl, Sp, Lk, 4 * n)
-    # ---- 3. grand products
-    Z = _zeros(S, n, 4)
+    tr.absorb_points(eng, c_ap, c_sp)
+    beta_i, gamma_i = tr.squeeze("beta"), tr.squeeze("gamma")
+    beta, gamma = M(beta_i), M(gamma_i)
+    phase("lookup_permute_commit")
+    # ---- 3. grand products, the vanishing argument's random polynomial -> y
     eng.permutation_product_sets_dev(cols.data_ptr(), 4 * n, pk.sigma_lagrange.data_ptr(), 4 * n, m, CHUNK, k, u, M(d.omega), beta, gamma,
                                      M(DELTA), Z.data_ptr(), 4 * n)
     Z[:, u + 1:] = _random_fr(gen, S, n - u - 1)
-    Zl = _zeros(Lk, n, 4)
     eng.lookup_product_dev(lk_in.data_ptr(), 4 * n, pk.table_lagrange.data_ptr(), Ap.data_ptr(), 4 * n, Sp.data_ptr(), 4 * n, Lk, n, beta,
                            gamma, M(1), Zl.data_ptr(), 4 * n)
     Zl[:, u + 1:] = _random_fr(gen, Lk, n - u - 1)
     if "products" in hooks:
         hooks["products"](Z, Zl)
     c_z, c_zl = commit(bl, Z, S, 4 * n), commit(bl, Zl, Lk, 4 * n)
-    # ---- 4. the vanishing argument's random polynomial (coefficient form)
-    rnd = _random_fr(gen, 1, n)
+    rnd = ws.rnd
+    rnd.copy_(_random_fr(gen, 1, n))
     c_rnd = commit(bm, rnd, 1, 4 * n)
-    # ---- 5. quotient.  Lagrange -> coefficients for everything the proof opens (in place: the Lagrange forms are done with)
+    tr.absorb_points(eng, c_z, c_zl, c_rnd)
+    y_i = tr.squeeze("y")
+    y = M(y_i)
+    phase("products_commit")
+    # ---- 4. quotient.  Lagrange -> coefficients for everything the proof opens (in place: the Lagrange forms are done with)
     for t, cnt in ((cols, m), (Ap, Lk), (Sp, Lk), (Z, S), (Zl, Lk)):
-        eng.ntt_dev(t.data_ptr(), cnt, 4 * n, M(d.omega_inv), k, None, M(d.n_inv))
-
-    def extend(src, cnt, dst):
-        eng.ntt_extend_dev(src.data_ptr(), cnt, 4 * n, dst.data_ptr(), 4 * N, k, LOG_E, M(d.omega), d.gens, None)
-
-    z_ext = _zeros(S, N, 4)                     # all sets: the chaining lines read z_{j-1} beside z_j
+        to_coeff(t, cnt)
+    z_ext = ws.z_ext                            # all sets: the chaining lines read z_{j-1} beside z_j
     for s0 in range(0, S, tile):
         extend(Z[s0:s0 + tile], min(tile, S - s0), z_ext[s0:s0 + tile])
-    hg, hp = _zeros(N, 4), _zeros(N, 4)         # gate lines / permutation lines, folded apart and joined below: one pass over the tiles
-    ext = _zeros(tile, N, 4)
+    ws.hh.zero_()
+    hg, hp = ws.hh[0], ws.hh[1]                 # gate lines / permutation lines, folded apart and joined below: one pass over the tiles
+    ext = ws.ext
     l0, llast, lact = (pk.l_ext[i].data_ptr() for i in range(3))
     for c0 in range(0, m, tile):
         cnt = min(tile, m - c0)
@@ -303,12 +409,12 @@ def create_proof(pk: ProvingKey, cols, ch: Challenges, seed: int = 0, tile: int 
                                           M(d.omega_ext), y, hp.data_ptr())
     # h = hg * y^(permutation lines) + hp, then the lookup lines on top
     n_perm_lines = 2 + (S - 1) + S
-    hh = torch.stack([hg, hp])
-    h = _zeros(N, 4)
-    eng.fr_lincomb_dev(hh.data_ptr(), 2, 4 * N, N, M(pow(ch.y, n_perm_lines, FR)), h.data_ptr())
-    for l0_ in range(0, Lk, tile):
-        cnt = min(tile, Lk - l0_)
-        e_in, e_ap, e_sp, e_zl = (_zeros(cnt, N, 4) for _ in range(4))
+    h = ws.h
+    eng.fr_lincomb_dev(ws.hh.data_ptr(), 2, 4 * N, N, M(pow(y_i, n_perm_lines, FR)), h.data_ptr())
+    lt = ws.lk_ext[0].shape[0]
+    for l0_ in range(0, Lk, lt):
+        cnt = min(lt, Lk - l0_)
+        e_in, e_ap, e_sp, e_zl = ws.lk_ext
         extend(cols[A + l0_:A + l0_ + cnt], cnt, e_in)
         extend(Ap[l0_:l0_ + cnt], cnt, e_ap)
         extend(Sp[l0_:l0_ + cnt], cnt, e_sp)
@@ -320,8 +426,11 @@ def create_proof(pk: ProvingKey, cols, ch: Challenges, seed: int = 0, tile: int 
     eng.fr_distribute_powers_dev(h.data_ptr(), 1, 4 * N, N, M(pow(d.coset_g, -1, FR)))
     pieces = h.view(d.E, n, 4)                  # h(X) = sum_i X^(n i) h_i(X); degree <= 3n - 4: piece 3 and the top of piece 2 vanish
     c_h = commit(bm, pieces, d.E - 1, 4 * n)
-    # ---- 6. evaluations
-    xs = rotation_points(d, ch.x)
+    tr.absorb_points(eng, c_h)
+    x_i = tr.squeeze("x")
+    phase("quotient")
+    # ---- 5. evaluations -> SHPLONK's y, v
+    xs = rotation_points(d, x_i)
     P = lambda idx: np.stack([M(xs[i]) for i in idx])
 
     def evals(t, cnt, idx):
@@ -329,8 +438,8 @@ def create_proof(pk: ProvingKey, cols, ch: Challenges, seed: int = 0, tile: int 
         eng.poly_eval_multi_dev(t.data_ptr(), cnt, 4 * n, n, P(idx), out.data_ptr())
         return out
 
-    xn = pow(ch.x, n, FR)
-    hcomb = _zeros(n, 4)                        # h_0 + x^n h_1 + x^2n h_2: what halo2 opens at x
+    xn = pow(x_i, n, FR)
+    hcomb = ws.hcomb                            # h_0 + x^n h_1 + x^2n h_2: what halo2 opens at x
     for i in reversed(range(d.E - 1)):
         eng.fr_lincomb_dev(pieces[i].data_ptr(), 1, 4 * n, n, M(xn), hcomb.data_ptr(), i != d.E - 2)
     F = A + 2
@@ -344,29 +453,36 @@ def create_proof(pk: ProvingKey, cols, ch: Challenges, seed: int = 0, tile: int 
     e_sp = evals(Sp, Lk, [0])
     e_rnd = evals(rnd, 1, [0])
     e_h = evals(hcomb.view(1, n, 4), 1, [0])
-    # ---- 7. SHPLONK
     eng.sync()
     host = lambda t: t.cpu().numpy().view(np.uint64)
     polys = {"lookup_advice": cols[A:], "fixed": pk.fixed_coeff, "sigma": pk.sigma_coeff, "perm_tables": Sp, "h": hcomb.view(1, n, 4),
              "random": rnd, "advice": cols, "perm_z": Z, "lookup_z": Zl, "perm_inputs": Ap}
     ev = {"lookup_advice": host(e_lk), "fixed": host(e_fix), "sigma": host(e_sig), "perm_tables": host(e_sp), "h": host(e_h),
           "random": host(e_rnd), "advice": host(e_adv), "perm_z": host(e_z), "lookup_z": host(e_zl), "perm_inputs": host(e_ap)}
+    tr.absorb_scalars(*[ev[f] for f in ("advice", "lookup_advice", "fixed", "sigma", "perm_z", "lookup_z", "perm_inputs", "perm_tables", "random")])
+    shy, shv = tr.squeeze("sh_y"), tr.squeeze("sh_v")
+    phase("evaluations")
+    # ---- 6. SHPLONK -> u
     sets = [([polys[f][i].data_ptr() for f, i in members], idx, np.stack([ev[f][i][:len(idx)] for f, i in members]))
             for idx, members in query_layout(A, Lk, m, S)]
-    w1, w2 = _zeros(n, 4), _zeros(n, 4)
-    state = eng.shplonk_begin_dev(n, sets, np.stack([M(p) for p in xs]), M(ch.sh_y), M(ch.sh_v), w1.data_ptr())
+    w1, w2 = ws.w1, ws.w2
+    state = eng.shplonk_begin_dev(n, sets, np.stack([M(p) for p in xs]), M(shy), M(shv), w1.data_ptr())
     c_w1 = commit(bm, w1.view(1, n, 4), 1, 4 * n)
-    eng.shplonk_finish_dev(state, M(ch.sh_u), w1.data_ptr(), w2.data_ptr())
+    tr.absorb_points(eng, c_w1)
+    shu = tr.squeeze("sh_u")
+    eng.shplonk_finish_dev(state, M(shu), w1.data_ptr(), w2.data_ptr())
     c_w2 = commit(bm, w2.view(1, n, 4), 1, 4 * n)
     eng.sync()
+    phase("multiopen")
     # ---- the proof
     norm = lambda t: eng.g1_normalize(host(t))
     pr.commitments = {"advice": norm(c_adv)[:A], "lookup_advice": norm(c_adv)[A:], "perm_inputs": norm(c_ap), "perm_tables": norm(c_sp),
                       "perm_z": norm(c_z), "lookup_z": norm(c_zl), "random": norm(c_rnd), "h": norm(c_h), "w1": norm(c_w1), "w2": norm(c_w2)}
-    pr.evals = {"advice": host(e_adv), "lookup_advice": host(e_lk)[:Lk], "constants": host(e_lk)[Lk:], "fixed": host(e_fix),
-                "sigma": host(e_sig), "perm_z": host(e_z), "lookup_z": host(e_zl), "perm_inputs": host(e_ap), "perm_tables": host(e_sp),
-                "random": host(e_rnd), "h": host(e_h)}
+    pr.evals = {"advice": ev["advice"], "lookup_advice": ev["lookup_advice"][:Lk], "constants": ev["lookup_advice"][Lk:], "fixed": ev["fixed"],
+                "sigma": ev["sigma"], "perm_z": ev["perm_z"], "lookup_z": ev["lookup_z"], "perm_inputs": ev["perm_inputs"],
+                "perm_tables": ev["perm_tables"], "random": ev["random"], "h": ev["h"]}
     top = host(h[3 * n - 3:])
     pr.h_top = top
     pr.h_degree_ok = not top.any()
+    phase("finalise")
     return pr

@@ -65,3 +65,40 @@ def test_lagrange_values_of_the_verifier():
     # l_i is the interpolation of the unit vector e_i
     coeffs = P.intt([1 if i == 3 else 0 for i in range(n)], w)
     assert P.poly_eval(coeffs, x) == li[3]
+
+
+def test_product_structure_generator_equals_the_oracle_restatement():
+    """paillier_halo2_amd/circuit_structure.py (a value-free walk of one mul_mod block, tiled) against oracle/circuit.py (a walk of the
+    whole circuit WITH values): gate mask, break points, selectors, lookup sources and sigma, for the reference's encrypt shape, a
+    larger lookup width, a 3-limb key and the add circuit on 88-bit limbs (paillier.rs:186-187)"""
+    import numpy as np
+
+    from paillier_halo2_amd import circuit_structure as CS
+
+    for bits, W, lb, k, seed, kind in ((128, 64, 13, 14, 0x5042, "encrypt"), (128, 64, 15, 16, 0x77, "encrypt"), (264, 88, 12, 13, 0x99, "add"),
+                                       (192, 64, 11, 14, 0x31, "encrypt")):
+        n, g, m, r = P.synth_paillier_inputs(bits, seed, standard_g=False)
+        res = P.paillier_enc_native(n, g, m, r) if kind == "encrypt" else P.paillier_add_native(n, m, r)
+        st = CQ.build(kind, n, g, m, r, res, bits, W, lb, k)
+        sa = CS.stream_structure(kind, bits, W, lb, m, n)
+        cs, starts = CS.columns(sa, k, lb, device="cpu")
+        ng = m.bit_length() + bin(m).count("1") if kind == "encrypt" else 0
+        nr = n.bit_length() + bin(n).count("1") if kind == "encrypt" else 0
+        assert (sa.n_steps_g, sa.n_steps_r) == (ng, nr)
+        mask, _ = P.gate_mask_circuit(kind, bits, W, lb, ng, nr)
+        assert np.array_equal(mask, sa.gate_mask) and starts.tolist() == st.starts and np.array_equal(cs.selectors, st.selectors)
+        assert sa.n_cells == st.n_cells and sa.lookup_src.shape[0] == st.n_lookups and cs.n_lk == st.n_lk
+        assert sorted(cs.constants) == sorted(st.constants)
+        # sigma: identical wherever the image is not in the constants column (whose row order is each generator's own) ...
+        Wd = st.n_adv + st.n_lk
+        keep = st.map_col[:Wd] < Wd
+        assert np.array_equal(cs.map_col[:Wd] < Wd, keep)
+        assert np.array_equal(cs.map_col[:Wd][keep], st.map_col[:Wd][keep]) and np.array_equal(cs.map_row[:Wd][keep], st.map_row[:Wd][keep])
+        # ... and there it maps to a cell with the same VALUE: the product's sigma is satisfied by the oracle's witness
+        st.constants = list(cs.constants)
+        cols = CQ.perm_columns(st)
+        flat = cs.map_col.astype(np.int64) * st.n + cs.map_row
+        assert np.unique(flat).size == flat.size
+        moved = np.argwhere(flat != np.arange(flat.size).reshape(flat.shape))
+        for c, rr in moved[:: max(1, moved.shape[0] // 4000)].tolist():
+            assert cols[c][rr] == cols[int(cs.map_col[c, rr])][int(cs.map_row[c, rr])], (kind, c, rr)

@@ -74,8 +74,17 @@ def world(eng, cref):
     eng.srs_setup_g1_dev(K, F(s_tox), F(P.fr_omega(K)), d_g.data_ptr(), d_gl.data_ptr())
     eng.sync()
     bl, bm = eng.load_bases_dev(d_gl.data_ptr(), n), eng.load_bases_dev(d_g.data_ptr(), n)
-    cs = prover.CircuitStructure(k=K, lookup_bits=LB, max_rows=st.max_rows, blinding_factors=st.blinding_factors, selectors=st.selectors,
-                                 n_lk=st.n_lk, constants=st.constants, map_col=st.map_col, map_row=st.map_row)
+    # the keygen input comes from the PRODUCT's structure generator (what bench.py uses at config c2); it must describe the same
+    # circuit as the oracle's restatement: same selectors, same break points, the same sigma up to the order of the constants column
+    from paillier_halo2_amd import circuit_structure as CS
+
+    sa = CS.stream_structure("encrypt", BITS, W, LB, m, nn)
+    cs, cs_starts = CS.columns(sa, K, LB, max_rows=st.max_rows, blinding_factors=st.blinding_factors)
+    assert cs_starts.tolist() == st.starts and np.array_equal(cs.selectors, st.selectors) and cs.n_lk == st.n_lk
+    assert sorted(cs.constants) == sorted(st.constants)
+    W_ = st.n_adv + st.n_lk
+    keep = st.map_col[:W_] < W_
+    assert np.array_equal(cs.map_col[:W_][keep], st.map_col[:W_][keep]) and np.array_equal(cs.map_row[:W_][keep], st.map_row[:W_][keep])
     pk = prover.keygen(eng, cs, bl, bm)
     ch = prover.Challenges(*(rng.randrange(2, R) for _ in range(8)))
     yield dict(st=st, pk=pk, ch=ch, witness=witness, s_tox=s_tox, inputs=(nn, g, m, r, res))
@@ -138,6 +147,24 @@ def test_connected_proof_satisfies_the_verifier(eng, cref, world):
         assert np.array_equal(pr.commitments[kname], pr2.commitments[kname]), kname
     for kname in pr.evals:
         assert np.array_equal(pr.evals[kname], pr2.evals[kname]), kname
+
+
+def test_connected_proof_with_a_hashing_transcript(eng, cref, world):
+    """the same flow with every challenge DERIVED from the commitments of the phase before it (a Blake2b stand-in for halo2's
+    transcript: a synchronising download per phase) -- what bench.py's with_next_rows times; verified with the challenges it drew"""
+    from paillier_halo2_amd import prover
+
+    tr = prover.HashTranscript(b"test")
+    tm = {}
+    pr = prover.create_proof(world["pk"], world["witness"](), tr, seed=7, tile=16, timings=tm)
+    w2 = dict(world)
+    w2["ch"] = tr.challenges()
+    assert w2["ch"] != world["ch"] and set(tm) >= {"advice_commit", "quotient", "multiopen"}
+    assert _verify(cref, w2, pr) == (True, True, True)
+    # a different witness (another randomness r is not available here, so: another blinding seed) changes every challenge
+    tr2 = prover.HashTranscript(b"test")
+    prover.create_proof(world["pk"], world["witness"](), tr2, seed=8, tile=16)
+    assert tr2.challenges().beta != tr.challenges().beta
 
 
 def _mont1(cref, v):
