@@ -151,14 +151,14 @@ class ProvingKey:
         self.const_lagrange = fixed[A].clone()
         self.table_lagrange = fixed[A + 1].clone()
         # ---- sigma polynomials from the copy-constraint map
+        # (one call over all m columns: the images' column indices run over the whole permutation, and the entry point sizes its
+        # table of delta powers by the m it is given)
         sigma = _zeros(m, n, 4)
-        for c0 in range(0, m, GB):
-            cnt = min(GB, m - c0)
-            d_mc = torch.from_numpy(st.map_col[c0:c0 + cnt].astype(np.int32)).cuda()
-            d_mr = torch.from_numpy(st.map_row[c0:c0 + cnt].astype(np.int32)).cuda()
-            eng.permutation_sigma_dev(d_mc.data_ptr(), d_mr.data_ptr(), cnt, st.k, M(d.omega), M(DELTA), sigma[c0].data_ptr(), 4 * n)
-            eng.sync()
-            del d_mc, d_mr
+        d_mc = torch.from_numpy(st.map_col.view(np.int32)).cuda()
+        d_mr = torch.from_numpy(st.map_row.view(np.int32)).cuda()
+        eng.permutation_sigma_dev(d_mc.data_ptr(), d_mr.data_ptr(), m, st.k, M(d.omega), M(DELTA), sigma.data_ptr(), 4 * n)
+        eng.sync()
+        del d_mc, d_mr
         self.sigma_lagrange = sigma.clone()
         # ---- keygen_vk + keygen_pk: commitments, coefficient forms (in place), extended forms
         self.fixed_commit = _zeros(F, 12)
