@@ -1116,6 +1116,10 @@ def main():
     ap.add_argument("--no-body", action="store_true", help="skip the second timed loop (hot path + the prover steps after it)")
     ap.add_argument("--emulate-world", type=int, default=0, help="msm22 workload on ONE GPU: run each of W ranks' shares in turn, "
                     "print per-share stage times and the predicted W-GPU efficiency for both splits")
+    ap.add_argument("--emulate-ranks", type=int, default=0, help="msm22 workload (and, with --parallel columns, a c2 column batch) on ONE GPU: this "
+                    "process plays every rank 0..W-1 of a world of W in turn -- rank r's exact code path (its point / window / column range, "
+                    "offsets, padded gather slices) -- through the real process group of one rank (use with --force-dist: backend nccl = RCCL); "
+                    "every rank's folded / gathered result must equal the single-call result")
     ap.add_argument("--no-verify", action="store_true", help="skip the output check of the pipelined step after the timed loop (the line then says verified: null)")
     ap.add_argument("--no-fresh-key", action="store_true", help="skip the third timed loop (keygen per message inside the timed region)")
     ap.add_argument("--no-c2u", action="store_true", help="default c2 run only: skip the uniform-shape circuit's line (a second workload after the main one)")
@@ -1168,7 +1172,26 @@ def main():
     if args.workload == "msm22":
         from paillier_halo2_amd import dist as pzd
 
-        if args.emulate_world > 1:
+        if args.emulate_ranks > 1:
+            em = pzd.emulate_ranks_msm(eng, torch, dist if use_dist else None, args.emulate_ranks, args.log_n, args.msm_split, log)
+            em_cols = None
+            if args.parallel == "columns":     # the commitment all-gather of column-parallel proving, 37 full-width columns of 2^14 rows
+                kk, nc = 14, 37
+                g_ = torch.Generator(device="cuda")
+                g_.manual_seed(7)
+                d_c = torch.randint(-(1 << 63), (1 << 63) - 1, (nc, 1 << kk, 4), dtype=torch.int64, device="cuda", generator=g_)
+                d_c[:, :, 3] &= 0x0FFFFFFFFFFFFFFF
+                d_bb = torch.zeros((1 << kk, 8), dtype=torch.int64, device="cuda")
+                eng.g1_fixed_base_mul_dev(d_c[0].data_ptr(), 1 << kk, d_bb.data_ptr())
+                tb_ = eng.load_bases_dev(d_bb.data_ptr(), 1 << kk)
+                em_cols = pzd.emulate_ranks_columns(eng, torch, dist if use_dist else None, args.emulate_ranks, tb_, d_c, nc, 1 << kk, log)
+                tb_.free()
+            res = {"metric": "rank emulation of the sharded MSM: every rank's code path on one GPU", "value": 1.0 if em["all_equal"] and (em_cols is None or em_cols["all_equal"]) else 0.0,
+                   "unit": "all ranks equal the single-call result", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": None, "higher_is_better": True,
+                   "scaling": "strong", "vs_baseline": None, "dtype": "u32 limbs (254-bit modular integers)", "data": "synthetic",
+                   "config": {"workload": "c4 rank emulation: 2^%d-point MSM, world %d, %s split" % (args.log_n, args.emulate_ranks, args.msm_split)},
+                   "emulate_ranks": em, "emulate_ranks_columns": em_cols}
+        elif args.emulate_world > 1:
             res = pzd.emulate_sharded_msm(eng, torch, args.emulate_world, args.log_n, args.steps, args.warmup, log, scalars=args.msm_scalars,
                                           share_window_bits=int(os.environ.get("PZ_SHARE_WINDOW_BITS", "0")))
         else:

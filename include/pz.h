@@ -52,7 +52,8 @@ enum pz_status {
     PZ_ERR_CAPACITY = -8,     /* caller-provided output capacity too small                  */
     PZ_ERR_MESSAGE_RANGE = -9,/* uniform-shape circuit: a message does not fit the m_bits the circuit decomposes */
     PZ_ERR_ASYNC = -10        /* reported by a synchronising entry point (pz_sync, pz_download, the host-pointer MSM calls): an
-                                 earlier asynchronous pz_msm_g1* call found its scalars changed while it ran; its outputs are
+                                 earlier asynchronous pz_msm_g1* call found its scalars changed while it ran, or
+                                 pz_permutation_sigma_dev found an image outside its m x n cells; the outputs of that call are
                                  invalid (no out-of-bounds access took place: positions are checked on the device) */
     ,
     PZ_ERR_INTERNAL = -11     /* a device-side wait ran into its bound.  Only source today: K3 (pz_paillier_trace / pz_paillier_encrypt*):
@@ -328,7 +329,9 @@ int pz_srs_lagrange_from_monomial_dev(pz_ctx* ctx, uint32_t k, const uint64_t om
                                       const uint64_t* d_g, uint64_t* d_g_lagrange);
 /* keygen, permutation polynomials (halo2 permutation::keygen::Assembly::build_pk): d_sigma[j][i] = delta^(d_map_col[j*n+i]) *
  * omega^(d_map_row[j*n+i]) over the 2^k domain, n = 2^k, for m columns -- (map_col, map_row) is the cell the copy-constraint
- * cycle maps (j, i) to (circuit structure, supplied by the caller: device arrays of m * n u32 each). */
+ * cycle maps (j, i) to (circuit structure, supplied by the caller: device arrays of m * n u32 each).  ONE call covers the whole
+ * permutation: every image must lie inside the m x n cells of the call (an image outside is clamped on the device and the next
+ * synchronising entry point returns PZ_ERR_ASYNC). */
 int pz_permutation_sigma_dev(pz_ctx* ctx, const uint32_t* d_map_col, const uint32_t* d_map_row, size_t m, uint32_t k,
                              const uint64_t omega[4], const uint64_t delta[4], uint64_t* d_sigma, size_t sigma_stride);
 /* keygen_vk + keygen_pk for n_cols Lagrange-form fixed columns (selectors, constants, table, sigma) on the device: their

@@ -193,13 +193,22 @@ extern "C" int pz_poly_eval_multi_dev(pz_ctx* ctx, const uint64_t* d_coeffs, siz
 // permutation::keygen: the sigma polynomial of column j holds, at row i, the label delta^(col') * omega^(row') of the cell
 // the copy-constraint cycle maps (j, i) to.  The cycles themselves are circuit structure (the reference's dependency
 // builds them while synthesising); they arrive as two index arrays.
+// (the map is the caller's device data: an image outside the m x n cells -- e.g. a map cut into column batches whose images still
+// name columns of the whole permutation -- would index past the power tables; it is clamped and reported through the context's
+// asynchronous-failure word: the next synchronising entry point returns PZ_ERR_ASYNC)
 __global__ __launch_bounds__(256) void k_perm_sigma(const u32* __restrict__ map_col, const u32* __restrict__ map_row, size_t n,
-                                                    size_t total, const Fr* __restrict__ wpow, const Fr* __restrict__ dpow,
-                                                    Fr* __restrict__ sigma, size_t stride) {
+                                                    size_t total, unsigned m, const Fr* __restrict__ wpow, const Fr* __restrict__ dpow,
+                                                    Fr* __restrict__ sigma, size_t stride, volatile unsigned* err) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const size_t j = t / n, i = t % n;
-    fp_store(sigma + j * stride + i, fp_mul(fp_load<FrTag>(dpow + map_col[t]), fp_load<FrTag>(wpow + map_row[t])));
+    u32 c = map_col[t], r = map_row[t];
+    if (c >= m || r >= n) {
+        *err = 1u;
+        c = 0;
+        r = 0;
+    }
+    fp_store(sigma + j * stride + i, fp_mul(fp_load<FrTag>(dpow + c), fp_load<FrTag>(wpow + r)));
 }
 
 extern "C" int pz_permutation_sigma_dev(pz_ctx* ctx, const uint32_t* d_map_col, const uint32_t* d_map_row, size_t m, uint32_t k,
@@ -211,8 +220,9 @@ extern "C" int pz_permutation_sigma_dev(pz_ctx* ctx, const uint32_t* d_map_col, 
     void *wp, *dp;
     PZCHK(pz_get_pow_table(ctx, omega, n, &wp));
     PZCHK(pz_get_pow_table(ctx, delta, m, &dp));
-    hipLaunchKernelGGL(k_perm_sigma, dim3(pz_div_up(m * n, 256)), dim3(256), 0, ctx->stream, d_map_col, d_map_row, n, m * n,
-                       (const Fr*)wp, (const Fr*)dp, (Fr*)d_sigma, sigma_stride / 4);
+    PZCHK(pz_async_err_init(ctx));
+    hipLaunchKernelGGL(k_perm_sigma, dim3(pz_div_up(m * n, 256)), dim3(256), 0, ctx->stream, d_map_col, d_map_row, n, m * n, (unsigned)m,
+                       (const Fr*)wp, (const Fr*)dp, (Fr*)d_sigma, sigma_stride / 4, ctx->async_err_d);
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
 }

@@ -111,6 +111,114 @@ def hip_partial_points_fn(eng, torch, d_bases, d_scalars, n: int, rank: int, wor
     return fn, bases
 
 
+class EmulatedRank:
+    """Stands in for `torch.distributed` when ONE process plays rank `rank` of `world` over a real process group of one rank (RCCL on
+    the one GPU there is): every collective the caller makes still goes through the real communicator -- with this process's data as
+    the group's only contribution -- and the result is placed in slot `rank` of the gathered tensor, the other slots being what the
+    other emulated ranks contributed when THEIR turn ran (kept in `store`, keyed by call order).  Rank-dependent code -- offsets,
+    ranges, padding -- thus executes on the GPU for every rank, not only for rank 0."""
+
+    class ReduceOp:
+        MAX = "max"
+
+    def __init__(self, real_dist, rank: int, world: int, store: dict):
+        self.real, self.rank, self.world, self.store = real_dist, rank, world, store
+        self.calls = 0
+
+    def get_world_size(self):
+        return self.world
+
+    def all_gather_into_tensor(self, out, inp):
+        import torch
+
+        per = inp.numel()
+        assert out.numel() == self.world * per
+        mine = torch.empty_like(inp)
+        if self.real is not None:
+            self.real.all_gather_into_tensor(mine, inp.contiguous())     # the real collective: a group of one rank
+        else:
+            mine.copy_(inp)
+        slot = self.store.setdefault(self.calls, {})
+        slot[self.rank] = mine.reshape(-1).clone()
+        flat = out.view(-1)
+        flat.zero_()
+        for r, t in slot.items():
+            flat[r * per:(r + 1) * per] = t
+        self.calls += 1
+
+
+def emulate_ranks_msm(eng, torch, real_dist, world: int, log_n: int, split: str, log=lambda s: None):
+    """config c4 with EVERY rank's exact code path run in turn on this GPU (sharded_msm with rank = r of `world`: the `lo * 64` /
+    `lo * 32` offsets of the point split, the window ranges of the window split), each through the real one-rank process group.  Two
+    passes: the first fills the emulated group's slots, in the second every rank sees all partials and folds them.  -> dict with the
+    equality of every rank's folded point with the whole MSM computed in one call."""
+    n = 1 << log_n
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(0x5045)
+
+    def rand_fr(count):
+        x = torch.randint(-(1 << 63), (1 << 63) - 1, (count, 4), dtype=torch.int64, device="cuda", generator=gen)
+        x[:, 3] &= 0x0FFFFFFFFFFFFFFF
+        return x
+
+    ks = rand_fr(n)
+    d_b = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    eng.g1_fixed_base_mul_dev(ks.data_ptr(), n, d_b.data_ptr())
+    eng.sync()
+    d_s = rand_fr(n)
+    whole = eng.load_bases_dev(d_b.data_ptr(), n)
+    d_ref = torch.zeros((1, 12), dtype=torch.int64, device="cuda")
+    eng.msm_dev(whole, d_s.data_ptr(), 1, n, 4 * n, d_ref.data_ptr())
+    eng.sync()
+    ref = eng.g1_normalize(d_ref.cpu().numpy().astype(np.uint64))[0]
+    fold = hip_fold_fn(eng, torch)
+    store: dict = {}
+    equal = []
+    for pass_ in range(2):
+        for r in range(world):
+            em = EmulatedRank(real_dist, r, world, store)
+            if split == "points":
+                pfn, bases = hip_partial_points_fn(eng, torch, d_b, d_s, n, r, world)
+                units = n
+            else:
+                bases, pfn, units = whole, hip_partial_fn(eng, torch, whole, d_s, n), whole.n_windows
+            res = sharded_msm(torch, em, r, world, units, pfn, fold)
+            eng.sync()
+            if pass_ == 1:
+                equal.append(bool(np.array_equal(eng.g1_normalize(res.cpu().numpy().astype(np.uint64))[0], ref)))
+            if split == "points" and bases is not None:
+                bases.free()
+    whole.free()
+    log("msm emulate-ranks %d (%s split, 2^%d): every rank's fold == whole MSM: %s" % (world, split, log_n, all(equal)))
+    return {"world": world, "split": split, "log_n": log_n, "ranks_equal_whole_msm": equal, "all_equal": all(equal),
+            "through_process_group": real_dist is not None}
+
+
+def emulate_ranks_columns(eng, torch, real_dist, world: int, bases, d_cols, n_cols: int, n: int, log=lambda s: None):
+    """column-parallel proving (--parallel columns) with every rank's share computed in turn: rank r commits column_range(n_cols, r,
+    world) and gather_commitments pads / gathers / re-cuts; after the second pass every rank's gathered matrix must equal the
+    commitments of all columns computed in one call."""
+    d_all = torch.zeros((n_cols, 12), dtype=torch.int64, device="cuda")
+    eng.msm_dev(bases, d_cols.data_ptr(), n_cols, n, 4 * n, d_all.data_ptr())
+    eng.sync()
+    ref = eng.g1_normalize(d_all.cpu().numpy().astype(np.uint64))
+    store: dict = {}
+    equal = []
+    for pass_ in range(2):
+        for r in range(world):
+            em = EmulatedRank(real_dist, r, world, store)
+            lo, hi = column_range(n_cols, r, world)
+            share = torch.zeros((hi - lo, 12), dtype=torch.int64, device="cuda")
+            if hi > lo:
+                eng.msm_dev(bases, d_cols.data_ptr() + lo * n * 32, hi - lo, n, 4 * n, share.data_ptr())
+            got = gather_commitments(torch, em, share, n_cols, r, world)
+            eng.sync()
+            if pass_ == 1:
+                equal.append(bool(np.array_equal(eng.g1_normalize(got.cpu().numpy().astype(np.uint64)), ref)))
+    log("columns emulate-ranks %d (%d columns): every rank's gathered commitments == all columns at once: %s" % (world, n_cols, all(equal)))
+    return {"world": world, "n_cols": n_cols, "ranks_equal_single_call": equal, "all_equal": all(equal), "through_process_group": real_dist is not None}
+
+
 def bench_sharded_msm(eng, torch, dist, rank, world, log_n, steps, warmup, barrier, log, split="windows", scalars="uniform"):
     """config c4: one 2^log_n-point MSM, windows (or point ranges) sharded over `world` ranks."""
     n = 1 << log_n

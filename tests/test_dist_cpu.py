@@ -122,3 +122,23 @@ def test_column_parallel_gather_gloo(n_cols):
         p.join(timeout=60)
     for rank, vals in out:
         assert vals == list(range(12 * n_cols)), rank
+
+
+def test_emulated_rank_reassembles_the_group():
+    """EmulatedRank (one process playing every rank in turn): after a full pass every rank's gather holds all contributions in rank
+    order, and gather_commitments re-cuts ragged column shares exactly like a real group of `world` ranks would"""
+    from paillier_halo2_amd.dist import EmulatedRank
+
+    world, n_cols = 5, 13
+    cols = torch.arange(n_cols * 12, dtype=torch.int64).view(n_cols, 12)
+    store = {}
+    for pass_ in range(2):
+        for r in range(world):
+            em = EmulatedRank(None, r, world, store)
+            lo, hi = column_range(n_cols, r, world)
+            got = gather_commitments(torch, em, cols[lo:hi].clone(), n_cols, r, world)
+            part = torch.full((12,), r, dtype=torch.int64)
+            parts = sharded_msm(torch, em, r, world, 16, lambda a, b: part, lambda p: p.clone())
+            if pass_ == 1:
+                assert torch.equal(got, cols), r
+                assert torch.equal(parts, torch.arange(world, dtype=torch.int64).view(world, 1).expand(world, 12)), r

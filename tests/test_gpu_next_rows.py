@@ -621,6 +621,18 @@ def test_full_quotient_of_a_small_circuit(eng, cref):
     eng.sync()
     want = P.quotient_lookup(I(e_A), I(e_S)[0], I(e_Ap), I(e_Sp), I(e_zl), E, lv[0], lv[1], lv[2], beta, gamma, y, want)
     assert _ints(cref, d_h) == want
+    # the same lines added set range by set range (pz_quotient_permutation_part_dev: how the prover streams tiles of extended
+    # columns): head + sets [0, 2), then set [2, 3) with its own column pointers -- bit for bit the single call's h
+    d_hp = torch.zeros((N, 4), dtype=torch.int64, device="cuda")
+    for set_lo, ns in ((0, 2), (2, 1)):
+        c0 = set_lo * chunk
+        cnt = min(m - c0, ns * chunk)
+        eng.quotient_permutation_part_dev(e_val[c0].data_ptr(), 4 * N, e_sig[c0].data_ptr(), 4 * N, e_z.data_ptr(), 4 * N, nsets, set_lo, ns,
+                                          chunk, cnt, set_lo == 0, k + log_e, E, bf + 1, e_l[0].data_ptr(), e_l[1].data_ptr(), e_l[2].data_ptr(),
+                                          _m(cref, beta), _m(cref, gamma), _m(cref, delta), _m(cref, cg), _m(cref, w_ext), _m(cref, y), d_hp.data_ptr())
+    eng.sync()
+    assert _ints(cref, d_hp) == P.quotient_permutation(I(e_val), I(e_sig), I(e_z), chunk, E, bf + 1, lv[0], lv[1], lv[2], beta, gamma, delta, cg,
+                                                       w_ext, y, [0] * N)
     # divide by X^n - 1 and return to coefficients: the quotient is a polynomial of degree <= 3n - 4
     eng.quotient_finish_dev(d_h.data_ptr(), k, log_e, _m(cref, cg), _m(cref, w_ext))
     eng.ntt_dev(d_h.data_ptr(), 1, 4 * N, _m(cref, pow(w_ext, -1, R)), k + log_e, None, _m(cref, pow(N, -1, R)))
@@ -694,6 +706,20 @@ def test_keygen_sigma_and_resident_columns(eng, cref):
     for j in range(m):
         want = [pow(delta, int(mc[j, i]), P.FR_R) * pow(w, int(mr[j, i]), P.FR_R) % P.FR_R for i in range(n)]
         assert cref.fr_mont_to_ints(got[j]) == want, j
+    # an image outside the call's cells (here: column m) is clamped, never dereferenced, and reported at the next synchronisation
+    import paillier_halo2_amd as pz_
+    from paillier_halo2_amd import _lib as lib_
+
+    bad = mc.copy()
+    bad[1, 5] = m
+    d_bad = torch.from_numpy(bad.astype(np.int32)).cuda()
+    d_tmp = torch.zeros((m, n, 4), dtype=torch.int64, device="cuda")
+    eng.permutation_sigma_dev(d_bad.data_ptr(), d_mr.data_ptr(), m, k, cref.fr_ints_to_mont([w])[0], cref.fr_ints_to_mont([delta])[0],
+                              d_tmp.data_ptr(), 4 * n)
+    with pytest.raises(pz_.PzError) as ei:
+        eng.sync()
+    assert ei.value.status == lib_.PZ_ERR_ASYNC
+    eng.sync()       # the flag is cleared by the report
     # keygen of these sigma columns + a selector column: commit, coefficient form, extended coset
     sel = [rng.getrandbits(1) for _ in range(n)]
     cols = np.concatenate([got, cref.fr_ints_to_mont(sel).reshape(1, n, 4)])

@@ -50,3 +50,19 @@ def test_c2_column_parallel_world1_over_rccl():
     forced = _bench(common + ["--force-dist"])
     assert forced["backend"] == "nccl" and forced["rccl_ranks"] == 1
     assert forced["scaling"] == "strong" and forced["value"] > 0
+
+
+@pytest.mark.parametrize("split", ["windows", "points"])
+def test_every_ranks_code_path_through_the_rccl_group_of_one(split):
+    """rank-dependent code (the `lo * 64` / `lo * 32` offsets of the point split, window ranges, padded gather
+    slices of the column split) has only ever seen rank 0 on a GPU.  `--emulate-ranks 8 --force-dist`: one process plays ranks 0..7 in
+    turn, each collective through the NCCL group of one; every rank's folded point equals the whole 2^18-point MSM, every rank's
+    gathered commitment matrix equals all columns committed at once"""
+    out = _bench(["--gpus", "1", "--workload", "msm22", "--log-n", "18", "--msm-split", split, "--emulate-ranks", "8", "--force-dist",
+                  "--parallel", "columns"])
+    assert out["backend"] == "nccl" and out["rccl_ranks"] == 1
+    em = out["emulate_ranks"]
+    assert em["through_process_group"] and em["world"] == 8 and em["split"] == split
+    assert em["ranks_equal_whole_msm"] == [True] * 8
+    ec = out["emulate_ranks_columns"]
+    assert ec["through_process_group"] and ec["ranks_equal_single_call"] == [True] * 8
