@@ -762,10 +762,12 @@ template <int E> __global__ __launch_bounds__(64 * K3_TEAM) void k_pow_mod_chain
             // uniform schedule (pow_mod): multiply step for EVERY bit, then the squaring step
             const unsigned sq_slot = uni ? step_idx + 1 : step_idx, mul_slot = uni ? step_idx : step_idx + 1;
             if (squarer) {
-                // publish sq_i without a fence on the critical path (a __threadfence here -- L2 write-back + wait for every store in
-                // flight, the trace records included -- cost ~2 us per step): the limbs leave as agent-scope stores BEFORE the step,
-                // the counter follows AFTER it, behind a wait that finds them long acknowledged.  The multiplier reads both with
-                // agent-scope loads, the limbs only after it has seen the counter.
+                // publish sq_i: the limbs leave as agent-scope stores BEFORE the step, the counter follows AFTER it with RELEASE
+                // semantics at agent scope (the multiplier reads it and then fences with ACQUIRE: a textbook release / acquire pair, no
+                // reliance on how gfx950 orders relaxed accesses).  Measured (profiles/r05_k3_ab_waitstates_release.txt): the release
+                // costs 0.1 us of a 8.9-us step -- by the time the step's products are done the limb stores have long been
+                // acknowledged, so its write-back / wait finds nothing in flight.  (-DPZ_K3_RELAXED_PUBLISH: round 4's relaxed store
+                // behind s_waitcnt vmcnt(0), for measurement.)
                 if (writer) {
 #pragma unroll
                     for (int e = 0; e < E; ++e) {
@@ -776,8 +778,9 @@ template <int E> __global__ __launch_bounds__(64 * K3_TEAM) void k_pow_mod_chain
                 LD<E> q, r;
                 st |= mul_mod(B, q, r, sq, sq, tmul);
                 if (writer && !D.test_no_publish) {
-#ifdef PZ_K3_RELEASE
-                    // measurement arm: the textbook publish (release = L2 write-back of everything dirty + wait, then the store)
+#ifndef PZ_K3_RELAXED_PUBLISH
+                    // every lane of the writer wave stored limbs: all of them wait for their own stores, lane 0 then releases the counter
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (lane_id() == 0) __hip_atomic_store(D.ready, i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #else
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -240,3 +240,58 @@ def test_wrong_claimed_result_breaks_the_identity(eng, cref, world):
     pr = prover.create_proof(world["pk"], world["witness"](res ^ 2), world["ch"], seed=5, tile=8)
     deg, ident, _ = _verify(cref, world, pr)
     assert not deg and not ident
+
+
+def test_c3_add_circuit_connected_proof_at_size(eng, cref):
+    """BASELINE config c3 as ONE connected proof: c1 * c2 mod n^2 at a 2048-bit key (operands assigned at enc_bits, bench.rs:98-103), k = 15,
+    lookup_bits 14 -- pz_mul_mod -> K4 (kind 1, break-point columns) -> keygen from the product's own structure generator ->
+    create_proof with a hashing transcript -> the verifier's three checks.  (64 limbs: the mul_mod block template at the size the c2
+    circuit tiles 6171 times.)"""
+    import random
+
+    import torch
+    from paillier_halo2_amd import circuit_structure as CS
+    from paillier_halo2_amd import prover
+
+    enc_bits, k, lb = 2048, 15, 14
+    Ln, L, n = enc_bits // 64, 2 * (enc_bits // 64), 1 << 15
+    rng = random.Random(0x5044)
+    nn = P.synth_paillier_inputs(enc_bits, 0x5044)[0]
+    c1, c2 = rng.getrandbits(enc_bits), rng.getrandbits(enc_bits)
+    res = P.paillier_add_native(nn, c1, c2)
+    lim = lambda v, l: cref.int_to_limbs(v, l)
+    q, rem = eng.mul_mod(L, lim(c1, L), lim(c2, L), lim(nn * nn, L))
+    assert cref.limbs_to_int(rem) == res
+    sa = CS.stream_structure("add", enc_bits, 64, lb)
+    cs, starts = CS.columns(sa, k, lb)
+    assert sa.n_cells == eng.circuit_cells(1, Ln, 64, lb)[0] and cs.n_adv >= 2
+    d_starts = torch.from_numpy(starts.astype(np.int64)).cuda()
+    d_steps = torch.from_numpy(np.stack([lim(c1, L), lim(c2, L), q, rem]).astype(np.int64)).cuda().view(1, 4, L)
+    d_mod = torch.from_numpy(lim(nn * nn, L).astype(np.int64)).cuda()
+    cols = torch.zeros((cs.m, n, 4), dtype=torch.int64, device="cuda")
+    inputs = np.concatenate([lim(nn, Ln), lim(0, Ln), lim(c1, Ln), lim(c2, Ln), lim(res, L)])     # n | g (unused by add) | c1 | c2 | res
+    eng.circuit_expand_cols_dev(1, Ln, 64, lb, inputs, d_steps.data_ptr(), 0, 0, d_mod.data_ptr(), cols.data_ptr(), cols[cs.n_adv].data_ptr(),
+                                d_starts.data_ptr(), cs.n_adv, cs.max_rows, cs.max_rows, n)
+    s_tox = rng.randrange(2, R)
+    F = lambda v: cref.fr_ints_to_mont([v % R])[0]
+    d_g = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    d_gl = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    eng.srs_setup_g1_dev(k, F(s_tox), F(P.fr_omega(k)), d_g.data_ptr(), d_gl.data_ptr())
+    eng.sync()
+    bl, bm = eng.load_bases_dev(d_gl.data_ptr(), n), eng.load_bases_dev(d_g.data_ptr(), n)
+    pk = prover.keygen(eng, cs, bl, bm)
+    tr = prover.HashTranscript(b"c3")
+    pr = prover.create_proof(pk, cols, tr, seed=11)
+    ch = tr.challenges()
+    ev = {k_: _ints(cref, v_) for k_, v_ in pr.evals.items()}
+    want = V.expected_h(k, cs.blinding_factors, cs.n_adv, cs.n_lk, prover.CHUNK, ev, ch.beta, ch.gamma, ch.y, ch.x, prover.DELTA)
+    assert pr.h_degree_ok and want == ev["h"][0][0]
+    xn = pow(ch.x, n, R)
+    hc = cref.g1_normalize(cref.msm_g1(cref.fr_ints_to_mont([pow(xn, i, R) for i in range(3)]), pr.commitments["h"]))
+    vk = pk.vk_commitments()
+    com = dict(pr.commitments)
+    com.update(fixed=vk["fixed"], sigma=vk["sigma"], h=[hc])
+    assert V.shplonk_check(cref, prover.query_layout(cs.n_adv, cs.n_lk, cs.m, pk.n_sets), prover.rotation_points(pk.dom, ch.x), com, ev, ch.sh_y,
+                           ch.sh_v, ch.sh_u, pr.commitments["w1"][0], pr.commitments["w2"][0], s_tox)
+    bl.free()
+    bm.free()
