@@ -311,6 +311,11 @@ class ProofWorkload:
                     self.stream_w.wait_event(self.ntt_free_ev[slot])   # ... and so has the transform stream
         var = self.variants[variant]
         nn, g, m, r = var["inputs"]
+        if events and self.drop_edge in ("ready", "ntt_ready"):
+            # negative test only: with the consumer's wait removed the check must see STALE cells; that must not depend on K3 happening
+            # to take longer than the consumer's first reads -- the witness stream idles ~50 ms first
+            with t.cuda.stream(self.stream_w):
+                t.cuda._sleep(100_000_000)
         skip = os.environ.get("PZ_BENCH_SKIP", "")   # debug only ("k3" / "k4"): see consume()
         self._produced = getattr(self, "_produced", 0) + 1
         if self._produced <= 2:

@@ -21,6 +21,14 @@ import time
 import numpy as np
 
 
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class ConnectedWorkload:
     def __init__(self, eng, torch, enc_bits: int, k: int, seed: int, lookup_bits=None, log=lambda s: None, tile: int = 64):
         import random
@@ -72,7 +80,20 @@ class ConnectedWorkload:
         self.keygen_ms = (time.perf_counter() - t2) * 1e3
         torch.cuda.empty_cache()
         self.ws = prover.Workspace(self.pk, tile)
-        self.cols = torch.zeros((self.m, self.n, 4), dtype=torch.int64, device="cuda")
+        # two witness slots: proof i+1's K3 + K4 run on a second context / stream under proof i's advice commitments
+        self.pipeline = os.environ.get("PZ_CONNECTED_PIPELINE", "1") == "1"
+        self.slots = [torch.zeros((self.m, self.n, 4), dtype=torch.int64, device="cuda") for _ in range(2 if self.pipeline else 1)]
+        self.cols = self.slots[0]
+        self.engw, self.stream_w = eng, None
+        if self.pipeline:
+            import paillier_halo2_amd as pz
+
+            self.engw = pz.Engine(eng.device)
+            self.stream_w = torch.cuda.Stream()
+            self.engw.set_stream(self.stream_w.cuda_stream)
+            self.ready_ev = [torch.cuda.Event() for _ in range(2)]
+            self.free_ev = [torch.cuda.Event() for _ in range(2)]
+        self.produced = 0
         self.d_steps = torch.zeros((self.n_steps, 4, self.L), dtype=torch.int64, device="cuda")
         self.d_mod = torch.from_numpy(consts.int_to_limbs(nn * nn, self.L).astype(np.int64)).cuda()
         self.timings = {}
@@ -80,34 +101,61 @@ class ConnectedWorkload:
         self.done = 0
         pk_bytes = sum(t.numel() * 8 for t in (self.pk.fixed_ext, self.pk.sigma_ext, self.pk.fixed_coeff, self.pk.sigma_coeff, self.pk.sigma_lagrange))
         self.memory_gb = {"proving_key_resident": pk_bytes / 1e9, "of_which_extended_forms": (self.pk.fixed_ext.numel() + self.pk.sigma_ext.numel()) * 8 / 1e9,
-                          "grand_products_extended": self.ws.z_ext.numel() * 8 / 1e9, "witness_columns": self.cols.numel() * 8 / 1e9,
+                          "grand_products_extended": self.ws.z_ext.numel() * 8 / 1e9, "witness_columns": sum(t.numel() for t in self.slots) * 8 / 1e9,
                           "torch_allocated_after_setup": torch.cuda.memory_allocated() / 1e9}
 
-    def step(self, timed=True):
-        """one proof: witness, then create_proof with a fresh hashing transcript"""
+    def produce(self, eng=None):
+        """K3 + K4 of the next proof into the next witness slot (on the witness context when pipelining)"""
+        torch = self.torch
+        eng = eng or self.engw
+        i = self.produced
+        slot = i % len(self.slots)
+        nn, g, m, r = self.variants[i % len(self.variants)]
+        cols = self.slots[slot]
+        ctx = torch.cuda.stream(self.stream_w) if self.stream_w is not None else _Null()
+        with ctx:
+            if self.stream_w is not None:
+                self.stream_w.wait_event(self.free_ev[slot])        # the proof that used this slot has finished with it
+            cols.zero_()
+            c, _, _ = eng.paillier_encrypt_dev(self.Ln, nn, g, m, r, self.d_steps.data_ptr(), self.n_steps)      # K3 (returns the ciphertext)
+            inputs = np.concatenate([nn, g, m, r, np.asarray(c[0], dtype=np.uint64)])
+            eng.circuit_expand_cols_dev(0, self.Ln, 64, self.lb, inputs, self.d_steps.data_ptr(), self.ng, self.nr, self.d_mod.data_ptr(),
+                                        cols.data_ptr(), cols[self.A].data_ptr(), self.d_starts.data_ptr(), self.A, self.cs.max_rows,
+                                        self.cs.max_rows, self.n)                                               # K4, break-point layout
+            if self.stream_w is not None:
+                self.ready_ev[slot].record(self.stream_w)
+        self.produced += 1
+
+    def step(self, timed=True, last=False):
+        """one proof: its witness (already under way when pipelining), then create_proof with a fresh hashing transcript"""
         from paillier_halo2_amd import prover
 
-        eng = self.eng
-        nn, g, m, r = self.variants[self.done % len(self.variants)]
+        torch, eng = self.torch, self.eng
         t0 = time.perf_counter()
-        self.cols.zero_()
-        c, _, _ = eng.paillier_encrypt_dev(self.Ln, nn, g, m, r, self.d_steps.data_ptr(), self.n_steps)          # K3 (returns the ciphertext)
-        inputs = np.concatenate([nn, g, m, r, np.asarray(c[0], dtype=np.uint64)])
-        eng.circuit_expand_cols_dev(0, self.Ln, 64, self.lb, inputs, self.d_steps.data_ptr(), self.ng, self.nr, self.d_mod.data_ptr(),
-                                    self.cols.data_ptr(), self.cols[self.A].data_ptr(), self.d_starts.data_ptr(), self.A, self.cs.max_rows,
-                                    self.cs.max_rows, self.n)                                                     # K4, break-point layout
+        if self.produced <= self.done:
+            self.produce()
+        slot = self.done % len(self.slots)
+        cols = self.slots[slot]
+        if self.stream_w is not None:
+            torch.cuda.current_stream().wait_event(self.ready_ev[slot])
         tr = prover.HashTranscript(b"pz-bench-%d" % self.done)
         if timed:
             eng.sync()
             self.timings["witness"] = self.timings.get("witness", 0.0) + (time.perf_counter() - t0) * 1e3
-        pr = prover.create_proof(self.pk, self.cols, tr, seed=1000 + self.done, ws=self.ws, timings=self.timings if timed else None)
+        hooks = {}
+        if self.pipeline and not last:
+            hooks["after_advice_launch"] = self.produce
+        pr = prover.create_proof(self.pk, cols, tr, seed=1000 + self.done, ws=self.ws, timings=self.timings if timed else None, hooks=hooks)
+        if self.stream_w is not None:
+            self.free_ev[slot].record(torch.cuda.current_stream())
         self.last = (pr, tr.challenges(), self.done % len(self.variants))
         self.done += 1
         return pr
 
     def run(self, steps, timed=True):
-        for _ in range(steps):
-            self.step(timed)
+        for i in range(steps):
+            self.step(timed, last=(i == steps - 1))
+        self.torch.cuda.synchronize()
 
     def phase_ms(self, steps):
         return {k_: v_ / max(1, steps) for k_, v_ in self.timings.items()}
@@ -154,6 +202,9 @@ class ConnectedWorkload:
     def release(self):
         for b in (self.bl, self.bm):
             b.free()
-        for name in ("pk", "ws", "cols", "d_steps", "last"):
+        self.torch.cuda.synchronize()
+        if self.engw is not self.eng:
+            self.engw.close()
+        for name in ("pk", "ws", "cols", "slots", "d_steps", "last"):
             setattr(self, name, None)
         self.torch.cuda.empty_cache()

@@ -475,8 +475,9 @@ def columns(sa: StructureArrays, k: int, lb: int, max_rows: Optional[int] = None
     del order, members
     first = torch.ones_like(r_m, dtype=torch.bool)
     first[1:] = r_m[1:] != r_m[:-1]
-    idx = torch.arange(r_m.shape[0], dtype=torch.int64, device=dev)
-    start_of = torch.cummax(torch.where(first, idx, torch.zeros_like(idx)), 0)[0]
+    firsts = torch.nonzero(first).view(-1)                 # index of every class's first member ...
+    start_of = firsts[torch.cumsum(first.to(torch.int64), 0) - 1]   # ... broadcast over its members (a cumsum, not torch.cummax: that
+    #                                                                   scan-with-indices kernel took 0.9 s on 2 x 10^8 elements)
     nxt_p = torch.empty_like(p_m)
     nxt_p[:-1] = p_m[1:]
     last = torch.ones_like(first)

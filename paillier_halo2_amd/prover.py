@@ -354,6 +354,8 @@ def create_proof(pk: ProvingKey, cols, tr, seed: int = 0, tile: int = 64, hooks=
     if "advice" in hooks:
         hooks["advice"](cols)
     c_adv = commit(bl, cols, W, 4 * n)
+    if "after_advice_launch" in hooks:      # the caller's chance to queue independent work (the NEXT proof's witness on another context)
+        hooks["after_advice_launch"]()      # while this proof's largest commitment batch runs and before the host waits for it
     tr.absorb_points(eng, c_adv)
     tr.squeeze("theta")
     phase("advice_commit")
