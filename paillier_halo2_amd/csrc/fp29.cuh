@@ -100,6 +100,16 @@ template <class T> __device__ __host__ __forceinline__ constexpr u32 f29_kp_limb
     }
     return out;
 }
+// limb i of pbar = 2^261 - p in strict 29-bit limbs (f29_mulc subtracts q * p as q * pbar modulo 2^261)
+template <class T> __device__ __host__ __forceinline__ constexpr u32 f29_pbar_limb(int i) {
+    u32 borrow = 0, out = 0;
+    for (int j = 0; j <= i; ++j) {
+        const u32 pj = P29<T>::P(j) + borrow;          // <= 2^29
+        out = (0u - pj) & F29_MASK;
+        borrow = pj != 0 ? 1u : 0u;
+    }
+    return out;
+}
 // K*p spelled with low limbs >= 2^LB: limb_i + 2^LB for i < 8, minus the 2^(LB-29) units borrowed by the limb below
 template <class T, unsigned K, unsigned LB> __device__ __forceinline__ constexpr u32 f29_spread(int i) {
     return f29_kp_limb<T>(K, i) + (i < 8 ? (1u << LB) : 0u) - (i > 0 ? (1u << (LB - 29)) : 0u);
@@ -199,12 +209,14 @@ template <unsigned J, class T> __device__ __forceinline__ F29<T> f29_canon(const
     return r;
 }
 
-// ---- canonicalisation through a quotient estimate (a value below 32p, loose limbs): the top limb after the carry chain gives
+// ---- canonicalisation through a quotient estimate (a value below 64p, loose limbs; the estimate's multiplier is exact for
+// top limbs below 2^31): the top limb after the carry chain gives
 // q = floor(top / (p_top + 1)) with q <= floor(V / p) <= q + 1 (V / p - top / (p_top + 1) < 33 / p_top ~ 1e-5), so V - q p lies in
 // [0, 2p) and ONE conditional subtraction finishes -- ~125 cheap instructions instead of the ~250 of f29_canon<4>'s five-step
 // ladder.  q p comes from a 33-row table in LDS (f29_qtab_fill; a row per q, strict limbs).  p_top = p >> 232 = 0x30644e for
 // BOTH BN254 fields; 0xa948e6d8 = floor(2^53 / (p_top + 1)) + 1 makes (top * M) >> 53 the exact floor for top < 2^27.
-#define F29_QTAB_WORDS (33u * 9u)
+#define F29_QTAB_ROWS 65u   // values below 64p (round 5: the constant-operand products leave < 3p, a pair of stages adds up to 8p)
+#define F29_QTAB_WORDS (F29_QTAB_ROWS * 9u)
 template <class T> __device__ __forceinline__ void f29_qtab_fill(u32* tab) {   // every thread of the workgroup; __syncthreads() afterwards
     static_assert((P29<T>::P(8) == 0x30644eu), "quotient-estimate constant assumes p >> 232 == 0x30644e");
     for (unsigned t = threadIdx.x; t < F29_QTAB_WORDS; t += blockDim.x) {
@@ -376,4 +388,49 @@ template <class T> __device__ __noinline__ F29<T> f29_inv(const F29<T>& a) {
         if ((w >> (i & 31)) & 1) acc = f29_mul(acc, a);
     }
     return acc;
+}
+
+// A CONSTANT as f29_mulc takes it: c (the plain integer below p) and cq = floor(c * 2^261 / p), 9 + 9 limbs.  Built ONCE per table entry
+// from the Montgomery form t = c * 2^256 mod p the power tables hold (binary long division: 261 shift / compare / subtract steps).
+struct C18 {
+    u32 w[9], q[9];
+};
+template <class T> __device__ inline void f29_cpair_from_mont(const Fp<T>& t, u32 out[18]) {
+    const Fp<T> c = fp_from_mont(t);          // canonical plain value below p
+    u64 rem[4], P[4], Q[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+        rem[i] = (u64)c.v[2 * i] | ((u64)c.v[2 * i + 1] << 32);
+        P[i] = (u64)FieldParams<T>::P(2 * i) | ((u64)FieldParams<T>::P(2 * i + 1) << 32);
+    }
+    for (int b = 0; b < 261; ++b) {
+        // rem < p < 2^254: 2 rem fits 256 bits
+        for (int i = 3; i > 0; --i) rem[i] = (rem[i] << 1) | (rem[i - 1] >> 63);
+        rem[0] <<= 1;
+        for (int i = 4; i > 0; --i) Q[i] = (Q[i] << 1) | (Q[i - 1] >> 63);
+        Q[0] <<= 1;
+        bool ge = true;
+        for (int i = 3; i >= 0; --i)
+            if (rem[i] != P[i]) {
+                ge = rem[i] > P[i];
+                break;
+            }
+        if (ge) {
+            u64 br = 0;
+            for (int i = 0; i < 4; ++i) {
+                const u64 x = rem[i] - P[i], b1 = rem[i] < P[i], y = x - br;
+                br = b1 | (x < br);
+                rem[i] = y;
+            }
+            Q[0] |= 1;
+        }
+    }
+    const F29<T> cl = f29_unpack<T>(c.v);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out[i] = cl.v[i];
+    for (int i = 0; i < 9; ++i) {
+        const int bit = 29 * i, j = bit >> 6, o = bit & 63;
+        u64 x = Q[j] >> o;
+        if (o > 35 && j + 1 < 5) x |= Q[j + 1] << (64 - o);
+        out[9 + i] = (u32)x & F29_MASK;
+    }
 }

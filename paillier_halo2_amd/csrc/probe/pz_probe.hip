@@ -104,6 +104,20 @@ template <int SQR> __global__ void k_ubench_f29(Fq* out, unsigned iters) {
     }
     f29_store<1>(out + (size_t)blockIdx.x * blockDim.x + threadIdx.x, f29_mul(x, y));
 }
+// variant 5: the constant-operand product f29_mulc (Barrett / Shoup: 143 multiplier instructions), the constants held in registers as a
+// kernel keeps a loaded table entry; same dependency shape as variant 3 (two chains, each product waits for the previous one)
+__global__ void k_ubench_f29c(Fq* out, unsigned iters) {
+    Fq x0 = fp_one<FqTag>(), y0 = fp_one<FqTag>();
+    x0.v[0] ^= threadIdx.x;
+    y0.v[1] ^= blockIdx.x;
+    F29<FqTag> x = f29_from_fp(x0), y = f29_from_fp(y0), w = f29_from_fp(y0), wq = f29_from_fp(x0);
+    w.v[8] &= 0xffffu;
+    for (unsigned i = 0; i < iters; ++i) {
+        x = f29_mulc(x, w, wq);
+        y = f29_mulc(y, wq, w);
+    }
+    f29_store<1>(out + (size_t)blockIdx.x * blockDim.x + threadIdx.x, f29_mul(x, y));
+}
 // one product of the probe, for its correctness check: out = a * b * 2^-261 mod p as a 256-bit integer below 2p
 __global__ void k_fq_mul29(const u32* a, const u32* b, u32* out) {
     u32 aw[8], bw[8], rw[8];
@@ -161,7 +175,8 @@ extern "C" int pzp_ubench_mad_indep(int device, uint32_t blocks, uint32_t iters,
 // 4 = f29_sqr
 extern "C" int pzp_ubench_fqmul_variant(int device, int variant, uint32_t blocks, uint32_t iters, double* ms) {
     void* d = probe_buf(device, (size_t)blocks * 256 * 32);
-    if (!d || !ms || !blocks || variant < 0 || variant > 4) return -1;
+    if (!d || !ms || !blocks || variant < 0 || variant > 5) return -1;
+    if (variant == 5) return timed_launch(device, ms, k_ubench_f29c, dim3(blocks), dim3(256), (Fq*)d, (unsigned)iters);
     if (variant == 1) return timed_launch(device, ms, k_ubench_fqmul_nowait, dim3(blocks), dim3(256), (Fq*)d, (unsigned)iters);
     if (variant == 3) return timed_launch(device, ms, k_ubench_f29<0>, dim3(blocks), dim3(256), (Fq*)d, (unsigned)iters);
     if (variant == 4) return timed_launch(device, ms, k_ubench_f29<1>, dim3(blocks), dim3(256), (Fq*)d, (unsigned)iters);
@@ -210,11 +225,13 @@ template <class T> __global__ void k_f29_ops(int op, const u32* __restrict__ in,
         r.v[8] = 0;
     } else if (op == 7) {
         r = f29_canon_q(x[0], qtab);
+    } else if (op == 8) {
+        r = f29_mulc(x[0], x[1], x[2]);     // a, w, wq = floor(w * 2^261 / p)
     }
     f29_store_raw(out + i * 9, r);
 }
 extern "C" int pzp_f29_ops(int device, int field, int op, const uint32_t* in, uint32_t k, size_t count, uint32_t* out) {
-    if (!in || !out || !count || k == 0 || k > 8 || op < 0 || op > 7 || (field != 0 && field != 1)) return -1;
+    if (!in || !out || !count || k == 0 || k > 8 || op < 0 || op > 8 || (field != 0 && field != 1)) return -1;
     const size_t in_b = count * k * 36, out_b = count * 36;
     void* d = probe_buf(device, in_b + out_b);
     if (!d) return -1;

@@ -28,13 +28,16 @@ __global__ void k_pow_table(Fr base, Fr init, Fr* table, size_t n, unsigned ch) 
     }
 }
 
-// 256-bit integers -> 9 x 29-bit limbs (the form the K2 kernels multiply by: no unpack per use)
+// Montgomery table entries -> the constant pairs the K2 kernels multiply by (f29_mulc, fp29.cuh): 18 words per entry, the plain value
+// c and cq = floor(c * 2^261 / p) as 9 x 29-bit limbs each -- no unpack per use, and the product by a known constant costs 143
+// multiplier instructions instead of a Montgomery product's 180
 __global__ void k_raw29(const Fr* __restrict__ src, u32* __restrict__ dst, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const F29<FrTag> x = f29_load<FrTag>(src + i);
+    u32 o[18];
+    f29_cpair_from_mont(fp_load<FrTag>(src + i), o);
 #pragma unroll
-    for (int j = 0; j < 9; ++j) dst[9 * i + j] = x.v[j];
+    for (int j = 0; j < 18; ++j) dst[18 * i + j] = o[j];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -352,7 +355,7 @@ int pz_get_pow_table_raw(pz_ctx* ctx, const uint64_t base[4], size_t n, void** d
     for (auto& t : ctx->pow_tables)
         if (t.d == d) {
             if (!t.d_raw) {
-                HIPCHK(ctx, hipMalloc(&t.d_raw, t.cap * 36));
+                HIPCHK(ctx, hipMalloc(&t.d_raw, t.cap * 72));
                 t.raw_valid = false;
             }
             if (!t.raw_valid) {

@@ -19,14 +19,14 @@ struct pz_pow_table {   // cached table init * base^i, i < n  (twiddles omega^i,
     size_t n;
     size_t cap;         // entries the buffer holds (>= n: an evicted table's buffer is reused)
     void* d;            // cap x 32 B
-    void* d_raw = nullptr;   // the same entries as 9 x 29-bit limbs (36 B each), built on demand for the K2 kernels (no unpack per use)
+    void* d_raw = nullptr;   // the same entries as constant pairs (c, floor(c 2^261 / p)), 18 x 29-bit limbs = 72 B each, built on demand for the K2 kernels
     bool raw_valid = false;
     uint64_t stamp;     // last use (LRU: per-proof challenge points would otherwise grow the cache without bound)
 };
 
 struct pz_ext_table {   // packed [2^e][n] pre-scale tables of pz_ntt_fr_extend_dev, keyed by its parameters
     std::vector<uint64_t> key;
-    void* d;       // 9 x 29-bit limbs per entry (36 B): [2^e][n][9] u32
+    void* d;       // constant pairs, 72 B per entry: [2^e][n][18] u32
 };
 
 struct pz_wsbuf {

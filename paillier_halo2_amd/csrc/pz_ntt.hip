@@ -38,22 +38,27 @@ extern __shared__ __attribute__((aligned(16))) unsigned char pz_smem[];
 
 
 // ------------------------------------------------------------------------------------------------
-// The transforms on the reduced-radix field of fp29.cuh (9 x 29-bit limbs).  Data stays in the ABI's 2^256
-// Montgomery domain from load to store (a Montgomery product by a table constant kept as c * 2^261 does not change
-// its other operand's domain), so only the twiddle / pre-scale tables differ from the 32-bit path: they are the same
-// power tables with their first entry multiplied by 32.
+// The transforms on the reduced-radix field of fp29.cuh (9 x 29-bit limbs).  Data stays in the ABI's 2^256 Montgomery domain from
+// load to store.  [round 5] EVERY product of a transform is by a constant known in advance (twiddle, coset power, scale), so the
+// tables hold constant PAIRS (c, floor(c 2^261 / p): 72 B per entry, pz_get_pow_table_raw) and the kernels multiply with f29_mulc
+// (Barrett / Shoup with a precomputed quotient: 143 multiplier instructions instead of the Montgomery product's 180; x * c in x's own
+// domain, no Montgomery factor).
 //   LDS tile: 9 words per element (36 B, odd word stride: conflict-free for consecutive elements).
-//   Tile elements stay UNCARRIED between stages (limbs < 2^31.3: f29_mul takes 2^31.4 x 2^29 limbs); only the two
-//   operands of a radix-4 group that are added without being multiplied take one parallel carry round.  Values grow
-//   by at most 4p per pair of stages (one un-multiplied path, two subtractions with +2p each): below 21p after 9
-//   stages, far from 2^261, so nothing is reduced inside a pass.  A pass ends in a Montgomery
-//   product wherever the algorithm has one (inter-pass twiddle, post scale: value < 2p, one conditional
-//   subtraction before the store) and in the conditional-subtraction ladder from 32p otherwise.
+//   Tile elements stay UNCARRIED between stages (limbs < 2^31.3: f29_mulc takes 2^31.8 x 2^29 limbs); only the two
+//   operands of a radix-4 group that are added without being multiplied take one parallel carry round.  A product is tight and
+//   below 3p, a subtraction adds 4p: values grow by at most 8p per pair of stages (14p in the first pair, whose operands come
+//   straight from the load) -- below 46p after 9 stages, far from 2^261 = 169p, so nothing is reduced inside a pass.  A pass ends in
+//   a product wherever the algorithm has one (inter-pass twiddle, post scale: below 3p) and in the quotient-estimate
+//   canonicalisation (values below 64p) otherwise.
 // ------------------------------------------------------------------------------------------------
 typedef F29<FrTag> Fr29;
+#ifndef NTT_WAVES
+#define NTT_WAVES 4   // waves per SIMD the kernels are compiled for (128 VGPRs): with the 18-limb constant pairs hipcc otherwise takes 135
+#endif
+#define NTT_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTT_WAVES, NTT_WAVES)))
 
 #ifndef NTT_LB
-#define NTT_LB 4u    // elements a thread loads per batch of outstanding global loads
+#define NTT_LB 2u    // elements a thread loads per batch of outstanding global loads (4 before the 72-byte constant pairs: the batch held 4 x 18 + 4 x 8 registers; measured 48.6 vs 49.3 us per polynomial)
 #endif
 // a tile element to HBM.  CANON: the ABI's canonical representative (value below 2^(J+1) p).  Otherwise the packed 256-bit
 // integer as it is (tight limbs, below 2p after a product): the ping-pong buffer between two passes never crosses the ABI,
@@ -99,34 +104,32 @@ __device__ __forceinline__ void lds29_put(u32* sm, unsigned e, const Fr29& a) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) p[i] = a.v[i];
 }
-// entry idx of a raw table (9 x 29-bit limbs per entry, 36 B: pz_get_pow_table_raw): no unpacking
-__device__ __forceinline__ Fr29 raw9_get(const u32* __restrict__ tab, size_t idx) {
-    Fr29 r;
-    const u32* p = tab + idx * 9u;
+// entry idx of a constant-pair table (18 x 29-bit limbs per entry, 72 B: pz_get_pow_table_raw): no unpacking
+__device__ __forceinline__ C18 raw9_load(const u32* __restrict__ tab, size_t idx) {
+    C18 r;
+    const u32* p = tab + idx * 18u;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) r.v[i] = p[i];
+    for (int i = 0; i < 9; ++i) r.w[i] = p[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.q[i] = p[9 + i];
     return r;
 }
-struct Raw9 {
-    u32 v[9];
-};
-__device__ __forceinline__ Raw9 raw9_load(const u32* __restrict__ tab, size_t idx) {
-    Raw9 r;
-    const u32* p = tab + idx * 9u;
+typedef C18 Raw9;
+// x * c (mod p, below 3p, tight) for a table constant
+__device__ __forceinline__ Fr29 mulc(const Fr29& x, const C18& c) {
+    Fr29 w, q;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) r.v[i] = p[i];
-    return r;
+    for (int i = 0; i < 9; ++i) {
+        w.v[i] = c.w[i];
+        q.v[i] = c.q[i];
+    }
+    return f29_mulc(x, w, q);
 }
-__device__ __forceinline__ Fr29 raw9_fr(const Raw9& x) {
-    Fr29 r;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) r.v[i] = x.v[i];
-    return r;
-}
-// radix-2 butterfly on carried inputs (u any value, v the already multiplied, tight operand below 2p)
+__device__ __forceinline__ Fr29 mulc(const Fr29& x, const u32* __restrict__ tab, size_t idx) { return mulc(x, raw9_load(tab, idx)); }
+// radix-2 butterfly on carried inputs (u any value, v the already multiplied, tight operand below 3p)
 __device__ __forceinline__ void bf29(const Fr29& u, const Fr29& v, Fr29& sum, Fr29& diff) {
     sum = f29_add(u, v);
-    diff = f29_sub<2, 29>(u, v);
+    diff = f29_sub<4, 29>(u, v);
 }
 
 // logR radix-2 DIT stages over an LDS tile holding T independent transforms, taken TWO STAGES AT A TIME: a thread
@@ -166,27 +169,27 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
                 // parallel carry round each
                 a0 = f29_carry(a0);
                 a2 = f29_carry(a2);
-                const Fr29 w = stw ? raw9_get(stw, (h - 1u) + pos) : raw9_get(tw, pos * (n >> (s + 1)));
-                a1 = f29_mul(a1, w);
-                a3 = f29_mul(a3, w);
+                const C18 w = stw ? raw9_load(stw, (h - 1u) + pos) : raw9_load(tw, pos * (n >> (s + 1)));
+                a1 = mulc(a1, w);
+                a3 = mulc(a3, w);
                 bf29(a0, a1, b0, b1);
                 bf29(a2, a3, b2, b3);
-                b2 = f29_mul(b2, stw ? raw9_get(stw, (2u * h - 1u) + pos) : raw9_get(tw, pos * (n >> (s + 2))));
-                b3 = f29_mul(b3, stw ? raw9_get(stw, (2u * h - 1u) + pos + h) : raw9_get(tw, (pos + h) * (n >> (s + 2))));
+                b2 = stw ? mulc(b2, stw, (2u * h - 1u) + pos) : mulc(b2, tw, pos * (n >> (s + 2)));
+                b3 = stw ? mulc(b3, stw, (2u * h - 1u) + pos + h) : mulc(b3, tw, (pos + h) * (n >> (s + 2)));
                 bf29(b0, b2, o0, o2);
             } else {
-                // stages 0 + 1: operands straight from the load (tight, value < 2p); the first layer's twiddles and the
+                // stages 0 + 1: operands straight from the load (tight, value < 3p); the first layer's twiddles and the
                 // second layer's even twiddle are 1
                 b0 = f29_add(a0, a1);
-                b1 = f29_sub<2, 29>(a0, a1);
-                b2 = f29_add(a2, a3);          // un-multiplied: limbs < 2^30, value < 4p -> subtrahend of f29_sub<4, 30>
-                b3 = f29_sub<2, 29>(a2, a3);
-                b3 = f29_mul(b3, raw9_get(tw, (pos + h) * (n >> (s + 2))));
+                b1 = f29_sub<4, 29>(a0, a1);
+                b2 = f29_add(a2, a3);          // un-multiplied: limbs < 2^30, value < 6p -> subtrahend of f29_sub<8, 30>
+                b3 = f29_sub<4, 29>(a2, a3);
+                b3 = mulc(b3, tw, (pos + h) * (n >> (s + 2)));
                 o0 = f29_add(b0, b2);
-                o2 = f29_sub<4, 30>(b0, b2);
+                o2 = f29_sub<8, 30>(b0, b2);
             }
             bf29(b1, b3, o1, o3);
-            // outputs stay uncarried: limbs < 2^31.3, values grow by at most 4p per pair of stages
+            // outputs stay uncarried: limbs < 2^31.3, values grow by at most 8p per pair of stages (14p in the first)
             lds29_put(sm, e0, o0);
             lds29_put(sm, e0 + 2 * dh, o2);
             lds29_put(sm, e0 + dh, o1);
@@ -214,11 +217,11 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
             Fr29 o0, o1;
             if (s || stw) {
                 u = f29_carry(u);
-                v = f29_mul(v, stw ? raw9_get(stw, (half - 1u) + pos) : raw9_get(tw, pos * (n >> (s + 1))));
+                v = stw ? mulc(v, stw, (half - 1u) + pos) : mulc(v, tw, pos * (n >> (s + 1)));
                 bf29(u, v, o0, o1);
-            } else {  // a single stage (logR == 1): operands straight from the load (tight, < 2p)
+            } else {  // a single stage (logR == 1): operands straight from the load (tight, < 3p)
                 o0 = f29_add(u, v);
-                o1 = f29_sub<2, 29>(u, v);
+                o1 = f29_sub<4, 29>(u, v);
             }
             lds29_put(sm, e0, o0);
             lds29_put(sm, e1, o1);
@@ -232,7 +235,7 @@ __device__ __forceinline__ void lds_dit29(u32* sm, unsigned logR, unsigned T, un
 // pass): no product at the load, stage twiddles from stw0 (per coset, (1 << logR) entries apart), and pre0 holds the fused
 // inter-pass table c^col * omega^(col * k) indexed [k * lo + col] instead of the pre-scale table
 template <int PRE>
-__global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, size_t in_stride, size_t out_stride,
+__global__ NTT_BOUNDS void k_ntt_strided29(const Fr* in, Fr* out, size_t in_stride, size_t out_stride,
                                                        NttPass p, const u32* __restrict__ tw,
                                                        const u32* __restrict__ pre0, unsigned n_r, size_t pre_r_stride,
                                                        size_t out_r_stride, const u32* __restrict__ stw0,
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, si
     // (one per coset) into n_r outputs; the tile is re-read from L2, not from HBM, and one launch does the work of n_r
     Fr* const dst0 = dst;
     for (unsigned rr = 0; rr < n_r; ++rr) {
-    const u32* __restrict__ pre = pre0 + (size_t)rr * pre_r_stride * 9u;
+    const u32* __restrict__ pre = pre0 + (size_t)rr * pre_r_stride * 18u;
     dst = dst0 + (size_t)rr * out_r_stride;
     if (rr) __syncthreads();   // the previous coset's stores have read the tile
     for (unsigned i0 = 0; i0 < nelem; i0 += NTT_LB * 256u) {
@@ -273,13 +276,13 @@ __global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, si
             const unsigned idx = i0 + k * 256u + threadIdx.x;
             if (idx < nelem) {
                 Fr29 x = f29_from_fp(raw[k]);
-                if (PRE == 1) x = f29_mul(x, raw9_fr(praw[k]));
+                if (PRE == 1) x = mulc(x, praw[k]);
                 lds29_put(sm, bitrev32(idx >> logT, p.logR) * T + (idx & (T - 1)), x);
             }
         }
     }
     __syncthreads();
-    lds_dit29(sm, p.logR, T, T, 1, true, tw, p.n, PRE == 2 ? stw0 + (size_t)rr * R * 9u : nullptr);
+    lds_dit29(sm, p.logR, T, T, 1, true, tw, p.n, PRE == 2 ? stw0 + (size_t)rr * R * 18u : nullptr);
     for (unsigned i0 = 0; i0 < nelem; i0 += NTT_LB * 256u) {
         Raw9 traw[NTT_LB];
 #pragma unroll
@@ -293,8 +296,8 @@ __global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, si
             const unsigned idx = i0 + k * 256u + threadIdx.x;
             if (idx < nelem) {
                 const unsigned kk = idx >> logT, t = idx & (T - 1);
-                // always through the product (tw[0] = 1): the result is below 2p whatever the stages accumulated
-                const Fr29 x = f29_mul(lds29_get(sm, kk * T + t), raw9_fr(traw[k]));
+                // always through the product (tw[0] = 1): the result is below 3p (< 2^256: it packs) whatever the stages accumulated
+                const Fr29 x = mulc(lds29_get(sm, kk * T + t), traw[k]);
                 ntt_store<false, 1>(dst + base + (size_t)kk * p.lo + t, x);
             }
         }
@@ -304,9 +307,9 @@ __global__ __launch_bounds__(256) void k_ntt_strided29(const Fr* in, Fr* out, si
 
 // final pass.  grid.x = n2 * (n1 / T), grid.y = column
 template <bool PRE>
-__global__ __launch_bounds__(256) void k_ntt_final29(const Fr* in, Fr* out, size_t in_stride, size_t out_stride,
+__global__ NTT_BOUNDS void k_ntt_final29(const Fr* in, Fr* out, size_t in_stride, size_t out_stride,
                                                      NttPass p, const u32* __restrict__ tw, const u32* __restrict__ pre,
-                                                     Fr post, int has_post) {
+                                                     C18 post, int has_post) {
     u32* sm = reinterpret_cast<u32*>(pz_smem);
     const unsigned R = 1u << p.logR, T = p.T;
     const unsigned logT = 31u - (unsigned)__builtin_clz(T);
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(256) void k_ntt_final29(const Fr* in, Fr* out, size
             const unsigned idx = i0 + k * 256u + threadIdx.x;
             if (idx < nelem) {
                 Fr29 x = f29_from_fp(raw[k]);
-                if (PRE) x = f29_mul(x, raw9_fr(praw[k]));
+                if (PRE) x = mulc(x, praw[k]);
                 lds29_put(sm, (idx >> p.logR) * R + bitrev32(idx & (R - 1), p.logR), x);
             }
         }
@@ -340,12 +343,11 @@ __global__ __launch_bounds__(256) void k_ntt_final29(const Fr* in, Fr* out, size
     if (!has_post) f29_qtab_fill<FrTag>(qtab);   // before the barrier that publishes the tile: lds_dit29 has none when logR == 0
     __syncthreads();
     lds_dit29(sm, p.logR, T, 1, R, false, tw, p.n);
-    const Fr29 post29 = f29_from_fp(post);
     for (unsigned idx = threadIdx.x; idx < R * T; idx += blockDim.x) {
         unsigned k = idx >> logT, r = idx & (T - 1);
         Fr29 x = lds29_get(sm, r * R + k);
         Fr* o = dst + (k1_0 + r) + p.n1 * k2 + p.hi * (size_t)k;
-        if (has_post) f29_store_product(o, f29_mul(x, post29));   // a product: strict limbs, below 2p
+        if (has_post) f29_store<1>(o, mulc(x, post));   // a product: strict limbs, below 3p
         else ntt_store_q(o, x, qtab);
     }
 }
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(256) void k_ntt_final29(const Fr* in, Fr* out, size
 // as out[2^e * q + r].  The strided pass has already run per r (inputs at in + r * in_r_stride); this
 // block finishes T rows for ALL r at once so every store is a full T * 2^e * 32-byte run.
 template <bool PRE>
-__global__ __launch_bounds__(256) void k_ntt_final_ext29(const Fr* in, Fr* out, size_t in_stride, size_t in_r_stride,
+__global__ NTT_BOUNDS void k_ntt_final_ext29(const Fr* in, Fr* out, size_t in_stride, size_t in_r_stride,
                                                          size_t out_stride, NttPass p, unsigned log_e,
                                                          const u32* __restrict__ tw, const u32* __restrict__ pre,
                                                          size_t pre_r_stride) {
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(256) void k_ntt_final_ext29(const Fr* in, Fr* out, 
             if (idx < nelem) {
                 const unsigned j = idx & (R - 1), rr = (idx >> p.logR) & (T - 1), r = idx >> (p.logR + logT);
                 Fr29 x = f29_from_fp(raw[k]);
-                if (PRE) x = f29_mul(x, raw9_fr(praw[k]));
+                if (PRE) x = mulc(x, praw[k]);
                 lds29_put(sm, (r * T + rr) * R + bitrev32(j, p.logR), x);
             }
         }
@@ -472,17 +474,69 @@ static int launch_strided(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t 
     HIPCHK(ctx, hipGetLastError());
     return PZ_OK;
 }
+// host: a Montgomery constant (c * 2^256 mod r, canonical) -> the pair (c, floor(c 2^261 / r)) f29_mulc takes (the device tables get
+// theirs from f29_cpair_from_mont; this is the same arithmetic for the one scalar a launch passes by value)
+static void host_cpair(const uint64_t mont[4], C18& out) {
+    static const uint64_t R_[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+    auto ge = [&](const uint64_t a[4]) {
+        for (int i = 3; i >= 0; --i)
+            if (a[i] != R_[i]) return a[i] > R_[i];
+        return true;
+    };
+    auto sub = [&](uint64_t a[4]) {
+        unsigned __int128 br = 0;
+        for (int i = 0; i < 4; ++i) {
+            const unsigned __int128 d = (unsigned __int128)a[i] - R_[i] - br;
+            a[i] = (uint64_t)d;
+            br = (d >> 64) & 1;
+        }
+    };
+    // c = mont * 2^-256 mod r: 256 halvings (x odd: (x + r) / 2)
+    uint64_t c[4] = {mont[0], mont[1], mont[2], mont[3]};
+    for (int b = 0; b < 256; ++b) {
+        uint64_t top = 0;
+        if (c[0] & 1) {
+            unsigned __int128 cy = 0;
+            for (int i = 0; i < 4; ++i) {
+                const unsigned __int128 t = (unsigned __int128)c[i] + R_[i] + cy;
+                c[i] = (uint64_t)t;
+                cy = t >> 64;
+            }
+            top = (uint64_t)cy;
+        }
+        for (int i = 0; i < 3; ++i) c[i] = (c[i] >> 1) | (c[i + 1] << 63);
+        c[3] = (c[3] >> 1) | (top << 63);
+    }
+    uint64_t rem[4] = {c[0], c[1], c[2], c[3]}, Q[5] = {0, 0, 0, 0, 0};
+    for (int b = 0; b < 261; ++b) {
+        for (int i = 3; i > 0; --i) rem[i] = (rem[i] << 1) | (rem[i - 1] >> 63);
+        rem[0] <<= 1;
+        for (int i = 4; i > 0; --i) Q[i] = (Q[i] << 1) | (Q[i - 1] >> 63);
+        Q[0] <<= 1;
+        if (ge(rem)) {
+            sub(rem);
+            Q[0] |= 1;
+        }
+    }
+    auto limbs = [](const uint64_t* x, int words, u32* o) {
+        for (int i = 0; i < 9; ++i) {
+            const int bit = 29 * i, j = bit >> 6, sh = bit & 63;
+            uint64_t v = j < words ? x[j] >> sh : 0;
+            if (sh > 35 && j + 1 < words) v |= x[j + 1] << (64 - sh);
+            o[i] = (u32)v & F29_MASK;
+        }
+    };
+    limbs(c, 4, out.w);
+    limbs(Q, 5, out.q);
+}
+
 static int launch_final(pz_ctx* ctx, const Fr* in, Fr* out, size_t is, size_t os, size_t ncols, NttPass p,
                         const u32* tw, const u32* pre, const uint64_t* post_scale) {
     size_t blocks = p.n2 * (p.n1 / p.T);
     size_t lds = ntt29_lds_bytes(((size_t)1 << p.logR) * p.T) + F29_QTAB_WORDS * 4;
-    Fr post;
+    C18 post;
     memset(&post, 0, sizeof post);
-    if (post_scale) {   // into the 261-domain
-        uint64_t ps[4];
-        fr_times32(post_scale, ps);
-        memcpy(post.v, ps, 32);
-    }
+    if (post_scale) host_cpair(post_scale, post);
     p.swap = (ncols > 1 && blocks <= 65535) ? 1u : 0u;
     const dim3 grid = p.swap ? dim3((unsigned)ncols, (unsigned)blocks) : dim3((unsigned)blocks, (unsigned)ncols);
     if (pre) hipLaunchKernelGGL(k_ntt_final29<true>, grid, dim3(256), lds, ctx->stream, in, out, is, os, p, tw, pre, post, post_scale ? 1 : 0);
@@ -508,10 +562,10 @@ extern "C" int pz_ntt_fr_to_dev(pz_ctx* ctx, const uint64_t* d_in, size_t in_str
     Fr* a = reinterpret_cast<Fr*>(d_out);
     const Fr* ain = reinterpret_cast<const Fr*>(d_in);
     void* twv = nullptr;
-    PZCHK(pz_get_pow_table_raw(ctx, omega, n, &twv, one261()));   // omega^i * 2^261 as 9 x 29-bit limbs
+    PZCHK(pz_get_pow_table_raw(ctx, omega, n, &twv));   // omega^i as constant pairs
     const u32* tw = (const u32*)twv;
     void* prev = nullptr;
-    if (pre_coset_g) PZCHK(pz_get_pow_table_raw(ctx, pre_coset_g, n, &prev, one261()));
+    if (pre_coset_g) PZCHK(pz_get_pow_table_raw(ctx, pre_coset_g, n, &prev));
     const u32* pre = (const u32*)prev;
 
     const unsigned npass = log_n <= 9 ? 1 : (log_n <= 18 ? 2 : 3);
@@ -519,10 +573,8 @@ extern "C" int pz_ntt_fr_to_dev(pz_ctx* ctx, const uint64_t* d_in, size_t in_str
     // the scale as first entry -- instead of costing the last pass a product per element
     const u32* tw_ep = nullptr;
     if (post_scale && npass > 1) {
-        uint64_t init[4];
-        fr_times32(post_scale, init);
         void* t;
-        PZCHK(pz_get_pow_table_raw(ctx, omega, n, &t, init));
+        PZCHK(pz_get_pow_table_raw(ctx, omega, n, &t, post_scale));
         tw_ep = (const u32*)t;
         post_scale = nullptr;
     }
@@ -591,15 +643,12 @@ static int get_ext_pre_tables(pz_ctx* ctx, const uint64_t* coset_gens, size_t E,
             *out = c.d;
             return PZ_OK;
         }
-    uint64_t init[4];
-    if (scale) fr_times32(scale, init);
-    else memcpy(init, one261(), 32);
     void* prev = nullptr;
-    HIPCHK(ctx, hipMalloc(&prev, E * n * 36));   // raw 9 x 29-bit limbs per entry
+    HIPCHK(ctx, hipMalloc(&prev, E * n * 72));   // constant pairs
     for (size_t r = 0; r < E; ++r) {
         void* t;
-        PZCHK(pz_get_pow_table(ctx, coset_gens + 4 * r, n, &t, init));
-        PZCHK(pz_raw29_convert(ctx, t, (char*)prev + r * n * 36, n));
+        PZCHK(pz_get_pow_table(ctx, coset_gens + 4 * r, n, &t, scale));
+        PZCHK(pz_raw29_convert(ctx, t, (char*)prev + r * n * 72, n));
     }
     ctx->ext_tables.push_back(pz_ext_table{key, prev});
     *out = prev;
@@ -616,26 +665,30 @@ static int get_ext_pre_tables(pz_ctx* ctx, const uint64_t* coset_gens, size_t E,
 // stage's twiddles times a constant: stage s (blocks of 2^s joined into 2^(s+1)) uses K_s * omega^(pos * n / 2^(s+1)),
 // K_s = c^(n / 2^(s+1)).  Stages 0 + 1 lose their trivial twiddles (0.75 products per element more), the pre-scale goes
 // (1 product per element less).  Both tables in the 261-domain as raw limbs; S[(2^s - 1) + pos], R entries apart per coset.
-__global__ void k_ext_epilogue_table(const Fr* __restrict__ cpow, const u32* __restrict__ tw, size_t lo, size_t n, u32* __restrict__ out) {
+__global__ void k_ext_epilogue_table(const Fr* __restrict__ cpow, const Fr* __restrict__ twm, size_t lo, size_t n, u32* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const size_t k = i / lo, col = i % lo;
-    const Fr29 x = f29_mul(f29_load<FrTag>(cpow + col), raw9_get(tw, col * k));   // col * k < lo * R = n
-    f29_store_raw(out + i * 9, x);
+    u32 o[18];
+    f29_cpair_from_mont(fp_mul(fp_load<FrTag>(cpow + col), fp_load<FrTag>(twm + col * k)), o);   // col * k < lo * R = n
+#pragma unroll
+    for (int j = 0; j < 18; ++j) out[i * 18 + j] = o[j];
 }
-__global__ void k_ext_stage_table(Fr c, const u32* __restrict__ tw, size_t n, unsigned logR, u32* __restrict__ out) {
+__global__ void k_ext_stage_table(Fr c, const Fr* __restrict__ twm, size_t n, unsigned logR, u32* __restrict__ out) {
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x, R = 1u << logR;
     if (t + 1 >= R) return;
     const unsigned s = 31u - (unsigned)__builtin_clz(t + 1), pos = t + 1 - (1u << s);
-    // K_s = c^(n >> (s + 1)): a power of two, by squarings in the 261-domain
-    Fr29 K = f29_to_261(f29_from_fp(c));
-    for (size_t e = n >> (s + 1); e > 1; e >>= 1) K = f29_sqr(K);
-    const Fr29 x = f29_mul(K, raw9_get(tw, (size_t)pos * (n >> (s + 1))));
-    f29_store_raw(out + (size_t)t * 9, x);
+    // K_s = c^(n >> (s + 1)): a power of two, by squarings (Montgomery form)
+    Fr K = c;
+    for (size_t e = n >> (s + 1); e > 1; e >>= 1) K = fp_sqr(K);
+    u32 o[18];
+    f29_cpair_from_mont(fp_mul(K, fp_load<FrTag>(twm + (size_t)pos * (n >> (s + 1)))), o);
+#pragma unroll
+    for (int j = 0; j < 18; ++j) out[(size_t)t * 18 + j] = o[j];
 }
 // out_ep: [E][n][9], out_stw: [E][R][9]
 static int get_ext_abs_tables(pz_ctx* ctx, const uint64_t* coset_gens, size_t E, uint32_t log_n, unsigned logR, const uint64_t* scale,
-                              const uint64_t omega_n[4], const u32* tw, const u32** out_ep, const u32** out_stw) {
+                              const uint64_t omega_n[4], const u32** out_ep, const u32** out_stw) {
     const size_t n = (size_t)1 << log_n, R = (size_t)1 << logR, lo = n >> logR;
     std::vector<uint64_t> key(coset_gens, coset_gens + 4 * E);
     key.push_back(log_n);
@@ -645,23 +698,22 @@ static int get_ext_abs_tables(pz_ctx* ctx, const uint64_t* coset_gens, size_t E,
     for (auto& c : ctx->ext_tables)
         if (c.key == key) {
             *out_ep = (const u32*)c.d;
-            *out_stw = (const u32*)c.d + E * n * 9;
+            *out_stw = (const u32*)c.d + E * n * 18;
             return PZ_OK;
         }
-    uint64_t init[4];
-    if (scale) fr_times32(scale, init);
-    else memcpy(init, one261(), 32);
     void* d = nullptr;
-    HIPCHK(ctx, hipMalloc(&d, (E * n + E * R) * 36));
+    HIPCHK(ctx, hipMalloc(&d, (E * n + E * R) * 72));
     u32* ep = (u32*)d;
-    u32* stw = ep + E * n * 9;
+    u32* stw = ep + E * n * 18;
+    void* twm;
+    PZCHK(pz_get_pow_table(ctx, omega_n, n, &twm));   // omega^i, Montgomery form: the builders multiply in that form and convert once
     for (size_t r = 0; r < E; ++r) {
         void* cp;
-        PZCHK(pz_get_pow_table(ctx, coset_gens + 4 * r, lo, &cp, init));   // c^col * scale, 261-domain
-        hipLaunchKernelGGL(k_ext_epilogue_table, dim3(pz_div_up(n, 256)), dim3(256), 0, ctx->stream, (const Fr*)cp, tw, lo, n, ep + r * n * 9);
+        PZCHK(pz_get_pow_table(ctx, coset_gens + 4 * r, lo, &cp, scale));   // c^col * scale
+        hipLaunchKernelGGL(k_ext_epilogue_table, dim3(pz_div_up(n, 256)), dim3(256), 0, ctx->stream, (const Fr*)cp, (const Fr*)twm, lo, n, ep + r * n * 18);
         Fr c;
         memcpy(c.v, coset_gens + 4 * r, 32);
-        hipLaunchKernelGGL(k_ext_stage_table, dim3(pz_div_up(R, 256)), dim3(256), 0, ctx->stream, c, tw, n, logR, stw + r * R * 9);
+        hipLaunchKernelGGL(k_ext_stage_table, dim3(pz_div_up(R, 256)), dim3(256), 0, ctx->stream, c, (const Fr*)twm, n, logR, stw + r * R * 18);
         HIPCHK(ctx, hipGetLastError());
     }
     ctx->ext_tables.push_back(pz_ext_table{key, d});
@@ -681,7 +733,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
     PZ_ENTER(ctx);
     const size_t is = in_stride / 4, os = out_stride / 4;
     void* twv = nullptr;
-    PZCHK(pz_get_pow_table_raw(ctx, omega_n, n, &twv, one261()));
+    PZCHK(pz_get_pow_table_raw(ctx, omega_n, n, &twv));
     const u32* tw = (const u32*)twv;
     const unsigned npass_ = log_n <= 9 ? 1 : (log_n <= 18 ? 2 : 3);
     // several passes: the coset shift is absorbed into the first pass's twiddles (get_ext_abs_tables); a single-pass transform
@@ -690,7 +742,7 @@ extern "C" int pz_ntt_fr_extend_dev(pz_ctx* ctx, const uint64_t* d_coeff, size_t
     const unsigned logR_a = npass_ == 2 ? (log_n + 1) / 2 : (log_n + 2) / 3;   // size of the first pass (lg0 / lg[0] below)
     const u32 *pre = nullptr, *stw = nullptr;
     if (absorbed) {
-        PZCHK(get_ext_abs_tables(ctx, coset_gens, E, log_n, logR_a, scale, omega_n, tw, &pre, &stw));
+        PZCHK(get_ext_abs_tables(ctx, coset_gens, E, log_n, logR_a, scale, omega_n, &pre, &stw));
     } else {
         void* prev = nullptr;
         PZCHK(get_ext_pre_tables(ctx, coset_gens, E, log_n, scale, &prev));

@@ -59,7 +59,7 @@ def fq_mul29(device: int, a, b) -> np.ndarray:
     return out
 
 
-F29_OPS = {"mul": (0, 2), "sqr": (1, 1), "mul2": (2, 4), "dot4": (3, 8), "unpack_shl5": (4, 1), "canon4": (5, 1), "store_product": (6, 1), "canon_q": (7, 1)}
+F29_OPS = {"mul": (0, 2), "sqr": (1, 1), "mul2": (2, 4), "dot4": (3, 8), "unpack_shl5": (4, 1), "canon4": (5, 1), "store_product": (6, 1), "canon_q": (7, 1), "mulc": (8, 3)}
 
 
 def f29_ops(device: int, field: str, op: str, limbs) -> np.ndarray:

@@ -1470,3 +1470,36 @@ def test_ntt_extend_small_and_large_sizes_subprocess():
     e = dict(os.environ)
     r = subprocess.run([sys.executable, "-c", _NTT_ARM_SCRIPT, root], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ntt-arm-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("field", ["fq", "fr"])
+def test_f29_mulc_constant_operand_product(eng, field):
+    """fp29.cuh::f29_mulc (round 5: the product every K2 multiplication now is -- by a constant pair (c, floor(c 2^261 / p))): the result
+    is congruent to a * c, has tight limbs and stays below 3p for a below 2^261 -- on random operands, loose limbs up to 2^31 - 1 (the
+    uncarried tile elements), the extreme constants 0, 1, p - 1 and all-ones limb patterns"""
+    from paillier_halo2_amd import probe
+
+    p = P.FQ_P if field == "fq" else P.FR_R
+    M = (1 << 29) - 1
+    limbs = lambda x: [(x >> (29 * i)) & M for i in range(8)] + [x >> (29 * 8)]
+    val = lambda l: sum(int(v) << (29 * i) for i, v in enumerate(l))
+    rng = random.Random(29 + len(field))
+    rows, want = [], []
+    for t in range(3000):
+        c = rng.randrange(p) if t % 7 else [0, 1, p - 1][t % 3]
+        cq = (c << 261) // p
+        if t % 5 == 0:
+            al = [rng.randrange(1 << 31) for _ in range(9)] if t % 10 else [(1 << 31) - 1] * 9
+            a = val(al)
+        else:
+            a = rng.randrange(1 << 261) if t % 3 else rng.randrange(64 * p)
+            al = limbs(a)
+        rows.append([al, limbs(c), limbs(cq)])
+        want.append((a, c))
+    got = probe.f29_ops(eng.device, field, "mulc", np.array(rows, dtype=np.uint32))
+    for (a, c), g in zip(want, got):
+        r = val(g)
+        assert all(int(v) <= M for v in g)
+        assert r % p == a * c % p
+        if a < (1 << 261):
+            assert r < 3 * p, (r // p, a.bit_length())
