@@ -1364,7 +1364,7 @@ def main():
     # so the per-launch figure of the committed rocprofv3 --pmc passes of this same command is reported
     traffic, traffic_src = None, None
     try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")))
         if args.scale == 1.0 and (args.enc_bits, args.k) == (2048, 17):
             traffic = pj["k_msm_accumulate"]["fetch_bytes_per_launch_raw"] + pj["k_msm_accumulate"]["write_bytes_per_launch"]
             traffic_src = pj["source"]
