@@ -68,9 +68,9 @@ def _c_prototypes():
     return out
 
 
-def _rust_bindings():
-    """INTEGRATION.md's extern "C" declarations -> the same shape"""
-    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+def _rust_bindings(path="INTEGRATION.md"):
+    """the extern "C" declarations of INTEGRATION.md (or of the pz-sys crate source) -> the same shape"""
+    text = open(os.path.join(ROOT, path)).read()
     out = {}
     for m in re.finditer(r"pub fn (pz_[a-z0-9_]+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+))?;", text, flags=re.S):
         name, params, ret = m.group(1), m.group(2), (m.group(3) or "void").strip()
@@ -102,6 +102,9 @@ def test_bindings_match_the_header_parameter_by_parameter():
         elif rust[n] != c[n]:
             mism.append((n, c[n], rust[n]))
     assert not mism, mism
+    # the crate source (rust/pz-sys/src/lib.rs) is the same binding, file for file
+    crate = _rust_bindings(os.path.join("rust", "pz-sys", "src", "lib.rs"))
+    assert crate == rust and len(crate) == len(names)
     # the ctypes signatures
     def ct(t):
         if t is None:
