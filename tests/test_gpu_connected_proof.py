@@ -295,3 +295,80 @@ def test_c3_add_circuit_connected_proof_at_size(eng, cref):
                            ch.sh_v, ch.sh_u, pr.commitments["w1"][0], pr.commitments["w2"][0], s_tox)
     bl.free()
     bm.free()
+
+
+def _connected_workload(eng, bits, k, seed=0x5043):
+    import torch
+
+    import bench_connected
+
+    return bench_connected.ConnectedWorkload(eng, torch, bits, k, seed)
+
+
+def test_connected_proof_many_tiles_and_sets(eng, cref):
+    """the bench's connected workload (bench_connected.ConnectedWorkload: the product's structure generator, K3 -> K4 break-point
+    columns, keygen, create_proof with a hashing transcript, the next witness produced on a second context) at a 1024-bit key, k = 16:
+    967 + 54 + 1 permuted columns = 16 tiles of 64, 511 grand products, 23 GB of proving key -- three proofs, the last one checked as
+    the verifier would.  (A batching bug in keygen -- sigma built 256 columns at a time against a 256-entry table of delta powers --
+    passed every smaller test and failed exactly here.)"""
+    wl = _connected_workload(eng, 1024, 16)
+    try:
+        assert wl.A > 900 and wl.pk.n_sets > 500
+        wl.run(3, timed=False)
+        v = wl.verify(cref)
+        assert v["verified"] is True, v
+        assert v["commitments"] == wl.A + 4 * wl.Lk + wl.pk.n_sets + 1 + 3 + 2
+    finally:
+        wl.release()
+
+
+def test_c2_structure_and_witness_agree_at_size(eng, cref):
+    """config c2 itself (2048-bit n, k = 17: 3.97 x 10^8 advice cells in 3033 break-point columns, 1.1 x 10^7 lookup cells in 84): the
+    circuit structure the product generates and the witness K3 -> K4 writes describe the SAME circuit -- every one of sigma's
+    4 x 10^8 cells maps to a cell holding the same value (all copy constraints, constants and lookup copies included), and every
+    enabled gate holds inside its column (the custom-gate kernel over the 2^k domain with rotation 1 returns zero everywhere)"""
+    import torch
+    from paillier_halo2_amd import circuit_structure as CS
+    from paillier_halo2_amd import consts
+
+    import bench
+
+    bits, k, lb = 2048, 17, 16
+    n, Ln = 1 << k, bits // 64
+    nn, g, m, r = bench.synth_inputs(bits, 0x5043)
+    sa = CS.stream_structure("encrypt", bits, 64, lb, m, nn)
+    cs, starts = CS.columns(sa, k, lb)
+    A, Lk, M_ = cs.n_adv, cs.n_lk, cs.m
+    assert (A, Lk) == (3033, 84) and sa.n_cells == eng.circuit_cells(0, Ln, 64, lb, sa.n_steps_g, sa.n_steps_r)[0]
+    lim = lambda x, l: consts.int_to_limbs(x, l)
+    n_steps = sa.n_steps_g + sa.n_steps_r + 1
+    d_steps = torch.zeros((n_steps, 4, 2 * Ln), dtype=torch.int64, device="cuda")
+    c, _, _ = eng.paillier_encrypt_dev(Ln, lim(nn, Ln), lim(g, Ln), lim(m, Ln), lim(r, Ln), d_steps.data_ptr(), n_steps)
+    d_mod = torch.from_numpy(lim(nn * nn, 2 * Ln).astype(np.int64)).cuda()
+    d_starts = torch.from_numpy(starts.astype(np.int64)).cuda()
+    cols = torch.zeros((M_, n, 4), dtype=torch.int64, device="cuda")
+    inputs = np.concatenate([lim(nn, Ln), lim(g, Ln), lim(m, Ln), lim(r, Ln), np.asarray(c[0], dtype=np.uint64)])
+    eng.circuit_expand_cols_dev(0, Ln, 64, lb, inputs, d_steps.data_ptr(), sa.n_steps_g, sa.n_steps_r, d_mod.data_ptr(), cols.data_ptr(),
+                                cols[A].data_ptr(), d_starts.data_ptr(), A, cs.max_rows, cs.max_rows, n)
+    consts_col = np.zeros((n, 4), dtype=np.uint64)
+    consts_col[: len(cs.constants)] = cref.fr_ints_to_mont(list(cs.constants))
+    cols[A + Lk] = torch.from_numpy(consts_col.view(np.int64)).cuda()
+    eng.sync()
+    flat = cols.view(M_ * n, 4)
+    bad = 0
+    for c0 in range(0, M_, 256):
+        c1 = min(M_, c0 + 256)
+        img = torch.from_numpy(cs.map_col[c0:c1].astype(np.int64) * n + cs.map_row[c0:c1].astype(np.int64)).cuda().view(-1)
+        bad += int((flat[c0 * n:c1 * n] != flat[img]).any(dim=1).sum().item())
+    assert bad == 0, "%d cells differ from the cell sigma maps them to" % bad
+    one = torch.from_numpy(consts.fr_mont_limbs(1).view(np.int64)).cuda()
+    h = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    y = consts.fr_mont_limbs(0x1234567)
+    for c0 in range(0, A, 64):
+        c1 = min(A, c0 + 64)
+        sel = torch.from_numpy(np.ascontiguousarray(cs.selectors[c0:c1])).cuda()
+        selm = torch.where(sel.bool().unsqueeze(-1), one, torch.zeros_like(one)).contiguous()
+        eng.quotient_gate_dev(cols[c0].data_ptr(), 4 * n, selm.data_ptr(), 4 * n, c1 - c0, k, 1, y, h.data_ptr())
+    eng.sync()
+    assert not h.any().item(), "an enabled gate does not hold inside its column"
+    assert int(cs.selectors.sum()) > 10 ** 8
