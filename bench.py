@@ -1549,6 +1549,34 @@ def main():
             if ver is not None and ver.get("verified") is False:
                 out["comparable"] = False
             cw.release()
+            del cw
+            gc.collect()
+            torch.cuda.empty_cache()
+            # the same through the UNIFORM-shape circuit (row f4): ONE proving key for every message of a key, so the proofs of this
+            # loop are of DISTINCT messages -- what a user who encrypts different messages gets once that key exists.  (The reference's
+            # circuit needs a new structure + keygen per message: with_next_rows.circuit_structure_ms + keygen_ms.)  One witness slot:
+            # its proving key is 166 GB.
+            if (args.enc_bits, args.k) == (2048, 17) and not args.no_c2u:
+                t_u = time.time()
+                cu = bench_connected.ConnectedWorkload(eng, torch, args.enc_bits, args.k, args.seed, lookup_bits=args.lookup_bits, log=log,
+                                                       circuit="encrypt_uniform", pipeline=False)
+                cu.run(1, timed=False)
+                barrier()
+                tu0 = time.perf_counter()
+                cu.run(c_steps, timed=False)
+                barrier()
+                dtu = time.perf_counter() - tu0
+                cu.run(1, timed=True)
+                veru = cu.verify(_cref) if ver is not None else None
+                out["with_next_rows_c2u"] = {
+                    "value": c_steps / dtu, "unit": "proofs/s", "steps": c_steps, "ms_per_step": dtu / c_steps * 1e3, "connected": True,
+                    "distinct_messages_one_key": True, "verified": veru.get("verified") if veru else None, "verification": veru,
+                    "phases_ms_per_proof": cu.phase_ms(1), "counts": cu.counts(), "memory_gb": cu.memory_gb, "keygen_ms": cu.keygen_ms,
+                    "circuit_structure_ms": cu.structure_ms,
+                    "note": "the connected proof through the uniform-shape circuit (g^m over all message bits in circuit: 7192 mul_mod steps, "
+                            "3544 + 98 columns): every proof of the loop is of a different message, all under one proving key"}
+                log("connected c2u %.1fs: %.3f proofs/s, verified %s" % (time.time() - t_u, c_steps / dtu, veru.get("verified") if veru else None))
+                cu.release()
         except Exception as ex:
             import traceback
 

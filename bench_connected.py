@@ -30,7 +30,8 @@ class _Null:
 
 
 class ConnectedWorkload:
-    def __init__(self, eng, torch, enc_bits: int, k: int, seed: int, lookup_bits=None, log=lambda s: None, tile: int = 64):
+    def __init__(self, eng, torch, enc_bits: int, k: int, seed: int, lookup_bits=None, log=lambda s: None, tile: int = 64,
+                 circuit: str = "encrypt", pipeline=None):
         import random
 
         import bench
@@ -44,17 +45,26 @@ class ConnectedWorkload:
         self.L = 2 * self.Ln
         nn, g, m, r = bench.synth_inputs(enc_bits, seed)
         self.ints = (nn, g, m, r)
-        self.ng = m.bit_length() + bin(m).count("1")
+        self.circuit = circuit
+        self.uniform = circuit == "encrypt_uniform"
+        self.kind = 2 if self.uniform else 0
+        self.ng = 2 * enc_bits if self.uniform else m.bit_length() + bin(m).count("1")
         self.nr = nn.bit_length() + bin(nn).count("1")
         self.n_steps = self.ng + self.nr + 1
-        # one key serves the proofs of ONE message under different randomness: the message's bits are circuit structure
-        # (paillier.rs:50-55), r is not (r^n's exponent is the public n)
         vr = random.Random(seed ^ 0x636F6E)
         lim = lambda x: consts.int_to_limbs(x, self.Ln)
-        self.variants = [tuple(lim(x) for x in (nn, g, m, rr)) for rr in (r, vr.randrange(1, nn), vr.randrange(1, nn))]
+        if self.uniform:
+            # the uniform-shape circuit: the message's bits are WITNESS cells -- one key serves every message: the
+            # proofs of a run are of DISTINCT messages
+            self.variants = [tuple(lim(x) for x in (nn, g, mm, rr)) for mm, rr in ((m, r), (vr.randrange(0, nn), vr.randrange(1, nn)),
+                                                                                    (vr.randrange(0, nn), vr.randrange(1, nn)))]
+        else:
+            # one key serves the proofs of ONE message under different randomness: the message's bits are circuit structure
+            # (paillier.rs:50-55), r is not (r^n's exponent is the public n)
+            self.variants = [tuple(lim(x) for x in (nn, g, m, rr)) for rr in (r, vr.randrange(1, nn), vr.randrange(1, nn))]
         # ---- circuit structure (what halo2's keygen extracts by synthesising the circuit once)
         t0 = time.perf_counter()
-        sa = CS.stream_structure("encrypt", enc_bits, 64, self.lb, m, nn)
+        sa = CS.stream_structure(circuit, enc_bits, 64, self.lb, m, nn)
         assert (sa.n_steps_g, sa.n_steps_r) == (self.ng, self.nr)
         t1 = time.perf_counter()
         self.cs, starts = CS.columns(sa, k, self.lb)
@@ -81,7 +91,7 @@ class ConnectedWorkload:
         torch.cuda.empty_cache()
         self.ws = prover.Workspace(self.pk, tile)
         # two witness slots: proof i+1's K3 + K4 run on a second context / stream under proof i's advice commitments
-        self.pipeline = os.environ.get("PZ_CONNECTED_PIPELINE", "1") == "1"
+        self.pipeline = (os.environ.get("PZ_CONNECTED_PIPELINE", "1") == "1") if pipeline is None else bool(pipeline)
         self.slots = [torch.zeros((self.m, self.n, 4), dtype=torch.int64, device="cuda") for _ in range(2 if self.pipeline else 1)]
         self.cols = self.slots[0]
         self.engw, self.stream_w = eng, None
@@ -117,9 +127,12 @@ class ConnectedWorkload:
             if self.stream_w is not None:
                 self.stream_w.wait_event(self.free_ev[slot])        # the proof that used this slot has finished with it
             cols.zero_()
-            c, _, _ = eng.paillier_encrypt_dev(self.Ln, nn, g, m, r, self.d_steps.data_ptr(), self.n_steps)      # K3 (returns the ciphertext)
+            if self.uniform:
+                c, _, _ = eng.paillier_encrypt_uniform_dev(self.Ln, self.enc_bits, nn, g, m, r, self.d_steps.data_ptr(), self.n_steps)
+            else:
+                c, _, _ = eng.paillier_encrypt_dev(self.Ln, nn, g, m, r, self.d_steps.data_ptr(), self.n_steps)      # K3 (returns the ciphertext)
             inputs = np.concatenate([nn, g, m, r, np.asarray(c[0], dtype=np.uint64)])
-            eng.circuit_expand_cols_dev(0, self.Ln, 64, self.lb, inputs, self.d_steps.data_ptr(), self.ng, self.nr, self.d_mod.data_ptr(),
+            eng.circuit_expand_cols_dev(self.kind, self.Ln, 64, self.lb, inputs, self.d_steps.data_ptr(), self.ng, self.nr, self.d_mod.data_ptr(),
                                         cols.data_ptr(), cols[self.A].data_ptr(), self.d_starts.data_ptr(), self.A, self.cs.max_rows,
                                         self.cs.max_rows, self.n)                                               # K4, break-point layout
             if self.stream_w is not None:

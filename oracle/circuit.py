@@ -111,9 +111,17 @@ def build(kind: str, n: int, g: int, x: int, y: int, res: int, enc_bits: int, li
     if kind == "encrypt":
         ng = x.bit_length() + bin(x).count("1")
         nr = n.bit_length() + bin(n).count("1")
+    elif kind == "encrypt_uniform":
+        ng = 2 * enc_bits
+        nr = n.bit_length() + bin(n).count("1")
     else:
         ng = nr = 0
-    mask, total = P.gate_mask_circuit(kind, enc_bits, limb_bits, lb, ng, nr)
+    if kind == "encrypt_uniform":
+        gl, total = P.gate_offsets_uniform_circuit(enc_bits, limb_bits, lb, nr)
+        mask = np.zeros(total, dtype=np.uint8)
+        mask[np.asarray(gl, dtype=np.int64)] = 1
+    else:
+        mask, total = P.gate_mask_circuit(kind, enc_bits, limb_bits, lb, ng, nr)
     assert total == len(adv)
     starts = break_points(mask, max_rows)
     A = len(starts) - 1

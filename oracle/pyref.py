@@ -1316,6 +1316,54 @@ def expand_circuit_cells_wired(kind: str, n: int, g: int, x: int, y: int, res: i
         rn_val = pow(y, n, n * n)
         rn = vals_r[rn_val]
         c_limbs = mul_mod(gm, rn, fresh)
+    elif kind == "encrypt_uniform":
+        # the uniform-shape circuit (expand_uniform_circuit_cells): g^m through pow_mod over the message's BITS in circuit --
+        # num_to_bits of every limb of m (the recomposition copies the limb, every bit is asserted boolean), then per bit
+        # mul_mod(acc, sq), a limb-wise select(bit, product, acc) and square_mod(sq); r^n and the rest as in 'encrypt'
+        W = limb_bits
+        one = putc(1)
+        z2 = putc(0)
+        acc = [(1, one)] + [(0, z2)] * (L - 1)
+        sq = ext(g_c)
+        for li in range(Ln):
+            xv, xc = x_c[li]
+            bits = [(xv >> i) & 1 for i in range(W)]
+            bit_cells = [put(bits[0])]
+            accv = bits[0]
+            acc_cell = bit_cells[0]
+            for i in range(1, W):
+                accv += bits[i] << i
+                bit_cells.append(put(bits[i]))
+                putc(1 << i)
+                acc_cell = put(accv)
+            pairs.append((xc, acc_cell))
+            for b, bc in zip(bits, bit_cells):
+                putc(0); put(b, bc); put(b, bc); put(b, bc)
+            for bi in range(W):
+                mul = mul_mod(acc, sq, fresh)
+                new_acc = []
+                for t in range(L):
+                    (av, ac), (bv, bc_) = mul[t], acc[t]
+                    d = av - bv
+                    c_d = put(d); putc(1); put(bv, bc_); put(av, ac); put(bv, bc_); put(bits[bi], bit_cells[bi]); put(d, c_d)
+                    new_acc.append((d * bits[bi] + bv, put(d * bits[bi] + bv)))
+                acc = new_acc
+                sq = mul_mod(sq, sq, fresh)
+        gm = acc
+
+        def pow_mod_traced_r(base_limbs, e):
+            one_ = putc(1)
+            z2_ = putc(0)
+            acc_ = [(1, one_)] + [(0, z2_)] * (L - 1)
+            sq_ = base_limbs
+            for bit in exp_bits_lsb_first(e):
+                cur = sq_
+                sq_ = mul_mod(cur, cur, fresh)
+                if bit:
+                    acc_ = mul_mod(acc_, cur, fresh)
+            return acc_
+        rn = pow_mod_traced_r(ext(y_c), n)
+        c_limbs = mul_mod(gm, rn, fresh)
     else:
         c_limbs = mul_mod(ext(x_c), ext(y_c), fresh)
     res_c = assign(res, L)

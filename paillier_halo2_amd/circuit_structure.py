@@ -253,6 +253,41 @@ def _block_template(L: int, limb_bits: int, lb: int) -> _Template:
                      np.asarray(w.lk, dtype=np.int64), np.asarray(rl, dtype=np.int64))
 
 
+def _uniform_template(L: int, limb_bits: int, lb: int) -> _Template:
+    """one exponent bit of the uniform-shape circuit (pz_paillier_encrypt_uniform, circuit kind 2): mul_mod(acc, sq), the limb-wise
+    select(bit, product, acc) = 8 cells per limb [d | 1 | acc | prod | acc | bit | d | out] with gates at 0 and 4, square_mod(sq).
+    Operand limbs: 'a' = acc, 'b' = sq, 'n' = the refreshed n^2, 's' = the bit's cell.  r_cells holds the NEW acc (select outputs)
+    then the NEW sq (the square's remainder), L cells each."""
+    w = _Walk()
+    A = [("a", j) for j in range(L)]
+    B = [("b", j) for j in range(L)]
+    Nf = [("n", j) for j in range(L)]
+    mul = _mul_mod(w, A, B, Nf, L, limb_bits, lb)
+    outs = []
+    for t in range(L):
+        c_d = w.put()
+        w.gate(c_d)
+        w.putc(1); w.put(("a", t)); w.put(mul[t])
+        g = w.put(("a", t))
+        w.gate(g)
+        w.put(("s", 0)); w.put(c_d)
+        outs.append(w.put())
+    sq = _mul_mod(w, B, B, Nf, L, limb_bits, lb)
+    n = w.n
+    sol = np.arange(n, dtype=np.int64)
+    ext: Dict[str, Tuple[List[int], List[int]]] = {"a": ([], []), "b": ([], []), "n": ([], []), "s": ([], [])}
+    for i, s_ in enumerate(w.src):
+        if isinstance(s_, tuple):
+            ext[s_[0]][0].append(i)
+            ext[s_[0]][1].append(s_[1])
+        elif s_ >= 0:
+            sol[i] = s_
+    cpos = [i for i, v in enumerate(w.cval) if v is not None]
+    return _Template(n, sol, {k: (np.asarray(p, dtype=np.int64), np.asarray(j, dtype=np.int64)) for k, (p, j) in ext.items()},
+                     np.asarray(cpos, dtype=np.int64), [w.cval[i] for i in cpos], np.asarray(w.gates, dtype=np.int64),
+                     np.asarray(w.lk, dtype=np.int64), np.asarray(outs + sq, dtype=np.int64))
+
+
 @dataclass
 class StructureArrays:
     """stream-level structure: everything indexed by the advice stream's cell index"""
@@ -272,7 +307,8 @@ def _exp_bits(e: int) -> List[int]:
 
 def stream_structure(kind: str, enc_bits: int, limb_bits: int, lb: int, exp_g: int = 0, exp_r: int = 0) -> StructureArrays:
     """kind 'encrypt': exp_g = the message m, exp_r = the modulus n -- only their BITS are used, as in the reference's circuit
-    (pow_mod_fixed_exp, paillier.rs:50-55); kind 'add': no exponents."""
+    (pow_mod_fixed_exp, paillier.rs:50-55); kind 'add': no exponents; kind 'encrypt_uniform' (the uniform-shape circuit, SURVEY 8f rank
+    4): exp_g is ignored -- the message's bits are witness cells, ONE structure serves every message of a key."""
     Ln = enc_bits // limb_bits
     L = 2 * Ln
     tm = _block_template(L, limb_bits, lb)
@@ -357,9 +393,67 @@ def stream_structure(kind: str, enc_bits: int, limb_bits: int, lb: int, exp_g: i
         return off + ns * tm.cells, bases[:, None] + tm.r_cells[None, :]      # r cells of every block
 
     n_steps = [0, 0]
-    if kind == "encrypt":
+    if kind in ("encrypt", "encrypt_uniform"):
         results = []
-        for ci, (base_limbs, e) in enumerate(((ext_l(g_c), exp_g), (ext_l(y_c), exp_r))):
+        chains = [(ext_l(g_c), exp_g), (ext_l(y_c), exp_r)]
+        if kind == "encrypt_uniform":
+            # g^m over ALL enc_bits bits of m IN the circuit: assign_constant(1), load_zero, then per limb of m num_to_bits and per bit
+            # the (mul_mod, select, square_mod) block -- the same shape for every message
+            W_ = limb_bits
+            ut = _uniform_template(L, limb_bits, lb)
+            ut_const = np.asarray([cid(v) for v in ut.const_val], dtype=np.int64)
+            ut_mask = np.zeros(ut.cells, dtype=np.uint8)
+            ut_mask[ut.gates] = 1
+            wc = _Walk(off)
+            one = wc.putc(1)
+            z2 = wc.putc(0)
+            off = flush(wc)
+            acc_cells = np.asarray([one] + [z2] * (L - 1), dtype=np.int64)
+            sq_cells = np.asarray(ext_l(g_c), dtype=np.int64)
+            for li in range(Ln):
+                wb = _Walk(off)
+                bit_cells = [wb.put()]
+                wb.gate(bit_cells[0])
+                acc_cell = bit_cells[0]
+                for i in range(1, W_):
+                    bit_cells.append(wb.put())
+                    wb.putc(1 << i)
+                    acc_cell = wb.put()
+                    if i < W_ - 1:
+                        wb.gate(acc_cell)
+                wb.pair(x_c[li], acc_cell)
+                for bc in bit_cells:
+                    g_ = wb.putc(0)
+                    wb.gate(g_)
+                    wb.put(bc); wb.put(bc); wb.put(bc)
+                off = flush(wb)
+                # the limb's W_ bits: blocks chained through acc (select outputs) and sq (square remainders)
+                bases = off + ut.cells * np.arange(W_, dtype=np.int64)
+                new_acc = bases[:, None] + ut.r_cells[None, :L]
+                new_sq = bases[:, None] + ut.r_cells[None, L:]
+                a_cells = np.concatenate([acc_cells[None, :], new_acc[:-1]])
+                b_cells = np.concatenate([sq_cells[None, :], new_sq[:-1]])
+                sblk = bases[:, None] + ut.self_or_local[None, :]
+                for kind_, cells_ in (("a", a_cells), ("b", b_cells)):
+                    pos, j = ut.ext[kind_]
+                    sblk[:, pos] = cells_[:, j]
+                pos, j = ut.ext["n"]
+                sblk[:, pos] = fresh_arr[j][None, :]
+                pos, _ = ut.ext["s"]
+                sblk[:, pos] = np.asarray(bit_cells, dtype=np.int64)[:, None]
+                sblk[:, ut.const_pos] = -(1 + ut_const)[None, :]
+                parts_src.append(sblk.reshape(-1))
+                parts_mask.append(np.tile(ut_mask, W_))
+                parts_lk.append((bases[:, None] + ut.lk[None, :]).reshape(-1))
+                off += W_ * ut.cells
+                acc_cells, sq_cells = new_acc[-1], new_sq[-1]
+            n_steps[0] = 2 * Ln * W_
+            results.append(acc_cells)
+            chains = [None, chains[1]]
+        for ci, chain in enumerate(chains):
+            if chain is None:
+                continue
+            base_limbs, e = chain
             wc = _Walk(off)
             one = wc.putc(1)
             z2 = wc.putc(0)
@@ -388,7 +482,7 @@ def stream_structure(kind: str, enc_bits: int, limb_bits: int, lb: int, exp_g: i
                 off, _ = blocks(off, a_cells, b_cells)
             results.append(table[acc_blk + 2])
         gm, rn = results
-        off, rfin = blocks(off, gm[None, :], rn[None, :])
+        off, rfin = blocks(off, np.asarray(gm, dtype=np.int64)[None, :], np.asarray(rn, dtype=np.int64)[None, :])
     else:
         off, rfin = blocks(off, np.asarray(ext_l(x_c), dtype=np.int64)[None, :], np.asarray(ext_l(y_c), dtype=np.int64)[None, :])
     c_limbs = rfin[0].tolist()

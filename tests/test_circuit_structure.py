@@ -102,3 +102,33 @@ def test_product_structure_generator_equals_the_oracle_restatement():
         moved = np.argwhere(flat != np.arange(flat.size).reshape(flat.shape))
         for c, rr in moved[:: max(1, moved.shape[0] // 4000)].tolist():
             assert cols[c][rr] == cols[int(cs.map_col[c, rr])][int(cs.map_row[c, rr])], (kind, c, rr)
+
+
+def test_uniform_shape_circuit_structure():
+    """the uniform-shape encrypt circuit (g^m over the message's bits in circuit: num_to_bits, per bit mul_mod + limb-wise select +
+    square_mod): the oracle's wired walk reproduces expand_uniform_circuit_cells' stream and is satisfied; the product's generator
+    (one (mul_mod, select, square_mod) template tiled per bit) gives the same mask, break points, selectors and sigma -- and the
+    structure does not depend on the message"""
+    import numpy as np
+
+    from paillier_halo2_amd import circuit_structure as CS
+
+    bits, W, lb, k = 128, 64, 13, 14
+    n, g, m, r = P.synth_paillier_inputs(bits, 0x51, standard_g=False)
+    res = P.paillier_enc_native(n, g, m, r)
+    wired = P.expand_circuit_cells_wired("encrypt_uniform", n, g, m, r, res, bits, W, lb, full=True)
+    adv, lk, seg = P.expand_uniform_circuit_cells(n, g, m, r, res, bits, W, lb)
+    assert wired["advice"] == adv and [adv[i] for i in wired["lookup_src"]] == lk and wired["satisfied"] == 1
+    st = CQ.build("encrypt_uniform", n, g, m, r, res, bits, W, lb, k)
+    assert CQ.mock_prover(st) == []
+    sa = CS.stream_structure("encrypt_uniform", bits, W, lb, 0, n)
+    cs, starts = CS.columns(sa, k, lb, device="cpu")
+    assert sa.n_steps_g == 2 * bits and starts.tolist() == st.starts and np.array_equal(cs.selectors, st.selectors)
+    Wd = st.n_adv + st.n_lk
+    keep = st.map_col[:Wd] < Wd
+    assert np.array_equal(cs.map_col[:Wd][keep], st.map_col[:Wd][keep]) and np.array_equal(cs.map_row[:Wd][keep], st.map_row[:Wd][keep])
+    # another message: the same structure (the reference's circuit would differ: paillier.rs:50-55)
+    m2 = (m * 7 + 3) % n
+    st2 = CQ.build("encrypt_uniform", n, g, m2, r, P.paillier_enc_native(n, g, m2, r), bits, W, lb, k)
+    assert np.array_equal(st2.map_col, st.map_col) and np.array_equal(st2.map_row, st.map_row) and np.array_equal(st2.selectors, st.selectors)
+    assert st2.adv_cols != st.adv_cols and CQ.mock_prover(st2) == []

@@ -372,3 +372,32 @@ def test_c2_structure_and_witness_agree_at_size(eng, cref):
     eng.sync()
     assert not h.any().item(), "an enabled gate does not hold inside its column"
     assert int(cs.selectors.sum()) > 10 ** 8
+
+
+def test_uniform_shape_circuit_connected_proof(eng, cref):
+    """the uniform-shape circuit (row f4: one key for every message) as a connected proof: K3's uniform schedule -> K4 kind 2 in
+    break-point columns (cell for cell against the oracle's columns) -> keygen from the product's structure -> THREE DISTINCT
+    messages proved under the one key, the last checked as the verifier would"""
+    import torch
+
+    import bench_connected
+
+    wl = bench_connected.ConnectedWorkload(eng, torch, 128, 14, 0x51, circuit="encrypt_uniform")
+    try:
+        nn, g, m, r = wl.ints
+        res = P.paillier_enc_native(nn, g, m, r)
+        st = CQ.build("encrypt_uniform", nn, g, m, r, res, 128, 64, 13, 14)
+        assert (wl.A, wl.Lk) == (st.n_adv, st.n_lk)
+        wl.produce()                       # the first proof's witness (on the witness context); run() below proves it first
+        torch.cuda.synchronize()
+        cols = wl.slots[0].cpu().numpy().view(np.uint64)
+        for j in range(st.n_adv):
+            assert cref.fr_mont_to_ints(cols[j]) == st.adv_cols[j], j
+        for j in range(st.n_lk):
+            assert cref.fr_mont_to_ints(cols[st.n_adv + j]) == st.lk_cols[j], j
+        msgs = {tuple(v[2].tolist()) for v in wl.variants}
+        assert len(msgs) == 3
+        wl.run(3, timed=False)
+        assert wl.verify(cref)["verified"] is True
+    finally:
+        wl.release()
