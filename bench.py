@@ -1540,6 +1540,9 @@ def main():
                 "verified": ver.get("verified") if ver else None, "verification": ver,
                 "phases_ms_per_proof": cw.phase_ms(1), "counts": cw.counts(), "memory_gb": cw.memory_gb,
                 "keygen_ms": cw.keygen_ms, "circuit_structure_ms": cw.structure_ms,
+                # what a NEW message costs with the reference's circuit (its bits are circuit structure, paillier.rs:50-55): structure +
+                # keygen of the real selectors / sigma + the proof -- `fresh_key` above times a stand-in keygen and no structure generation
+                "fresh_message_s": (sum(cw.structure_ms.values()) + cw.keygen_ms + dtc / c_steps * 1e3) / 1e3,
                 "note": "one connected proof per step: K3 -> K4 (break-point columns) -> advice commitments -> permuted lookup columns -> grand "
                         "products -> quotient (64-column tiles extended and folded as produced, against the resident extended proving key) -> h "
                         "pieces -> evaluations -> SHPLONK; five transcript round trips (commitments downloaded and hashed: a stand-in for halo2's "
