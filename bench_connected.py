@@ -31,7 +31,7 @@ class _Null:
 
 class ConnectedWorkload:
     def __init__(self, eng, torch, enc_bits: int, k: int, seed: int, lookup_bits=None, log=lambda s: None, tile: int = 64,
-                 circuit: str = "encrypt", pipeline=None):
+                 circuit: str = "encrypt", pipeline=None, cosets=None):
         import random
 
         import bench
@@ -85,7 +85,9 @@ class ConnectedWorkload:
         # ---- keygen_vk + keygen_pk: all three forms of the fixed and permutation polynomials, resident
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        self.pk = prover.keygen(eng, self.cs, self.bl, self.bm)
+        # the quotient from THREE cosets (its degree is below 3n) instead of halo2's 4n-point coset: PZ_CONNECTED_COSETS=4 for the A/B
+        self.cosets = int(os.environ.get("PZ_CONNECTED_COSETS", "3")) if cosets is None else int(cosets)
+        self.pk = prover.keygen(eng, self.cs, self.bl, self.bm, cosets=self.cosets)
         torch.cuda.synchronize()
         self.keygen_ms = (time.perf_counter() - t2) * 1e3
         torch.cuda.empty_cache()
@@ -109,9 +111,11 @@ class ConnectedWorkload:
         self.timings = {}
         self.last = None
         self.done = 0
-        pk_bytes = sum(t.numel() * 8 for t in (self.pk.fixed_ext, self.pk.sigma_ext, self.pk.fixed_coeff, self.pk.sigma_coeff, self.pk.sigma_lagrange))
-        self.memory_gb = {"proving_key_resident": pk_bytes / 1e9, "of_which_extended_forms": (self.pk.fixed_ext.numel() + self.pk.sigma_ext.numel()) * 8 / 1e9,
-                          "grand_products_extended": self.ws.z_ext.numel() * 8 / 1e9, "witness_columns": sum(t.numel() for t in self.slots) * 8 / 1e9,
+        ext_bytes = sum(t.numel() * 8 for t in self.pk.fixed_ext + self.pk.sigma_ext)
+        pk_bytes = ext_bytes + sum(t.numel() * 8 for t in (self.pk.fixed_coeff, self.pk.sigma_coeff, self.pk.sigma_lagrange))
+        self.memory_gb = {"proving_key_resident": pk_bytes / 1e9, "of_which_extended_forms": ext_bytes / 1e9,
+                          "quotient_domain_cosets": self.pk.dom.cosets,
+                          "grand_products_extended": sum(t.numel() for t in self.ws.z_ext) * 8 / 1e9, "witness_columns": sum(t.numel() for t in self.slots) * 8 / 1e9,
                           "torch_allocated_after_setup": torch.cuda.memory_allocated() / 1e9}
 
     def produce(self, eng=None):

@@ -441,7 +441,9 @@ int pz_quotient_lookup_dev(pz_ctx* ctx, const uint64_t* d_input_ext, size_t inpu
                            const uint64_t* d_l_active, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t y[4],
                            uint64_t* d_h);
 /* division by the vanishing polynomial on the extended coset: d_h[i] /= (coset_g * omega_ext^i)^(2^log_n) - 1,
- * i < 2^(log_n + log_e) (the divisor takes 2^log_e distinct values). */
+ * i < 2^(log_n + log_e) (the divisor takes 2^log_e distinct values; log_e = 0: the points are ONE coset of the 2^log_n-th roots and
+ * the divisor is the constant coset_g^n - 1 -- the prover evaluates a quotient of degree < 3n on three such cosets instead of halo2's
+ * 4n-point coset, paillier_halo2_amd/prover.py). */
 int pz_quotient_finish_dev(pz_ctx* ctx, uint64_t* d_h, uint32_t log_n, uint32_t log_e, const uint64_t coset_g[4],
                            const uint64_t omega_ext[4]);
 /* d_a[col][i] *= c * g^i, i < n (distribute_powers; with g = 1/coset_g the un-scaling step of extended_to_coeff).

@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void k_scale_periodic(Fr* __restrict__ h, size
 
 extern "C" int pz_quotient_finish_dev(pz_ctx* ctx, uint64_t* d_h, uint32_t log_n, uint32_t log_e, const uint64_t coset_g[4],
                                       const uint64_t omega_ext[4]) {
-    if (!ctx || !d_h || !coset_g || !omega_ext || log_e == 0 || log_e > 6 || log_n + log_e > 28) return PZ_ERR_INVALID;
+    if (!ctx || !d_h || !coset_g || !omega_ext || log_e > 6 || log_n + log_e > 28) return PZ_ERR_INVALID;   // log_e = 0: one coset of <omega_n>, a single divisor
     PZ_ENTER(ctx);
     const unsigned E = 1u << log_e;
     const size_t N = (size_t)1 << (log_n + log_e);

@@ -107,6 +107,7 @@ def _random_fr(gen, *shape):
 class Domain:
     k: int
     bf: int
+    cosets: int = 3
 
     def __post_init__(self):
         self.n = 1 << self.k
@@ -121,15 +122,31 @@ class Domain:
         self.N_inv = pow(self.N, -1, FR)
         self.coset_g = ZETA
         self.gens = np.stack([M(self.coset_g * pow(self.omega_ext, r, FR) % FR) for r in range(self.E)])
+        self.parts = self._parts(self.cosets)
+
+    def _parts(self, cosets: int):
+        """the points the quotient is evaluated on.  halo2 takes the whole extended coset g <w_4n> (4n points); the quotient has degree
+        below 3n, so THREE of its four cosets of <w_n> determine it: part A = g <w_2n> (the cosets r = 0 and r = 2 interleaved: a coset
+        of the 2n-th roots), part B = g w_4n <w_n> (r = 1).  Every kernel of evaluate_h is generic in (log of the domain, rows per
+        step, coset generator, domain generator), so a part is just another call; what changes is the way back to coefficients
+        (create_proof, "the quotient from three cosets").  cosets = 4: halo2's own domain as one part (kept for the A/B and the tests)."""
+        w4, g = self.omega_ext, self.coset_g
+        mk = lambda log_e, cg, om: dict(log_e=log_e, E=1 << log_e, size=self.n << log_e, coset_g=cg, omega=om, omega_inv=pow(om, -1, FR),
+                                        size_inv=pow(self.n << log_e, -1, FR),
+                                        gens=np.stack([M(cg * pow(om, r, FR) % FR) for r in range(1 << log_e)]))
+        if cosets == 4:
+            return [mk(2, g, w4)]
+        assert cosets == 3
+        return [mk(1, g, w4 * w4 % FR), mk(0, g * w4 % FR, pow(w4, 4, FR))]
 
 
 class ProvingKey:
     """fixed + permutation polynomials in all three forms, resident in HBM; the SRS tables"""
 
-    def __init__(self, eng: Engine, st: CircuitStructure, bases_lagrange: Bases, bases_monomial: Bases):
+    def __init__(self, eng: Engine, st: CircuitStructure, bases_lagrange: Bases, bases_monomial: Bases, cosets: int = 3):
         torch = _torch()
         self.eng, self.st = eng, st
-        self.dom = d = Domain(st.k, st.blinding_factors)
+        self.dom = d = Domain(st.k, st.blinding_factors, cosets)
         self.bases_lagrange, self.bases_monomial = bases_lagrange, bases_monomial
         n, N, A, m = d.n, d.N, st.n_adv, st.m
         assert st.max_rows <= d.usable and st.map_col.shape == (m, n) and st.selectors.shape == (A, n)
@@ -162,14 +179,19 @@ class ProvingKey:
         self.sigma_lagrange = sigma.clone()
         # ---- keygen_vk + keygen_pk: commitments, coefficient forms (in place), extended forms
         self.fixed_commit = _zeros(F, 12)
-        self.fixed_ext = _zeros(F, N, 4)
         self.sigma_commit = _zeros(m, 12)
-        self.sigma_ext = _zeros(m, N, 4)
+        P0 = d.parts[0]
+        self.fixed_ext = [_zeros(F, pt["size"], 4) for pt in d.parts]      # per part of the quotient's domain (Domain._parts)
+        self.sigma_ext = [_zeros(m, pt["size"], 4) for pt in d.parts]
         for t_, cnt_all, com, ext in ((fixed, F, self.fixed_commit, self.fixed_ext), (sigma, m, self.sigma_commit, self.sigma_ext)):
             for c0 in range(0, cnt_all, GB):
                 cnt = min(GB, cnt_all - c0)
-                eng.keygen_columns_dev(bases_lagrange, t_[c0].data_ptr(), cnt, 4 * n, st.k, LOG_E, M(d.omega), M(d.omega_inv), M(d.n_inv),
-                                       d.gens, com[c0].data_ptr(), ext[c0].data_ptr(), 4 * N)
+                eng.keygen_columns_dev(bases_lagrange, t_[c0].data_ptr(), cnt, 4 * n, st.k, P0["log_e"], M(d.omega), M(d.omega_inv), M(d.n_inv),
+                                       P0["gens"], com[c0].data_ptr(), ext[0][c0].data_ptr(), 4 * P0["size"])
+                for pi in range(1, len(d.parts)):     # the further parts from the coefficient form keygen_columns_dev left in place
+                    pt = d.parts[pi]
+                    eng.ntt_extend_dev(t_[c0].data_ptr(), cnt, 4 * n, ext[pi][c0].data_ptr(), 4 * pt["size"], st.k, pt["log_e"], M(d.omega),
+                                       pt["gens"], None)
         self.fixed_coeff = fixed
         self.sigma_coeff = sigma
         # ---- l_0, l_last, l_active on the extended coset
@@ -179,8 +201,9 @@ class ProvingKey:
         lrows[1, u] = one
         lrows[2, :u] = one
         eng.ntt_dev(lrows.data_ptr(), 3, 4 * n, M(d.omega_inv), st.k, None, M(d.n_inv))
-        self.l_ext = _zeros(3, N, 4)
-        eng.ntt_extend_dev(lrows.data_ptr(), 3, 4 * n, self.l_ext.data_ptr(), 4 * N, st.k, LOG_E, M(d.omega), d.gens, None)
+        self.l_ext = [_zeros(3, pt["size"], 4) for pt in d.parts]
+        for pi, pt in enumerate(d.parts):
+            eng.ntt_extend_dev(lrows.data_ptr(), 3, 4 * n, self.l_ext[pi].data_ptr(), 4 * pt["size"], st.k, pt["log_e"], M(d.omega), pt["gens"], None)
         eng.sync()
 
     def vk_commitments(self) -> Dict[str, np.ndarray]:
@@ -190,8 +213,8 @@ class ProvingKey:
         return {"fixed": jac(self.fixed_commit), "sigma": jac(self.sigma_commit)}
 
 
-def keygen(eng: Engine, st: CircuitStructure, bases_lagrange: Bases, bases_monomial: Bases) -> ProvingKey:
-    return ProvingKey(eng, st, bases_lagrange, bases_monomial)
+def keygen(eng: Engine, st: CircuitStructure, bases_lagrange: Bases, bases_monomial: Bases, cosets: int = 3) -> ProvingKey:
+    return ProvingKey(eng, st, bases_lagrange, bases_monomial, cosets)
 
 
 @dataclass
@@ -291,12 +314,14 @@ class Workspace:
         self.tile = tile
         self.Ap, self.Sp, self.Zl = _zeros(Lk, n, 4), _zeros(Lk, n, 4), _zeros(Lk, n, 4)
         self.Z = _zeros(S, n, 4)
-        self.z_ext = _zeros(S, N, 4)
-        self.ext = _zeros(tile, N, 4)
         lt = min(tile, Lk)
-        self.lk_ext = [_zeros(lt, N, 4) for _ in range(4)]
-        self.hh = _zeros(2, N, 4)
-        self.h = _zeros(N, 4)
+        self.z_ext = [_zeros(S, pt["size"], 4) for pt in d.parts]
+        self.ext = [_zeros(tile, pt["size"], 4) for pt in d.parts]
+        self.lk_ext = [[_zeros(lt, pt["size"], 4) for _ in range(4)] for pt in d.parts]
+        self.hh = [_zeros(2, pt["size"], 4) for pt in d.parts]
+        self.hp = [_zeros(pt["size"], 4) for pt in d.parts]
+        self.h = _zeros(N, 4)                     # the quotient's coefficients: pieces h_0, h_1, h_2 (and the vanishing h_3 with 4 cosets)
+        self.tmp = _zeros(2, n, 4)
         self.rnd = _zeros(1, n, 4)
         self.hcomb = _zeros(n, 4)
         self.w1, self.w2 = _zeros(n, 4), _zeros(n, 4)
@@ -345,8 +370,8 @@ def create_proof(pk: ProvingKey, cols, tr, seed: int = 0, tile: int = 64, hooks=
         for c0 in range(0, cnt, tile):
             eng.ntt_dev(t[c0].data_ptr(), min(tile, cnt - c0), 4 * n, M(d.omega_inv), k, None, M(d.n_inv))
 
-    def extend(src, cnt, dst):
-        eng.ntt_extend_dev(src.data_ptr(), cnt, 4 * n, dst.data_ptr(), 4 * N, k, LOG_E, M(d.omega), d.gens, None)
+    def extend(src, cnt, dst, pt):
+        eng.ntt_extend_dev(src.data_ptr(), cnt, 4 * n, dst.data_ptr(), 4 * pt["size"], k, pt["log_e"], M(d.omega), pt["gens"], None)
 
     # ---- 1. advice: blinding rows, commitments -> theta
     cols[:W, u:] = _random_fr(gen, W, n - u)
@@ -392,41 +417,65 @@ def create_proof(pk: ProvingKey, cols, tr, seed: int = 0, tile: int = 64, hooks=
     # ---- 4. quotient.  Lagrange -> coefficients for everything the proof opens (in place: the Lagrange forms are done with)
     for t, cnt in ((cols, m), (Ap, Lk), (Sp, Lk), (Z, S), (Zl, Lk)):
         to_coeff(t, cnt)
-    z_ext = ws.z_ext                            # all sets: the chaining lines read z_{j-1} beside z_j
-    for s0 in range(0, S, tile):
-        extend(Z[s0:s0 + tile], min(tile, S - s0), z_ext[s0:s0 + tile])
-    ws.hh.zero_()
-    hg, hp = ws.hh[0], ws.hh[1]                 # gate lines / permutation lines, folded apart and joined below: one pass over the tiles
-    ext = ws.ext
-    l0, llast, lact = (pk.l_ext[i].data_ptr() for i in range(3))
-    for c0 in range(0, m, tile):
-        cnt = min(tile, m - c0)
-        extend(cols[c0:c0 + cnt], cnt, ext)
-        na = max(0, min(A, c0 + cnt) - c0)      # advice columns of this tile carry the custom gate
-        if na:
-            eng.quotient_gate_dev(ext.data_ptr(), 4 * N, pk.fixed_ext[c0].data_ptr(), 4 * N, na, k + LOG_E, d.E, y, hg.data_ptr())
-        set_lo, nsets = c0 // CHUNK, -(-cnt // CHUNK)
-        eng.quotient_permutation_part_dev(ext.data_ptr(), 4 * N, pk.sigma_ext[c0].data_ptr(), 4 * N, z_ext.data_ptr(), 4 * N, S, set_lo, nsets,
-                                          CHUNK, cnt, c0 == 0, k + LOG_E, d.E, bf + 1, l0, llast, lact, beta, gamma, M(DELTA), M(d.coset_g),
-                                          M(d.omega_ext), y, hp.data_ptr())
-    # h = hg * y^(permutation lines) + hp, then the lookup lines on top
     n_perm_lines = 2 + (S - 1) + S
+    lt = ws.lk_ext[0][0].shape[0]
+    for pi, pt in enumerate(d.parts):           # the parts of the quotient's domain: one (halo2's 4n coset) or two (three cosets of <w_n>)
+        Np, lg, rot = pt["size"], k + pt["log_e"], pt["E"]
+        cg, om = M(pt["coset_g"]), M(pt["omega"])
+        z_ext = ws.z_ext[pi]                    # all sets: the chaining lines read z_{j-1} beside z_j
+        for s0 in range(0, S, tile):
+            extend(Z[s0:s0 + tile], min(tile, S - s0), z_ext[s0:s0 + tile], pt)
+        ws.hh[pi].zero_()
+        hg, hp = ws.hh[pi][0], ws.hh[pi][1]     # gate lines / permutation lines, folded apart and joined below: one pass over the tiles
+        ext = ws.ext[pi]
+        l0, llast, lact = (pk.l_ext[pi][i].data_ptr() for i in range(3))
+        for c0 in range(0, m, tile):
+            cnt = min(tile, m - c0)
+            extend(cols[c0:c0 + cnt], cnt, ext, pt)
+            na = max(0, min(A, c0 + cnt) - c0)  # advice columns of this tile carry the custom gate
+            if na:
+                eng.quotient_gate_dev(ext.data_ptr(), 4 * Np, pk.fixed_ext[pi][c0].data_ptr(), 4 * Np, na, lg, rot, y, hg.data_ptr())
+            set_lo, nsets = c0 // CHUNK, -(-cnt // CHUNK)
+            eng.quotient_permutation_part_dev(ext.data_ptr(), 4 * Np, pk.sigma_ext[pi][c0].data_ptr(), 4 * Np, z_ext.data_ptr(), 4 * Np, S, set_lo,
+                                              nsets, CHUNK, cnt, c0 == 0, lg, rot, bf + 1, l0, llast, lact, beta, gamma, M(DELTA), cg, om, y,
+                                              hp.data_ptr())
+        # h = hg * y^(permutation lines) + hp, then the lookup lines on top
+        hq = ws.hp[pi]
+        eng.fr_lincomb_dev(ws.hh[pi].data_ptr(), 2, 4 * Np, Np, M(pow(y_i, n_perm_lines, FR)), hq.data_ptr())
+        for l0_ in range(0, Lk, lt):
+            cnt = min(lt, Lk - l0_)
+            e_in, e_ap, e_sp, e_zl = ws.lk_ext[pi]
+            extend(cols[A + l0_:A + l0_ + cnt], cnt, e_in, pt)
+            extend(Ap[l0_:l0_ + cnt], cnt, e_ap, pt)
+            extend(Sp[l0_:l0_ + cnt], cnt, e_sp, pt)
+            extend(Zl[l0_:l0_ + cnt], cnt, e_zl, pt)
+            eng.quotient_lookup_dev(e_in.data_ptr(), 4 * Np, pk.fixed_ext[pi][A + 1].data_ptr(), e_ap.data_ptr(), 4 * Np, e_sp.data_ptr(), 4 * Np,
+                                    e_zl.data_ptr(), 4 * Np, cnt, lg, rot, l0, llast, lact, beta, gamma, y, hq.data_ptr())
+        eng.quotient_finish_dev(hq.data_ptr(), k, pt["log_e"], cg, om)
+        # back to coefficients on this part: the quotient modulo X^size - coset_g^size
+        eng.ntt_dev(hq.data_ptr(), 1, 4 * Np, M(pt["omega_inv"]), lg, None, M(pt["size_inv"]))
+        eng.fr_distribute_powers_dev(hq.data_ptr(), 1, 4 * Np, Np, M(pow(pt["coset_g"], -1, FR)))
     h = ws.h
-    eng.fr_lincomb_dev(ws.hh.data_ptr(), 2, 4 * N, N, M(pow(y_i, n_perm_lines, FR)), h.data_ptr())
-    lt = ws.lk_ext[0].shape[0]
-    for l0_ in range(0, Lk, lt):
-        cnt = min(lt, Lk - l0_)
-        e_in, e_ap, e_sp, e_zl = ws.lk_ext
-        extend(cols[A + l0_:A + l0_ + cnt], cnt, e_in)
-        extend(Ap[l0_:l0_ + cnt], cnt, e_ap)
-        extend(Sp[l0_:l0_ + cnt], cnt, e_sp)
-        extend(Zl[l0_:l0_ + cnt], cnt, e_zl)
-        eng.quotient_lookup_dev(e_in.data_ptr(), 4 * N, pk.fixed_ext[A + 1].data_ptr(), e_ap.data_ptr(), 4 * N, e_sp.data_ptr(), 4 * N,
-                                e_zl.data_ptr(), 4 * N, cnt, k + LOG_E, d.E, l0, llast, lact, beta, gamma, y, h.data_ptr())
-    eng.quotient_finish_dev(h.data_ptr(), k, LOG_E, M(d.coset_g), M(d.omega_ext))
-    eng.ntt_dev(h.data_ptr(), 1, 4 * N, M(d.omega_ext_inv), k + LOG_E, None, M(d.N_inv))
-    eng.fr_distribute_powers_dev(h.data_ptr(), 1, 4 * N, N, M(pow(d.coset_g, -1, FR)))
-    pieces = h.view(d.E, n, 4)                  # h(X) = sum_i X^(n i) h_i(X); degree <= 3n - 4: piece 3 and the top of piece 2 vanish
+    pieces = h.view(d.E, n, 4)                  # h(X) = sum_i X^(n i) h_i(X); degree <= 3n - 4
+    if len(d.parts) == 1:
+        h.copy_(ws.hp[0])                       # halo2's domain: the 4n coefficients themselves (piece 3 and the top of piece 2 vanish)
+    else:
+        # the quotient from three cosets.  With deg h < 3n:  on part A (g <w_2n>) X^2n = g^2n, so the 2n coefficients found there are
+        # [U | h_1] with U = h_0 + g^2n h_2;  on part B (the coset of <w_n> by c = g w_4n) X^n = c^n =: lam (lam^2 = -g^2n), so the n
+        # coefficients found there are V = h_0 + lam h_1 - g^2n h_2.  Hence h_2 = (U - V + lam h_1) / (2 g^2n), h_0 = U - g^2n h_2.
+        g2n = pow(d.coset_g, 2 * n, FR)
+        lam = pow(d.parts[1]["coset_g"], n, FR)
+        U, h1, V = ws.hp[0][:n], ws.hp[0][n:], ws.hp[1]
+        pieces[1].copy_(h1)
+        t01 = ws.tmp
+        t01[0].copy_(h1); t01[1].copy_(V)
+        eng.fr_lincomb_dev(t01.data_ptr(), 2, 4 * n, n, M(-lam % FR), pieces[2].data_ptr())            # T = V - lam h_1
+        t01[0].copy_(pieces[2]); t01[1].copy_(U)
+        eng.fr_lincomb_dev(t01.data_ptr(), 2, 4 * n, n, M(FR - 1), pieces[2].data_ptr())               # U - T
+        eng.fr_distribute_powers_dev(pieces[2].data_ptr(), 1, 4 * n, n, M(1), M(pow(2 * g2n, -1, FR)))     # h_2
+        t01[0].copy_(pieces[2]); t01[1].copy_(U)
+        eng.fr_lincomb_dev(t01.data_ptr(), 2, 4 * n, n, M(-g2n % FR), pieces[0].data_ptr())            # h_0 = U - g^2n h_2
+        pieces[3].zero_()
     c_h = commit(bm, pieces, d.E - 1, 4 * n)
     tr.absorb_points(eng, c_h)
     x_i = tr.squeeze("x")
@@ -483,7 +532,10 @@ def create_proof(pk: ProvingKey, cols, tr, seed: int = 0, tile: int = 64, hooks=
     pr.evals = {"advice": ev["advice"], "lookup_advice": ev["lookup_advice"][:Lk], "constants": ev["lookup_advice"][Lk:], "fixed": ev["fixed"],
                 "sigma": ev["sigma"], "perm_z": ev["perm_z"], "lookup_z": ev["lookup_z"], "perm_inputs": ev["perm_inputs"],
                 "perm_tables": ev["perm_tables"], "random": ev["random"], "h": ev["h"]}
-    top = host(h[3 * n - 3:])
+    # degree <= 3n - 4.  With halo2's domain: every coefficient from 3n - 3 to 4n - 1; from three cosets the interpolation has only 3n
+    # coefficients, of which the top three must vanish (an unsatisfied witness fails this with probability 1 - 2^-760, and the
+    # identity at x below it in any case)
+    top = host(h[3 * n - 3:] if len(d.parts) == 1 else h[3 * n - 3:3 * n])
     pr.h_top = top
     pr.h_degree_ok = not top.any()
     phase("finalise")

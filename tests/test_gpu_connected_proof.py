@@ -86,8 +86,9 @@ def world(eng, cref):
     keep = st.map_col[:W_] < W_
     assert np.array_equal(cs.map_col[:W_][keep], st.map_col[:W_][keep]) and np.array_equal(cs.map_row[:W_][keep], st.map_row[:W_][keep])
     pk = prover.keygen(eng, cs, bl, bm)
+    pk4 = prover.keygen(eng, cs, bl, bm, cosets=4)       # the same key over halo2's own 4n-point quotient domain
     ch = prover.Challenges(*(rng.randrange(2, R) for _ in range(8)))
-    yield dict(st=st, pk=pk, ch=ch, witness=witness, s_tox=s_tox, inputs=(nn, g, m, r, res))
+    yield dict(st=st, pk=pk, pk4=pk4, ch=ch, witness=witness, s_tox=s_tox, inputs=(nn, g, m, r, res))
     bl.free()
     bm.free()
 
@@ -135,7 +136,7 @@ def test_connected_proof_satisfies_the_verifier(eng, cref, world):
     from paillier_halo2_amd import prover
 
     pr = prover.create_proof(world["pk"], world["witness"](), world["ch"], seed=1, tile=8)     # 34 columns in five tiles
-    assert pr.h_top is not None and pr.h_top.shape[0] == (1 << K) + 3
+    assert pr.h_top is not None and pr.h_top.shape[0] == 3
     deg, ident, opening = _verify(cref, world, pr)
     assert deg, "quotient degree > 3n - 4"
     assert ident, "h(x) (x^n - 1) != the constraint expression of the evaluations"
@@ -147,6 +148,14 @@ def test_connected_proof_satisfies_the_verifier(eng, cref, world):
         assert np.array_equal(pr.commitments[kname], pr2.commitments[kname]), kname
     for kname in pr.evals:
         assert np.array_equal(pr.evals[kname], pr2.evals[kname]), kname
+    # the quotient from THREE cosets of <w_n> (the default: deg h < 3n) is the quotient halo2 computes on its 4n-point coset: the same
+    # pieces, the same commitments, the same openings -- byte for byte
+    pr4 = prover.create_proof(world["pk4"], world["witness"](), world["ch"], seed=1, tile=8)
+    assert pr4.h_top.shape[0] == (1 << K) + 3 and pr4.h_degree_ok
+    for kname in pr.commitments:
+        assert np.array_equal(pr.commitments[kname], pr4.commitments[kname]), kname
+    for kname in pr.evals:
+        assert np.array_equal(pr.evals[kname], pr4.evals[kname]), kname
 
 
 def test_connected_proof_with_a_hashing_transcript(eng, cref, world):
