@@ -70,22 +70,28 @@ def test_lagrange_values_of_the_verifier():
 def test_product_structure_generator_equals_the_oracle_restatement():
     """paillier_halo2_amd/circuit_structure.py (a value-free walk of one mul_mod block, tiled) against oracle/circuit.py (a walk of the
     whole circuit WITH values): gate mask, break points, selectors, lookup sources and sigma, for the reference's encrypt shape, a
-    larger lookup width, a 3-limb key and the add circuit on 88-bit limbs (paillier.rs:186-187)"""
+    larger lookup width, a 3-limb key, the add circuit on 88-bit limbs (paillier.rs:186-187), 48-bit limbs, and the uniform-shape
+    circuit on 88-bit limbs"""
     import numpy as np
 
     from paillier_halo2_amd import circuit_structure as CS
 
     for bits, W, lb, k, seed, kind in ((128, 64, 13, 14, 0x5042, "encrypt"), (128, 64, 15, 16, 0x77, "encrypt"), (264, 88, 12, 13, 0x99, "add"),
-                                       (192, 64, 11, 14, 0x31, "encrypt")):
+                                       (192, 64, 11, 14, 0x31, "encrypt"), (96, 48, 9, 13, 0x62, "encrypt"), (176, 88, 12, 16, 0x63, "encrypt_uniform")):
         n, g, m, r = P.synth_paillier_inputs(bits, seed, standard_g=False)
-        res = P.paillier_enc_native(n, g, m, r) if kind == "encrypt" else P.paillier_add_native(n, m, r)
+        res = P.paillier_add_native(n, m, r) if kind == "add" else P.paillier_enc_native(n, g, m, r)
         st = CQ.build(kind, n, g, m, r, res, bits, W, lb, k)
         sa = CS.stream_structure(kind, bits, W, lb, m, n)
         cs, starts = CS.columns(sa, k, lb, device="cpu")
-        ng = m.bit_length() + bin(m).count("1") if kind == "encrypt" else 0
-        nr = n.bit_length() + bin(n).count("1") if kind == "encrypt" else 0
+        ng = m.bit_length() + bin(m).count("1") if kind == "encrypt" else 2 * bits if kind == "encrypt_uniform" else 0
+        nr = n.bit_length() + bin(n).count("1") if kind != "add" else 0
         assert (sa.n_steps_g, sa.n_steps_r) == (ng, nr)
-        mask, _ = P.gate_mask_circuit(kind, bits, W, lb, ng, nr)
+        if kind == "encrypt_uniform":
+            gl, tot_ = P.gate_offsets_uniform_circuit(bits, W, lb, nr)
+            mask = np.zeros(tot_, dtype=np.uint8)
+            mask[np.asarray(gl, dtype=np.int64)] = 1
+        else:
+            mask, _ = P.gate_mask_circuit(kind, bits, W, lb, ng, nr)
         assert np.array_equal(mask, sa.gate_mask) and starts.tolist() == st.starts and np.array_equal(cs.selectors, st.selectors)
         assert sa.n_cells == st.n_cells and sa.lookup_src.shape[0] == st.n_lookups and cs.n_lk == st.n_lk
         assert sorted(cs.constants) == sorted(st.constants)
