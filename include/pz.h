@@ -101,6 +101,9 @@ int pz_dev_memset(pz_ctx* ctx, void* d_dst, int byte_value, size_t bytes);
 /* asynchronous device -> device copy on the context's stream (e.g. a column's Lagrange values into the buffer its coefficient
  * form is computed in) */
 int pz_dev_copy(pz_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
+/* the same for `rows` runs of `width` bytes, the runs dst_pitch / src_pitch bytes apart (a prover fills the blinding rows at the end
+ * of every column of a proof from one staged block of random elements) */
+int pz_dev_copy_2d(pz_ctx* ctx, void* d_dst, size_t dst_pitch, const void* d_src, size_t src_pitch, size_t width, size_t rows);
 /* order two contexts of one device: everything queued on `producer`'s stream so far happens before whatever `waiter` queues
  * from now on (an event wait, no host synchronisation) */
 int pz_ctx_wait(pz_ctx* waiter, pz_ctx* producer);

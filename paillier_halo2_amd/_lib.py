@@ -34,6 +34,7 @@ SIGNATURES = {
     "pz_download": (C.c_int, [VP, VP, VP, C.c_size_t]),
     "pz_dev_memset": (C.c_int, [VP, VP, C.c_int, C.c_size_t]),
     "pz_dev_copy": (C.c_int, [VP, VP, VP, C.c_size_t]),
+    "pz_dev_copy_2d": (C.c_int, [VP, VP, C.c_size_t, VP, C.c_size_t, C.c_size_t, C.c_size_t]),
     "pz_ctx_wait": (C.c_int, [VP, VP]),
     "pz_srs_load_g1": (C.c_int, [VP, C.c_uint32, VP, C.c_int, C.POINTER(VP)]),
     "pz_bases_load_g1": (C.c_int, [VP, VP, C.c_size_t, C.c_int, C.c_uint32, C.POINTER(VP)]),

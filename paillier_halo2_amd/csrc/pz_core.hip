@@ -190,6 +190,15 @@ extern "C" int pz_dev_copy(pz_ctx* ctx, void* d_dst, const void* d_src, size_t b
     HIPCHK(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return PZ_OK;
 }
+// `rows` runs of `width` bytes, the runs dst_pitch / src_pitch bytes apart: the blinding rows of a proof's columns (a few rows at
+// the end of every 2^k-row column) filled from one staged block
+extern "C" int pz_dev_copy_2d(pz_ctx* ctx, void* d_dst, size_t dst_pitch, const void* d_src, size_t src_pitch, size_t width, size_t rows) {
+    if (!ctx || (width && rows && (!d_dst || !d_src)) || dst_pitch < width || src_pitch < width) return PZ_ERR_INVALID;
+    if (!width || !rows) return PZ_OK;
+    PZ_ENTER(ctx);
+    HIPCHK(ctx, hipMemcpy2DAsync(d_dst, dst_pitch, d_src, src_pitch, width, rows, hipMemcpyDeviceToDevice, ctx->stream));
+    return PZ_OK;
+}
 // everything queued on `producer`'s stream so far happens before whatever `waiter` queues from now on (an event, no host
 // synchronisation): how a host with several contexts -- witness / commitments / transforms, each with its own stream -- orders a
 // buffer one context writes and another reads

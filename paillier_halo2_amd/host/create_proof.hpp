@@ -1,0 +1,541 @@
+// create_proof.hpp -- the prover's phases composed in create_proof's order from plain C++ over the C ABI (include/pz.h) only: no torch,
+// no HIP call of its own.  The compiled-language counterpart of paillier_halo2_amd/prover.py (same phases, same entry points, same
+// three-coset quotient: DESIGN.md section 6.3) -- what a reference prover patched at point D of INTEGRATION.md runs between
+// /root/reference/src/bench.rs:161 and :171 (bench_builder -> keygen -> gen_proof):
+//
+//   keygen        fixed columns (selectors, constants, table) and the sigma polynomials of the circuit's copy constraints: commitments,
+//                 coefficient forms, extended forms on the quotient's three cosets, resident in HBM
+//   create_proof  advice commitments -> permuted lookup columns -> grand products -> quotient (tiles of columns extended and folded as
+//                 produced) -> h pieces -> evaluations -> SHPLONK, a transcript round trip (synchronising download + hash) per phase
+//
+// The circuit STRUCTURE (selectors, copy-constraint map, constants, break points) is an input, as in prover.py: the dependency's keygen
+// knows it; tests hand over what paillier_halo2_amd/circuit_structure.py generates.  Device memory through pz_dev_alloc only.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pz.h"
+#include "fr_host.hpp"
+
+namespace pzp {
+using pzh::Fr;
+
+#define PZP_CK(x)                                                                                          \
+    do {                                                                                                   \
+        int rc_ = (x);                                                                                     \
+        if (rc_ != PZ_OK) {                                                                                \
+            fprintf(stderr, "%s:%d: %s -> %d (%s)\n", __FILE__, __LINE__, #x, rc_, pz_strerror(rc_));      \
+            exit(2);                                                                                       \
+        }                                                                                                  \
+    } while (0)
+
+static const unsigned CHUNK = 2;   // permutation columns per grand product: degree - 2
+
+struct Structure {   // what keygen derives from the circuit (INPUT)
+    unsigned k = 0, lookup_bits = 0, blinding_factors = 6;
+    size_t max_rows = 0, n_adv = 0, n_lk = 0;
+    std::vector<uint8_t> selectors;          // [n_adv][2^k]
+    std::vector<uint64_t> constants;         // canonical integers, 4 words each
+    std::vector<uint32_t> map_col, map_row;  // [m][2^k]
+    std::vector<uint64_t> starts;            // n_adv + 1 (the break-point layout K4 writes the advice stream in)
+    size_t m() const { return n_adv + n_lk + 1; }
+};
+
+struct Part {   // a part of the quotient's domain (prover.py Domain._parts): part A = g <w_2n>, part B = g w_4n <w_n>
+    unsigned log_e;
+    size_t size;
+    Fr coset_g, omega, omega_inv, size_inv;
+    std::vector<uint64_t> gens;   // 2^log_e x 4 words
+};
+
+struct Dev {   // a device buffer of Fr elements (or points), freed with the key / workspace
+    uint64_t* p = nullptr;
+    size_t words = 0;
+};
+
+struct Domain {
+    unsigned k, bf;
+    size_t n, usable;
+    Fr omega, omega_inv, n_inv, omega4, coset_g;
+    std::vector<Part> parts;
+    Domain(unsigned k_, unsigned bf_) : k(k_), bf(bf_) {
+        n = (size_t)1 << k;
+        usable = n - (bf + 1);
+        omega = pzh::omega(k);
+        omega_inv = pzh::inv(omega);
+        n_inv = pzh::inv(pzh::from_u64(n));
+        omega4 = pzh::omega(k + 2);
+        coset_g = pzh::zeta();
+        auto mk = [&](unsigned log_e, const Fr& cg, const Fr& om) {
+            Part p;
+            p.log_e = log_e;
+            p.size = n << log_e;
+            p.coset_g = cg;
+            p.omega = om;
+            p.omega_inv = pzh::inv(om);
+            p.size_inv = pzh::inv(pzh::from_u64(p.size));
+            Fr x = cg;
+            for (unsigned r = 0; r < (1u << log_e); ++r) {
+                p.gens.insert(p.gens.end(), x.v, x.v + 4);
+                x = pzh::mul(x, om);
+            }
+            return p;
+        };
+        parts.push_back(mk(1, coset_g, pzh::mul(omega4, omega4)));
+        parts.push_back(mk(0, pzh::mul(coset_g, omega4), omega));
+    }
+};
+
+class Ctx {
+  public:
+    pz_ctx* c = nullptr;
+    std::vector<void*> owned;
+    uint64_t* alloc(size_t words) {
+        void* d = nullptr;
+        PZP_CK(pz_dev_alloc(c, words * 8, &d));
+        PZP_CK(pz_dev_memset(c, d, 0, words * 8));
+        owned.push_back(d);
+        return (uint64_t*)d;
+    }
+    void release() {
+        for (void* d : owned) pz_dev_free(c, d);
+        owned.clear();
+    }
+};
+
+struct ProvingKey {
+    Structure st;
+    Domain dom;
+    size_t n_sets = 0, F = 0;
+    const pz_bases *bl = nullptr, *bm = nullptr;
+    uint64_t *fixed_coeff = nullptr, *sigma_coeff = nullptr, *sigma_lagrange = nullptr, *const_lagrange = nullptr, *table_lagrange = nullptr;
+    uint64_t *fixed_ext[2] = {nullptr, nullptr}, *sigma_ext[2] = {nullptr, nullptr}, *l_ext[2] = {nullptr, nullptr};
+    std::vector<uint64_t> fixed_commit, sigma_commit;   // affine, 8 words each
+    ProvingKey(const Structure& s) : st(s), dom(s.k, s.blinding_factors) {}
+};
+
+inline void upload_mont(Ctx& cx, uint64_t* d, const std::vector<Fr>& v) {
+    PZP_CK(pz_upload(cx.c, d, v.data(), v.size() * 32));
+}
+
+inline ProvingKey* keygen(Ctx& cx, const Structure& st, const pz_bases* bl, const pz_bases* bm) {
+    ProvingKey* pk = new ProvingKey(st);
+    Domain& d = pk->dom;
+    const size_t n = d.n, A = st.n_adv, m = st.m(), F = A + 2;
+    pk->bl = bl; pk->bm = bm; pk->F = F;
+    pk->n_sets = (m + CHUNK - 1) / CHUNK;
+    // fixed columns [selectors | constants | table], Lagrange form, built on the host and uploaded column by column
+    uint64_t* fixed = cx.alloc(F * n * 4);
+    {
+        std::vector<Fr> col(n);
+        const Fr zero = {{0, 0, 0, 0}};
+        for (size_t j = 0; j < A; ++j) {
+            for (size_t i = 0; i < n; ++i) col[i] = st.selectors[j * n + i] ? pzh::FR_ONE : zero;
+            upload_mont(cx, fixed + j * n * 4, col);
+        }
+        for (size_t i = 0; i < n; ++i) col[i] = i < st.constants.size() / 4 ? pzh::from_raw(&st.constants[4 * i]) : zero;
+        upload_mont(cx, fixed + A * n * 4, col);
+        for (size_t i = 0; i < n; ++i) col[i] = i < ((size_t)1 << st.lookup_bits) ? pzh::from_u64(i) : zero;
+        upload_mont(cx, fixed + (A + 1) * n * 4, col);
+    }
+    pk->const_lagrange = cx.alloc(n * 4);
+    pk->table_lagrange = cx.alloc(n * 4);
+    PZP_CK(pz_dev_copy(cx.c, pk->const_lagrange, fixed + A * n * 4, n * 32));
+    PZP_CK(pz_dev_copy(cx.c, pk->table_lagrange, fixed + (A + 1) * n * 4, n * 32));
+    // sigma from the copy-constraint map (one call over all m columns)
+    uint64_t* sigma = cx.alloc(m * n * 4);
+    {
+        void *dmc = nullptr, *dmr = nullptr;
+        PZP_CK(pz_dev_alloc(cx.c, m * n * 4, &dmc));
+        PZP_CK(pz_dev_alloc(cx.c, m * n * 4, &dmr));
+        PZP_CK(pz_upload(cx.c, dmc, st.map_col.data(), m * n * 4));
+        PZP_CK(pz_upload(cx.c, dmr, st.map_row.data(), m * n * 4));
+        const Fr delta = pzh::delta();
+        PZP_CK(pz_permutation_sigma_dev(cx.c, (const uint32_t*)dmc, (const uint32_t*)dmr, m, st.k, d.omega.v, delta.v, sigma, 4 * n));
+        PZP_CK(pz_sync(cx.c));
+        pz_dev_free(cx.c, dmc);
+        pz_dev_free(cx.c, dmr);
+    }
+    pk->sigma_lagrange = cx.alloc(m * n * 4);
+    PZP_CK(pz_dev_copy(cx.c, pk->sigma_lagrange, sigma, m * n * 32));
+    // keygen_vk + keygen_pk: commitments, coefficient forms in place, extended forms per part
+    uint64_t* com_f = cx.alloc(F * 12);
+    uint64_t* com_s = cx.alloc(m * 12);
+    for (int pi = 0; pi < 2; ++pi) {
+        pk->fixed_ext[pi] = cx.alloc(F * d.parts[pi].size * 4);
+        pk->sigma_ext[pi] = cx.alloc(m * d.parts[pi].size * 4);
+        pk->l_ext[pi] = cx.alloc(3 * d.parts[pi].size * 4);
+    }
+    struct Job { uint64_t* cols; size_t cnt; uint64_t* com; uint64_t** ext; };
+    Job jobs[2] = {{fixed, F, com_f, pk->fixed_ext}, {sigma, m, com_s, pk->sigma_ext}};
+    for (auto& jb : jobs) {
+        for (size_t c0 = 0; c0 < jb.cnt; c0 += 256) {
+            const size_t cnt = jb.cnt - c0 < 256 ? jb.cnt - c0 : 256;
+            const Part& A_ = d.parts[0];
+            PZP_CK(pz_keygen_columns_dev(cx.c, bl, jb.cols + c0 * n * 4, cnt, 4 * n, st.k, A_.log_e, d.omega.v, d.omega_inv.v, d.n_inv.v, A_.gens.data(),
+                                         jb.com + c0 * 12, jb.ext[0] + c0 * A_.size * 4, 4 * A_.size));
+            const Part& B_ = d.parts[1];
+            PZP_CK(pz_ntt_fr_extend_dev(cx.c, jb.cols + c0 * n * 4, cnt, 4 * n, jb.ext[1] + c0 * B_.size * 4, 4 * B_.size, st.k, B_.log_e, d.omega.v,
+                                        B_.gens.data(), nullptr));
+        }
+    }
+    pk->fixed_coeff = fixed;
+    pk->sigma_coeff = sigma;
+    // l_0, l_last, l_active
+    {
+        uint64_t* lrows = cx.alloc(3 * n * 4);
+        std::vector<Fr> col(n);
+        const Fr zero = {{0, 0, 0, 0}};
+        for (int w = 0; w < 3; ++w) {
+            for (size_t i = 0; i < n; ++i) col[i] = (w == 0 ? i == 0 : w == 1 ? i == d.usable : i < d.usable) ? pzh::FR_ONE : zero;
+            upload_mont(cx, lrows + (size_t)w * n * 4, col);
+        }
+        PZP_CK(pz_ntt_fr_dev(cx.c, lrows, 3, 4 * n, d.omega_inv.v, st.k, nullptr, d.n_inv.v));
+        for (int pi = 0; pi < 2; ++pi)
+            PZP_CK(pz_ntt_fr_extend_dev(cx.c, lrows, 3, 4 * n, pk->l_ext[pi], 4 * d.parts[pi].size, st.k, d.parts[pi].log_e, d.omega.v,
+                                        d.parts[pi].gens.data(), nullptr));
+    }
+    // the verifying key's commitments, affine
+    std::vector<uint64_t> jac(12 * (F > m ? F : m));
+    pk->fixed_commit.resize(8 * F);
+    pk->sigma_commit.resize(8 * m);
+    PZP_CK(pz_download(cx.c, jac.data(), com_f, F * 96));
+    PZP_CK(pz_g1_normalize(cx.c, jac.data(), F, pk->fixed_commit.data()));
+    PZP_CK(pz_download(cx.c, jac.data(), com_s, m * 96));
+    PZP_CK(pz_g1_normalize(cx.c, jac.data(), m, pk->sigma_commit.data()));
+    return pk;
+}
+
+// ---- transcript: every phase's commitments come to the host in affine form (a synchronising download) and are hashed; a challenge is
+// the running hash expanded to 252 bits.  The dataflow and round trips of halo2's Blake2b transcript, not its byte format.
+struct Transcript {
+    uint64_t h = 0xcbf29ce484222325ULL;
+    std::vector<std::pair<std::string, Fr>> drawn;       // (name, canonical value as 4 words)
+    void absorb(const void* data, size_t bytes) {
+        const uint8_t* p = (const uint8_t*)data;
+        for (size_t i = 0; i < bytes; ++i) {
+            h ^= p[i];
+            h *= 0x100000001b3ULL;
+        }
+    }
+    void absorb_points(Ctx& cx, const uint64_t* d_jac, size_t count, std::vector<uint64_t>* keep_affine = nullptr) {
+        std::vector<uint64_t> jac(12 * count), aff(8 * count);
+        PZP_CK(pz_download(cx.c, jac.data(), d_jac, count * 96));
+        PZP_CK(pz_g1_normalize(cx.c, jac.data(), count, aff.data()));
+        absorb(aff.data(), aff.size() * 8);
+        if (keep_affine) keep_affine->insert(keep_affine->end(), aff.begin(), aff.end());
+    }
+    Fr squeeze(const char* name) {   // -> Montgomery form; the canonical words are recorded for the checker
+        absorb(name, strlen(name));
+        uint64_t w[4], s = h;
+        for (int i = 0; i < 4; ++i) {   // splitmix64 expansion of the running hash
+            s += 0x9e3779b97f4a7c15ULL;
+            uint64_t z = s;
+            z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+            z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+            w[i] = z ^ (z >> 31);
+        }
+        w[3] &= 0x0fffffffffffffffULL;   // < 2^252 < r
+        w[0] |= 2;                       // not 0 or 1
+        Fr c;
+        memcpy(c.v, w, 32);
+        drawn.push_back({name, c});
+        h = s;
+        return pzh::from_raw(w);
+    }
+};
+
+struct Proof {
+    std::vector<std::pair<std::string, std::vector<uint64_t>>> commitments;   // family -> affine points (8 words each)
+    std::vector<std::pair<std::string, std::vector<uint64_t>>> evals;         // family -> [count][points][4] Montgomery
+    std::vector<std::pair<std::string, uint32_t>> eval_points;                // family -> points per polynomial
+    bool h_degree_ok = false;
+};
+
+struct Workspace {
+    uint64_t *Ap, *Sp, *Zl, *Z, *z_ext[2], *ext[2], *lk_ext[2][4], *hh[2], *hp[2], *h, *tmp, *rnd, *hcomb, *w1, *w2, *blind, *out12, *evals;
+    size_t tile, lt;
+};
+
+inline Workspace make_workspace(Ctx& cx, const ProvingKey& pk, size_t tile = 64) {
+    const Domain& d = pk.dom;
+    const size_t n = d.n, Lk = pk.st.n_lk, S = pk.n_sets, m = pk.st.m();
+    Workspace w;
+    w.tile = tile;
+    w.lt = tile < Lk ? tile : Lk;
+    w.Ap = cx.alloc(Lk * n * 4); w.Sp = cx.alloc(Lk * n * 4); w.Zl = cx.alloc(Lk * n * 4);
+    w.Z = cx.alloc(S * n * 4);
+    for (int pi = 0; pi < 2; ++pi) {
+        const size_t Np = d.parts[pi].size;
+        w.z_ext[pi] = cx.alloc(S * Np * 4);
+        w.ext[pi] = cx.alloc(tile * Np * 4);
+        for (int q = 0; q < 4; ++q) w.lk_ext[pi][q] = cx.alloc(w.lt * Np * 4);
+        w.hh[pi] = cx.alloc(2 * Np * 4);
+        w.hp[pi] = cx.alloc(Np * 4);
+    }
+    w.h = cx.alloc(4 * n * 4);
+    w.tmp = cx.alloc(2 * n * 4);
+    w.rnd = cx.alloc(n * 4);
+    w.hcomb = cx.alloc(n * 4);
+    w.w1 = cx.alloc(n * 4);
+    w.w2 = cx.alloc(n * 4);
+    w.blind = cx.alloc((m + S + 3 * Lk) * (d.bf + 1) * 4 + n * 4);
+    w.out12 = cx.alloc((m + S + 8) * 12);
+    w.evals = cx.alloc((4 * m + 4 * S + 16) * 4 * 4);
+    return w;
+}
+
+// blinding values: uniform 252-bit integers as Montgomery representatives (all below r), from a seeded xorshift
+struct Rng {
+    uint64_t s;
+    explicit Rng(uint64_t seed) : s(seed * 0x9e3779b97f4a7c15ULL + 1) {}
+    uint64_t next() {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        return s;
+    }
+    void fill(std::vector<uint64_t>& v) {
+        for (size_t i = 0; i < v.size(); ++i) v[i] = next();
+        for (size_t i = 3; i < v.size(); i += 4) v[i] &= 0x0fffffffffffffffULL;
+    }
+};
+
+// rows [row0, n) of `count` columns (stride n elements) <- random elements
+inline void blind_rows(Ctx& cx, Workspace& w, Rng& rng, uint64_t* d_cols, size_t count, size_t n, size_t row0) {
+    const size_t rows = n - row0;
+    std::vector<uint64_t> host(count * rows * 4);
+    rng.fill(host);
+    PZP_CK(pz_upload(cx.c, w.blind, host.data(), host.size() * 8));
+    PZP_CK(pz_dev_copy_2d(cx.c, d_cols + row0 * 4, n * 32, w.blind, rows * 32, rows * 32, count));
+}
+
+inline Fr pow_small(const Fr& a, uint64_t e) { return pzh::pow_u64(a, e); }
+
+// d_cols: [m][2^k] elements: advice then lookup-advice columns as K4 wrote them; consumed (ends in coefficient form)
+inline Proof create_proof(Ctx& cx, ProvingKey& pk, Workspace& w, uint64_t* d_cols, Transcript& tr, uint64_t seed) {
+    const Structure& st = pk.st;
+    const Domain& d = pk.dom;
+    const size_t n = d.n, u = d.usable, A = st.n_adv, Lk = st.n_lk, m = st.m(), S = pk.n_sets, W = A + Lk, tile = w.tile;
+    const unsigned k = d.k, bf = d.bf;
+    Rng rng(seed);
+    Proof pr;
+    auto commit = [&](const pz_bases* b, const uint64_t* t, size_t count, uint64_t* out) {
+        uint32_t nw = 0, cb = 0;
+        size_t np = 0;
+        PZP_CK(pz_bases_info(b, &np, &cb, &nw));
+        PZP_CK(pz_msm_g1_dev(cx.c, b, t, count, n, 4 * n, 0, nw, out));
+    };
+    auto keep = [&](const char* name, const uint64_t* d_jac, size_t count) {
+        std::vector<uint64_t> aff;
+        tr.absorb_points(cx, d_jac, count, &aff);
+        pr.commitments.push_back({name, aff});
+    };
+    const Fr delta = pzh::delta();
+    // ---- 1. advice
+    blind_rows(cx, w, rng, d_cols, W, n, u);
+    PZP_CK(pz_dev_copy(cx.c, d_cols + W * n * 4, pk.const_lagrange, n * 32));
+    uint64_t* c_adv = w.out12;
+    commit(pk.bl, d_cols, W, c_adv);
+    {
+        std::vector<uint64_t> aff;
+        tr.absorb_points(cx, c_adv, W, &aff);
+        pr.commitments.push_back({"advice", std::vector<uint64_t>(aff.begin(), aff.begin() + 8 * A)});
+        pr.commitments.push_back({"lookup_advice", std::vector<uint64_t>(aff.begin() + 8 * A, aff.end())});
+    }
+    tr.squeeze("theta");
+    // ---- 2. lookups
+    uint64_t* lk_in = d_cols + A * n * 4;
+    PZP_CK(pz_lookup_permute_dev(cx.c, lk_in, Lk, 4 * n, pk.table_lagrange, u, st.lookup_bits, w.Ap, w.Sp, 4 * n));
+    blind_rows(cx, w, rng, w.Ap, Lk, n, u);
+    blind_rows(cx, w, rng, w.Sp, Lk, n, u);
+    commit(pk.bl, w.Ap, Lk, w.out12);
+    keep("perm_inputs", w.out12, Lk);
+    commit(pk.bl, w.Sp, Lk, w.out12);
+    keep("perm_tables", w.out12, Lk);
+    const Fr beta = tr.squeeze("beta"), gamma = tr.squeeze("gamma");
+    // ---- 3. grand products
+    PZP_CK(pz_permutation_product_sets_dev(cx.c, d_cols, 4 * n, pk.sigma_lagrange, 4 * n, m, CHUNK, k, u, d.omega.v, beta.v, gamma.v, delta.v, w.Z,
+                                           4 * n));
+    blind_rows(cx, w, rng, w.Z, S, n, u + 1);
+    PZP_CK(pz_lookup_product_dev(cx.c, lk_in, 4 * n, pk.table_lagrange, w.Ap, 4 * n, w.Sp, 4 * n, Lk, n, beta.v, gamma.v, pzh::FR_ONE.v, w.Zl, 4 * n));
+    blind_rows(cx, w, rng, w.Zl, Lk, n, u + 1);
+    commit(pk.bl, w.Z, S, w.out12);
+    keep("perm_z", w.out12, S);
+    commit(pk.bl, w.Zl, Lk, w.out12);
+    keep("lookup_z", w.out12, Lk);
+    blind_rows(cx, w, rng, w.rnd, 1, n, 0);
+    commit(pk.bm, w.rnd, 1, w.out12);
+    keep("random", w.out12, 1);
+    const Fr y = tr.squeeze("y");
+    // ---- 4. quotient
+    auto to_coeff = [&](uint64_t* t, size_t cnt) {
+        for (size_t c0 = 0; c0 < cnt; c0 += tile)
+            PZP_CK(pz_ntt_fr_dev(cx.c, t + c0 * n * 4, cnt - c0 < tile ? cnt - c0 : tile, 4 * n, d.omega_inv.v, k, nullptr, d.n_inv.v));
+    };
+    to_coeff(d_cols, m); to_coeff(w.Ap, Lk); to_coeff(w.Sp, Lk); to_coeff(w.Z, S); to_coeff(w.Zl, Lk);
+    const size_t n_perm_lines = 2 + (S - 1) + S;
+    const Fr y_lines = pow_small(y, n_perm_lines);
+    for (int pi = 0; pi < 2; ++pi) {
+        const Part& pt = d.parts[pi];
+        const size_t Np = pt.size;
+        const unsigned lg = k + pt.log_e, rot = 1u << pt.log_e;
+        auto extend = [&](const uint64_t* src, size_t cnt, uint64_t* dst) {
+            PZP_CK(pz_ntt_fr_extend_dev(cx.c, src, cnt, 4 * n, dst, 4 * Np, k, pt.log_e, d.omega.v, pt.gens.data(), nullptr));
+        };
+        for (size_t s0 = 0; s0 < S; s0 += tile) extend(w.Z + s0 * n * 4, S - s0 < tile ? S - s0 : tile, w.z_ext[pi] + s0 * Np * 4);
+        PZP_CK(pz_dev_memset(cx.c, w.hh[pi], 0, 2 * Np * 32));
+        uint64_t *hg = w.hh[pi], *hp = w.hh[pi] + Np * 4;
+        const uint64_t *l0 = pk.l_ext[pi], *llast = pk.l_ext[pi] + Np * 4, *lact = pk.l_ext[pi] + 2 * Np * 4;
+        for (size_t c0 = 0; c0 < m; c0 += tile) {
+            const size_t cnt = m - c0 < tile ? m - c0 : tile;
+            extend(d_cols + c0 * n * 4, cnt, w.ext[pi]);
+            const size_t na = c0 >= A ? 0 : (A - c0 < cnt ? A - c0 : cnt);
+            if (na) PZP_CK(pz_quotient_gate_dev(cx.c, w.ext[pi], 4 * Np, pk.fixed_ext[pi] + c0 * Np * 4, 4 * Np, na, lg, rot, y.v, hg));
+            PZP_CK(pz_quotient_permutation_part_dev(cx.c, w.ext[pi], 4 * Np, pk.sigma_ext[pi] + c0 * Np * 4, 4 * Np, w.z_ext[pi], 4 * Np, (uint32_t)S,
+                                                    (uint32_t)(c0 / CHUNK), (uint32_t)((cnt + CHUNK - 1) / CHUNK), CHUNK, (uint32_t)cnt, c0 == 0, lg, rot,
+                                                    bf + 1, l0, llast, lact, beta.v, gamma.v, delta.v, pt.coset_g.v, pt.omega.v, y.v, hp));
+        }
+        uint64_t* hq = w.hp[pi];
+        PZP_CK(pz_fr_lincomb_dev(cx.c, w.hh[pi], 2, 4 * Np, Np, y_lines.v, hq, 0));
+        for (size_t l0_ = 0; l0_ < Lk; l0_ += w.lt) {
+            const size_t cnt = Lk - l0_ < w.lt ? Lk - l0_ : w.lt;
+            extend(d_cols + (A + l0_) * n * 4, cnt, w.lk_ext[pi][0]);
+            extend(w.Ap + l0_ * n * 4, cnt, w.lk_ext[pi][1]);
+            extend(w.Sp + l0_ * n * 4, cnt, w.lk_ext[pi][2]);
+            extend(w.Zl + l0_ * n * 4, cnt, w.lk_ext[pi][3]);
+            PZP_CK(pz_quotient_lookup_dev(cx.c, w.lk_ext[pi][0], 4 * Np, pk.fixed_ext[pi] + (A + 1) * Np * 4, w.lk_ext[pi][1], 4 * Np, w.lk_ext[pi][2],
+                                          4 * Np, w.lk_ext[pi][3], 4 * Np, (uint32_t)cnt, lg, rot, l0, llast, lact, beta.v, gamma.v, y.v, hq));
+        }
+        PZP_CK(pz_quotient_finish_dev(cx.c, hq, k, pt.log_e, pt.coset_g.v, pt.omega.v));
+        PZP_CK(pz_ntt_fr_dev(cx.c, hq, 1, 4 * Np, pt.omega_inv.v, lg, nullptr, pt.size_inv.v));
+        const Fr cg_inv = pzh::inv(pt.coset_g);
+        PZP_CK(pz_fr_distribute_powers_dev(cx.c, hq, 1, 4 * Np, Np, cg_inv.v, nullptr));
+    }
+    // the quotient from three cosets (prover.py): [U | h_1] on part A, V on part B
+    uint64_t* pieces = w.h;
+    {
+        const Fr g2n = pow_small(pzh::mul(d.coset_g, d.coset_g), n);
+        const Fr lam = pow_small(d.parts[1].coset_g, n);
+        uint64_t *U = w.hp[0], *h1 = w.hp[0] + n * 4, *V = w.hp[1];
+        uint64_t *t0 = w.tmp, *t1 = w.tmp + n * 4;
+        PZP_CK(pz_dev_copy(cx.c, pieces + n * 4, h1, n * 32));
+        PZP_CK(pz_dev_copy(cx.c, t0, h1, n * 32));
+        PZP_CK(pz_dev_copy(cx.c, t1, V, n * 32));
+        const Fr mlam = pzh::neg(lam), m1 = pzh::neg(pzh::FR_ONE), mg2n = pzh::neg(g2n);
+        PZP_CK(pz_fr_lincomb_dev(cx.c, w.tmp, 2, 4 * n, n, mlam.v, pieces + 2 * n * 4, 0));      // T = V - lam h_1
+        PZP_CK(pz_dev_copy(cx.c, t0, pieces + 2 * n * 4, n * 32));
+        PZP_CK(pz_dev_copy(cx.c, t1, U, n * 32));
+        PZP_CK(pz_fr_lincomb_dev(cx.c, w.tmp, 2, 4 * n, n, m1.v, pieces + 2 * n * 4, 0));        // U - T
+        const Fr half = pzh::inv(pzh::add(g2n, g2n));
+        PZP_CK(pz_fr_distribute_powers_dev(cx.c, pieces + 2 * n * 4, 1, 4 * n, n, pzh::FR_ONE.v, half.v));   // h_2
+        PZP_CK(pz_dev_copy(cx.c, t0, pieces + 2 * n * 4, n * 32));
+        PZP_CK(pz_dev_copy(cx.c, t1, U, n * 32));
+        PZP_CK(pz_fr_lincomb_dev(cx.c, w.tmp, 2, 4 * n, n, mg2n.v, pieces, 0));                  // h_0 = U - g^2n h_2
+    }
+    commit(pk.bm, pieces, 3, w.out12);
+    keep("h", w.out12, 3);
+    const Fr x = tr.squeeze("x");
+    // ---- 5. evaluations
+    Fr xs[6];
+    {
+        xs[0] = x;
+        xs[1] = pzh::mul(x, d.omega);
+        xs[2] = pzh::mul(xs[1], d.omega);
+        xs[3] = pzh::mul(xs[2], d.omega);
+        xs[4] = pzh::mul(x, pow_small(d.omega_inv, bf + 1));
+        xs[5] = pzh::mul(x, d.omega_inv);
+    }
+    const Fr xn = pow_small(x, n);
+    PZP_CK(pz_fr_lincomb_dev(cx.c, pieces + 2 * n * 4, 1, 4 * n, n, xn.v, w.hcomb, 0));
+    PZP_CK(pz_fr_lincomb_dev(cx.c, pieces + 1 * n * 4, 1, 4 * n, n, xn.v, w.hcomb, 1));
+    PZP_CK(pz_fr_lincomb_dev(cx.c, pieces, 1, 4 * n, n, xn.v, w.hcomb, 1));
+    struct Fam { const char* name; const uint64_t* polys; size_t count; std::vector<int> idx; };
+    const size_t F = pk.F;
+    std::vector<Fam> fams = {
+        {"advice", d_cols, A, {0, 1, 2, 3}}, {"lookup_advice", d_cols + A * n * 4, Lk + 1, {0}}, {"fixed", pk.fixed_coeff, F, {0}},
+        {"sigma", pk.sigma_coeff, m, {0}}, {"perm_z", w.Z, S, {0, 1, 4}}, {"lookup_z", w.Zl, Lk, {0, 1}}, {"perm_inputs", w.Ap, Lk, {0, 5}},
+        {"perm_tables", w.Sp, Lk, {0}}, {"random", w.rnd, 1, {0}}, {"h", w.hcomb, 1, {0}}};
+    std::vector<std::vector<uint64_t>> ev(fams.size());
+    for (size_t f = 0; f < fams.size(); ++f) {
+        const Fam& fm = fams[f];
+        std::vector<uint64_t> pts;
+        for (int i : fm.idx) pts.insert(pts.end(), xs[i].v, xs[i].v + 4);
+        PZP_CK(pz_poly_eval_multi_dev(cx.c, fm.polys, fm.count, 4 * n, n, pts.data(), (uint32_t)fm.idx.size(), w.evals));
+        ev[f].resize(fm.count * fm.idx.size() * 4);
+        PZP_CK(pz_download(cx.c, ev[f].data(), w.evals, ev[f].size() * 8));
+        pr.evals.push_back({fm.name, ev[f]});
+        pr.eval_points.push_back({fm.name, (uint32_t)fm.idx.size()});
+        if (strcmp(fm.name, "h")) tr.absorb(ev[f].data(), ev[f].size() * 8);
+    }
+    const Fr shy = tr.squeeze("sh_y"), shv = tr.squeeze("sh_v");
+    // ---- 6. SHPLONK: the rotation sets in prover.py's query_layout order
+    auto fam_of = [&](const char* nm) -> size_t {
+        for (size_t f = 0; f < fams.size(); ++f)
+            if (!strcmp(fams[f].name, nm)) return f;
+        return 0;
+    };
+    struct Member { size_t fam, idx; };
+    std::vector<std::pair<std::vector<uint32_t>, std::vector<Member>>> sets;
+    {
+        std::vector<Member> s0;
+        for (size_t i = 0; i < Lk; ++i) s0.push_back({fam_of("lookup_advice"), i});
+        for (size_t i = 0; i < F; ++i) s0.push_back({fam_of("fixed"), i});
+        for (size_t i = 0; i < m; ++i) s0.push_back({fam_of("sigma"), i});
+        for (size_t i = 0; i < Lk; ++i) s0.push_back({fam_of("perm_tables"), i});
+        s0.push_back({fam_of("h"), 0});
+        s0.push_back({fam_of("random"), 0});
+        sets.push_back({{0}, s0});
+        std::vector<Member> s1;
+        for (size_t i = 0; i < A; ++i) s1.push_back({fam_of("advice"), i});
+        sets.push_back({{0, 1, 2, 3}, s1});
+        if (S > 1) {
+            std::vector<Member> s2;
+            for (size_t i = 0; i + 1 < S; ++i) s2.push_back({fam_of("perm_z"), i});
+            sets.push_back({{0, 1, 4}, s2});
+        }
+        std::vector<Member> s3;
+        s3.push_back({fam_of("perm_z"), S - 1});
+        for (size_t i = 0; i < Lk; ++i) s3.push_back({fam_of("lookup_z"), i});
+        sets.push_back({{0, 1}, s3});
+        std::vector<Member> s4;
+        for (size_t i = 0; i < Lk; ++i) s4.push_back({fam_of("perm_inputs"), i});
+        sets.push_back({{0, 5}, s4});
+    }
+    std::vector<uint32_t> set_n_polys, set_n_points, point_idx;
+    std::vector<const uint64_t*> polys;
+    std::vector<uint64_t> evals_flat, points;
+    for (int i = 0; i < 6; ++i) points.insert(points.end(), xs[i].v, xs[i].v + 4);
+    for (auto& sp : sets) {
+        set_n_polys.push_back((uint32_t)sp.second.size());
+        set_n_points.push_back((uint32_t)sp.first.size());
+        for (uint32_t pi_ : sp.first) point_idx.push_back(pi_);
+        for (const Member& mb : sp.second) {
+            const Fam& fm = fams[mb.fam];
+            polys.push_back(fm.polys + mb.idx * n * 4);
+            const size_t npts = fm.idx.size();
+            for (size_t q = 0; q < sp.first.size(); ++q)   // the set's points are a prefix of the family's
+                evals_flat.insert(evals_flat.end(), &ev[mb.fam][(mb.idx * npts + q) * 4], &ev[mb.fam][(mb.idx * npts + q) * 4] + 4);
+        }
+    }
+    pz_shplonk* state = nullptr;
+    PZP_CK(pz_shplonk_begin_dev(cx.c, n, (uint32_t)sets.size(), set_n_polys.data(), polys.data(), set_n_points.data(), point_idx.data(), 6,
+                                points.data(), evals_flat.data(), shy.v, shv.v, w.w1, &state));
+    commit(pk.bm, w.w1, 1, w.out12);
+    keep("w1", w.out12, 1);
+    const Fr shu = tr.squeeze("sh_u");
+    PZP_CK(pz_shplonk_finish_dev(cx.c, state, shu.v, w.w1, w.w2));
+    commit(pk.bm, w.w2, 1, w.out12);
+    keep("w2", w.out12, 1);
+    // degree <= 3n - 4: the top three coefficients of h_2 vanish
+    uint64_t top[12];
+    PZP_CK(pz_download(cx.c, top, pieces + (3 * n - 3) * 4, 96));
+    pr.h_degree_ok = true;
+    for (int i = 0; i < 12; ++i)
+        if (top[i]) pr.h_degree_ok = false;
+    return pr;
+}
+
+}   // namespace pzp

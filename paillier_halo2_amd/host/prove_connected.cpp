@@ -1,0 +1,181 @@
+// prove_connected.cpp -- ONE CONNECTED PROOF from plain C++ over the C ABI (include/pz.h): K3 trace -> K4 columns in halo2-lib's
+// break-point layout -> keygen -> create_proof (host/create_proof.hpp) with a hashing transcript, the proof written to a file.  No
+// torch, no HIP call of its own, no oracle: the compiled-language counterpart of bench_connected.ConnectedWorkload, what a reference
+// prover patched at point D of INTEGRATION.md runs between /root/reference/src/bench.rs:161 and :171.
+//
+// usage: prove_connected <job file> <proof file>
+// job file: little-endian u64 words
+//   [0] magic 0x435a50  [1] enc_bits  [2] k  [3] lookup_bits  [4] max_rows  [5] blinding_factors  [6] n_adv  [7] n_lk  [8] n_constants
+//   [9] kind (0 encrypt, 2 encrypt_uniform)  [10] n_steps_g  [11] n_steps_r  [12] seed  [13] proofs  [14] tile  [15] n_messages
+//   then n | g (Ln words each), n^2 (2 Ln), s_toxic (4, Montgomery), starts (n_adv + 1), constants (4 x n_constants, canonical),
+//   per message m | r (Ln each), then BYTES: selectors [n_adv][2^k] (padded to 8), then u32 map_col [m][2^k], u32 map_row [m][2^k]
+// The circuit structure is an INPUT (paillier_halo2_amd/circuit_structure.py writes it): the dependency's keygen knows it.
+// proof file: records  [name_len u64][name bytes, padded to 8][kind u64: 0 points (8 words), 1 evaluations, 2 challenge][count u64]
+//   [per-item words u64][data]; proof p's records are prefixed "p<p>/"; the verifying key's commitments are "vk/fixed", "vk/sigma".
+// stdout: one JSON line with the timings.
+#include <chrono>
+
+#include "create_proof.hpp"
+
+using namespace pzp;
+
+static std::vector<uint64_t> slurp(const char* path) {
+    FILE* f = fopen(path, "rb");
+    if (!f) { perror(path); exit(2); }
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (sz < 0 || sz % 8) { fprintf(stderr, "job file length\n"); exit(2); }
+    std::vector<uint64_t> w((size_t)sz / 8);
+    if (fread(w.data(), 8, w.size(), f) != w.size()) { fprintf(stderr, "short read\n"); exit(2); }
+    fclose(f);
+    return w;
+}
+
+struct Out {
+    FILE* f;
+    void rec(const std::string& name, uint64_t kind, uint64_t count, uint64_t per, const uint64_t* data) {
+        const uint64_t len = name.size();
+        std::string padded = name;
+        padded.resize((len + 7) / 8 * 8, '\0');
+        fwrite(&len, 8, 1, f);
+        fwrite(padded.data(), 1, padded.size(), f);
+        fwrite(&kind, 8, 1, f);
+        fwrite(&count, 8, 1, f);
+        fwrite(&per, 8, 1, f);
+        fwrite(data, 8, count * per, f);
+    }
+};
+
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int main(int argc, char** argv) {
+    if (argc != 3) { fprintf(stderr, "usage: %s <job file> <proof file>\n", argv[0]); return 2; }
+    const std::vector<uint64_t> w = slurp(argv[1]);
+    if (w.size() < 16 || w[0] != 0x435a50) { fprintf(stderr, "bad job file\n"); return 2; }
+    Structure st;
+    const uint64_t enc_bits = w[1];
+    st.k = (unsigned)w[2]; st.lookup_bits = (unsigned)w[3]; st.max_rows = w[4]; st.blinding_factors = (unsigned)w[5];
+    st.n_adv = w[6]; st.n_lk = w[7];
+    const size_t n_const = w[8], kind = w[9], ng = w[10], nr = w[11], seed = w[12], proofs = w[13], tile = w[14], n_msg = w[15];
+    const size_t Ln = enc_bits / 64, L = 2 * Ln, n = (size_t)1 << st.k, m = st.m(), A = st.n_adv;
+    if (st.k < 4 || st.k > 24 || !Ln || !A || st.max_rows + st.blinding_factors + 1 > n || tile % CHUNK || !n_msg || !proofs) {
+        fprintf(stderr, "job parameters\n");
+        return 2;
+    }
+    size_t p = 16;
+    auto take = [&](std::vector<uint64_t>& v, size_t cnt) {
+        if (p + cnt > w.size()) { fprintf(stderr, "job file truncated\n"); exit(2); }
+        v.assign(w.begin() + p, w.begin() + p + cnt);
+        p += cnt;
+    };
+    std::vector<uint64_t> vn, vg, n2, s_tox;
+    take(vn, Ln); take(vg, Ln); take(n2, L); take(s_tox, 4);
+    take(st.starts, A + 1);
+    take(st.constants, 4 * n_const);
+    std::vector<std::vector<uint64_t>> vm(n_msg), vr(n_msg);
+    for (size_t v = 0; v < n_msg; ++v) { take(vm[v], Ln); take(vr[v], Ln); }
+    const size_t sel_words = (A * n + 7) / 8, map_words = (m * n + 1) / 2;
+    if (p + sel_words + 2 * map_words != w.size()) { fprintf(stderr, "job file length (%zu + %zu + 2 x %zu != %zu)\n", p, sel_words, map_words, w.size()); return 2; }
+    st.selectors.assign((const uint8_t*)&w[p], (const uint8_t*)&w[p] + A * n);
+    p += sel_words;
+    st.map_col.assign((const uint32_t*)&w[p], (const uint32_t*)&w[p] + m * n);
+    p += map_words;
+    st.map_row.assign((const uint32_t*)&w[p], (const uint32_t*)&w[p] + m * n);
+    for (size_t j = 0; j + 1 < st.starts.size(); ++j)
+        if (st.starts[j] > st.starts[j + 1] || st.starts[j + 1] - st.starts[j] > st.max_rows) { fprintf(stderr, "break points\n"); return 2; }
+
+    Ctx cx;
+    int dev = 0;
+    PZP_CK(pz_init(1, &dev, &cx.c));
+    // SRS: monomial and Lagrange bases from the seeded scalar (ParamsKZG::setup, as gen_srs does)
+    const double t_setup = now_ms();
+    const Fr om = pzh::omega(st.k);
+    void *d_g = nullptr, *d_gl = nullptr;
+    PZP_CK(pz_dev_alloc(cx.c, n * 64, &d_g));
+    PZP_CK(pz_dev_alloc(cx.c, n * 64, &d_gl));
+    PZP_CK(pz_srs_setup_g1_dev(cx.c, st.k, s_tox.data(), om.v, (uint64_t*)d_g, (uint64_t*)d_gl));
+    PZP_CK(pz_sync(cx.c));
+    pz_bases *bl = nullptr, *bm = nullptr;
+    PZP_CK(pz_bases_load_g1(cx.c, (const uint64_t*)d_gl, n, 1, 0, &bl));
+    PZP_CK(pz_bases_load_g1(cx.c, (const uint64_t*)d_g, n, 1, 0, &bm));
+    pz_dev_free(cx.c, d_g);
+    pz_dev_free(cx.c, d_gl);
+    const double t_keygen = now_ms();
+    ProvingKey* pk = keygen(cx, st, bl, bm);
+    PZP_CK(pz_sync(cx.c));
+    const double keygen_ms = now_ms() - t_keygen;
+    Workspace ws = make_workspace(cx, *pk, tile);
+    uint64_t* d_cols = cx.alloc(m * n * 4);
+    uint64_t* d_steps = cx.alloc((ng + nr + 1) * 4 * L);
+    uint64_t* d_mod = cx.alloc(L);
+    uint64_t* d_starts = cx.alloc(A + 1);
+    PZP_CK(pz_upload(cx.c, d_mod, n2.data(), L * 8));
+    PZP_CK(pz_upload(cx.c, d_starts, st.starts.data(), (A + 1) * 8));
+
+    Out out{fopen(argv[2], "wb")};
+    if (!out.f) { perror(argv[2]); return 2; }
+    out.rec("vk/fixed", 0, pk->F, 8, pk->fixed_commit.data());
+    out.rec("vk/sigma", 0, m, 8, pk->sigma_commit.data());
+    double best = 1e30, witness_ms = 0;
+    bool degree_ok = true;
+    for (size_t pi = 0; pi < proofs; ++pi) {
+        const size_t v = pi % n_msg;
+        PZP_CK(pz_sync(cx.c));
+        const double t0 = now_ms();
+        // K3 + K4
+        PZP_CK(pz_dev_memset(cx.c, d_cols, 0, m * n * 32));
+        uint32_t sg = 0, sr = 0;
+        std::vector<uint64_t> c_out(L);
+        if (kind == 2)
+            PZP_CK(pz_paillier_encrypt_uniform_dev(cx.c, (uint32_t)Ln, 1, (uint32_t)enc_bits, vn.data(), vg.data(), vm[v].data(), vr[v].data(), d_steps,
+                                                   ng + nr + 1, &sg, &sr, c_out.data()));
+        else
+            PZP_CK(pz_paillier_encrypt_dev(cx.c, (uint32_t)Ln, 1, vn.data(), vg.data(), vm[v].data(), vr[v].data(), d_steps, ng + nr + 1, &sg, &sr,
+                                           c_out.data()));
+        if (sg != ng || sr != nr) { fprintf(stderr, "trace shape (%u, %u) is not the structure's (%zu, %zu)\n", sg, sr, ng, nr); return 2; }
+        std::vector<uint64_t> inputs;
+        for (const auto* x : {&vn, &vg, &vm[v], &vr[v], &c_out}) inputs.insert(inputs.end(), x->begin(), x->end());
+        PZP_CK(pz_circuit_expand_cols_dev(cx.c, (int)kind, (uint32_t)Ln, 64, st.lookup_bits, inputs.data(), d_steps, ng, nr, d_mod, d_cols,
+                                          d_cols + A * n * 4, d_starts, A, st.max_rows, st.max_rows, n));
+        if (const char* tw = getenv("PZ_PROVE_TAMPER_WORD")) {   // tests' negative control: flip one bit of one witness word
+            const size_t idx = strtoull(tw, nullptr, 10);
+            uint64_t word = 0;
+            if (idx >= m * n * 4) { fprintf(stderr, "tamper index\n"); return 2; }
+            PZP_CK(pz_download(cx.c, &word, d_cols + idx, 8));
+            word ^= 1;
+            PZP_CK(pz_upload(cx.c, d_cols + idx, &word, 8));
+        }
+        PZP_CK(pz_sync(cx.c));
+        const double t1 = now_ms();
+        Transcript tr;
+        tr.absorb(&pi, 8);
+        Proof pr = create_proof(cx, *pk, ws, d_cols, tr, seed + pi);
+        PZP_CK(pz_sync(cx.c));
+        const double t2 = now_ms();
+        if (t2 - t0 < best) { best = t2 - t0; witness_ms = t1 - t0; }
+        degree_ok = degree_ok && pr.h_degree_ok;
+        const std::string pre = "p" + std::to_string(pi) + "/";
+        out.rec(pre + "ciphertext", 3, 1, L, c_out.data());
+        const uint64_t flags[2] = {pr.h_degree_ok, v};
+        out.rec(pre + "flags", 3, 1, 2, flags);
+        for (auto& c : pr.commitments) out.rec(pre + "c/" + c.first, 0, c.second.size() / 8, 8, c.second.data());
+        for (size_t f = 0; f < pr.evals.size(); ++f) {
+            const uint64_t per = 4ull * pr.eval_points[f].second;
+            out.rec(pre + "e/" + pr.evals[f].first, 1, pr.evals[f].second.size() / per, per, pr.evals[f].second.data());
+        }
+        for (auto& c : tr.drawn) out.rec(pre + "ch/" + c.first, 2, 1, 4, c.second.v);
+    }
+    fclose(out.f);
+    printf("{\"proofs\": %zu, \"k\": %u, \"enc_bits\": %llu, \"n_adv\": %zu, \"n_lk\": %zu, \"cosets\": 3, \"keygen_ms\": %.1f, \"setup_ms\": %.1f, "
+           "\"best_proof_ms\": %.2f, \"of_which_witness_ms\": %.2f, \"quotient_degree_ok\": %s}\n",
+           proofs, st.k, (unsigned long long)enc_bits, A, st.n_lk, keygen_ms, t_keygen - t_setup, best, witness_ms, degree_ok ? "true" : "false");
+    cx.release();
+    pz_bases_free(cx.c, bl);
+    pz_bases_free(cx.c, bm);
+    delete pk;
+    pz_free(cx.c);
+    return degree_ok ? 0 : 1;
+}

@@ -1,0 +1,71 @@
+"""Files of the compiled prover (paillier_halo2_amd/host/prove_connected.cpp): the job it reads -- inputs + the circuit STRUCTURE keygen
+takes (prover.CircuitStructure; the format is stated at the top of prove_connected.cpp) -- and the proof file it writes."""
+from __future__ import annotations
+
+import os
+import subprocess
+from typing import Dict, Sequence
+
+import numpy as np
+
+from . import consts
+
+MAGIC = 0x435A50
+HERE = os.path.dirname(os.path.abspath(__file__))
+BINARY = os.path.join(os.path.dirname(HERE), "tests", "cpp", "prove_connected")
+
+
+def write_job(path: str, st, starts: Sequence[int], enc_bits: int, kind: int, ng: int, nr: int, nn: int, g: int, messages, s_toxic: int,
+              seed: int = 1, proofs: int = 1, tile: int = 64):
+    """st: prover.CircuitStructure; starts: the advice break points (n_adv + 1); messages: [(m, r)] integers of the SAME circuit shape"""
+    Ln = enc_bits // 64
+    n = 1 << st.k
+    A, m = st.n_adv, st.m
+    lim = lambda x, l: consts.int_to_limbs(x, l).astype("<u8")
+    hdr = np.array([MAGIC, enc_bits, st.k, st.lookup_bits, st.max_rows, st.blinding_factors, A, st.n_lk, len(st.constants), kind, ng, nr, seed,
+                    proofs, tile, len(messages)], dtype="<u8")
+    assert len(starts) == A + 1 and st.selectors.shape == (A, n) and st.map_col.shape == (m, n) == st.map_row.shape
+    with open(path, "wb") as f:
+        f.write(hdr.tobytes())
+        f.write(lim(nn, Ln).tobytes())
+        f.write(lim(g, Ln).tobytes())
+        f.write(lim(nn * nn, 2 * Ln).tobytes())
+        f.write(consts.fr_mont_limbs(s_toxic).astype("<u8").tobytes())
+        f.write(np.asarray(starts, dtype="<u8").tobytes())
+        for c in st.constants:
+            f.write(lim(int(c) % consts.FR_R, 4).tobytes())
+        for mm, rr in messages:
+            f.write(lim(mm, Ln).tobytes())
+            f.write(lim(rr, Ln).tobytes())
+        sel = np.ascontiguousarray(st.selectors, dtype=np.uint8).tobytes()
+        f.write(sel + b"\0" * (-len(sel) % 8))
+        for a in (st.map_col, st.map_row):
+            b = np.ascontiguousarray(a, dtype="<u4").tobytes()
+            f.write(b + b"\0" * (-len(b) % 8))
+
+
+def read_proofs(path: str) -> Dict[str, np.ndarray]:
+    """-> {record name: uint64 array (count, words per item)}"""
+    w = np.fromfile(path, dtype="<u8")
+    out, p = {}, 0
+    while p < len(w):
+        ln = int(w[p]); p += 1
+        nw = (ln + 7) // 8
+        name = w[p:p + nw].tobytes()[:ln].decode(); p += nw
+        _kind, count, per = (int(x) for x in w[p:p + 3]); p += 3
+        out[name] = w[p:p + count * per].reshape(count, per).copy(); p += count * per
+    assert p == len(w)
+    return out
+
+
+def run(job_path: str, proof_path: str, timeout: float = 600.0, env=None, allow_unsatisfied: bool = False) -> dict:
+    """runs the binary (built by tests/cpp/Makefile); raises with its stderr if it fails.  -> its JSON line.  Exit code 1 = the proofs were
+    written but a quotient's degree check failed (an unsatisfied witness): raised unless allow_unsatisfied"""
+    import json
+
+    if not os.path.exists(BINARY):
+        raise RuntimeError("tests/cpp/prove_connected is not built (make -C tests/cpp prove_connected)")
+    r = subprocess.run([BINARY, job_path, proof_path], capture_output=True, text=True, timeout=timeout, env=env)
+    if r.returncode != 0 and not (allow_unsatisfied and r.returncode == 1):
+        raise RuntimeError("prove_connected exit %d: %s" % (r.returncode, r.stderr[-2000:]))
+    return json.loads(r.stdout.strip().splitlines()[-1])

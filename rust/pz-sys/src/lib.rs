@@ -29,6 +29,8 @@ extern "C" {
     pub fn pz_download(ctx: *mut pz_ctx, dst: *mut c_void, d_src: *const c_void, bytes: usize) -> c_int;
     pub fn pz_dev_memset(ctx: *mut pz_ctx, d_dst: *mut c_void, byte_value: c_int, bytes: usize) -> c_int;
     pub fn pz_dev_copy(ctx: *mut pz_ctx, d_dst: *mut c_void, d_src: *const c_void, bytes: usize) -> c_int;
+    pub fn pz_dev_copy_2d(ctx: *mut pz_ctx, d_dst: *mut c_void, dst_pitch: usize, d_src: *const c_void, src_pitch: usize, width: usize,
+                          rows: usize) -> c_int;
     pub fn pz_ctx_wait(waiter: *mut pz_ctx, producer: *mut pz_ctx) -> c_int;
 
     // K1  (replaces halo2curves::msm::best_multiexp)
