@@ -174,6 +174,114 @@ class ConnectedWorkload:
             self.step(timed, last=(i == steps - 1))
         self.torch.cuda.synchronize()
 
+    def _lanes(self, n_lanes):
+        """contexts for proofs in flight beside each other: lane 0 is the workload's own context / stream / workspace; every further lane
+        gets its own library context (stream, library workspaces) and its own prover Workspace; lane i proves out of witness slot i"""
+        from paillier_halo2_amd import prover
+
+        import paillier_halo2_amd as pz
+
+        torch = self.torch
+        if getattr(self, "lanes", None) and len(self.lanes) >= n_lanes:
+            return self.lanes[:n_lanes]
+        assert n_lanes <= len(self.slots)
+        lanes = [dict(eng=self.eng, stream=torch.cuda.current_stream(), ws=self.ws, cols=self.slots[0], d_steps=self.d_steps, own=False)]
+        for i in range(1, n_lanes):
+            e = pz.Engine(self.eng.device)
+            st = torch.cuda.Stream()
+            e.set_stream(st.cuda_stream)
+            lanes.append(dict(eng=e, stream=st, ws=prover.Workspace(self.pk, self.ws.tile), cols=self.slots[i],
+                              d_steps=torch.zeros_like(self.d_steps), own=True))
+        self.lanes = lanes
+        return lanes
+
+    def run_in_flight(self, steps, n_lanes=2):
+        """`steps` proofs with `n_lanes` in flight: proofs are independent, so while one is in its commitment-heavy phases (advice,
+        lookups, grand products: K1, whose sort / fold / reduction kernels leave the multiplier idle a third of the time) the other is
+        in its transform-heavy ones (quotient, evaluations, opening: K2 and the line kernels).  Two stage locks keep the lanes in that
+        alternation and the proofs in order; each lane is a host thread with its own context, stream and workspace; the witness of a
+        lane's next proof (K3: four workgroups) is produced before the lane asks for stage 1.  Per-proof LATENCY is not improved
+        (it grows: the lanes share the GPU); throughput is.  -> seconds of wall time for the `steps` proofs"""
+        import threading
+
+        from paillier_halo2_amd import prover
+
+        torch = self.torch
+        lanes = self._lanes(n_lanes)
+        torch.cuda.synchronize()
+        stage1, stage2 = threading.Lock(), threading.Lock()
+        turn = threading.Condition()
+        state = {"next": 0, "err": None}
+        results = [None] * steps
+        lat = [0.0] * steps
+
+        def lane_main(li):
+            ln = lanes[li]
+            eng = ln["eng"]
+            try:
+                with torch.cuda.stream(ln["stream"]):
+                    for idx in range(li, steps, n_lanes):
+                        nn, g, m, r = self.variants[idx % len(self.variants)]
+                        cols = ln["cols"]
+                        cols.zero_()
+                        if self.uniform:
+                            c, _, _ = eng.paillier_encrypt_uniform_dev(self.Ln, self.enc_bits, nn, g, m, r, ln["d_steps"].data_ptr(), self.n_steps)
+                        else:
+                            c, _, _ = eng.paillier_encrypt_dev(self.Ln, nn, g, m, r, ln["d_steps"].data_ptr(), self.n_steps)
+                        inputs = np.concatenate([nn, g, m, r, np.asarray(c[0], dtype=np.uint64)])
+                        eng.circuit_expand_cols_dev(self.kind, self.Ln, 64, self.lb, inputs, ln["d_steps"].data_ptr(), self.ng, self.nr,
+                                                    self.d_mod.data_ptr(), cols.data_ptr(), cols[self.A].data_ptr(), self.d_starts.data_ptr(), self.A,
+                                                    self.cs.max_rows, self.cs.max_rows, self.n)
+                        with turn:                      # proofs enter stage 1 in order
+                            turn.wait_for(lambda: state["next"] == idx or state["err"])
+                        if state["err"]:
+                            return
+                        stage1.acquire()
+                        t0 = time.perf_counter()
+                        with turn:
+                            state["next"] = idx + 1
+                            turn.notify_all()
+                        held = {"s1": True, "s2": False}
+
+                        def on_phase(name):
+                            if name == "products_commit":
+                                stage2.acquire()
+                                held["s2"] = True
+                                stage1.release()
+                                held["s1"] = False
+
+                        try:
+                            tr = prover.HashTranscript(b"pz-bench-%d" % (self.done + idx))
+                            pr = prover.create_proof(self.pk, cols, tr, seed=1000 + self.done + idx, ws=ln["ws"], hooks={"on_phase": on_phase}, eng=eng)
+                            eng.sync()
+                        finally:
+                            if held["s1"]:
+                                stage1.release()
+                            if held["s2"]:
+                                stage2.release()
+                        lat[idx] = time.perf_counter() - t0
+                        results[idx] = (pr, tr.challenges(), idx % len(self.variants))
+            except BaseException as ex:   # noqa: BLE001 -- reported by the caller
+                with turn:
+                    state["err"] = ex
+                    turn.notify_all()
+
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=lane_main, args=(i,)) for i in range(n_lanes)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if state["err"] is not None:
+            raise state["err"]
+        self.done += steps
+        self.produced = self.done
+        self.last = results[-1]
+        self.in_flight_latency_ms = [x * 1e3 for x in lat]
+        return dt
+
     def phase_ms(self, steps):
         return {k_: v_ / max(1, steps) for k_, v_ in self.timings.items()}
 
@@ -222,6 +330,10 @@ class ConnectedWorkload:
         self.torch.cuda.synchronize()
         if self.engw is not self.eng:
             self.engw.close()
+        for ln in getattr(self, "lanes", None) or []:
+            if ln["own"]:
+                ln["eng"].close()
+        self.lanes = None
         for name in ("pk", "ws", "cols", "slots", "d_steps", "last"):
             setattr(self, name, None)
         self.torch.cuda.empty_cache()

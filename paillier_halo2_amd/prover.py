@@ -328,16 +328,18 @@ class Workspace:
 
 
 def create_proof(pk: ProvingKey, cols, tr, seed: int = 0, tile: int = 64, hooks=None, ws: Optional[Workspace] = None,
-                 timings: Optional[Dict[str, float]] = None) -> Proof:
+                 timings: Optional[Dict[str, float]] = None, eng: Optional[Engine] = None) -> Proof:
     """cols: int64 CUDA tensor [m][2^k][4]: the advice columns then the lookup-advice columns as K4 wrote them (rows >= max_rows
     zero); the last column (constants) and the blinding rows are filled here; cols is consumed (it ends up in coefficient form).
     tr: a Transcript (or plain Challenges).  Runs on the engine's stream (bind_torch_stream).
     hooks: optional dict of callables name -> f(tensors) applied to intermediate device buffers (the tests' tamper points).
-    timings: if given, phase -> milliseconds of wall time (each phase ends with the transcript's synchronising download)."""
+    timings: if given, phase -> milliseconds of wall time (each phase ends with the transcript's synchronising download).
+    eng: the context (stream, library workspaces) this proof runs on -- default the key's; a second proof in flight beside this one
+    takes its own (bench_connected.run_in_flight); hooks["on_phase"](name) is called as each phase ends (there: the stage hand-over)."""
     import time
 
     torch = _torch()
-    eng, st, d = pk.eng, pk.st, pk.dom
+    eng, st, d = eng or pk.eng, pk.st, pk.dom
     n, N, k, u, bf = d.n, d.N, d.k, d.usable, d.bf
     A, Lk, m, S = st.n_adv, st.n_lk, st.m, pk.n_sets
     W = A + Lk
@@ -355,6 +357,8 @@ def create_proof(pk: ProvingKey, cols, tr, seed: int = 0, tile: int = 64, hooks=
     t_last = [time.perf_counter()]
 
     def phase(name):
+        if "on_phase" in hooks:
+            hooks["on_phase"](name)
         if timings is not None:
             eng.sync()
             now = time.perf_counter()

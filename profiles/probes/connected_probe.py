@@ -21,6 +21,20 @@ wl.run(steps, timed=False)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t1
 log("%d proofs: %.1f ms per proof (%.3f proofs/s)" % (steps, dt / steps * 1e3, steps / dt))
+if os.environ.get("PZ_PROBE_IN_FLIGHT", "2") != "1":
+    nl = int(os.environ.get("PZ_PROBE_IN_FLIGHT", "2"))
+    free, tot = torch.cuda.mem_get_info()
+    log("before the second lane: %.1f GB free of %.1f" % (free / 1e9, tot / 1e9))
+    wl.run_in_flight(2, nl)            # warm-up: the second lane's workspaces
+    free, tot = torch.cuda.mem_get_info()
+    log("with %d lanes: %.1f GB free of %.1f" % (nl, free / 1e9, tot / 1e9))
+    for rep in range(2):
+        dtf = wl.run_in_flight(2 * steps, nl)
+        log("%d proofs, %d in flight: %.1f ms per proof (%.3f proofs/s); latency per proof %s ms" % (
+            2 * steps, nl, dtf / (2 * steps) * 1e3, 2 * steps / dtf, [round(x) for x in wl.in_flight_latency_ms]))
+    from oracle import cref
+    cref.build()
+    log("verify (last proof of the in-flight run): %s" % wl.verify(cref))
 wl.run(1, timed=True)
 log("phases (one more proof, synchronised per phase): %s" % {k_: round(v_, 1) for k_, v_ in wl.phase_ms(1).items()})
 from oracle import cref
