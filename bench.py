@@ -1567,9 +1567,21 @@ def main():
             if ver is not None and ver.get("verified") is False:
                 out["comparable"] = False
             cw.release()
-            del cw
             gc.collect()
             torch.cuda.empty_cache()
+            # the same proof from the compiled prover: plain C++ over the C ABI, a child process with its own contexts
+            if not args.no_dropin:
+                try:
+                    t_p = time.time()
+                    out["with_next_rows_cpp"] = bench_connected.cpp_connected(cw, proofs=3, verify_with=_cref if ver is not None else None, log=log)
+                    log("connected, compiled prover %.1fs: %.1f ms per proof, verified %s" % (
+                        time.time() - t_p, out["with_next_rows_cpp"]["ms_per_proof_best_of"], out["with_next_rows_cpp"].get("verified")))
+                    if out["with_next_rows_cpp"].get("verified") is False:
+                        out["comparable"] = False
+                except Exception as ex:
+                    out["with_next_rows_cpp"] = {"error": repr(ex)[:600]}
+            del cw
+            gc.collect()
             # the same through the UNIFORM-shape circuit (row f4): ONE proving key for every message of a key, so the proofs of this
             # loop are of DISTINCT messages -- what a user who encrypts different messages gets once that key exists.  (The reference's
             # circuit needs a new structure + keygen per message: with_next_rows.circuit_structure_ms + keygen_ms.)  One witness slot:

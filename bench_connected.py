@@ -29,6 +29,40 @@ class _Null:
         return False
 
 
+def cpp_connected(cw, proofs=3, verify_with=None, log=lambda s: None):
+    """the same connected proof from the COMPILED prover (paillier_halo2_amd/host/prove_connected.cpp over include/pz.h only): the
+    workload's structure and inputs written to a job file, the binary run as a child process (its own contexts: call after
+    cw.release()), its last proof checked by verify_file_proof when verify_with (oracle.cref) is given.  -> dict for the bench line"""
+    import tempfile
+
+    from paillier_halo2_amd import consts, prover_job
+
+    L = consts.limbs_to_int
+    nn, g, m, r = (L(x) for x in cw.variants[0])
+    msgs = [(L(v[2]), L(v[3])) for v in cw.variants]
+    with tempfile.TemporaryDirectory(prefix="pz_job_") as td:
+        job, proof = os.path.join(td, "job.bin"), os.path.join(td, "proof.bin")
+        t0 = time.perf_counter()
+        prover_job.write_job(job, cw.cs, cw.starts_host, cw.enc_bits, cw.kind, cw.ng, cw.nr, nn, g, msgs, cw.s_tox, seed=11, proofs=proofs)
+        t1 = time.perf_counter()
+        line = prover_job.run(job, proof, timeout=600)
+        t2 = time.perf_counter()
+        out = {"value": 1e3 / line["best_proof_ms"], "unit": "proofs/s", "ms_per_proof_best_of": line["best_proof_ms"], "proofs": proofs,
+               "of_which_witness_ms": line["of_which_witness_ms"], "keygen_ms": line["keygen_ms"], "connected": True,
+               "job_file_gb": os.path.getsize(job) / 1e9, "job_write_s": t1 - t0, "binary_wall_s": t2 - t1,
+               "quotient_degree_ok": line["quotient_degree_ok"],
+               "note": "tests/cpp/prove_connected: keygen + create_proof (paillier_halo2_amd/host/create_proof.hpp) from plain C++ over the C "
+                       "ABI only -- no torch, no HIP call in the host, no oracle; one context, no overlap of the next witness; the circuit "
+                       "structure and inputs arrive in a job file; best of `proofs` consecutive proofs incl. each proof's K3 + K4"}
+        if verify_with is not None:
+            rec = prover_job.read_proofs(proof)
+            last = "p%d/" % (proofs - 1)
+            ver = verify_file_proof(verify_with, rec, last, cw.cs, cw.k, cw.s_tox)
+            ver.pop("ciphertext", None)
+            out["verified"], out["verification"] = ver["verified"], ver
+    return out
+
+
 class ConnectedWorkload:
     def __init__(self, eng, torch, enc_bits: int, k: int, seed: int, lookup_bits=None, log=lambda s: None, tile: int = 64,
                  circuit: str = "encrypt", pipeline=None, cosets=None):
@@ -72,6 +106,7 @@ class ConnectedWorkload:
         del sa
         self.structure_ms = {"stream_walk_and_tiling": (t1 - t0) * 1e3, "columns_cycles_selectors": (time.perf_counter() - t1) * 1e3}
         self.d_starts = torch.from_numpy(starts.astype(np.int64)).cuda()
+        self.starts_host = np.asarray(starts, dtype=np.int64)
         self.A, self.Lk, self.m = self.cs.n_adv, self.cs.n_lk, self.cs.m
         # ---- SRS: monomial and Lagrange bases from a seeded scalar (ParamsKZG::setup, as gen_srs does)
         self.s_tox = random.Random(seed ^ 0x535253).randrange(2, consts.FR_R)
@@ -337,3 +372,41 @@ class ConnectedWorkload:
         for name in ("pk", "ws", "cols", "slots", "d_steps", "last"):
             setattr(self, name, None)
         self.torch.cuda.empty_cache()
+
+
+def verify_file_proof(cref, rec, prefix, st, k, s_tox):
+    """the checker leg for a proof written by the compiled prover (paillier_halo2_amd/host/prove_connected.cpp; `rec` =
+    prover_job.read_proofs): the identity h(x)(x^n - 1) == the constraint expression of the evaluations, and SHPLONK's identity in the
+    exponent over the proof's commitments and the key's, with the challenges the binary's transcript drew.  st: prover.CircuitStructure"""
+    from oracle import pyref as P
+    from oracle import verifier as V
+    from paillier_halo2_amd import prover
+
+    R = P.FR_R
+    A, Lk, m, n = st.n_adv, st.n_lk, st.m, 1 << k
+    S = -(-m // prover.CHUNK)
+    L = lambda x: sum(int(v) << (64 * i) for i, v in enumerate(x))
+
+    def ints(a):
+        flat = cref.fr_mont_to_ints(np.ascontiguousarray(a).reshape(-1, 4))
+        p = a.shape[1] // 4
+        return [flat[i * p:(i + 1) * p] for i in range(a.shape[0])]
+
+    ch = {nm: L(rec[prefix + "ch/" + nm][0]) for nm in ("theta", "beta", "gamma", "y", "x", "sh_y", "sh_v", "sh_u")}
+    ev = {k_[len(prefix) + 2:]: ints(v_) for k_, v_ in rec.items() if k_.startswith(prefix + "e/")}
+    ev["constants"] = ev["lookup_advice"][Lk:]
+    ev["lookup_advice"] = ev["lookup_advice"][:Lk]
+    want = V.expected_h(k, st.blinding_factors, A, Lk, prover.CHUNK, ev, ch["beta"], ch["gamma"], ch["y"], ch["x"], prover.DELTA)
+    ident = bool(want == ev["h"][0][0])
+    com = {k_[len(prefix) + 2:]: v_ for k_, v_ in rec.items() if k_.startswith(prefix + "c/")}
+    shapes = com["advice"].shape == (A, 8) and com["perm_z"].shape == (S, 8) and com["h"].shape == (3, 8)
+    xn = pow(ch["x"], n, R)
+    hc = cref.g1_normalize(cref.msm_g1(cref.fr_ints_to_mont([pow(xn, i, R) for i in range(3)]), com["h"]))
+    com.update(fixed=rec["vk/fixed"], sigma=rec["vk/sigma"], h=[hc])
+    lay = prover.query_layout(A, Lk, m, S)
+    pts = prover.rotation_points(prover.Domain(k, st.blinding_factors), ch["x"])
+    opening = bool(V.shplonk_check(cref, lay, pts, com, ev, ch["sh_y"], ch["sh_v"], ch["sh_u"], com["w1"][0], com["w2"][0], s_tox))
+    degree = bool(int(rec[prefix + "flags"][0][0]) == 1)
+    return {"verified": bool(degree and ident and opening and shapes), "quotient_degree_le_3n_minus_4": degree,
+            "h_x_times_xn_minus_1_equals_expression_of_evaluations": ident, "shplonk_identity_on_the_proofs_commitments": opening,
+            "ciphertext": L(rec[prefix + "ciphertext"][0])}

@@ -106,10 +106,10 @@ def test_cpp_connected_proof_verifies(cref, tmp_path, circuit):
     evaluations alone, SHPLONK against the proof's commitments and the key's -- with the challenges the binary's own transcript drew"""
     import random
 
+    import bench_connected
     from oracle import pyref as P
-    from oracle import verifier as V
     from paillier_halo2_amd import circuit_structure as CS
-    from paillier_halo2_amd import consts, prover, prover_job
+    from paillier_halo2_amd import prover_job
 
     BITS, K, LB = 128, 14, 13
     R = P.FR_R
@@ -126,34 +126,12 @@ def test_cpp_connected_proof_verifies(cref, tmp_path, circuit):
     line = prover_job.run(job, proof)
     assert line["quotient_degree_ok"] is True and line["proofs"] == 2
     rec = prover_job.read_proofs(proof)
-    A, Lk, mcols, S, n = st.n_adv, st.n_lk, st.m, -(-st.m // prover.CHUNK), 1 << K
-    dom = prover.Domain(K, st.blinding_factors)
-
-    def ints(a):
-        flat = cref.fr_mont_to_ints(np.ascontiguousarray(a).reshape(-1, 4))
-        p = a.shape[1] // 4
-        return [flat[i * p:(i + 1) * p] for i in range(a.shape[0])]
-
-    L = lambda x: sum(int(v) << (64 * i) for i, v in enumerate(x))
     for pi in range(2):
-        pre = "p%d/" % pi
         mm, rr = msgs[pi]
-        assert L(rec[pre + "ciphertext"][0]) == P.paillier_enc_native(nn, g, mm, rr)
-        assert rec[pre + "flags"][0].tolist() == [1, pi]
-        ch = {nm: L(rec[pre + "ch/" + nm][0]) for nm in ("theta", "beta", "gamma", "y", "x", "sh_y", "sh_v", "sh_u")}
-        ev = {k_[len(pre) + 2:]: ints(v_) for k_, v_ in rec.items() if k_.startswith(pre + "e/")}
-        ev["constants"] = ev["lookup_advice"][Lk:]
-        ev["lookup_advice"] = ev["lookup_advice"][:Lk]
-        want = V.expected_h(K, st.blinding_factors, A, Lk, prover.CHUNK, ev, ch["beta"], ch["gamma"], ch["y"], ch["x"], prover.DELTA)
-        assert want == ev["h"][0][0], "h(x)(x^n - 1) != the expression of the evaluations (proof %d)" % pi
-        com = {k_[len(pre) + 2:]: v_ for k_, v_ in rec.items() if k_.startswith(pre + "c/")}
-        assert com["advice"].shape == (A, 8) and com["perm_z"].shape == (S, 8) and com["h"].shape == (3, 8)
-        xn = pow(ch["x"], n, R)
-        hc = cref.g1_normalize(cref.msm_g1(cref.fr_ints_to_mont([pow(xn, i, R) for i in range(3)]), com["h"]))
-        com.update(fixed=rec["vk/fixed"], sigma=rec["vk/sigma"], h=[hc])
-        lay = prover.query_layout(A, Lk, mcols, S)
-        pts = prover.rotation_points(dom, ch["x"])
-        assert V.shplonk_check(cref, lay, pts, com, ev, ch["sh_y"], ch["sh_v"], ch["sh_u"], com["w1"][0], com["w2"][0], s_tox), pi
+        out = bench_connected.verify_file_proof(cref, rec, "p%d/" % pi, st, K, s_tox)
+        assert out["verified"] is True, (pi, out)
+        assert out["ciphertext"] == P.paillier_enc_native(nn, g, mm, rr)
+        assert rec["p%d/flags" % pi][0].tolist() == [1, pi]
     # the two proofs are of different randomness (and, uniform circuit, different messages) under ONE key
     assert not np.array_equal(rec["p0/c/advice"], rec["p1/c/advice"])
     # negative control: one bit of one witness cell flipped after K4 (a gated cell of the first column) -> the quotient is not a
@@ -163,9 +141,8 @@ def test_cpp_connected_proof_verifies(cref, tmp_path, circuit):
     line = prover_job.run(job, bad, env=env, allow_unsatisfied=True)
     assert line["quotient_degree_ok"] is False
     rec = prover_job.read_proofs(bad)
-    ch = {nm: L(rec["p0/ch/" + nm][0]) for nm in ("beta", "gamma", "y", "x")}
-    ev = {k_[5:]: ints(v_) for k_, v_ in rec.items() if k_.startswith("p0/e/")}
-    ev["constants"] = ev["lookup_advice"][Lk:]
-    ev["lookup_advice"] = ev["lookup_advice"][:Lk]
-    assert V.expected_h(K, st.blinding_factors, A, Lk, prover.CHUNK, ev, ch["beta"], ch["gamma"], ch["y"], ch["x"], prover.DELTA) != ev["h"][0][0]
+    out = bench_connected.verify_file_proof(cref, rec, "p0/", st, K, s_tox)
+    assert out["verified"] is False and out["quotient_degree_le_3n_minus_4"] is False
+    assert out["h_x_times_xn_minus_1_equals_expression_of_evaluations"] is False
+    assert out["shplonk_identity_on_the_proofs_commitments"] is True      # the openings of a wrong proof are still honest openings
     print(line)
