@@ -98,10 +98,12 @@ class ConnectedWorkload:
             self.variants = [tuple(lim(x) for x in (nn, g, m, rr)) for rr in (r, vr.randrange(1, nn), vr.randrange(1, nn))]
         # ---- circuit structure (what halo2's keygen extracts by synthesising the circuit once)
         t0 = time.perf_counter()
-        sa = CS.stream_structure(circuit, enc_bits, 64, self.lb, m, nn)
+        sa = CS.stream_structure(circuit, enc_bits, 64, self.lb, m, nn, device="cuda")        # the template tiled on the device ...
         assert (sa.n_steps_g, sa.n_steps_r) == (self.ng, self.nr)
+        torch.cuda.synchronize()
         t1 = time.perf_counter()
-        self.cs, starts = CS.columns(sa, k, self.lb)
+        self.cs, starts = CS.columns(sa, k, self.lb, device="cuda", keep_on_device=True)       # ... and the structure kept there for keygen
+        torch.cuda.synchronize()
         self.n_cells, self.n_lookups = sa.n_cells, int(sa.lookup_src.shape[0])
         del sa
         self.structure_ms = {"stream_walk_and_tiling": (t1 - t0) * 1e3, "columns_cycles_selectors": (time.perf_counter() - t1) * 1e3}

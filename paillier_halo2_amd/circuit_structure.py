@@ -305,10 +305,32 @@ def _exp_bits(e: int) -> List[int]:
     return [(e >> i) & 1 for i in range(e.bit_length())]
 
 
-def stream_structure(kind: str, enc_bits: int, limb_bits: int, lb: int, exp_g: int = 0, exp_r: int = 0) -> StructureArrays:
+def stream_structure(kind: str, enc_bits: int, limb_bits: int, lb: int, exp_g: int = 0, exp_r: int = 0, device: Optional[str] = None) -> StructureArrays:
     """kind 'encrypt': exp_g = the message m, exp_r = the modulus n -- only their BITS are used, as in the reference's circuit
     (pow_mod_fixed_exp, paillier.rs:50-55); kind 'add': no exponents; kind 'encrypt_uniform' (the uniform-shape circuit, SURVEY 8f rank
-    4): exp_g is ignored -- the message's bits are witness cells, ONE structure serves every message of a key."""
+    4): exp_g is ignored -- the message's bits are witness cells, ONE structure serves every message of a key.
+    device: None -> numpy arrays; a torch device ("cuda") -> the template is tiled THERE and `src` / `lookup_src` are tensors on it (at
+    config c2 the tiled arrays are 3.2 GB: 0.9 s of host numpy against a few ms; `columns` takes either)."""
+    dev = None
+    if device is not None:
+        import torch
+
+        dev = torch.device(device)
+
+    def tile(bases: np.ndarray, sol: np.ndarray, assigns=()) -> "np.ndarray | torch.Tensor":
+        """flattened [len(bases)][len(sol)] array of bases[i] + sol[j], columns `pos` overwritten by `vals` ([ns][len(pos)] or [len(pos)])"""
+        if dev is None:
+            t_ = bases[:, None] + sol[None, :]
+            for pos, vals in assigns:
+                t_[:, pos] = vals
+            return t_.reshape(-1)
+        up = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.int64).to(dev)
+        t_ = up(bases)[:, None] + up(sol)[None, :]
+        for pos, vals in assigns:
+            v = up(vals)
+            t_[:, up(pos)] = v if v.dim() == 2 else v[None, :].expand(t_.shape[0], -1)
+        return t_.reshape(-1)
+
     Ln = enc_bits // limb_bits
     L = 2 * Ln
     tm = _block_template(L, limb_bits, lb)
@@ -380,16 +402,16 @@ def stream_structure(kind: str, enc_bits: int, limb_bits: int, lb: int, exp_g: i
         """ns mul_mod blocks starting at stream index `off`; a_cells / b_cells: int64 [ns][L] global cells of the operands' limbs"""
         ns = a_cells.shape[0]
         bases = off + tm.cells * np.arange(ns, dtype=np.int64)
-        s = bases[:, None] + tm.self_or_local[None, :]
+        assigns = []
         for kind_, cells_ in (("a", a_cells), ("b", b_cells)):
             pos, j = tm.ext[kind_]
-            s[:, pos] = cells_[:, j]
+            assigns.append((pos, cells_[:, j]))
         pos, j = tm.ext["n"]
-        s[:, pos] = fresh_arr[j][None, :]
-        s[:, tm.const_pos] = -(1 + tm_const_ids)[None, :]
-        parts_src.append(s.reshape(-1))
+        assigns.append((pos, fresh_arr[j]))
+        assigns.append((tm.const_pos, -(1 + tm_const_ids)))
+        parts_src.append(tile(bases, tm.self_or_local, assigns))
         parts_mask.append(np.tile(tm_mask, ns))
-        parts_lk.append((bases[:, None] + tm.lk[None, :]).reshape(-1))
+        parts_lk.append(tile(bases, tm.lk))
         return off + ns * tm.cells, bases[:, None] + tm.r_cells[None, :]      # r cells of every block
 
     n_steps = [0, 0]
@@ -433,18 +455,18 @@ def stream_structure(kind: str, enc_bits: int, limb_bits: int, lb: int, exp_g: i
                 new_sq = bases[:, None] + ut.r_cells[None, L:]
                 a_cells = np.concatenate([acc_cells[None, :], new_acc[:-1]])
                 b_cells = np.concatenate([sq_cells[None, :], new_sq[:-1]])
-                sblk = bases[:, None] + ut.self_or_local[None, :]
+                assigns = []
                 for kind_, cells_ in (("a", a_cells), ("b", b_cells)):
                     pos, j = ut.ext[kind_]
-                    sblk[:, pos] = cells_[:, j]
+                    assigns.append((pos, cells_[:, j]))
                 pos, j = ut.ext["n"]
-                sblk[:, pos] = fresh_arr[j][None, :]
+                assigns.append((pos, fresh_arr[j]))
                 pos, _ = ut.ext["s"]
-                sblk[:, pos] = np.asarray(bit_cells, dtype=np.int64)[:, None]
-                sblk[:, ut.const_pos] = -(1 + ut_const)[None, :]
-                parts_src.append(sblk.reshape(-1))
+                assigns.append((pos, np.repeat(np.asarray(bit_cells, dtype=np.int64)[:, None], len(pos), axis=1)))
+                assigns.append((ut.const_pos, -(1 + ut_const)))
+                parts_src.append(tile(bases, ut.self_or_local, assigns))
                 parts_mask.append(np.tile(ut_mask, W_))
-                parts_lk.append((bases[:, None] + ut.lk[None, :]).reshape(-1))
+                parts_lk.append(tile(bases, ut.lk))
                 off += W_ * ut.cells
                 acc_cells, sq_cells = new_acc[-1], new_sq[-1]
             n_steps[0] = 2 * Ln * W_
@@ -497,15 +519,22 @@ def stream_structure(kind: str, enc_bits: int, limb_bits: int, lb: int, exp_g: i
         ws.put(eq_cell); ws.put()
         eq_cell = ws.put()
     off = flush(ws)
-    src = np.concatenate(parts_src)
+    if dev is None:
+        src, lookup_src = np.concatenate(parts_src), np.concatenate(parts_lk)
+    else:
+        cat = lambda parts: torch.cat([p_ if isinstance(p_, torch.Tensor) else torch.as_tensor(p_, dtype=torch.int64).to(dev) for p_ in parts])
+        src, lookup_src = cat(parts_src), cat(parts_lk)
     src[eq_cell] = -(1 + cid(1))          # assert_equal_fresh's result is constrained to the constant 1 (bench.rs:74)
-    return StructureArrays(n_cells=off, src=src, gate_mask=np.concatenate(parts_mask), lookup_src=np.concatenate(parts_lk),
+    return StructureArrays(n_cells=off, src=src, gate_mask=np.concatenate(parts_mask), lookup_src=lookup_src,
                            constants=constants, result_cell=eq_cell, n_steps_g=n_steps[0], n_steps_r=n_steps[1])
 
 
-def columns(sa: StructureArrays, k: int, lb: int, max_rows: Optional[int] = None, blinding_factors: int = 6, device: Optional[str] = None):
+def columns(sa: StructureArrays, k: int, lb: int, max_rows: Optional[int] = None, blinding_factors: int = 6, device: Optional[str] = None,
+            keep_on_device: bool = False):
     """stream structure -> (CircuitStructure for prover.keygen, starts).  The permutation covers [advice | lookup advice | constants];
-    every equality class becomes one cycle of sigma (cells in increasing (column, row) order)."""
+    every equality class becomes one cycle of sigma (cells in increasing (column, row) order).
+    keep_on_device: selectors / map_col / map_row stay tensors on `device` (uint8 / int32) for prover.keygen instead of travelling to the
+    host and back (4 GB each way at config c2)."""
     import torch
 
     n = 1 << k
@@ -538,10 +567,10 @@ def columns(sa: StructureArrays, k: int, lb: int, max_rows: Optional[int] = None
     pos[NC + NL + NK:] = (j - 1) * n + (st[j] - st[j - 1])
     # ---- what every node copies
     src = torch.arange(T, dtype=torch.int64, device=dev)
-    s_adv = torch.from_numpy(sa.src).to(dev)
+    s_adv = torch.as_tensor(sa.src).to(dev)
     src[:NC] = torch.where(s_adv < 0, NC + NL - 1 - s_adv, s_adv)          # -(1 + id) -> constant node NC + NL + id
     del s_adv
-    src[NC:NC + NL] = torch.from_numpy(sa.lookup_src).to(dev)
+    src[NC:NC + NL] = torch.as_tensor(sa.lookup_src).to(dev)
     src[NC + NL + NK:] = st[j]
     del j
     while True:                                                           # roots by pointer jumping (chains are a few links long)
@@ -562,11 +591,12 @@ def columns(sa: StructureArrays, k: int, lb: int, max_rows: Optional[int] = None
     del ids, touched
     r_m, p_m = key_root[members], pos[members]
     del key_root
-    order = torch.argsort(p_m)                      # by position ...
-    r_m, p_m = r_m[order], p_m[order]
-    order = torch.argsort(r_m, stable=True)         # ... then stably by class
-    r_m, p_m = r_m[order], p_m[order]
-    del order, members
+    # sorted by (class, position): one sort of the combined key (class < T < 2^31, position < m n < 2^31 at every supported size)
+    span = m * n
+    assert T < (1 << 31) and span < (1 << 31)
+    key, _ = torch.sort(r_m * span + p_m)
+    r_m, p_m = key // span, key % span
+    del key, members
     first = torch.ones_like(r_m, dtype=torch.bool)
     first[1:] = r_m[1:] != r_m[:-1]
     firsts = torch.nonzero(first).view(-1)                 # index of every class's first member ...
@@ -579,14 +609,17 @@ def columns(sa: StructureArrays, k: int, lb: int, max_rows: Optional[int] = None
     nxt_p[last] = p_m[start_of[last]]
     image = torch.arange(m * n, dtype=torch.int64, device=dev)
     image[p_m] = nxt_p
-    map_col = (image // n).to(torch.int32).cpu().numpy().astype(np.uint32).reshape(m, n)
-    map_row = (image % n).to(torch.int32).cpu().numpy().astype(np.uint32).reshape(m, n)
+    map_col, map_row = (image // n).to(torch.int32).view(m, n), (image % n).to(torch.int32).view(m, n)
     del image, p_m, nxt_p, r_m
     # ---- selectors: the gate of a shared break cell is enabled in the column it starts
-    gi = torch.from_numpy(np.flatnonzero(sa.gate_mask).astype(np.int64)).to(dev)
+    gi = torch.nonzero(torch.from_numpy(sa.gate_mask).to(dev)).view(-1)
     sel = torch.zeros(A * n, dtype=torch.uint8, device=dev)
     sel[pos[gi]] = 1
-    selectors = sel.cpu().numpy().reshape(A, n)
+    selectors = sel.view(A, n)
+    if not keep_on_device:
+        map_col = map_col.cpu().numpy().view(np.uint32)
+        map_row = map_row.cpu().numpy().view(np.uint32)
+        selectors = selectors.cpu().numpy()
     cs = CircuitStructure(k=k, lookup_bits=lb, max_rows=max_rows, blinding_factors=blinding_factors, selectors=selectors, n_lk=Lk,
                           constants=list(sa.constants), map_col=map_col, map_row=map_row)
     return cs, starts.astype(np.uint64)

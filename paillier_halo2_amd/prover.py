@@ -53,7 +53,7 @@ class CircuitStructure:
     lookup_bits: int
     max_rows: int                  # rows of a column the circuit assigns (halo2-lib: 2^k - minimum_rows)
     blinding_factors: int          # cs.blinding_factors(): 6 for halo2-lib's 4-rotation gate
-    selectors: np.ndarray          # uint8 [n_adv][2^k]
+    selectors: np.ndarray          # uint8 [n_adv][2^k]  (selectors / map_col / map_row: numpy, or torch tensors already on the device)
     n_lk: int
     constants: Sequence[int]       # the constants fixed column (row i), canonical integers
     map_col: np.ndarray            # uint32 [m][2^k]: sigma as the (column, row) every cell maps to; m = n_adv + n_lk + 1
@@ -149,7 +149,7 @@ class ProvingKey:
         self.dom = d = Domain(st.k, st.blinding_factors, cosets)
         self.bases_lagrange, self.bases_monomial = bases_lagrange, bases_monomial
         n, N, A, m = d.n, d.N, st.n_adv, st.m
-        assert st.max_rows <= d.usable and st.map_col.shape == (m, n) and st.selectors.shape == (A, n)
+        assert st.max_rows <= d.usable and tuple(st.map_col.shape) == (m, n) and tuple(st.selectors.shape) == (A, n)
         self.n_sets = -(-m // CHUNK)
         one = torch.from_numpy(M(1).view(np.int64)).cuda()
         zero4 = torch.zeros_like(one)
@@ -158,7 +158,8 @@ class ProvingKey:
         F = A + 2
         fixed = _zeros(F, n, 4)
         for a0 in range(0, A, GB):
-            sel = torch.from_numpy(np.ascontiguousarray(st.selectors[a0:a0 + GB])).cuda()
+            sel = st.selectors[a0:a0 + GB]          # numpy, or a tensor already on the device (circuit_structure.columns(keep_on_device=True))
+            sel = sel.cuda() if isinstance(sel, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(sel)).cuda()
             fixed[a0:a0 + sel.shape[0]] = torch.where(sel.bool().unsqueeze(-1), one, zero4)
             del sel
         consts_col = list(st.constants) + [0] * (n - len(st.constants))
@@ -171,8 +172,8 @@ class ProvingKey:
         # (one call over all m columns: the images' column indices run over the whole permutation, and the entry point sizes its
         # table of delta powers by the m it is given)
         sigma = _zeros(m, n, 4)
-        d_mc = torch.from_numpy(st.map_col.view(np.int32)).cuda()
-        d_mr = torch.from_numpy(st.map_row.view(np.int32)).cuda()
+        as_dev = lambda a: a.to(torch.int32).cuda().contiguous() if isinstance(a, torch.Tensor) else torch.from_numpy(a.view(np.int32)).cuda()
+        d_mc, d_mr = as_dev(st.map_col), as_dev(st.map_row)
         eng.permutation_sigma_dev(d_mc.data_ptr(), d_mr.data_ptr(), m, st.k, M(d.omega), M(DELTA), sigma.data_ptr(), 4 * n)
         eng.sync()
         del d_mc, d_mr

@@ -24,7 +24,9 @@ def write_job(path: str, st, starts: Sequence[int], enc_bits: int, kind: int, ng
     lim = lambda x, l: consts.int_to_limbs(x, l).astype("<u8")
     hdr = np.array([MAGIC, enc_bits, st.k, st.lookup_bits, st.max_rows, st.blinding_factors, A, st.n_lk, len(st.constants), kind, ng, nr, seed,
                     proofs, tile, len(messages)], dtype="<u8")
-    assert len(starts) == A + 1 and st.selectors.shape == (A, n) and st.map_col.shape == (m, n) == st.map_row.shape
+    host = lambda a: a.cpu().numpy() if hasattr(a, "cpu") else a          # the structure may live on the device
+    selectors, map_col, map_row = host(st.selectors), host(st.map_col), host(st.map_row)
+    assert len(starts) == A + 1 and selectors.shape == (A, n) and map_col.shape == (m, n) == map_row.shape
     with open(path, "wb") as f:
         f.write(hdr.tobytes())
         f.write(lim(nn, Ln).tobytes())
@@ -37,11 +39,9 @@ def write_job(path: str, st, starts: Sequence[int], enc_bits: int, kind: int, ng
         for mm, rr in messages:
             f.write(lim(mm, Ln).tobytes())
             f.write(lim(rr, Ln).tobytes())
-        sel = np.ascontiguousarray(st.selectors, dtype=np.uint8).tobytes()
-        f.write(sel + b"\0" * (-len(sel) % 8))
-        for a in (st.map_col, st.map_row):
-            b = np.ascontiguousarray(a, dtype="<u4").tobytes()
-            f.write(b + b"\0" * (-len(b) % 8))
+        for a in (np.ascontiguousarray(selectors, dtype=np.uint8), np.ascontiguousarray(map_col).view("<u4"), np.ascontiguousarray(map_row).view("<u4")):
+            a.tofile(f)
+            f.write(b"\0" * (-a.nbytes % 8))
 
 
 def read_proofs(path: str) -> Dict[str, np.ndarray]:

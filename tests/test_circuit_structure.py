@@ -93,6 +93,13 @@ def test_product_structure_generator_equals_the_oracle_restatement():
         else:
             mask, _ = P.gate_mask_circuit(kind, bits, W, lb, ng, nr)
         assert np.array_equal(mask, sa.gate_mask) and starts.tolist() == st.starts and np.array_equal(cs.selectors, st.selectors)
+        # the tensor path (what bench.py runs on the device: template tiled by torch, structure kept as tensors) gives the same arrays
+        sa_t = CS.stream_structure(kind, bits, W, lb, m, n, device="cpu")
+        assert np.array_equal(sa_t.src.numpy(), sa.src) and np.array_equal(sa_t.lookup_src.numpy(), sa.lookup_src)
+        assert np.array_equal(sa_t.gate_mask, sa.gate_mask) and sa_t.constants == sa.constants and sa_t.result_cell == sa.result_cell
+        cs_t, starts_t = CS.columns(sa_t, k, lb, device="cpu", keep_on_device=True)
+        assert np.array_equal(starts_t, starts) and np.array_equal(cs_t.selectors.numpy(), cs.selectors)
+        assert np.array_equal(cs_t.map_col.numpy().view(np.uint32), cs.map_col) and np.array_equal(cs_t.map_row.numpy().view(np.uint32), cs.map_row)
         assert sa.n_cells == st.n_cells and sa.lookup_src.shape[0] == st.n_lookups and cs.n_lk == st.n_lk
         assert sorted(cs.constants) == sorted(st.constants)
         # sigma: identical wherever the image is not in the constants column (whose row order is each generator's own) ...
