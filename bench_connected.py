@@ -65,7 +65,7 @@ def cpp_connected(cw, proofs=3, verify_with=None, log=lambda s: None):
 
 class ConnectedWorkload:
     def __init__(self, eng, torch, enc_bits: int, k: int, seed: int, lookup_bits=None, log=lambda s: None, tile: int = 64,
-                 circuit: str = "encrypt", pipeline=None, cosets=None):
+                 circuit: str = "encrypt", pipeline=None, cosets=None, srs=None, trim: bool = True):
         import random
 
         import bench
@@ -111,14 +111,19 @@ class ConnectedWorkload:
         self.starts_host = np.asarray(starts, dtype=np.int64)
         self.A, self.Lk, self.m = self.cs.n_adv, self.cs.n_lk, self.cs.m
         # ---- SRS: monomial and Lagrange bases from a seeded scalar (ParamsKZG::setup, as gen_srs does)
-        self.s_tox = random.Random(seed ^ 0x535253).randrange(2, consts.FR_R)
+        # (srs: (bases_lagrange, bases_monomial, scalar) of another workload of the same k -- the parameters do not depend on the message)
         M = consts.fr_mont_limbs
-        d_g = torch.zeros((self.n, 8), dtype=torch.int64, device="cuda")
-        d_gl = torch.zeros((self.n, 8), dtype=torch.int64, device="cuda")
-        eng.srs_setup_g1_dev(k, M(self.s_tox), M(consts.fr_omega(k)), d_g.data_ptr(), d_gl.data_ptr())
-        eng.sync()
-        self.bl, self.bm = eng.load_bases_dev(d_gl.data_ptr(), self.n), eng.load_bases_dev(d_g.data_ptr(), self.n)
-        del d_g, d_gl
+        self.own_srs = srs is None
+        if srs is None:
+            self.s_tox = random.Random(seed ^ 0x535253).randrange(2, consts.FR_R)
+            d_g = torch.zeros((self.n, 8), dtype=torch.int64, device="cuda")
+            d_gl = torch.zeros((self.n, 8), dtype=torch.int64, device="cuda")
+            eng.srs_setup_g1_dev(k, M(self.s_tox), M(consts.fr_omega(k)), d_g.data_ptr(), d_gl.data_ptr())
+            eng.sync()
+            self.bl, self.bm = eng.load_bases_dev(d_gl.data_ptr(), self.n), eng.load_bases_dev(d_g.data_ptr(), self.n)
+            del d_g, d_gl
+        else:
+            self.bl, self.bm, self.s_tox = srs
         # ---- keygen_vk + keygen_pk: all three forms of the fixed and permutation polynomials, resident
         torch.cuda.synchronize()
         t2 = time.perf_counter()
@@ -127,11 +132,12 @@ class ConnectedWorkload:
         self.pk = prover.keygen(eng, self.cs, self.bl, self.bm, cosets=self.cosets)
         torch.cuda.synchronize()
         self.keygen_ms = (time.perf_counter() - t2) * 1e3
-        torch.cuda.empty_cache()
+        if trim:                                   # hand the allocator's free blocks back (trim=False: a following key reuses them)
+            torch.cuda.empty_cache()
         self.ws = prover.Workspace(self.pk, tile)
         # two witness slots: proof i+1's K3 + K4 run on a second context / stream under proof i's advice commitments
         self.pipeline = (os.environ.get("PZ_CONNECTED_PIPELINE", "1") == "1") if pipeline is None else bool(pipeline)
-        self.slots = [torch.zeros((self.m, self.n, 4), dtype=torch.int64, device="cuda") for _ in range(2 if self.pipeline else 1)]
+        self.slots = [prover._zeros_cap(self.m, self.n, 4) for _ in range(2 if self.pipeline else 1)]
         self.cols = self.slots[0]
         self.engw, self.stream_w = eng, None
         if self.pipeline:
@@ -361,9 +367,10 @@ class ConnectedWorkload:
                 "commitments": int(sum(v.shape[0] for v in pr.commitments.values())), "evaluations": int(sum(v.shape[0] * v.shape[1] for v in pr.evals.values())),
                 "checker_s": time.perf_counter() - t0}
 
-    def release(self):
-        for b in (self.bl, self.bm):
-            b.free()
+    def release(self, trim: bool = True):
+        if self.own_srs:
+            for b in (self.bl, self.bm):
+                b.free()
         self.torch.cuda.synchronize()
         if self.engw is not self.eng:
             self.engw.close()
@@ -373,7 +380,8 @@ class ConnectedWorkload:
         self.lanes = None
         for name in ("pk", "ws", "cols", "slots", "d_steps", "last"):
             setattr(self, name, None)
-        self.torch.cuda.empty_cache()
+        if trim:
+            self.torch.cuda.empty_cache()
 
 
 def verify_file_proof(cref, rec, prefix, st, k, s_tox):

@@ -80,6 +80,13 @@ def _zeros(*shape):
     return torch.zeros(shape, dtype=torch.int64, device="cuda")
 
 
+def _zeros_cap(count: int, *shape, q: int = 64):
+    """[count, *shape] zeros inside an allocation of ceil(count / q) * q rows: keys of nearly equal column counts (a new message of the
+    reference's circuit moves the advice column count by a few) then ask torch's caching allocator for IDENTICAL block sizes, so the
+    next key's 100-GB tensors reuse the previous key's blocks instead of fragmenting them (a re-malloc of the key costs 4-5 s)"""
+    return _zeros(-(-count // q) * q, *shape)[:count]
+
+
 def _ints_to_dev_mont(eng: Engine, vals: Sequence[int]):
     """canonical integers -> Montgomery elements on the device (upload of raw limbs + pz_fr_convert_dev)"""
     torch = _torch()
@@ -156,7 +163,7 @@ class ProvingKey:
         GB = 256                                   # columns per keygen call (bounds the library's MSM / NTT workspaces)
         # ---- fixed columns: [selectors | constants | table], Lagrange form
         F = A + 2
-        fixed = _zeros(F, n, 4)
+        fixed = _zeros_cap(F, n, 4)
         for a0 in range(0, A, GB):
             sel = st.selectors[a0:a0 + GB]          # numpy, or a tensor already on the device (circuit_structure.columns(keep_on_device=True))
             sel = sel.cuda() if isinstance(sel, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(sel)).cuda()
@@ -171,19 +178,19 @@ class ProvingKey:
         # ---- sigma polynomials from the copy-constraint map
         # (one call over all m columns: the images' column indices run over the whole permutation, and the entry point sizes its
         # table of delta powers by the m it is given)
-        sigma = _zeros(m, n, 4)
+        sigma = _zeros_cap(m, n, 4)
         as_dev = lambda a: a.to(torch.int32).cuda().contiguous() if isinstance(a, torch.Tensor) else torch.from_numpy(a.view(np.int32)).cuda()
         d_mc, d_mr = as_dev(st.map_col), as_dev(st.map_row)
         eng.permutation_sigma_dev(d_mc.data_ptr(), d_mr.data_ptr(), m, st.k, M(d.omega), M(DELTA), sigma.data_ptr(), 4 * n)
         eng.sync()
         del d_mc, d_mr
-        self.sigma_lagrange = sigma.clone()
+        self.sigma_lagrange = _zeros_cap(m, n, 4).copy_(sigma)
         # ---- keygen_vk + keygen_pk: commitments, coefficient forms (in place), extended forms
         self.fixed_commit = _zeros(F, 12)
         self.sigma_commit = _zeros(m, 12)
         P0 = d.parts[0]
-        self.fixed_ext = [_zeros(F, pt["size"], 4) for pt in d.parts]      # per part of the quotient's domain (Domain._parts)
-        self.sigma_ext = [_zeros(m, pt["size"], 4) for pt in d.parts]
+        self.fixed_ext = [_zeros_cap(F, pt["size"], 4) for pt in d.parts]      # per part of the quotient's domain (Domain._parts)
+        self.sigma_ext = [_zeros_cap(m, pt["size"], 4) for pt in d.parts]
         for t_, cnt_all, com, ext in ((fixed, F, self.fixed_commit, self.fixed_ext), (sigma, m, self.sigma_commit, self.sigma_ext)):
             for c0 in range(0, cnt_all, GB):
                 cnt = min(GB, cnt_all - c0)
@@ -313,10 +320,10 @@ class Workspace:
         n, N, Lk, S = d.n, d.N, st.n_lk, pk.n_sets
         assert tile % CHUNK == 0
         self.tile = tile
-        self.Ap, self.Sp, self.Zl = _zeros(Lk, n, 4), _zeros(Lk, n, 4), _zeros(Lk, n, 4)
-        self.Z = _zeros(S, n, 4)
+        self.Ap, self.Sp, self.Zl = _zeros_cap(Lk, n, 4, q=8), _zeros_cap(Lk, n, 4, q=8), _zeros_cap(Lk, n, 4, q=8)
+        self.Z = _zeros_cap(S, n, 4)
         lt = min(tile, Lk)
-        self.z_ext = [_zeros(S, pt["size"], 4) for pt in d.parts]
+        self.z_ext = [_zeros_cap(S, pt["size"], 4) for pt in d.parts]
         self.ext = [_zeros(tile, pt["size"], 4) for pt in d.parts]
         self.lk_ext = [[_zeros(lt, pt["size"], 4) for _ in range(4)] for pt in d.parts]
         self.hh = [_zeros(2, pt["size"], 4) for pt in d.parts]
