@@ -1627,12 +1627,12 @@ def main():
             gc.collect()
             # the same through the UNIFORM-shape circuit (row f4): ONE proving key for every message of a key, so the proofs of this
             # loop are of DISTINCT messages -- what a user who encrypts different messages gets once that key exists.  (The reference's
-            # circuit needs a new structure + keygen per message: with_next_rows.circuit_structure_ms + keygen_ms.)  One witness slot:
-            # its proving key is 166 GB.
+            # circuit needs a new structure + keygen per message: `fresh_message`.)  Two witness slots since the three-coset quotient
+            # (its proving key: 136 GB resident, 208 GB allocated in all).
             if (args.enc_bits, args.k) == (2048, 17) and not args.no_c2u:
                 t_u = time.time()
                 cu = bench_connected.ConnectedWorkload(eng, torch, args.enc_bits, args.k, args.seed, lookup_bits=args.lookup_bits, log=log,
-                                                       circuit="encrypt_uniform", pipeline=False)
+                                                       circuit="encrypt_uniform")
                 cu.run(1, timed=False)
                 barrier()
                 tu0 = time.perf_counter()

@@ -1,5 +1,5 @@
 """The connected-proof workload of bench.py (bench_connected.ConnectedWorkload) alone: setup times, memory, per-phase times, the
-checker's verdict.  Usage: python profiles/probes/connected_probe.py [enc_bits k steps]   (default 2048 17 3)"""
+checker's verdict.  Usage: python profiles/probes/connected_probe.py [enc_bits k steps [circuit]]   (default 2048 17 3 encrypt)"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -7,11 +7,12 @@ import paillier_halo2_amd as pz
 import bench_connected
 
 bits, k, steps = (int(x) for x in (sys.argv[1:4] + ["2048", "17", "3"][len(sys.argv) - 1:]))
+circuit = sys.argv[4] if len(sys.argv) > 4 else "encrypt"
 eng = pz.Engine(0)
 eng.bind_torch_stream()
 log = lambda s: print("[probe] " + s, flush=True)
 t0 = time.time()
-wl = bench_connected.ConnectedWorkload(eng, torch, bits, k, 0x5043, log=log)
+wl = bench_connected.ConnectedWorkload(eng, torch, bits, k, 0x5043, log=log, circuit=circuit)
 log("setup %.1f s: structure %s keygen %.0f ms memory %s counts %s" % (time.time() - t0, wl.structure_ms, wl.keygen_ms, wl.memory_gb, wl.counts()))
 wl.run(1, timed=False)
 torch.cuda.synchronize()
