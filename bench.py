@@ -1616,9 +1616,9 @@ def main():
             if not args.no_dropin:
                 try:
                     t_p = time.time()
-                    out["with_next_rows_cpp"] = bench_connected.cpp_connected(cw, proofs=3, verify_with=_cref if ver is not None else None, log=log)
+                    out["with_next_rows_cpp"] = bench_connected.cpp_connected(cw, proofs=4, verify_with=_cref if ver is not None else None, log=log)
                     log("connected, compiled prover %.1fs: %.1f ms per proof, verified %s" % (
-                        time.time() - t_p, out["with_next_rows_cpp"]["ms_per_proof_best_of"], out["with_next_rows_cpp"].get("verified")))
+                        time.time() - t_p, out["with_next_rows_cpp"]["ms_per_step"], out["with_next_rows_cpp"].get("verified")))
                     if out["with_next_rows_cpp"].get("verified") is False:
                         out["comparable"] = False
                 except Exception as ex:

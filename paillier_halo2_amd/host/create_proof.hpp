@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -315,7 +316,10 @@ inline void blind_rows(Ctx& cx, Workspace& w, Rng& rng, uint64_t* d_cols, size_t
 inline Fr pow_small(const Fr& a, uint64_t e) { return pzh::pow_u64(a, e); }
 
 // d_cols: [m][2^k] elements: advice then lookup-advice columns as K4 wrote them; consumed (ends in coefficient form)
-inline Proof create_proof(Ctx& cx, ProvingKey& pk, Workspace& w, uint64_t* d_cols, Transcript& tr, uint64_t seed) {
+// after_advice_launch: called once the advice commitments are queued and before the host waits for them -- the caller's chance to queue
+// independent work on ANOTHER context (the next proof's K3 + K4) under this proof's largest commitment batch
+inline Proof create_proof(Ctx& cx, ProvingKey& pk, Workspace& w, uint64_t* d_cols, Transcript& tr, uint64_t seed,
+                          const std::function<void()>& after_advice_launch = nullptr) {
     const Structure& st = pk.st;
     const Domain& d = pk.dom;
     const size_t n = d.n, u = d.usable, A = st.n_adv, Lk = st.n_lk, m = st.m(), S = pk.n_sets, W = A + Lk, tile = w.tile;
@@ -339,6 +343,7 @@ inline Proof create_proof(Ctx& cx, ProvingKey& pk, Workspace& w, uint64_t* d_col
     PZP_CK(pz_dev_copy(cx.c, d_cols + W * n * 4, pk.const_lagrange, n * 32));
     uint64_t* c_adv = w.out12;
     commit(pk.bl, d_cols, W, c_adv);
+    if (after_advice_launch) after_advice_launch();
     {
         std::vector<uint64_t> aff;
         tr.absorb_points(cx, c_adv, W, &aff);
