@@ -577,6 +577,10 @@ class Engine:
     def dev_copy(self, d_dst: int, d_src: int, nbytes: int):
         self._chk(self.L.pz_dev_copy(self.ctx, VP(d_dst), VP(d_src), nbytes), "pz_dev_copy")
 
+    def dev_copy_2d(self, d_dst: int, dst_pitch: int, d_src: int, src_pitch: int, width: int, rows: int):
+        """`rows` runs of `width` bytes, the runs dst_pitch / src_pitch bytes apart (device to device, on the context's stream)"""
+        self._chk(self.L.pz_dev_copy_2d(self.ctx, VP(d_dst), dst_pitch, VP(d_src), src_pitch, width, rows), "pz_dev_copy_2d")
+
     def wait_for(self, other: "Engine"):
         """everything `other` has queued so far happens before what this engine queues from now on"""
         self._chk(self.L.pz_ctx_wait(self.ctx, other.ctx), "pz_ctx_wait")

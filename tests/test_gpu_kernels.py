@@ -466,6 +466,32 @@ def test_device_memory_entry_points(eng, cref):
     eng.dev_free(0)
 
 
+def test_dev_copy_2d(eng):
+    """pz_dev_copy_2d: the strided device copy the compiled prover fills the blinding rows with (rows [u, n) of every column from one
+    staged block); pitches below the width and null pointers are refused"""
+    import paillier_halo2_amd as pz
+
+    rng = np.random.default_rng(77)
+    n, cols, rows = 256, 5, 7                       # 5 columns of 256 elements; the last 7 elements of each are overwritten
+    base = rng.integers(0, 1 << 63, size=(cols, n, 4), dtype=np.uint64)
+    blind = rng.integers(0, 1 << 63, size=(cols, rows, 4), dtype=np.uint64)
+    d_cols, d_blind = eng.dev_alloc(base.nbytes), eng.dev_alloc(blind.nbytes)
+    eng.upload(d_cols, base)
+    eng.upload(d_blind, blind)
+    eng.dev_copy_2d(d_cols + (n - rows) * 32, n * 32, d_blind, rows * 32, rows * 32, cols)
+    want = base.copy()
+    want[:, n - rows:] = blind
+    assert np.array_equal(eng.download(d_cols, (cols * n, 4)).reshape(cols, n, 4), want)
+    eng.dev_copy_2d(d_cols, n * 32, d_blind, rows * 32, 0, cols)          # nothing to copy
+    eng.dev_copy_2d(d_cols, n * 32, d_blind, rows * 32, rows * 32, 0)
+    assert np.array_equal(eng.download(d_cols, (cols * n, 4)).reshape(cols, n, 4), want)
+    for args in ((d_cols, 8, d_blind, rows * 32, 16, 2), (d_cols, 64, d_blind, 8, 16, 2), (0, 64, d_blind, 64, 16, 2), (d_cols, 64, 0, 64, 16, 2)):
+        with pytest.raises(pz.PzError):
+            eng.dev_copy_2d(*args)
+    eng.dev_free(d_cols)
+    eng.dev_free(d_blind)
+
+
 # ------------------------------------------------------------------------------------------ K4
 @pytest.mark.parametrize("L,lb,W", [(2, 15, 64), (4, 16, 64), (4, 14, 64), (4, 8, 64), (64, 16, 64), (64, 14, 64), (96, 18, 64),
                                     (6, 15, 88),     # the reference's add test: 264-bit key, 88-bit limbs (paillier.rs:186-187,247)
