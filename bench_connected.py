@@ -3,7 +3,7 @@ of paillier_halo2_amd/prover.py on the proof's own data (reference: /root/refere
 
     K3 trace -> K4 cells in halo2-lib's break-point column layout -> advice commitments -> permuted lookup columns -> grand products
     -> (challenge y) -> coefficient forms -> 64-column tiles extended and folded into the quotient as they are produced, against the
-    RESIDENT extended forms of the proving key (selectors + sigma: 103 GB at c2) -> h pieces -> evaluations -> SHPLONK,
+    RESIDENT extended forms of the proving key (selectors + sigma: 77 GB at c2 on the quotient's three cosets) -> h pieces -> evaluations -> SHPLONK,
 
 every phase closed by a synchronising download of its commitments into a hashing transcript (the host round trip a real transcript
 forces).  The circuit structure (selectors, copy constraints, break points) comes from paillier_halo2_amd/circuit_structure.py; the

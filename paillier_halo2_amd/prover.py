@@ -24,7 +24,7 @@ hands back -- that is the host round trip between phases), the verifier / G2 sid
 positions, copy constraints, break points: the dependency's keygen knows them; they are an input, `CircuitStructure`).
 
 Memory plan: the proving key's extended forms are RESIDENT (at config c2: 3033 selectors + 3118 sigma
-columns x 2^19 x 32 B = 103 GB of the 288 GB); the proof's own columns are extended tile by tile (`tile` columns at a time) and never
+columns x 2^19 x 32 B = 103 GB of the 288 GB on halo2's 4n-point domain, 77 GB on the three cosets used here); the proof's own columns are extended tile by tile (`tile` columns at a time) and never
 exist on the extended domain all at once -- only the grand products Z (which the chaining lines read across sets) do.
 """
 from __future__ import annotations
