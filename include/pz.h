@@ -481,6 +481,67 @@ int pz_shplonk_finish_dev(pz_ctx* ctx, pz_shplonk* state, const uint64_t u[4], c
 int pz_shplonk_free(pz_ctx* ctx, pz_shplonk* state);
 
 /* ---------------------------------------------------------------------------------------------
+ * Patch point D as entry points: keygen and create_proof, one call per transcript round.
+ * Replaces, for halo2-lib circuits (one gate q (a + b c - d) per advice column, range-check lookups of lookup-enabled advice columns
+ * against one table column, a permutation over [advice | lookup advice | constants]): halo2-axiom's keygen_vk / keygen_pk /
+ * create_proof as reached from /root/reference/src/bench.rs:161-171 (bench_builder -> keygen -> gen_proof).  The composition is the
+ * one of paillier_halo2_amd/host/create_proof.hpp (the code tests/cpp/prove_connected runs; the quotient on three cosets of <omega_n>:
+ * DESIGN.md section 6.3); the transcript stays with the caller: every phase returns what must be absorbed (affine points of 8 words,
+ * evaluations of 4 words, all Montgomery) and takes the challenges squeezed after it (Montgomery representatives below r, else
+ * PZ_ERR_INVALID).  The circuit STRUCTURE is an input of keygen, as it is of halo2's: selector positions, the constants column, and
+ * the copy constraints as a permutation map (cell (c, r) of the permutation's columns -> (map_col, map_row); identity where
+ * unconstrained) over m = n_adv + n_lk + 1 columns; the lookup table is 0 .. 2^lookup_bits - 1.  chunk = 2 (cs.degree() = 4).
+ *
+ * pz_pk_create   selectors: u8 [n_adv][2^k]; constants: n_constants x 4 words, canonical integers (NOT Montgomery), row order;
+ *                map_col / map_row: u32 [m][2^k] (all host).  Builds and keeps RESIDENT the commitments, the coefficient forms and the
+ *                extended forms of the fixed and sigma columns, l_0 / l_last / l_active, and one proof's workspace (at config c2:
+ *                116 + 30 GB).  tile: columns extended per step of the quotient (even; 64).  The key holds device memory of `ctx`
+ *                (which must outlive it) and serves ONE proof at a time.
+ * pz_pk_info     n_fixed = n_adv + 2 (selectors | constants | table); blinding_words = 64-bit words of caller randomness one proof
+ *                consumes; evals_words = length of pz_proof_evaluate's output.
+ * pz_pk_commitments  the verifying key's commitments: n_fixed x 8 and m x 8 words.
+ *
+ * pz_proof_begin d_cols: device, [m][2^k] elements: the advice then the lookup-advice columns as pz_circuit_expand_cols_dev wrote
+ *                them (rows >= max_rows zero); the last column and the blinding rows are filled here; CONSUMED (ends in coefficient
+ *                form).  blinding: n_blinding >= blinding_words random words (host), or NULL: a xorshift stream from `seed` (tests,
+ *                benches -- not for production).  -> advice_affine: (n_adv + n_lk) x 8.           [transcript: ... -> theta]
+ * pz_proof_lookups       -> n_lk x 8 each (permuted inputs A', permuted tables S')                 [-> beta, gamma]
+ * pz_proof_products      -> n_sets x 8 (permutation products), n_lk x 8 (lookup products), 8 (the vanishing argument's random
+ *                        polynomial)                                                              [-> y]
+ * pz_proof_quotient      -> 3 x 8: the quotient's pieces h_0, h_1, h_2                             [-> x]
+ * pz_proof_evaluate      -> evals_words words: for each family in this order, for each of its polynomials, its values at the
+ *                        family's points (indices into {x, wx, w^2 x, w^3 x, w^-(blinding_factors+1) x, w^-1 x}):
+ *                        advice n_adv {0,1,2,3} | lookup advice then the constants column n_lk + 1 {0} | fixed n_fixed {0} |
+ *                        sigma m {0} | permutation products n_sets {0,1,4} | lookup products n_lk {0,1} | A' n_lk {0,5} |
+ *                        S' n_lk {0} | random 1 {0} | h_0 + x^n h_1 + x^2n h_2 1 {0} (the verifier computes the last itself:
+ *                        not absorbed)                                                            [-> SHPLONK's y, v]
+ * pz_proof_open_begin    -> 8: SHPLONK's first commitment                                          [-> u]
+ * pz_proof_open_finish   -> 8: the second; quotient_degree_ok = 0 if the quotient's degree exceeds 3n - 4 (an unsatisfied
+ *                        witness: the proof will not verify).
+ * Phases out of order return PZ_ERR_INVALID; after any error only pz_proof_free is valid.  pz_proof_free releases the key's
+ * workspace for the next proof; pz_pk_free refuses (PZ_ERR_INVALID) while a proof is open.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct pz_pk pz_pk;
+typedef struct pz_proof pz_proof;
+int pz_pk_create(pz_ctx* ctx, const pz_bases* bases_lagrange, const pz_bases* bases_monomial, uint32_t k, uint32_t lookup_bits,
+                 uint32_t blinding_factors, size_t max_rows, size_t n_adv, size_t n_lk, const uint8_t* selectors,
+                 const uint64_t* constants, size_t n_constants, const uint32_t* map_col, const uint32_t* map_row, size_t tile,
+                 pz_pk** out);
+int pz_pk_info(const pz_pk* pk, size_t* n_fixed, size_t* n_perm_cols, size_t* n_sets, size_t* blinding_words, size_t* evals_words);
+int pz_pk_commitments(const pz_pk* pk, uint64_t* fixed_affine, uint64_t* sigma_affine);
+int pz_pk_free(pz_pk* pk);
+int pz_proof_begin(pz_pk* pk, uint64_t* d_cols, uint64_t seed, const uint64_t* blinding, size_t n_blinding, pz_proof** out,
+                   uint64_t* advice_affine);
+int pz_proof_lookups(pz_proof* proof, const uint64_t theta[4], uint64_t* perm_inputs_affine, uint64_t* perm_tables_affine);
+int pz_proof_products(pz_proof* proof, const uint64_t beta[4], const uint64_t gamma[4], uint64_t* perm_z_affine,
+                      uint64_t* lookup_z_affine, uint64_t* random_affine);
+int pz_proof_quotient(pz_proof* proof, const uint64_t y[4], uint64_t* h_affine);
+int pz_proof_evaluate(pz_proof* proof, const uint64_t x[4], uint64_t* evals);
+int pz_proof_open_begin(pz_proof* proof, const uint64_t y[4], const uint64_t v[4], uint64_t* w1_affine);
+int pz_proof_open_finish(pz_proof* proof, const uint64_t u[4], uint64_t* w2_affine, int* quotient_degree_ok);
+int pz_proof_free(pz_proof* proof);
+
+/* ---------------------------------------------------------------------------------------------
  * measurement helpers (used by bench.py; not part of the reference surface).  Issue-rate microbenchmarks: libpz_probe.so.
  * ------------------------------------------------------------------------------------------- */
 /* HIP-event timing of the dominant kernel on the context's stream: accumulated since the last

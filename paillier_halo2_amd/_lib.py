@@ -109,6 +109,21 @@ SIGNATURES = {
                                        C.POINTER(VP)]),
     "pz_shplonk_finish_dev": (C.c_int, [VP, VP, VP, VP, VP]),
     "pz_shplonk_free": (C.c_int, [VP, VP]),
+    # patch point D as entry points: keygen + create_proof, one call per transcript round
+    "pz_pk_create": (C.c_int, [VP, VP, VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, C.c_size_t, C.c_size_t, VP, VP, C.c_size_t, VP, VP,
+                               C.c_size_t, C.POINTER(VP)]),
+    "pz_pk_info": (C.c_int, [VP, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                             C.POINTER(C.c_size_t)]),
+    "pz_pk_commitments": (C.c_int, [VP, VP, VP]),
+    "pz_pk_free": (C.c_int, [VP]),
+    "pz_proof_begin": (C.c_int, [VP, VP, C.c_uint64, VP, C.c_size_t, C.POINTER(VP), VP]),
+    "pz_proof_lookups": (C.c_int, [VP, VP, VP, VP]),
+    "pz_proof_products": (C.c_int, [VP, VP, VP, VP, VP, VP]),
+    "pz_proof_quotient": (C.c_int, [VP, VP, VP]),
+    "pz_proof_evaluate": (C.c_int, [VP, VP, VP]),
+    "pz_proof_open_begin": (C.c_int, [VP, VP, VP, VP]),
+    "pz_proof_open_finish": (C.c_int, [VP, VP, VP, C.POINTER(C.c_int)]),
+    "pz_proof_free": (C.c_int, [VP]),
     "pz_timing_enable": (C.c_int, [VP, C.c_int]),
     "pz_timing_reset": (C.c_int, [VP]),
     "pz_timing_get": (C.c_int, [VP, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

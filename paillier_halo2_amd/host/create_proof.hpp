@@ -25,13 +25,24 @@
 namespace pzp {
 using pzh::Fr;
 
-#define PZP_CK(x)                                                                                          \
+// a failed entry point: the drivers print and exit; inside the library (PZP_THROW: csrc/pz_prover.cpp) it becomes an exception that the C
+// entry point catches and returns as its status -- nothing is thrown across the ABI
+struct PzpError {
+    int rc;
+};
+#ifdef PZP_THROW
+#define PZP_FAIL(rc_, what_) throw ::pzp::PzpError{rc_}
+#else
+#define PZP_FAIL(rc_, what_)                                                                               \
     do {                                                                                                   \
-        int rc_ = (x);                                                                                     \
-        if (rc_ != PZ_OK) {                                                                                \
-            fprintf(stderr, "%s:%d: %s -> %d (%s)\n", __FILE__, __LINE__, #x, rc_, pz_strerror(rc_));      \
-            exit(2);                                                                                       \
-        }                                                                                                  \
+        fprintf(stderr, "%s:%d: %s -> %d (%s)\n", __FILE__, __LINE__, what_, rc_, pz_strerror(rc_));       \
+        exit(2);                                                                                           \
+    } while (0)
+#endif
+#define PZP_CK(x)                           \
+    do {                                    \
+        int rc_ = (x);                      \
+        if (rc_ != PZ_OK) PZP_FAIL(rc_, #x); \
     } while (0)
 
 static const unsigned CHUNK = 2;   // permutation columns per grand product: degree - 2
@@ -290,11 +301,19 @@ inline Workspace make_workspace(Ctx& cx, const ProvingKey& pk, size_t tile = 64)
     return w;
 }
 
-// blinding values: uniform 252-bit integers as Montgomery representatives (all below r), from a seeded xorshift
+// blinding values: uniform 252-bit integers as Montgomery representatives (all below r) -- from the caller's random words when given
+// (a production prover hands over OS randomness: pz_pk_blinding_words says how many), else from a seeded xorshift (tests, benches)
 struct Rng {
     uint64_t s;
+    const uint64_t* words = nullptr;
+    size_t n_words = 0, used = 0;
     explicit Rng(uint64_t seed) : s(seed * 0x9e3779b97f4a7c15ULL + 1) {}
+    Rng(const uint64_t* w, size_t n) : s(1), words(w), n_words(n) {}
     uint64_t next() {
+        if (words) {
+            if (used >= n_words) PZP_FAIL(PZ_ERR_INVALID, "blinding words exhausted");
+            return words[used++];
+        }
         s ^= s << 13; s ^= s >> 7; s ^= s << 17;
         return s;
     }
@@ -303,6 +322,11 @@ struct Rng {
         for (size_t i = 3; i < v.size(); i += 4) v[i] &= 0x0fffffffffffffffULL;
     }
 };
+// 64-bit words of randomness one proof consumes (blinding rows of the advice / permuted / product columns + the random polynomial)
+inline size_t blinding_words(const ProvingKey& pk) {
+    const size_t b = pk.dom.bf + 1, W = pk.st.n_adv + pk.st.n_lk, Lk = pk.st.n_lk, S = pk.n_sets;
+    return 4 * (W * b + 2 * Lk * b + (S + Lk) * (b - 1) + pk.dom.n);
+}
 
 // rows [row0, n) of `count` columns (stride n elements) <- random elements
 inline void blind_rows(Ctx& cx, Workspace& w, Rng& rng, uint64_t* d_cols, size_t count, size_t n, size_t row0) {
@@ -315,231 +339,325 @@ inline void blind_rows(Ctx& cx, Workspace& w, Rng& rng, uint64_t* d_cols, size_t
 
 inline Fr pow_small(const Fr& a, uint64_t e) { return pzh::pow_u64(a, e); }
 
-// d_cols: [m][2^k] elements: advice then lookup-advice columns as K4 wrote them; consumed (ends in coefficient form)
-// after_advice_launch: called once the advice commitments are queued and before the host waits for them -- the caller's chance to queue
-// independent work on ANOTHER context (the next proof's K3 + K4) under this proof's largest commitment batch
-inline Proof create_proof(Ctx& cx, ProvingKey& pk, Workspace& w, uint64_t* d_cols, Transcript& tr, uint64_t seed,
-                          const std::function<void()>& after_advice_launch = nullptr) {
-    const Structure& st = pk.st;
-    const Domain& d = pk.dom;
-    const size_t n = d.n, u = d.usable, A = st.n_adv, Lk = st.n_lk, m = st.m(), S = pk.n_sets, W = A + Lk, tile = w.tile;
-    const unsigned k = d.k, bf = d.bf;
-    Rng rng(seed);
-    Proof pr;
-    auto commit = [&](const pz_bases* b, const uint64_t* t, size_t count, uint64_t* out) {
+// the families of polynomials a proof opens, in the order their evaluations are handed over (and absorbed); points = indices into the six
+// rotation points {x, wx, w^2 x, w^3 x, w^-(bf+1) x, w^-1 x}.  "lookup_advice" carries the constants column as its last polynomial.
+struct Fam {
+    const char* name;
+    const uint64_t* polys;
+    size_t count;
+    std::vector<int> idx;
+};
+
+// ONE PROOF IN FLIGHT, phase by phase: each method runs a phase on the device and hands back what the transcript must absorb before the
+// next challenge exists (affine commitments, 8 words each; evaluations, 4 words each, Montgomery).  Methods must be called in order.
+// d_cols: [m][2^k] elements: advice then lookup-advice columns as K4 wrote them; consumed (ends in coefficient form).
+struct Session {
+    Ctx& cx;
+    ProvingKey& pk;
+    Workspace& w;
+    uint64_t* d_cols;
+    Rng rng;
+    Fr beta, gamma, y, x, xs[6];
+    uint64_t* pieces = nullptr;
+    std::vector<Fam> fams;
+    std::vector<std::vector<uint64_t>> ev;
+    pz_shplonk* state = nullptr;
+    int phase = 0;
+
+    Session(Ctx& cx_, ProvingKey& pk_, Workspace& w_, uint64_t* d_cols_, Rng rng_) : cx(cx_), pk(pk_), w(w_), d_cols(d_cols_), rng(rng_) {}
+    ~Session() {
+        if (state) pz_shplonk_free(cx.c, state);
+    }
+    void expect(int p) {
+        if (phase != p) PZP_FAIL(PZ_ERR_INVALID, "proof phases out of order");
+        phase = p + 1;
+    }
+    void commit(const pz_bases* b, const uint64_t* t, size_t count, uint64_t* out) {
         uint32_t nw = 0, cb = 0;
         size_t np = 0;
         PZP_CK(pz_bases_info(b, &np, &cb, &nw));
-        PZP_CK(pz_msm_g1_dev(cx.c, b, t, count, n, 4 * n, 0, nw, out));
-    };
-    auto keep = [&](const char* name, const uint64_t* d_jac, size_t count) {
-        std::vector<uint64_t> aff;
-        tr.absorb_points(cx, d_jac, count, &aff);
-        pr.commitments.push_back({name, aff});
-    };
-    const Fr delta = pzh::delta();
-    // ---- 1. advice
-    blind_rows(cx, w, rng, d_cols, W, n, u);
-    PZP_CK(pz_dev_copy(cx.c, d_cols + W * n * 4, pk.const_lagrange, n * 32));
-    uint64_t* c_adv = w.out12;
-    commit(pk.bl, d_cols, W, c_adv);
-    if (after_advice_launch) after_advice_launch();
-    {
-        std::vector<uint64_t> aff;
-        tr.absorb_points(cx, c_adv, W, &aff);
-        pr.commitments.push_back({"advice", std::vector<uint64_t>(aff.begin(), aff.begin() + 8 * A)});
-        pr.commitments.push_back({"lookup_advice", std::vector<uint64_t>(aff.begin() + 8 * A, aff.end())});
+        PZP_CK(pz_msm_g1_dev(cx.c, b, t, count, pk.dom.n, 4 * pk.dom.n, 0, nw, out));
     }
-    tr.squeeze("theta");
-    // ---- 2. lookups
-    uint64_t* lk_in = d_cols + A * n * 4;
-    PZP_CK(pz_lookup_permute_dev(cx.c, lk_in, Lk, 4 * n, pk.table_lagrange, u, st.lookup_bits, w.Ap, w.Sp, 4 * n));
-    blind_rows(cx, w, rng, w.Ap, Lk, n, u);
-    blind_rows(cx, w, rng, w.Sp, Lk, n, u);
-    commit(pk.bl, w.Ap, Lk, w.out12);
-    keep("perm_inputs", w.out12, Lk);
-    commit(pk.bl, w.Sp, Lk, w.out12);
-    keep("perm_tables", w.out12, Lk);
-    const Fr beta = tr.squeeze("beta"), gamma = tr.squeeze("gamma");
-    // ---- 3. grand products
-    PZP_CK(pz_permutation_product_sets_dev(cx.c, d_cols, 4 * n, pk.sigma_lagrange, 4 * n, m, CHUNK, k, u, d.omega.v, beta.v, gamma.v, delta.v, w.Z,
-                                           4 * n));
-    blind_rows(cx, w, rng, w.Z, S, n, u + 1);
-    PZP_CK(pz_lookup_product_dev(cx.c, lk_in, 4 * n, pk.table_lagrange, w.Ap, 4 * n, w.Sp, 4 * n, Lk, n, beta.v, gamma.v, pzh::FR_ONE.v, w.Zl, 4 * n));
-    blind_rows(cx, w, rng, w.Zl, Lk, n, u + 1);
-    commit(pk.bl, w.Z, S, w.out12);
-    keep("perm_z", w.out12, S);
-    commit(pk.bl, w.Zl, Lk, w.out12);
-    keep("lookup_z", w.out12, Lk);
-    blind_rows(cx, w, rng, w.rnd, 1, n, 0);
-    commit(pk.bm, w.rnd, 1, w.out12);
-    keep("random", w.out12, 1);
-    const Fr y = tr.squeeze("y");
-    // ---- 4. quotient
-    auto to_coeff = [&](uint64_t* t, size_t cnt) {
-        for (size_t c0 = 0; c0 < cnt; c0 += tile)
-            PZP_CK(pz_ntt_fr_dev(cx.c, t + c0 * n * 4, cnt - c0 < tile ? cnt - c0 : tile, 4 * n, d.omega_inv.v, k, nullptr, d.n_inv.v));
-    };
-    to_coeff(d_cols, m); to_coeff(w.Ap, Lk); to_coeff(w.Sp, Lk); to_coeff(w.Z, S); to_coeff(w.Zl, Lk);
-    const size_t n_perm_lines = 2 + (S - 1) + S;
-    const Fr y_lines = pow_small(y, n_perm_lines);
-    for (int pi = 0; pi < 2; ++pi) {
-        const Part& pt = d.parts[pi];
-        const size_t Np = pt.size;
-        const unsigned lg = k + pt.log_e, rot = 1u << pt.log_e;
-        auto extend = [&](const uint64_t* src, size_t cnt, uint64_t* dst) {
-            PZP_CK(pz_ntt_fr_extend_dev(cx.c, src, cnt, 4 * n, dst, 4 * Np, k, pt.log_e, d.omega.v, pt.gens.data(), nullptr));
+    void affine(const uint64_t* d_jac, size_t count, uint64_t* out) {   // the synchronising download of a phase's commitments
+        std::vector<uint64_t> jac(12 * count);
+        PZP_CK(pz_download(cx.c, jac.data(), d_jac, count * 96));
+        PZP_CK(pz_g1_normalize(cx.c, jac.data(), count, out));
+    }
+
+    // ---- 1. advice: out (n_adv + n_lk) x 8.  after_launch: called once the commitments are queued and before the host waits for them --
+    // the caller's chance to queue independent work on ANOTHER context (the next proof's K3 + K4) under this proof's largest batch
+    void advice(uint64_t* out_affine, const std::function<void()>& after_launch = nullptr) {
+        expect(0);
+        const Domain& d = pk.dom;
+        const size_t n = d.n, W = pk.st.n_adv + pk.st.n_lk;
+        blind_rows(cx, w, rng, d_cols, W, n, d.usable);
+        PZP_CK(pz_dev_copy(cx.c, d_cols + W * n * 4, pk.const_lagrange, n * 32));
+        commit(pk.bl, d_cols, W, w.out12);
+        if (after_launch) after_launch();
+        affine(w.out12, W, out_affine);
+    }
+    // ---- 2. lookups (one expression each side: theta does not enter).  out: n_lk x 8 each
+    void lookups(uint64_t* out_inputs, uint64_t* out_tables) {
+        expect(1);
+        const Domain& d = pk.dom;
+        const size_t n = d.n, Lk = pk.st.n_lk;
+        uint64_t* lk_in = d_cols + pk.st.n_adv * n * 4;
+        PZP_CK(pz_lookup_permute_dev(cx.c, lk_in, Lk, 4 * n, pk.table_lagrange, d.usable, pk.st.lookup_bits, w.Ap, w.Sp, 4 * n));
+        blind_rows(cx, w, rng, w.Ap, Lk, n, d.usable);
+        blind_rows(cx, w, rng, w.Sp, Lk, n, d.usable);
+        commit(pk.bl, w.Ap, Lk, w.out12);
+        commit(pk.bl, w.Sp, Lk, w.out12 + Lk * 12);
+        affine(w.out12, Lk, out_inputs);
+        affine(w.out12 + Lk * 12, Lk, out_tables);
+    }
+    // ---- 3. grand products + the vanishing argument's random polynomial.  out: n_sets x 8, n_lk x 8, 8
+    void products(const Fr& beta_, const Fr& gamma_, uint64_t* out_z, uint64_t* out_zl, uint64_t* out_random) {
+        expect(2);
+        beta = beta_; gamma = gamma_;
+        const Domain& d = pk.dom;
+        const size_t n = d.n, u = d.usable, Lk = pk.st.n_lk, S = pk.n_sets;
+        const Fr delta = pzh::delta();
+        uint64_t* lk_in = d_cols + pk.st.n_adv * n * 4;
+        PZP_CK(pz_permutation_product_sets_dev(cx.c, d_cols, 4 * n, pk.sigma_lagrange, 4 * n, pk.st.m(), CHUNK, d.k, u, d.omega.v, beta.v, gamma.v,
+                                               delta.v, w.Z, 4 * n));
+        blind_rows(cx, w, rng, w.Z, S, n, u + 1);
+        PZP_CK(pz_lookup_product_dev(cx.c, lk_in, 4 * n, pk.table_lagrange, w.Ap, 4 * n, w.Sp, 4 * n, Lk, n, beta.v, gamma.v, pzh::FR_ONE.v, w.Zl,
+                                     4 * n));
+        blind_rows(cx, w, rng, w.Zl, Lk, n, u + 1);
+        blind_rows(cx, w, rng, w.rnd, 1, n, 0);
+        commit(pk.bl, w.Z, S, w.out12);
+        commit(pk.bl, w.Zl, Lk, w.out12 + S * 12);
+        commit(pk.bm, w.rnd, 1, w.out12 + (S + Lk) * 12);
+        affine(w.out12, S, out_z);
+        affine(w.out12 + S * 12, Lk, out_zl);
+        affine(w.out12 + (S + Lk) * 12, 1, out_random);
+    }
+    // ---- 4. quotient.  out: 3 x 8 (the pieces h_0, h_1, h_2)
+    void quotient(const Fr& y_, uint64_t* out_h) {
+        expect(3);
+        y = y_;
+        const Structure& st = pk.st;
+        const Domain& d = pk.dom;
+        const size_t n = d.n, A = st.n_adv, Lk = st.n_lk, m = st.m(), S = pk.n_sets, tile = w.tile;
+        const unsigned k = d.k, bf = d.bf;
+        const Fr delta = pzh::delta();
+        auto to_coeff = [&](uint64_t* t, size_t cnt) {
+            for (size_t c0 = 0; c0 < cnt; c0 += tile)
+                PZP_CK(pz_ntt_fr_dev(cx.c, t + c0 * n * 4, cnt - c0 < tile ? cnt - c0 : tile, 4 * n, d.omega_inv.v, k, nullptr, d.n_inv.v));
         };
-        for (size_t s0 = 0; s0 < S; s0 += tile) extend(w.Z + s0 * n * 4, S - s0 < tile ? S - s0 : tile, w.z_ext[pi] + s0 * Np * 4);
-        PZP_CK(pz_dev_memset(cx.c, w.hh[pi], 0, 2 * Np * 32));
-        uint64_t *hg = w.hh[pi], *hp = w.hh[pi] + Np * 4;
-        const uint64_t *l0 = pk.l_ext[pi], *llast = pk.l_ext[pi] + Np * 4, *lact = pk.l_ext[pi] + 2 * Np * 4;
-        for (size_t c0 = 0; c0 < m; c0 += tile) {
-            const size_t cnt = m - c0 < tile ? m - c0 : tile;
-            extend(d_cols + c0 * n * 4, cnt, w.ext[pi]);
-            const size_t na = c0 >= A ? 0 : (A - c0 < cnt ? A - c0 : cnt);
-            if (na) PZP_CK(pz_quotient_gate_dev(cx.c, w.ext[pi], 4 * Np, pk.fixed_ext[pi] + c0 * Np * 4, 4 * Np, na, lg, rot, y.v, hg));
-            PZP_CK(pz_quotient_permutation_part_dev(cx.c, w.ext[pi], 4 * Np, pk.sigma_ext[pi] + c0 * Np * 4, 4 * Np, w.z_ext[pi], 4 * Np, (uint32_t)S,
-                                                    (uint32_t)(c0 / CHUNK), (uint32_t)((cnt + CHUNK - 1) / CHUNK), CHUNK, (uint32_t)cnt, c0 == 0, lg, rot,
-                                                    bf + 1, l0, llast, lact, beta.v, gamma.v, delta.v, pt.coset_g.v, pt.omega.v, y.v, hp));
+        to_coeff(d_cols, m); to_coeff(w.Ap, Lk); to_coeff(w.Sp, Lk); to_coeff(w.Z, S); to_coeff(w.Zl, Lk);
+        const size_t n_perm_lines = 2 + (S - 1) + S;
+        const Fr y_lines = pow_small(y, n_perm_lines);
+        for (int pi = 0; pi < 2; ++pi) {
+            const Part& pt = d.parts[pi];
+            const size_t Np = pt.size;
+            const unsigned lg = k + pt.log_e, rot = 1u << pt.log_e;
+            auto extend = [&](const uint64_t* src, size_t cnt, uint64_t* dst) {
+                PZP_CK(pz_ntt_fr_extend_dev(cx.c, src, cnt, 4 * n, dst, 4 * Np, k, pt.log_e, d.omega.v, pt.gens.data(), nullptr));
+            };
+            for (size_t s0 = 0; s0 < S; s0 += tile) extend(w.Z + s0 * n * 4, S - s0 < tile ? S - s0 : tile, w.z_ext[pi] + s0 * Np * 4);
+            PZP_CK(pz_dev_memset(cx.c, w.hh[pi], 0, 2 * Np * 32));
+            uint64_t *hg = w.hh[pi], *hp = w.hh[pi] + Np * 4;
+            const uint64_t *l0 = pk.l_ext[pi], *llast = pk.l_ext[pi] + Np * 4, *lact = pk.l_ext[pi] + 2 * Np * 4;
+            for (size_t c0 = 0; c0 < m; c0 += tile) {
+                const size_t cnt = m - c0 < tile ? m - c0 : tile;
+                extend(d_cols + c0 * n * 4, cnt, w.ext[pi]);
+                const size_t na = c0 >= A ? 0 : (A - c0 < cnt ? A - c0 : cnt);
+                if (na) PZP_CK(pz_quotient_gate_dev(cx.c, w.ext[pi], 4 * Np, pk.fixed_ext[pi] + c0 * Np * 4, 4 * Np, na, lg, rot, y.v, hg));
+                PZP_CK(pz_quotient_permutation_part_dev(cx.c, w.ext[pi], 4 * Np, pk.sigma_ext[pi] + c0 * Np * 4, 4 * Np, w.z_ext[pi], 4 * Np,
+                                                        (uint32_t)S, (uint32_t)(c0 / CHUNK), (uint32_t)((cnt + CHUNK - 1) / CHUNK), CHUNK, (uint32_t)cnt,
+                                                        c0 == 0, lg, rot, bf + 1, l0, llast, lact, beta.v, gamma.v, delta.v, pt.coset_g.v, pt.omega.v,
+                                                        y.v, hp));
+            }
+            uint64_t* hq = w.hp[pi];
+            PZP_CK(pz_fr_lincomb_dev(cx.c, w.hh[pi], 2, 4 * Np, Np, y_lines.v, hq, 0));
+            for (size_t l0_ = 0; l0_ < Lk; l0_ += w.lt) {
+                const size_t cnt = Lk - l0_ < w.lt ? Lk - l0_ : w.lt;
+                extend(d_cols + (A + l0_) * n * 4, cnt, w.lk_ext[pi][0]);
+                extend(w.Ap + l0_ * n * 4, cnt, w.lk_ext[pi][1]);
+                extend(w.Sp + l0_ * n * 4, cnt, w.lk_ext[pi][2]);
+                extend(w.Zl + l0_ * n * 4, cnt, w.lk_ext[pi][3]);
+                PZP_CK(pz_quotient_lookup_dev(cx.c, w.lk_ext[pi][0], 4 * Np, pk.fixed_ext[pi] + (A + 1) * Np * 4, w.lk_ext[pi][1], 4 * Np,
+                                              w.lk_ext[pi][2], 4 * Np, w.lk_ext[pi][3], 4 * Np, (uint32_t)cnt, lg, rot, l0, llast, lact, beta.v, gamma.v,
+                                              y.v, hq));
+            }
+            PZP_CK(pz_quotient_finish_dev(cx.c, hq, k, pt.log_e, pt.coset_g.v, pt.omega.v));
+            PZP_CK(pz_ntt_fr_dev(cx.c, hq, 1, 4 * Np, pt.omega_inv.v, lg, nullptr, pt.size_inv.v));
+            const Fr cg_inv = pzh::inv(pt.coset_g);
+            PZP_CK(pz_fr_distribute_powers_dev(cx.c, hq, 1, 4 * Np, Np, cg_inv.v, nullptr));
         }
-        uint64_t* hq = w.hp[pi];
-        PZP_CK(pz_fr_lincomb_dev(cx.c, w.hh[pi], 2, 4 * Np, Np, y_lines.v, hq, 0));
-        for (size_t l0_ = 0; l0_ < Lk; l0_ += w.lt) {
-            const size_t cnt = Lk - l0_ < w.lt ? Lk - l0_ : w.lt;
-            extend(d_cols + (A + l0_) * n * 4, cnt, w.lk_ext[pi][0]);
-            extend(w.Ap + l0_ * n * 4, cnt, w.lk_ext[pi][1]);
-            extend(w.Sp + l0_ * n * 4, cnt, w.lk_ext[pi][2]);
-            extend(w.Zl + l0_ * n * 4, cnt, w.lk_ext[pi][3]);
-            PZP_CK(pz_quotient_lookup_dev(cx.c, w.lk_ext[pi][0], 4 * Np, pk.fixed_ext[pi] + (A + 1) * Np * 4, w.lk_ext[pi][1], 4 * Np, w.lk_ext[pi][2],
-                                          4 * Np, w.lk_ext[pi][3], 4 * Np, (uint32_t)cnt, lg, rot, l0, llast, lact, beta.v, gamma.v, y.v, hq));
+        // the quotient from three cosets (prover.py): [U | h_1] on part A, V on part B
+        pieces = w.h;
+        {
+            const Fr g2n = pow_small(pzh::mul(d.coset_g, d.coset_g), n);
+            const Fr lam = pow_small(d.parts[1].coset_g, n);
+            uint64_t *U = w.hp[0], *h1 = w.hp[0] + n * 4, *V = w.hp[1];
+            uint64_t *t0 = w.tmp, *t1 = w.tmp + n * 4;
+            PZP_CK(pz_dev_copy(cx.c, pieces + n * 4, h1, n * 32));
+            PZP_CK(pz_dev_copy(cx.c, t0, h1, n * 32));
+            PZP_CK(pz_dev_copy(cx.c, t1, V, n * 32));
+            const Fr mlam = pzh::neg(lam), m1 = pzh::neg(pzh::FR_ONE), mg2n = pzh::neg(g2n);
+            PZP_CK(pz_fr_lincomb_dev(cx.c, w.tmp, 2, 4 * n, n, mlam.v, pieces + 2 * n * 4, 0));      // T = V - lam h_1
+            PZP_CK(pz_dev_copy(cx.c, t0, pieces + 2 * n * 4, n * 32));
+            PZP_CK(pz_dev_copy(cx.c, t1, U, n * 32));
+            PZP_CK(pz_fr_lincomb_dev(cx.c, w.tmp, 2, 4 * n, n, m1.v, pieces + 2 * n * 4, 0));        // U - T
+            const Fr half = pzh::inv(pzh::add(g2n, g2n));
+            PZP_CK(pz_fr_distribute_powers_dev(cx.c, pieces + 2 * n * 4, 1, 4 * n, n, pzh::FR_ONE.v, half.v));   // h_2
+            PZP_CK(pz_dev_copy(cx.c, t0, pieces + 2 * n * 4, n * 32));
+            PZP_CK(pz_dev_copy(cx.c, t1, U, n * 32));
+            PZP_CK(pz_fr_lincomb_dev(cx.c, w.tmp, 2, 4 * n, n, mg2n.v, pieces, 0));                  // h_0 = U - g^2n h_2
         }
-        PZP_CK(pz_quotient_finish_dev(cx.c, hq, k, pt.log_e, pt.coset_g.v, pt.omega.v));
-        PZP_CK(pz_ntt_fr_dev(cx.c, hq, 1, 4 * Np, pt.omega_inv.v, lg, nullptr, pt.size_inv.v));
-        const Fr cg_inv = pzh::inv(pt.coset_g);
-        PZP_CK(pz_fr_distribute_powers_dev(cx.c, hq, 1, 4 * Np, Np, cg_inv.v, nullptr));
+        commit(pk.bm, pieces, 3, w.out12);
+        affine(w.out12, 3, out_h);
     }
-    // the quotient from three cosets (prover.py): [U | h_1] on part A, V on part B
-    uint64_t* pieces = w.h;
-    {
-        const Fr g2n = pow_small(pzh::mul(d.coset_g, d.coset_g), n);
-        const Fr lam = pow_small(d.parts[1].coset_g, n);
-        uint64_t *U = w.hp[0], *h1 = w.hp[0] + n * 4, *V = w.hp[1];
-        uint64_t *t0 = w.tmp, *t1 = w.tmp + n * 4;
-        PZP_CK(pz_dev_copy(cx.c, pieces + n * 4, h1, n * 32));
-        PZP_CK(pz_dev_copy(cx.c, t0, h1, n * 32));
-        PZP_CK(pz_dev_copy(cx.c, t1, V, n * 32));
-        const Fr mlam = pzh::neg(lam), m1 = pzh::neg(pzh::FR_ONE), mg2n = pzh::neg(g2n);
-        PZP_CK(pz_fr_lincomb_dev(cx.c, w.tmp, 2, 4 * n, n, mlam.v, pieces + 2 * n * 4, 0));      // T = V - lam h_1
-        PZP_CK(pz_dev_copy(cx.c, t0, pieces + 2 * n * 4, n * 32));
-        PZP_CK(pz_dev_copy(cx.c, t1, U, n * 32));
-        PZP_CK(pz_fr_lincomb_dev(cx.c, w.tmp, 2, 4 * n, n, m1.v, pieces + 2 * n * 4, 0));        // U - T
-        const Fr half = pzh::inv(pzh::add(g2n, g2n));
-        PZP_CK(pz_fr_distribute_powers_dev(cx.c, pieces + 2 * n * 4, 1, 4 * n, n, pzh::FR_ONE.v, half.v));   // h_2
-        PZP_CK(pz_dev_copy(cx.c, t0, pieces + 2 * n * 4, n * 32));
-        PZP_CK(pz_dev_copy(cx.c, t1, U, n * 32));
-        PZP_CK(pz_fr_lincomb_dev(cx.c, w.tmp, 2, 4 * n, n, mg2n.v, pieces, 0));                  // h_0 = U - g^2n h_2
-    }
-    commit(pk.bm, pieces, 3, w.out12);
-    keep("h", w.out12, 3);
-    const Fr x = tr.squeeze("x");
-    // ---- 5. evaluations
-    Fr xs[6];
-    {
+    // ---- 5. evaluations at x and its rotations: ev[f] = [count][points][4] per family of `fams`
+    void evaluate(const Fr& x_) {
+        expect(4);
+        x = x_;
+        const Structure& st = pk.st;
+        const Domain& d = pk.dom;
+        const size_t n = d.n, A = st.n_adv, Lk = st.n_lk, m = st.m(), S = pk.n_sets;
         xs[0] = x;
         xs[1] = pzh::mul(x, d.omega);
         xs[2] = pzh::mul(xs[1], d.omega);
         xs[3] = pzh::mul(xs[2], d.omega);
-        xs[4] = pzh::mul(x, pow_small(d.omega_inv, bf + 1));
+        xs[4] = pzh::mul(x, pow_small(d.omega_inv, d.bf + 1));
         xs[5] = pzh::mul(x, d.omega_inv);
+        const Fr xn = pow_small(x, n);
+        PZP_CK(pz_fr_lincomb_dev(cx.c, pieces + 2 * n * 4, 1, 4 * n, n, xn.v, w.hcomb, 0));
+        PZP_CK(pz_fr_lincomb_dev(cx.c, pieces + 1 * n * 4, 1, 4 * n, n, xn.v, w.hcomb, 1));
+        PZP_CK(pz_fr_lincomb_dev(cx.c, pieces, 1, 4 * n, n, xn.v, w.hcomb, 1));
+        fams = {{"advice", d_cols, A, {0, 1, 2, 3}}, {"lookup_advice", d_cols + A * n * 4, Lk + 1, {0}}, {"fixed", pk.fixed_coeff, pk.F, {0}},
+                {"sigma", pk.sigma_coeff, m, {0}}, {"perm_z", w.Z, S, {0, 1, 4}}, {"lookup_z", w.Zl, Lk, {0, 1}}, {"perm_inputs", w.Ap, Lk, {0, 5}},
+                {"perm_tables", w.Sp, Lk, {0}}, {"random", w.rnd, 1, {0}}, {"h", w.hcomb, 1, {0}}};
+        ev.assign(fams.size(), {});
+        for (size_t f = 0; f < fams.size(); ++f) {
+            const Fam& fm = fams[f];
+            std::vector<uint64_t> pts;
+            for (int i : fm.idx) pts.insert(pts.end(), xs[i].v, xs[i].v + 4);
+            PZP_CK(pz_poly_eval_multi_dev(cx.c, fm.polys, fm.count, 4 * n, n, pts.data(), (uint32_t)fm.idx.size(), w.evals));
+            ev[f].resize(fm.count * fm.idx.size() * 4);
+            PZP_CK(pz_download(cx.c, ev[f].data(), w.evals, ev[f].size() * 8));
+        }
     }
-    const Fr xn = pow_small(x, n);
-    PZP_CK(pz_fr_lincomb_dev(cx.c, pieces + 2 * n * 4, 1, 4 * n, n, xn.v, w.hcomb, 0));
-    PZP_CK(pz_fr_lincomb_dev(cx.c, pieces + 1 * n * 4, 1, 4 * n, n, xn.v, w.hcomb, 1));
-    PZP_CK(pz_fr_lincomb_dev(cx.c, pieces, 1, 4 * n, n, xn.v, w.hcomb, 1));
-    struct Fam { const char* name; const uint64_t* polys; size_t count; std::vector<int> idx; };
-    const size_t F = pk.F;
-    std::vector<Fam> fams = {
-        {"advice", d_cols, A, {0, 1, 2, 3}}, {"lookup_advice", d_cols + A * n * 4, Lk + 1, {0}}, {"fixed", pk.fixed_coeff, F, {0}},
-        {"sigma", pk.sigma_coeff, m, {0}}, {"perm_z", w.Z, S, {0, 1, 4}}, {"lookup_z", w.Zl, Lk, {0, 1}}, {"perm_inputs", w.Ap, Lk, {0, 5}},
-        {"perm_tables", w.Sp, Lk, {0}}, {"random", w.rnd, 1, {0}}, {"h", w.hcomb, 1, {0}}};
-    std::vector<std::vector<uint64_t>> ev(fams.size());
-    for (size_t f = 0; f < fams.size(); ++f) {
-        const Fam& fm = fams[f];
-        std::vector<uint64_t> pts;
-        for (int i : fm.idx) pts.insert(pts.end(), xs[i].v, xs[i].v + 4);
-        PZP_CK(pz_poly_eval_multi_dev(cx.c, fm.polys, fm.count, 4 * n, n, pts.data(), (uint32_t)fm.idx.size(), w.evals));
-        ev[f].resize(fm.count * fm.idx.size() * 4);
-        PZP_CK(pz_download(cx.c, ev[f].data(), w.evals, ev[f].size() * 8));
-        pr.evals.push_back({fm.name, ev[f]});
-        pr.eval_points.push_back({fm.name, (uint32_t)fm.idx.size()});
-        if (strcmp(fm.name, "h")) tr.absorb(ev[f].data(), ev[f].size() * 8);
+    // ---- 6. SHPLONK: the rotation sets in prover.py's query_layout order.  out: 8 each
+    void open_begin(const Fr& shy, const Fr& shv, uint64_t* out_w1) {
+        expect(5);
+        const size_t n = pk.dom.n, A = pk.st.n_adv, Lk = pk.st.n_lk, m = pk.st.m(), S = pk.n_sets, F = pk.F;
+        auto fam_of = [&](const char* nm) -> size_t {
+            for (size_t f = 0; f < fams.size(); ++f)
+                if (!strcmp(fams[f].name, nm)) return f;
+            return 0;
+        };
+        struct Member { size_t fam, idx; };
+        std::vector<std::pair<std::vector<uint32_t>, std::vector<Member>>> sets;
+        {
+            std::vector<Member> s0;
+            for (size_t i = 0; i < Lk; ++i) s0.push_back({fam_of("lookup_advice"), i});
+            for (size_t i = 0; i < F; ++i) s0.push_back({fam_of("fixed"), i});
+            for (size_t i = 0; i < m; ++i) s0.push_back({fam_of("sigma"), i});
+            for (size_t i = 0; i < Lk; ++i) s0.push_back({fam_of("perm_tables"), i});
+            s0.push_back({fam_of("h"), 0});
+            s0.push_back({fam_of("random"), 0});
+            sets.push_back({{0}, s0});
+            std::vector<Member> s1;
+            for (size_t i = 0; i < A; ++i) s1.push_back({fam_of("advice"), i});
+            sets.push_back({{0, 1, 2, 3}, s1});
+            if (S > 1) {
+                std::vector<Member> s2;
+                for (size_t i = 0; i + 1 < S; ++i) s2.push_back({fam_of("perm_z"), i});
+                sets.push_back({{0, 1, 4}, s2});
+            }
+            std::vector<Member> s3;
+            s3.push_back({fam_of("perm_z"), S - 1});
+            for (size_t i = 0; i < Lk; ++i) s3.push_back({fam_of("lookup_z"), i});
+            sets.push_back({{0, 1}, s3});
+            std::vector<Member> s4;
+            for (size_t i = 0; i < Lk; ++i) s4.push_back({fam_of("perm_inputs"), i});
+            sets.push_back({{0, 5}, s4});
+        }
+        std::vector<uint32_t> set_n_polys, set_n_points, point_idx;
+        std::vector<const uint64_t*> polys;
+        std::vector<uint64_t> evals_flat, points;
+        for (int i = 0; i < 6; ++i) points.insert(points.end(), xs[i].v, xs[i].v + 4);
+        for (auto& sp : sets) {
+            set_n_polys.push_back((uint32_t)sp.second.size());
+            set_n_points.push_back((uint32_t)sp.first.size());
+            for (uint32_t pi_ : sp.first) point_idx.push_back(pi_);
+            for (const Member& mb : sp.second) {
+                const Fam& fm = fams[mb.fam];
+                polys.push_back(fm.polys + mb.idx * n * 4);
+                const size_t npts = fm.idx.size();
+                for (size_t q = 0; q < sp.first.size(); ++q)   // the set's points are a prefix of the family's
+                    evals_flat.insert(evals_flat.end(), &ev[mb.fam][(mb.idx * npts + q) * 4], &ev[mb.fam][(mb.idx * npts + q) * 4] + 4);
+            }
+        }
+        PZP_CK(pz_shplonk_begin_dev(cx.c, n, (uint32_t)sets.size(), set_n_polys.data(), polys.data(), set_n_points.data(), point_idx.data(), 6,
+                                    points.data(), evals_flat.data(), shy.v, shv.v, w.w1, &state));
+        commit(pk.bm, w.w1, 1, w.out12);
+        affine(w.out12, 1, out_w1);
+    }
+    // -> whether the quotient has degree <= 3n - 4 (the top three coefficients of h_2 vanish): false for an unsatisfied witness
+    bool open_finish(const Fr& shu, uint64_t* out_w2) {
+        expect(6);
+        const size_t n = pk.dom.n;
+        pz_shplonk* st_ = state;
+        state = nullptr;                                   // pz_shplonk_finish_dev frees it on every path
+        PZP_CK(pz_shplonk_finish_dev(cx.c, st_, shu.v, w.w1, w.w2));
+        commit(pk.bm, w.w2, 1, w.out12);
+        affine(w.out12, 1, out_w2);
+        uint64_t top[12];
+        PZP_CK(pz_download(cx.c, top, pieces + (3 * n - 3) * 4, 96));
+        for (int i = 0; i < 12; ++i)
+            if (top[i]) return false;
+        return true;
+    }
+};
+
+// the phases behind a transcript (the drivers' form): every phase's hand-over is absorbed, the next challenge squeezed
+inline Proof create_proof(Ctx& cx, ProvingKey& pk, Workspace& w, uint64_t* d_cols, Transcript& tr, uint64_t seed,
+                          const std::function<void()>& after_advice_launch = nullptr) {
+    const size_t A = pk.st.n_adv, Lk = pk.st.n_lk, S = pk.n_sets, W = A + Lk;
+    Session se(cx, pk, w, d_cols, Rng(seed));
+    Proof pr;
+    auto keep = [&](const char* name, const std::vector<uint64_t>& aff) {
+        tr.absorb(aff.data(), aff.size() * 8);
+        pr.commitments.push_back({name, aff});
+    };
+    std::vector<uint64_t> a(8 * W), b, c;
+    se.advice(a.data(), after_advice_launch);
+    tr.absorb(a.data(), a.size() * 8);
+    pr.commitments.push_back({"advice", std::vector<uint64_t>(a.begin(), a.begin() + 8 * A)});
+    pr.commitments.push_back({"lookup_advice", std::vector<uint64_t>(a.begin() + 8 * A, a.end())});
+    tr.squeeze("theta");
+    a.assign(8 * Lk, 0); b.assign(8 * Lk, 0);
+    se.lookups(a.data(), b.data());
+    keep("perm_inputs", a);
+    keep("perm_tables", b);
+    const Fr beta = tr.squeeze("beta"), gamma = tr.squeeze("gamma");
+    a.assign(8 * S, 0); b.assign(8 * Lk, 0); c.assign(8, 0);
+    se.products(beta, gamma, a.data(), b.data(), c.data());
+    keep("perm_z", a);
+    keep("lookup_z", b);
+    keep("random", c);
+    const Fr y = tr.squeeze("y");
+    a.assign(24, 0);
+    se.quotient(y, a.data());
+    keep("h", a);
+    const Fr x = tr.squeeze("x");
+    se.evaluate(x);
+    for (size_t f = 0; f < se.fams.size(); ++f) {
+        pr.evals.push_back({se.fams[f].name, se.ev[f]});
+        pr.eval_points.push_back({se.fams[f].name, (uint32_t)se.fams[f].idx.size()});
+        if (strcmp(se.fams[f].name, "h")) tr.absorb(se.ev[f].data(), se.ev[f].size() * 8);
     }
     const Fr shy = tr.squeeze("sh_y"), shv = tr.squeeze("sh_v");
-    // ---- 6. SHPLONK: the rotation sets in prover.py's query_layout order
-    auto fam_of = [&](const char* nm) -> size_t {
-        for (size_t f = 0; f < fams.size(); ++f)
-            if (!strcmp(fams[f].name, nm)) return f;
-        return 0;
-    };
-    struct Member { size_t fam, idx; };
-    std::vector<std::pair<std::vector<uint32_t>, std::vector<Member>>> sets;
-    {
-        std::vector<Member> s0;
-        for (size_t i = 0; i < Lk; ++i) s0.push_back({fam_of("lookup_advice"), i});
-        for (size_t i = 0; i < F; ++i) s0.push_back({fam_of("fixed"), i});
-        for (size_t i = 0; i < m; ++i) s0.push_back({fam_of("sigma"), i});
-        for (size_t i = 0; i < Lk; ++i) s0.push_back({fam_of("perm_tables"), i});
-        s0.push_back({fam_of("h"), 0});
-        s0.push_back({fam_of("random"), 0});
-        sets.push_back({{0}, s0});
-        std::vector<Member> s1;
-        for (size_t i = 0; i < A; ++i) s1.push_back({fam_of("advice"), i});
-        sets.push_back({{0, 1, 2, 3}, s1});
-        if (S > 1) {
-            std::vector<Member> s2;
-            for (size_t i = 0; i + 1 < S; ++i) s2.push_back({fam_of("perm_z"), i});
-            sets.push_back({{0, 1, 4}, s2});
-        }
-        std::vector<Member> s3;
-        s3.push_back({fam_of("perm_z"), S - 1});
-        for (size_t i = 0; i < Lk; ++i) s3.push_back({fam_of("lookup_z"), i});
-        sets.push_back({{0, 1}, s3});
-        std::vector<Member> s4;
-        for (size_t i = 0; i < Lk; ++i) s4.push_back({fam_of("perm_inputs"), i});
-        sets.push_back({{0, 5}, s4});
-    }
-    std::vector<uint32_t> set_n_polys, set_n_points, point_idx;
-    std::vector<const uint64_t*> polys;
-    std::vector<uint64_t> evals_flat, points;
-    for (int i = 0; i < 6; ++i) points.insert(points.end(), xs[i].v, xs[i].v + 4);
-    for (auto& sp : sets) {
-        set_n_polys.push_back((uint32_t)sp.second.size());
-        set_n_points.push_back((uint32_t)sp.first.size());
-        for (uint32_t pi_ : sp.first) point_idx.push_back(pi_);
-        for (const Member& mb : sp.second) {
-            const Fam& fm = fams[mb.fam];
-            polys.push_back(fm.polys + mb.idx * n * 4);
-            const size_t npts = fm.idx.size();
-            for (size_t q = 0; q < sp.first.size(); ++q)   // the set's points are a prefix of the family's
-                evals_flat.insert(evals_flat.end(), &ev[mb.fam][(mb.idx * npts + q) * 4], &ev[mb.fam][(mb.idx * npts + q) * 4] + 4);
-        }
-    }
-    pz_shplonk* state = nullptr;
-    PZP_CK(pz_shplonk_begin_dev(cx.c, n, (uint32_t)sets.size(), set_n_polys.data(), polys.data(), set_n_points.data(), point_idx.data(), 6,
-                                points.data(), evals_flat.data(), shy.v, shv.v, w.w1, &state));
-    commit(pk.bm, w.w1, 1, w.out12);
-    keep("w1", w.out12, 1);
+    a.assign(8, 0);
+    se.open_begin(shy, shv, a.data());
+    keep("w1", a);
     const Fr shu = tr.squeeze("sh_u");
-    PZP_CK(pz_shplonk_finish_dev(cx.c, state, shu.v, w.w1, w.w2));
-    commit(pk.bm, w.w2, 1, w.out12);
-    keep("w2", w.out12, 1);
-    // degree <= 3n - 4: the top three coefficients of h_2 vanish
-    uint64_t top[12];
-    PZP_CK(pz_download(cx.c, top, pieces + (3 * n - 3) * 4, 96));
-    pr.h_degree_ok = true;
-    for (int i = 0; i < 12; ++i)
-        if (top[i]) pr.h_degree_ok = false;
+    pr.h_degree_ok = se.open_finish(shu, a.data());
+    keep("w2", a);
     return pr;
 }
 

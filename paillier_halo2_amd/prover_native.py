@@ -1,0 +1,115 @@
+"""The library's own keygen / create_proof (include/pz.h "patch point D as entry points": pz_pk_* / pz_proof_*, one call per transcript
+round -- the composition of host/create_proof.hpp behind the C ABI), driven from Python: what a reference prover patched at
+/root/reference/src/bench.rs:161-171 calls with halo2's transcript in between.  Same inputs and the same Proof layout as prover.py, so
+the same checker verifies both."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import consts
+from ._lib import VP
+from .engine import Bases, Engine
+from .prover import CHUNK, Challenges, CircuitStructure, Proof, Transcript
+
+M = consts.fr_mont_limbs
+
+
+def _host(a):
+    return a.cpu().numpy() if hasattr(a, "cpu") else a
+
+
+def _p(a: np.ndarray):
+    return VP(a.ctypes.data)
+
+
+class NativeKey:
+    """pz_pk: the proving key resident on the device + one proof's workspace; serves one proof at a time"""
+
+    def __init__(self, eng: Engine, st: CircuitStructure, bases_lagrange: Bases, bases_monomial: Bases, tile: int = 64):
+        self.eng, self.st = eng, st
+        n = 1 << st.k
+        sel = np.ascontiguousarray(_host(st.selectors), dtype=np.uint8)
+        mc = np.ascontiguousarray(_host(st.map_col)).view(np.uint32)
+        mr = np.ascontiguousarray(_host(st.map_row)).view(np.uint32)
+        assert sel.shape == (st.n_adv, n) and mc.shape == (st.m, n) == mr.shape
+        consts_w = np.zeros((len(st.constants), 4), dtype=np.uint64)
+        for i, v in enumerate(st.constants):
+            consts_w[i] = consts.int_to_limbs(int(v) % consts.FR_R, 4)
+        h = VP()
+        eng._chk(eng.L.pz_pk_create(eng.ctx, bases_lagrange.handle, bases_monomial.handle, st.k, st.lookup_bits, st.blinding_factors, st.max_rows,
+                                    st.n_adv, st.n_lk, _p(sel), _p(consts_w), len(st.constants), _p(mc), _p(mr), tile, C.byref(h)), "pz_pk_create")
+        self.handle = h
+        out = [C.c_size_t() for _ in range(5)]
+        eng._chk(eng.L.pz_pk_info(h, *[C.byref(x) for x in out]), "pz_pk_info")
+        self.n_fixed, self.m, self.n_sets, self.blinding_words, self.evals_words = (int(x.value) for x in out)
+        assert self.m == st.m and self.n_sets == -(-st.m // CHUNK)
+
+    def vk_commitments(self) -> Dict[str, np.ndarray]:
+        f, s = np.zeros((self.n_fixed, 8), dtype=np.uint64), np.zeros((self.m, 8), dtype=np.uint64)
+        self.eng._chk(self.eng.L.pz_pk_commitments(self.handle, _p(f), _p(s)), "pz_pk_commitments")
+        return {"fixed": f, "sigma": s}
+
+    def free(self):
+        if self.handle:
+            self.eng._chk(self.eng.L.pz_pk_free(self.handle), "pz_pk_free")
+            self.handle = None
+
+
+def create_proof(key: NativeKey, d_cols: int, tr, seed: int = 0, blinding: Optional[np.ndarray] = None) -> Proof:
+    """d_cols: device pointer of [m][2^k][4] words (the K4 columns; consumed).  tr: prover.Transcript / HashTranscript / Challenges.
+    blinding: optional uint64 array of key.blinding_words caller-supplied random words (else the library's seeded stream)"""
+    eng, st, L = key.eng, key.st, key.eng.L
+    if isinstance(tr, Challenges):
+        tr = Transcript(tr)
+    A, Lk, m, S = st.n_adv, st.n_lk, st.m, key.n_sets
+    z = lambda cnt: np.zeros((cnt, 8), dtype=np.uint64)
+    h = VP()
+    adv = z(A + Lk)
+    bl = np.ascontiguousarray(blinding, dtype=np.uint64) if blinding is not None else None
+    eng._chk(L.pz_proof_begin(key.handle, VP(d_cols), seed, _p(bl) if bl is not None else None, 0 if bl is None else bl.size, C.byref(h), _p(adv)),
+             "pz_proof_begin")
+    try:
+        pr = Proof()
+        tr.absorb_scalars(adv)
+        c_theta = M(tr.squeeze("theta"))         # (the limb arrays are named: a pointer into a temporary would dangle)
+        ap, sp = z(Lk), z(Lk)
+        eng._chk(L.pz_proof_lookups(h, _p(c_theta), _p(ap), _p(sp)), "pz_proof_lookups")
+        tr.absorb_scalars(ap, sp)
+        c_beta, c_gamma = M(tr.squeeze("beta")), M(tr.squeeze("gamma"))
+        cz, czl, crnd = z(S), z(Lk), z(1)
+        eng._chk(L.pz_proof_products(h, _p(c_beta), _p(c_gamma), _p(cz), _p(czl), _p(crnd)), "pz_proof_products")
+        tr.absorb_scalars(cz, czl, crnd)
+        c_y = M(tr.squeeze("y"))
+        ch_ = z(3)
+        eng._chk(L.pz_proof_quotient(h, _p(c_y), _p(ch_)), "pz_proof_quotient")
+        tr.absorb_scalars(ch_)
+        c_x = M(tr.squeeze("x"))
+        ev = np.zeros(key.evals_words, dtype=np.uint64)
+        eng._chk(L.pz_proof_evaluate(h, _p(c_x), _p(ev)), "pz_proof_evaluate")
+        fams = (("advice", A, 4), ("lookup_advice", Lk + 1, 1), ("fixed", key.n_fixed, 1), ("sigma", m, 1), ("perm_z", S, 3), ("lookup_z", Lk, 2),
+                ("perm_inputs", Lk, 2), ("perm_tables", Lk, 1), ("random", 1, 1), ("h", 1, 1))
+        off, evs = 0, {}
+        for name, cnt, pts in fams:
+            evs[name] = ev[off:off + cnt * pts * 4].reshape(cnt, pts, 4)
+            off += cnt * pts * 4
+        assert off == ev.size
+        tr.absorb_scalars(*[evs[f] for f, _, _ in fams if f != "h"])
+        c_shy, c_shv = M(tr.squeeze("sh_y")), M(tr.squeeze("sh_v"))
+        w1, w2 = z(1), z(1)
+        eng._chk(L.pz_proof_open_begin(h, _p(c_shy), _p(c_shv), _p(w1)), "pz_proof_open_begin")
+        tr.absorb_scalars(w1)
+        c_shu = M(tr.squeeze("sh_u"))
+        ok = C.c_int(0)
+        eng._chk(L.pz_proof_open_finish(h, _p(c_shu), _p(w2), C.byref(ok)), "pz_proof_open_finish")
+        pr.commitments = {"advice": adv[:A], "lookup_advice": adv[A:], "perm_inputs": ap, "perm_tables": sp, "perm_z": cz, "lookup_z": czl,
+                          "random": crnd, "h": ch_, "w1": w1, "w2": w2}
+        pr.evals = dict(evs)
+        pr.evals["constants"] = evs["lookup_advice"][Lk:]
+        pr.evals["lookup_advice"] = evs["lookup_advice"][:Lk]
+        pr.h_degree_ok = bool(ok.value)
+        return pr
+    finally:
+        eng._chk(L.pz_proof_free(h), "pz_proof_free")

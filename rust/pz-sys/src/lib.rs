@@ -12,6 +12,8 @@ use core::ffi::{c_char, c_int, c_void};
 #[repr(C)] pub struct pz_ctx     { _p: [u8; 0] }
 #[repr(C)] pub struct pz_bases   { _p: [u8; 0] }
 #[repr(C)] pub struct pz_shplonk { _p: [u8; 0] }
+#[repr(C)] pub struct pz_pk      { _p: [u8; 0] }
+#[repr(C)] pub struct pz_proof   { _p: [u8; 0] }
 
 extern "C" {
     pub fn pz_init(n_devices: c_int, device_ids: *const c_int, out: *mut *mut pz_ctx) -> c_int;
@@ -108,6 +110,26 @@ extern "C" {
                                 state: *mut *mut pz_shplonk) -> c_int;
     pub fn pz_shplonk_finish_dev(ctx: *mut pz_ctx, state: *mut pz_shplonk, u: *const u64, d_h: *const u64, d_h2: *mut u64) -> c_int;
     pub fn pz_shplonk_free(ctx: *mut pz_ctx, state: *mut pz_shplonk) -> c_int;
+
+    // patch point D as entry points: keygen + create_proof, one call per transcript round (section 5d)
+    pub fn pz_pk_create(ctx: *mut pz_ctx, bases_lagrange: *const pz_bases, bases_monomial: *const pz_bases, k: u32, lookup_bits: u32,
+                        blinding_factors: u32, max_rows: usize, n_adv: usize, n_lk: usize, selectors: *const u8,
+                        constants: *const u64, n_constants: usize, map_col: *const u32, map_row: *const u32, tile: usize,
+                        out: *mut *mut pz_pk) -> c_int;
+    pub fn pz_pk_info(pk: *const pz_pk, n_fixed: *mut usize, n_perm_cols: *mut usize, n_sets: *mut usize, blinding_words: *mut usize,
+                      evals_words: *mut usize) -> c_int;
+    pub fn pz_pk_commitments(pk: *const pz_pk, fixed_affine: *mut u64, sigma_affine: *mut u64) -> c_int;
+    pub fn pz_pk_free(pk: *mut pz_pk) -> c_int;
+    pub fn pz_proof_begin(pk: *mut pz_pk, d_cols: *mut u64, seed: u64, blinding: *const u64, n_blinding: usize, out: *mut *mut pz_proof,
+                          advice_affine: *mut u64) -> c_int;
+    pub fn pz_proof_lookups(proof: *mut pz_proof, theta: *const u64, perm_inputs_affine: *mut u64, perm_tables_affine: *mut u64) -> c_int;
+    pub fn pz_proof_products(proof: *mut pz_proof, beta: *const u64, gamma: *const u64, perm_z_affine: *mut u64,
+                             lookup_z_affine: *mut u64, random_affine: *mut u64) -> c_int;
+    pub fn pz_proof_quotient(proof: *mut pz_proof, y: *const u64, h_affine: *mut u64) -> c_int;
+    pub fn pz_proof_evaluate(proof: *mut pz_proof, x: *const u64, evals: *mut u64) -> c_int;
+    pub fn pz_proof_open_begin(proof: *mut pz_proof, y: *const u64, v: *const u64, w1_affine: *mut u64) -> c_int;
+    pub fn pz_proof_open_finish(proof: *mut pz_proof, u: *const u64, w2_affine: *mut u64, quotient_degree_ok: *mut c_int) -> c_int;
+    pub fn pz_proof_free(proof: *mut pz_proof) -> c_int;
 
     // next rows (SRS setup, evaluation at a point)
     pub fn pz_srs_setup_g1_dev(ctx: *mut pz_ctx, k: u32, s: *const u64, omega: *const u64, d_g: *mut u64,

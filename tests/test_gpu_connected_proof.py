@@ -410,3 +410,67 @@ def test_uniform_shape_circuit_connected_proof(eng, cref):
         assert wl.verify(cref)["verified"] is True
     finally:
         wl.release()
+
+
+def test_library_stepper_is_the_same_prover(eng, cref, world):
+    """include/pz.h "patch point D as entry points" (pz_pk_* / pz_proof_*: one call per transcript round, the composition of
+    host/create_proof.hpp inside the library) through ctypes: the key it builds has the Python key's commitments, its proof satisfies the
+    verifier's three checks (fixed challenges and a hashing transcript, library and caller-supplied blinding), a tampered cell fails
+    the degree check and the identity, and the misuse paths return PZ_ERR_INVALID"""
+    import ctypes as C
+
+    import paillier_halo2_amd as pz
+    from paillier_halo2_amd import consts, prover, prover_native
+
+    pk = world["pk"]
+    key = prover_native.NativeKey(eng, pk.st, pk.bases_lagrange, pk.bases_monomial, tile=8)
+    try:
+        vk, vk_py = key.vk_commitments(), pk.vk_commitments()
+        assert np.array_equal(vk["fixed"], vk_py["fixed"]) and np.array_equal(vk["sigma"], vk_py["sigma"])
+        assert key.n_sets == pk.n_sets and key.n_fixed == pk.st.n_adv + 2
+        cols = world["witness"]()
+        pr = prover_native.create_proof(key, cols.data_ptr(), world["ch"], seed=3)
+        assert _verify(cref, world, pr) == (True, True, True)
+        # caller-supplied randomness, a hashing transcript: every challenge derived from what the phases handed back
+        rng = np.random.default_rng(5)
+        words = rng.integers(0, 1 << 63, size=key.blinding_words, dtype=np.uint64)
+        tr = prover.HashTranscript(b"native")
+        cols = world["witness"]()
+        pr2 = prover_native.create_proof(key, cols.data_ptr(), tr, blinding=words)
+        w2 = dict(world)
+        w2["ch"] = tr.challenges()
+        assert _verify(cref, w2, pr2) == (True, True, True)
+        assert not np.array_equal(pr.commitments["advice"], pr2.commitments["advice"])          # other blinding rows
+        # too few random words
+        cols = world["witness"]()
+        with pytest.raises(pz.PzError):
+            prover_native.create_proof(key, cols.data_ptr(), world["ch"], blinding=words[:-1])
+        # a tampered gate output: degree check and identity fail, the openings stay honest openings
+        cols = world["witness"]()
+        cols[0, 3, 0] ^= 1
+        bad = prover_native.create_proof(key, cols.data_ptr(), world["ch"], seed=3)
+        deg, ident, opening = _verify(cref, world, bad)
+        assert (deg, ident, opening) == (False, False, True)
+        # misuse: a phase out of order, a challenge that is not below r, freeing the key under an open proof
+        L_, Mf = eng.L, consts.fr_mont_limbs
+        VP = C.c_void_p
+        ptr = lambda a: VP(a.ctypes.data)
+        cols = world["witness"]()
+        h = VP()
+        adv = np.zeros((pk.st.n_adv + pk.st.n_lk, 8), dtype=np.uint64)
+        assert L_.pz_proof_begin(key.handle, VP(cols.data_ptr()), 1, None, 0, C.byref(h), ptr(adv)) == 0
+        h2 = VP()
+        assert L_.pz_proof_begin(key.handle, VP(cols.data_ptr()), 1, None, 0, C.byref(h2), ptr(adv)) != 0      # one proof per key at a time
+        assert L_.pz_pk_free(key.handle) != 0
+        out3 = np.zeros((3, 8), dtype=np.uint64)
+        five = Mf(5)
+        assert L_.pz_proof_quotient(h, ptr(five), ptr(out3)) != 0                                              # lookups and products come first
+        a_, b_ = np.zeros((pk.st.n_lk, 8), dtype=np.uint64), np.zeros((pk.st.n_lk, 8), dtype=np.uint64)
+        not_canonical = np.full(4, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+        assert L_.pz_proof_lookups(h, ptr(not_canonical), ptr(a_), ptr(b_)) != 0
+        assert L_.pz_proof_free(h) == 0
+        # ... and the key serves the next proof
+        pr3 = prover_native.create_proof(key, world["witness"]().data_ptr(), world["ch"], seed=9)
+        assert _verify(cref, world, pr3) == (True, True, True)
+    finally:
+        key.free()
