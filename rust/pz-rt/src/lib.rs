@@ -91,3 +91,105 @@ pub fn encrypt_trace(n: &[u64], g: &[u64], m: &[u64], r: &[u64]) -> EncryptTrace
     });
     out
 }
+
+/// Patch point D through the library's stepper (include/pz.h "patch point D as entry points"): the proving key
+/// resident on the device, built from the structure halo2's `Assembly` holds.  `create_proof` then is `ProofSession`'s seven methods with the
+/// caller's transcript in between (reference: /root/reference/src/bench.rs:161-171, `gen_proof` -> halo2-axiom `create_proof`).
+pub struct DeviceKey {
+    pub pk: *mut pz_pk,
+    pub n_fixed: usize,
+    pub n_perm_cols: usize,
+    pub n_sets: usize,
+    pub blinding_words: usize,
+    pub evals_words: usize,
+}
+impl DeviceKey {
+    /// selectors: `n_adv * 2^k` bytes; constants: canonical 4-limb integers in row order; map_col / map_row: `(n_adv + n_lk + 1) * 2^k` each
+    #[allow(clippy::too_many_arguments)]
+    pub fn new(lagrange: *const pz_bases, monomial: *const pz_bases, k: u32, lookup_bits: u32, blinding_factors: u32, max_rows: usize,
+               n_adv: usize, n_lk: usize, selectors: &[u8], constants: &[u64], map_col: &[u32], map_row: &[u32]) -> Self {
+        let n = 1usize << k;
+        assert_eq!(selectors.len(), n_adv * n);
+        assert_eq!(map_col.len(), (n_adv + n_lk + 1) * n);
+        assert_eq!(map_row.len(), map_col.len());
+        assert_eq!(constants.len() % 4, 0);
+        let mut pk: *mut pz_pk = core::ptr::null_mut();
+        check(unsafe {
+            pz_pk_create(ctx(), lagrange, monomial, k, lookup_bits, blinding_factors, max_rows, n_adv, n_lk, selectors.as_ptr(), constants.as_ptr(),
+                         constants.len() / 4, map_col.as_ptr(), map_row.as_ptr(), 64, &mut pk)
+        });
+        let (mut a, mut b, mut c, mut d, mut e) = (0usize, 0usize, 0usize, 0usize, 0usize);
+        check(unsafe { pz_pk_info(pk, &mut a, &mut b, &mut c, &mut d, &mut e) });
+        DeviceKey { pk, n_fixed: a, n_perm_cols: b, n_sets: c, blinding_words: d, evals_words: e }
+    }
+    /// the verifying key's commitments (affine, Montgomery; 8 words per point): fixed columns, sigma columns
+    pub fn vk_commitments(&self) -> (Vec<u64>, Vec<u64>) {
+        let (mut f, mut s) = (vec![0u64; 8 * self.n_fixed], vec![0u64; 8 * self.n_perm_cols]);
+        check(unsafe { pz_pk_commitments(self.pk, f.as_mut_ptr(), s.as_mut_ptr()) });
+        (f, s)
+    }
+}
+impl Drop for DeviceKey {
+    fn drop(&mut self) {
+        unsafe { pz_pk_free(self.pk) };
+    }
+}
+
+/// one proof in flight on a `DeviceKey`: every method runs a phase on the device and returns what the transcript absorbs before the next
+/// challenge exists (points: 8 words each; evaluations: 4 words each, the family order of include/pz.h).  Challenges: Montgomery limbs of
+/// `Fr` (`mont(&c)` = the in-memory representation of halo2curves' `Fr`).
+pub struct ProofSession<'k> {
+    p: *mut pz_proof,
+    key: &'k DeviceKey,
+    n_adv_lk: usize,
+    n_lk: usize,
+}
+impl<'k> ProofSession<'k> {
+    /// d_cols: the K4 columns on the device (`(n_adv + n_lk + 1) * 2^k` elements; consumed); random: `key.blinding_words` words of OS randomness
+    pub fn begin(key: &'k DeviceKey, d_cols: *mut u64, n_adv: usize, n_lk: usize, random: &[u64]) -> (Self, Vec<u64>) {
+        assert!(random.len() >= key.blinding_words);
+        let mut p: *mut pz_proof = core::ptr::null_mut();
+        let mut advice = vec![0u64; 8 * (n_adv + n_lk)];
+        check(unsafe { pz_proof_begin(key.pk, d_cols, 0, random.as_ptr(), random.len(), &mut p, advice.as_mut_ptr()) });
+        (ProofSession { p, key, n_adv_lk: n_adv + n_lk, n_lk }, advice)
+    }
+    pub fn lookups(&mut self, theta: &[u64; 4]) -> (Vec<u64>, Vec<u64>) {
+        let (mut a, mut s) = (vec![0u64; 8 * self.n_lk], vec![0u64; 8 * self.n_lk]);
+        check(unsafe { pz_proof_lookups(self.p, theta.as_ptr(), a.as_mut_ptr(), s.as_mut_ptr()) });
+        (a, s)
+    }
+    pub fn products(&mut self, beta: &[u64; 4], gamma: &[u64; 4]) -> (Vec<u64>, Vec<u64>, [u64; 8]) {
+        let (mut z, mut zl, mut rnd) = (vec![0u64; 8 * self.key.n_sets], vec![0u64; 8 * self.n_lk], [0u64; 8]);
+        check(unsafe { pz_proof_products(self.p, beta.as_ptr(), gamma.as_ptr(), z.as_mut_ptr(), zl.as_mut_ptr(), rnd.as_mut_ptr()) });
+        (z, zl, rnd)
+    }
+    pub fn quotient(&mut self, y: &[u64; 4]) -> [u64; 24] {
+        let mut h = [0u64; 24];
+        check(unsafe { pz_proof_quotient(self.p, y.as_ptr(), h.as_mut_ptr()) });
+        h
+    }
+    pub fn evaluate(&mut self, x: &[u64; 4]) -> Vec<u64> {
+        let mut e = vec![0u64; self.key.evals_words];
+        check(unsafe { pz_proof_evaluate(self.p, x.as_ptr(), e.as_mut_ptr()) });
+        e
+    }
+    pub fn open_begin(&mut self, y: &[u64; 4], v: &[u64; 4]) -> [u64; 8] {
+        let mut w = [0u64; 8];
+        check(unsafe { pz_proof_open_begin(self.p, y.as_ptr(), v.as_ptr(), w.as_mut_ptr()) });
+        w
+    }
+    /// -> (second opening commitment, whether the quotient's degree is within 3n - 4: false = the witness does not satisfy the circuit)
+    pub fn open_finish(&mut self, u: &[u64; 4]) -> ([u64; 8], bool) {
+        let (mut w, mut ok) = ([0u64; 8], 0 as c_int);
+        check(unsafe { pz_proof_open_finish(self.p, u.as_ptr(), w.as_mut_ptr(), &mut ok) });
+        (w, ok != 0)
+    }
+    pub fn advice_points(&self) -> usize {
+        self.n_adv_lk
+    }
+}
+impl Drop for ProofSession<'_> {
+    fn drop(&mut self) {
+        unsafe { pz_proof_free(self.p) };
+    }
+}
