@@ -495,7 +495,7 @@ int pz_shplonk_free(pz_ctx* ctx, pz_shplonk* state);
  * pz_pk_create   selectors: u8 [n_adv][2^k]; constants: n_constants x 4 words, canonical integers (NOT Montgomery), row order;
  *                map_col / map_row: u32 [m][2^k] (all host).  Builds and keeps RESIDENT the commitments, the coefficient forms and the
  *                extended forms of the fixed and sigma columns, l_0 / l_last / l_active, and one proof's workspace (at config c2:
- *                116 + 30 GB).  tile: columns extended per step of the quotient (even; 64).  The key holds device memory of `ctx`
+ *                116 + 30 GB).  n_adv, n_lk >= 1; lookup_bits < k.  tile: columns extended per step of the quotient (even; 64).  The key holds device memory of `ctx`
  *                (which must outlive it) and serves ONE proof at a time.
  * pz_pk_info     n_fixed = n_adv + 2 (selectors | constants | table); blinding_words = 64-bit words of caller randomness one proof
  *                consumes; evals_words = length of pz_proof_evaluate's output.

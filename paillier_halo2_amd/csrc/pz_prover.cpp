@@ -53,7 +53,8 @@ extern "C" int pz_pk_create(pz_ctx* ctx, const pz_bases* bases_lagrange, const p
                             const uint64_t* constants, size_t n_constants, const uint32_t* map_col, const uint32_t* map_row, size_t tile,
                             pz_pk** out) {
     if (!ctx || !bases_lagrange || !bases_monomial || !selectors || !map_col || !map_row || !out || (n_constants && !constants)) return PZ_ERR_INVALID;
-    if (k < 4 || k > 24 || !n_adv || lookup_bits >= k + 1 || tile == 0 || tile % pzp::CHUNK) return PZ_ERR_INVALID;
+    // (n_lk = 0: a circuit without range-check lookups is not a halo2-lib circuit; the composition assumes at least one lookup column)
+    if (k < 4 || k > 24 || !n_adv || !n_lk || lookup_bits >= k || tile == 0 || tile % pzp::CHUNK) return PZ_ERR_INVALID;
     const size_t n = (size_t)1 << k;
     if (max_rows + blinding_factors + 1 > n || n_constants > max_rows) return PZ_ERR_INVALID;
     size_t np_l = 0, np_m = 0;
