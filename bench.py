@@ -92,7 +92,7 @@ class ProofWorkload:
     """device-resident state of the c2 hot path on one GPU"""
 
     def __init__(self, eng, torch, enc_bits: int, k: int, seed: int, scale: float, pool: int = 256, circuit: str = "encrypt",
-                 lookup_bits=None, shard=(0, 1), dist=None):
+                 lookup_bits=None, shard=(0, 1), dist=None, minimum_rows: int = 20):
         from paillier_halo2_amd import consts, layout
 
         self.eng, self.torch = eng, torch
@@ -116,7 +116,7 @@ class ProofWorkload:
         self.n_steps = n_steps
         self.ng = (m.bit_length() + bin(m).count("1")) if circuit == "encrypt" else 2 * enc_bits if circuit == "encrypt_uniform" else 0
         self.nr = (nn.bit_length() + bin(nn).count("1")) if circuit != "add" else 0
-        self.shape = layout.encrypt_proof_shape(enc_bits, k, n_steps, lookup_bits=lookup_bits, kind=circuit, n_steps_g=self.ng)
+        self.shape = layout.encrypt_proof_shape(enc_bits, k, n_steps, lookup_bits=lookup_bits, kind=circuit, n_steps_g=self.ng, minimum_rows=minimum_rows)
         self.kind = {"encrypt": 0, "add": 1, "encrypt_uniform": 2}[circuit]
         # the driver's inputs as the C ABI takes them (n | g | m | r | res words).  `res` is the expected ciphertext the
         # reference's driver receives from paillier_enc_native / paillier_add_native (bench.rs:149,193): here the library's own
@@ -159,12 +159,13 @@ class ProofWorkload:
         # consecutive runs of `rows` cells (2^k minus the blinding rows), lookup columns likewise
         self.d_mod = torch.from_numpy(consts.int_to_limbs(nn * nn, self.L).astype(np.int64)).to(dev)
         self.cells, self.lookups = eng.witness_cells_per_step(self.L, 64, self.shape.lookup_bits)
-        self.rows = self.n - 10
+        self.row_budget = rb = layout.row_budget(k, minimum_rows)     # the tester's: calculate_params(Some(20)) on the bench path (layout.RowBudget)
+        self.rows = rb.max_rows
         # the WHOLE circuit's stream (assignments, square + refresh, every mul_mod, assert_equal_fresh): row a6
         self.circ_adv, self.circ_lk = eng.circuit_cells(self.kind, self.Ln, 64, self.shape.lookup_bits, self.ng, self.nr)
         assert (self.circ_adv, self.circ_lk) == (self.shape.advice_cells, self.shape.lookup_cells)
-        self.adv_cols = -(-self.circ_adv // self.rows)
-        self.lk_cols = -(-self.circ_lk // self.rows)
+        self.adv_cols = rb.columns_for(self.circ_adv)     # configured columns: >= the ones a cut at `rows` fills (an empty one is committed all the same)
+        self.lk_cols = rb.columns_for(self.circ_lk)
         # proofs are independent, so the witness of proof i+1 (K3 trace: 4 wavefronts busy for 50 ms, then K4) is
         # produced on a second context / stream while proof i's commitments and NTTs run: two witness slots
         self.pipeline = os.environ.get("PZ_BENCH_PIPELINE", "1") == "1"
@@ -705,7 +706,8 @@ class ProofWorkload:
         t = self.torch
         z = lambda *shape: t.zeros(shape, dtype=t.int64, device="cuda")
         a, l = self.adv_cols, self.lk_cols
-        samples = sorted({(0, 0), (0, a // 2), (0, a - 1)} | ({(1, 0), (1, l - 1)} if l else set()))
+        af, lf = -(-self.circ_adv // self.rows), -(-self.circ_lk // self.rows)     # the columns the cells fill (the last of them ragged)
+        samples = sorted({(0, 0), (0, af // 2), (0, af - 1)} | ({(1, 0), (1, lf - 1)} if l else set()))
         return dict(adv=z(a, 12), lk=z(max(1, l), 12), full=z(self.counts["msm_full"], 12), samples=samples,
                     coef=z(len(samples), self.n, 4), ext=z(len(samples), self.ext_n, 4))
 
@@ -1012,8 +1014,8 @@ def dropin_device_resident(wl, args, log, env_extra=None, replicas=1):
     s_toxic = _random.Random(args.seed ^ 0x535253).randrange(2, consts.FR_R)
     sh = wl.shape
     nn = consts.limbs_to_int(wl.inputs[0]) if hasattr(consts, "limbs_to_int") else sum(int(v) << (64 * i) for i, v in enumerate(wl.inputs[0]))
-    words = [0x325A50, wl.enc_bits, wl.k, sh.lookup_bits, wl.n_steps, wl.counts["msm_full"], wl.counts["polys"], wl.pool, wl.ntt_batch,
-             args.steps, args.warmup, sh.ext_k - wl.k, args.seed]
+    words = [0x335A50, wl.enc_bits, wl.k, sh.lookup_bits, wl.n_steps, wl.counts["msm_full"], wl.counts["polys"], wl.pool, wl.ntt_batch,
+             args.steps, args.warmup, sh.ext_k - wl.k, args.seed, wl.rows, wl.row_budget.minimum_rows]
     arrs = [np.asarray(a, dtype=np.uint64) for a in wl.inputs] + [wl.circ_inputs[4 * wl.Ln:].astype(np.uint64),
                                                                    consts.int_to_limbs(nn * nn, wl.L)]
     arrs += [consts.fr_mont_limbs(s_toxic), wl.omega_n, wl.omega_inv, wl.n_inv, wl.coset_gens.reshape(-1)]

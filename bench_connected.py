@@ -67,7 +67,8 @@ def cpp_connected(cw, proofs=4, verify_with=None, log=lambda s: None):
 
 class ConnectedWorkload:
     def __init__(self, eng, torch, enc_bits: int, k: int, seed: int, lookup_bits=None, log=lambda s: None, tile: int = 64,
-                 circuit: str = "encrypt", pipeline=None, cosets=None, srs=None, trim: bool = True):
+                 circuit: str = "encrypt", pipeline=None, cosets=None, srs=None, trim: bool = True, minimum_rows: int = 20,
+                 streamed_key=None, lookup_tile=None):
         import random
 
         import bench
@@ -104,7 +105,9 @@ class ConnectedWorkload:
         assert (sa.n_steps_g, sa.n_steps_r) == (self.ng, self.nr)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        self.cs, starts = CS.columns(sa, k, self.lb, device="cuda", keep_on_device=True)       # ... and the structure kept there for keygen
+        # the tester's row budget (layout.RowBudget): calculate_params(Some(20)) on the reference's bench path (bench.rs:161-171)
+        self.minimum_rows = minimum_rows
+        self.cs, starts = CS.columns(sa, k, self.lb, minimum_rows=minimum_rows, device="cuda", keep_on_device=True)   # ... and the structure kept there for keygen
         torch.cuda.synchronize()
         self.n_cells, self.n_lookups = sa.n_cells, int(sa.lookup_src.shape[0])
         del sa
@@ -131,12 +134,17 @@ class ConnectedWorkload:
         t2 = time.perf_counter()
         # the quotient from THREE cosets (its degree is below 3n) instead of halo2's 4n-point coset: PZ_CONNECTED_COSETS=4 for the A/B
         self.cosets = int(os.environ.get("PZ_CONNECTED_COSETS", "3")) if cosets is None else int(cosets)
-        self.pk = prover.keygen(eng, self.cs, self.bl, self.bm, cosets=self.cosets)
+        # streamed_key: None = the extended proving key resident (c2: 77 GB); an integer R = only the first R permuted columns' extended forms
+        # stay, the rest is re-extended per tile from the coefficient forms (R = 0 at BASELINE config c5: its extended key would be 239 GB)
+        if streamed_key is None and os.environ.get("PZ_CONNECTED_STREAMED_KEY", "") != "":
+            streamed_key = int(os.environ["PZ_CONNECTED_STREAMED_KEY"])
+        self.streamed_key = streamed_key
+        self.pk = prover.keygen(eng, self.cs, self.bl, self.bm, cosets=self.cosets, ext_resident_cols=streamed_key)
         torch.cuda.synchronize()
         self.keygen_ms = (time.perf_counter() - t2) * 1e3
         if trim:                                   # hand the allocator's free blocks back (trim=False: a following key reuses them)
             torch.cuda.empty_cache()
-        self.ws = prover.Workspace(self.pk, tile)
+        self.ws = prover.Workspace(self.pk, tile, lookup_tile=lookup_tile)
         # two witness slots: proof i+1's K3 + K4 run on a second context / stream under proof i's advice commitments
         self.pipeline = (os.environ.get("PZ_CONNECTED_PIPELINE", "1") == "1") if pipeline is None else bool(pipeline)
         self.slots = [prover._zeros_cap(self.m, self.n, 4) for _ in range(2 if self.pipeline else 1)]
@@ -159,8 +167,9 @@ class ConnectedWorkload:
         ext_bytes = sum(t.numel() * 8 for t in self.pk.fixed_ext + self.pk.sigma_ext)
         pk_bytes = ext_bytes + sum(t.numel() * 8 for t in (self.pk.fixed_coeff, self.pk.sigma_coeff, self.pk.sigma_lagrange))
         self.memory_gb = {"proving_key_resident": pk_bytes / 1e9, "of_which_extended_forms": ext_bytes / 1e9,
+                          "proving_key_streamed": bool(self.pk.streamed), "extended_forms_resident_columns": list(self.pk.ext_resident),
                           "quotient_domain_cosets": self.pk.dom.cosets,
-                          "grand_products_extended": sum(t.numel() for t in self.ws.z_ext) * 8 / 1e9, "witness_columns": sum(t.numel() for t in self.slots) * 8 / 1e9,
+                          "grand_products_extended": self.ws._z_ext_flat.numel() * 8 / 1e9, "witness_columns": sum(t.numel() for t in self.slots) * 8 / 1e9,
                           "torch_allocated_after_setup": torch.cuda.memory_allocated() / 1e9}
 
     def produce(self, eng=None):
@@ -332,7 +341,8 @@ class ConnectedWorkload:
 
     def counts(self):
         S = self.pk.n_sets
-        return {"advice_cols": self.A, "lookup_cols": self.Lk, "permutation_cols": self.m, "permutation_sets": S,
+        return {"advice_cols": self.A, "advice_cols_filled": self.cs.n_adv_used, "lookup_cols": self.Lk, "minimum_rows": self.minimum_rows,
+                "max_rows": self.cs.max_rows, "permutation_cols": self.m, "permutation_sets": S,
                 "advice_cells": self.n_cells, "lookup_cells": self.n_lookups,
                 "msm_witness": self.A + self.Lk, "msm_full": 3 * self.Lk + S + 1 + 3 + 2,
                 "ntt_polys": self.m + 3 * self.Lk + S, "polys_opened": 2 * self.m + self.A + 2 + 3 * self.Lk + S + 2 - 1}

@@ -503,8 +503,11 @@ int pz_shplonk_free(pz_ctx* ctx, pz_shplonk* state);
  *
  * pz_proof_begin d_cols: device, [m][2^k] elements: the advice then the lookup-advice columns as pz_circuit_expand_cols_dev wrote
  *                them (rows >= max_rows zero); the last column and the blinding rows are filled here; CONSUMED (ends in coefficient
- *                form).  blinding: n_blinding >= blinding_words random words (host), or NULL: a xorshift stream from `seed` (tests,
- *                benches -- not for production).  -> advice_affine: (n_adv + n_lk) x 8.           [transcript: ... -> theta]
+ *                form).  blinding: n_blinding >= blinding_words random words (host) -- a production prover hands over OS randomness; the
+ *                elements are drawn uniformly below r by rejection (254-bit candidates), blinding_words includes the margin.  The
+ *                deterministic stream from `seed` (tests, benches: NOT zero-knowledge) must be asked for explicitly: blinding = NULL
+ *                AND n_blinding = PZ_BLINDING_SEEDED_TEST_STREAM; NULL with any other count is PZ_ERR_INVALID.
+ *                -> advice_affine: (n_adv + n_lk) x 8.                                            [transcript: ... -> theta]
  * pz_proof_lookups       -> n_lk x 8 each (permuted inputs A', permuted tables S')                 [-> beta, gamma]
  * pz_proof_products      -> n_sets x 8 (permutation products), n_lk x 8 (lookup products), 8 (the vanishing argument's random
  *                        polynomial)                                                              [-> y]
@@ -523,6 +526,7 @@ int pz_shplonk_free(pz_ctx* ctx, pz_shplonk* state);
  * ------------------------------------------------------------------------------------------- */
 typedef struct pz_pk pz_pk;
 typedef struct pz_proof pz_proof;
+#define PZ_BLINDING_SEEDED_TEST_STREAM (~(size_t)0)
 int pz_pk_create(pz_ctx* ctx, const pz_bases* bases_lagrange, const pz_bases* bases_monomial, uint32_t k, uint32_t lookup_bits,
                  uint32_t blinding_factors, size_t max_rows, size_t n_adv, size_t n_lk, const uint8_t* selectors,
                  const uint64_t* constants, size_t n_constants, const uint32_t* map_col, const uint32_t* map_row, size_t tile,

@@ -93,19 +93,24 @@ class Structure:
         import bisect
 
         j = bisect.bisect_right(self.starts, c) - 1
-        if j >= self.n_adv:
-            j = self.n_adv - 1
+        used = self.info.get("n_adv_used", self.n_adv)
+        if j >= used:
+            j = used - 1
         return j, c - self.starts[j]
 
 
 def build(kind: str, n: int, g: int, x: int, y: int, res: int, enc_bits: int, limb_bits: int, lb: int, k: int,
-          max_rows: int | None = None, blinding_factors: int = 6) -> Structure:
-    """structure + expected witness columns of one encrypt / add circuit instance"""
+          minimum_rows: int = 20, blinding_factors: int = 6, break_rows: int | None = None) -> Structure:
+    """structure + expected witness columns of one encrypt / add circuit instance.
+    minimum_rows: the argument of halo2-lib's `calculate_params` [D] -- it fixes the NUMBER of advice / lookup-advice columns as
+    ceil(cells / (2^k - minimum_rows)): 20 on the reference's bench path (bench_builder, reached from /root/reference/src/bench.rs:161-171),
+    9 under MockProver (src/paillier.rs:167-171).  Columns are FILLED to max_rows = 2^k - cs.minimum_rows() = 2^k - (blinding_factors + 3)
+    (FlexGateConfig::max_rows [D]; break_rows overrides), so configured columns beyond the ones the cells fill stay empty."""
     N = 1 << k
     usable = N - (blinding_factors + 1)
-    if max_rows is None:
-        max_rows = N - 10                   # the repo's convention (layout.py: blinding_rows = 10), <= usable
-    assert max_rows <= usable
+    max_rows = N - (blinding_factors + 3) if break_rows is None else break_rows
+    count_rows = N - minimum_rows
+    assert max_rows <= usable and count_rows > 0
     W = P.expand_circuit_cells_wired(kind, n, g, x, y, res, enc_bits, limb_bits, lb, full=True)
     adv = W["advice"]
     if kind == "encrypt":
@@ -124,22 +129,28 @@ def build(kind: str, n: int, g: int, x: int, y: int, res: int, enc_bits: int, li
         mask, total = P.gate_mask_circuit(kind, enc_bits, limb_bits, lb, ng, nr)
     assert total == len(adv)
     starts = break_points(mask, max_rows)
-    A = len(starts) - 1
+    A_used = len(starts) - 1
+    A = max(A_used, -(-len(adv) // count_rows))     # configured columns (calculate_params); the ones past A_used stay empty
     lk_src = W["lookup_src"]
-    Lk = -(-len(lk_src) // max_rows)
+    Lk = max(-(-len(lk_src) // max_rows), -(-len(lk_src) // count_rows))
     m = A + Lk + 1
     st = Structure(k=k, lookup_bits=lb, max_rows=max_rows, blinding_factors=blinding_factors, starts=starts, n_adv=A, n_lk=Lk,
                    selectors=np.zeros((A, N), dtype=np.uint8), constants=[], table=[], map_col=None, map_row=None, equalities=[],
                    adv_cols=[], lk_cols=[], n_cells=len(adv), n_lookups=len(lk_src), satisfied=W["satisfied"])
+    st.info["n_adv_used"], st.info["minimum_rows"] = A_used, minimum_rows
+    st.starts = starts + [len(adv)] * (A - A_used)      # n_adv + 1 entries: an empty configured column starts (and ends) at the stream's end
     # columns and selectors
     for j in range(A):
+        if j >= A_used:
+            st.adv_cols.append([0] * N)
+            continue
         lo, hi = starts[j], starts[j + 1]
-        last = hi if j + 1 < A else hi - 1          # a non-final column also holds the cell the next one starts with
+        last = hi if j + 1 < A_used else hi - 1     # a non-final column also holds the cell the next one starts with
         col = adv[lo:last + 1]
         assert len(col) <= max_rows, (j, len(col))
         st.adv_cols.append(col + [0] * (N - len(col)))
         st.selectors[j, : hi - lo] = mask[lo:hi]    # the shared last cell's gate is enabled in the NEXT column
-        if j + 1 < A:
+        if j + 1 < A_used:
             st.equalities.append(((j + 1, 0), (j, hi - lo)))
     lk_vals = [adv[c] for c in lk_src]
     for j in range(Lk):

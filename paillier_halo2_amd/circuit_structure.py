@@ -529,41 +529,48 @@ def stream_structure(kind: str, enc_bits: int, limb_bits: int, lb: int, exp_g: i
                            constants=constants, result_cell=eq_cell, n_steps_g=n_steps[0], n_steps_r=n_steps[1])
 
 
-def columns(sa: StructureArrays, k: int, lb: int, max_rows: Optional[int] = None, blinding_factors: int = 6, device: Optional[str] = None,
-            keep_on_device: bool = False):
+def columns(sa: StructureArrays, k: int, lb: int, minimum_rows: int = layout.MINIMUM_ROWS_BENCH, blinding_factors: int = layout.BLINDING_FACTORS,
+            device: Optional[str] = None, keep_on_device: bool = False, break_rows: Optional[int] = None):
     """stream structure -> (CircuitStructure for prover.keygen, starts).  The permutation covers [advice | lookup advice | constants];
     every equality class becomes one cycle of sigma (cells in increasing (column, row) order).
+    minimum_rows: the argument of the tester's calculate_params (layout.RowBudget): it fixes the NUMBER of advice / lookup-advice columns
+    (20 on the reference's bench path, /root/reference/src/bench.rs:161-171; 9 under MockProver, src/paillier.rs:167-171); columns are
+    FILLED to 2^k - (blinding_factors + 3) rows (break_rows overrides), so with 20 the last configured column can stay empty -- it is a
+    column of the circuit all the same (selector all zero, identity permutation, committed and opened).
+    starts: n_adv + 1 break points -- what K4 takes (pz_circuit_expand_cols_dev); a configured column the cells do not reach starts and
+    ends at the stream's end.
     keep_on_device: selectors / map_col / map_row stay tensors on `device` (uint8 / int32) for prover.keygen instead of travelling to the
     host and back (4 GB each way at config c2)."""
     import torch
 
     n = 1 << k
-    if max_rows is None:
-        max_rows = n - 10
+    rb = layout.row_budget(k, minimum_rows, blinding_factors, break_rows)
+    max_rows = rb.max_rows
     assert max_rows <= n - (blinding_factors + 1)
     starts = layout.break_points(sa.gate_mask, max_rows).astype(np.int64)
-    A = starts.shape[0] - 1
+    A_used = starts.shape[0] - 1
     NC, NL, NK = sa.n_cells, sa.lookup_src.shape[0], len(sa.constants)
-    Lk = -(-NL // max_rows)
+    A = rb.columns_for(NC, filled=A_used)
+    Lk = rb.columns_for(NL)
     m = A + Lk + 1
     assert NK <= max_rows
     if device is None:
         device = "cuda" if (torch.cuda.is_available() and NC > (1 << 22)) else "cpu"
     dev = torch.device(device)
-    T = NC + NL + NK + (A - 1)
+    T = NC + NL + NK + (A_used - 1)
     st = torch.from_numpy(starts).to(dev)
     # ---- node -> flat position (column * n + row)
     pos = torch.empty(T, dtype=torch.int64, device=dev)
     c = torch.arange(NC, dtype=torch.int64, device=dev)
     col = torch.searchsorted(st, c, right=True) - 1
-    col.clamp_(max=A - 1)
+    col.clamp_(max=A_used - 1)
     pos[:NC] = col * n + (c - st[col])
     del c, col
     t = torch.arange(NL, dtype=torch.int64, device=dev)
     pos[NC:NC + NL] = (A + t // max_rows) * n + t % max_rows
     del t
     pos[NC + NL:NC + NL + NK] = (A + Lk) * n + torch.arange(NK, dtype=torch.int64, device=dev)
-    j = torch.arange(1, A, dtype=torch.int64, device=dev)
+    j = torch.arange(1, A_used, dtype=torch.int64, device=dev)
     pos[NC + NL + NK:] = (j - 1) * n + (st[j] - st[j - 1])
     # ---- what every node copies
     src = torch.arange(T, dtype=torch.int64, device=dev)
@@ -621,5 +628,6 @@ def columns(sa: StructureArrays, k: int, lb: int, max_rows: Optional[int] = None
         map_row = map_row.cpu().numpy().view(np.uint32)
         selectors = selectors.cpu().numpy()
     cs = CircuitStructure(k=k, lookup_bits=lb, max_rows=max_rows, blinding_factors=blinding_factors, selectors=selectors, n_lk=Lk,
-                          constants=list(sa.constants), map_col=map_col, map_row=map_row)
+                          constants=list(sa.constants), map_col=map_col, map_row=map_row, minimum_rows=minimum_rows, n_adv_used=A_used)
+    starts = np.concatenate([starts, np.full(A - A_used, NC, dtype=np.int64)])
     return cs, starts.astype(np.uint64)

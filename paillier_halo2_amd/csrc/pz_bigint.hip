@@ -927,8 +927,23 @@ static unsigned env_u32(const char* name, unsigned dflt) {
     const char* v = getenv(name);
     return v && *v ? (unsigned)strtoul(v, nullptr, 0) : dflt;
 }
-static size_t chains_per_launch(unsigned bits, unsigned L, size_t n_chains) {
-    const size_t cap_kib = env_u32("PZ_K3_HANDOFF_CAP_KIB", 0);   // test hook: a small cap splits a small batch into several launches
+// Test hooks (tests/test_gpu_kernels.py::test_k3_bounded_wait_reports_internal, test_encrypt_batch_beyond_residency): honoured only
+// when PZ_K3_TEST_HOOKS=1 is set as well, and read ONCE PER CALL (chain_handoff_alloc), never inside the per-chain loop -- a stray
+// PZ_K3_* variable in a deployment changes nothing, and the production path makes one getenv per entry point.
+struct K3Hooks {
+    unsigned spin_limit = K3_SPIN_LIMIT, test_no_publish = 0;
+    size_t cap_kib = 0;
+};
+static K3Hooks k3_hooks() {
+    K3Hooks h;
+    const char* on = getenv("PZ_K3_TEST_HOOKS");
+    if (!(on && on[0] == '1')) return h;
+    h.spin_limit = env_u32("PZ_K3_SPIN_LIMIT", K3_SPIN_LIMIT);
+    h.test_no_publish = env_u32("PZ_K3_TEST_NO_PUBLISH", 0);
+    h.cap_kib = env_u32("PZ_K3_HANDOFF_CAP_KIB", 0);   // a small cap splits a small batch into several launches
+    return h;
+}
+static size_t chains_per_launch(unsigned bits, unsigned L, size_t n_chains, size_t cap_kib) {
     size_t per = (cap_kib ? cap_kib << 10 : K3_HANDOFF_CAP) / chain_squares_bytes(bits, L);
     per = per < 2 ? 2 : per & ~(size_t)1;   // the two chains of an instance stay in one launch
     return per < n_chains ? per : n_chains;
@@ -937,9 +952,11 @@ struct ChainHandoff {
     char* squares;     // chains_per_launch x chain_squares_bytes, reused by every launch of the call
     char* counters;    // n_launches tickets, then n_chains ready counters, 64 bytes apart
     size_t per_launch, n_launches;
+    K3Hooks hooks;
 };
 static int chain_handoff_alloc(pz_ctx* ctx, size_t n_chains, unsigned bits, unsigned L, ChainHandoff* h) {
-    h->per_launch = chains_per_launch(bits, L, n_chains);
+    h->hooks = k3_hooks();
+    h->per_launch = chains_per_launch(bits, L, n_chains, h->hooks.cap_kib);
     h->n_launches = (n_chains + h->per_launch - 1) / h->per_launch;
     const size_t sq = h->per_launch * chain_squares_bytes(bits, L), cnt = (h->n_launches + n_chains) * 64;
     void* d;
@@ -952,8 +969,8 @@ static int chain_handoff_alloc(pz_ctx* ctx, size_t n_chains, unsigned bits, unsi
 static void chain_handoff_set(ChainDesc& d, const ChainHandoff& h, size_t i, unsigned bits, unsigned L) {
     d.sq_buf = (u64*)(h.squares + (i % h.per_launch) * chain_squares_bytes(bits, L));
     d.ready = (u32*)(h.counters + (h.n_launches + i) * 64);
-    d.spin_limit = env_u32("PZ_K3_SPIN_LIMIT", K3_SPIN_LIMIT);        // test hooks: tests/test_gpu_kernels.py::test_k3_bounded_wait
-    d.test_no_publish = env_u32("PZ_K3_TEST_NO_PUBLISH", 0);
+    d.spin_limit = h.hooks.spin_limit;
+    d.test_no_publish = h.hooks.test_no_publish;
 }
 static int launch_chains(pz_ctx* ctx, const ChainDesc* d_descs, size_t n, unsigned L, const ChainHandoff& h) {
     // per launch: 2 m workgroups for m chains; who squares and who multiplies is decided by arrival (k_pow_mod_chain)

@@ -232,6 +232,30 @@ extern "C" int pz_permutation_sigma_dev(pz_ctx* ctx, const uint32_t* d_map_col, 
 // left RESIDENT in the caller's device buffers for every proof that follows.
 extern "C" int pz_msm_g1_dev(pz_ctx* ctx, const pz_bases* bases, const uint64_t* d_scalars, size_t n_cols, size_t n, size_t col_stride,
                              uint32_t win_lo, uint32_t win_hi, uint64_t* d_out_jac);
+// selectors cross the ABI as bytes (0 / 1) and become Lagrange-form fixed columns here: out[i] = mask[i] ? 1 : 0 in Montgomery form.
+// HBM-bound elementwise work: 1 byte read, 32 written per element; a thread takes four consecutive elements (one 4-byte load, four
+// 32-byte stores that the wave lays down as whole 128-byte lines).
+__global__ __launch_bounds__(256) void k_fr_from_mask(const uint8_t* __restrict__ mask, size_t n, Fr* __restrict__ out) {
+    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    const Fr one = fp_one<FrTag>(), zero = fp_zero<FrTag>();
+    if (i0 + 4 <= n && ((uintptr_t)(mask + i0) & 3) == 0) {
+        const u32 w = *(const u32*)(mask + i0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fp_store(out + i0 + j, ((w >> (8 * j)) & 0xffu) ? one : zero);
+    } else {
+        for (size_t i = i0; i < n && i < i0 + 4; ++i) fp_store(out + i, mask[i] ? one : zero);
+    }
+}
+extern "C" int pz_fr_from_mask_dev(pz_ctx* ctx, const uint8_t* d_mask, size_t n, uint64_t* d_out) {
+    if (!ctx || (n && (!d_mask || !d_out))) return PZ_ERR_INVALID;
+    if (!n) return PZ_OK;
+    PZ_ENTER(ctx);
+    hipLaunchKernelGGL(k_fr_from_mask, dim3((unsigned)pz_div_up(pz_div_up(n, 4), 256)), dim3(256), 0, ctx->stream, d_mask, n, (Fr*)d_out);
+    HIPCHK(ctx, hipGetLastError());
+    return PZ_OK;
+}
+
 extern "C" int pz_keygen_columns_dev(pz_ctx* ctx, const pz_bases* bases_lagrange, uint64_t* d_cols, size_t n_cols, size_t col_stride,
                                      uint32_t k, uint32_t log_e, const uint64_t omega_n[4], const uint64_t omega_n_inv[4],
                                      const uint64_t n_inv[4], const uint64_t* coset_gens, uint64_t* d_commit_jac, uint64_t* d_ext,

@@ -398,10 +398,11 @@ extern "C" int pz_permutation_product_dev(pz_ctx* ctx, const uint64_t* d_cols, s
 __global__ __launch_bounds__(256) void k_perm_terms_sets(const Fr* __restrict__ cols, size_t cs, const Fr* __restrict__ sigma,
                                                          size_t ss, unsigned m, unsigned chunk_len, size_t n,
                                                          const Fr* __restrict__ wpow, const Fr* __restrict__ dpow,
-                                                         S29 beta266, S29 g, S29 d, Fr* __restrict__ num, Fr* __restrict__ den) {
+                                                         S29 beta266, S29 g, S29 d, Fr* __restrict__ num, Fr* __restrict__ den,
+                                                         unsigned set0) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const unsigned set = blockIdx.y, c0 = set * chunk_len;
+    const unsigned c0 = (set0 + blockIdx.y) * chunk_len, set = blockIdx.y;   // num / den hold the launch's sets only
     Fr29 nm = fr29_one256(), dn = nm;
     Fr29 bd = f29_mul(f29_mul_s(f29_load<FrTag>(dpow + c0), beta266.v), f29_load_shl5<FrTag>(wpow + i));
     // the next column's value and sigma are requested before the current column's products start
@@ -468,16 +469,26 @@ extern "C" int pz_permutation_product_sets_dev(pz_ctx* ctx, const uint64_t* d_co
     void *wp, *dp, *ws, *mu;
     PZCHK(pz_get_pow_table(ctx, omega, n, &wp));
     PZCHK(pz_get_pow_table(ctx, delta, m, &dp));
-    PZCHK(pz_ws_get(ctx, WS_BIG_C, 2 * n_sets * n * 32, &ws));
+    // numerators and denominators of a BATCH of sets at a time: the workspace is bounded (4 GiB of terms: 512 sets of 2^17 rows, 128 of
+    // 2^19) instead of growing with the circuit -- at BASELINE config c5 (1200 sets of 2^19 rows) all sets at once would be 40 GB of
+    // library workspace beside a proving key that has to share 288 GB with it.  Sets are independent until the chaining below.
+    size_t sb = ((size_t)4 << 30) / (2 * n * 32);
+    if (sb < 1) sb = 1;
+    if (sb > n_sets) sb = n_sets;
+    PZCHK(pz_ws_get(ctx, WS_BIG_C, 2 * sb * n * 32, &ws));
     PZCHK(pz_ws_get(ctx, WS_MISC, n_sets * 32, &mu));
     Fr* num = (Fr*)ws;
-    Fr* den = num + n_sets * n;
-    hipLaunchKernelGGL(k_perm_terms_sets, dim3(pz_div_up(n, 256), (unsigned)n_sets), dim3(256), 0, ctx->stream,
-                       (const Fr*)d_cols, col_stride / 4, (const Fr*)d_sigma, sigma_stride / 4, (unsigned)m, (unsigned)chunk_len, n,
-                       (const Fr*)wp, (const Fr*)dp, host_fr_shl(beta, 10), host_fr_shl(gamma, 5), host_fr_shl(delta, 5), num, den);
-    HIPCHK(ctx, hipGetLastError());
-    PZCHK(pz_batch_invert_internal(ctx, den, n_sets * n, num));   // num <- num / den
-    PZCHK(pz_prefix_product_batch_internal(ctx, num, n, n_sets, n, fp_one_host(), (Fr*)d_z, z_stride / 4));
+    Fr* den = num + sb * n;
+    for (size_t s0 = 0; s0 < n_sets; s0 += sb) {
+        const size_t ns = n_sets - s0 < sb ? n_sets - s0 : sb;
+        hipLaunchKernelGGL(k_perm_terms_sets, dim3(pz_div_up(n, 256), (unsigned)ns), dim3(256), 0, ctx->stream,
+                           (const Fr*)d_cols, col_stride / 4, (const Fr*)d_sigma, sigma_stride / 4, (unsigned)m, (unsigned)chunk_len, n,
+                           (const Fr*)wp, (const Fr*)dp, host_fr_shl(beta, 10), host_fr_shl(gamma, 5), host_fr_shl(delta, 5), num, den,
+                           (unsigned)s0);
+        HIPCHK(ctx, hipGetLastError());
+        PZCHK(pz_batch_invert_internal(ctx, den, ns * n, num));   // num <- num / den
+        PZCHK(pz_prefix_product_batch_internal(ctx, num, n, ns, n, fp_one_host(), (Fr*)d_z + s0 * (z_stride / 4), z_stride / 4));
+    }
     if (n_sets > 1) {
         hipLaunchKernelGGL(k_perm_chain, dim3(1), dim3(256), 0, ctx->stream, (const Fr*)d_z, z_stride / 4, (unsigned)n_sets,
                            usable_rows, (Fr*)mu);

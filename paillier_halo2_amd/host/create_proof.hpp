@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -54,6 +55,10 @@ struct Structure {   // what keygen derives from the circuit (INPUT)
     std::vector<uint64_t> constants;         // canonical integers, 4 words each
     std::vector<uint32_t> map_col, map_row;  // [m][2^k]
     std::vector<uint64_t> starts;            // n_adv + 1 (the break-point layout K4 writes the advice stream in)
+    // the same three arrays ALREADY ON THE DEVICE (pz_pk_create_dev: a structure generated there, or uploaded once by the caller):
+    // when set they are used as they are and the host vectors above stay empty -- no host copy, no PCIe crossing
+    const uint8_t* d_selectors = nullptr;
+    const uint32_t *d_map_col = nullptr, *d_map_row = nullptr;
     size_t m() const { return n_adv + n_lk + 1; }
 };
 
@@ -126,29 +131,69 @@ struct ProvingKey {
     const pz_bases *bl = nullptr, *bm = nullptr;
     uint64_t *fixed_coeff = nullptr, *sigma_coeff = nullptr, *sigma_lagrange = nullptr, *const_lagrange = nullptr, *table_lagrange = nullptr;
     uint64_t *fixed_ext[2] = {nullptr, nullptr}, *sigma_ext[2] = {nullptr, nullptr}, *l_ext[2] = {nullptr, nullptr};
+    uint64_t* table_ext[2] = {nullptr, nullptr};   // the lookup table on the quotient's domain: one column, always resident
+    // the STREAMED proving key (prover.py ProvingKey.ext_resident_cols): extended forms are resident for selector j < res_fixed and sigma
+    // j < res_sigma only; create_proof re-extends the rest per tile from the coefficient forms.  Resident mode: res_fixed = n_adv,
+    // res_sigma = m (what halo2's ProvingKey keeps).  The proof is byte for byte the same either way.
+    size_t res_fixed = 0, res_sigma = 0;
+    bool streamed = false;
     std::vector<uint64_t> fixed_commit, sigma_commit;   // affine, 8 words each
-    ProvingKey(const Structure& s) : st(s), dom(s.k, s.blinding_factors) {}
+    explicit ProvingKey(Structure&& s) : st(std::move(s)), dom(st.k, st.blinding_factors) {}
 };
 
 inline void upload_mont(Ctx& cx, uint64_t* d, const std::vector<Fr>& v) {
     PZP_CK(pz_upload(cx.c, d, v.data(), v.size() * 32));
 }
 
-inline ProvingKey* keygen(Ctx& cx, const Structure& st, const pz_bases* bl, const pz_bases* bm) {
-    ProvingKey* pk = new ProvingKey(st);
+// st is CONSUMED (moved into the key; its large arrays -- selectors, the copy-constraint map -- are released once they are on the device:
+// at config c2 they are 0.4 + 2 x 1.6 GB of host memory).  A failing step throws (PZP_THROW) or exits: the key under construction and the
+// map's device buffers are released on the way out (the buffers of `cx` are the caller's to release: Ctx::release)
+static const size_t EXT_ALL = ~(size_t)0;   // pz.h PZ_PK_EXT_ALL
+
+// device buffers that do not outlive a scope (freed on every path out of it, a throwing PZP_CK included)
+struct Scratch {
+    pz_ctx* c;
+    std::vector<void*> bufs;
+    explicit Scratch(pz_ctx* c_) : c(c_) {}
+    void* get(size_t bytes) {
+        void* d = nullptr;
+        PZP_CK(pz_dev_alloc(c, bytes, &d));
+        bufs.push_back(d);
+        return d;
+    }
+    ~Scratch() {
+        for (void* d : bufs) pz_dev_free(c, d);
+    }
+};
+
+inline ProvingKey* keygen(Ctx& cx, Structure&& st_in, const pz_bases* bl, const pz_bases* bm, size_t ext_resident_cols = EXT_ALL) {
+    std::unique_ptr<ProvingKey> pk(new ProvingKey(std::move(st_in)));
+    const Structure& st = pk->st;
     Domain& d = pk->dom;
     const size_t n = d.n, A = st.n_adv, m = st.m(), F = A + 2;
     pk->bl = bl; pk->bm = bm; pk->F = F;
     pk->n_sets = (m + CHUNK - 1) / CHUNK;
-    // fixed columns [selectors | constants | table], Lagrange form, built on the host and uploaded column by column
+    pk->streamed = ext_resident_cols < m;
+    pk->res_sigma = pk->streamed ? ext_resident_cols : m;
+    pk->res_fixed = pk->res_sigma < A ? pk->res_sigma : A;
+    // fixed columns [selectors | constants | table], Lagrange form.  The selectors are bytes (0 / 1): they cross PCIe as bytes (or are on the
+    // device already) and become field elements THERE (pz_fr_from_mask_dev) -- built on the host as 32-byte elements they were 12.7 GB of
+    // uploads at config c2, most of pz_pk_create's 5 s
     uint64_t* fixed = cx.alloc(F * n * 4);
+    {
+        Scratch tmp(cx.c);
+        const uint8_t* d_sel = st.d_selectors;
+        if (!d_sel) {
+            void* up = tmp.get(A * n);
+            PZP_CK(pz_upload(cx.c, up, st.selectors.data(), A * n));
+            d_sel = (const uint8_t*)up;
+        }
+        PZP_CK(pz_fr_from_mask_dev(cx.c, d_sel, A * n, fixed));
+        PZP_CK(pz_sync(cx.c));
+    }
     {
         std::vector<Fr> col(n);
         const Fr zero = {{0, 0, 0, 0}};
-        for (size_t j = 0; j < A; ++j) {
-            for (size_t i = 0; i < n; ++i) col[i] = st.selectors[j * n + i] ? pzh::FR_ONE : zero;
-            upload_mont(cx, fixed + j * n * 4, col);
-        }
         for (size_t i = 0; i < n; ++i) col[i] = i < st.constants.size() / 4 ? pzh::from_raw(&st.constants[4 * i]) : zero;
         upload_mont(cx, fixed + A * n * 4, col);
         for (size_t i = 0; i < n; ++i) col[i] = i < ((size_t)1 << st.lookup_bits) ? pzh::from_u64(i) : zero;
@@ -161,16 +206,24 @@ inline ProvingKey* keygen(Ctx& cx, const Structure& st, const pz_bases* bl, cons
     // sigma from the copy-constraint map (one call over all m columns)
     uint64_t* sigma = cx.alloc(m * n * 4);
     {
-        void *dmc = nullptr, *dmr = nullptr;
-        PZP_CK(pz_dev_alloc(cx.c, m * n * 4, &dmc));
-        PZP_CK(pz_dev_alloc(cx.c, m * n * 4, &dmr));
-        PZP_CK(pz_upload(cx.c, dmc, st.map_col.data(), m * n * 4));
-        PZP_CK(pz_upload(cx.c, dmr, st.map_row.data(), m * n * 4));
+        Scratch tmp(cx.c);
+        const uint32_t *dmc = st.d_map_col, *dmr = st.d_map_row;
+        if (!dmc || !dmr) {
+            void *mc = tmp.get(m * n * 4), *mr = tmp.get(m * n * 4);
+            PZP_CK(pz_upload(cx.c, mc, st.map_col.data(), m * n * 4));
+            PZP_CK(pz_upload(cx.c, mr, st.map_row.data(), m * n * 4));
+            dmc = (const uint32_t*)mc;
+            dmr = (const uint32_t*)mr;
+        }
         const Fr delta = pzh::delta();
-        PZP_CK(pz_permutation_sigma_dev(cx.c, (const uint32_t*)dmc, (const uint32_t*)dmr, m, st.k, d.omega.v, delta.v, sigma, 4 * n));
+        PZP_CK(pz_permutation_sigma_dev(cx.c, dmc, dmr, m, st.k, d.omega.v, delta.v, sigma, 4 * n));
         PZP_CK(pz_sync(cx.c));
-        pz_dev_free(cx.c, dmc);
-        pz_dev_free(cx.c, dmr);
+    }
+    {   // the host copies of the structure's large arrays are done with
+        Structure& s_ = pk->st;
+        std::vector<uint8_t>().swap(s_.selectors);
+        std::vector<uint32_t>().swap(s_.map_col);
+        std::vector<uint32_t>().swap(s_.map_row);
     }
     pk->sigma_lagrange = cx.alloc(m * n * 4);
     PZP_CK(pz_dev_copy(cx.c, pk->sigma_lagrange, sigma, m * n * 32));
@@ -178,25 +231,37 @@ inline ProvingKey* keygen(Ctx& cx, const Structure& st, const pz_bases* bl, cons
     uint64_t* com_f = cx.alloc(F * 12);
     uint64_t* com_s = cx.alloc(m * 12);
     for (int pi = 0; pi < 2; ++pi) {
-        pk->fixed_ext[pi] = cx.alloc(F * d.parts[pi].size * 4);
-        pk->sigma_ext[pi] = cx.alloc(m * d.parts[pi].size * 4);
+        pk->fixed_ext[pi] = cx.alloc((pk->res_fixed ? pk->res_fixed : 1) * d.parts[pi].size * 4);
+        pk->sigma_ext[pi] = cx.alloc((pk->res_sigma ? pk->res_sigma : 1) * d.parts[pi].size * 4);
         pk->l_ext[pi] = cx.alloc(3 * d.parts[pi].size * 4);
+        pk->table_ext[pi] = cx.alloc(d.parts[pi].size * 4);
     }
-    struct Job { uint64_t* cols; size_t cnt; uint64_t* com; uint64_t** ext; };
-    Job jobs[2] = {{fixed, F, com_f, pk->fixed_ext}, {sigma, m, com_s, pk->sigma_ext}};
+    struct Job { uint64_t* cols; size_t cnt; uint64_t* com; uint64_t** ext; size_t res; };
+    Job jobs[2] = {{fixed, F, com_f, pk->fixed_ext, pk->res_fixed}, {sigma, m, com_s, pk->sigma_ext, pk->res_sigma}};
     for (auto& jb : jobs) {
         for (size_t c0 = 0; c0 < jb.cnt; c0 += 256) {
             const size_t cnt = jb.cnt - c0 < 256 ? jb.cnt - c0 : 256;
-            const Part& A_ = d.parts[0];
-            PZP_CK(pz_keygen_columns_dev(cx.c, bl, jb.cols + c0 * n * 4, cnt, 4 * n, st.k, A_.log_e, d.omega.v, d.omega_inv.v, d.n_inv.v, A_.gens.data(),
-                                         jb.com + c0 * 12, jb.ext[0] + c0 * A_.size * 4, 4 * A_.size));
-            const Part& B_ = d.parts[1];
-            PZP_CK(pz_ntt_fr_extend_dev(cx.c, jb.cols + c0 * n * 4, cnt, 4 * n, jb.ext[1] + c0 * B_.size * 4, 4 * B_.size, st.k, B_.log_e, d.omega.v,
-                                        B_.gens.data(), nullptr));
+            // a batch that straddles the resident prefix runs as two calls: with and without the extended forms kept
+            const size_t r_here = jb.res <= c0 ? 0 : (jb.res - c0 < cnt ? jb.res - c0 : cnt);
+            const size_t lo[2] = {c0, c0 + r_here}, bc[2] = {r_here, cnt - r_here};
+            for (int keep = 1; keep >= 0; --keep) {
+                const size_t b0 = lo[1 - keep], bn = bc[1 - keep];
+                if (!bn) continue;
+                const Part& A_ = d.parts[0];
+                PZP_CK(pz_keygen_columns_dev(cx.c, bl, jb.cols + b0 * n * 4, bn, 4 * n, st.k, A_.log_e, d.omega.v, d.omega_inv.v, d.n_inv.v,
+                                             A_.gens.data(), jb.com + b0 * 12, keep ? jb.ext[0] + b0 * A_.size * 4 : nullptr, 4 * A_.size));
+                if (!keep) continue;
+                const Part& B_ = d.parts[1];
+                PZP_CK(pz_ntt_fr_extend_dev(cx.c, jb.cols + b0 * n * 4, bn, 4 * n, jb.ext[1] + b0 * B_.size * 4, 4 * B_.size, st.k, B_.log_e, d.omega.v,
+                                            B_.gens.data(), nullptr));
+            }
         }
     }
     pk->fixed_coeff = fixed;
     pk->sigma_coeff = sigma;
+    for (int pi = 0; pi < 2; ++pi)
+        PZP_CK(pz_ntt_fr_extend_dev(cx.c, fixed + (A + 1) * n * 4, 1, 4 * n, pk->table_ext[pi], 4 * d.parts[pi].size, st.k, d.parts[pi].log_e,
+                                    d.omega.v, d.parts[pi].gens.data(), nullptr));
     // l_0, l_last, l_active
     {
         uint64_t* lrows = cx.alloc(3 * n * 4);
@@ -219,7 +284,7 @@ inline ProvingKey* keygen(Ctx& cx, const Structure& st, const pz_bases* bl, cons
     PZP_CK(pz_g1_normalize(cx.c, jac.data(), F, pk->fixed_commit.data()));
     PZP_CK(pz_download(cx.c, jac.data(), com_s, m * 96));
     PZP_CK(pz_g1_normalize(cx.c, jac.data(), m, pk->sigma_commit.data()));
-    return pk;
+    return pk.release();
 }
 
 // ---- transcript: every phase's commitments come to the host in affine form (a synchronising download) and are hashed; a challenge is
@@ -270,6 +335,7 @@ struct Proof {
 
 struct Workspace {
     uint64_t *Ap, *Sp, *Zl, *Z, *z_ext[2], *ext[2], *lk_ext[2][4], *hh[2], *hp[2], *h, *tmp, *rnd, *hcomb, *w1, *w2, *blind, *out12, *evals;
+    uint64_t* key_ext[2] = {nullptr, nullptr};   // streamed proving key: the tile of selectors / of sigma columns re-extended per step
     size_t tile, lt;
 };
 
@@ -281,9 +347,14 @@ inline Workspace make_workspace(Ctx& cx, const ProvingKey& pk, size_t tile = 64)
     w.lt = tile < Lk ? tile : Lk;
     w.Ap = cx.alloc(Lk * n * 4); w.Sp = cx.alloc(Lk * n * 4); w.Zl = cx.alloc(Lk * n * 4);
     w.Z = cx.alloc(S * n * 4);
+    // the grand products on the quotient's domain: all sets of ONE part at once (the chaining lines read z_{j-1} beside z_j); the parts are
+    // worked one after the other, so one buffer of the larger part serves both
+    const size_t big = d.parts[0].size > d.parts[1].size ? d.parts[0].size : d.parts[1].size;
+    w.z_ext[0] = w.z_ext[1] = cx.alloc(S * big * 4);
+    if (pk.streamed)
+        for (int q = 0; q < 2; ++q) w.key_ext[q] = cx.alloc(tile * big * 4);
     for (int pi = 0; pi < 2; ++pi) {
         const size_t Np = d.parts[pi].size;
-        w.z_ext[pi] = cx.alloc(S * Np * 4);
         w.ext[pi] = cx.alloc(tile * Np * 4);
         for (int q = 0; q < 4; ++q) w.lk_ext[pi][q] = cx.alloc(w.lt * Np * 4);
         w.hh[pi] = cx.alloc(2 * Np * 4);
@@ -296,13 +367,20 @@ inline Workspace make_workspace(Ctx& cx, const ProvingKey& pk, size_t tile = 64)
     w.w1 = cx.alloc(n * 4);
     w.w2 = cx.alloc(n * 4);
     w.blind = cx.alloc((m + S + 3 * Lk) * (d.bf + 1) * 4 + n * 4);
-    w.out12 = cx.alloc((m + S + 8) * 12);
+    {   // the largest batch of commitments a phase leaves there: advice (m - 1), lookups (2 Lk), products (S + Lk + 1), the pieces (3)
+        size_t pts = m - 1;
+        if (2 * Lk > pts) pts = 2 * Lk;
+        if (S + Lk + 1 > pts) pts = S + Lk + 1;
+        if (pts < 3) pts = 3;
+        w.out12 = cx.alloc(pts * 12);
+    }
     w.evals = cx.alloc((4 * m + 4 * S + 16) * 4 * 4);
     return w;
 }
 
-// blinding values: uniform 252-bit integers as Montgomery representatives (all below r) -- from the caller's random words when given
-// (a production prover hands over OS randomness: pz_pk_blinding_words says how many), else from a seeded xorshift (tests, benches)
+// blinding values: UNIFORM field elements (as Montgomery representatives: any value below r is one), drawn by rejection from 254-bit
+// candidates (accepted with probability r / 2^254 = 0.756) -- from the caller's random words when given (a production prover hands over
+// OS randomness: pz_pk_info says how many, margin included), else from a seeded xorshift (tests, benches: not zero-knowledge)
 struct Rng {
     uint64_t s;
     const uint64_t* words = nullptr;
@@ -317,15 +395,28 @@ struct Rng {
         s ^= s << 13; s ^= s >> 7; s ^= s << 17;
         return s;
     }
-    void fill(std::vector<uint64_t>& v) {
-        for (size_t i = 0; i < v.size(); ++i) v[i] = next();
-        for (size_t i = 3; i < v.size(); i += 4) v[i] &= 0x0fffffffffffffffULL;
+    void fill(std::vector<uint64_t>& v) {   // v: 4 words per element
+        for (size_t i = 0; i + 3 < v.size(); i += 4) {
+            for (;;) {
+                for (int j = 0; j < 4; ++j) v[i + j] = next();
+                v[i + 3] &= 0x3fffffffffffffffULL;
+                bool below = false;
+                for (int j = 3; j >= 0; --j)
+                    if (v[i + j] != pzh::FR_MOD[j]) {
+                        below = v[i + j] < pzh::FR_MOD[j];
+                        break;
+                    }
+                if (below) break;
+            }
+        }
     }
 };
-// 64-bit words of randomness one proof consumes (blinding rows of the advice / permuted / product columns + the random polynomial)
+// 64-bit words of randomness one proof may consume (blinding rows of the advice / permuted / product columns + the random polynomial):
+// twice the words of the elements drawn -- the rejection sampling takes 1.32 draws per element on average, and a factor 2 over tens of
+// thousands of elements is out of reach of its fluctuations (a caller's array that does run out: PZ_ERR_INVALID, nothing reused)
 inline size_t blinding_words(const ProvingKey& pk) {
     const size_t b = pk.dom.bf + 1, W = pk.st.n_adv + pk.st.n_lk, Lk = pk.st.n_lk, S = pk.n_sets;
-    return 4 * (W * b + 2 * Lk * b + (S + Lk) * (b - 1) + pk.dom.n);
+    return 2 * 4 * (W * b + 2 * Lk * b + (S + Lk) * (b - 1) + pk.dom.n);
 }
 
 // rows [row0, n) of `count` columns (stride n elements) <- random elements
@@ -368,10 +459,13 @@ struct Session {
     ~Session() {
         if (state) pz_shplonk_free(cx.c, state);
     }
+    // phases run in order, each once: a phase is entered only from its predecessor's COMPLETION (done(p) is the last statement of phase
+    // p), so after a phase that failed half-way every later call is refused instead of running on half-built state
     void expect(int p) {
         if (phase != p) PZP_FAIL(PZ_ERR_INVALID, "proof phases out of order");
-        phase = p + 1;
+        phase = -1;   // in progress: re-entering or skipping ahead is refused until done(p)
     }
+    void done(int p) { phase = p + 1; }
     void commit(const pz_bases* b, const uint64_t* t, size_t count, uint64_t* out) {
         uint32_t nw = 0, cb = 0;
         size_t np = 0;
@@ -395,6 +489,7 @@ struct Session {
         commit(pk.bl, d_cols, W, w.out12);
         if (after_launch) after_launch();
         affine(w.out12, W, out_affine);
+        done(0);
     }
     // ---- 2. lookups (one expression each side: theta does not enter).  out: n_lk x 8 each
     void lookups(uint64_t* out_inputs, uint64_t* out_tables) {
@@ -409,6 +504,7 @@ struct Session {
         commit(pk.bl, w.Sp, Lk, w.out12 + Lk * 12);
         affine(w.out12, Lk, out_inputs);
         affine(w.out12 + Lk * 12, Lk, out_tables);
+        done(1);
     }
     // ---- 3. grand products + the vanishing argument's random polynomial.  out: n_sets x 8, n_lk x 8, 8
     void products(const Fr& beta_, const Fr& gamma_, uint64_t* out_z, uint64_t* out_zl, uint64_t* out_random) {
@@ -431,6 +527,7 @@ struct Session {
         affine(w.out12, S, out_z);
         affine(w.out12 + S * 12, Lk, out_zl);
         affine(w.out12 + (S + Lk) * 12, 1, out_random);
+        done(2);
     }
     // ---- 4. quotient.  out: 3 x 8 (the pieces h_0, h_1, h_2)
     void quotient(const Fr& y_, uint64_t* out_h) {
@@ -459,12 +556,21 @@ struct Session {
             PZP_CK(pz_dev_memset(cx.c, w.hh[pi], 0, 2 * Np * 32));
             uint64_t *hg = w.hh[pi], *hp = w.hh[pi] + Np * 4;
             const uint64_t *l0 = pk.l_ext[pi], *llast = pk.l_ext[pi] + Np * 4, *lact = pk.l_ext[pi] + 2 * Np * 4;
+            // the extended forms of key columns [c0, c0 + cnt): resident, or (streamed proving key) re-extended into the tile buffer
+            auto key_tile = [&](const uint64_t* coeff, const uint64_t* resident, size_t res, int which, size_t c0, size_t cnt) -> const uint64_t* {
+                if (c0 + cnt <= res) return resident + c0 * Np * 4;
+                extend(coeff + c0 * n * 4, cnt, w.key_ext[which]);
+                return w.key_ext[which];
+            };
             for (size_t c0 = 0; c0 < m; c0 += tile) {
                 const size_t cnt = m - c0 < tile ? m - c0 : tile;
                 extend(d_cols + c0 * n * 4, cnt, w.ext[pi]);
                 const size_t na = c0 >= A ? 0 : (A - c0 < cnt ? A - c0 : cnt);
-                if (na) PZP_CK(pz_quotient_gate_dev(cx.c, w.ext[pi], 4 * Np, pk.fixed_ext[pi] + c0 * Np * 4, 4 * Np, na, lg, rot, y.v, hg));
-                PZP_CK(pz_quotient_permutation_part_dev(cx.c, w.ext[pi], 4 * Np, pk.sigma_ext[pi] + c0 * Np * 4, 4 * Np, w.z_ext[pi], 4 * Np,
+                if (na)
+                    PZP_CK(pz_quotient_gate_dev(cx.c, w.ext[pi], 4 * Np, key_tile(pk.fixed_coeff, pk.fixed_ext[pi], pk.res_fixed, 0, c0, na), 4 * Np, na,
+                                                lg, rot, y.v, hg));
+                PZP_CK(pz_quotient_permutation_part_dev(cx.c, w.ext[pi], 4 * Np, key_tile(pk.sigma_coeff, pk.sigma_ext[pi], pk.res_sigma, 1, c0, cnt),
+                                                        4 * Np, w.z_ext[pi], 4 * Np,
                                                         (uint32_t)S, (uint32_t)(c0 / CHUNK), (uint32_t)((cnt + CHUNK - 1) / CHUNK), CHUNK, (uint32_t)cnt,
                                                         c0 == 0, lg, rot, bf + 1, l0, llast, lact, beta.v, gamma.v, delta.v, pt.coset_g.v, pt.omega.v,
                                                         y.v, hp));
@@ -477,7 +583,7 @@ struct Session {
                 extend(w.Ap + l0_ * n * 4, cnt, w.lk_ext[pi][1]);
                 extend(w.Sp + l0_ * n * 4, cnt, w.lk_ext[pi][2]);
                 extend(w.Zl + l0_ * n * 4, cnt, w.lk_ext[pi][3]);
-                PZP_CK(pz_quotient_lookup_dev(cx.c, w.lk_ext[pi][0], 4 * Np, pk.fixed_ext[pi] + (A + 1) * Np * 4, w.lk_ext[pi][1], 4 * Np,
+                PZP_CK(pz_quotient_lookup_dev(cx.c, w.lk_ext[pi][0], 4 * Np, pk.table_ext[pi], w.lk_ext[pi][1], 4 * Np,
                                               w.lk_ext[pi][2], 4 * Np, w.lk_ext[pi][3], 4 * Np, (uint32_t)cnt, lg, rot, l0, llast, lact, beta.v, gamma.v,
                                               y.v, hq));
             }
@@ -509,6 +615,7 @@ struct Session {
         }
         commit(pk.bm, pieces, 3, w.out12);
         affine(w.out12, 3, out_h);
+        done(3);
     }
     // ---- 5. evaluations at x and its rotations: ev[f] = [count][points][4] per family of `fams`
     void evaluate(const Fr& x_) {
@@ -539,6 +646,7 @@ struct Session {
             ev[f].resize(fm.count * fm.idx.size() * 4);
             PZP_CK(pz_download(cx.c, ev[f].data(), w.evals, ev[f].size() * 8));
         }
+        done(4);
     }
     // ---- 6. SHPLONK: the rotation sets in prover.py's query_layout order.  out: 8 each
     void open_begin(const Fr& shy, const Fr& shv, uint64_t* out_w1) {
@@ -596,6 +704,7 @@ struct Session {
                                     points.data(), evals_flat.data(), shy.v, shv.v, w.w1, &state));
         commit(pk.bm, w.w1, 1, w.out12);
         affine(w.out12, 1, out_w1);
+        done(5);
     }
     // -> whether the quotient has degree <= 3n - 4 (the top three coefficients of h_2 vanish): false for an unsatisfied witness
     bool open_finish(const Fr& shu, uint64_t* out_w2) {
@@ -608,6 +717,7 @@ struct Session {
         affine(w.out12, 1, out_w2);
         uint64_t top[12];
         PZP_CK(pz_download(cx.c, top, pieces + (3 * n - 3) * 4, 96));
+        done(6);
         for (int i = 0; i < 12; ++i)
             if (top[i]) return false;
         return true;

@@ -40,6 +40,7 @@
 
 struct Job {
     uint64_t enc_bits, k, lb, n_steps, msm_full, polys, pool, ntt_batch, steps, warmup, log_e, seed;
+    uint64_t max_rows, minimum_rows;   // the row budget (paillier_halo2_amd/layout.py RowBudget): rows a column is filled to / calculate_params' argument
     std::vector<uint64_t> n, g, m, r, res, n2;
     uint64_t s_toxic[4], omega[4], omega_inv[4], n_inv[4];
     std::vector<uint64_t> gens;
@@ -54,11 +55,13 @@ static Job read_job(const char* path) {
     size_t got;
     while ((got = fread(buf, 8, 512, f)) > 0) w.insert(w.end(), buf, buf + got);
     fclose(f);
-    if (w.size() < 13 || w[0] != 0x325a50) { fprintf(stderr, "bad job file\n"); exit(2); }
+    if (w.size() < 15 || w[0] != 0x335a50) { fprintf(stderr, "bad job file\n"); exit(2); }
     Job j;
     j.enc_bits = w[1]; j.k = w[2]; j.lb = w[3]; j.n_steps = w[4]; j.msm_full = w[5]; j.polys = w[6]; j.pool = w[7];
     j.ntt_batch = w[8]; j.steps = w[9]; j.warmup = w[10]; j.log_e = w[11]; j.seed = w[12];
-    size_t Ln = j.enc_bits / 64, p = 13;
+    j.max_rows = w[13]; j.minimum_rows = w[14];
+    if (j.max_rows < 8 || j.max_rows > ((uint64_t)1 << j.k) - 7 || j.minimum_rows >= ((uint64_t)1 << j.k)) { fprintf(stderr, "bad row budget\n"); exit(2); }
+    size_t Ln = j.enc_bits / 64, p = 15;
     auto take = [&](std::vector<uint64_t>& v, size_t cnt) { v.assign(w.begin() + p, w.begin() + p + cnt); p += cnt; };
     take(j.n, Ln); take(j.g, Ln); take(j.m, Ln); take(j.r, Ln); take(j.res, 2 * Ln); take(j.n2, 2 * Ln);
     memcpy(j.s_toxic, &w[p], 32); p += 4;
@@ -124,7 +127,7 @@ struct Result {
 
 // one prover: three contexts on `device`, the two-slot pipeline, J.steps timed steps, then the verification
 static void prove(const Job& J, int device, Gate& gate, Result& out) {
-    const size_t Ln = J.enc_bits / 64, L = 2 * Ln, n = (size_t)1 << J.k, rows = n - 10, E = (size_t)1 << J.log_e;
+    const size_t Ln = J.enc_bits / 64, L = 2 * Ln, n = (size_t)1 << J.k, rows = J.max_rows, E = (size_t)1 << J.log_e;
     pz_ctx *ctx, *ctxw, *ctxn;   // commitments / witness / transforms
     CK(pz_init(1, &device, &ctx));
     CK(pz_init(1, &device, &ctxw));
@@ -141,7 +144,10 @@ static void prove(const Job& J, int device, Gate& gate, Result& out) {
     if (memcmp(c_out.data(), J.res.data(), L * 8) != 0) { fprintf(stderr, "ciphertext mismatch\n"); exit(2); }
     if ((size_t)ng + nr + 1 != J.n_steps) { fprintf(stderr, "step count mismatch\n"); exit(2); }
     CK(pz_circuit_cells(0, (uint32_t)Ln, 64, (uint32_t)J.lb, ng, nr, &adv_cells, &lk_cells));
-    const size_t adv_cols = (adv_cells + rows - 1) / rows, lk_cols = (lk_cells + rows - 1) / rows;
+    // configured columns = calculate_params(Some(minimum_rows)): at least the columns a cut at `rows` fills (the rest stay empty)
+    const size_t count_rows = n - J.minimum_rows;
+    auto cols_for = [&](size_t cells) { const size_t a = (cells + rows - 1) / rows, b = (cells + count_rows - 1) / count_rows; return a > b ? a : b; };
+    const size_t adv_cols = cols_for(adv_cells), lk_cols = cols_for(lk_cells);
     void *d_adv[2], *d_lk[2], *d_mod, *d_out_adv, *d_out_full, *d_lagr, *d_pool_f, *d_pool_n, *d_ext;
     for (int s = 0; s < 2; ++s) {
         CK(pz_dev_alloc(ctxw, adv_cols * n * 32, &d_adv[s]));

@@ -104,7 +104,7 @@ int main(int argc, char** argv) {
     pz_dev_free(cx.c, d_g);
     pz_dev_free(cx.c, d_gl);
     const double t_keygen = now_ms();
-    ProvingKey* pk = keygen(cx, st, bl, bm);
+    ProvingKey* pk = keygen(cx, std::move(st), bl, bm);   // st's arrays now live in (or were released by) the key; its scalar fields stay readable
     PZP_CK(pz_sync(cx.c));
     const double keygen_ms = now_ms() - t_keygen;
     Workspace ws = make_workspace(cx, *pk, tile);
@@ -120,7 +120,7 @@ int main(int argc, char** argv) {
     uint64_t* d_mod = cx.alloc(L);
     uint64_t* d_starts = cx.alloc(A + 1);
     PZP_CK(pz_upload(cx.c, d_mod, n2.data(), L * 8));
-    PZP_CK(pz_upload(cx.c, d_starts, st.starts.data(), (A + 1) * 8));
+    PZP_CK(pz_upload(cx.c, d_starts, pk->st.starts.data(), (A + 1) * 8));
     PZP_CK(pz_sync(cx.c));
 
     Out out{fopen(argv[2], "wb")};

@@ -15,6 +15,50 @@ import math
 from dataclasses import dataclass
 
 
+# ---- the row budget of a column (halo2-lib's tester, reached from /root/reference/src/bench.rs:161-171 and src/paillier.rs:167-171) [D]
+BLINDING_FACTORS = 6          # cs.blinding_factors() of halo2-lib's circuits: max(3, the basic gate's 4 rotations) + 2
+MINIMUM_ROWS_BENCH = 20       # bench_builder: builder.calculate_params(Some(20))   
+MINIMUM_ROWS_MOCK = 9         # base_test().run(..): builder.calculate_params(Some(9)) before MockProver::run
+
+
+@dataclass(frozen=True)
+class RowBudget:
+    """Two different row counts shape a halo2-lib circuit, and the reference's two test paths differ in the first:
+    count_rows = 2^k - minimum_rows   what calculate_params(Some(minimum_rows)) divides the cell totals by: the NUMBER of advice /
+                                      lookup-advice columns the circuit is configured with (20 on the bench path, 9 under MockProver);
+    max_rows   = 2^k - unusable_rows  how far a column is FILLED: FlexGateConfig::max_rows = 2^k - cs.minimum_rows(), and
+                                      cs.minimum_rows() = blinding_factors + 3 = 9 -- what assign_with_constraints breaks columns at.
+    With minimum_rows = 20 the configured column count can exceed the columns the cells fill (the last one stays empty: it is still
+    committed, opened and part of the permutation).  Both numbers restate dependency behaviour (halo2-lib v0.4 lineage, SURVEY tag
+    [D]: unpinned); `break_rows` overrides max_rows for a dependency version that fills columns to 2^k - minimum_rows instead."""
+    k: int
+    minimum_rows: int
+    unusable_rows: int
+
+    @property
+    def n(self) -> int:
+        return 1 << self.k
+
+    @property
+    def count_rows(self) -> int:
+        return self.n - self.minimum_rows
+
+    @property
+    def max_rows(self) -> int:
+        return self.n - self.unusable_rows
+
+    def columns_for(self, cells: int, filled: int | None = None) -> int:
+        """configured columns for a stream of `cells` cells of which the fill needs `filled` (default: a plain cut at max_rows)"""
+        used = -(-cells // self.max_rows) if filled is None else filled
+        return max(used, -(-cells // self.count_rows))
+
+
+def row_budget(k: int, minimum_rows: int = MINIMUM_ROWS_BENCH, blinding_factors: int = BLINDING_FACTORS, break_rows: int | None = None) -> RowBudget:
+    unusable = blinding_factors + 3 if break_rows is None else (1 << k) - break_rows
+    assert unusable >= blinding_factors + 1 and minimum_rows >= 0
+    return RowBudget(k, minimum_rows, unusable)
+
+
 def range_check_cells(bits: int, lookup_bits: int):
     """halo2-lib RangeChip::range_check(a, bits): (advice cells, lookup cells)."""
     k = -(-bits // lookup_bits)
@@ -186,7 +230,8 @@ class ProofShape:
 
 
 def encrypt_proof_shape(enc_bits: int, k: int, n_steps: int, limb_bits: int = 64, lookup_bits: int | None = None,
-                        blinding_rows: int = 10, max_degree: int = 4, kind: str = "encrypt", n_steps_g: int | None = None) -> ProofShape:
+                        minimum_rows: int = MINIMUM_ROWS_BENCH, max_degree: int = 4, kind: str = "encrypt", n_steps_g: int | None = None,
+                        blinding_factors: int = BLINDING_FACTORS) -> ProofShape:
     """Column / MSM / NTT counts of one encrypt (or add) proof (SURVEY.md section 3.4's table, made concrete).  n_steps
     counts every mul_mod of the circuit (both chains + the final one); the split between the chains only moves the four
     constant cells of pow_mod_fixed_exp and does not change any count."""
@@ -195,7 +240,7 @@ def encrypt_proof_shape(enc_bits: int, k: int, n_steps: int, limb_bits: int = 64
     Ln = enc_bits // limb_bits
     L = 2 * Ln
     sc = mul_mod_cells(L, limb_bits, lookup_bits)
-    rows = (1 << k) - blinding_rows
+    rb = row_budget(k, minimum_rows, blinding_factors)
     if kind == "encrypt":
         ng = (n_steps - 1) // 2 if n_steps_g is None else n_steps_g
         cc = circuit_cells("encrypt", Ln, limb_bits, lookup_bits, ng, n_steps - 1 - ng)
@@ -204,8 +249,8 @@ def encrypt_proof_shape(enc_bits: int, k: int, n_steps: int, limb_bits: int = 64
         cc = circuit_cells("encrypt_uniform", Ln, limb_bits, lookup_bits, ng, n_steps - 1 - ng)
     else:
         cc = circuit_cells("add", Ln, limb_bits, lookup_bits)
-    A = math.ceil(cc.advice / rows)
-    Lk = math.ceil(cc.lookup / rows)
+    A = rb.columns_for(cc.advice)     # (plain cut; the break-point layout of circuit_structure.columns loses 1-3 rows per column)
+    Lk = rb.columns_for(cc.lookup)
     P = math.ceil((A + Lk + 1) / (max_degree - 2))
     return ProofShape(k=k, lookup_bits=lookup_bits, limbs=L, n_steps=n_steps, cells_per_step=sc.advice,
                       lookups_per_step=sc.lookup, advice_cols=A, lookup_cols=Lk, perm_cols=P, msm_witness=A,

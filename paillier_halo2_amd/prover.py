@@ -51,7 +51,7 @@ class CircuitStructure:
     """what keygen derives from the circuit (INPUT; in the reference the dependency's synthesize / Assembly produce it)"""
     k: int
     lookup_bits: int
-    max_rows: int                  # rows of a column the circuit assigns (halo2-lib: 2^k - minimum_rows)
+    max_rows: int                  # rows a column is filled to (halo2-lib: FlexGateConfig::max_rows = 2^k - cs.minimum_rows(); layout.RowBudget)
     blinding_factors: int          # cs.blinding_factors(): 6 for halo2-lib's 4-rotation gate
     selectors: np.ndarray          # uint8 [n_adv][2^k]  (selectors / map_col / map_row: numpy, or torch tensors already on the device)
     n_lk: int
@@ -59,6 +59,8 @@ class CircuitStructure:
     map_col: np.ndarray            # uint32 [m][2^k]: sigma as the (column, row) every cell maps to; m = n_adv + n_lk + 1
     map_row: np.ndarray
     table: Optional[Sequence[int]] = None      # default: 0 .. 2^lookup_bits - 1, then zeros
+    minimum_rows: Optional[int] = None         # the calculate_params argument the column COUNT came from (layout.RowBudget; informational)
+    n_adv_used: Optional[int] = None           # advice columns the cells fill (<= n_adv: K4's break-point table has n_adv_used + 1 entries)
 
     @property
     def n_adv(self) -> int:
@@ -102,12 +104,25 @@ def _ints_to_dev_mont(eng: Engine, vals: Sequence[int]):
     return t
 
 
+_R3 = FR >> 192                  # the top 64-bit word of r
+
+
 def _random_fr(gen, *shape):
-    """blinding values: uniform 252-bit integers taken as Montgomery representatives (all below r)"""
+    """blinding values: UNIFORM field elements as Montgomery representatives, by rejection from 254-bit candidates (a candidate is kept
+    when its top word is below r's: that drops a 2^-62 fraction of the field -- the values whose top word EQUALS r's -- and nothing else)"""
     torch = _torch()
-    t = torch.randint(-(1 << 63), (1 << 63) - 1, (*shape, 4), dtype=torch.int64, device="cuda", generator=gen)
-    t[..., 3] &= 0x0FFFFFFFFFFFFFFF
-    return t
+    draw = lambda *sh: torch.randint(-(1 << 63), (1 << 63) - 1, (*sh, 4), dtype=torch.int64, device="cuda", generator=gen)
+    t = draw(*shape)
+    t[..., 3] &= 0x3FFFFFFFFFFFFFFF
+    for _ in range(64):
+        bad = t[..., 3] >= _R3
+        nb = int(bad.sum().item())
+        if nb == 0:
+            return t
+        c = draw(nb)
+        c[:, 3] &= 0x3FFFFFFFFFFFFFFF
+        t[bad] = c
+    raise RuntimeError("rejection sampling did not terminate")
 
 
 @dataclass
@@ -148,9 +163,15 @@ class Domain:
 
 
 class ProvingKey:
-    """fixed + permutation polynomials in all three forms, resident in HBM; the SRS tables"""
+    """fixed + permutation polynomials in all three forms, resident in HBM; the SRS tables.
+    ext_resident_cols: how many of the permuted columns' EXTENDED key forms (selector j and sigma j for j < R) stay resident.  None = all of
+    them (halo2's ProvingKey: fixed_cosets / permutation.cosets; at config c2 77 GB); an integer R = the STREAMED proving key: only the
+    coefficient forms of the rest are kept and create_proof re-extends them per tile beside the advice tile they are folded with (R = 0
+    at BASELINE config c5, where the extended key would be 239 GB: DESIGN.md section 6.3).  The proof is byte for byte the same: the tile's
+    values come from the same transform either way.  The lookup table's extended form (one column) is always resident."""
 
-    def __init__(self, eng: Engine, st: CircuitStructure, bases_lagrange: Bases, bases_monomial: Bases, cosets: int = 3):
+    def __init__(self, eng: Engine, st: CircuitStructure, bases_lagrange: Bases, bases_monomial: Bases, cosets: int = 3,
+                 ext_resident_cols: Optional[int] = None):
         torch = _torch()
         self.eng, self.st = eng, st
         self.dom = d = Domain(st.k, st.blinding_factors, cosets)
@@ -189,19 +210,34 @@ class ProvingKey:
         self.fixed_commit = _zeros(F, 12)
         self.sigma_commit = _zeros(m, 12)
         P0 = d.parts[0]
-        self.fixed_ext = [_zeros_cap(F, pt["size"], 4) for pt in d.parts]      # per part of the quotient's domain (Domain._parts)
-        self.sigma_ext = [_zeros_cap(m, pt["size"], 4) for pt in d.parts]
-        for t_, cnt_all, com, ext in ((fixed, F, self.fixed_commit, self.fixed_ext), (sigma, m, self.sigma_commit, self.sigma_ext)):
+        self.streamed = ext_resident_cols is not None and ext_resident_cols < m
+        R = m if not self.streamed else max(0, int(ext_resident_cols))
+        self.ext_resident = (min(R, A), R)                                     # resident extended columns of (selectors, sigma)
+        Rf, Rs = self.ext_resident
+        if not self.streamed:
+            Rf = F                                                             # (resident mode keeps the constants and table columns in the same tensor)
+        self.fixed_ext = [_zeros_cap(Rf, pt["size"], 4) for pt in d.parts]     # per part of the quotient's domain (Domain._parts)
+        self.sigma_ext = [_zeros_cap(Rs, pt["size"], 4) for pt in d.parts]
+        for t_, cnt_all, com, ext, Rx in ((fixed, F, self.fixed_commit, self.fixed_ext, Rf), (sigma, m, self.sigma_commit, self.sigma_ext, Rs)):
             for c0 in range(0, cnt_all, GB):
                 cnt = min(GB, cnt_all - c0)
-                eng.keygen_columns_dev(bases_lagrange, t_[c0].data_ptr(), cnt, 4 * n, st.k, P0["log_e"], M(d.omega), M(d.omega_inv), M(d.n_inv),
-                                       P0["gens"], com[c0].data_ptr(), ext[0][c0].data_ptr(), 4 * P0["size"])
-                for pi in range(1, len(d.parts)):     # the further parts from the coefficient form keygen_columns_dev left in place
-                    pt = d.parts[pi]
-                    eng.ntt_extend_dev(t_[c0].data_ptr(), cnt, 4 * n, ext[pi][c0].data_ptr(), 4 * pt["size"], st.k, pt["log_e"], M(d.omega),
-                                       pt["gens"], None)
+                # (columns, whether their extended forms are kept): a batch that straddles the resident prefix runs as two calls
+                r_here = max(0, min(cnt, Rx - c0))
+                for b0, bc, keep in ((c0, r_here, True), (c0 + r_here, cnt - r_here, False)):
+                    if not bc:
+                        continue
+                    eng.keygen_columns_dev(bases_lagrange, t_[b0].data_ptr(), bc, 4 * n, st.k, P0["log_e"], M(d.omega), M(d.omega_inv), M(d.n_inv),
+                                           P0["gens"], com[b0].data_ptr(), ext[0][b0].data_ptr() if keep else None, 4 * P0["size"])
+                    for pi in range(1, len(d.parts) if keep else 0):     # the further parts from the coefficient form keygen_columns_dev left in place
+                        pt = d.parts[pi]
+                        eng.ntt_extend_dev(t_[b0].data_ptr(), bc, 4 * n, ext[pi][b0].data_ptr(), 4 * pt["size"], st.k, pt["log_e"], M(d.omega),
+                                           pt["gens"], None)
         self.fixed_coeff = fixed
         self.sigma_coeff = sigma
+        # the lookup table on the quotient's domain: one column, always resident (every lookup tile of evaluate_h reads it)
+        self.table_ext = [_zeros(1, pt["size"], 4) for pt in d.parts]
+        for pi, pt in enumerate(d.parts):
+            eng.ntt_extend_dev(fixed[A + 1].data_ptr(), 1, 4 * n, self.table_ext[pi].data_ptr(), 4 * pt["size"], st.k, pt["log_e"], M(d.omega), pt["gens"], None)
         # ---- l_0, l_last, l_active on the extended coset
         u = d.usable
         lrows = _zeros(3, n, 4)
@@ -221,8 +257,9 @@ class ProvingKey:
         return {"fixed": jac(self.fixed_commit), "sigma": jac(self.sigma_commit)}
 
 
-def keygen(eng: Engine, st: CircuitStructure, bases_lagrange: Bases, bases_monomial: Bases, cosets: int = 3) -> ProvingKey:
-    return ProvingKey(eng, st, bases_lagrange, bases_monomial, cosets)
+def keygen(eng: Engine, st: CircuitStructure, bases_lagrange: Bases, bases_monomial: Bases, cosets: int = 3,
+           ext_resident_cols: Optional[int] = None) -> ProvingKey:
+    return ProvingKey(eng, st, bases_lagrange, bases_monomial, cosets, ext_resident_cols)
 
 
 @dataclass
@@ -315,16 +352,24 @@ class Workspace:
     """the per-proof device buffers of create_proof, allocated once per proving key and reused by every proof (at config c2: the
     grand products on the extended domain are 26 GB; everything else is a few GB)"""
 
-    def __init__(self, pk: ProvingKey, tile: int = 64):
+    def __init__(self, pk: ProvingKey, tile: int = 64, lookup_tile: Optional[int] = None):
         d, st = pk.dom, pk.st
         n, N, Lk, S = d.n, d.N, st.n_lk, pk.n_sets
         assert tile % CHUNK == 0
         self.tile = tile
         self.Ap, self.Sp, self.Zl = _zeros_cap(Lk, n, 4, q=8), _zeros_cap(Lk, n, 4, q=8), _zeros_cap(Lk, n, 4, q=8)
         self.Z = _zeros_cap(S, n, 4)
-        lt = min(tile, Lk)
-        self.z_ext = [_zeros_cap(S, pt["size"], 4) for pt in d.parts]
+        lt = min(tile, Lk, lookup_tile or tile)
+        # the grand products on the quotient's domain: ALL sets of one part at once (the chaining lines read z_{j-1} beside z_j); the parts
+        # are worked one after the other, so ONE buffer of the largest part serves them all (at c2: 13 GB instead of 20)
+        big = max(pt["size"] for pt in d.parts)
+        self._z_ext_flat = _zeros_cap(S, big, 4).view(-1)
+        self.z_ext = [self._z_ext_flat[: S * pt["size"] * 4].view(S, pt["size"], 4) for pt in d.parts]
         self.ext = [_zeros(tile, pt["size"], 4) for pt in d.parts]
+        # streamed proving key: the tile of selectors and the tile of sigma columns, re-extended beside the advice tile (one buffer each)
+        if pk.streamed:
+            self._key_tiles = [_zeros(tile, big, 4).view(-1) for _ in range(2)]
+            self.key_ext = [[kt[: tile * pt["size"] * 4].view(tile, pt["size"], 4) for kt in self._key_tiles] for pt in d.parts]
         self.lk_ext = [[_zeros(lt, pt["size"], 4) for _ in range(4)] for pt in d.parts]
         self.hh = [_zeros(2, pt["size"], 4) for pt in d.parts]
         self.hp = [_zeros(pt["size"], 4) for pt in d.parts]
@@ -335,11 +380,13 @@ class Workspace:
         self.w1, self.w2 = _zeros(n, 4), _zeros(n, 4)
 
 
-def create_proof(pk: ProvingKey, cols, tr, seed: int = 0, tile: int = 64, hooks=None, ws: Optional[Workspace] = None,
+def create_proof(pk: ProvingKey, cols, tr, seed: Optional[int] = 0, tile: int = 64, hooks=None, ws: Optional[Workspace] = None,
                  timings: Optional[Dict[str, float]] = None, eng: Optional[Engine] = None) -> Proof:
     """cols: int64 CUDA tensor [m][2^k][4]: the advice columns then the lookup-advice columns as K4 wrote them (rows >= max_rows
     zero); the last column (constants) and the blinding rows are filled here; cols is consumed (it ends up in coefficient form).
     tr: a Transcript (or plain Challenges).  Runs on the engine's stream (bind_torch_stream).
+    seed: of the device generator the blinding values come from (tests and benches want reproducible proofs); None = 64 bits of OS
+    randomness per proof (os.urandom) -- what a caller who needs the proof to be zero-knowledge passes.
     hooks: optional dict of callables name -> f(tensors) applied to intermediate device buffers (the tests' tamper points).
     timings: if given, phase -> milliseconds of wall time (each phase ends with the transcript's synchronising download).
     eng: the context (stream, library workspaces) this proof runs on -- default the key's; a second proof in flight beside this one
@@ -359,6 +406,10 @@ def create_proof(pk: ProvingKey, cols, tr, seed: int = 0, tile: int = 64, hooks=
     assert tuple(cols.shape) == (m, n, 4)
     hooks = hooks or {}
     gen = torch.Generator(device="cuda")
+    if seed is None:
+        import os
+
+        seed = int.from_bytes(os.urandom(8), "little") >> 1
     gen.manual_seed(seed)
     pr = Proof()
     bl, bm = pk.bases_lagrange, pk.bases_monomial
@@ -441,14 +492,24 @@ def create_proof(pk: ProvingKey, cols, tr, seed: int = 0, tile: int = 64, hooks=
         hg, hp = ws.hh[pi][0], ws.hh[pi][1]     # gate lines / permutation lines, folded apart and joined below: one pass over the tiles
         ext = ws.ext[pi]
         l0, llast, lact = (pk.l_ext[pi][i].data_ptr() for i in range(3))
+        Rf, Rs = pk.ext_resident
+
+        def key_tile(coeff, resident, R_, which, c0, cnt):
+            """the extended forms of key columns [c0, c0 + cnt): resident, or (streamed proving key) re-extended into the tile buffer"""
+            if not pk.streamed or c0 + cnt <= R_:
+                return resident[pi][c0].data_ptr()
+            buf = ws.key_ext[pi][which]
+            extend(coeff[c0:c0 + cnt], cnt, buf, pt)
+            return buf.data_ptr()
+
         for c0 in range(0, m, tile):
             cnt = min(tile, m - c0)
             extend(cols[c0:c0 + cnt], cnt, ext, pt)
             na = max(0, min(A, c0 + cnt) - c0)  # advice columns of this tile carry the custom gate
             if na:
-                eng.quotient_gate_dev(ext.data_ptr(), 4 * Np, pk.fixed_ext[pi][c0].data_ptr(), 4 * Np, na, lg, rot, y, hg.data_ptr())
+                eng.quotient_gate_dev(ext.data_ptr(), 4 * Np, key_tile(pk.fixed_coeff, pk.fixed_ext, Rf, 0, c0, na), 4 * Np, na, lg, rot, y, hg.data_ptr())
             set_lo, nsets = c0 // CHUNK, -(-cnt // CHUNK)
-            eng.quotient_permutation_part_dev(ext.data_ptr(), 4 * Np, pk.sigma_ext[pi][c0].data_ptr(), 4 * Np, z_ext.data_ptr(), 4 * Np, S, set_lo,
+            eng.quotient_permutation_part_dev(ext.data_ptr(), 4 * Np, key_tile(pk.sigma_coeff, pk.sigma_ext, Rs, 1, c0, cnt), 4 * Np, z_ext.data_ptr(), 4 * Np, S, set_lo,
                                               nsets, CHUNK, cnt, c0 == 0, lg, rot, bf + 1, l0, llast, lact, beta, gamma, M(DELTA), cg, om, y,
                                               hp.data_ptr())
         # h = hg * y^(permutation lines) + hp, then the lookup lines on top
@@ -461,7 +522,7 @@ def create_proof(pk: ProvingKey, cols, tr, seed: int = 0, tile: int = 64, hooks=
             extend(Ap[l0_:l0_ + cnt], cnt, e_ap, pt)
             extend(Sp[l0_:l0_ + cnt], cnt, e_sp, pt)
             extend(Zl[l0_:l0_ + cnt], cnt, e_zl, pt)
-            eng.quotient_lookup_dev(e_in.data_ptr(), 4 * Np, pk.fixed_ext[pi][A + 1].data_ptr(), e_ap.data_ptr(), 4 * Np, e_sp.data_ptr(), 4 * Np,
+            eng.quotient_lookup_dev(e_in.data_ptr(), 4 * Np, pk.table_ext[pi].data_ptr(), e_ap.data_ptr(), 4 * Np, e_sp.data_ptr(), 4 * Np,
                                     e_zl.data_ptr(), 4 * Np, cnt, lg, rot, l0, llast, lact, beta, gamma, y, hq.data_ptr())
         eng.quotient_finish_dev(hq.data_ptr(), k, pt["log_e"], cg, om)
         # back to coefficients on this part: the quotient modulo X^size - coset_g^size

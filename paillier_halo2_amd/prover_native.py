@@ -69,7 +69,8 @@ def create_proof(key: NativeKey, d_cols: int, tr, seed: int = 0, blinding: Optio
     h = VP()
     adv = z(A + Lk)
     bl = np.ascontiguousarray(blinding, dtype=np.uint64) if blinding is not None else None
-    eng._chk(L.pz_proof_begin(key.handle, VP(d_cols), seed, _p(bl) if bl is not None else None, 0 if bl is None else bl.size, C.byref(h), _p(adv)),
+    # no caller randomness: the library's seeded stream must be asked for by name (pz.h PZ_BLINDING_SEEDED_TEST_STREAM: tests, benches)
+    eng._chk(L.pz_proof_begin(key.handle, VP(d_cols), seed, _p(bl) if bl is not None else None, (1 << 64) - 1 if bl is None else bl.size, C.byref(h), _p(adv)),
              "pz_proof_begin")
     try:
         pr = Proof()

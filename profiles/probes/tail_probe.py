@@ -40,7 +40,7 @@ p64, q64 = rand(64, n), rand(64, n)
 t("kate_division 64 cols @2^17", lambda: eng.poly_div_linear_dev(p64.data_ptr(), 64, 4 * n, n, g7, q64.data_ptr(), 4 * n), per=64, unit="column")
 ev = rand(64)
 t("poly_eval 64 cols @2^17", lambda: eng.poly_eval_dev(p64.data_ptr(), 64, 4 * n, n, g7, ev.data_ptr()), per=64, unit="column")
-rows = n - 10
+rows = n - 9   # layout.row_budget(k).max_rows
 lk = torch.zeros((84, rows, 4), dtype=torch.int64, device="cuda")
 lk[:, :, 0] = torch.randint(0, 1 << 16, (84, rows), dtype=torch.int64, device="cuda", generator=gen)
 eng.fr_convert_dev(lk.data_ptr(), 84 * rows, True)

@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 
 from oracle import pyref as P
-from tests.util import canon_rand_scalars, ints_to_u64x4, walk_dlog_sum, witness_like_canon
+from tests.util import column_rows, canon_rand_scalars, ints_to_u64x4, walk_dlog_sum, witness_like_canon
 
 pytestmark = pytest.mark.gpu
 
@@ -127,7 +127,7 @@ def test_c5_3072bit_k19_column_sample(eng, cref):
 
     enc_bits, k, lb = 3072, 19, 18
     Ln, L = enc_bits // 64, 2 * (enc_bits // 64)
-    rows = (1 << k) - 10
+    rows = column_rows(k)
     nn, g, m, r = P.synth_paillier_inputs(enc_bits, 0x5046)
     arr = lambda x: cref.int_to_limbs(x, Ln)
     c, steps, ng, nr = eng.paillier_encrypt(Ln, arr(nn), arr(g), arr(m), arr(r))
@@ -177,7 +177,7 @@ def test_c2_encrypt_circuit_k17_at_size(eng, cref):
     enc_bits, k, lb = 2048, 17, 16
     Ln, L = enc_bits // 64, 2 * (enc_bits // 64)
     n = 1 << k
-    rows = n - 10
+    rows = column_rows(k)
     nn, g, m, r = P.synth_paillier_inputs(enc_bits, 0x5043)
     res = P.paillier_enc_native(nn, g, m, r)
     arr = lambda x: cref.int_to_limbs(x, Ln)
@@ -244,7 +244,7 @@ def test_c2_uniform_circuit_k17_at_size(eng, cref):
     enc_bits, k, lb = 2048, 17, 16
     Ln, L = enc_bits // 64, 2 * (enc_bits // 64)
     n = 1 << k
-    rows = n - 10
+    rows = column_rows(k)
     nn, g, m, r = P.synth_paillier_inputs(enc_bits, 0x5047)
     res = P.paillier_enc_native(nn, g, m, r)
     arr = lambda x: cref.int_to_limbs(x, Ln)
@@ -301,7 +301,7 @@ def test_c3_add_circuit_k15_whole(eng, cref):
 
     enc_bits, k, lb = 2048, 15, 14
     L = 2 * (enc_bits // 64)
-    rows = (1 << k) - 10
+    rows = column_rows(k)
     rng = random.Random(0x5044)
     nn = P.synth_paillier_inputs(enc_bits, 0x5044)[0]
     c1, c2 = rng.getrandbits(enc_bits), rng.getrandbits(enc_bits)

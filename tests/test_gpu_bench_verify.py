@@ -62,14 +62,17 @@ def test_pipelined_step_equals_serial_and_oracle(c2, cref):
     v = wl.verify_pipelined()
     assert v["verified"] is True, v
     assert v["pipelined_steps_checked"] == 4 and v["messages"] == 3
-    assert v["commitments_compared"] == 4 * (3033 + 84 + wl.counts["msm_full"]) and v["transforms_compared"] == 4 * 5 * 2
+    # the tester's row budget (layout.RowBudget): calculate_params(Some(20)) configures 3034 advice columns, the cells fill 3033 of them
+    assert (wl.adv_cols, wl.lk_cols, wl.rows, wl.row_budget.minimum_rows) == (3034, 84, (1 << 17) - 9, 20)
+    assert v["commitments_compared"] == 4 * (3034 + 84 + wl.counts["msm_full"]) and v["transforms_compared"] == 4 * 5 * 2
     assert len(set(v["commitment_hash_by_message"].values())) == 3     # three different witnesses went through the two slots
     # ... and they are the commitments every box and every caller has produced for this seed (tests/golden/c2_commitment_hashes.json)
     import json
 
     with open(os.path.join(ROOT, "tests", "golden", "c2_commitment_hashes.json")) as f:
         gold = json.load(f)
-    assert gold["seed"] == "0x5043" and v["commitment_hash_by_message"] == gold["commitment_hash_by_message"]
+    assert gold["seed"] == "0x5043" and (gold["advice_cols"], gold["lookup_cols"], gold["minimum_rows"]) == (3034, 84, 20)
+    assert v["commitment_hash_by_message"] == gold["commitment_hash_by_message"]
     vo = bench.oracle_check(wl, lambda s: None)
     assert vo["ok"] is True, vo
 
@@ -103,7 +106,7 @@ def test_prove_c2_at_size_verifies_and_matches_the_python_path(c2):
     out = bench.dropin_device_resident(wl, _args(2, 1, 0x5043), lambda s: None)
     assert "error" not in out, out
     assert out["verified"] is True, out
-    assert out["advice_cols"] == 3033 and out["lookup_cols"] == 84 and out["messages"] == 3
+    assert out["advice_cols"] == 3034 and out["lookup_cols"] == 84 and out["messages"] == 3
     theirs = out["commitment_hash_by_message"]
     assert set(theirs) == {"0", "1", "2"}
     for k_, h_ in theirs.items():

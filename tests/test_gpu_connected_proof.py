@@ -49,8 +49,8 @@ def world(eng, cref):
     ng, nr = m.bit_length() + bin(m).count("1"), nn.bit_length() + bin(nn).count("1")
     mask, total = P.gate_mask_circuit("encrypt", BITS, W, LB, ng, nr)
     starts = layout.break_points(mask, st.max_rows)
-    assert starts.tolist() == st.starts           # the library's break rule == the oracle's restatement
-    d_starts = torch.from_numpy(starts.astype(np.int64)).cuda()
+    assert starts.tolist() == st.starts[: st.info["n_adv_used"] + 1]     # the library's break rule == the oracle's restatement
+    d_starts = torch.from_numpy(np.asarray(st.starts, dtype=np.int64)).cuda()     # n_adv + 1 entries (configured columns past the filled ones are empty)
     arr = lambda v, l: cref.int_to_limbs(v, l)
 
     def witness(res_claimed=res):
@@ -79,7 +79,7 @@ def world(eng, cref):
     from paillier_halo2_amd import circuit_structure as CS
 
     sa = CS.stream_structure("encrypt", BITS, W, LB, m, nn)
-    cs, cs_starts = CS.columns(sa, K, LB, max_rows=st.max_rows, blinding_factors=st.blinding_factors)
+    cs, cs_starts = CS.columns(sa, K, LB, blinding_factors=st.blinding_factors)
     assert cs_starts.tolist() == st.starts and np.array_equal(cs.selectors, st.selectors) and cs.n_lk == st.n_lk
     assert sorted(cs.constants) == sorted(st.constants)
     W_ = st.n_adv + st.n_lk
@@ -331,6 +331,49 @@ def test_connected_proof_many_tiles_and_sets(eng, cref):
         wl.release()
 
 
+def test_streamed_proving_key_proves_byte_for_byte_the_same(eng, cref):
+    """the STREAMED proving key (prover.ProvingKey(ext_resident_cols = R): only the coefficient forms of the fixed / sigma columns stay in
+    HBM beyond the first R columns, create_proof re-extends them per 64-column tile beside the advice tile -- the memory plan BASELINE
+    config c5 needs) at a 1024-bit key, k = 16 (16 tiles, 511 grand products): verifying key, every commitment
+    and every evaluation of the proof are BYTE FOR BYTE those of the resident key, fully streamed (R = 0), with a resident prefix on a
+    tile boundary (R = 128) and off it (R = 100: the straddling tile is re-extended whole); and the streamed proof verifies."""
+    import torch
+
+    import bench_connected
+
+    srs, ref, ref_vk, key_gb = None, None, None, {}
+    for R_ in (None, 0, 128, 100):
+        wl = bench_connected.ConnectedWorkload(eng, torch, 1024, 16, 0x5043, pipeline=False, srs=srs, streamed_key=R_)
+        try:
+            if srs is None:
+                srs = (wl.bl, wl.bm, wl.s_tox)
+                wl.own_srs = False                   # the bases outlive this workload: freed at the end of the test
+            assert wl.pk.streamed == (R_ is not None) and wl.memory_gb["proving_key_streamed"] == (R_ is not None)
+            key_gb[R_] = wl.memory_gb["of_which_extended_forms"]
+            pr = wl.step(timed=False)
+            torch.cuda.synchronize()
+            vk = wl.pk.vk_commitments()
+            if ref is None:
+                ref, ref_vk = pr, vk
+                assert pr.h_degree_ok
+            else:
+                assert all(np.array_equal(vk[f], ref_vk[f]) for f in ("fixed", "sigma"))
+                assert sorted(pr.commitments) == sorted(ref.commitments) and sorted(pr.evals) == sorted(ref.evals)
+                for f in ref.commitments:
+                    assert np.array_equal(pr.commitments[f], ref.commitments[f]), (R_, "commitment", f)
+                for f in ref.evals:
+                    assert np.array_equal(pr.evals[f], ref.evals[f]), (R_, "evaluation", f)
+                assert pr.h_degree_ok
+                if R_ == 0:
+                    v = wl.verify(cref)
+                    assert v["verified"] is True, v
+        finally:
+            wl.release()
+    assert key_gb[0] == 0.0 and 0 < key_gb[100] < key_gb[128] < key_gb[None]
+    srs[0].free()
+    srs[1].free()
+
+
 def test_c2_structure_and_witness_agree_at_size(eng, cref):
     """config c2 itself (2048-bit n, k = 17: 3.97 x 10^8 advice cells in 3033 break-point columns, 1.1 x 10^7 lookup cells in 84): the
     circuit structure the product generates and the witness K3 -> K4 writes describe the SAME circuit -- every one of sigma's
@@ -348,7 +391,7 @@ def test_c2_structure_and_witness_agree_at_size(eng, cref):
     sa = CS.stream_structure("encrypt", bits, 64, lb, m, nn)
     cs, starts = CS.columns(sa, k, lb)
     A, Lk, M_ = cs.n_adv, cs.n_lk, cs.m
-    assert (A, Lk) == (3033, 84) and sa.n_cells == eng.circuit_cells(0, Ln, 64, lb, sa.n_steps_g, sa.n_steps_r)[0]
+    assert (A, cs.n_adv_used, Lk) == (3034, 3033, 84) and sa.n_cells == eng.circuit_cells(0, Ln, 64, lb, sa.n_steps_g, sa.n_steps_r)[0]
     lim = lambda x, l: consts.int_to_limbs(x, l)
     n_steps = sa.n_steps_g + sa.n_steps_r + 1
     d_steps = torch.zeros((n_steps, 4, 2 * Ln), dtype=torch.int64, device="cuda")
@@ -420,7 +463,7 @@ def test_library_stepper_is_the_same_prover(eng, cref, world):
     import ctypes as C
 
     import paillier_halo2_amd as pz
-    from paillier_halo2_amd import consts, prover, prover_native
+    from paillier_halo2_amd import _lib, consts, prover, prover_native
 
     pk = world["pk"]
     key = prover_native.NativeKey(eng, pk.st, pk.bases_lagrange, pk.bases_monomial, tile=8)
@@ -458,9 +501,11 @@ def test_library_stepper_is_the_same_prover(eng, cref, world):
         cols = world["witness"]()
         h = VP()
         adv = np.zeros((pk.st.n_adv + pk.st.n_lk, 8), dtype=np.uint64)
-        assert L_.pz_proof_begin(key.handle, VP(cols.data_ptr()), 1, None, 0, C.byref(h), ptr(adv)) == 0
+        SEEDED = C.c_size_t((1 << 64) - 1)             # pz.h PZ_BLINDING_SEEDED_TEST_STREAM: the deterministic stream is asked for by name
+        assert L_.pz_proof_begin(key.handle, VP(cols.data_ptr()), 1, None, 0, C.byref(h), ptr(adv)) == _lib.PZ_ERR_INVALID   # NULL blinding without it
+        assert L_.pz_proof_begin(key.handle, VP(cols.data_ptr()), 1, None, SEEDED, C.byref(h), ptr(adv)) == 0
         h2 = VP()
-        assert L_.pz_proof_begin(key.handle, VP(cols.data_ptr()), 1, None, 0, C.byref(h2), ptr(adv)) != 0      # one proof per key at a time
+        assert L_.pz_proof_begin(key.handle, VP(cols.data_ptr()), 1, None, SEEDED, C.byref(h2), ptr(adv)) != 0      # one proof per key at a time
         assert L_.pz_pk_free(key.handle) != 0
         out3 = np.zeros((3, 8), dtype=np.uint64)
         five = Mf(5)
@@ -468,9 +513,71 @@ def test_library_stepper_is_the_same_prover(eng, cref, world):
         a_, b_ = np.zeros((pk.st.n_lk, 8), dtype=np.uint64), np.zeros((pk.st.n_lk, 8), dtype=np.uint64)
         not_canonical = np.full(4, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
         assert L_.pz_proof_lookups(h, ptr(not_canonical), ptr(a_), ptr(b_)) != 0
+        # sticky failure (pz.h: after any error only pz_proof_free is valid): the out-of-order phase above has voided the proof, so even
+        # the phase that WAS next is refused now instead of running on half-built state
+        assert L_.pz_proof_lookups(h, ptr(five), ptr(a_), ptr(b_)) == _lib.PZ_ERR_INVALID
         assert L_.pz_proof_free(h) == 0
+        # two threads race pz_proof_begin on ONE key (pz.h: entry points may be called from any thread): exactly one claims it
+        import threading
+
+        for _round in range(4):
+            cols_t = [world["witness"](), world["witness"]()]
+            hs, rcs = [VP(), VP()], [None, None]
+            advs = [np.zeros_like(adv), np.zeros_like(adv)]
+            gate = threading.Barrier(2)
+
+            def racer(i):
+                gate.wait()
+                rcs[i] = L_.pz_proof_begin(key.handle, VP(cols_t[i].data_ptr()), 1, None, SEEDED, C.byref(hs[i]), ptr(advs[i]))
+
+            th = [threading.Thread(target=racer, args=(i,)) for i in range(2)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            assert sorted(rcs) == sorted([0, _lib.PZ_ERR_INVALID]), rcs
+            assert L_.pz_proof_free(hs[rcs.index(0)]) == 0
         # ... and the key serves the next proof
         pr3 = prover_native.create_proof(key, world["witness"]().data_ptr(), world["ch"], seed=9)
         assert _verify(cref, world, pr3) == (True, True, True)
     finally:
         key.free()
+
+
+def test_stepper_shape_with_many_lookup_columns(eng, cref):
+    """the stepper's commitment staging buffer was sized (m + S + 8) points while the lookups phase writes 2 n_lk --
+    more once n_lk > 3 n_adv + 19.  pz_pk_create accepts any n_adv, n_lk >= 1, so such a shape must prove without touching memory it
+    does not own: one gate-free advice column, 30 lookup columns of in-table values (k = 6), identity permutation."""
+    import torch
+
+    from paillier_halo2_amd import prover, prover_native
+
+    k, lb, A, Lk = 6, 3, 1, 30
+    n, m = 1 << k, A + Lk + 1
+    rng = random.Random(0x6c6b)
+    F = lambda v: cref.fr_ints_to_mont([v % R])[0]
+    d_g = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    d_gl = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    eng.srs_setup_g1_dev(k, F(rng.randrange(2, R)), F(P.fr_omega(k)), d_g.data_ptr(), d_gl.data_ptr())
+    eng.sync()
+    bl, bm = eng.load_bases_dev(d_gl.data_ptr(), n), eng.load_bases_dev(d_g.data_ptr(), n)
+    ident_c = np.repeat(np.arange(m, dtype=np.uint32), n).reshape(m, n)
+    ident_r = np.tile(np.arange(n, dtype=np.uint32), m).reshape(m, n)
+    cs = prover.CircuitStructure(k=k, lookup_bits=lb, max_rows=n - 9, blinding_factors=6, selectors=np.zeros((A, n), dtype=np.uint8), n_lk=Lk,
+                                 constants=[0, 1], map_col=ident_c, map_row=ident_r)
+    key = prover_native.NativeKey(eng, cs, bl, bm, tile=2)
+    try:
+        assert 2 * Lk > (m - 1) + key.n_sets + 8 - 1            # the shape the old sizing could not hold
+        vals = np.zeros((m, n, 4), dtype=np.uint64)
+        lk = [[rng.randrange(1 << lb) for _ in range(n - 9)] + [0] * 9 for _ in range(Lk)]
+        for j in range(Lk):
+            vals[A + j] = cref.fr_ints_to_mont(lk[j])
+        for seed in (1, 2):
+            cols = torch.from_numpy(vals.view(np.int64)).cuda()
+            ch = prover.Challenges(*(rng.randrange(2, R) for _ in range(8)))
+            pr = prover_native.create_proof(key, cols.data_ptr(), ch, seed=seed)
+            eng.sync()                                            # PZ_ERR_ASYNC would surface here
+            assert pr.h_degree_ok and pr.commitments["perm_inputs"].shape == (Lk, 8) and pr.commitments["perm_tables"].shape == (Lk, 8)
+            assert not np.array_equal(pr.commitments["perm_inputs"], pr.commitments["perm_tables"])
+    finally:
+        key.free()
+        bl.free()
+        bm.free()

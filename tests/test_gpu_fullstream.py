@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 from oracle import pyref as P
+from tests.util import column_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -45,7 +46,7 @@ def _stream_to_host(torch, d_buf, ncols, n, rows, total):
 def _circuit_on_device(eng, cref, torch, enc_bits, k, lb, seed):
     Ln, L = enc_bits // 64, 2 * (enc_bits // 64)
     n = 1 << k
-    rows = n - 10
+    rows = column_rows(k)
     nn, g, m, r = P.synth_paillier_inputs(enc_bits, seed)
     res = P.paillier_enc_native(nn, g, m, r)
     arr = lambda x: cref.int_to_limbs(x, Ln)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import pyref as P
-from tests.util import H, load_golden, steps_digest_arr, steps_digest_ints
+from tests.util import column_rows, H, load_golden, steps_digest_arr, steps_digest_ints
 
 pytestmark = pytest.mark.gpu
 
@@ -381,6 +381,7 @@ def test_encrypt_batch_beyond_residency(eng, cref, monkeypatch, cap_kib):
     multiplier roles are handed out by arrival, so no multiplier can be resident ahead of its squarer whatever the dispatch order.
     cap_kib = 256: the hand-off area capped at 256 KiB (test hook) so the same batch runs as 50 launches sharing one squares buffer."""
     if cap_kib:
+        monkeypatch.setenv("PZ_K3_TEST_HOOKS", "1")        # the hooks are honoured only with this set (and read once per call)
         monkeypatch.setenv("PZ_K3_HANDOFF_CAP_KIB", str(cap_kib))
     Ln, B = 2, 1600
     rng = random.Random(0x5200 + cap_kib)
@@ -410,8 +411,12 @@ def test_k3_bounded_wait_reports_internal(eng, cref, monkeypatch):
     Ln = 2
     n, g, m, r = P.synth_paillier_inputs(128, 0x5300, standard_g=False)
     arr = lambda x: cref.int_to_limbs(x, Ln)
+    # a stray PZ_K3_* variable without PZ_K3_TEST_HOOKS=1 changes nothing (a deployment must not trip over a test hook)
     monkeypatch.setenv("PZ_K3_TEST_NO_PUBLISH", "1")
     monkeypatch.setenv("PZ_K3_SPIN_LIMIT", "3000")
+    c_ok, _, _, _ = eng.paillier_encrypt(Ln, arr(n), arr(g), arr(m), arr(r))
+    assert cref.limbs_to_int(c_ok[0]) == P.paillier_enc_native(n, g, m, r)
+    monkeypatch.setenv("PZ_K3_TEST_HOOKS", "1")
     with pytest.raises(pz.PzError) as ei:
         eng.paillier_encrypt(Ln, arr(n), arr(g), arr(m), arr(r))
     assert ei.value.status == _lib.PZ_ERR_INTERNAL
@@ -707,7 +712,7 @@ def test_end_to_end_columns_and_commitments(eng, cref):
 
     nn, g, m, r = P.synth_paillier_inputs(128, 0x6001, standard_g=False)
     Ln, L, lb, k = 2, 4, 9, 10
-    rows = (1 << k) - 10
+    rows = column_rows(k)
     arr = lambda x: cref.int_to_limbs(x, Ln)
     c, steps, ng, nr = eng.paillier_encrypt(Ln, arr(nn), arr(g), arr(m), arr(r))
     tot = int(ng[0]) + int(nr[0]) + 1

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import pyref as P
+from tests.util import column_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -243,7 +244,7 @@ def test_quotient_of_real_witness_columns(eng, cref):
     _, steps, ng, nr = eng.paillier_encrypt(Ln, arr(nn), arr(g), arr(m), arr(r))
     tot = int(ng[0]) + int(nr[0]) + 1
     adv_n, lk_n = eng.witness_cells_per_step(L, 64, lb)
-    per_col = (n - 10) // adv_n   # whole mul_mod blocks per column: halo2-lib never splits a gate across columns
+    per_col = column_rows(k) // adv_n   # whole mul_mod blocks per column: halo2-lib never splits a gate across columns
     assert per_col >= 1
     ncols = 5
     use = ncols * per_col
@@ -348,7 +349,7 @@ def test_params_kzg_file_to_commitments(eng, cref, tmp_path):
     assert eng.g1_check_dev(bad.data_ptr(), n) == 2
 
 
-@pytest.mark.parametrize("rows,bits,ncols", [(1, 3, 1), (50, 4, 2), (1000, 8, 3), (4086, 11, 2), ((1 << 17) - 10, 16, 2)])
+@pytest.mark.parametrize("rows,bits,ncols", [(1, 3, 1), (50, 4, 2), (1000, 8, 3), (4086, 11, 2), (column_rows(17), 16, 2)])
 def test_lookup_permute_and_product_vs_oracle(eng, cref, rows, bits, ncols):
     """permute_expression_pair (counting sort) and the lookup product vs the oracle's sort + BTreeMap restatement;
     table = {0 .. 2^bits - 1} zero-padded, as halo2-lib's RangeChip lays it out"""
@@ -468,7 +469,7 @@ def test_lookup_argument_on_real_witness_digits(eng, cref):
     nn, g, m, r = P.synth_paillier_inputs(128, 0x5042, standard_g=False)
     Ln, L, k = 2, 4, 12
     lb, n = k - 1, 1 << k
-    rows = n - 10
+    rows = column_rows(k)
     arr = lambda x: cref.int_to_limbs(x, Ln)
     _, steps, ng, nr = eng.paillier_encrypt(Ln, arr(nn), arr(g), arr(m), arr(r))
     tot = int(ng[0]) + int(nr[0]) + 1

@@ -8,6 +8,13 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+def column_rows(k):
+    """rows a column of the circuit is filled to -- the row budget's max_rows (paillier_halo2_amd/layout.py RowBudget: 2^k - 9)"""
+    from paillier_halo2_amd import layout
+
+    return layout.row_budget(k).max_rows
+
+
 def load_golden(name):
     with open(os.path.join(GOLDEN, name)) as f:
         return json.load(f)
