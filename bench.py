@@ -3,8 +3,12 @@
 
 Metric (BASELINE.json): Paillier-encrypt proofs/s (2048-bit n, k=17); MSM achieved HBM GB/s vs peak.
 
-A "step" is ONE pass of the hot path of ONE encrypt proof at config c2 (2048-bit n, k=17,
-lookup_bits=16, limb_bits=64), inputs resident in HBM:
+Since round 6 a "step" is ONE CONNECTED PROOF at config c2 (2048-bit n, k=17, lookup_bits=16, limb_bits=64) -- the whole create_proof
+dataflow on the proof's own data, checked after the timed loop as the verifier would (connected_line, bench_connected.py; BASELINE.json
+config 2: "full KZG proof at k=17").  Rounds 1-5's headline -- the HOT PATH ONLY -- is the `hot_path_only` leg of the same line
+(hot_path_line; `--hot-path-headline` makes it `value` again):
+
+A hot-path step is ONE pass of the hot path of ONE encrypt proof at config c2, inputs resident in HBM:
     K3  witness trace   g^m * r^n mod n^2, ~6145 mul_mod steps (pz_paillier_encrypt_dev)
     K1  commitments     A advice-column MSMs (short witness scalars) + Lk lookup-column MSMs
                         + the full-width MSMs of the lookup / permutation / quotient / opening phases
@@ -822,7 +826,25 @@ class _stdout_to_stderr:
         return False
 
 
-def cpu_baseline(shape, n_steps, enc_bits, k, log, check_wl=None):
+def connected_cpu_counts(c):
+    """what halo2's CPU create_proof does for ONE connected proof of the shape `c` (ConnectedWorkload.counts()), in the units the port is
+    timed in: MSMs, 2^k and 2^(k+2) transforms (halo2 extends to the 4n-point coset), and the field multiplications of the phases that are
+    plain field arithmetic (counted per row from the formulas of halo2's permutation / lookup / evaluation / multiopen code; an estimate of
+    the multiplication COUNT, priced with the measured multiplication rate)"""
+    A, Lk, m, S, n = c["advice_cols"], c["lookup_cols"], c["permutation_cols"], c["permutation_sets"], c["n"]
+    F = A + 2
+    evaluations = 4 * A + (Lk + 1) + F + m + 3 * S + 2 * Lk + 2 * Lk + Lk + 2
+    mults = {
+        "grand_products": n * (5 * m + 4 * S) + n * 12 * Lk,            # numerator / denominator terms, batch inversion, prefix products
+        "evaluate_h": 4 * n * (3 * A + 4 * m + 6 * S + 15 * Lk),         # gate, permutation, chaining / boundary and lookup lines on the 4n coset
+        "evaluations": evaluations * n,                                  # Horner at x and its rotations
+        "multiopen": (c["polys_opened"] + 24) * n,                       # SHPLONK's folds and the divisions by the sets' vanishing polynomials
+    }
+    return {"msm_witness": A + Lk, "msm_full": c["msm_full"], "ntt_n": A + 4 * Lk + S, "ntt_4n": A + 4 * Lk + S + 1, "evaluations": evaluations,
+            "field_mults": mults}
+
+
+def cpu_baseline(shape, n_steps, enc_bits, k, log, check_wl=None, connected=None):
     """The C restatement (oracle/pz_oracle.c, kind 'port') timed on this host's cores on a bounded
     sample of the same workload, extrapolated with the per-proof counts of `shape`.  This leg is the ONE place of bench.py that
     touches oracle/: besides the timing it runs the checker (`oracle_check`) on the serial reference verify_pipelined kept in
@@ -876,8 +898,20 @@ def cpu_baseline(shape, n_steps, enc_bits, k, log, check_wl=None):
     t = time.time()
     rc, res, steps = cref.pow_mod_trace(L, nn * nn, g, e, L // 2)
     t_step = (time.time() - t) / max(1, len(steps))
-    per_proof = (shape.msm_full * t_msm_full + (shape.msm_witness + shape.msm_lookup) * t_msm_wit
-                 + shape.polys * (t_ntt + t_ntt_ext) + n_steps * t_step)
+    tail = None
+    if connected is None:
+        per_proof = (shape.msm_full * t_msm_full + (shape.msm_witness + shape.msm_lookup) * t_msm_wit
+                     + shape.polys * (t_ntt + t_ntt_ext) + n_steps * t_step)
+    else:
+        # ONE CONNECTED PROOF on the CPU: the same kernels at the connected proof's counts + the field-arithmetic phases priced with this
+        # host's measured multiplication rate (all threads, the way halo2's parallelize() splits them)
+        cc = connected_cpu_counts(connected)
+        rate = cref.fr_mul_rate()
+        tail = {"field_mults_per_proof": cc["field_mults"], "field_mults_per_s_all_threads": rate,
+                "seconds_per_proof": {k_: v_ / rate for k_, v_ in cc["field_mults"].items()}}
+        per_proof = (cc["msm_full"] * t_msm_full + cc["msm_witness"] * t_msm_wit + cc["ntt_n"] * t_ntt + cc["ntt_4n"] * t_ntt_ext
+                     + n_steps * t_step + sum(cc["field_mults"].values()) / rate)
+        tail["counts"] = {k_: v_ for k_, v_ in cc.items() if k_ != "field_mults"}
     checker = None
     if check_wl is not None:
         try:
@@ -895,6 +929,10 @@ def cpu_baseline(shape, n_steps, enc_bits, k, log, check_wl=None):
                    "steps single-thread (%.1f us each); extrapolated with the per-proof counts in config"
                    % (r_full, k, t_msm_full, r_wit, k, t_msm_wit, r_ntt, k, t_ntt, r_ext, k + 2, t_ntt_ext, len(steps), t_step * 1e6)),
         "sample_cpu_seconds": r_full * t_msm_full + r_wit * t_msm_wit + r_ntt * t_ntt + r_ext * t_ntt_ext + len(steps) * t_step,
+        "scope": ("one connected proof as halo2's CPU create_proof runs it: commitments, 2^k and 4n-coset transforms, the witness trace, and the "
+                  "grand-product / evaluate_h / evaluation / multiopen phases as field-multiplication counts priced with this host's measured rate "
+                  "(keygen, the transcript and permute_expression_pair's sort omitted)") if connected is not None else "the hot path's kernels only",
+        "connected_tail": tail,
     }
 
 
@@ -1110,124 +1148,16 @@ def stub_workload(args):
         dist.destroy_process_group()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c2u", "c3", "c5", "msm22", "stub"],
-                    help="c2: encrypt proof hot path (headline); c2u: the same key size through the uniform-shape circuit (g^m over all message bits in circuit, SURVEY 8f rank 4); c3: homomorphic-add circuit at --k 15; msm22: one sharded MSM")
-    ap.add_argument("--k", type=int, default=17)
-    ap.add_argument("--enc-bits", type=int, default=2048)
-    ap.add_argument("--scale", type=float, default=1.0, help="fraction of the per-proof MSM/NTT counts (debug only; "
-                    "any value != 1 marks the line as not comparable)")
-    ap.add_argument("--log-n", type=int, default=22, help="msm22 workload: log2 of the MSM size")
-    ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5043,
-                    help="base seed of the synthetic key / message (rank r uses seed + r); default = SURVEY section 8d's c2 seed")
-    ap.add_argument("--lookup-bits", type=int, default=None, help="RangeChip lookup bits (default k - 1, the reference's pattern)")
-    ap.add_argument("--msm-scalars", default="uniform", choices=["uniform", "witness"],
-                    help="msm22 workload: uniform scalars, or SURVEY section 8d's witness-like mix (60%% < 2^16, 30%% < 2^64, 10%% < 2^135)")
-    ap.add_argument("--parallel", default="replicas", choices=["replicas", "columns"],
-                    help="N > 1: independent proofs per GPU (weak scaling, the default and the headline) or ONE proof whose "
-                         "columns are split over the ranks with an all-gather of the commitments (strong scaling)")
-    ap.add_argument("--msm-split", default="points", choices=["windows", "points"],
-                    help="msm22 workload: shard point ranges across the ranks (default: measured / emulated to scale better, "
-                         "DESIGN.md section 8) or Pippenger windows (north_star's split)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-dropin", action="store_true", help="skip the host-pointer (drop-in binding) measurement")
-    ap.add_argument("--no-body", action="store_true", help="skip the second timed loop (hot path + the prover steps after it)")
-    ap.add_argument("--emulate-world", type=int, default=0, help="msm22 workload on ONE GPU: run each of W ranks' shares in turn, "
-                    "print per-share stage times and the predicted W-GPU efficiency for both splits")
-    ap.add_argument("--emulate-ranks", type=int, default=0, help="msm22 workload (and, with --parallel columns, a c2 column batch) on ONE GPU: this "
-                    "process plays every rank 0..W-1 of a world of W in turn -- rank r's exact code path (its point / window / column range, "
-                    "offsets, padded gather slices) -- through the real process group of one rank (use with --force-dist: backend nccl = RCCL); "
-                    "every rank's folded / gathered result must equal the single-call result")
-    ap.add_argument("--no-verify", action="store_true", help="skip the output check of the pipelined step after the timed loop (the line then says verified: null)")
-    ap.add_argument("--no-fresh-key", action="store_true", help="skip the third timed loop (keygen per message inside the timed region)")
-    ap.add_argument("--no-c2u", action="store_true", help="default c2 run only: skip the uniform-shape circuit's line (a second workload after the main one)")
-    ap.add_argument("--no-tail", action="store_true", help="skip the (untimed) measurement of the prover steps after the hot path")
-    ap.add_argument("--force-dist", action="store_true", help="with --gpus 1: still start through torch.distributed.run, create the process group "
-                    "(backend nccl = RCCL) and run every collective of the N > 1 path on the one rank (all_gather_into_tensor + device fold of msm22, "
-                    "the commitment all-gather of --parallel columns, the barriers and the MAX all-reduce of the timing)")
-    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo only with --workload stub)")
-    args = ap.parse_args()
-
-    # typed as `python bench.py --gpus N` (not pre-launched by torch.distributed.run): become the launcher.  Nothing above
-    # this line has touched the GPU (numpy only), and the ranks are CHILD processes -- never an exec of this one
-    if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
-        sys.exit(self_launch(args.gpus, sys.argv[1:]))
-    if args.workload == "stub":
-        return stub_workload(args)
-
+def hot_path_line(args, R):
+    """the HOT PATH ONLY (K3 -> K4 -> K1 over the proof's own columns + K2, the later phases' commitments / transforms over
+    pool scalars): rounds 1-5's headline, now reported under `hot_path_only` beside the connected proof (and still the whole line of
+    --workload c3 and of --hot-path-headline).  -> the JSON dict on rank 0, None elsewhere"""
     import torch
     import torch.distributed as dist
 
-    import paillier_halo2_amd as pz
     from paillier_halo2_amd import engine as E
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
-    torch.cuda.set_device(local)
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)  # launched by torch.distributed.run
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        with _stdout_to_stderr():
-            dist.init_process_group(args.backend or "nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-            dist.barrier()   # the communicator comes up here (and says so), not inside a timed region
-    log = (lambda s: print("[bench] " + s, file=sys.stderr, flush=True)) if rank == 0 else (lambda s: None)
-
-    eng = pz.Engine(local)
-    eng.bind_torch_stream()  # a real stream, current for torch too: the event waits of the pipeline order against it
-    # multiplier issue peak of this device, measured live (8 independent mads per lane and iteration)
-    from paillier_halo2_amd import probe   # libpz_probe.so: measurement only, outside the product ABI
-
-    mad_peak = max(8192 * 256 * 1024 * 8 / (probe.ubench_mad_indep(local, 8192, 1024) * 1e-3) / 1e12 for _ in range(3))
-
-    def barrier():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    if args.workload == "msm22":
-        from paillier_halo2_amd import dist as pzd
-
-        if args.emulate_ranks > 1:
-            em = pzd.emulate_ranks_msm(eng, torch, dist if use_dist else None, args.emulate_ranks, args.log_n, args.msm_split, log)
-            em_cols = None
-            if args.parallel == "columns":     # the commitment all-gather of column-parallel proving, 37 full-width columns of 2^14 rows
-                kk, nc = 14, 37
-                g_ = torch.Generator(device="cuda")
-                g_.manual_seed(7)
-                d_c = torch.randint(-(1 << 63), (1 << 63) - 1, (nc, 1 << kk, 4), dtype=torch.int64, device="cuda", generator=g_)
-                d_c[:, :, 3] &= 0x0FFFFFFFFFFFFFFF
-                d_bb = torch.zeros((1 << kk, 8), dtype=torch.int64, device="cuda")
-                eng.g1_fixed_base_mul_dev(d_c[0].data_ptr(), 1 << kk, d_bb.data_ptr())
-                tb_ = eng.load_bases_dev(d_bb.data_ptr(), 1 << kk)
-                em_cols = pzd.emulate_ranks_columns(eng, torch, dist if use_dist else None, args.emulate_ranks, tb_, d_c, nc, 1 << kk, log)
-                tb_.free()
-            res = {"metric": "rank emulation of the sharded MSM: every rank's code path on one GPU", "value": 1.0 if em["all_equal"] and (em_cols is None or em_cols["all_equal"]) else 0.0,
-                   "unit": "all ranks equal the single-call result", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": None, "higher_is_better": True,
-                   "scaling": "strong", "vs_baseline": None, "dtype": "u32 limbs (254-bit modular integers)", "data": "synthetic",
-                   "config": {"workload": "c4 rank emulation: 2^%d-point MSM, world %d, %s split" % (args.log_n, args.emulate_ranks, args.msm_split)},
-                   "emulate_ranks": em, "emulate_ranks_columns": em_cols}
-        elif args.emulate_world > 1:
-            res = pzd.emulate_sharded_msm(eng, torch, args.emulate_world, args.log_n, args.steps, args.warmup, log, scalars=args.msm_scalars,
-                                          share_window_bits=int(os.environ.get("PZ_SHARE_WINDOW_BITS", "0")))
-        else:
-            res = pzd.bench_sharded_msm(eng, torch, dist if use_dist else None, rank, world, args.log_n, args.steps,
-                                        args.warmup, barrier, log, split=args.msm_split, scalars=args.msm_scalars)
-        if rank == 0:
-            res["rccl_ranks"] = dist.get_world_size() if use_dist else 1
-            res["backend"] = dist.get_backend() if use_dist else None
-            res["config"]["env_switches"] = env_switches()
-            print(json.dumps(res))
-        if use_dist:
-            dist.destroy_process_group()
-        return
-
+    rank, world, use_dist, log, eng, mad_peak, barrier = R.rank, R.world, R.use_dist, R.log, R.eng, R.mad_peak, R.barrier
     t0 = time.time()
     if args.workload == "c3" and args.k == 17:
         args.k = 15
@@ -1240,7 +1170,8 @@ def main():
     wl = ProofWorkload(eng, torch, args.enc_bits, args.k, seed=args.seed + (0 if colpar else rank), scale=args.scale,
                        pool=int(os.environ.get("PZ_BENCH_POOL", "256")),   # columns per full-width commitment call (tuning only)
                        lookup_bits=args.lookup_bits, shard=(rank, world) if colpar else (0, 1), dist=dist if (colpar and use_dist) else None,
-                       circuit="add" if args.workload == "c3" else "encrypt_uniform" if args.workload == "c2u" else "encrypt")
+                       circuit="add" if args.workload == "c3" else "encrypt_uniform" if args.workload == "c2u" else "encrypt",
+                       minimum_rows=getattr(args, "minimum_rows", 20))
     log("setup %.1fs: %s ; per-step counts %s" % (time.time() - t0, wl.shape, wl.counts))
     wl.run(args.warmup)
     if args.warmup:
@@ -1334,9 +1265,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     if rank != 0:
-        if use_dist:
-            dist.destroy_process_group()
-        return
+        return None
     sh, cnt = wl.shape, wl.counts
     keygen = None
     fresh = None
@@ -1398,6 +1327,7 @@ def main():
             "workload": "%s: %d-bit n, KZG prover hot path at k=%d (K3 trace + K4 cell expansion + K1 commitments + K2 NTTs), 1 proof per GPU per step"
                         % ("c3 homomorphic add" if args.workload == "c3" else "c2u uniform-shape encrypt" if args.workload == "c2u" else "c2 encrypt" if (args.enc_bits, args.k) == (2048, 17) else "c5-shape encrypt" if (args.enc_bits, args.k) == (3072, 19) else "custom encrypt", args.enc_bits, args.k),
             "enc_bits": args.enc_bits, "k": args.k, "lookup_bits": sh.lookup_bits, "limb_bits": 64,
+            "minimum_rows": wl.row_budget.minimum_rows, "max_rows": wl.rows,
             "mul_mod_steps": wl.n_steps, "advice_cols": sh.advice_cols, "lookup_cols": sh.lookup_cols,
             "perm_cols": sh.perm_cols, "advice_cols_committed": wl.adv_cols, "lookup_cols_committed": wl.lk_cols,
             "cells_per_mul_mod": wl.cells, "advice_cells": wl.n_steps * wl.cells, "msm_per_proof": n_adv + cnt["msm_full"],
@@ -1523,140 +1453,424 @@ def main():
             wu.release()
         except Exception as ex:
             out["c2u"] = {"error": repr(ex)}
-    # with_next_rows: ONE CONNECTED PROOF per step (bench_connected.py): the whole create_proof dataflow on the proof's own data, every
-    # phase closed by a transcript round trip; the proving key's extended forms resident.  After everything else has released its memory.
-    if (args.workload == "c2" and args.scale == 1.0 and world == 1 and not args.no_body and not args.no_tail and not os.environ.get("PZ_BENCH_SKIP")):
+    return out
+
+
+def count_digit_adds_cols(eng, torch, cols, n_cols, n, full_cols):
+    """non-zero signed 16-bit digits K1 accumulates for one proof: the witness columns `cols` [n_cols][n][4] (Montgomery, as K4 wrote them;
+    counted on the device from the canonical values) + full-width columns at 16 digits each (measurement support for roofline_int)"""
+    total = 0
+    flat = cols[:n_cols].reshape(-1, 4)
+    CH = 1 << 22
+    for c0 in range(0, flat.shape[0], CH):
+        x = flat[c0:c0 + CH].clone()
+        eng.fr_convert_dev(x.data_ptr(), x.shape[0], False)
+        eng.sync()
+        neg = x[:, 3] != 0
+        nz = torch.zeros(x.shape[0], dtype=torch.int64, device=x.device)
+        for limb in range(3):
+            v = x[:, limb]
+            for sh in (0, 16, 32, 48):
+                nz += ((v >> sh) & 0xFFFF) != 0
+        total += int(nz[~neg].sum().item()) + int(neg.sum().item()) * 9
+        del x
+    return int(total + full_cols * n * 16 * (1.0 - 2.0 ** -16))
+
+
+def connected_line(args, R):
+    """THE HEADLINE: one CONNECTED proof per step (bench_connected.ConnectedWorkload: K3 -> K4 in halo2-lib's break-point columns -> advice
+    commitments -> permuted lookup columns -> grand products -> quotient -> evaluations -> SHPLONK, five transcript round trips, every phase
+    on the proof's own data; reference: /root/reference/src/bench.rs:161-171 gen_proof after keygen), checked after the timed loop as the
+    verifier would.  BASELINE.json config 2: "full KZG proof at k=17".  -> the JSON dict on rank 0, None elsewhere"""
+    import gc
+
+    import torch
+    import torch.distributed as dist
+
+    import bench_connected
+    from paillier_halo2_amd import engine as E
+
+    rank, world, use_dist, log, eng, mad_peak, barrier = R.rank, R.world, R.use_dist, R.log, R.eng, R.mad_peak, R.barrier
+    t_all = time.time()
+    preset = args.workload
+    streamed, pipeline, lookup_tile = None, None, None
+    if preset == "c5":      # BASELINE config c5: 3072-bit n, k = 19, 64 independent proofs over 8 GPUs = replicas; its extended proving key (239 GB)
+        args.enc_bits, args.k = 3072, 19          # does not fit beside the rest: the STREAMED key (coefficient forms resident, tiles re-extended)
+        if "--steps" not in sys.argv:
+            args.steps = 3
+        streamed, pipeline, lookup_tile = 0, False, 16
+    if os.environ.get("PZ_CONNECTED_STREAMED_KEY", "") != "":
+        streamed = int(os.environ["PZ_CONNECTED_STREAMED_KEY"])
+    circuit = "encrypt_uniform" if preset == "c2u" else "encrypt"
+    headline_cfg = preset == "c2" and (args.enc_bits, args.k) == (2048, 17)
+    cw = bench_connected.ConnectedWorkload(eng, torch, args.enc_bits, args.k, args.seed + rank, lookup_bits=args.lookup_bits, log=log, circuit=circuit,
+                                           minimum_rows=args.minimum_rows, streamed_key=streamed, pipeline=pipeline, lookup_tile=lookup_tile)
+    cnt = cw.counts()
+    log("connected setup %.1fs: structure %s ms, keygen %.0f ms, %s" % (time.time() - t_all, {k_: round(v_) for k_, v_ in cw.structure_ms.items()}, cw.keygen_ms, cnt))
+    # digits K1 accumulates per proof (roofline_int): counted on the first witness, which the first proof then consumes
+    cw.produce()
+    torch.cuda.synchronize()
+    digit_adds = count_digit_adds_cols(eng, torch, cw.slots[0], cw.A + cw.Lk, cw.n, cnt["msm_full"])
+    cw.run(max(1, args.warmup), timed=False)      # (the first proof also grows the library's workspaces)
+    barrier()
+    engines = [eng] + ([cw.engw] if cw.engw is not eng else [])
+    for e_ in engines:
+        e_.timing_enable(True)
+        e_.timing_reset()
+    t0 = time.perf_counter()
+    cw.run(args.steps, timed=False)
+    barrier()
+    dt = time.perf_counter() - t0
+    tsum = lambda which: tuple(sum(x) for x in zip(*[e_.timing_get(which) for e_ in engines]))
+    acc_ms, acc_n = tsum(E.T_MSM_ACC)
+    ntt_ms, ntt_n = tsum(E.T_NTT)
+    trace_ms, _ = tsum(E.T_TRACE)
+    msm_ms, _ = tsum(E.T_MSM_ALL)
+    exp_ms, _ = tsum(E.T_EXPAND)
+    for e_ in engines:
+        e_.timing_enable(False)
+    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if use_dist:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    if rank != 0:
+        cw.release()
+        return None
+    cw.run(1, timed=True)       # one more proof, synchronised phase by phase, OUTSIDE the timed region: where the time goes
+    ver, _cref = None, None
+    if not args.no_verify and not args.no_cpu_baseline:
+        from oracle import cref as _cref     # the checker leg (the one place bench.py may touch oracle/)
+
+        _cref.build()
+        ver = cw.verify(_cref)
+    n = 1 << args.k
+    value = args.steps * world / dt
+    cols_per_proof = cnt["msm_witness"] + cnt["msm_full"]
+    alg_bytes_total = cols_per_proof * args.steps * n * 32.0 + acc_n * n * 64.0
+    ach = alg_bytes_total / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+    traffic, traffic_src = None, None
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_traffic_connected.json")))
+        if headline_cfg:
+            traffic = pj["k_msm_accumulate"]["fetch_bytes_per_launch_raw"] + pj["k_msm_accumulate"]["write_bytes_per_launch"]
+            traffic_src = pj["source"]
+    except Exception:
+        pass
+    shape_name = ("c2 encrypt" if headline_cfg else "c2u uniform-shape encrypt" if preset == "c2u" else "c5-shape encrypt" if (args.enc_bits, args.k) == (3072, 19) else "custom encrypt")
+    out = {
+        "metric": ("Paillier-encrypt proofs/s (2048-bit n, k=17); MSM achieved HBM GB/s vs peak" if headline_cfg
+                   else "Paillier-encrypt%s proofs/s (%d-bit n, k=%d) -- NOT the headline configuration; MSM achieved HBM GB/s vs peak"
+                   % (" (uniform-shape circuit)" if preset == "c2u" else "", args.enc_bits, args.k)),
+        "value": value, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32 limbs (29-bit reduced radix, 254-bit modular integers), u64 limbs (4096-bit integers)", "data": "synthetic",
+        "config": {
+            "workload": "%s: %d-bit n, ONE CONNECTED KZG proof per GPU per step at k=%d (K3 trace -> K4 break-point columns -> create_proof's phases in order, "
+                        "a transcript round trip per phase)" % (shape_name, args.enc_bits, args.k),
+            "scope": "one connected proof (keygen once per key and message shape, outside: keygen_ms; the transcript is a hashing stand-in with halo2's "
+                     "round trips, not its byte format)",
+            "enc_bits": args.enc_bits, "k": args.k, "lookup_bits": cw.lb, "limb_bits": 64, "mul_mod_steps": cw.n_steps,
+            "minimum_rows": cw.minimum_rows, "max_rows": cw.cs.max_rows, "advice_cols": cw.A, "advice_cols_filled": cw.cs.n_adv_used,
+            "lookup_cols": cw.Lk, "permutation_cols": cw.m, "permutation_sets": cw.pk.n_sets,
+            "row_budget": "halo2-lib's tester [D]: calculate_params(Some(minimum_rows)) fixes the column COUNT (20 on the reference's bench path, bench.rs:161-171); "
+                          "columns are filled to 2^k - cs.minimum_rows() = 2^k - 9 (paillier_halo2_amd/layout.py RowBudget)",
+            "msm_per_proof": cols_per_proof, "ntt_polys_per_proof": cnt["ntt_polys"], "polys_opened": cnt["polys_opened"],
+            "quotient_domain_cosets": cw.pk.dom.cosets, "proving_key_streamed": bool(cw.pk.streamed),
+            "pipeline_witness_of_next_proof": bool(cw.pipeline),
+            "prover": "paillier_halo2_amd/prover.py (Python driver over the C ABI; the compiled driver's figure: compiled_prover)",
+            "layout_parity": "unpinned: cell patterns, break points and column counts restate the biguint-halo2 / halo2-lib dependencies (SURVEY tag [D])",
+            "parallelism": "proof replicas, one per GPU, no collective", "scale": 1.0,
+        },
+        "verified": ver.get("verified") if ver else None, "verification": ver,
+        "comparable": bool(not os.environ.get("PZ_BENCH_SKIP")),
+        "roofline": {
+            "bound": "hbm", "kernel": "k_msm_accumulate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": alg_bytes_total / max(1, acc_n), "launches": int(acc_n), "avg_launch_ms": acc_ms / max(1, acc_n),
+            "launches_per_proof": acc_n / max(1, args.steps),
+            "note": "the connected loop's own k_msm_accumulate launches (HIP events on the library's stream): 32 B per scalar of every committed column + "
+                    "64 B per base per launch; integer-multiply-issue bound by construction (v_mad_u64_u32) -- the HBM fraction is the metric's definition",
+        },
+        "roofline_int": {
+            "bound": "v_mad_u64_u32 issue", "kernel": "k_msm_accumulate",
+            "achieved": (digit_adds * args.steps * MULT_PER_MADD / (acc_ms * 1e-3) / 1e12) if acc_ms > 0 else None,
+            "peak": mad_peak, "unit": "T multiplier instructions/s", "digit_adds_per_proof": digit_adds,
+            "multiplier_instructions_per_mixed_addition": MULT_PER_MADD,
+        },
+        "breakdown_ms_per_proof": {"trace": trace_ms / args.steps, "expand": exp_ms / args.steps, "msm_all": msm_ms / args.steps,
+                                   "msm_accumulate": acc_ms / args.steps, "ntt": ntt_ms / args.steps, "ntt_calls": ntt_n / args.steps},
+        "phases_ms_per_proof": cw.phase_ms(1), "counts": cnt, "memory_gb": cw.memory_gb,
+        "keygen_ms": cw.keygen_ms, "circuit_structure_ms": cw.structure_ms,
+        "rccl_ranks": dist.get_world_size() if use_dist else 1, "backend": dist.get_backend() if use_dist else None,
+    }
+    out["memory_gb"]["torch_allocated_peak"] = torch.cuda.max_memory_allocated() / 1e9
+    try:
+        free_b, total_b = torch.cuda.mem_get_info()
+        out["memory_gb"]["device_total"], out["memory_gb"]["device_free_after_timed_loop"] = total_b / 1e9, free_b / 1e9
+    except Exception:
+        pass
+    if out["roofline_int"]["achieved"]:
+        out["roofline_int"]["frac"] = out["roofline_int"]["achieved"] / mad_peak
+    out["config"]["env_switches"] = env_switches()
+    if ver is not None and ver.get("verified") is False:
+        out["comparable"] = False
+    log("connected %.1fs: %.3f proofs/s (%.1f ms), verified %s" % (time.time() - t_all, value, dt / args.steps * 1e3, out["verified"]))
+    if not args.no_cpu_baseline and world == 1:
         try:
-            import gc
-
-            import bench_connected
-
-            if "wl" in dir():
-                wl.release()
-                del wl
+            cc = dict(cnt)
+            cc["n"] = n
+            out["cpu_baseline"] = cpu_baseline(None, cw.n_steps, args.enc_bits, args.k, log, connected=cc)
+            out["cpu_baseline"].pop("checker", None)
+        except Exception as ex:
+            out["cpu_baseline"] = {"value": None, "error": repr(ex)}
+    extras = world == 1 and not args.headline_only and not os.environ.get("PZ_BENCH_SKIP")
+    # ---- a NEW MESSAGE per proof with the reference's circuit: its bits are circuit structure (paillier.rs:50-55), so every step generates
+    # the structure, runs keygen_vk + keygen_pk on its real selectors / sigma and then the connected proof.  The SRS is shared.
+    if extras and headline_cfg and not args.no_fresh_key:
+        try:
+            srs = (cw.bl, cw.bm, cw.s_tox)
+            for nm in ("pk", "ws", "slots", "cols", "d_steps"):
+                setattr(cw, nm, None)           # the first key leaves the device; its SRS stays
             gc.collect()
-            torch.cuda.empty_cache()
-            t_c = time.time()
-            cw = bench_connected.ConnectedWorkload(eng, torch, args.enc_bits, args.k, args.seed, lookup_bits=args.lookup_bits, log=log)
-            cw.run(1, timed=False)
-            barrier()
-            c_steps = max(2, args.steps // 2)
-            tc0 = time.perf_counter()
-            cw.run(c_steps, timed=False)
-            barrier()
-            dtc = time.perf_counter() - tc0
-            cw.run(1, timed=True)      # one more proof, synchronised phase by phase, outside the timed region: where the time goes
-            ver = None
-            if not args.no_verify and not args.no_cpu_baseline:
-                from oracle import cref as _cref    # the checker leg
-
-                _cref.build()
-                ver = cw.verify(_cref)
-            out["with_next_rows"] = {
-                "value": c_steps / dtc, "unit": "proofs/s", "steps": c_steps, "ms_per_step": dtc / c_steps * 1e3, "connected": True,
-                "verified": ver.get("verified") if ver else None, "verification": ver,
-                "phases_ms_per_proof": cw.phase_ms(1), "counts": cw.counts(), "memory_gb": cw.memory_gb,
-                "keygen_ms": cw.keygen_ms, "circuit_structure_ms": cw.structure_ms,
-                # what a NEW message costs with the reference's circuit (its bits are circuit structure, paillier.rs:50-55): structure +
-                # keygen of the real selectors / sigma + the proof -- `fresh_key` above times a stand-in keygen and no structure generation
-                "fresh_message_s": (sum(cw.structure_ms.values()) + cw.keygen_ms + dtc / c_steps * 1e3) / 1e3,
-                "note": "one connected proof per step: K3 -> K4 (break-point columns) -> advice commitments -> permuted lookup columns -> grand "
-                        "products -> quotient (64-column tiles extended and folded as produced, against the resident extended proving key) -> h "
-                        "pieces -> evaluations -> SHPLONK; five transcript round trips (commitments downloaded and hashed: a stand-in for halo2's "
-                        "Blake2b transcript); serial on one stream (no overlap of the next proof's witness); excluded: the transcript's byte "
-                        "format, keygen (keygen_ms, once per key and message shape)"}
-            log("connected %.1fs: %.3f proofs/s, verified %s" % (time.time() - t_c, c_steps / dtc, ver.get("verified") if ver else None))
-            if ver is not None and ver.get("verified") is False:
-                out["comparable"] = False
-            # a NEW MESSAGE per proof with the reference's circuit, for real: its bits are circuit structure (paillier.rs:50-55), so every
-            # step generates the structure, runs keygen_vk + keygen_pk on the real selectors / sigma and then the connected proof
-            # (`fresh_key` above: the hot path with a stand-in keygen).  The SRS is shared (it does not depend on the message).
-            if not args.no_fresh_key:
-                try:
-                    srs = (cw.bl, cw.bm, cw.s_tox)
-                    keep = {nm: getattr(cw, nm) for nm in ("pk", "ws", "slots", "cols", "d_steps")}
-                    for nm in keep:
-                        setattr(cw, nm, None)           # the first key leaves the device; its SRS stays
-                    del keep
-                    gc.collect()
-                    fm_steps, t_f, verf, last = 3, time.perf_counter(), None, None
-                    parts = {"structure_ms": 0.0, "keygen_ms": 0.0}
-                    for i in range(fm_steps):
-                        if last is not None:      # the previous key's blocks go back to torch's allocator, not to the driver: the next key reuses them
-                            last.release(trim=False)
-                            del last
-                            gc.collect()
-                        last = bench_connected.ConnectedWorkload(eng, torch, args.enc_bits, args.k, args.seed + 7001 + i, lookup_bits=args.lookup_bits,
-                                                                 log=log, pipeline=False, srs=srs, trim=False)
-                        last.run(1, timed=False)
-                        parts["structure_ms"] += sum(last.structure_ms.values()) / fm_steps
-                        parts["keygen_ms"] += last.keygen_ms / fm_steps
-                    torch.cuda.synchronize()
-                    dtf = time.perf_counter() - t_f
-                    if ver is not None:
-                        verf = last.verify(_cref)
-                    out["fresh_message"] = {
-                        "value": fm_steps / dtf, "unit": "proofs/s", "steps": fm_steps, "s_per_step": dtf / fm_steps, "connected": True,
-                        "verified": verf.get("verified") if verf else None, "verification": verf, "of_which": parts,
-                        "note": "every step: a new key pair and message -> circuit structure generated on the device (circuit_structure.py) -> "
-                                "keygen_vk + keygen_pk of its real selectors and sigma (all three forms resident) -> one connected proof; "
-                                "the whole step is inside the timed region, incl. the release of the previous key; SRS shared"}
-                    log("fresh message: %.2f s per step (structure %.0f + keygen %.0f ms), verified %s" % (
-                        dtf / fm_steps, parts["structure_ms"], parts["keygen_ms"], verf.get("verified") if verf else None))
-                    if verf is not None and verf.get("verified") is False:
-                        out["comparable"] = False
-                    last.release()
+            fm_steps, t_f, verf, last = 3, time.perf_counter(), None, None
+            parts = {"structure_ms": 0.0, "keygen_ms": 0.0}
+            for i in range(fm_steps):
+                if last is not None:      # the previous key's blocks go back to torch's allocator, not to the driver: the next key reuses them
+                    last.release(trim=False)
                     del last
-                except Exception as ex:
-                    import traceback
-
-                    out["fresh_message"] = {"error": repr(ex)[:400], "trace": traceback.format_exc()[-600:]}
-            cw.release()
-            gc.collect()
-            torch.cuda.empty_cache()
-            # the same proof from the compiled prover: plain C++ over the C ABI, a child process with its own contexts
-            if not args.no_dropin:
-                try:
-                    t_p = time.time()
-                    out["with_next_rows_cpp"] = bench_connected.cpp_connected(cw, proofs=4, verify_with=_cref if ver is not None else None, log=log)
-                    log("connected, compiled prover %.1fs: %.1f ms per proof, verified %s" % (
-                        time.time() - t_p, out["with_next_rows_cpp"]["ms_per_step"], out["with_next_rows_cpp"].get("verified")))
-                    if out["with_next_rows_cpp"].get("verified") is False:
-                        out["comparable"] = False
-                except Exception as ex:
-                    out["with_next_rows_cpp"] = {"error": repr(ex)[:600]}
-            del cw
-            gc.collect()
-            # the same through the UNIFORM-shape circuit (row f4): ONE proving key for every message of a key, so the proofs of this
-            # loop are of DISTINCT messages -- what a user who encrypts different messages gets once that key exists.  (The reference's
-            # circuit needs a new structure + keygen per message: `fresh_message`.)  Two witness slots since the three-coset quotient
-            # (its proving key: 136 GB resident, 208 GB allocated in all).
-            if (args.enc_bits, args.k) == (2048, 17) and not args.no_c2u:
-                t_u = time.time()
-                cu = bench_connected.ConnectedWorkload(eng, torch, args.enc_bits, args.k, args.seed, lookup_bits=args.lookup_bits, log=log,
-                                                       circuit="encrypt_uniform")
-                cu.run(1, timed=False)
-                barrier()
-                tu0 = time.perf_counter()
-                cu.run(c_steps, timed=False)
-                barrier()
-                dtu = time.perf_counter() - tu0
-                cu.run(1, timed=True)
-                veru = cu.verify(_cref) if ver is not None else None
-                out["with_next_rows_c2u"] = {
-                    "value": c_steps / dtu, "unit": "proofs/s", "steps": c_steps, "ms_per_step": dtu / c_steps * 1e3, "connected": True,
-                    "distinct_messages_one_key": True, "verified": veru.get("verified") if veru else None, "verification": veru,
-                    "phases_ms_per_proof": cu.phase_ms(1), "counts": cu.counts(), "memory_gb": cu.memory_gb, "keygen_ms": cu.keygen_ms,
-                    "circuit_structure_ms": cu.structure_ms,
-                    "note": "the connected proof through the uniform-shape circuit (g^m over all message bits in circuit: 7192 mul_mod steps, "
-                            "3544 + 98 columns): every proof of the loop is of a different message, all under one proving key"}
-                log("connected c2u %.1fs: %.3f proofs/s, verified %s" % (time.time() - t_u, c_steps / dtu, veru.get("verified") if veru else None))
-                cu.release()
+                    gc.collect()
+                last = bench_connected.ConnectedWorkload(eng, torch, args.enc_bits, args.k, args.seed + 7001 + i, lookup_bits=args.lookup_bits,
+                                                         log=log, pipeline=False, srs=srs, trim=False, minimum_rows=args.minimum_rows)
+                last.run(1, timed=False)
+                parts["structure_ms"] += sum(last.structure_ms.values()) / fm_steps
+                parts["keygen_ms"] += last.keygen_ms / fm_steps
+            torch.cuda.synchronize()
+            dtf = time.perf_counter() - t_f
+            if ver is not None:
+                verf = last.verify(_cref)
+            out["fresh_message"] = {
+                "value": fm_steps / dtf, "unit": "proofs/s", "steps": fm_steps, "s_per_step": dtf / fm_steps, "connected": True,
+                "verified": verf.get("verified") if verf else None, "verification": verf, "of_which": parts,
+                "note": "every step: a new key pair and message -> circuit structure generated on the device (circuit_structure.py) -> "
+                        "keygen_vk + keygen_pk of its real selectors and sigma (all three forms resident) -> one connected proof; "
+                        "the whole step is inside the timed region, incl. the release of the previous key; SRS shared"}
+            log("fresh message: %.2f s per step (structure %.0f + keygen %.0f ms), verified %s" % (
+                dtf / fm_steps, parts["structure_ms"], parts["keygen_ms"], verf.get("verified") if verf else None))
+            if verf is not None and verf.get("verified") is False:
+                out["comparable"] = False
+            last.release()
+            del last
         except Exception as ex:
             import traceback
 
-            out["with_next_rows"] = {"error": repr(ex), "trace": traceback.format_exc()[-800:], "connected": True}
-    print(json.dumps(out))
+            out["fresh_message"] = {"error": repr(ex)[:400], "trace": traceback.format_exc()[-600:]}
+    cw.release()
+    gc.collect()
+    torch.cuda.empty_cache()
+    # ---- the same proof from the COMPILED prover: plain C++ over the C ABI, a child process with its own contexts
+    if extras and not args.no_dropin and preset != "c5":
+        try:
+            t_p = time.time()
+            out["compiled_prover"] = bench_connected.cpp_connected(cw, proofs=5, verify_with=_cref if ver is not None else None, log=log)
+            log("connected, compiled prover %.1fs: %.1f ms per proof, verified %s" % (
+                time.time() - t_p, out["compiled_prover"]["ms_per_step"], out["compiled_prover"].get("verified")))
+            if out["compiled_prover"].get("verified") is False:
+                out["comparable"] = False
+        except Exception as ex:
+            out["compiled_prover"] = {"error": repr(ex)[:600]}
+    del cw
+    gc.collect()
+    # ---- the same through the UNIFORM-shape circuit (row f4): ONE proving key for every message of a key -- the proofs of this loop are
+    # of DISTINCT messages (the reference's circuit needs a new structure + keygen per message: `fresh_message`)
+    if extras and headline_cfg and not args.no_c2u:
+        try:
+            t_u = time.time()
+            c_steps = max(2, args.steps // 2)
+            cu = bench_connected.ConnectedWorkload(eng, torch, args.enc_bits, args.k, args.seed, lookup_bits=args.lookup_bits, log=log,
+                                                   circuit="encrypt_uniform", minimum_rows=args.minimum_rows)
+            cu.run(1, timed=False)
+            barrier()
+            tu0 = time.perf_counter()
+            cu.run(c_steps, timed=False)
+            barrier()
+            dtu = time.perf_counter() - tu0
+            cu.run(1, timed=True)
+            veru = cu.verify(_cref) if ver is not None else None
+            out["uniform_circuit_distinct_messages"] = {
+                "value": c_steps / dtu, "unit": "proofs/s", "steps": c_steps, "ms_per_step": dtu / c_steps * 1e3, "connected": True,
+                "distinct_messages_one_key": True, "verified": veru.get("verified") if veru else None, "verification": veru,
+                "phases_ms_per_proof": cu.phase_ms(1), "counts": cu.counts(), "memory_gb": cu.memory_gb, "keygen_ms": cu.keygen_ms,
+                "circuit_structure_ms": cu.structure_ms,
+                "note": "the connected proof through the uniform-shape circuit (g^m over all message bits in circuit): every proof of the loop is of "
+                        "a different message, all under one proving key"}
+            log("connected c2u %.1fs: %.3f proofs/s, verified %s" % (time.time() - t_u, c_steps / dtu, veru.get("verified") if veru else None))
+            if veru is not None and veru.get("verified") is False:
+                out["comparable"] = False
+            cu.release()
+            del cu
+            gc.collect()
+            torch.cuda.empty_cache()
+        except Exception as ex:
+            import traceback
+
+            out["uniform_circuit_distinct_messages"] = {"error": repr(ex)[:400], "trace": traceback.format_exc()[-600:]}
+    # ---- the HOT PATH ONLY (rounds 1-5's headline): K3 -> K4 -> K1 + K2 with the later phases' commitments / transforms over pool scalars,
+    # three-stream pipeline, checked against a serial recomputation; kept beside the connected proof for continuity
+    if extras and headline_cfg and not args.no_hot_path:
+        try:
+            t_h = time.time()
+            a2 = argparse.Namespace(**vars(args))
+            a2.workload, a2.steps, a2.warmup = "c2", min(args.steps, 6), 1
+            a2.no_tail = a2.no_body = a2.no_fresh_key = a2.no_c2u = a2.no_cpu_baseline = True
+            a2.no_dropin = not args.full_hot_path
+            hp = hot_path_line(a2, R)
+            keep = ("value", "unit", "steps", "warmup", "ms_per_step", "verified", "verification", "comparable", "roofline", "roofline_int",
+                    "breakdown_ms_per_proof", "srs_ms", "dropin_device_resident", "dropin_host_pointer")
+            out["hot_path_only"] = {k_: hp[k_] for k_ in keep if k_ in hp}
+            out["hot_path_only"]["config"] = {k_: hp["config"][k_] for k_ in ("workload", "scope", "advice_cols_committed", "lookup_cols_committed", "msm_per_proof",
+                                                                                "ntt_polys_per_proof", "pipeline_witness_of_next_proof", "ntt_on_second_stream") if k_ in hp["config"]}
+            log("hot path only %.1fs: %.3f proofs/s, verified %s" % (time.time() - t_h, hp["value"], hp.get("verified")))
+            if hp.get("verified") is False:
+                out["comparable"] = False
+        except Exception as ex:
+            import traceback
+
+            out["hot_path_only"] = {"error": repr(ex)[:400], "trace": traceback.format_exc()[-600:]}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2u", "c3", "c5", "msm22", "stub"],
+                    help="c2: encrypt proof hot path (headline); c2u: the same key size through the uniform-shape circuit (g^m over all message bits in circuit, SURVEY 8f rank 4); c3: homomorphic-add circuit at --k 15; msm22: one sharded MSM")
+    ap.add_argument("--k", type=int, default=17)
+    ap.add_argument("--enc-bits", type=int, default=2048)
+    ap.add_argument("--scale", type=float, default=1.0, help="fraction of the per-proof MSM/NTT counts (debug only; "
+                    "any value != 1 marks the line as not comparable)")
+    ap.add_argument("--log-n", type=int, default=22, help="msm22 workload: log2 of the MSM size")
+    ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5043,
+                    help="base seed of the synthetic key / message (rank r uses seed + r); default = SURVEY section 8d's c2 seed")
+    ap.add_argument("--lookup-bits", type=int, default=None, help="RangeChip lookup bits (default k - 1, the reference's pattern)")
+    ap.add_argument("--msm-scalars", default="uniform", choices=["uniform", "witness"],
+                    help="msm22 workload: uniform scalars, or SURVEY section 8d's witness-like mix (60%% < 2^16, 30%% < 2^64, 10%% < 2^135)")
+    ap.add_argument("--parallel", default="replicas", choices=["replicas", "columns"],
+                    help="N > 1: independent proofs per GPU (weak scaling, the default and the headline) or ONE proof whose "
+                         "columns are split over the ranks with an all-gather of the commitments (strong scaling)")
+    ap.add_argument("--msm-split", default="points", choices=["windows", "points"],
+                    help="msm22 workload: shard point ranges across the ranks (default: measured / emulated to scale better, "
+                         "DESIGN.md section 8) or Pippenger windows (north_star's split)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the host-pointer (drop-in binding) measurement")
+    ap.add_argument("--no-body", action="store_true", help="skip the second timed loop (hot path + the prover steps after it)")
+    ap.add_argument("--emulate-world", type=int, default=0, help="msm22 workload on ONE GPU: run each of W ranks' shares in turn, "
+                    "print per-share stage times and the predicted W-GPU efficiency for both splits")
+    ap.add_argument("--emulate-ranks", type=int, default=0, help="msm22 workload (and, with --parallel columns, a c2 column batch) on ONE GPU: this "
+                    "process plays every rank 0..W-1 of a world of W in turn -- rank r's exact code path (its point / window / column range, "
+                    "offsets, padded gather slices) -- through the real process group of one rank (use with --force-dist: backend nccl = RCCL); "
+                    "every rank's folded / gathered result must equal the single-call result")
+    ap.add_argument("--no-verify", action="store_true", help="skip the output check of the pipelined step after the timed loop (the line then says verified: null)")
+    ap.add_argument("--no-fresh-key", action="store_true", help="skip the third timed loop (keygen per message inside the timed region)")
+    ap.add_argument("--no-c2u", action="store_true", help="default c2 run only: skip the uniform-shape circuit's line (a second workload after the main one)")
+    ap.add_argument("--no-tail", action="store_true", help="skip the (untimed) measurement of the prover steps after the hot path")
+    ap.add_argument("--force-dist", action="store_true", help="with --gpus 1: still start through torch.distributed.run, create the process group "
+                    "(backend nccl = RCCL) and run every collective of the N > 1 path on the one rank (all_gather_into_tensor + device fold of msm22, "
+                    "the commitment all-gather of --parallel columns, the barriers and the MAX all-reduce of the timing)")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo only with --workload stub)")
+    ap.add_argument("--minimum-rows", type=int, default=20, help="the argument of halo2-lib's calculate_params: 20 on the reference's bench path "
+                    "(bench.rs:161-171 -> bench_builder), 9 under MockProver (paillier.rs:167-171); fixes the column COUNT (layout.RowBudget)")
+    ap.add_argument("--hot-path-headline", action="store_true", help="rounds 1-5's line: `value` = the hot path only (K3 + K4 + K1 + K2), not the connected proof")
+    ap.add_argument("--headline-only", action="store_true", help="the connected proof's timed loop, its check and the CPU baseline only (no fresh_message / "
+                    "compiled_prover / uniform circuit / hot_path_only legs)")
+    ap.add_argument("--no-hot-path", action="store_true", help="skip the hot_path_only leg")
+    ap.add_argument("--full-hot-path", action="store_true", help="hot_path_only leg: also the C++ hot-path caller and the host-pointer binding")
+    args = ap.parse_args()
+
+    # typed as `python bench.py --gpus N` (not pre-launched by torch.distributed.run): become the launcher.  Nothing above
+    # this line has touched the GPU (numpy only), and the ranks are CHILD processes -- never an exec of this one
+    if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if args.workload == "stub":
+        return stub_workload(args)
+
+    import torch
+    import torch.distributed as dist
+
+    import paillier_halo2_amd as pz
+    from paillier_halo2_amd import engine as E
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    torch.cuda.set_device(local)
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)  # launched by torch.distributed.run
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        with _stdout_to_stderr():
+            dist.init_process_group(args.backend or "nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.barrier()   # the communicator comes up here (and says so), not inside a timed region
+    log = (lambda s: print("[bench] " + s, file=sys.stderr, flush=True)) if rank == 0 else (lambda s: None)
+
+    eng = pz.Engine(local)
+    eng.bind_torch_stream()  # a real stream, current for torch too: the event waits of the pipeline order against it
+    # multiplier issue peak of this device, measured live (8 independent mads per lane and iteration)
+    from paillier_halo2_amd import probe   # libpz_probe.so: measurement only, outside the product ABI
+
+    mad_peak = max(8192 * 256 * 1024 * 8 / (probe.ubench_mad_indep(local, 8192, 1024) * 1e-3) / 1e12 for _ in range(3))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.workload == "msm22":
+        from paillier_halo2_amd import dist as pzd
+
+        if args.emulate_ranks > 1:
+            em = pzd.emulate_ranks_msm(eng, torch, dist if use_dist else None, args.emulate_ranks, args.log_n, args.msm_split, log)
+            em_cols = None
+            if args.parallel == "columns":     # the commitment all-gather of column-parallel proving, 37 full-width columns of 2^14 rows
+                kk, nc = 14, 37
+                g_ = torch.Generator(device="cuda")
+                g_.manual_seed(7)
+                d_c = torch.randint(-(1 << 63), (1 << 63) - 1, (nc, 1 << kk, 4), dtype=torch.int64, device="cuda", generator=g_)
+                d_c[:, :, 3] &= 0x0FFFFFFFFFFFFFFF
+                d_bb = torch.zeros((1 << kk, 8), dtype=torch.int64, device="cuda")
+                eng.g1_fixed_base_mul_dev(d_c[0].data_ptr(), 1 << kk, d_bb.data_ptr())
+                tb_ = eng.load_bases_dev(d_bb.data_ptr(), 1 << kk)
+                em_cols = pzd.emulate_ranks_columns(eng, torch, dist if use_dist else None, args.emulate_ranks, tb_, d_c, nc, 1 << kk, log)
+                tb_.free()
+            res = {"metric": "rank emulation of the sharded MSM: every rank's code path on one GPU", "value": 1.0 if em["all_equal"] and (em_cols is None or em_cols["all_equal"]) else 0.0,
+                   "unit": "all ranks equal the single-call result", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": None, "higher_is_better": True,
+                   "scaling": "strong", "vs_baseline": None, "dtype": "u32 limbs (254-bit modular integers)", "data": "synthetic",
+                   "config": {"workload": "c4 rank emulation: 2^%d-point MSM, world %d, %s split" % (args.log_n, args.emulate_ranks, args.msm_split)},
+                   "emulate_ranks": em, "emulate_ranks_columns": em_cols}
+        elif args.emulate_world > 1:
+            res = pzd.emulate_sharded_msm(eng, torch, args.emulate_world, args.log_n, args.steps, args.warmup, log, scalars=args.msm_scalars,
+                                          share_window_bits=int(os.environ.get("PZ_SHARE_WINDOW_BITS", "0")))
+        else:
+            res = pzd.bench_sharded_msm(eng, torch, dist if use_dist else None, rank, world, args.log_n, args.steps,
+                                        args.warmup, barrier, log, split=args.msm_split, scalars=args.msm_scalars)
+        if rank == 0:
+            res["rccl_ranks"] = dist.get_world_size() if use_dist else 1
+            res["backend"] = dist.get_backend() if use_dist else None
+            res["config"]["env_switches"] = env_switches()
+            print(json.dumps(res))
+        if use_dist:
+            dist.destroy_process_group()
+        return
+
+    R = argparse.Namespace(rank=rank, world=world, local=local, use_dist=use_dist, log=log, eng=eng, mad_peak=mad_peak, barrier=barrier)
+    if args.workload in ("c2", "c2u", "c5") and not args.hot_path_headline:
+        out = connected_line(args, R)
+    else:
+        out = hot_path_line(args, R)
+    if rank == 0:
+        print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
 

@@ -81,7 +81,7 @@ int pz_set_stream(pz_ctx* ctx, void* hip_stream);
 int pz_sync(pz_ctx* ctx);
 /* explicit ABI version, bumped whenever an entry point below is added, removed or changes meaning (measurement probes are
  * not part of this ABI: they live in libpz_probe.so).  A binding compares it with the PZ_ABI_VERSION it was built against. */
-#define PZ_ABI_VERSION 5
+#define PZ_ABI_VERSION 6
 int pz_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -203,6 +203,9 @@ int pz_ntt_fr_coeff_extend_dev(pz_ctx* ctx, uint64_t* d_values, size_t n_cols, s
                                size_t out_stride, uint32_t log_n, uint32_t log_e, const uint64_t omega_n[4],
                                const uint64_t omega_n_inv[4], const uint64_t n_inv[4], const uint64_t* coset_gens);
 int pz_fr_convert_dev(pz_ctx* ctx, uint64_t* d_a, size_t n, int to_mont);
+/* a byte mask -> field elements: d_out[i] = d_mask[i] != 0 ? 1 : 0 (Montgomery form), n elements, both on the device.  How selectors --
+ * 0 / 1 bytes in halo2's Assembly -- become Lagrange-form fixed columns without crossing PCIe as 32-byte elements (keygen). */
+int pz_fr_from_mask_dev(pz_ctx* ctx, const uint8_t* d_mask, size_t n, uint64_t* d_out);
 
 /* ---------------------------------------------------------------------------------------------
  * K3 -- big-integer witness generation for g^m * r^n mod n^2.  Replaces the native
@@ -496,7 +499,16 @@ int pz_shplonk_free(pz_ctx* ctx, pz_shplonk* state);
  *                map_col / map_row: u32 [m][2^k] (all host).  Builds and keeps RESIDENT the commitments, the coefficient forms and the
  *                extended forms of the fixed and sigma columns, l_0 / l_last / l_active, and one proof's workspace (at config c2:
  *                116 + 30 GB).  n_adv, n_lk >= 1; lookup_bits < k.  tile: columns extended per step of the quotient (even; 64).  The key holds device memory of `ctx`
- *                (which must outlive it) and serves ONE proof at a time.
+ *                (which must outlive it) and serves ONE proof at a time.  The selectors are uploaded as bytes and become field elements on
+ *                the device (pz_fr_from_mask_dev); the host arrays are not referenced after the call returns.
+ *                ext_resident_cols: PZ_PK_EXT_ALL = the extended-coset forms of every selector and sigma column stay resident (halo2's
+ *                ProvingKey: fixed_cosets / permutation.cosets); a number R = the STREAMED proving key: only selector j / sigma j with j < R
+ *                keep them, the others are re-extended from their coefficient forms per tile inside pz_proof_quotient (+ one transform per
+ *                such column, three cosets, per proof) -- the memory plan of shapes whose extended key does not fit (BASELINE config c5:
+ *                3072-bit n, k = 19: 239 GB; R = 0 there).  The proof does not depend on R, byte for byte.
+ * pz_pk_create_dev  the same with selectors / map_col / map_row ALREADY ON THE DEVICE (device pointers of `ctx`'s device: a structure
+ *                generated there -- pz_circuit_structure_dev -- or uploaded by the caller): nothing of them crosses PCIe or is copied on the
+ *                host; they are only read during the call.  constants stay a (small) host array.
  * pz_pk_info     n_fixed = n_adv + 2 (selectors | constants | table); blinding_words = 64-bit words of caller randomness one proof
  *                consumes; evals_words = length of pz_proof_evaluate's output.
  * pz_pk_commitments  the verifying key's commitments: n_fixed x 8 and m x 8 words.
@@ -524,13 +536,46 @@ int pz_shplonk_free(pz_ctx* ctx, pz_shplonk* state);
  * Phases out of order return PZ_ERR_INVALID; after any error only pz_proof_free is valid.  pz_proof_free releases the key's
  * workspace for the next proof; pz_pk_free refuses (PZ_ERR_INVALID) while a proof is open.
  * ------------------------------------------------------------------------------------------- */
+/* ---------------------------------------------------------------------------------------------
+ * The circuit STRUCTURE of the reference's drivers, generated on the device (csrc/pz_structure.hip) -- what halo2's keygen extracts by
+ * synthesising paillier_enc_test / paillier_enc_add_test (/root/reference/src/bench.rs:33-117) once: selector positions, the
+ * copy-constraint permutation, the constants column, the break-point column layout.  It depends on the shape only: key size, limb
+ * width, lookup bits and the BITS of the two fixed exponents (paillier.rs:50-55 hands m and n to pow_mod_fixed_exp), so with the
+ * reference's circuit every new message needs a new structure and a new key:  pz_circuit_structure_dev -> pz_pk_create_dev ->
+ * pz_structure_free -> proofs.  The compiled counterpart of paillier_halo2_amd/circuit_structure.py, equal to it array for array.
+ * kind: 0 encrypt (exp_g = the message m, exp_r = the modulus n: ceil(limbs_n * limb_bits / 64) words each; only their bits are used), 1 add (no exponents),
+ * 2 the uniform-shape encrypt circuit (exp_g ignored: one structure for every message of a key).  limb_bits 16..90, lookup_bits < k.
+ * minimum_rows: the argument of the tester's calculate_params -- it fixes the NUMBER of advice / lookup-advice columns as
+ * ceil(cells / (2^k - minimum_rows)) (20 on the reference's bench path, 9 under MockProver); columns are FILLED to
+ * max_rows = 2^k - (blinding_factors + 3) (halo2-lib's FlexGateConfig::max_rows [D]).  PZ_ERR_UNSUPPORTED beyond 2^31 cells.
+ * pz_structure_info: n_adv configured advice columns of which n_adv_filled hold cells; n_lk; max_rows; the counts K4 needs
+ * (n_steps_g, n_steps_r) and the stream's sizes.
+ * pz_structure_arrays: DEVICE pointers d_selectors u8 [n_adv][2^k], d_map_col / d_map_row u32 [m][2^k] (m = n_adv + n_lk + 1),
+ * d_col_starts u64 [n_adv + 1] (what pz_circuit_expand_cols_dev takes); HOST pointers constants (n_constants x 4 words, canonical)
+ * and col_starts_host.  All owned by the structure, valid until pz_structure_free.  Any output may be NULL.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct pz_structure pz_structure;
+int pz_circuit_structure_dev(pz_ctx* ctx, int kind, uint32_t limbs_n, uint32_t limb_bits, uint32_t lookup_bits, uint32_t k,
+                             const uint64_t* exp_g, const uint64_t* exp_r, size_t minimum_rows, uint32_t blinding_factors,
+                             pz_structure** out);
+int pz_structure_info(const pz_structure* st, size_t* n_adv, size_t* n_adv_filled, size_t* n_lk, size_t* max_rows, size_t* n_constants,
+                      size_t* n_cells, size_t* n_lookups, size_t* n_steps_g, size_t* n_steps_r);
+int pz_structure_arrays(const pz_structure* st, const uint8_t** d_selectors, const uint32_t** d_map_col, const uint32_t** d_map_row,
+                        const uint64_t** d_col_starts, const uint64_t** constants, const uint64_t** col_starts_host);
+int pz_structure_free(pz_structure* st);
+
 typedef struct pz_pk pz_pk;
 typedef struct pz_proof pz_proof;
 #define PZ_BLINDING_SEEDED_TEST_STREAM (~(size_t)0)
+#define PZ_PK_EXT_ALL (~(size_t)0)
 int pz_pk_create(pz_ctx* ctx, const pz_bases* bases_lagrange, const pz_bases* bases_monomial, uint32_t k, uint32_t lookup_bits,
                  uint32_t blinding_factors, size_t max_rows, size_t n_adv, size_t n_lk, const uint8_t* selectors,
                  const uint64_t* constants, size_t n_constants, const uint32_t* map_col, const uint32_t* map_row, size_t tile,
-                 pz_pk** out);
+                 size_t ext_resident_cols, pz_pk** out);
+int pz_pk_create_dev(pz_ctx* ctx, const pz_bases* bases_lagrange, const pz_bases* bases_monomial, uint32_t k, uint32_t lookup_bits,
+                     uint32_t blinding_factors, size_t max_rows, size_t n_adv, size_t n_lk, const uint8_t* d_selectors,
+                     const uint64_t* constants, size_t n_constants, const uint32_t* d_map_col, const uint32_t* d_map_row, size_t tile,
+                     size_t ext_resident_cols, pz_pk** out);
 int pz_pk_info(const pz_pk* pk, size_t* n_fixed, size_t* n_perm_cols, size_t* n_sets, size_t* blinding_words, size_t* evals_words);
 int pz_pk_commitments(const pz_pk* pk, uint64_t* fixed_affine, uint64_t* sigma_affine);
 int pz_pk_free(pz_pk* pk);

@@ -55,6 +55,8 @@ def lib():
         _lib.ora_check_gates.restype = C.c_size_t
         _lib.ora_check_range.argtypes = [U64P, C.c_size_t, C.c_uint32, C.POINTER(C.c_size_t)]
         _lib.ora_check_range.restype = C.c_size_t
+        _lib.ora_fr_mul_seconds.argtypes = [C.c_size_t, C.c_int, C.c_int]
+        _lib.ora_fr_mul_seconds.restype = C.c_double
     return _lib
 
 
@@ -171,6 +173,15 @@ def ntt_fr(a_mont, omega_mont, log_n: int, threads: int = 0) -> np.ndarray:
     rc = lib().ora_ntt_fr(_p(a), _p(_c(omega_mont).reshape(4)), log_n, threads)
     assert rc == 0
     return a
+
+
+def fr_mul_rate(n: int = 1 << 20, reps: int = 8, threads: int = 0) -> float:
+    """Montgomery multiplications over Fr per second on `threads` OpenMP threads (0: the cgroup quota, ora_num_threads)"""
+    L = lib()
+    th = threads or L.ora_num_threads()
+    L.ora_fr_mul_seconds(n, 1, th)
+    dt = L.ora_fr_mul_seconds(n, reps, th)
+    return n * reps / dt
 
 
 def fr_scale(a_mont, scale_mont) -> np.ndarray:

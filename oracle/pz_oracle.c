@@ -594,6 +594,37 @@ int ora_fr_scale(u64 *a_, size_t n, const u64 scale[4]) {
     for (size_t i = 0; i < n; ++i) fe_mul(&a[i], &a[i], (const fe *)scale, &FR);
     return 0;
 }
+/* field-multiplication throughput of this host (bench.py's cpu_baseline leg prices the prover phases that are plain field arithmetic --
+ * grand products, evaluate_h, evaluations, the SHPLONK fold -- with it): `reps` passes of a[i] = a[i] * b[i] over n elements on `threads`
+ * OpenMP threads, the way halo2's parallelize() splits such loops.  -> seconds (n * reps Montgomery multiplications). */
+double ora_fr_mul_seconds(size_t n, int reps, int threads) {
+    fe *a = (fe *)malloc(n * sizeof(fe)), *b = (fe *)malloc(n * sizeof(fe));
+    if (!a || !b) {
+        free(a);
+        free(b);
+        return -1.0;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        memcpy(a[i].l, FR.r1, 32);
+        memcpy(b[i].l, FR.r1, 32);
+        a[i].l[0] ^= (u64)i * 0x9e3779b97f4a7c15ULL;
+        a[i].l[3] &= 0x0fffffffffffffffULL;
+        b[i].l[1] ^= (u64)(i + 7) * 0xbf58476d1ce4e5b9ULL;
+        b[i].l[3] &= 0x0fffffffffffffffULL;
+    }
+    if (threads < 1) threads = 1;
+    const double t0 = omp_get_wtime();
+    for (int r = 0; r < reps; ++r) {
+#pragma omp parallel for num_threads(threads) schedule(static)
+        for (long i = 0; i < (long)n; ++i) fe_mul(&a[i], &a[i], &b[i], &FR);
+    }
+    const double dt = omp_get_wtime() - t0;
+    volatile u64 sink = a[n / 2].l[0];
+    (void)sink;
+    free(a);
+    free(b);
+    return dt;
+}
 /* a[i] *= g^i (distribute_powers) */
 int ora_fr_distribute_powers(u64 *a_, size_t n, const u64 g[4]) {
     fe *a = (fe *)a_;

@@ -57,6 +57,7 @@ SIGNATURES = {
     "pz_ntt_fr_coeff_extend_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_size_t, VP, C.c_size_t, C.c_uint32, C.c_uint32, VP, VP, VP,
                                              VP]),
     "pz_fr_convert_dev": (C.c_int, [VP, VP, C.c_size_t, C.c_int]),
+    "pz_fr_from_mask_dev": (C.c_int, [VP, VP, C.c_size_t, VP]),
     "pz_mul_mod": (C.c_int, [VP, C.c_uint32, VP, VP, VP, VP, VP]),
     "pz_paillier_trace": (C.c_int, [VP, C.c_uint32, VP, VP, VP, C.c_uint32, VP, C.POINTER(C.c_size_t), VP]),
     "pz_paillier_encrypt": (C.c_int, [VP, C.c_uint32, C.c_size_t, VP, VP, VP, VP, VP, C.c_size_t, VP, VP, VP]),
@@ -110,8 +111,14 @@ SIGNATURES = {
     "pz_shplonk_finish_dev": (C.c_int, [VP, VP, VP, VP, VP]),
     "pz_shplonk_free": (C.c_int, [VP, VP]),
     # patch point D as entry points: keygen + create_proof, one call per transcript round
+    "pz_circuit_structure_dev": (C.c_int, [VP, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, VP, VP, C.c_size_t, C.c_uint32, C.POINTER(VP)]),
+    "pz_structure_info": (C.c_int, [VP] + [C.POINTER(C.c_size_t)] * 9),
+    "pz_structure_arrays": (C.c_int, [VP] + [C.POINTER(VP)] * 6),
+    "pz_structure_free": (C.c_int, [VP]),
     "pz_pk_create": (C.c_int, [VP, VP, VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, C.c_size_t, C.c_size_t, VP, VP, C.c_size_t, VP, VP,
-                               C.c_size_t, C.POINTER(VP)]),
+                               C.c_size_t, C.c_size_t, C.POINTER(VP)]),
+    "pz_pk_create_dev": (C.c_int, [VP, VP, VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, C.c_size_t, C.c_size_t, VP, VP, C.c_size_t, VP, VP,
+                                   C.c_size_t, C.c_size_t, C.POINTER(VP)]),
     "pz_pk_info": (C.c_int, [VP, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                              C.POINTER(C.c_size_t)]),
     "pz_pk_commitments": (C.c_int, [VP, VP, VP]),

@@ -104,7 +104,10 @@ int main(int argc, char** argv) {
     pz_dev_free(cx.c, d_g);
     pz_dev_free(cx.c, d_gl);
     const double t_keygen = now_ms();
-    ProvingKey* pk = keygen(cx, std::move(st), bl, bm);   // st's arrays now live in (or were released by) the key; its scalar fields stay readable
+    // PZ_PROVE_STREAMED_KEY=R: the streamed proving key (only the first R permuted columns keep their extended forms; 0 at config c5)
+    const char* sk = getenv("PZ_PROVE_STREAMED_KEY");
+    const size_t ext_res = sk && *sk ? strtoull(sk, nullptr, 10) : EXT_ALL;
+    ProvingKey* pk = keygen(cx, std::move(st), bl, bm, ext_res);   // st's arrays now live in (or were released by) the key; its scalar fields stay readable
     PZP_CK(pz_sync(cx.c));
     const double keygen_ms = now_ms() - t_keygen;
     Workspace ws = make_workspace(cx, *pk, tile);
@@ -195,7 +198,7 @@ int main(int argc, char** argv) {
     fclose(out.f);
     printf("{\"proofs\": %zu, \"k\": %u, \"enc_bits\": %llu, \"n_adv\": %zu, \"n_lk\": %zu, \"cosets\": 3, \"pipelined_witness\": %s, \"keygen_ms\": %.1f, \"setup_ms\": %.1f, "
            "\"best_proof_ms\": %.2f, \"mean_proof_ms\": %.2f, \"of_which_witness_ms\": %.2f, \"quotient_degree_ok\": %s}\n",
-           proofs, st.k, (unsigned long long)enc_bits, A, st.n_lk, pipeline ? "true" : "false", keygen_ms, t_keygen - t_setup, best,
+           proofs, st.k, (unsigned long long)enc_bits, A, st.n_lk, pk->streamed ? "true" : "false", pipeline ? "true" : "false", keygen_ms, t_keygen - t_setup, best,
            proofs > 1 ? sum_after_first / (double)(proofs - 1) : best, witness_ms, degree_ok ? "true" : "false");
     cx.release();
     if (pipeline) pz_free(cw.c);

@@ -12,7 +12,7 @@ use std::collections::HashMap;
 use std::sync::Mutex;
 
 /// `PZ_ABI_VERSION` this crate was written against (include/pz.h)
-pub const ABI: c_int = 5;
+pub const ABI: c_int = 6;
 
 pub struct Ctx(pub *mut pz_ctx);
 unsafe impl Send for Ctx {}
@@ -116,7 +116,7 @@ impl DeviceKey {
         let mut pk: *mut pz_pk = core::ptr::null_mut();
         check(unsafe {
             pz_pk_create(ctx(), lagrange, monomial, k, lookup_bits, blinding_factors, max_rows, n_adv, n_lk, selectors.as_ptr(), constants.as_ptr(),
-                         constants.len() / 4, map_col.as_ptr(), map_row.as_ptr(), 64, &mut pk)
+                         constants.len() / 4, map_col.as_ptr(), map_row.as_ptr(), 64, usize::MAX /* PZ_PK_EXT_ALL */, &mut pk)
         });
         let (mut a, mut b, mut c, mut d, mut e) = (0usize, 0usize, 0usize, 0usize, 0usize);
         check(unsafe { pz_pk_info(pk, &mut a, &mut b, &mut c, &mut d, &mut e) });
@@ -133,6 +133,79 @@ impl Drop for DeviceKey {
     fn drop(&mut self) {
         unsafe { pz_pk_free(self.pk) };
     }
+}
+
+impl DeviceKey {
+    /// A NEW MESSAGE of the reference's circuit (its bits are circuit structure: paillier.rs:50-55 -> pow_mod_fixed_exp) from the library
+    /// alone: the structure generated on the device (`pz_circuit_structure_dev`: what halo2's keygen would extract by synthesising
+    /// bench.rs:33-75 once), the key built from its device arrays (`pz_pk_create_dev`: nothing crosses PCIe), the structure released.
+    /// -> (key, column starts for `pz_circuit_expand_cols_dev` as a device pointer owner, n_adv, n_lk, n_steps_g, n_steps_r).
+    /// `ext_resident_cols`: `usize::MAX` = extended key resident; 0 = the streamed proving key (BASELINE config c5: 3072-bit, k = 19).
+    pub fn for_message(lagrange: *const pz_bases, monomial: *const pz_bases, k: u32, lookup_bits: u32, m: &[u64], n: &[u64],
+                       minimum_rows: usize, ext_resident_cols: usize) -> (Self, MessageShape) {
+        let mut st: *mut pz_structure = core::ptr::null_mut();
+        check(unsafe { pz_circuit_structure_dev(ctx(), 0, n.len() as u32, 64, lookup_bits, k, m.as_ptr(), n.as_ptr(), minimum_rows, 6, &mut st) });
+        let (mut n_adv, mut filled, mut n_lk, mut max_rows, mut n_const, mut cells, mut lks, mut sg, mut sr) = (0usize, 0usize, 0usize, 0usize, 0usize, 0usize, 0usize, 0usize, 0usize);
+        check(unsafe { pz_structure_info(st, &mut n_adv, &mut filled, &mut n_lk, &mut max_rows, &mut n_const, &mut cells, &mut lks, &mut sg, &mut sr) });
+        let (mut d_sel, mut d_mc, mut d_mr, mut d_starts, mut consts, mut starts_h) =
+            (core::ptr::null::<u8>(), core::ptr::null::<u32>(), core::ptr::null::<u32>(), core::ptr::null::<u64>(), core::ptr::null::<u64>(), core::ptr::null::<u64>());
+        check(unsafe { pz_structure_arrays(st, &mut d_sel, &mut d_mc, &mut d_mr, &mut d_starts, &mut consts, &mut starts_h) });
+        let mut pk: *mut pz_pk = core::ptr::null_mut();
+        check(unsafe {
+            pz_pk_create_dev(ctx(), lagrange, monomial, k, lookup_bits, 6, max_rows, n_adv, n_lk, d_sel, consts, n_const, d_mc, d_mr, 64, ext_resident_cols, &mut pk)
+        });
+        // K4 needs the break points after the structure is gone: keep a device copy of the (n_adv + 1)-entry table
+        let mut d_copy: *mut core::ffi::c_void = core::ptr::null_mut();
+        check(unsafe { pz_dev_alloc(ctx(), (n_adv + 1) * 8, &mut d_copy) });
+        check(unsafe { pz_upload(ctx(), d_copy, starts_h as *const core::ffi::c_void, (n_adv + 1) * 8) });
+        check(unsafe { pz_sync(ctx()) });
+        check(unsafe { pz_structure_free(st) });
+        let (mut a, mut b, mut c, mut d, mut e) = (0usize, 0usize, 0usize, 0usize, 0usize);
+        check(unsafe { pz_pk_info(pk, &mut a, &mut b, &mut c, &mut d, &mut e) });
+        (DeviceKey { pk, n_fixed: a, n_perm_cols: b, n_sets: c, blinding_words: d, evals_words: e },
+         MessageShape { d_col_starts: d_copy as *const u64, n_adv, n_lk, max_rows, n_steps_g: sg, n_steps_r: sr })
+    }
+}
+/// what K3 / K4 need to write the witness of one message shape (`pz_paillier_encrypt_dev`, `pz_circuit_expand_cols_dev`)
+pub struct MessageShape {
+    pub d_col_starts: *const u64,
+    pub n_adv: usize,
+    pub n_lk: usize,
+    pub max_rows: usize,
+    pub n_steps_g: usize,
+    pub n_steps_r: usize,
+}
+
+/// The two-context recipe: proofs are independent, so while `prove` runs proof i's seven phases on the key's
+/// context, a SECOND host thread writes proof i + 1's witness (K3's four workgroups + K4's stores) into the other column slot on a second
+/// context -- distinct `pz_ctx` run concurrently (pz.h), and the stepper blocks its own thread only.  `witness(i, ctx, d_cols)` queues
+/// K3 + K4 of proof i on `ctx` and returns after `pz_sync(ctx)`; `prove(i, d_cols)` is the caller's `ProofSession` walk with its
+/// transcript.  Measured through the same calls from Python threads at config c2: the stepper's serial 8xx ms per proof becomes the
+/// compiled prover's 74x (profiles/r06_stepper_two_contexts.json).
+pub fn prove_pipelined<W, P>(proofs: usize, slots: [*mut u64; 2], witness: W, mut prove: P)
+where
+    W: Fn(usize, *mut pz_ctx, *mut u64) + Sync,
+    P: FnMut(usize, *mut u64),
+{
+    struct SendPtr(*mut u64);
+    unsafe impl Send for SendPtr {}
+    let wctx = new_ctx();
+    witness(0, wctx, slots[0]);
+    for i in 0..proofs {
+        std::thread::scope(|s| {
+            if i + 1 < proofs {
+                let next = SendPtr(slots[(i + 1) & 1]);
+                let w = &witness;
+                let wc = Ctx(wctx);
+                s.spawn(move || {
+                    let next = next;
+                    w(i + 1, wc.0, next.0)
+                });
+            }
+            prove(i, slots[i & 1]);
+        });
+    }
+    unsafe { pz_free(wctx) };
 }
 
 /// one proof in flight on a `DeviceKey`: every method runs a phase on the device and returns what the transcript absorbs before the next

@@ -13,6 +13,7 @@ use core::ffi::{c_char, c_int, c_void};
 #[repr(C)] pub struct pz_bases   { _p: [u8; 0] }
 #[repr(C)] pub struct pz_shplonk { _p: [u8; 0] }
 #[repr(C)] pub struct pz_pk      { _p: [u8; 0] }
+#[repr(C)] pub struct pz_structure { _p: [u8; 0] }
 #[repr(C)] pub struct pz_proof   { _p: [u8; 0] }
 
 extern "C" {
@@ -22,7 +23,7 @@ extern "C" {
     pub fn pz_last_hip_error(ctx: *const pz_ctx) -> *const c_char;
     pub fn pz_set_stream(ctx: *mut pz_ctx, hip_stream: *mut c_void) -> c_int;
     pub fn pz_sync(ctx: *mut pz_ctx) -> c_int;
-    pub fn pz_abi_version() -> c_int;       // == PZ_ABI_VERSION (5); checked once in pz_rt::ctx()
+    pub fn pz_abi_version() -> c_int;       // == PZ_ABI_VERSION (6); checked once in pz_rt::ctx()
 
     // device memory + context ordering: what lets the columns of a proof stay in HBM (patch points C / D, section 5a)
     pub fn pz_dev_alloc(ctx: *mut pz_ctx, bytes: usize, d_out: *mut *mut c_void) -> c_int;
@@ -72,6 +73,7 @@ extern "C" {
                                       out_stride: usize, log_n: u32, log_e: u32, omega_n: *const u64, omega_n_inv: *const u64,
                                       n_inv: *const u64, coset_gens: *const u64) -> c_int;
     pub fn pz_fr_convert_dev(ctx: *mut pz_ctx, d_a: *mut u64, n: usize, to_mont: c_int) -> c_int;
+    pub fn pz_fr_from_mask_dev(ctx: *mut pz_ctx, d_mask: *const u8, n: usize, d_out: *mut u64) -> c_int;
 
     // K3  (replaces num-bigint mul / div_rem inside BigUintChip::{mul_mod, pow_mod_fixed_exp})
     pub fn pz_mul_mod(ctx: *mut pz_ctx, limbs: u32, a: *const u64, b: *const u64, modulus: *const u64,
@@ -112,10 +114,22 @@ extern "C" {
     pub fn pz_shplonk_free(ctx: *mut pz_ctx, state: *mut pz_shplonk) -> c_int;
 
     // patch point D as entry points: keygen + create_proof, one call per transcript round (section 5d)
+    pub fn pz_circuit_structure_dev(ctx: *mut pz_ctx, kind: c_int, limbs_n: u32, limb_bits: u32, lookup_bits: u32, k: u32, exp_g: *const u64,
+                                    exp_r: *const u64, minimum_rows: usize, blinding_factors: u32, out: *mut *mut pz_structure) -> c_int;
+    pub fn pz_structure_info(st: *const pz_structure, n_adv: *mut usize, n_adv_filled: *mut usize, n_lk: *mut usize, max_rows: *mut usize,
+                             n_constants: *mut usize, n_cells: *mut usize, n_lookups: *mut usize, n_steps_g: *mut usize,
+                             n_steps_r: *mut usize) -> c_int;
+    pub fn pz_structure_arrays(st: *const pz_structure, d_selectors: *mut *const u8, d_map_col: *mut *const u32, d_map_row: *mut *const u32,
+                               d_col_starts: *mut *const u64, constants: *mut *const u64, col_starts_host: *mut *const u64) -> c_int;
+    pub fn pz_structure_free(st: *mut pz_structure) -> c_int;
     pub fn pz_pk_create(ctx: *mut pz_ctx, bases_lagrange: *const pz_bases, bases_monomial: *const pz_bases, k: u32, lookup_bits: u32,
                         blinding_factors: u32, max_rows: usize, n_adv: usize, n_lk: usize, selectors: *const u8,
                         constants: *const u64, n_constants: usize, map_col: *const u32, map_row: *const u32, tile: usize,
-                        out: *mut *mut pz_pk) -> c_int;
+                        ext_resident_cols: usize, out: *mut *mut pz_pk) -> c_int;
+    pub fn pz_pk_create_dev(ctx: *mut pz_ctx, bases_lagrange: *const pz_bases, bases_monomial: *const pz_bases, k: u32, lookup_bits: u32,
+                            blinding_factors: u32, max_rows: usize, n_adv: usize, n_lk: usize, d_selectors: *const u8,
+                            constants: *const u64, n_constants: usize, d_map_col: *const u32, d_map_row: *const u32, tile: usize,
+                            ext_resident_cols: usize, out: *mut *mut pz_pk) -> c_int;
     pub fn pz_pk_info(pk: *const pz_pk, n_fixed: *mut usize, n_perm_cols: *mut usize, n_sets: *mut usize, blinding_words: *mut usize,
                       evals_words: *mut usize) -> c_int;
     pub fn pz_pk_commitments(pk: *const pz_pk, fixed_affine: *mut u64, sigma_affine: *mut u64) -> c_int;

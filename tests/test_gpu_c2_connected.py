@@ -1,0 +1,144 @@
+"""BASELINE config c2 ITSELF (2048-bit n, k = 17, lookup_bits 16: /root/reference/src/bench.rs:161-171 at the benchmark's size) as a
+connected proof under the driver's `pytest -m gpu` -- not only in bench.py's output: (1) the Python-driven prover (bench.py's headline
+loop: ConnectedWorkload with the next witness on a second context), (2) the library's stepper (pz_pk_create_dev on the device-resident
+structure + pz_proof_*, one call per transcript round) -- each proof checked as the verifier would (oracle/verifier.py: degree bound,
+h(x)(x^n - 1) = the expression of the evaluations, SHPLONK's identity over the proof's commitments), and (3) the streamed proving key at
+this size: same proof bytes as the resident key.  One structure and one SRS serve the module; every test builds (and frees) its own key,
+so at most one 116-GB key is resident at a time."""
+import numpy as np
+import pytest
+
+from oracle import pyref as P
+from oracle import verifier as V
+
+pytestmark = pytest.mark.gpu
+
+BITS, K, LB, SEED = 2048, 17, 16, 0x5043
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import paillier_halo2_amd as pz
+
+    e = pz.Engine(0)
+    e.bind_torch_stream()
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def srs(eng):
+    """(bases_lagrange, bases_monomial, toxic scalar) as ConnectedWorkload derives them from the seed"""
+    import random
+
+    import torch
+
+    from paillier_halo2_amd import consts
+
+    n = 1 << K
+    s_tox = random.Random(SEED ^ 0x535253).randrange(2, consts.FR_R)
+    M = consts.fr_mont_limbs
+    d_g = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    d_gl = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    eng.srs_setup_g1_dev(K, M(s_tox), M(consts.fr_omega(K)), d_g.data_ptr(), d_gl.data_ptr())
+    eng.sync()
+    bl, bm = eng.load_bases_dev(d_gl.data_ptr(), n), eng.load_bases_dev(d_g.data_ptr(), n)
+    del d_g, d_gl
+    yield bl, bm, s_tox
+    bl.free()
+    bm.free()
+
+
+def _workload(eng, srs, **kw):
+    import torch
+
+    import bench_connected
+
+    return bench_connected.ConnectedWorkload(eng, torch, BITS, K, SEED, srs=srs, **kw)
+
+
+def test_c2_connected_proof_verifies(eng, cref, srs):
+    wl = _workload(eng, srs)
+    try:
+        assert (wl.A, wl.cs.n_adv_used, wl.Lk, wl.cs.max_rows, wl.minimum_rows) == (3034, 3033, 84, (1 << K) - 9, 20)
+        wl.run(3, timed=False)                      # three messages' witnesses through the two slots (the next one under the advice commitments)
+        v = wl.verify(cref)
+        assert v["verified"] is True, v
+        assert v["commitments"] == wl.A + 4 * wl.Lk + wl.pk.n_sets + 1 + 3 + 2 and v["evaluations"] > 23000
+    finally:
+        wl.release()
+
+
+def test_c2_streamed_key_same_proof(eng, cref, srs):
+    """the streamed proving key at the benchmark's size: 39 GB of extended forms less per... all of them: 77 GB less resident, the same
+    commitments and evaluations, and it verifies"""
+    ref = None
+    for R_ in (None, 0):
+        wl = _workload(eng, srs, pipeline=False, streamed_key=R_)
+        try:
+            pr = wl.step(timed=False)
+            import torch
+
+            torch.cuda.synchronize()
+            if ref is None:
+                ref = pr
+                assert wl.memory_gb["of_which_extended_forms"] > 70
+            else:
+                assert wl.memory_gb["of_which_extended_forms"] == 0.0
+                for f in ref.commitments:
+                    assert np.array_equal(pr.commitments[f], ref.commitments[f]), f
+                for f in ref.evals:
+                    assert np.array_equal(pr.evals[f], ref.evals[f]), f
+                assert wl.verify(cref)["verified"] is True
+        finally:
+            wl.release()
+
+
+def test_c2_library_stepper_verifies(eng, cref, srs):
+    """structure on the device (pz_circuit_structure_dev) -> pz_pk_create_dev -> K3 -> K4 -> pz_proof_* with a hashing transcript, at c2"""
+    import torch
+
+    import bench
+    from paillier_halo2_amd import consts, prover, prover_native
+
+    bl, bm, s_tox = srs
+    n, Ln = 1 << K, BITS // 64
+    nn, g, m, r = bench.synth_inputs(BITS, SEED)
+    ns = prover_native.NativeStructure(eng, "encrypt", BITS, 64, LB, K, exp_g=m, exp_r=nn)
+    assert (ns.n_adv, ns.n_adv_used, ns.n_lk) == (3034, 3033, 84)
+    key = ns.key(bl, bm)
+    lim = lambda x, l: consts.int_to_limbs(x, l)
+    cap = ns.n_steps_g + ns.n_steps_r + 1
+    d_steps = torch.zeros((cap, 4, 2 * Ln), dtype=torch.int64, device="cuda")
+    d_mod = torch.from_numpy(lim(nn * nn, 2 * Ln).astype(np.int64)).cuda()
+    cols = torch.zeros((ns.m, n, 4), dtype=torch.int64, device="cuda")
+    c, _, _ = eng.paillier_encrypt_dev(Ln, lim(nn, Ln), lim(g, Ln), lim(m, Ln), lim(r, Ln), d_steps.data_ptr(), cap)
+    inputs = np.concatenate([lim(nn, Ln), lim(g, Ln), lim(m, Ln), lim(r, Ln), np.asarray(c[0], dtype=np.uint64)])
+    eng.circuit_expand_cols_dev(0, Ln, 64, LB, inputs, d_steps.data_ptr(), ns.n_steps_g, ns.n_steps_r, d_mod.data_ptr(), cols.data_ptr(),
+                                cols[ns.n_adv].data_ptr(), ns.d_starts, ns.n_adv, ns.max_rows, ns.max_rows, n)
+    A, Lk, m_ = ns.n_adv, ns.n_lk, ns.m
+    ns.free()
+    try:
+        tr = prover.HashTranscript(b"c2-stepper")
+        pr = prover_native.create_proof(key, cols.data_ptr(), tr, seed=17)
+        ch = tr.challenges()
+        R = P.FR_R
+
+        def ints(a):
+            a = np.asarray(a, dtype=np.uint64)
+            flat = cref.fr_mont_to_ints(a.reshape(-1, 4))
+            p_ = a.shape[1]
+            return [flat[i * p_:(i + 1) * p_] for i in range(a.shape[0])]
+
+        ev = {k_: ints(v_) for k_, v_ in pr.evals.items()}
+        assert pr.h_degree_ok
+        assert V.expected_h(K, 6, A, Lk, prover.CHUNK, ev, ch.beta, ch.gamma, ch.y, ch.x, prover.DELTA) == ev["h"][0][0]
+        xn = pow(ch.x, n, R)
+        hc = cref.g1_normalize(cref.msm_g1(cref.fr_ints_to_mont([pow(xn, i, R) for i in range(3)]), pr.commitments["h"]))
+        vk = key.vk_commitments()
+        com = dict(pr.commitments)
+        com.update(fixed=vk["fixed"], sigma=vk["sigma"], h=[hc])
+        assert V.shplonk_check(cref, prover.query_layout(A, Lk, m_, key.n_sets), prover.rotation_points(prover.Domain(K, 6), ch.x), com, ev,
+                               ch.sh_y, ch.sh_v, ch.sh_u, pr.commitments["w1"][0], pr.commitments["w2"][0], s_tox)
+    finally:
+        key.free()

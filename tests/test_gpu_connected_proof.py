@@ -542,6 +542,41 @@ def test_library_stepper_is_the_same_prover(eng, cref, world):
         key.free()
 
 
+def test_stepper_keys_from_device_arrays_and_streamed(eng, cref, world):
+    """pz_pk_create_dev (the structure's arrays already on the device: no host copy, no PCIe crossing) builds the SAME key as pz_pk_create
+    (equal verifying-key commitments); and the library's streamed proving key (ext_resident_cols = 0 / 10: extended forms re-derived per
+    tile inside pz_proof_quotient) gives the resident key's proof byte for byte -- same seed, same challenges"""
+    import dataclasses
+
+    import torch
+
+    from paillier_halo2_amd import prover_native
+
+    pk = world["pk"]
+    st_dev = dataclasses.replace(pk.st, selectors=torch.from_numpy(np.ascontiguousarray(pk.st.selectors)).cuda(),
+                                 map_col=torch.from_numpy(np.ascontiguousarray(pk.st.map_col).view(np.int32)).cuda(),
+                                 map_row=torch.from_numpy(np.ascontiguousarray(pk.st.map_row).view(np.int32)).cuda())
+    vk_py = pk.vk_commitments()
+    ref = None
+    for st_, R_ in ((pk.st, None), (st_dev, None), (st_dev, 0), (pk.st, 10)):
+        key = prover_native.NativeKey(eng, st_, pk.bases_lagrange, pk.bases_monomial, tile=8, ext_resident_cols=R_)
+        try:
+            vk = key.vk_commitments()
+            assert np.array_equal(vk["fixed"], vk_py["fixed"]) and np.array_equal(vk["sigma"], vk_py["sigma"])
+            pr = prover_native.create_proof(key, world["witness"]().data_ptr(), world["ch"], seed=21)
+            if ref is None:
+                ref = pr
+                assert _verify(cref, world, pr) == (True, True, True)
+            else:
+                for f in ref.commitments:
+                    assert np.array_equal(pr.commitments[f], ref.commitments[f]), (R_, f)
+                for f in ref.evals:
+                    assert np.array_equal(pr.evals[f], ref.evals[f]), (R_, f)
+                assert pr.h_degree_ok
+        finally:
+            key.free()
+
+
 def test_stepper_shape_with_many_lookup_columns(eng, cref):
     """the stepper's commitment staging buffer was sized (m + S + 8) points while the lookups phase writes 2 n_lk --
     more once n_lk > 3 n_adv + 19.  pz_pk_create accepts any n_adv, n_lk >= 1, so such a shape must prove without touching memory it
