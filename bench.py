@@ -1680,6 +1680,18 @@ def connected_line(args, R):
             out["compiled_prover"] = {"error": repr(ex)[:600]}
     del cw
     gc.collect()
+    # ---- ... and a NEW KEY AND MESSAGE per proof from compiled code alone: structure generated by the library on the device
+    if extras and headline_cfg and not args.no_dropin and not args.no_fresh_key:
+        try:
+            t_p = time.time()
+            out["fresh_message_cpp"] = bench_connected.cpp_fresh_message(args.enc_bits, args.k, args.lookup_bits, args.seed, steps=4, minimum_rows=args.minimum_rows,
+                                                                         verify_with=_cref if ver is not None else None, log=log)
+            log("fresh message, compiled prover %.1fs: %.2f s per step %s, verified %s" % (
+                time.time() - t_p, out["fresh_message_cpp"]["s_per_step"], out["fresh_message_cpp"]["of_which"], out["fresh_message_cpp"].get("verified")))
+            if out["fresh_message_cpp"].get("verified") is False:
+                out["comparable"] = False
+        except Exception as ex:
+            out["fresh_message_cpp"] = {"error": repr(ex)[:600]}
     # ---- the same through the UNIFORM-shape circuit (row f4): ONE proving key for every message of a key -- the proofs of this loop are
     # of DISTINCT messages (the reference's circuit needs a new structure + keygen per message: `fresh_message`)
     if extras and headline_cfg and not args.no_c2u:
@@ -1851,7 +1863,8 @@ def main():
                    "emulate_ranks": em, "emulate_ranks_columns": em_cols}
         elif args.emulate_world > 1:
             res = pzd.emulate_sharded_msm(eng, torch, args.emulate_world, args.log_n, args.steps, args.warmup, log, scalars=args.msm_scalars,
-                                          share_window_bits=int(os.environ.get("PZ_SHARE_WINDOW_BITS", "0")))
+                                          share_window_bits=int(os.environ.get("PZ_SHARE_WINDOW_BITS", "0")),
+                                          window_split_bits=int(os.environ.get("PZ_WINDOW_SPLIT_BITS", "0")))
         else:
             res = pzd.bench_sharded_msm(eng, torch, dist if use_dist else None, rank, world, args.log_n, args.steps,
                                         args.warmup, barrier, log, split=args.msm_split, scalars=args.msm_scalars)

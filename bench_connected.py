@@ -65,6 +65,44 @@ def cpp_connected(cw, proofs=4, verify_with=None, log=lambda s: None):
     return out
 
 
+def cpp_fresh_message(enc_bits, k, lookup_bits, seed, steps=4, minimum_rows=20, verify_with=None, log=lambda s: None):
+    """a NEW key pair and message per proof from the COMPILED prover alone (`prove_connected --fresh`): per step the circuit structure
+    generated on the device by the library (pz_circuit_structure_dev), keygen on its device arrays, K3 + K4, create_proof -- the
+    reference's per-message cost (paillier.rs:50-55 makes every message its own circuit; bench.rs:161-171) with no Python in the loop.
+    The last proof is checked by verify_file_proof when verify_with (oracle.cref) is given.  -> dict for the bench line"""
+    import random
+    import tempfile
+    from types import SimpleNamespace
+
+    import bench
+    from paillier_halo2_amd import consts, prover_job
+
+    s_tox = random.Random(seed ^ 0x535253).randrange(2, consts.FR_R)
+    inputs = [bench.synth_inputs(enc_bits, seed + 9001 + i) for i in range(steps)]
+    with tempfile.TemporaryDirectory(prefix="pz_fresh_") as td:
+        params, proof = os.path.join(td, "params.bin"), os.path.join(td, "proof.bin")
+        prover_job.write_fresh_params(params, enc_bits, k, lookup_bits if lookup_bits is not None else k - 1, inputs, s_tox, minimum_rows=minimum_rows,
+                                      seed=13)
+        t0 = time.perf_counter()
+        line = prover_job.run_fresh(params, proof, timeout=900)
+        wall = time.perf_counter() - t0
+        out = {"value": 1e3 / line["mean_step_ms"], "unit": "proofs/s", "steps": steps, "s_per_step": line["mean_step_ms"] / 1e3, "of_which": line["of_which"],
+               "connected": True, "binary_wall_s": wall, "quotient_degree_ok": line["quotient_degree_ok"], "per_step_log": line.get("stderr_tail"),
+               "note": "tests/cpp/prove_connected --fresh: every step a new key pair and message -> circuit structure on the device (pz_circuit_structure_dev) "
+                       "-> keygen on its device arrays (host/create_proof.hpp) -> K3 + K4 -> create_proof, from plain C++ over the C ABI only; device "
+                       "blocks recycled from key to key; mean over the steps after the first"}
+        if verify_with is not None:
+            rec = prover_job.read_proofs(proof)
+            last = "p%d/" % (steps - 1)
+            A, Lk, m_ = (int(x) for x in rec[last + "shape"][0][:3])
+            st = SimpleNamespace(n_adv=A, n_lk=Lk, m=m_, blinding_factors=6)
+            ver = verify_file_proof(verify_with, rec, last, st, k, s_tox)
+            nn, g, m, r = inputs[-1]
+            ver["ciphertext_is_g_m_r_n"] = bool(ver.pop("ciphertext") == pow(g, m, nn * nn) * pow(r, nn, nn * nn) % (nn * nn))
+            out["verified"], out["verification"] = bool(ver["verified"] and ver["ciphertext_is_g_m_r_n"]), ver
+    return out
+
+
 class ConnectedWorkload:
     def __init__(self, eng, torch, enc_bits: int, k: int, seed: int, lookup_bits=None, log=lambda s: None, tile: int = 64,
                  circuit: str = "encrypt", pipeline=None, cosets=None, srs=None, trim: bool = True, minimum_rows: int = 20,
@@ -424,7 +462,8 @@ def verify_file_proof(cref, rec, prefix, st, k, s_tox):
     shapes = com["advice"].shape == (A, 8) and com["perm_z"].shape == (S, 8) and com["h"].shape == (3, 8)
     xn = pow(ch["x"], n, R)
     hc = cref.g1_normalize(cref.msm_g1(cref.fr_ints_to_mont([pow(xn, i, R) for i in range(3)]), com["h"]))
-    com.update(fixed=rec["vk/fixed"], sigma=rec["vk/sigma"], h=[hc])
+    vkp = prefix if (prefix + "vk/fixed") in rec else ""          # (--fresh: every proof has its own key)
+    com.update(fixed=rec[vkp + "vk/fixed"], sigma=rec[vkp + "vk/sigma"], h=[hc])
     lay = prover.query_layout(A, Lk, m, S)
     pts = prover.rotation_points(prover.Domain(k, st.blinding_factors), ch["x"])
     opening = bool(V.shplonk_check(cref, lay, pts, com, ev, ch["sh_y"], ch["sh_v"], ch["sh_u"], com["w1"][0], com["w2"][0], s_tox))

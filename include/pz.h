@@ -90,6 +90,13 @@ int pz_abi_version(void);
  * columns can stay in HBM from K4 through K1 and K2 (patch points C / D of INTEGRATION.md: bench.rs:161-171's create_proof).
  * ------------------------------------------------------------------------------------------- */
 int pz_dev_alloc(pz_ctx* ctx, size_t bytes, void** d_out);
+/* block cache of pz_dev_alloc / pz_dev_free (off by default: max_bytes = 0): freed blocks of 32 MiB and more are KEPT by the context, up
+ * to max_bytes in all, and handed to the next pz_dev_alloc of that size (or up to an eighth smaller) instead of going back to the driver.
+ * For a caller that proves message after message of the reference's circuit -- a new 116-GB proving key each (paillier.rs:50-55 makes
+ * every message its own circuit) -- the driver's allocation cost (seconds per key) is then paid once: pz_pk_create / pz_pk_free allocate
+ * through these functions, with column counts rounded up to 64 so that keys of nearly equal shape ask for identical sizes.  Lowering the
+ * limit releases what exceeds it; the library releases the cache itself when one of its own allocations runs out of memory. */
+int pz_dev_cache_limit(pz_ctx* ctx, size_t max_bytes);
 /* waits for the context's queued work, then frees */
 int pz_dev_free(pz_ctx* ctx, void* d);
 /* host -> device on the context's stream; returns when the host buffer may be reused */

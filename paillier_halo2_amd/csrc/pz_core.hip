@@ -95,6 +95,7 @@ extern "C" int pz_free(pz_ctx* ctx) {
     if (!ctx) return PZ_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    pz_dev_cache_trim(ctx, 0);
     for (auto& w : ctx->ws)
         if (w.d) (void)hipFree(w.d);
     for (auto& t : ctx->pow_tables) {
@@ -144,12 +145,57 @@ extern "C" int pz_set_stream(pz_ctx* ctx, void* s) {
 // ---- device memory for hosts that own no HIP runtime of their own (a Rust prover behind the FFI; tests/cpp) ------------
 // Plain hipMalloc'd buffers; the `_dev` entry points take them as they are.  Transfers are ordered on the context's stream:
 // pz_upload returns once the host buffer may be reused, pz_download once the data has arrived.
+#define PZ_DEV_CACHE_MIN ((size_t)32 << 20)
+void pz_dev_cache_trim(pz_ctx* ctx, size_t keep_bytes) {   // largest blocks go first
+    while (ctx->dev_cache_bytes > keep_bytes && !ctx->dev_cache.empty()) {
+        size_t big = 0;
+        for (size_t i = 1; i < ctx->dev_cache.size(); ++i)
+            if (ctx->dev_cache[i].second > ctx->dev_cache[big].second) big = i;
+        (void)hipFree(ctx->dev_cache[big].first);
+        ctx->dev_cache_bytes -= ctx->dev_cache[big].second;
+        ctx->dev_cache.erase(ctx->dev_cache.begin() + (long)big);
+    }
+}
+hipError_t pz_hip_malloc(pz_ctx* ctx, void** d, size_t bytes) {
+    hipError_t e = hipMalloc(d, bytes);
+    if (e == hipErrorOutOfMemory && ctx && !ctx->dev_cache.empty()) {
+        (void)hipGetLastError();
+        pz_dev_cache_trim(ctx, 0);
+        e = hipMalloc(d, bytes);
+    }
+    return e;
+}
+extern "C" int pz_dev_cache_limit(pz_ctx* ctx, size_t max_bytes) {
+    if (!ctx) return PZ_ERR_INVALID;
+    PZ_ENTER(ctx);
+    ctx->dev_cache_limit = max_bytes;
+    if (ctx->dev_cache_bytes > max_bytes) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        pz_dev_cache_trim(ctx, max_bytes);
+    }
+    return PZ_OK;
+}
 extern "C" int pz_dev_alloc(pz_ctx* ctx, size_t bytes, void** d_out) {
     if (!ctx || !d_out) return PZ_ERR_INVALID;
     *d_out = nullptr;
     if (!bytes) return PZ_OK;
     PZ_ENTER(ctx);
-    HIPCHK(ctx, hipMalloc(d_out, bytes));
+    if (ctx->dev_cache_limit && bytes >= PZ_DEV_CACHE_MIN) {
+        int best = -1;   // best fit: the smallest cached block that holds the request and is at most an eighth larger
+        for (size_t i = 0; i < ctx->dev_cache.size(); ++i) {
+            const size_t c = ctx->dev_cache[i].second;
+            if (c >= bytes && c - bytes <= bytes / 8 && (best < 0 || c < ctx->dev_cache[(size_t)best].second)) best = (int)i;
+        }
+        if (best >= 0) {
+            *d_out = ctx->dev_cache[(size_t)best].first;
+            ctx->dev_live[*d_out] = ctx->dev_cache[(size_t)best].second;
+            ctx->dev_cache_bytes -= ctx->dev_cache[(size_t)best].second;
+            ctx->dev_cache.erase(ctx->dev_cache.begin() + best);
+            return PZ_OK;
+        }
+    }
+    HIPCHK(ctx, pz_hip_malloc(ctx, d_out, bytes));
+    if (ctx->dev_cache_limit && bytes >= PZ_DEV_CACHE_MIN) ctx->dev_live[*d_out] = bytes;
     return PZ_OK;
 }
 extern "C" int pz_dev_free(pz_ctx* ctx, void* d) {
@@ -157,6 +203,16 @@ extern "C" int pz_dev_free(pz_ctx* ctx, void* d) {
     if (!d) return PZ_OK;
     PZ_ENTER(ctx);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // kernels queued by this context may still use it
+    auto it = ctx->dev_live.find(d);
+    if (it != ctx->dev_live.end()) {
+        const size_t bytes = it->second;
+        ctx->dev_live.erase(it);
+        if (ctx->dev_cache_limit && ctx->dev_cache_bytes + bytes <= ctx->dev_cache_limit) {
+            ctx->dev_cache.push_back({d, bytes});
+            ctx->dev_cache_bytes += bytes;
+            return PZ_OK;
+        }
+    }
     HIPCHK(ctx, hipFree(d));
     return PZ_OK;
 }
@@ -286,7 +342,7 @@ int pz_ws_get(pz_ctx* ctx, int slot, size_t bytes, void** out) {
         w.d = nullptr;
         w.cap = 0;
         size_t want = bytes + bytes / 8 + 256;
-        HIPCHK(ctx, hipMalloc(&w.d, want));
+        HIPCHK(ctx, pz_hip_malloc(ctx, &w.d, want));
         w.cap = want;
     }
     *out = w.d;
@@ -336,7 +392,7 @@ int pz_get_pow_table(pz_ctx* ctx, const uint64_t base[4], size_t n, void** d_out
         t.d_raw = reuse_raw;
         t.raw_valid = false;
     } else {
-        HIPCHK(ctx, hipMalloc(&t.d, n * 32));
+        HIPCHK(ctx, pz_hip_malloc(ctx, &t.d, n * 32));
         t.cap = n;
     }
     Fr b, i0;
@@ -364,7 +420,7 @@ int pz_get_pow_table_raw(pz_ctx* ctx, const uint64_t base[4], size_t n, void** d
     for (auto& t : ctx->pow_tables)
         if (t.d == d) {
             if (!t.d_raw) {
-                HIPCHK(ctx, hipMalloc(&t.d_raw, t.cap * 72));
+                HIPCHK(ctx, pz_hip_malloc(ctx, &t.d_raw, t.cap * 72));
                 t.raw_valid = false;
             }
             if (!t.raw_valid) {

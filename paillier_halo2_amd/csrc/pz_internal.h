@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -73,6 +74,12 @@ struct pz_ctx {
     // scatter kernels' position checks, pz_msm.hip); read and cleared by pz_check_async after a synchronisation
     volatile unsigned* async_err_h = nullptr;
     volatile unsigned* async_err_d = nullptr;   // the same word as the device addresses it
+    // pz_dev_alloc / pz_dev_free block cache (pz_dev_cache_limit; off by default): freed blocks of 32 MiB and more are kept, up to
+    // dev_cache_limit bytes, and handed to the next request of (nearly) that size -- a caller that builds a 116-GB proving key per
+    // message pays the driver's allocation cost once, not per key
+    size_t dev_cache_limit = 0, dev_cache_bytes = 0;
+    std::vector<std::pair<void*, size_t>> dev_cache;
+    std::map<void*, size_t> dev_live;   // sizes of the live pz_dev_alloc blocks (only tracked while the cache is on)
     std::recursive_mutex mu;   // one context is serialised internally: entry points may be called from any thread
 };
 
@@ -108,6 +115,9 @@ static inline int pz_hip_fail(pz_ctx* ctx, hipError_t e, const char* what) {
 
 // grow-only workspace slot; contents are NOT preserved across growth
 int pz_ws_get(pz_ctx* ctx, int slot, size_t bytes, void** out);
+// hipMalloc for the library's own buffers: on out-of-memory the pz_dev_alloc block cache is released and the request repeated once
+hipError_t pz_hip_malloc(pz_ctx* ctx, void** d, size_t bytes);
+void pz_dev_cache_trim(pz_ctx* ctx, size_t keep_bytes);
 // cached base^i table (device, Fr Montgomery)
 int pz_get_pow_table(pz_ctx* ctx, const uint64_t base[4], size_t n, void** d_out, const uint64_t* init = nullptr);
 // the same table as raw 9 x 29-bit limbs per entry (n x 9 u32), cached beside it

@@ -1329,7 +1329,7 @@ extern "C" int pz_bases_load_g1(pz_ctx* ctx, const uint64_t* bases_affine, size_
     b->c = c;
     b->nwin = nwin;
     b->device = ctx->device;
-    hipError_t e = hipMalloc(&b->d_table, (size_t)nwin * n_points * 64);
+    hipError_t e = pz_hip_malloc(ctx, &b->d_table, (size_t)nwin * n_points * 64);
     if (e != hipSuccess) {
         delete b;
         return pz_hip_fail(ctx, e, "hipMalloc(table)");

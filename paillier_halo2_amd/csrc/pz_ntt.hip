@@ -644,7 +644,7 @@ static int get_ext_pre_tables(pz_ctx* ctx, const uint64_t* coset_gens, size_t E,
             return PZ_OK;
         }
     void* prev = nullptr;
-    HIPCHK(ctx, hipMalloc(&prev, E * n * 72));   // constant pairs
+    HIPCHK(ctx, pz_hip_malloc(ctx, &prev, E * n * 72));   // constant pairs
     for (size_t r = 0; r < E; ++r) {
         void* t;
         PZCHK(pz_get_pow_table(ctx, coset_gens + 4 * r, n, &t, scale));
@@ -702,7 +702,7 @@ static int get_ext_abs_tables(pz_ctx* ctx, const uint64_t* coset_gens, size_t E,
             return PZ_OK;
         }
     void* d = nullptr;
-    HIPCHK(ctx, hipMalloc(&d, (E * n + E * R) * 72));
+    HIPCHK(ctx, pz_hip_malloc(ctx, &d, (E * n + E * R) * 72));
     u32* ep = (u32*)d;
     u32* stw = ep + E * n * 18;
     void* twm;

@@ -80,6 +80,7 @@ int pk_create(pz_ctx* ctx, const pz_bases* bases_lagrange, const pz_bases* bases
     pz_pk* pk = new (std::nothrow) pz_pk;
     if (!pk) return PZ_ERR_OOM;
     pk->mem.c = ctx;
+    pk->mem.round_cols = true;   // identical block sizes for keys of nearly equal shape: what pz_dev_cache_limit's cache can serve
     const int rc = guarded_raw([&] {
         pzp::Structure st;
         st.k = k; st.lookup_bits = lookup_bits; st.blinding_factors = blinding_factors; st.max_rows = max_rows; st.n_adv = n_adv; st.n_lk = n_lk;

@@ -425,6 +425,7 @@ struct Stream {
 
 int build_stream(int kind, unsigned Ln, unsigned W, unsigned lb, const u64* exp_g, const u64* exp_r, Stream& S) {
     const unsigned L = 2 * Ln;
+    S.tmpls.reserve(2);                  // (references to the templates stay valid when the uniform circuit adds the second one)
     S.tmpls.push_back(block_template(L, W, lb));
     const Template& tm = S.tmpls[0];
     // ---- prefix: the four assign_integer, square, refresh, load_zero
@@ -748,26 +749,31 @@ __global__ __launch_bounds__(256) void k_struct_keys(const u32* __restrict__ mem
     const u32 id = members[j];
     keys[j] = (u64)root[id] * span + pos[id];
 }
-__global__ __launch_bounds__(256) void k_struct_first(const u64* __restrict__ keys, i64 M, u64 span, u32* __restrict__ first) {
-    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= M) return;
-    first[j] = (j == 0 || keys[j] / span != keys[j - 1] / span) ? (u32)j : 0u;
-}
 __global__ __launch_bounds__(256) void k_struct_identity(u32* __restrict__ map_col, u32* __restrict__ map_row, i64 total, i64 n) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     map_col[i] = (u32)(i / n);
     map_row[i] = (u32)(i % n);
 }
-// every class becomes one cycle: a member maps to the next member of its class in (column, row) order, the last one to the first
-__global__ __launch_bounds__(256) void k_struct_cycles(const u64* __restrict__ keys, const u32* __restrict__ start, i64 M, u64 span, i64 n,
-                                                       u32* __restrict__ map_col, u32* __restrict__ map_row) {
+// every class becomes one cycle: a member maps to the next member of its class in (column, row) order, the last one to the first --
+// found by a binary search for the class's first key (keys are sorted; only the LAST member of a class searches)
+__global__ __launch_bounds__(256) void k_struct_cycles(const u64* __restrict__ keys, i64 M, u64 span, i64 n, u32* __restrict__ map_col,
+                                                       u32* __restrict__ map_row) {
     const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= M) return;
-    const u64 kj = keys[j], cls = kj / span, p = kj - cls * span;
+    const u64 kj = keys[j], cls = kj / span, base = cls * span, p = kj - base;
     u64 nxt;
-    if (j + 1 < M && keys[j + 1] / span == cls) nxt = keys[j + 1] - cls * span;
-    else nxt = keys[start[j]] - cls * span;
+    if (j + 1 < M && keys[j + 1] < base + span) {
+        nxt = keys[j + 1] - base;
+    } else {
+        i64 lo = -1, hi = j;                 // the first index whose key is >= base lies in (lo, hi]
+        while (hi - lo > 1) {
+            const i64 mid = (lo + hi) >> 1;
+            if (keys[mid] >= base) hi = mid;
+            else lo = mid;
+        }
+        nxt = keys[hi] - base;
+    }
     map_col[p] = (u32)(nxt / (u64)n);
     map_row[p] = (u32)(nxt % (u64)n);
 }
@@ -779,10 +785,6 @@ __global__ __launch_bounds__(256) void k_struct_selectors(DStream D, const u32* 
     const u8 g = P.tmpl < 0 ? P.mask[rel] : D.tmpls[P.tmpl].mask[rel % D.tmpls[P.tmpl].cells];
     if (g) sel[pos[c]] = 1;   // (the gate of a shared break cell is enabled in the column it starts: pos is that column's row 0)
 }
-
-struct MaxOp {
-    __host__ __device__ __forceinline__ u32 operator()(const u32& a, const u32& b) const { return a > b ? a : b; }
-};
 
 // device buffers of one call, freed on every path out
 struct DevBufs {
@@ -1008,20 +1010,8 @@ extern "C" int pz_circuit_structure_dev(pz_ctx* ctx, int kind, uint32_t limbs_n,
             PZCHK(tmp.get(ctx, tb, &t_));
             HIPCHK(ctx, hipcub::DeviceRadixSort::SortKeys(t_, tb, (const u64*)keys, keys2, (int)M, 0, (int)key_bits, ctx->stream));
         }
-        // ---- every member's class start (a max-scan of the first-member indices), then the cycles
-        u32 *first = nullptr, *start = nullptr;
-        PZCHK(tmp.get(ctx, (size_t)M, &first)); PZCHK(tmp.get(ctx, (size_t)M, &start));
-        hipLaunchKernelGGL(k_struct_first, grid(M), dim3(TB), 0, ctx->stream, (const u64*)keys2, M, (u64)span, first);
-        HIPCHK(ctx, hipGetLastError());
-        {
-            size_t tb = 0;
-            HIPCHK(ctx, hipcub::DeviceScan::InclusiveScan(nullptr, tb, (const u32*)first, start, MaxOp(), (int)M, ctx->stream));
-            char* t_ = nullptr;
-            PZCHK(tmp.get(ctx, tb, &t_));
-            HIPCHK(ctx, hipcub::DeviceScan::InclusiveScan(t_, tb, (const u32*)first, start, MaxOp(), (int)M, ctx->stream));
-        }
-        hipLaunchKernelGGL(k_struct_cycles, grid(M), dim3(TB), 0, ctx->stream, (const u64*)keys2, (const u32*)start, M, (u64)span, n, st->d_map_col,
-                           st->d_map_row);
+        // ---- the cycles
+        hipLaunchKernelGGL(k_struct_cycles, grid(M), dim3(TB), 0, ctx->stream, (const u64*)keys2, M, (u64)span, n, st->d_map_col, st->d_map_row);
         HIPCHK(ctx, hipGetLastError());
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

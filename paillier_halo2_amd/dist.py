@@ -288,7 +288,8 @@ def bench_sharded_msm(eng, torch, dist, rank, world, log_n, steps, warmup, barri
     }
 
 
-def emulate_sharded_msm(eng, torch, world: int, log_n: int, steps: int, warmup: int, log, scalars="uniform", share_window_bits=0):
+def emulate_sharded_msm(eng, torch, world: int, log_n: int, steps: int, warmup: int, log, scalars="uniform", share_window_bits=0,
+                        window_split_bits=0):
     """config c4 on ONE GPU: each of `world` ranks' shares of the 2^log_n-point MSM run in turn (window split and point
     split), with per-share stage times from HIP events (digit sort, bucket accumulation, bucket folds + reduction tree) and
     the device fold of the `world` partial points.  predicted_efficiency = T(one GPU, whole MSM) / (world * T(slowest
@@ -345,17 +346,22 @@ def emulate_sharded_msm(eng, torch, world: int, log_n: int, steps: int, warmup: 
     ref = eng.g1_normalize(d_out.cpu().numpy().astype(np.uint64))[0]
     res = {"full": full, "splits": {}}
     t_fold = timed(lambda: eng.g1_sum_dev(d_parts.data_ptr(), world, d_out.data_ptr()))["total"]
-    # ---- window split
+    # ---- window split (window_split_bits: the shares' table with another window width than the one-GPU run's -- more, narrower windows
+    # divide more evenly over the ranks and shrink every share's bucket set)
+    tbw = eng.load_bases_dev(d_b.data_ptr(), n, window_split_bits) if window_split_bits else tb
     shares = []
     for r in range(world):
-        lo, hi = window_range(tb.n_windows, r, world)
-        shares.append(timed(lambda: eng.msm_dev(tb, d_s.data_ptr(), 1, n, 4 * n, d_parts[r].data_ptr(), lo, hi)))
+        lo, hi = window_range(tbw.n_windows, r, world)
+        shares.append(timed(lambda: eng.msm_dev(tbw, d_s.data_ptr(), 1, n, 4 * n, d_parts[r].data_ptr(), lo, hi)))
     eng.g1_sum_dev(d_parts.data_ptr(), world, d_out.data_ptr())
     eng.sync()
     ok_w = bool(np.array_equal(eng.g1_normalize(d_out.cpu().numpy().astype(np.uint64))[0], ref))
     worst = max(sh["total"] for sh in shares)
-    res["splits"]["windows"] = {"shares": shares, "slowest_share_ms": worst, "fold_ms": t_fold,
+    res["splits"]["windows"] = {"shares": shares, "slowest_share_ms": worst, "fold_ms": t_fold, "window_bits": window_split_bits or 16,
+                                "windows": tbw.n_windows,
                                 "predicted_efficiency": full["total"] / (world * (worst + t_fold)), "equals_full_msm": ok_w}
+    if tbw is not tb:
+        tbw.free()
     tb.free()
     # ---- point split: every rank's table holds its own n / world bases
     shares = []
@@ -369,7 +375,7 @@ def emulate_sharded_msm(eng, torch, world: int, log_n: int, steps: int, warmup: 
     eng.sync()
     ok_p = bool(np.array_equal(eng.g1_normalize(d_out.cpu().numpy().astype(np.uint64))[0], ref))
     worst = max(sh["total"] for sh in shares)
-    res["splits"]["points"] = {"shares": shares, "slowest_share_ms": worst, "fold_ms": t_fold,
+    res["splits"]["points"] = {"shares": shares, "slowest_share_ms": worst, "fold_ms": t_fold, "window_bits": share_window_bits or 16,
                                "predicted_efficiency": full["total"] / (world * (worst + t_fold)), "equals_full_msm": ok_p}
     eng.timing_enable(False)
     best = max(res["splits"], key=lambda k: res["splits"][k]["predicted_efficiency"])

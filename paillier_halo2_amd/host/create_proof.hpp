@@ -111,11 +111,16 @@ class Ctx {
   public:
     pz_ctx* c = nullptr;
     std::vector<void*> owned;
+    // round_cols: column counts of the big arrays are rounded up to 64, so that keys whose column counts differ by a few (a new message of
+    // the reference's circuit moves them by a handful) ask for IDENTICAL block sizes -- with the library's block cache on
+    // (pz_dev_cache_limit) a released key's blocks then serve the next key instead of going back to the driver (seconds per 116-GB key)
+    bool round_cols = false;
+    size_t cols(size_t x) const { return round_cols ? (x + 63) / 64 * 64 : x; }
     uint64_t* alloc(size_t words) {
         void* d = nullptr;
         PZP_CK(pz_dev_alloc(c, words * 8, &d));
-        PZP_CK(pz_dev_memset(c, d, 0, words * 8));
         owned.push_back(d);
+        PZP_CK(pz_dev_memset(c, d, 0, words * 8));
         return (uint64_t*)d;
     }
     void release() {
@@ -179,7 +184,7 @@ inline ProvingKey* keygen(Ctx& cx, Structure&& st_in, const pz_bases* bl, const 
     // fixed columns [selectors | constants | table], Lagrange form.  The selectors are bytes (0 / 1): they cross PCIe as bytes (or are on the
     // device already) and become field elements THERE (pz_fr_from_mask_dev) -- built on the host as 32-byte elements they were 12.7 GB of
     // uploads at config c2, most of pz_pk_create's 5 s
-    uint64_t* fixed = cx.alloc(F * n * 4);
+    uint64_t* fixed = cx.alloc(cx.cols(F) * n * 4);
     {
         Scratch tmp(cx.c);
         const uint8_t* d_sel = st.d_selectors;
@@ -204,7 +209,7 @@ inline ProvingKey* keygen(Ctx& cx, Structure&& st_in, const pz_bases* bl, const 
     PZP_CK(pz_dev_copy(cx.c, pk->const_lagrange, fixed + A * n * 4, n * 32));
     PZP_CK(pz_dev_copy(cx.c, pk->table_lagrange, fixed + (A + 1) * n * 4, n * 32));
     // sigma from the copy-constraint map (one call over all m columns)
-    uint64_t* sigma = cx.alloc(m * n * 4);
+    uint64_t* sigma = cx.alloc(cx.cols(m) * n * 4);
     {
         Scratch tmp(cx.c);
         const uint32_t *dmc = st.d_map_col, *dmr = st.d_map_row;
@@ -225,14 +230,14 @@ inline ProvingKey* keygen(Ctx& cx, Structure&& st_in, const pz_bases* bl, const 
         std::vector<uint32_t>().swap(s_.map_col);
         std::vector<uint32_t>().swap(s_.map_row);
     }
-    pk->sigma_lagrange = cx.alloc(m * n * 4);
+    pk->sigma_lagrange = cx.alloc(cx.cols(m) * n * 4);
     PZP_CK(pz_dev_copy(cx.c, pk->sigma_lagrange, sigma, m * n * 32));
     // keygen_vk + keygen_pk: commitments, coefficient forms in place, extended forms per part
-    uint64_t* com_f = cx.alloc(F * 12);
-    uint64_t* com_s = cx.alloc(m * 12);
+    uint64_t* com_f = cx.alloc(cx.cols(F) * 12);
+    uint64_t* com_s = cx.alloc(cx.cols(m) * 12);
     for (int pi = 0; pi < 2; ++pi) {
-        pk->fixed_ext[pi] = cx.alloc((pk->res_fixed ? pk->res_fixed : 1) * d.parts[pi].size * 4);
-        pk->sigma_ext[pi] = cx.alloc((pk->res_sigma ? pk->res_sigma : 1) * d.parts[pi].size * 4);
+        pk->fixed_ext[pi] = cx.alloc((pk->res_fixed ? cx.cols(pk->res_fixed) : 1) * d.parts[pi].size * 4);
+        pk->sigma_ext[pi] = cx.alloc((pk->res_sigma ? cx.cols(pk->res_sigma) : 1) * d.parts[pi].size * 4);
         pk->l_ext[pi] = cx.alloc(3 * d.parts[pi].size * 4);
         pk->table_ext[pi] = cx.alloc(d.parts[pi].size * 4);
     }
@@ -340,17 +345,18 @@ struct Workspace {
 };
 
 inline Workspace make_workspace(Ctx& cx, const ProvingKey& pk, size_t tile = 64) {
+    // (with cx.round_cols the per-proof buffers below are sized by rounded counts too, so a following key finds them in the block cache)
     const Domain& d = pk.dom;
     const size_t n = d.n, Lk = pk.st.n_lk, S = pk.n_sets, m = pk.st.m();
     Workspace w;
     w.tile = tile;
     w.lt = tile < Lk ? tile : Lk;
-    w.Ap = cx.alloc(Lk * n * 4); w.Sp = cx.alloc(Lk * n * 4); w.Zl = cx.alloc(Lk * n * 4);
-    w.Z = cx.alloc(S * n * 4);
+    w.Ap = cx.alloc(cx.cols(Lk) * n * 4); w.Sp = cx.alloc(cx.cols(Lk) * n * 4); w.Zl = cx.alloc(cx.cols(Lk) * n * 4);
+    w.Z = cx.alloc(cx.cols(S) * n * 4);
     // the grand products on the quotient's domain: all sets of ONE part at once (the chaining lines read z_{j-1} beside z_j); the parts are
     // worked one after the other, so one buffer of the larger part serves both
     const size_t big = d.parts[0].size > d.parts[1].size ? d.parts[0].size : d.parts[1].size;
-    w.z_ext[0] = w.z_ext[1] = cx.alloc(S * big * 4);
+    w.z_ext[0] = w.z_ext[1] = cx.alloc(cx.cols(S) * big * 4);
     if (pk.streamed)
         for (int q = 0; q < 2; ++q) w.key_ext[q] = cx.alloc(tile * big * 4);
     for (int pi = 0; pi < 2; ++pi) {
@@ -366,15 +372,15 @@ inline Workspace make_workspace(Ctx& cx, const ProvingKey& pk, size_t tile = 64)
     w.hcomb = cx.alloc(n * 4);
     w.w1 = cx.alloc(n * 4);
     w.w2 = cx.alloc(n * 4);
-    w.blind = cx.alloc((m + S + 3 * Lk) * (d.bf + 1) * 4 + n * 4);
+    w.blind = cx.alloc((cx.cols(m) + cx.cols(S) + 3 * cx.cols(Lk)) * (d.bf + 1) * 4 + n * 4);
     {   // the largest batch of commitments a phase leaves there: advice (m - 1), lookups (2 Lk), products (S + Lk + 1), the pieces (3)
         size_t pts = m - 1;
         if (2 * Lk > pts) pts = 2 * Lk;
         if (S + Lk + 1 > pts) pts = S + Lk + 1;
         if (pts < 3) pts = 3;
-        w.out12 = cx.alloc(pts * 12);
+        w.out12 = cx.alloc(cx.cols(pts) * 12);
     }
-    w.evals = cx.alloc((4 * m + 4 * S + 16) * 4 * 4);
+    w.evals = cx.alloc((4 * cx.cols(m) + 4 * cx.cols(S) + 16) * 4 * 4);
     return w;
 }
 

@@ -13,6 +13,14 @@
 // proof file: records  [name_len u64][name bytes, padded to 8][kind u64: 0 points (8 words), 1 evaluations, 2 challenge][count u64]
 //   [per-item words u64][data]; proof p's records are prefixed "p<p>/"; the verifying key's commitments are "vk/fixed", "vk/sigma".
 // stdout: one JSON line with the timings.
+//
+// usage: prove_connected --fresh <params file> <proof file>
+//   A NEW KEY PAIR AND MESSAGE PER PROOF with the reference's circuit, from compiled code alone: the message's bits are circuit structure
+//   (paillier.rs:50-55), so every step generates the structure ON THE DEVICE (pz_circuit_structure_dev), runs keygen on its device arrays,
+//   writes the witness (K3 + K4 in the structure's break-point layout) and proves -- what bench.rs:161-171 pays per message.
+//   params file (u64 words): [0] magic 0x465a50  [1] enc_bits  [2] k  [3] lookup_bits  [4] minimum_rows  [5] blinding_factors  [6] seed
+//   [7] steps  [8] tile  then s_toxic (4, Montgomery), then per step n | g | m | r (Ln words each).
+//   Device blocks are recycled from key to key (pz_dev_cache_limit): re-allocating 116 GB per message would cost seconds.
 #include <chrono>
 
 #include "create_proof.hpp"
@@ -51,8 +59,142 @@ static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+static void write_proof(Out& out, const std::string& pre, const Proof& pr, const Transcript& tr) {
+    for (auto& c : pr.commitments) out.rec(pre + "c/" + c.first, 0, c.second.size() / 8, 8, c.second.data());
+    for (size_t f = 0; f < pr.evals.size(); ++f) {
+        const uint64_t per = 4ull * pr.eval_points[f].second;
+        out.rec(pre + "e/" + pr.evals[f].first, 1, pr.evals[f].second.size() / per, per, pr.evals[f].second.data());
+    }
+    for (auto& c : tr.drawn) out.rec(pre + "ch/" + c.first, 2, 1, 4, c.second.v);
+}
+
+static int fresh_main(const char* params_path, const char* proof_path) {
+    const std::vector<uint64_t> w = slurp(params_path);
+    if (w.size() < 13 || w[0] != 0x465a50) { fprintf(stderr, "bad params file\n"); return 2; }
+    const uint64_t enc_bits = w[1];
+    const unsigned k = (unsigned)w[2], lb = (unsigned)w[3], bf = (unsigned)w[5];
+    const size_t minimum_rows = w[4], seed = w[6], steps = w[7], tile = w[8];
+    const size_t Ln = enc_bits / 64, L = 2 * Ln, n = (size_t)1 << k;
+    if (k < 4 || k > 24 || !Ln || !steps || tile % CHUNK || w.size() != 13 + steps * 4 * Ln) { fprintf(stderr, "params\n"); return 2; }
+    const uint64_t* s_tox = &w[9];
+    Ctx cx;
+    cx.round_cols = true;
+    int dev = 0;
+    PZP_CK(pz_init(1, &dev, &cx.c));
+    PZP_CK(pz_dev_cache_limit(cx.c, ~(size_t)0));     // a released key's blocks serve the next key (pz.h)
+    const Fr om = pzh::omega(k);
+    void *d_g = nullptr, *d_gl = nullptr;
+    PZP_CK(pz_dev_alloc(cx.c, n * 64, &d_g));
+    PZP_CK(pz_dev_alloc(cx.c, n * 64, &d_gl));
+    PZP_CK(pz_srs_setup_g1_dev(cx.c, k, s_tox, om.v, (uint64_t*)d_g, (uint64_t*)d_gl));
+    PZP_CK(pz_sync(cx.c));
+    pz_bases *bl = nullptr, *bm = nullptr;
+    PZP_CK(pz_bases_load_g1(cx.c, (const uint64_t*)d_gl, n, 1, 0, &bl));
+    PZP_CK(pz_bases_load_g1(cx.c, (const uint64_t*)d_g, n, 1, 0, &bm));
+    pz_dev_free(cx.c, d_g);
+    pz_dev_free(cx.c, d_gl);
+    Out out{fopen(proof_path, "wb")};
+    if (!out.f) { perror(proof_path); return 2; }
+    bool degree_ok = true;
+    double sum_after_first = 0, structure_ms = 0, keygen_ms = 0, witness_ms = 0, prove_ms = 0;
+    size_t last_adv = 0, last_lk = 0;
+    for (size_t si = 0; si < steps; ++si) {
+        const uint64_t *vn = &w[13 + si * 4 * Ln], *vg = vn + Ln, *vm = vg + Ln, *vr = vm + Ln;
+        PZP_CK(pz_sync(cx.c));
+        const double t0 = now_ms();
+        // ---- the structure of THIS message's circuit, on the device
+        pz_structure* ps = nullptr;
+        PZP_CK(pz_circuit_structure_dev(cx.c, 0, (uint32_t)Ln, 64, lb, k, vm, vn, minimum_rows, bf, &ps));
+        Structure st;
+        st.k = k; st.lookup_bits = lb; st.blinding_factors = bf;
+        size_t filled = 0, n_const = 0, cells = 0, lks = 0, ng = 0, nr = 0;
+        PZP_CK(pz_structure_info(ps, &st.n_adv, &filled, &st.n_lk, &st.max_rows, &n_const, &cells, &lks, &ng, &nr));
+        const uint64_t *consts = nullptr, *d_starts = nullptr, *starts_h = nullptr;
+        PZP_CK(pz_structure_arrays(ps, &st.d_selectors, &st.d_map_col, &st.d_map_row, &d_starts, &consts, &starts_h));
+        st.constants.assign(consts, consts + 4 * n_const);
+        const size_t A = st.n_adv, m = st.m();
+        const double t1 = now_ms();
+        // ---- keygen on the structure's device arrays; the break points stay (K4), the rest of the structure goes
+        ProvingKey* pk = keygen(cx, std::move(st), bl, bm);
+        pk->st.d_selectors = nullptr; pk->st.d_map_col = pk->st.d_map_row = nullptr;
+        uint64_t* d_starts_own = cx.alloc(cx.cols(A + 1));
+        PZP_CK(pz_dev_copy(cx.c, d_starts_own, d_starts, (A + 1) * 8));
+        PZP_CK(pz_sync(cx.c));
+        PZP_CK(pz_structure_free(ps));
+        Workspace ws = make_workspace(cx, *pk, tile);
+        PZP_CK(pz_sync(cx.c));
+        const double t2 = now_ms();
+        // ---- the witness: K3 -> K4 in the structure's break-point layout
+        uint64_t* d_cols = cx.alloc(cx.cols(m) * n * 4);
+        uint64_t* d_steps = cx.alloc((ng + nr + 1 + 64) / 64 * 64 * 4 * L);
+        uint64_t* d_mod = cx.alloc(L);
+        std::vector<uint64_t> n2(L), c_out(L);
+        {   // n^2 by schoolbook (host, 2 Ln words): the modulus K4's refresh cells need
+            std::fill(n2.begin(), n2.end(), 0);
+            for (size_t i = 0; i < Ln; ++i) {
+                unsigned __int128 carry = 0;
+                for (size_t j = 0; j < Ln; ++j) {
+                    const unsigned __int128 t = (unsigned __int128)vn[i] * vn[j] + n2[i + j] + carry;
+                    n2[i + j] = (uint64_t)t;
+                    carry = t >> 64;
+                }
+                n2[i + Ln] = (uint64_t)carry;
+            }
+        }
+        PZP_CK(pz_upload(cx.c, d_mod, n2.data(), L * 8));
+        uint32_t sg = 0, sr = 0;
+        PZP_CK(pz_paillier_encrypt_dev(cx.c, (uint32_t)Ln, 1, vn, vg, vm, vr, d_steps, ng + nr + 1, &sg, &sr, c_out.data()));
+        if (sg != ng || sr != nr) { fprintf(stderr, "trace shape (%u, %u) is not the structure's (%zu, %zu)\n", sg, sr, ng, nr); return 2; }
+        std::vector<uint64_t> inputs;
+        inputs.insert(inputs.end(), vn, vn + Ln); inputs.insert(inputs.end(), vg, vg + Ln); inputs.insert(inputs.end(), vm, vm + Ln);
+        inputs.insert(inputs.end(), vr, vr + Ln); inputs.insert(inputs.end(), c_out.begin(), c_out.end());
+        PZP_CK(pz_circuit_expand_cols_dev(cx.c, 0, (uint32_t)Ln, 64, lb, inputs.data(), d_steps, ng, nr, d_mod, d_cols, d_cols + A * n * 4, d_starts_own, A,
+                                          pk->st.max_rows, pk->st.max_rows, n));
+        PZP_CK(pz_sync(cx.c));
+        const double t3 = now_ms();
+        Transcript tr;
+        tr.absorb(&si, 8);
+        Proof pr = create_proof(cx, *pk, ws, d_cols, tr, seed + si);
+        PZP_CK(pz_sync(cx.c));
+        const double t4 = now_ms();
+        degree_ok = degree_ok && pr.h_degree_ok;
+        const std::string pre = "p" + std::to_string(si) + "/";
+        const uint64_t shape[8] = {A, pk->st.n_lk, m, pk->n_sets, pk->st.max_rows, filled, ng, nr};
+        out.rec(pre + "shape", 3, 1, 8, shape);
+        out.rec(pre + "vk/fixed", 0, pk->F, 8, pk->fixed_commit.data());
+        out.rec(pre + "vk/sigma", 0, m, 8, pk->sigma_commit.data());
+        out.rec(pre + "ciphertext", 3, 1, L, c_out.data());
+        const uint64_t flags[2] = {pr.h_degree_ok, si};
+        out.rec(pre + "flags", 3, 1, 2, flags);
+        write_proof(out, pre, pr, tr);
+        last_adv = A; last_lk = pk->st.n_lk;
+        delete pk;
+        cx.release();                       // the key's and the workspace's blocks: kept by the library's block cache for the next message
+        PZP_CK(pz_sync(cx.c));
+        const double t5 = now_ms();
+        if (si) {
+            sum_after_first += t5 - t0;
+            structure_ms += t1 - t0; keygen_ms += t2 - t1; witness_ms += t3 - t2; prove_ms += t4 - t3;
+        }
+        fprintf(stderr, "[fresh %zu] structure %.0f + keygen %.0f + witness %.0f + proof %.0f + release %.0f = %.0f ms (n_adv %zu)\n", si, t1 - t0, t2 - t1,
+                t3 - t2, t4 - t3, t5 - t4, t5 - t0, A);
+    }
+    fclose(out.f);
+    const double d = steps > 1 ? (double)(steps - 1) : 1.0;
+    printf("{\"mode\": \"fresh_message\", \"steps\": %zu, \"k\": %u, \"enc_bits\": %llu, \"minimum_rows\": %zu, \"n_adv_last\": %zu, \"n_lk_last\": %zu, "
+           "\"mean_step_ms\": %.1f, \"of_which\": {\"structure_ms\": %.1f, \"keygen_and_workspace_ms\": %.1f, \"witness_ms\": %.1f, \"proof_ms\": %.1f}, "
+           "\"quotient_degree_ok\": %s}\n",
+           steps, k, (unsigned long long)enc_bits, minimum_rows, last_adv, last_lk, sum_after_first / d, structure_ms / d, keygen_ms / d, witness_ms / d,
+           prove_ms / d, degree_ok ? "true" : "false");
+    pz_bases_free(cx.c, bl);
+    pz_bases_free(cx.c, bm);
+    pz_free(cx.c);
+    return degree_ok ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
-    if (argc != 3) { fprintf(stderr, "usage: %s <job file> <proof file>\n", argv[0]); return 2; }
+    if (argc == 4 && !strcmp(argv[1], "--fresh")) return fresh_main(argv[2], argv[3]);
+    if (argc != 3) { fprintf(stderr, "usage: %s <job file> <proof file>  |  %s --fresh <params file> <proof file>\n", argv[0], argv[0]); return 2; }
     const std::vector<uint64_t> w = slurp(argv[1]);
     if (w.size() < 16 || w[0] != 0x435a50) { fprintf(stderr, "bad job file\n"); return 2; }
     Structure st;
@@ -196,7 +338,7 @@ int main(int argc, char** argv) {
     }
     if (pipeline) PZP_CK(pz_sync(wctx));
     fclose(out.f);
-    printf("{\"proofs\": %zu, \"k\": %u, \"enc_bits\": %llu, \"n_adv\": %zu, \"n_lk\": %zu, \"cosets\": 3, \"pipelined_witness\": %s, \"keygen_ms\": %.1f, \"setup_ms\": %.1f, "
+    printf("{\"proofs\": %zu, \"k\": %u, \"enc_bits\": %llu, \"n_adv\": %zu, \"n_lk\": %zu, \"cosets\": 3, \"streamed_key\": %s, \"pipelined_witness\": %s, \"keygen_ms\": %.1f, \"setup_ms\": %.1f, "
            "\"best_proof_ms\": %.2f, \"mean_proof_ms\": %.2f, \"of_which_witness_ms\": %.2f, \"quotient_degree_ok\": %s}\n",
            proofs, st.k, (unsigned long long)enc_bits, A, st.n_lk, pk->streamed ? "true" : "false", pipeline ? "true" : "false", keygen_ms, t_keygen - t_setup, best,
            proofs > 1 ? sum_after_first / (double)(proofs - 1) : best, witness_ms, degree_ok ? "true" : "false");

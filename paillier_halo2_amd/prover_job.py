@@ -44,6 +44,37 @@ def write_job(path: str, st, starts: Sequence[int], enc_bits: int, kind: int, ng
             f.write(b"\0" * (-a.nbytes % 8))
 
 
+FRESH_MAGIC = 0x465A50
+
+
+def write_fresh_params(path: str, enc_bits: int, k: int, lookup_bits: int, inputs, s_toxic: int, minimum_rows: int = 20, blinding_factors: int = 6,
+                       seed: int = 1, tile: int = 64):
+    """the params file of `prove_connected --fresh`: inputs = [(n, g, m, r)] integers, one NEW key pair and message per step (the format is
+    stated at the top of host/prove_connected.cpp).  No circuit structure: the binary generates it on the device per message."""
+    Ln = enc_bits // 64
+    lim = lambda x: consts.int_to_limbs(x, Ln).astype("<u8")
+    hdr = np.array([FRESH_MAGIC, enc_bits, k, lookup_bits, minimum_rows, blinding_factors, seed, len(inputs), tile], dtype="<u8")
+    with open(path, "wb") as f:
+        f.write(hdr.tobytes())
+        f.write(consts.fr_mont_limbs(s_toxic).astype("<u8").tobytes())
+        for nn, g, m, r in inputs:
+            for x in (nn, g, m, r):
+                f.write(lim(x).tobytes())
+
+
+def run_fresh(params_path: str, proof_path: str, timeout: float = 600.0, env=None) -> dict:
+    import json
+
+    if not os.path.exists(BINARY):
+        raise RuntimeError("tests/cpp/prove_connected is not built (make -C tests/cpp prove_connected)")
+    r = subprocess.run([BINARY, "--fresh", params_path, proof_path], capture_output=True, text=True, timeout=timeout, env=env)
+    if r.returncode != 0:
+        raise RuntimeError("prove_connected --fresh exit %d: %s" % (r.returncode, r.stderr[-2000:]))
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    line["stderr_tail"] = r.stderr.strip().splitlines()[-8:]
+    return line
+
+
 def read_proofs(path: str) -> Dict[str, np.ndarray]:
     """-> {record name: uint64 array (count, words per item)}"""
     w = np.fromfile(path, dtype="<u8")

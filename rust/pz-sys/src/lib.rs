@@ -27,6 +27,7 @@ extern "C" {
 
     // device memory + context ordering: what lets the columns of a proof stay in HBM (patch points C / D, section 5a)
     pub fn pz_dev_alloc(ctx: *mut pz_ctx, bytes: usize, d_out: *mut *mut c_void) -> c_int;
+    pub fn pz_dev_cache_limit(ctx: *mut pz_ctx, max_bytes: usize) -> c_int;
     pub fn pz_dev_free(ctx: *mut pz_ctx, d: *mut c_void) -> c_int;
     pub fn pz_upload(ctx: *mut pz_ctx, d_dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
     pub fn pz_download(ctx: *mut pz_ctx, dst: *mut c_void, d_src: *const c_void, bytes: usize) -> c_int;

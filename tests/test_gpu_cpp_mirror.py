@@ -146,3 +146,16 @@ def test_cpp_connected_proof_verifies(cref, tmp_path, circuit):
     assert out["h_x_times_xn_minus_1_equals_expression_of_evaluations"] is False
     assert out["shplonk_identity_on_the_proofs_commitments"] is True      # the openings of a wrong proof are still honest openings
     print(line)
+
+
+@pytest.mark.gpu
+def test_cpp_fresh_message_mode_verifies(cref):
+    """`prove_connected --fresh`: a NEW key pair and message per proof from compiled code alone -- the circuit structure generated by the
+    library on the device per message (pz_circuit_structure_dev), keygen on its device arrays, K3 + K4, create_proof, device blocks
+    recycled from key to key -- at the reference's bench shape (128-bit n, k = 14; /root/reference/src/bench.rs:139-140,161-171): three
+    steps, the last proof checked as the verifier would with ITS OWN key's commitments, its ciphertext against g^m r^n mod n^2"""
+    import bench_connected
+
+    out = bench_connected.cpp_fresh_message(128, 14, 13, 0x5043, steps=3, verify_with=cref)
+    assert out["quotient_degree_ok"] is True and out["verified"] is True, out
+    assert out["verification"]["ciphertext_is_g_m_r_n"] is True and out["steps"] == 3
