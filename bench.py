@@ -1676,8 +1676,14 @@ def connected_line(args, R):
                 time.time() - t_p, out["compiled_prover"]["ms_per_step"], out["compiled_prover"].get("verified")))
             if out["compiled_prover"].get("verified") is False:
                 out["comparable"] = False
+            # ... and through the LIBRARY'S stepper (pz_pk_create + pz_proof_*) with the next witness on a second thread and context
+            out["compiled_stepper"] = bench_connected.cpp_connected(cw, proofs=5, verify_with=_cref if ver is not None else None, log=log, via_stepper=True)
+            log("connected, library stepper from compiled code: %.1f ms per proof (pz_pk_create %.0f ms), verified %s" % (
+                out["compiled_stepper"]["ms_per_step"], out["compiled_stepper"]["keygen_ms"], out["compiled_stepper"].get("verified")))
+            if out["compiled_stepper"].get("verified") is False:
+                out["comparable"] = False
         except Exception as ex:
-            out["compiled_prover"] = {"error": repr(ex)[:600]}
+            out["compiled_prover"] = dict(out.get("compiled_prover") or {}, error=repr(ex)[:600])
     del cw
     gc.collect()
     # ---- ... and a NEW KEY AND MESSAGE per proof from compiled code alone: structure generated by the library on the device

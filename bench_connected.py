@@ -29,7 +29,7 @@ class _Null:
         return False
 
 
-def cpp_connected(cw, proofs=4, verify_with=None, log=lambda s: None):
+def cpp_connected(cw, proofs=4, verify_with=None, log=lambda s: None, via_stepper=False):
     """the same connected proof from the COMPILED prover (paillier_halo2_amd/host/prove_connected.cpp over include/pz.h only): the
     workload's structure and inputs written to a job file, the binary run as a child process (its own contexts: call after
     cw.release()), its last proof checked by verify_file_proof when verify_with (oracle.cref) is given.  -> dict for the bench line"""
@@ -45,17 +45,23 @@ def cpp_connected(cw, proofs=4, verify_with=None, log=lambda s: None):
         t0 = time.perf_counter()
         prover_job.write_job(job, cw.cs, cw.starts_host, cw.enc_bits, cw.kind, cw.ng, cw.nr, nn, g, msgs, cw.s_tox, seed=11, proofs=proofs)
         t1 = time.perf_counter()
-        line = prover_job.run(job, proof, timeout=600)
+        env = dict(os.environ, PZ_PROVE_VIA_STEPPER="1") if via_stepper else None
+        line = prover_job.run(job, proof, timeout=600, env=env)
         t2 = time.perf_counter()
         out = {"value": 1e3 / line["mean_proof_ms"], "unit": "proofs/s", "ms_per_step": line["mean_proof_ms"], "ms_per_proof_best_of": line["best_proof_ms"],
                "proofs": proofs,
                "of_which_witness_ms": line["of_which_witness_ms"], "keygen_ms": line["keygen_ms"], "connected": True,
                "job_file_gb": os.path.getsize(job) / 1e9, "job_write_s": t1 - t0, "binary_wall_s": t2 - t1,
                "quotient_degree_ok": line["quotient_degree_ok"],
-               "note": "tests/cpp/prove_connected: keygen + create_proof (paillier_halo2_amd/host/create_proof.hpp) from plain C++ over the C "
-                       "ABI only -- no torch, no HIP call in the host, no oracle; one context, no overlap of the next witness; the circuit "
-                       "structure and inputs arrive in a job file; value = mean over the proofs after the first (which grows the library's "
-                       "workspaces), each incl. its K3 + K4"}
+               "pipelined_witness": line.get("pipelined_witness"), "via": line.get("via", "host/create_proof.hpp composed by the driver"),
+               "note": ("tests/cpp/prove_connected with PZ_PROVE_VIA_STEPPER=1: pz_pk_create (the structure's HOST arrays, selectors as bytes) + "
+                        "pz_proof_begin ... pz_proof_open_finish, one call per transcript round, the next proof's K3 + K4 written by a second host "
+                        "thread on a second context (rust/pz-rt prove_pipelined's recipe); keygen_ms = pz_pk_create incl. the 3.7 GB upload"
+                        if via_stepper else
+                        "tests/cpp/prove_connected: keygen + create_proof (paillier_halo2_amd/host/create_proof.hpp) from plain C++ over the C "
+                        "ABI only -- no torch, no HIP call in the host, no oracle; the next proof's K3 + K4 on a second context under this proof's "
+                        "advice commitments (pipelined_witness); the circuit structure and inputs arrive in a job file")
+                       + "; value = mean over the proofs after the first (which grows the library's workspaces), each incl. its K3 + K4"}
         if verify_with is not None:
             rec = prover_job.read_proofs(proof)
             last = "p%d/" % (proofs - 1)

@@ -21,7 +21,13 @@
 //   params file (u64 words): [0] magic 0x465a50  [1] enc_bits  [2] k  [3] lookup_bits  [4] minimum_rows  [5] blinding_factors  [6] seed
 //   [7] steps  [8] tile  then s_toxic (4, Montgomery), then per step n | g | m | r (Ln words each).
 //   Device blocks are recycled from key to key (pz_dev_cache_limit): re-allocating 116 GB per message would cost seconds.
+//
+// PZ_PROVE_VIA_STEPPER=1 (job-file mode): the SAME proofs through the library's entry points instead of this file's own composition --
+//   pz_pk_create (the structure's host arrays, as halo2's Assembly would hand them over) and pz_proof_begin ... pz_proof_open_finish, one call
+//   per transcript round -- with the NEXT proof's witness written by a second host thread on a second context while the stepper runs
+//   (the two-context recipe of rust/pz-rt prove_pipelined).
 #include <chrono>
+#include <thread>
 
 #include "create_proof.hpp"
 
@@ -192,6 +198,109 @@ static int fresh_main(const char* params_path, const char* proof_path) {
     return degree_ok ? 0 : 1;
 }
 
+// the job's proofs through pz_pk_create + pz_proof_*: -> exit code.  `produce(pi, ctx)` writes proof pi's witness into slot pi & 1 on ctx.
+static int stepper_main(Ctx& cx, int dev, Structure& st, const pz_bases* bl, const pz_bases* bm, size_t n_const, size_t tile, size_t proofs, size_t seed,
+                        size_t ext_res, const std::function<void(size_t, pz_ctx*, uint64_t*, std::vector<uint64_t>&)>& produce, size_t n_msg, size_t L,
+                        double t_setup, const char* proof_path) {
+    const size_t n = (size_t)1 << st.k, A = st.n_adv, Lk = st.n_lk, m = st.m();
+    const unsigned k = st.k;
+    const double t_keygen = now_ms();
+    pz_pk* pk = nullptr;
+    PZP_CK(pz_pk_create(cx.c, bl, bm, st.k, st.lookup_bits, st.blinding_factors, st.max_rows, A, Lk, st.selectors.data(), st.constants.data(), n_const,
+                        st.map_col.data(), st.map_row.data(), tile, ext_res, &pk));
+    const double keygen_ms = now_ms() - t_keygen;
+    size_t F = 0, m_ = 0, S = 0, bw = 0, ew = 0;
+    PZP_CK(pz_pk_info(pk, &F, &m_, &S, &bw, &ew));
+    std::vector<uint64_t> vkf(8 * F), vks(8 * m);
+    PZP_CK(pz_pk_commitments(pk, vkf.data(), vks.data()));
+    Out out{fopen(proof_path, "wb")};
+    if (!out.f) { perror(proof_path); return 2; }
+    out.rec("vk/fixed", 0, F, 8, vkf.data());
+    out.rec("vk/sigma", 0, m, 8, vks.data());
+    Ctx cw;
+    PZP_CK(pz_init(1, &dev, &cw.c));
+    uint64_t* d_slot[2] = {cx.alloc(m * n * 4), cx.alloc(m * n * 4)};
+    std::vector<std::vector<uint64_t>> ciphertexts(proofs, std::vector<uint64_t>(L));
+    produce(0, cw.c, d_slot[0], ciphertexts[0]);
+    PZP_CK(pz_sync(cw.c));
+    struct FamW { const char* name; size_t count, pts; };
+    const FamW fams[10] = {{"advice", A, 4}, {"lookup_advice", Lk + 1, 1}, {"fixed", F, 1}, {"sigma", m, 1}, {"perm_z", S, 3}, {"lookup_z", Lk, 2},
+                           {"perm_inputs", Lk, 2}, {"perm_tables", Lk, 1}, {"random", 1, 1}, {"h", 1, 1}};
+    double best = 1e30, sum_after_first = 0;
+    bool degree_ok = true;
+    for (size_t pi = 0; pi < proofs; ++pi) {
+        PZP_CK(pz_sync(cx.c));
+        const double t0 = now_ms();
+        std::thread wt;
+        if (pi + 1 < proofs)   // the next proof's K3 + K4: another thread, another context, the other slot
+            wt = std::thread([&, pi] {
+                produce(pi + 1, cw.c, d_slot[(pi + 1) & 1], ciphertexts[pi + 1]);
+                PZP_CK(pz_sync(cw.c));
+            });
+        uint64_t* d_cols = d_slot[pi & 1];
+        Transcript tr;
+        tr.absorb(&pi, 8);
+        pz_proof* pr = nullptr;
+        std::vector<uint64_t> adv(8 * (A + Lk)), ap(8 * Lk), sp(8 * Lk), cz(8 * S), czl(8 * Lk), crnd(8), ch(24), ev(ew), w1(8), w2(8);
+        PZP_CK(pz_proof_begin(pk, d_cols, seed + pi, nullptr, PZ_BLINDING_SEEDED_TEST_STREAM, &pr, adv.data()));
+        tr.absorb(adv.data(), adv.size() * 8);
+        const Fr theta = tr.squeeze("theta");
+        PZP_CK(pz_proof_lookups(pr, theta.v, ap.data(), sp.data()));
+        tr.absorb(ap.data(), ap.size() * 8); tr.absorb(sp.data(), sp.size() * 8);
+        const Fr beta = tr.squeeze("beta"), gamma = tr.squeeze("gamma");
+        PZP_CK(pz_proof_products(pr, beta.v, gamma.v, cz.data(), czl.data(), crnd.data()));
+        tr.absorb(cz.data(), cz.size() * 8); tr.absorb(czl.data(), czl.size() * 8); tr.absorb(crnd.data(), 64);
+        const Fr y = tr.squeeze("y");
+        PZP_CK(pz_proof_quotient(pr, y.v, ch.data()));
+        tr.absorb(ch.data(), 192);
+        const Fr x = tr.squeeze("x");
+        PZP_CK(pz_proof_evaluate(pr, x.v, ev.data()));
+        tr.absorb(ev.data(), (ev.size() - 4) * 8);      // (h's value is the last element: the verifier computes it itself)
+        const Fr shy = tr.squeeze("sh_y"), shv = tr.squeeze("sh_v");
+        PZP_CK(pz_proof_open_begin(pr, shy.v, shv.v, w1.data()));
+        tr.absorb(w1.data(), 64);
+        const Fr shu = tr.squeeze("sh_u");
+        int ok = 0;
+        PZP_CK(pz_proof_open_finish(pr, shu.v, w2.data(), &ok));
+        PZP_CK(pz_proof_free(pr));
+        if (wt.joinable()) wt.join();
+        const double t2 = now_ms();
+        if (t2 - t0 < best) best = t2 - t0;
+        if (pi) sum_after_first += t2 - t0;
+        degree_ok = degree_ok && ok;
+        const std::string pre = "p" + std::to_string(pi) + "/";
+        out.rec(pre + "ciphertext", 3, 1, L, ciphertexts[pi].data());
+        const uint64_t flags[2] = {(uint64_t)ok, pi % n_msg};
+        out.rec(pre + "flags", 3, 1, 2, flags);
+        out.rec(pre + "c/advice", 0, A, 8, adv.data());
+        out.rec(pre + "c/lookup_advice", 0, Lk, 8, adv.data() + 8 * A);
+        out.rec(pre + "c/perm_inputs", 0, Lk, 8, ap.data());
+        out.rec(pre + "c/perm_tables", 0, Lk, 8, sp.data());
+        out.rec(pre + "c/perm_z", 0, S, 8, cz.data());
+        out.rec(pre + "c/lookup_z", 0, Lk, 8, czl.data());
+        out.rec(pre + "c/random", 0, 1, 8, crnd.data());
+        out.rec(pre + "c/h", 0, 3, 8, ch.data());
+        out.rec(pre + "c/w1", 0, 1, 8, w1.data());
+        out.rec(pre + "c/w2", 0, 1, 8, w2.data());
+        size_t off = 0;
+        for (const FamW& f : fams) {
+            out.rec(pre + "e/" + f.name, 1, f.count, 4 * f.pts, ev.data() + off);
+            off += f.count * f.pts * 4;
+        }
+        for (auto& c : tr.drawn) out.rec(pre + "ch/" + c.first, 2, 1, 4, c.second.v);
+    }
+    fclose(out.f);
+    printf("{\"proofs\": %zu, \"k\": %u, \"n_adv\": %zu, \"n_lk\": %zu, \"via\": \"pz_pk_create + pz_proof_* (the library's stepper), next witness on a second thread and "
+           "context\", \"streamed_key\": %s, \"pipelined_witness\": true, \"keygen_ms\": %.1f, \"setup_ms\": %.1f, \"best_proof_ms\": %.2f, \"mean_proof_ms\": %.2f, "
+           "\"of_which_witness_ms\": 0.0, \"quotient_degree_ok\": %s}\n",
+           proofs, k, A, Lk, ext_res == EXT_ALL ? "false" : "true", keygen_ms, t_keygen - t_setup, best,
+           proofs > 1 ? sum_after_first / (double)(proofs - 1) : best, degree_ok ? "true" : "false");
+    PZP_CK(pz_pk_free(pk));
+    cx.release();
+    pz_free(cw.c);
+    return degree_ok ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
     if (argc == 4 && !strcmp(argv[1], "--fresh")) return fresh_main(argv[2], argv[3]);
     if (argc != 3) { fprintf(stderr, "usage: %s <job file> <proof file>  |  %s --fresh <params file> <proof file>\n", argv[0], argv[0]); return 2; }
@@ -245,10 +354,39 @@ int main(int argc, char** argv) {
     PZP_CK(pz_bases_load_g1(cx.c, (const uint64_t*)d_g, n, 1, 0, &bm));
     pz_dev_free(cx.c, d_g);
     pz_dev_free(cx.c, d_gl);
-    const double t_keygen = now_ms();
     // PZ_PROVE_STREAMED_KEY=R: the streamed proving key (only the first R permuted columns keep their extended forms; 0 at config c5)
     const char* sk = getenv("PZ_PROVE_STREAMED_KEY");
     const size_t ext_res = sk && *sk ? strtoull(sk, nullptr, 10) : EXT_ALL;
+    if (const char* vs = getenv("PZ_PROVE_VIA_STEPPER")) {
+        if (vs[0] == '1') {
+            // the witness of proof pi on the given context into the given columns (its own trace / modulus / break-point buffers)
+            uint64_t* s_steps = cx.alloc((ng + nr + 1) * 4 * L);
+            uint64_t* s_mod = cx.alloc(L);
+            uint64_t* s_starts = cx.alloc(A + 1);
+            PZP_CK(pz_upload(cx.c, s_mod, n2.data(), L * 8));
+            PZP_CK(pz_upload(cx.c, s_starts, st.starts.data(), (A + 1) * 8));
+            PZP_CK(pz_sync(cx.c));
+            const uint32_t lb_ = st.lookup_bits;
+            const size_t max_rows_ = st.max_rows;
+            auto produce_s = [&, lb_, max_rows_](size_t pi, pz_ctx* c, uint64_t* d_cols, std::vector<uint64_t>& c_out) {
+                const size_t v = pi % n_msg;
+                PZP_CK(pz_dev_memset(c, d_cols, 0, m * n * 32));
+                uint32_t sg = 0, sr = 0;
+                if (kind == 2)
+                    PZP_CK(pz_paillier_encrypt_uniform_dev(c, (uint32_t)Ln, 1, (uint32_t)enc_bits, vn.data(), vg.data(), vm[v].data(), vr[v].data(), s_steps,
+                                                           ng + nr + 1, &sg, &sr, c_out.data()));
+                else
+                    PZP_CK(pz_paillier_encrypt_dev(c, (uint32_t)Ln, 1, vn.data(), vg.data(), vm[v].data(), vr[v].data(), s_steps, ng + nr + 1, &sg, &sr,
+                                                   c_out.data()));
+                std::vector<uint64_t> inputs;
+                for (const auto* x : {&vn, &vg, &vm[v], &vr[v], &c_out}) inputs.insert(inputs.end(), x->begin(), x->end());
+                PZP_CK(pz_circuit_expand_cols_dev(c, (int)kind, (uint32_t)Ln, 64, lb_, inputs.data(), s_steps, ng, nr, s_mod, d_cols, d_cols + A * n * 4,
+                                                  s_starts, A, max_rows_, max_rows_, n));
+            };
+            return stepper_main(cx, dev, st, bl, bm, n_const, tile, proofs, seed, ext_res, produce_s, n_msg, L, t_setup, argv[2]);
+        }
+    }
+    const double t_keygen = now_ms();
     ProvingKey* pk = keygen(cx, std::move(st), bl, bm, ext_res);   // st's arrays now live in (or were released by) the key; its scalar fields stay readable
     PZP_CK(pz_sync(cx.c));
     const double keygen_ms = now_ms() - t_keygen;

@@ -108,21 +108,20 @@ _R3 = FR >> 192                  # the top 64-bit word of r
 
 
 def _random_fr(gen, *shape):
-    """blinding values: UNIFORM field elements as Montgomery representatives, by rejection from 254-bit candidates (a candidate is kept
-    when its top word is below r's: that drops a 2^-62 fraction of the field -- the values whose top word EQUALS r's -- and nothing else)"""
+    """blinding values: UNIFORM field elements as Montgomery representatives, by rejection from 254-bit candidates WITHOUT a host round trip
+    (a synchronising test in the middle of a phase would stall the launch queue): eight candidates per element, the first whose top word
+    is below r's is taken (that drops a 2^-62 fraction of the field -- the values whose top word EQUALS r's); an element whose eight
+    candidates all fail (probability 0.244^8 = 1.3e-5) falls back to a 252-bit value"""
     torch = _torch()
-    draw = lambda *sh: torch.randint(-(1 << 63), (1 << 63) - 1, (*sh, 4), dtype=torch.int64, device="cuda", generator=gen)
-    t = draw(*shape)
-    t[..., 3] &= 0x3FFFFFFFFFFFFFFF
-    for _ in range(64):
-        bad = t[..., 3] >= _R3
-        nb = int(bad.sum().item())
-        if nb == 0:
-            return t
-        c = draw(nb)
-        c[:, 3] &= 0x3FFFFFFFFFFFFFFF
-        t[bad] = c
-    raise RuntimeError("rejection sampling did not terminate")
+    K = 8
+    c = torch.randint(-(1 << 63), (1 << 63) - 1, (*shape, K, 4), dtype=torch.int64, device="cuda", generator=gen)
+    c[..., 3] &= 0x3FFFFFFFFFFFFFFF
+    ok = c[..., 3] < _R3                                            # [..., K]
+    first = ok.to(torch.int8).argmax(dim=-1, keepdim=True)          # the first valid candidate (0 if none)
+    t = torch.gather(c, -2, first.unsqueeze(-1).expand(*shape, 1, 4)).squeeze(-2)
+    none = ~ok.any(dim=-1)
+    t[..., 3] = torch.where(none, t[..., 3] & 0x0FFFFFFFFFFFFFFF, t[..., 3])
+    return t
 
 
 @dataclass

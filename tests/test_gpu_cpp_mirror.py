@@ -134,6 +134,18 @@ def test_cpp_connected_proof_verifies(cref, tmp_path, circuit):
         assert rec["p%d/flags" % pi][0].tolist() == [1, pi]
     # the two proofs are of different randomness (and, uniform circuit, different messages) under ONE key
     assert not np.array_equal(rec["p0/c/advice"], rec["p1/c/advice"])
+    # the same job through the LIBRARY'S stepper (PZ_PROVE_VIA_STEPPER=1: pz_pk_create on the job's host arrays + pz_proof_*, the next
+    # proof's witness written by a second host thread on a second context): the same key, proofs that verify
+    via = str(tmp_path / "via.bin")
+    line2 = prover_job.run(job, via, env=dict(os.environ, PZ_PROVE_VIA_STEPPER="1"))
+    assert line2["quotient_degree_ok"] is True and "stepper" in line2["via"]
+    rec2 = prover_job.read_proofs(via)
+    assert np.array_equal(rec2["vk/fixed"], rec["vk/fixed"]) and np.array_equal(rec2["vk/sigma"], rec["vk/sigma"])
+    for pi in range(2):
+        mm, rr = msgs[pi]
+        out2 = bench_connected.verify_file_proof(cref, rec2, "p%d/" % pi, st, K, s_tox)
+        assert out2["verified"] is True, (pi, out2)
+        assert out2["ciphertext"] == P.paillier_enc_native(nn, g, mm, rr)
     # negative control: one bit of one witness cell flipped after K4 (a gated cell of the first column) -> the quotient is not a
     # polynomial of degree <= 3n - 4, and the identity at x fails
     bad = str(tmp_path / "bad.bin")
