@@ -1884,7 +1884,8 @@ def main():
         return
 
     R = argparse.Namespace(rank=rank, world=world, local=local, use_dist=use_dist, log=log, eng=eng, mad_peak=mad_peak, barrier=barrier)
-    if args.workload in ("c2", "c2u", "c5") and not args.hot_path_headline:
+    # (--parallel columns splits ONE proof's hot-path columns over the ranks: a mode of the hot-path workload)
+    if args.workload in ("c2", "c2u", "c5") and not args.hot_path_headline and args.parallel != "columns":
         out = connected_line(args, R)
     else:
         out = hot_path_line(args, R)
