@@ -260,6 +260,12 @@ class ConnectedWorkload:
         hooks = {}
         if self.pipeline and not last:
             hooks["after_advice_launch"] = self.produce
+        if os.environ.get("PZ_CONNECTED_SPLIT_COMMIT"):      # experiment: commitments' column groups alternate between two contexts
+            if getattr(self, "eng2", None) is None:
+                import paillier_halo2_amd as pz
+
+                self.eng2 = pz.Engine(eng.device)
+            hooks["commit_engine"], hooks["commit_split"] = self.eng2, int(os.environ["PZ_CONNECTED_SPLIT_COMMIT"])
         pr = prover.create_proof(self.pk, cols, tr, seed=1000 + self.done, ws=self.ws, timings=self.timings if timed else None, hooks=hooks)
         if self.stream_w is not None:
             self.free_ev[slot].record(torch.cuda.current_stream())
@@ -430,6 +436,9 @@ class ConnectedWorkload:
         self.torch.cuda.synchronize()
         if self.engw is not self.eng:
             self.engw.close()
+        if getattr(self, "eng2", None) is not None:
+            self.eng2.close()
+            self.eng2 = None
         for ln in getattr(self, "lanes", None) or []:
             if ln["own"]:
                 ln["eng"].close()

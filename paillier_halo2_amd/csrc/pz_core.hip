@@ -193,6 +193,20 @@ extern "C" int pz_dev_alloc(pz_ctx* ctx, size_t bytes, void** d_out) {
             ctx->dev_cache.erase(ctx->dev_cache.begin() + best);
             return PZ_OK;
         }
+        // a miss.  Cached blocks a little SMALLER than the request (down to 7/8 of it) are what the same array was for a key of slightly
+        // fewer columns: the block allocated now serves both sizes from here on, so they are obsolete -- released before the allocation.
+        // Without this the cache converges to TWO blocks per array (one per size class on either side of a rounding boundary): 2 x 150 GB
+        // at config c2 (found by the 40-message soak of prove_connected --fresh: out of memory at the fifth key)
+        for (size_t i = 0; i < ctx->dev_cache.size();) {
+            const size_t c = ctx->dev_cache[i].second;
+            if (c < bytes && bytes - c <= bytes / 8) {
+                (void)hipFree(ctx->dev_cache[i].first);
+                ctx->dev_cache_bytes -= c;
+                ctx->dev_cache.erase(ctx->dev_cache.begin() + (long)i);
+            } else {
+                ++i;
+            }
+        }
     }
     HIPCHK(ctx, pz_hip_malloc(ctx, d_out, bytes));
     if (ctx->dev_cache_limit && bytes >= PZ_DEV_CACHE_MIN) ctx->dev_live[*d_out] = bytes;

@@ -794,7 +794,7 @@ struct DevBufs {
     }
     template <class T> int get(pz_ctx* ctx, size_t count, T** out) {
         void* d = nullptr;
-        HIPCHK(ctx, hipMalloc(&d, (count ? count : 1) * sizeof(T)));
+        HIPCHK(ctx, pz_hip_malloc(ctx, &d, (count ? count : 1) * sizeof(T)));   // (out of memory: the pz_dev_alloc block cache is released, once)
         bufs.push_back(d);
         *out = (T*)d;
         return PZ_OK;
@@ -934,7 +934,7 @@ extern "C" int pz_circuit_structure_dev(pz_ctx* ctx, int kind, uint32_t limbs_n,
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // the host vectors above go out of use only now
 
     // ---- outputs
-    HIPCHK(ctx, hipMalloc((void**)&st->d_selectors, (size_t)(A * n)));
+    HIPCHK(ctx, pz_hip_malloc(ctx, (void**)&st->d_selectors, (size_t)(A * n)));
     st->ctx = ctx;                                      // from here pz_structure_free releases what was allocated
     struct Guard {                                      // (a failing step below frees the half-built structure)
         std::unique_ptr<pz_structure>& s;
@@ -943,9 +943,9 @@ extern "C" int pz_circuit_structure_dev(pz_ctx* ctx, int kind, uint32_t limbs_n,
             if (armed) pz_structure_free(s.release());
         }
     } guard{st};
-    HIPCHK(ctx, hipMalloc((void**)&st->d_map_col, (size_t)span * 4));
-    HIPCHK(ctx, hipMalloc((void**)&st->d_map_row, (size_t)span * 4));
-    HIPCHK(ctx, hipMalloc((void**)&st->d_starts, ((size_t)A + 1) * 8));
+    HIPCHK(ctx, pz_hip_malloc(ctx, (void**)&st->d_map_col, (size_t)span * 4));
+    HIPCHK(ctx, pz_hip_malloc(ctx, (void**)&st->d_map_row, (size_t)span * 4));
+    HIPCHK(ctx, pz_hip_malloc(ctx, (void**)&st->d_starts, ((size_t)A + 1) * 8));
     HIPCHK(ctx, hipMemcpyAsync(st->d_starts, st->starts.data(), ((size_t)A + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(st->d_selectors, 0, (size_t)(A * n), ctx->stream));
 

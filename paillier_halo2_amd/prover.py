@@ -281,7 +281,8 @@ class Transcript:
         self.ch = ch
 
     def absorb_points(self, eng: Engine, *jac_tensors):
-        pass
+        """-> the affine forms (one array per tensor): the phase's synchronising download; create_proof keeps them for the proof"""
+        return [eng.g1_normalize(t.cpu().numpy().view(np.uint64)) for t in jac_tensors]
 
     def absorb_scalars(self, *host_arrays):
         pass
@@ -302,8 +303,12 @@ class HashTranscript(Transcript):
         self.drawn: Dict[str, int] = {}
 
     def absorb_points(self, eng: Engine, *jac_tensors):
+        out = []
         for t in jac_tensors:
-            self.h.update(eng.g1_normalize(t.cpu().numpy().view(np.uint64)).tobytes())
+            a = eng.g1_normalize(t.cpu().numpy().view(np.uint64))
+            self.h.update(a.tobytes())
+            out.append(a)
+        return out
 
     def absorb_scalars(self, *host_arrays):
         for a in host_arrays:
@@ -423,9 +428,19 @@ def create_proof(pk: ProvingKey, cols, tr, seed: Optional[int] = 0, tile: int = 
             timings[name] = timings.get(name, 0.0) + (now - t_last[0]) * 1e3
             t_last[0] = now
 
+    eng2, split_cols = hooks.get("commit_engine"), int(hooks.get("commit_split", 512))
+
     def commit(bases, t, count, stride_u64):
         out = _zeros(count, 12)
-        eng.msm_dev(bases, t.data_ptr(), count, n, stride_u64, out.data_ptr())
+        if eng2 is None or count < 2 * split_cols:
+            eng.msm_dev(bases, t.data_ptr(), count, n, stride_u64, out.data_ptr())
+            return out
+        # EXPERIMENT (hooks["commit_engine"]; measured and not adopted): column groups alternate between two contexts, so
+        # that one group's memory-bound sort / latency-bound tree can run beside the other's multiplier-bound accumulation
+        eng2.wait_for(eng)
+        for i, c0 in enumerate(range(0, count, split_cols)):
+            (eng if i % 2 == 0 else eng2).msm_dev(bases, t[c0].data_ptr(), min(split_cols, count - c0), n, stride_u64, out[c0].data_ptr())
+        eng.wait_for(eng2)
         return out
 
     def to_coeff(t, cnt):       # lagrange_to_coeff in place, `tile` columns per call (bounds the transform workspace)
@@ -443,7 +458,7 @@ def create_proof(pk: ProvingKey, cols, tr, seed: Optional[int] = 0, tile: int = 
     c_adv = commit(bl, cols, W, 4 * n)
     if "after_advice_launch" in hooks:      # the caller's chance to queue independent work (the NEXT proof's witness on another context)
         hooks["after_advice_launch"]()      # while this proof's largest commitment batch runs and before the host waits for it
-    tr.absorb_points(eng, c_adv)
+    (a_adv,) = tr.absorb_points(eng, c_adv)
     tr.squeeze("theta")
     phase("advice_commit")
     # ---- 2. lookups: permuted input / table (one expression each side: theta does not enter) -> beta, gamma
@@ -455,7 +470,7 @@ def create_proof(pk: ProvingKey, cols, tr, seed: Optional[int] = 0, tile: int = 
     Ap[:, u:] = _random_fr(gen, Lk, n - u)
     Sp[:, u:] = _random_fr(gen, Lk, n - u)
     c_ap, c_sp = commit(bl, Ap, Lk, 4 * n), commit(bl, Sp, Lk, 4 * n)
-    tr.absorb_points(eng, c_ap, c_sp)
+    a_ap, a_sp = tr.absorb_points(eng, c_ap, c_sp)
     beta_i, gamma_i = tr.squeeze("beta"), tr.squeeze("gamma")
     beta, gamma = M(beta_i), M(gamma_i)
     phase("lookup_permute_commit")
@@ -472,7 +487,7 @@ def create_proof(pk: ProvingKey, cols, tr, seed: Optional[int] = 0, tile: int = 
     rnd = ws.rnd
     rnd.copy_(_random_fr(gen, 1, n))
     c_rnd = commit(bm, rnd, 1, 4 * n)
-    tr.absorb_points(eng, c_z, c_zl, c_rnd)
+    a_z, a_zl, a_rnd = tr.absorb_points(eng, c_z, c_zl, c_rnd)
     y_i = tr.squeeze("y")
     y = M(y_i)
     phase("products_commit")
@@ -549,7 +564,7 @@ def create_proof(pk: ProvingKey, cols, tr, seed: Optional[int] = 0, tile: int = 
         eng.fr_lincomb_dev(t01.data_ptr(), 2, 4 * n, n, M(-g2n % FR), pieces[0].data_ptr())            # h_0 = U - g^2n h_2
         pieces[3].zero_()
     c_h = commit(bm, pieces, d.E - 1, 4 * n)
-    tr.absorb_points(eng, c_h)
+    (a_h,) = tr.absorb_points(eng, c_h)
     x_i = tr.squeeze("x")
     phase("quotient")
     # ---- 5. evaluations -> SHPLONK's y, v
@@ -604,16 +619,15 @@ def create_proof(pk: ProvingKey, cols, tr, seed: Optional[int] = 0, tile: int = 
     w1, w2 = ws.w1, ws.w2
     state = eng.shplonk_begin_dev(n, sets, np.stack([M(p) for p in xs]), M(shy), M(shv), w1.data_ptr())
     c_w1 = commit(bm, w1.view(1, n, 4), 1, 4 * n)
-    tr.absorb_points(eng, c_w1)
+    (a_w1,) = tr.absorb_points(eng, c_w1)
     shu = tr.squeeze("sh_u")
     eng.shplonk_finish_dev(state, M(shu), w1.data_ptr(), w2.data_ptr())
     c_w2 = commit(bm, w2.view(1, n, 4), 1, 4 * n)
     eng.sync()
     phase("multiopen")
-    # ---- the proof
-    norm = lambda t: eng.g1_normalize(host(t))
-    pr.commitments = {"advice": norm(c_adv)[:A], "lookup_advice": norm(c_adv)[A:], "perm_inputs": norm(c_ap), "perm_tables": norm(c_sp),
-                      "perm_z": norm(c_z), "lookup_z": norm(c_zl), "random": norm(c_rnd), "h": norm(c_h), "w1": norm(c_w1), "w2": norm(c_w2)}
+    # ---- the proof (the affine forms are the ones the transcript absorbed phase by phase: normalised once)
+    pr.commitments = {"advice": a_adv[:A], "lookup_advice": a_adv[A:], "perm_inputs": a_ap, "perm_tables": a_sp,
+                      "perm_z": a_z, "lookup_z": a_zl, "random": a_rnd, "h": a_h, "w1": a_w1, "w2": eng.g1_normalize(host(c_w2))}
     pr.evals = {"advice": ev["advice"], "lookup_advice": ev["lookup_advice"][:Lk], "constants": ev["lookup_advice"][Lk:], "fixed": ev["fixed"],
                 "sigma": ev["sigma"], "perm_z": ev["perm_z"], "lookup_z": ev["lookup_z"], "perm_inputs": ev["perm_inputs"],
                 "perm_tables": ev["perm_tables"], "random": ev["random"], "h": ev["h"]}

@@ -471,6 +471,50 @@ def test_device_memory_entry_points(eng, cref):
     eng.dev_free(0)
 
 
+def test_dev_block_cache(cref):
+    """pz_dev_cache_limit: freed blocks of 32 MiB and more are kept by the context and serve the next request of that size (or up to an
+    eighth smaller); a request a little LARGER than a cached block releases that block (it is obsolete: the new one serves both sizes --
+    the growth the 40-message soak of `prove_connected --fresh` ran out of memory on); small blocks and a zero limit bypass the cache"""
+    import ctypes as C
+
+    import paillier_halo2_amd as pz
+
+    e = pz.Engine(0)
+    try:
+        MiB = 1 << 20
+        limit = lambda b: e._chk(e.L.pz_dev_cache_limit(e.ctx, C.c_size_t(b)), "pz_dev_cache_limit")
+        limit(1 << 32)
+        p1 = e.dev_alloc(64 * MiB)
+        e.dev_memset(p1, 0x5A, 64 * MiB)
+        e.dev_free(p1)
+        p2 = e.dev_alloc(64 * MiB)                    # the cached block
+        assert p2 == p1
+        e.dev_free(p2)
+        p3 = e.dev_alloc(60 * MiB)                    # within an eighth: the same block again
+        assert p3 == p1
+        e.dev_free(p3)
+        small = e.dev_alloc(MiB)                      # below 32 MiB: never cached
+        e.dev_free(small)
+        p4 = e.dev_alloc(40 * MiB)                    # 64 is more than an eighth larger than 40: not served from the cache
+        assert p4 != p1
+        p5 = e.dev_alloc(68 * MiB)                    # a little larger than the cached 64: a new block, the 64 released
+        e.dev_free(p5)
+        p6 = e.dev_alloc(64 * MiB)                    # ... so a 64 request now gets the 68-MiB block
+        assert p6 == p5
+        e.dev_free(p6)
+        e.dev_free(p4)
+        limit(0)                                      # everything cached goes back to the driver; later frees are real frees
+        p7 = e.dev_alloc(64 * MiB)
+        e.dev_free(p7)
+        w = np.arange(8, dtype=np.uint64)
+        d = e.dev_alloc(64)
+        e.upload(d, w)
+        assert np.array_equal(e.download(d, (8,)), w)
+        e.dev_free(d)
+    finally:
+        e.close()
+
+
 def test_dev_copy_2d(eng):
     """pz_dev_copy_2d: the strided device copy the compiled prover fills the blinding rows with (rows [u, n) of every column from one
     staged block); pitches below the width and null pointers are refused"""
