@@ -894,7 +894,8 @@ def cpu_baseline(shape, n_steps, enc_bits, k, log, check_wl=None, connected=None
     t_ntt_ext = timeit(f_ext, r_ext)
     nn, g, m, r = P.synth_paillier_inputs(enc_bits, 0x5043)
     L = 2 * (enc_bits // 64)
-    e = m & ((1 << 1024) - 1) | (1 << 1023)
+    eb = min(1024, enc_bits)                       # a bounded sample of the chain: 1024 exponent bits (the whole exponent of a smaller key)
+    e = m & ((1 << eb) - 1) | (1 << (eb - 1))
     t = time.time()
     rc, res, steps = cref.pow_mod_trace(L, nn * nn, g, e, L // 2)
     t_step = (time.time() - t) / max(1, len(steps))

@@ -7,8 +7,9 @@
 // file, runs this binary and reports its proofs/s as `dropin_device_resident` beside its own `value`.
 //
 // job file: little-endian u64 words
-//   [0] magic 0x325a50  [1] enc_bits  [2] k  [3] lookup_bits  [4] n_steps  [5] msm_full  [6] polys  [7] pool  [8] ntt_batch
-//   [9] steps  [10] warmup  [11] log_e  [12] seed
+//   [0] magic 0x335a50  [1] enc_bits  [2] k  [3] lookup_bits  [4] n_steps  [5] msm_full  [6] polys  [7] pool  [8] ntt_batch
+//   [9] steps  [10] warmup  [11] log_e  [12] seed  [13] max_rows (rows a column is filled to)  [14] minimum_rows (calculate_params' argument:
+//   fixes the column COUNT; paillier_halo2_amd/layout.py RowBudget)
 //   then n | g | m | r (Ln words each), res | n^2 (2 Ln words each), s_toxic, omega_n, omega_n_inv, n_inv (4 words each,
 //   Montgomery), coset_gens (2^log_e x 4 words), then [n_extra] and per extra message of the SAME circuit shape: m | r (Ln
 //   words each), res (2 Ln words)
