@@ -1245,7 +1245,7 @@ def hot_path_line(args, R):
                     "note": "WORK-EQUIVALENT STAND-IN, not a prover: the pipelined hot path + the later phases' kernels run for their WORK (the "
                             "quotient kernels over one stale 64-column tile with random selector / product inputs, the full-width commitments "
                             "over pool scalars, evaluations and SHPLONK over pool polynomials) -- instruction counts of a proof, not its dataflow. "
-                            "The connected flow is `with_next_rows`"}
+                            "The connected flow is the headline `value` (connected_line)"}
         except Exception as ex:
             body = {"error": repr(ex)}
     dropin = None
@@ -1333,7 +1333,7 @@ def hot_path_line(args, R):
             "perm_cols": sh.perm_cols, "advice_cols_committed": wl.adv_cols, "lookup_cols_committed": wl.lk_cols,
             "cells_per_mul_mod": wl.cells, "advice_cells": wl.n_steps * wl.cells, "msm_per_proof": n_adv + cnt["msm_full"],
             "ntt_polys_per_proof": cnt["polys"], "scale": args.scale,
-            "scope": "hot path only (SURVEY section 8a): value excludes the prover steps after it (products, evaluate_h, evaluations: inside the timed region of with_next_rows, phase by phase in next_rows_ms_per_proof) and the transcript",
+            "scope": "hot path only (SURVEY section 8a): excludes the prover steps after it (products, evaluate_h, evaluations, openings -- all inside the connected proof, the headline `value`) and the transcript",
             "layout_parity": "unpinned: cell patterns and column counts restate the biguint-halo2 / halo2-lib dependencies (SURVEY tag [D]); emitted: assign_integer x5, square, refresh, load_zero, pow_mod constants, every mul_mod, assert_equal_fresh (the whole driver, row a6); omitted: nothing of the driver; blinding rows are left zero",
             "advice_cells_whole_circuit": wl.circ_adv, "lookup_cells_whole_circuit": wl.circ_lk,
             "parallelism": ("one proof, columns split over the ranks, all-gather of the commitments" if colpar
@@ -1500,9 +1500,12 @@ def connected_line(args, R):
         if "--steps" not in sys.argv:
             args.steps = 3
         streamed, pipeline, lookup_tile = 0, False, 16
+    if preset == "c3":      # BASELINE config c3: the homomorphic-add circuit (PaillierChip::add, paillier.rs:62-85; bench.rs:77-117) at k = 15
+        if args.k == 17:
+            args.k = 15
     if os.environ.get("PZ_CONNECTED_STREAMED_KEY", "") != "":
         streamed = int(os.environ["PZ_CONNECTED_STREAMED_KEY"])
-    circuit = "encrypt_uniform" if preset == "c2u" else "encrypt"
+    circuit = "encrypt_uniform" if preset == "c2u" else "add" if preset == "c3" else "encrypt"
     headline_cfg = preset == "c2" and (args.enc_bits, args.k) == (2048, 17)
     cw = bench_connected.ConnectedWorkload(eng, torch, args.enc_bits, args.k, args.seed + rank, lookup_bits=args.lookup_bits, log=log, circuit=circuit,
                                            minimum_rows=args.minimum_rows, streamed_key=streamed, pipeline=pipeline, lookup_tile=lookup_tile)
@@ -1557,11 +1560,12 @@ def connected_line(args, R):
             traffic_src = pj["source"]
     except Exception:
         pass
-    shape_name = ("c2 encrypt" if headline_cfg else "c2u uniform-shape encrypt" if preset == "c2u" else "c5-shape encrypt" if (args.enc_bits, args.k) == (3072, 19) else "custom encrypt")
+    shape_name = ("c2 encrypt" if headline_cfg else "c2u uniform-shape encrypt" if preset == "c2u" else "c3 homomorphic add" if preset == "c3"
+                  else "c5-shape encrypt" if (args.enc_bits, args.k) == (3072, 19) else "custom encrypt")
     out = {
         "metric": ("Paillier-encrypt proofs/s (2048-bit n, k=17); MSM achieved HBM GB/s vs peak" if headline_cfg
-                   else "Paillier-encrypt%s proofs/s (%d-bit n, k=%d) -- NOT the headline configuration; MSM achieved HBM GB/s vs peak"
-                   % (" (uniform-shape circuit)" if preset == "c2u" else "", args.enc_bits, args.k)),
+                   else "Paillier-%s proofs/s (%d-bit n, k=%d) -- NOT the headline configuration; MSM achieved HBM GB/s vs peak"
+                   % ("add" if preset == "c3" else "encrypt (uniform-shape circuit)" if preset == "c2u" else "encrypt", args.enc_bits, args.k)),
         "value": value, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32 limbs (29-bit reduced radix, 254-bit modular integers), u64 limbs (4096-bit integers)", "data": "synthetic",
@@ -1669,7 +1673,7 @@ def connected_line(args, R):
     gc.collect()
     torch.cuda.empty_cache()
     # ---- the same proof from the COMPILED prover: plain C++ over the C ABI, a child process with its own contexts
-    if extras and not args.no_dropin and preset != "c5":
+    if extras and not args.no_dropin and preset not in ("c5", "c3"):
         try:
             t_p = time.time()
             out["compiled_prover"] = bench_connected.cpp_connected(cw, proofs=5, verify_with=_cref if ver is not None else None, log=log)
@@ -1764,7 +1768,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=["c2", "c2u", "c3", "c5", "msm22", "stub"],
-                    help="c2: encrypt proof hot path (headline); c2u: the same key size through the uniform-shape circuit (g^m over all message bits in circuit, SURVEY 8f rank 4); c3: homomorphic-add circuit at --k 15; msm22: one sharded MSM")
+                    help="c2: ONE CONNECTED encrypt proof per step (headline); c2u: the same key size through the uniform-shape circuit (g^m over all message bits in circuit, SURVEY 8f rank 4); "
+                         "c3: homomorphic-add circuit at --k 15; c5: 3072-bit n, k = 19 (streamed proving key); msm22: one sharded MSM; each of c2 / c2u / c3 / c5 as a connected proof "
+                         "(--hot-path-headline: the hot path only)")
     ap.add_argument("--k", type=int, default=17)
     ap.add_argument("--enc-bits", type=int, default=2048)
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the per-proof MSM/NTT counts (debug only; "
@@ -1886,7 +1892,7 @@ def main():
 
     R = argparse.Namespace(rank=rank, world=world, local=local, use_dist=use_dist, log=log, eng=eng, mad_peak=mad_peak, barrier=barrier)
     # (--parallel columns splits ONE proof's hot-path columns over the ranks: a mode of the hot-path workload)
-    if args.workload in ("c2", "c2u", "c5") and not args.hot_path_headline and args.parallel != "columns":
+    if args.workload in ("c2", "c2u", "c3", "c5") and not args.hot_path_headline and args.parallel != "columns":
         out = connected_line(args, R)
     else:
         out = hot_path_line(args, R)

@@ -1,4 +1,4 @@
-"""bench.py's `with_next_rows` leg: ONE connected proof per step at the benchmark's configuration -- the whole create_proof dataflow
+"""bench.py's HEADLINE workload (round 5: its `with_next_rows` leg): ONE connected proof per step at the benchmark's configuration -- the whole create_proof dataflow
 of paillier_halo2_amd/prover.py on the proof's own data (reference: /root/reference/src/bench.rs:161-171, `gen_proof` after keygen):
 
     K3 trace -> K4 cells in halo2-lib's break-point column layout -> advice commitments -> permuted lookup columns -> grand products
@@ -128,13 +128,18 @@ class ConnectedWorkload:
         self.ints = (nn, g, m, r)
         self.circuit = circuit
         self.uniform = circuit == "encrypt_uniform"
-        self.kind = 2 if self.uniform else 0
-        self.ng = 2 * enc_bits if self.uniform else m.bit_length() + bin(m).count("1")
-        self.nr = nn.bit_length() + bin(nn).count("1")
+        self.add = circuit == "add"            # PaillierChip::add (paillier.rs:62-85): ONE mul_mod of two ciphertexts assigned at enc_bits (bench.rs:98-103)
+        self.kind = 2 if self.uniform else 1 if self.add else 0
+        self.ng = 0 if self.add else 2 * enc_bits if self.uniform else m.bit_length() + bin(m).count("1")
+        self.nr = 0 if self.add else nn.bit_length() + bin(nn).count("1")
         self.n_steps = self.ng + self.nr + 1
         vr = random.Random(seed ^ 0x636F6E)
         lim = lambda x: consts.int_to_limbs(x, self.Ln)
-        if self.uniform:
+        if self.add:
+            # the add circuit's shape does not depend on its inputs: one key, the proofs of a run are of DISTINCT ciphertext pairs
+            # (variant = n | unused | c1 | c2, each Ln words: c1, c2 uniform below 2^enc_bits as the reference's test assigns them)
+            self.variants = [tuple(lim(x) for x in (nn, 0, vr.getrandbits(enc_bits), vr.getrandbits(enc_bits))) for _ in range(3)]
+        elif self.uniform:
             # the uniform-shape circuit: the message's bits are WITNESS cells -- one key serves every message: the
             # proofs of a run are of DISTINCT messages
             self.variants = [tuple(lim(x) for x in (nn, g, mm, rr)) for mm, rr in ((m, r), (vr.randrange(0, nn), vr.randrange(1, nn)),
@@ -204,7 +209,8 @@ class ConnectedWorkload:
             self.free_ev = [torch.cuda.Event() for _ in range(2)]
         self.produced = 0
         self.d_steps = torch.zeros((self.n_steps, 4, self.L), dtype=torch.int64, device="cuda")
-        self.d_mod = torch.from_numpy(consts.int_to_limbs(nn * nn, self.L).astype(np.int64)).cuda()
+        self._n2_limbs = consts.int_to_limbs(nn * nn, self.L)
+        self.d_mod = torch.from_numpy(self._n2_limbs.astype(np.int64)).cuda()
         self.timings = {}
         self.last = None
         self.done = 0
@@ -229,7 +235,15 @@ class ConnectedWorkload:
             if self.stream_w is not None:
                 self.stream_w.wait_event(self.free_ev[slot])        # the proof that used this slot has finished with it
             cols.zero_()
-            if self.uniform:
+            if self.add:
+                # K3: the single step (c1, c2, q, r) of c1 c2 mod n^2 (pz_mul_mod; host-pointer form: four 4096-bit integers)
+                ext = lambda a: np.concatenate([a, np.zeros(self.L - a.shape[0], dtype=np.uint64)])
+                a_, b_ = ext(m), ext(r)
+                q, rem = eng.mul_mod(self.L, a_, b_, self._n2_limbs)
+                self.d_steps.copy_(torch.from_numpy(np.stack([a_, b_, np.asarray(q, dtype=np.uint64), np.asarray(rem, dtype=np.uint64)]).astype(np.int64)).view(1, 4, self.L),
+                                   non_blocking=False)
+                c = [rem]
+            elif self.uniform:
                 c, _, _ = eng.paillier_encrypt_uniform_dev(self.Ln, self.enc_bits, nn, g, m, r, self.d_steps.data_ptr(), self.n_steps)
             else:
                 c, _, _ = eng.paillier_encrypt_dev(self.Ln, nn, g, m, r, self.d_steps.data_ptr(), self.n_steps)      # K3 (returns the ciphertext)

@@ -73,3 +73,14 @@ def test_default_line_legs_small_shape():
     assert "compiled_prover" in d and d["compiled_prover"]["quotient_degree_ok"] is True and d["compiled_prover"]["ms_per_step"] > 0
     assert d["compiled_stepper"]["quotient_degree_ok"] is True and "stepper" in d["compiled_stepper"]["via"]
     assert "hot_path_only" not in d and "fresh_message_cpp" not in d
+
+
+def test_c3_add_circuit_is_a_connected_line_too():
+    """BASELINE config c3 (PaillierChip::add, /root/reference/src/paillier.rs:62-85 through bench.rs:77-117) as a connected proof: one key, distinct
+    ciphertext pairs per proof, verified -- here at 256-bit / k = 12; `--hot-path-headline` keeps rounds 1-5's hot-path line"""
+    d = _bench(["--workload", "c3", "--enc-bits", "256", "--k", "12", "--steps", "3", "--warmup", "1", "--headline-only"])
+    assert d["verified"] is True and d["config"]["scope"].startswith("one connected proof") and "add" in d["metric"]
+    assert d["config"]["mul_mod_steps"] == 1 and d["value"] > 0
+    h = _bench(["--workload", "c3", "--enc-bits", "256", "--k", "12", "--steps", "3", "--warmup", "1", "--hot-path-headline", "--no-cpu-baseline", "--no-dropin",
+                "--no-tail"])
+    assert h["config"]["scope"].startswith("hot path only") and h["verified"] is True
