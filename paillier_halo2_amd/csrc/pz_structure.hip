@@ -998,9 +998,16 @@ extern "C" int pz_circuit_structure_dev(pz_ctx* ctx, int kind, uint32_t limbs_n,
     if (M > 0) {
         // ---- sorted by (class, position): ONE radix sort of the combined key (class < T < 2^32, position < m n < 2^32)
         u64 *keys = nullptr, *keys2 = nullptr;
-        PZCHK(tmp.get(ctx, (size_t)M, &keys)); PZCHK(tmp.get(ctx, (size_t)M, &keys2));
+        PZCHK(tmp.get(ctx, (size_t)M, &keys));
         hipLaunchKernelGGL(k_struct_keys, grid(M), dim3(TB), 0, ctx->stream, (const u32*)members, M, root, (const u32*)pos, (u64)span, keys);
         HIPCHK(ctx, hipGetLastError());
+        // the node arrays are done with once the keys exist: released BEFORE the sort's second buffer is allocated (peak 25 GB instead of 45
+        // at config c5, where the generator runs beside a cached 119-GB key)
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        tmp.drop(src);
+        tmp.drop(src2);
+        tmp.drop(pos);
+        PZCHK(tmp.get(ctx, (size_t)M, &keys2));
         unsigned key_bits = 1;
         while (key_bits < 64 && (((u64)T * (u64)span) >> key_bits) != 0) ++key_bits;
         {

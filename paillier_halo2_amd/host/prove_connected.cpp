@@ -102,6 +102,8 @@ static int fresh_main(const char* params_path, const char* proof_path) {
     Out out{fopen(proof_path, "wb")};
     if (!out.f) { perror(proof_path); return 2; }
     bool degree_ok = true;
+    const char* sk = getenv("PZ_PROVE_STREAMED_KEY");      // R: the streamed proving key (0 at config c5)
+    const size_t ext_res = sk && *sk ? strtoull(sk, nullptr, 10) : EXT_ALL;
     double sum_after_first = 0, structure_ms = 0, keygen_ms = 0, witness_ms = 0, prove_ms = 0;
     size_t last_adv = 0, last_lk = 0;
     for (size_t si = 0; si < steps; ++si) {
@@ -121,7 +123,7 @@ static int fresh_main(const char* params_path, const char* proof_path) {
         const size_t A = st.n_adv, m = st.m();
         const double t1 = now_ms();
         // ---- keygen on the structure's device arrays; the break points stay (K4), the rest of the structure goes
-        ProvingKey* pk = keygen(cx, std::move(st), bl, bm);
+        ProvingKey* pk = keygen(cx, std::move(st), bl, bm, ext_res);
         pk->st.d_selectors = nullptr; pk->st.d_map_col = pk->st.d_map_row = nullptr;
         uint64_t* d_starts_own = cx.alloc(cx.cols(A + 1));
         PZP_CK(pz_dev_copy(cx.c, d_starts_own, d_starts, (A + 1) * 8));
