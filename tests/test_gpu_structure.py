@@ -52,6 +52,38 @@ def test_native_structure_equals_the_python_generator(eng, bits, W, lb, k, seed,
         ns.free()
 
 
+def test_native_structure_against_the_oracle_walk(eng):
+    """the library's generator held directly against the ORACLE's restatement (oracle/circuit.py: a walk of the whole circuit WITH values, no code
+    shared with either product generator): break points, selectors, lookup column count, and sigma wherever the image is not in the constants column
+    (whose row order is each generator's own); and the native sigma is satisfied by the oracle's witness (a cell only maps to a cell of equal value)"""
+    from oracle import circuit as CQ
+    from paillier_halo2_amd import prover_native
+
+    for bits, W, lb, k, seed, kind in ((128, 64, 13, 14, 0x5042, "encrypt"), (264, 88, 12, 13, 0x99, "add")):
+        n, g, m, r = P.synth_paillier_inputs(bits, seed, standard_g=False)
+        res = P.paillier_add_native(n, m, r) if kind == "add" else P.paillier_enc_native(n, g, m, r)
+        st = CQ.build(kind, n, g, m, r, res, bits, W, lb, k)
+        assert CQ.mock_prover(st) == []
+        ns = prover_native.NativeStructure(eng, kind, bits, W, lb, k, exp_g=m, exp_r=n)
+        try:
+            assert (ns.n_adv, ns.n_lk, ns.max_rows) == (st.n_adv, st.n_lk, st.max_rows) and ns.starts().tolist() == st.starts
+            sel, mc, mr = ns.download()
+            assert np.array_equal(sel, st.selectors)
+            Wd = st.n_adv + st.n_lk
+            keep = st.map_col[:Wd] < Wd
+            assert np.array_equal(mc[:Wd] < Wd, keep)
+            assert np.array_equal(mc[:Wd][keep], st.map_col[:Wd][keep]) and np.array_equal(mr[:Wd][keep], st.map_row[:Wd][keep])
+            st.constants = ns.constants()
+            cols = CQ.perm_columns(st)
+            flat = mc.astype(np.int64) * st.n + mr
+            assert np.unique(flat).size == flat.size                      # a permutation
+            moved = np.argwhere(flat != np.arange(flat.size).reshape(flat.shape))
+            for c, rr in moved[:: max(1, moved.shape[0] // 4000)].tolist():
+                assert cols[c][rr] == cols[int(mc[c, rr])][int(mr[c, rr])], (kind, c, rr)
+        finally:
+            ns.free()
+
+
 def test_structure_to_key_to_proof_from_the_library_alone(eng, cref):
     """pz_circuit_structure_dev -> pz_pk_create_dev -> pz_structure_free -> K3 -> K4 with the structure's break points -> the stepper's
     proof, checked as the verifier would (oracle/verifier.py); the key equals the Python prover's key on the Python structure"""
