@@ -1499,12 +1499,15 @@ def connected_line(args, R):
         args.enc_bits, args.k = 3072, 19          # does not fit beside the rest: the STREAMED key (coefficient forms resident, tiles re-extended)
         if "--steps" not in sys.argv:
             args.steps = 3
-        streamed, pipeline, lookup_tile = 0, False, 16
+        streamed, pipeline, lookup_tile = "auto", False, 16        # memory_plan: R = 0 there (its extended key alone would be 239 GB)
     if preset == "c3":      # BASELINE config c3: the homomorphic-add circuit (PaillierChip::add, paillier.rs:62-85; bench.rs:77-117) at k = 15
         if args.k == 17:
             args.k = 15
     if os.environ.get("PZ_CONNECTED_STREAMED_KEY", "") != "":
-        streamed = int(os.environ["PZ_CONNECTED_STREAMED_KEY"])
+        sk_ = os.environ["PZ_CONNECTED_STREAMED_KEY"]
+        streamed = sk_ if sk_ == "auto" else int(sk_)
+    elif args.k >= 18 and streamed is None:
+        streamed = "auto"       # shapes beyond c2: keep what fits of the extended key, stream the rest (ConnectedWorkload.memory_plan)
     circuit = "encrypt_uniform" if preset == "c2u" else "add" if preset == "c3" else "encrypt"
     headline_cfg = preset == "c2" and (args.enc_bits, args.k) == (2048, 17)
     cw = bench_connected.ConnectedWorkload(eng, torch, args.enc_bits, args.k, args.seed + rank, lookup_bits=args.lookup_bits, log=log, circuit=circuit,

@@ -187,7 +187,10 @@ class ConnectedWorkload:
         # streamed_key: None = the extended proving key resident (c2: 77 GB); an integer R = only the first R permuted columns' extended forms
         # stay, the rest is re-extended per tile from the coefficient forms (R = 0 at BASELINE config c5: its extended key would be 239 GB)
         if streamed_key is None and os.environ.get("PZ_CONNECTED_STREAMED_KEY", "") != "":
-            streamed_key = int(os.environ["PZ_CONNECTED_STREAMED_KEY"])
+            streamed_key = os.environ["PZ_CONNECTED_STREAMED_KEY"]
+            streamed_key = streamed_key if streamed_key == "auto" else int(streamed_key)
+        if streamed_key == "auto":
+            streamed_key = self.memory_plan(tile, lookup_tile, 2 if (pipeline is None or pipeline) else 1)
         self.streamed_key = streamed_key
         self.pk = prover.keygen(eng, self.cs, self.bl, self.bm, cosets=self.cosets, ext_resident_cols=streamed_key)
         torch.cuda.synchronize()
@@ -217,11 +220,38 @@ class ConnectedWorkload:
         self.done = 0
         ext_bytes = sum(t.numel() * 8 for t in self.pk.fixed_ext + self.pk.sigma_ext)
         pk_bytes = ext_bytes + sum(t.numel() * 8 for t in (self.pk.fixed_coeff, self.pk.sigma_coeff, self.pk.sigma_lagrange))
-        self.memory_gb = {"proving_key_resident": pk_bytes / 1e9, "of_which_extended_forms": ext_bytes / 1e9,
+        self.memory_gb = {"plan": getattr(self, "memory_plan_gb", None), "proving_key_resident": pk_bytes / 1e9, "of_which_extended_forms": ext_bytes / 1e9,
                           "proving_key_streamed": bool(self.pk.streamed), "extended_forms_resident_columns": list(self.pk.ext_resident),
                           "quotient_domain_cosets": self.pk.dom.cosets,
                           "grand_products_extended": self.ws._z_ext_flat.numel() * 8 / 1e9, "witness_columns": sum(t.numel() for t in self.slots) * 8 / 1e9,
                           "torch_allocated_after_setup": torch.cuda.memory_allocated() / 1e9}
+
+    def memory_plan(self, tile, lookup_tile, n_slots, library_reserve_gb: float = 64.0):
+        """how many permuted columns' EXTENDED key forms can stay resident on this device (prover.ProvingKey ext_resident_cols): everything the
+        proof must hold is counted first -- coefficient forms of the key and sigma's Lagrange values, the witness slot(s), the grand products
+        and their extended form, the tiles -- then a reserve for the library's own workspaces (K1's sort / partial sums take up to 48 GiB, the
+        transforms and the product scans a few GB); what is left of the device's free memory goes to the extended key, whole tiles of 64
+        columns at a time.  -> None (all resident: config c2) or R (0 at config c5)"""
+        torch = self.torch
+        n, A, Lk, m = self.n, self.cs.n_adv, self.cs.n_lk, self.cs.m
+        F, S, E = A + 2, -(-m // 2), 32
+        parts = (2 * n, n)                       # the quotient's three cosets: a 2n-point and an n-point part
+        cap = lambda c, q=64: -(-c // q) * q
+        lt = min(tile, Lk, lookup_tile or tile)
+        fixed_need = (cap(F) + 2 * cap(m)) * n * E                                            # fixed + sigma coefficient forms, sigma's Lagrange values
+        fixed_need += n_slots * cap(m) * n * E                                                # witness
+        fixed_need += cap(S) * n * E + cap(S) * max(parts) * E + 3 * cap(Lk, 8) * n * E       # Z, its extended form (one part at a time), A' / S' / Z_lookup
+        fixed_need += sum(tile * p * E + 4 * lt * p * E + 3 * p * E for p in parts)          # advice tile, lookup tiles, accumulators
+        fixed_need += 2 * tile * max(parts) * E                                               # (streamed) the two key tiles
+        free_b, _total = torch.cuda.mem_get_info()
+        free_b += torch.cuda.memory_reserved() - torch.cuda.memory_allocated()       # blocks torch's allocator holds but nothing uses are available too
+        budget = free_b - fixed_need - int(library_reserve_gb * 1e9)
+        per_col = 2 * sum(parts) * E                                                          # one selector + one sigma column on all three cosets
+        R = int(budget // per_col) if budget > 0 else 0
+        self.memory_plan_gb = {"device_free_before_keygen": free_b / 1e9, "needed_without_extended_key": fixed_need / 1e9,
+                               "library_reserve": library_reserve_gb, "extended_key_if_all_resident": m * per_col / 1e9,
+                               "resident_columns_planned": None if R >= m else max(0, R // tile * tile)}
+        return None if R >= m else max(0, R // tile * tile)
 
     def produce(self, eng=None):
         """K3 + K4 of the next proof into the next witness slot (on the witness context when pipelining)"""

@@ -374,6 +374,26 @@ def test_streamed_proving_key_proves_byte_for_byte_the_same(eng, cref):
     srs[1].free()
 
 
+def test_memory_plan_of_the_extended_key(eng):
+    """ConnectedWorkload(streamed_key="auto"): what fits of the extended key stays resident -- all of it at a small shape, none when the
+    reserve exceeds the device (what config c5 comes to: bench.py --workload c5), whole tiles in between"""
+    import torch
+
+    import bench_connected
+
+    wl = bench_connected.ConnectedWorkload(eng, torch, 128, 14, 0x5042, streamed_key="auto", pipeline=False)
+    try:
+        assert wl.streamed_key is None and wl.pk.streamed is False and wl.memory_gb["plan"]["resident_columns_planned"] is None
+        assert wl.memory_plan(8, None, 1, library_reserve_gb=1e6) == 0
+        free_gb = wl.memory_plan_gb["device_free_before_keygen"]
+        need = wl.memory_plan_gb["needed_without_extended_key"]
+        per_col_gb = 2 * 3 * wl.n * 32 / 1e9
+        R = wl.memory_plan(8, None, 1, library_reserve_gb=free_gb - need - 10.5 * per_col_gb)     # room for ten and a half columns
+        assert R == 8, (R, wl.memory_plan_gb)
+    finally:
+        wl.release()
+
+
 def test_c2_structure_and_witness_agree_at_size(eng, cref):
     """config c2 itself (2048-bit n, k = 17: 3.97 x 10^8 advice cells in 3033 break-point columns, 1.1 x 10^7 lookup cells in 84): the
     circuit structure the product generates and the witness K3 -> K4 writes describe the SAME circuit -- every one of sigma's
