@@ -458,6 +458,9 @@ class ConnectedWorkload:
             p = a.shape[1]
             return [flat[i * p:(i + 1) * p] for i in range(a.shape[0])]
 
+        # the verifier's side of Fiat-Shamir: every challenge re-derived from the proof (must be the ones the prover's transcript drew)
+        drawn = V.replay_challenges(ch.transcript_seed, pr.commitments, pr.evals)
+        replayed = all(getattr(ch, nm) == v_ for nm, v_ in drawn.items()) and len(drawn) == 8
         ev = {k_: ints(v_) for k_, v_ in pr.evals.items()}
         want = V.expected_h(self.k, self.cs.blinding_factors, self.A, self.Lk, prover.CHUNK, ev, ch.beta, ch.gamma, ch.y, ch.x, prover.DELTA)
         ident = bool(want == ev["h"][0][0])
@@ -469,8 +472,8 @@ class ConnectedWorkload:
         lay = prover.query_layout(self.A, self.Lk, self.m, self.pk.n_sets)
         pts = prover.rotation_points(self.pk.dom, ch.x)
         opening = bool(V.shplonk_check(cref, lay, pts, com, ev, ch.sh_y, ch.sh_v, ch.sh_u, pr.commitments["w1"][0], pr.commitments["w2"][0], self.s_tox))
-        return {"verified": bool(pr.h_degree_ok and ident and opening), "quotient_degree_le_3n_minus_4": bool(pr.h_degree_ok),
-                "h_x_times_xn_minus_1_equals_expression_of_evaluations": ident, "shplonk_identity_on_the_proofs_commitments": opening,
+        return {"verified": bool(pr.h_degree_ok and ident and opening and replayed), "quotient_degree_le_3n_minus_4": bool(pr.h_degree_ok),
+                "challenges_rederived_from_the_proof": bool(replayed), "h_x_times_xn_minus_1_equals_expression_of_evaluations": ident, "shplonk_identity_on_the_proofs_commitments": opening,
                 "commitments": int(sum(v.shape[0] for v in pr.commitments.values())), "evaluations": int(sum(v.shape[0] * v.shape[1] for v in pr.evals.values())),
                 "checker_s": time.perf_counter() - t0}
 
@@ -513,6 +516,12 @@ def verify_file_proof(cref, rec, prefix, st, k, s_tox):
         return [flat[i * p:(i + 1) * p] for i in range(a.shape[0])]
 
     ch = {nm: L(rec[prefix + "ch/" + nm][0]) for nm in ("theta", "beta", "gamma", "y", "x", "sh_y", "sh_v", "sh_u")}
+    # the verifier's side of Fiat-Shamir: the binary seeds a proof's transcript with its index (8 bytes); every challenge it recorded
+    # must be the one re-derived here from the proof's own commitments and evaluations
+    seed = int(prefix[1:-1]).to_bytes(8, "little")
+    drawn = V.replay_challenges(seed, {k_[len(prefix) + 2:]: v_ for k_, v_ in rec.items() if k_.startswith(prefix + "c/")},
+                                {k_[len(prefix) + 2:]: v_ for k_, v_ in rec.items() if k_.startswith(prefix + "e/")})
+    replayed = drawn == ch
     ev = {k_[len(prefix) + 2:]: ints(v_) for k_, v_ in rec.items() if k_.startswith(prefix + "e/")}
     ev["constants"] = ev["lookup_advice"][Lk:]
     ev["lookup_advice"] = ev["lookup_advice"][:Lk]
@@ -528,6 +537,6 @@ def verify_file_proof(cref, rec, prefix, st, k, s_tox):
     pts = prover.rotation_points(prover.Domain(k, st.blinding_factors), ch["x"])
     opening = bool(V.shplonk_check(cref, lay, pts, com, ev, ch["sh_y"], ch["sh_v"], ch["sh_u"], com["w1"][0], com["w2"][0], s_tox))
     degree = bool(int(rec[prefix + "flags"][0][0]) == 1)
-    return {"verified": bool(degree and ident and opening and shapes), "quotient_degree_le_3n_minus_4": degree,
-            "h_x_times_xn_minus_1_equals_expression_of_evaluations": ident, "shplonk_identity_on_the_proofs_commitments": opening,
+    return {"verified": bool(degree and ident and opening and shapes and replayed), "quotient_degree_le_3n_minus_4": degree,
+            "challenges_rederived_from_the_proof": bool(replayed), "h_x_times_xn_minus_1_equals_expression_of_evaluations": ident, "shplonk_identity_on_the_proofs_commitments": opening,
             "ciphertext": L(rec[prefix + "ciphertext"][0])}

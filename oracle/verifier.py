@@ -7,6 +7,8 @@ lookup/verifier.rs, vanishing/verifier.rs, multiopen/shplonk/verifier.rs; depend
 constraint lines on the extended coset, this file evaluates them at ONE point from the opened values only.
 
   expected_h(..)   : the verifier's expected_h_eval = (sum of all constraint lines folded by y) / (x^n - 1)
+  replay_challenges(..): the verifier's side of Fiat-Shamir -- every challenge re-derived from the proof's own commitments and evaluations
+                     (halo2's Blake2b transcript in its primitives; the drivers' HashTranscript / host/transcript.hpp are the prover's side)
   shplonk_check(..): the multi-point opening's final identity, in the exponent, against the proof's ACTUAL commitments (the tests
                      know the toxic scalar s of their SRS, so e(., [s - u]_2) becomes a scalar multiplication)
 """
@@ -119,3 +121,61 @@ def shplonk_check(cref, layout, points: Sequence[int], commitments: Dict[str, Se
     bases.append(cref.affine_ints_to_mont([P.G1_GEN])[0])
     acc = cref.g1_normalize(cref.msm_g1(cref.fr_ints_to_mont(scalars), np.stack(bases)))
     return not np.asarray(acc).any()                       # the identity: (0, 0) in the ABI's affine form
+
+
+COMMITMENT_ROUNDS = ((("advice", "lookup_advice"), ("theta",)), (("perm_inputs", "perm_tables"), ("beta", "gamma")),
+                     (("perm_z", "lookup_z", "random"), ("y",)), (("h",), ("x",)))
+EVAL_FAMILIES = ("advice", "lookup_advice", "fixed", "sigma", "perm_z", "lookup_z", "perm_inputs", "perm_tables", "random")
+
+
+def replay_challenges(seed: bytes, commitments: Dict[str, Sequence], evals: Dict[str, Sequence]) -> Dict[str, int]:
+    """what a verifier does before any arithmetic: read the proof in the order the prover wrote it and draw each challenge from
+    everything read so far.  Transcript = halo2's `Blake2bRead` [D] (halo2_proofs transcript/blake2b.rs) in its primitives: BLAKE2b-512,
+    personalisation "Halo2-Transcript", a domain byte per item (1 point, 2 scalar, 0 challenge), challenge = the digest of a clone of the
+    state as a little-endian 512-bit integer mod r (Fr::from_uniform_bytes).  Field elements enter as their 4 Montgomery words (the
+    form they have in a proof of this repo), a point as x then y; `seed` stands where halo2 absorbs the verifying key's digest.
+
+    commitments: family -> rows of 8 words (affine, Montgomery); evals: family -> rows of 4 * points words (Montgomery; the
+    "lookup_advice" family is followed by the "constants" row if that is held separately).  -> {challenge name: integer}"""
+    import hashlib
+    import struct
+
+    h = hashlib.blake2b(bytes(seed), digest_size=64, person=b"Halo2-Transcript")
+    out: Dict[str, int] = {}
+
+    def words(row):
+        return [int(w) for w in (row.reshape(-1) if hasattr(row, "reshape") else row)]
+
+    def point(row):
+        w = words(row)
+        assert len(w) == 8
+        h.update(b"\x01" + struct.pack("<8Q", *w))
+
+    def scalars(row):
+        w = words(row)
+        assert len(w) % 4 == 0
+        for i in range(0, len(w), 4):
+            h.update(b"\x02" + struct.pack("<4Q", *w[i:i + 4]))
+
+    def draw(name):
+        h.update(b"\x00")
+        out[name] = int.from_bytes(h.copy().digest(), "little") % R
+
+    for fams, names in COMMITMENT_ROUNDS:
+        for f in fams:
+            for row in commitments[f]:
+                point(row)
+        for nm in names:
+            draw(nm)
+    for f in EVAL_FAMILIES:
+        for row in evals[f]:
+            scalars(row)
+        if f == "lookup_advice" and "constants" in evals:
+            for row in evals["constants"]:
+                scalars(row)
+    draw("sh_y")
+    draw("sh_v")
+    for row in commitments["w1"]:
+        point(row)
+    draw("sh_u")
+    return out

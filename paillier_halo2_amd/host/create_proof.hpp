@@ -22,6 +22,7 @@
 
 #include "../../include/pz.h"
 #include "fr_host.hpp"
+#include "transcript.hpp"
 
 namespace pzp {
 using pzh::Fr;
@@ -291,45 +292,6 @@ inline ProvingKey* keygen(Ctx& cx, Structure&& st_in, const pz_bases* bl, const 
     PZP_CK(pz_g1_normalize(cx.c, jac.data(), m, pk->sigma_commit.data()));
     return pk.release();
 }
-
-// ---- transcript: every phase's commitments come to the host in affine form (a synchronising download) and are hashed; a challenge is
-// the running hash expanded to 252 bits.  The dataflow and round trips of halo2's Blake2b transcript, not its byte format.
-struct Transcript {
-    uint64_t h = 0xcbf29ce484222325ULL;
-    std::vector<std::pair<std::string, Fr>> drawn;       // (name, canonical value as 4 words)
-    void absorb(const void* data, size_t bytes) {
-        const uint8_t* p = (const uint8_t*)data;
-        for (size_t i = 0; i < bytes; ++i) {
-            h ^= p[i];
-            h *= 0x100000001b3ULL;
-        }
-    }
-    void absorb_points(Ctx& cx, const uint64_t* d_jac, size_t count, std::vector<uint64_t>* keep_affine = nullptr) {
-        std::vector<uint64_t> jac(12 * count), aff(8 * count);
-        PZP_CK(pz_download(cx.c, jac.data(), d_jac, count * 96));
-        PZP_CK(pz_g1_normalize(cx.c, jac.data(), count, aff.data()));
-        absorb(aff.data(), aff.size() * 8);
-        if (keep_affine) keep_affine->insert(keep_affine->end(), aff.begin(), aff.end());
-    }
-    Fr squeeze(const char* name) {   // -> Montgomery form; the canonical words are recorded for the checker
-        absorb(name, strlen(name));
-        uint64_t w[4], s = h;
-        for (int i = 0; i < 4; ++i) {   // splitmix64 expansion of the running hash
-            s += 0x9e3779b97f4a7c15ULL;
-            uint64_t z = s;
-            z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
-            z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
-            w[i] = z ^ (z >> 31);
-        }
-        w[3] &= 0x0fffffffffffffffULL;   // < 2^252 < r
-        w[0] |= 2;                       // not 0 or 1
-        Fr c;
-        memcpy(c.v, w, 32);
-        drawn.push_back({name, c});
-        h = s;
-        return pzh::from_raw(w);
-    }
-};
 
 struct Proof {
     std::vector<std::pair<std::string, std::vector<uint64_t>>> commitments;   // family -> affine points (8 words each)
@@ -737,12 +699,12 @@ inline Proof create_proof(Ctx& cx, ProvingKey& pk, Workspace& w, uint64_t* d_col
     Session se(cx, pk, w, d_cols, Rng(seed));
     Proof pr;
     auto keep = [&](const char* name, const std::vector<uint64_t>& aff) {
-        tr.absorb(aff.data(), aff.size() * 8);
+        tr.common_points(aff.data(), aff.size() / 8);
         pr.commitments.push_back({name, aff});
     };
     std::vector<uint64_t> a(8 * W), b, c;
     se.advice(a.data(), after_advice_launch);
-    tr.absorb(a.data(), a.size() * 8);
+    tr.common_points(a.data(), W);
     pr.commitments.push_back({"advice", std::vector<uint64_t>(a.begin(), a.begin() + 8 * A)});
     pr.commitments.push_back({"lookup_advice", std::vector<uint64_t>(a.begin() + 8 * A, a.end())});
     tr.squeeze("theta");
@@ -765,7 +727,7 @@ inline Proof create_proof(Ctx& cx, ProvingKey& pk, Workspace& w, uint64_t* d_col
     for (size_t f = 0; f < se.fams.size(); ++f) {
         pr.evals.push_back({se.fams[f].name, se.ev[f]});
         pr.eval_points.push_back({se.fams[f].name, (uint32_t)se.fams[f].idx.size()});
-        if (strcmp(se.fams[f].name, "h")) tr.absorb(se.ev[f].data(), se.ev[f].size() * 8);
+        if (strcmp(se.fams[f].name, "h")) tr.common_scalars(se.ev[f].data(), se.ev[f].size() / 4);
     }
     const Fr shy = tr.squeeze("sh_y"), shv = tr.squeeze("sh_v");
     a.assign(8, 0);

@@ -160,8 +160,7 @@ static int fresh_main(const char* params_path, const char* proof_path) {
                                           pk->st.max_rows, pk->st.max_rows, n));
         PZP_CK(pz_sync(cx.c));
         const double t3 = now_ms();
-        Transcript tr;
-        tr.absorb(&si, 8);
+        Transcript tr((uint64_t)si);
         Proof pr = create_proof(cx, *pk, ws, d_cols, tr, seed + si);
         PZP_CK(pz_sync(cx.c));
         const double t4 = now_ms();
@@ -240,27 +239,26 @@ static int stepper_main(Ctx& cx, int dev, Structure& st, const pz_bases* bl, con
                 PZP_CK(pz_sync(cw.c));
             });
         uint64_t* d_cols = d_slot[pi & 1];
-        Transcript tr;
-        tr.absorb(&pi, 8);
+        Transcript tr((uint64_t)pi);
         pz_proof* pr = nullptr;
         std::vector<uint64_t> adv(8 * (A + Lk)), ap(8 * Lk), sp(8 * Lk), cz(8 * S), czl(8 * Lk), crnd(8), ch(24), ev(ew), w1(8), w2(8);
         PZP_CK(pz_proof_begin(pk, d_cols, seed + pi, nullptr, PZ_BLINDING_SEEDED_TEST_STREAM, &pr, adv.data()));
-        tr.absorb(adv.data(), adv.size() * 8);
+        tr.common_points(adv.data(), A + Lk);
         const Fr theta = tr.squeeze("theta");
         PZP_CK(pz_proof_lookups(pr, theta.v, ap.data(), sp.data()));
-        tr.absorb(ap.data(), ap.size() * 8); tr.absorb(sp.data(), sp.size() * 8);
+        tr.common_points(ap.data(), Lk); tr.common_points(sp.data(), Lk);
         const Fr beta = tr.squeeze("beta"), gamma = tr.squeeze("gamma");
         PZP_CK(pz_proof_products(pr, beta.v, gamma.v, cz.data(), czl.data(), crnd.data()));
-        tr.absorb(cz.data(), cz.size() * 8); tr.absorb(czl.data(), czl.size() * 8); tr.absorb(crnd.data(), 64);
+        tr.common_points(cz.data(), S); tr.common_points(czl.data(), Lk); tr.common_points(crnd.data(), 1);
         const Fr y = tr.squeeze("y");
         PZP_CK(pz_proof_quotient(pr, y.v, ch.data()));
-        tr.absorb(ch.data(), 192);
+        tr.common_points(ch.data(), 3);
         const Fr x = tr.squeeze("x");
         PZP_CK(pz_proof_evaluate(pr, x.v, ev.data()));
-        tr.absorb(ev.data(), (ev.size() - 4) * 8);      // (h's value is the last element: the verifier computes it itself)
+        tr.common_scalars(ev.data(), ev.size() / 4 - 1);      // (h's value is the last element: the verifier computes it itself)
         const Fr shy = tr.squeeze("sh_y"), shv = tr.squeeze("sh_v");
         PZP_CK(pz_proof_open_begin(pr, shy.v, shv.v, w1.data()));
-        tr.absorb(w1.data(), 64);
+        tr.common_points(w1.data(), 1);
         const Fr shu = tr.squeeze("sh_u");
         int ok = 0;
         PZP_CK(pz_proof_open_finish(pr, shu.v, w2.data(), &ok));
@@ -455,8 +453,7 @@ int main(int argc, char** argv) {
         }
         PZP_CK(pz_sync(cx.c));
         const double t1 = now_ms();
-        Transcript tr;
-        tr.absorb(&pi, 8);
+        Transcript tr((uint64_t)pi);
         std::function<void()> hook;
         if (pipeline && pi + 1 < proofs) hook = [&, pi] { produce(pi + 1); };
         Proof pr = create_proof(cx, *pk, ws, d_cols, tr, seed + pi, hook);

@@ -272,6 +272,7 @@ class Challenges:
     sh_y: int      # SHPLONK's y, v, u
     sh_v: int
     sh_u: int
+    transcript_seed: Optional[bytes] = None      # HashTranscript: what a verifier needs to replay the transcript; None = fixed challenges
 
 
 class Transcript:
@@ -284,6 +285,9 @@ class Transcript:
         """-> the affine forms (one array per tensor): the phase's synchronising download; create_proof keeps them for the proof"""
         return [eng.g1_normalize(t.cpu().numpy().view(np.uint64)) for t in jac_tensors]
 
+    def absorb_affine(self, *host_arrays):
+        pass
+
     def absorb_scalars(self, *host_arrays):
         pass
 
@@ -292,36 +296,52 @@ class Transcript:
 
 
 class HashTranscript(Transcript):
-    """a stand-in for halo2's Blake2b transcript with the same DATAFLOW: every phase's commitments are brought to the host in affine
-    form (a synchronising download: the prover cannot start the next phase before the challenge exists), hashed, and the challenge is
-    the digest reduced mod r.  Not halo2's byte format (the transcript is out of scope)."""
+    """the drivers' Fiat-Shamir transcript: halo2's Blake2b transcript [D] (halo2_proofs transcript/blake2b.rs) in its PRIMITIVES -- BLAKE2b-512
+    personalised "Halo2-Transcript", one domain byte in front of every item (0 challenge, 1 point, 2 scalar), a challenge = the digest of a
+    clone of the running state read as a 512-bit little-endian integer mod r -- and in its DATAFLOW: every phase's commitments are brought to
+    the host in affine form (a synchronising download: the prover cannot start the next phase before the challenge exists).  Not halo2's
+    byte format: a field element enters as the 4 Montgomery words it crosses include/pz.h in (x then y for a point), families in this
+    prover's order, and `seed` stands where halo2 absorbs the verifying key's digest.  host/transcript.hpp is the same function (checked
+    value for value by tests/test_cpp_host_field.py); oracle/verifier.py::replay_challenges re-derives every challenge from a proof."""
+
+    PERSONAL = b"Halo2-Transcript"
 
     def __init__(self, seed: bytes = b"pz"):
         import hashlib
 
-        self.h = hashlib.blake2b(seed, digest_size=64)
+        self.seed = bytes(seed)
+        self.h = hashlib.blake2b(self.seed, digest_size=64, person=self.PERSONAL)
         self.drawn: Dict[str, int] = {}
 
+    def _items(self, tag: int, a: np.ndarray, words: int):
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, words)
+        buf = np.empty((a.shape[0], 1 + 8 * words), dtype=np.uint8)
+        buf[:, 0] = tag
+        buf[:, 1:] = a.view(np.uint8).reshape(a.shape[0], 8 * words)
+        self.h.update(buf.tobytes())
+
+    def absorb_affine(self, *host_arrays):
+        """affine points already on the host: (count, 8) Montgomery words each"""
+        for a in host_arrays:
+            self._items(1, a, 8)
+
     def absorb_points(self, eng: Engine, *jac_tensors):
-        out = []
-        for t in jac_tensors:
-            a = eng.g1_normalize(t.cpu().numpy().view(np.uint64))
-            self.h.update(a.tobytes())
-            out.append(a)
+        out = [eng.g1_normalize(t.cpu().numpy().view(np.uint64)) for t in jac_tensors]
+        self.absorb_affine(*out)
         return out
 
     def absorb_scalars(self, *host_arrays):
         for a in host_arrays:
-            self.h.update(np.ascontiguousarray(a).tobytes())
+            self._items(2, a, 4)
 
     def squeeze(self, name: str) -> int:
-        self.h.update(name.encode())
-        v = int.from_bytes(self.h.digest(), "little") % (FR - 2) + 2
+        self.h.update(b"\0")
+        v = int.from_bytes(self.h.digest(), "little") % FR          # (digest() leaves the running state as it is: halo2 hashes a clone)
         self.drawn[name] = v
         return v
 
     def challenges(self) -> Challenges:
-        return Challenges(**self.drawn)
+        return Challenges(**self.drawn, transcript_seed=self.seed)
 
 
 @dataclass

@@ -110,19 +110,19 @@ def create_proof(key: NativeKey, d_cols: int, tr, seed: int = 0, blinding: Optio
              "pz_proof_begin")
     try:
         pr = Proof()
-        tr.absorb_scalars(adv)
+        tr.absorb_affine(adv)
         c_theta = M(tr.squeeze("theta"))         # (the limb arrays are named: a pointer into a temporary would dangle)
         ap, sp = z(Lk), z(Lk)
         eng._chk(L.pz_proof_lookups(h, _p(c_theta), _p(ap), _p(sp)), "pz_proof_lookups")
-        tr.absorb_scalars(ap, sp)
+        tr.absorb_affine(ap, sp)
         c_beta, c_gamma = M(tr.squeeze("beta")), M(tr.squeeze("gamma"))
         cz, czl, crnd = z(S), z(Lk), z(1)
         eng._chk(L.pz_proof_products(h, _p(c_beta), _p(c_gamma), _p(cz), _p(czl), _p(crnd)), "pz_proof_products")
-        tr.absorb_scalars(cz, czl, crnd)
+        tr.absorb_affine(cz, czl, crnd)
         c_y = M(tr.squeeze("y"))
         ch_ = z(3)
         eng._chk(L.pz_proof_quotient(h, _p(c_y), _p(ch_)), "pz_proof_quotient")
-        tr.absorb_scalars(ch_)
+        tr.absorb_affine(ch_)
         c_x = M(tr.squeeze("x"))
         ev = np.zeros(key.evals_words, dtype=np.uint64)
         eng._chk(L.pz_proof_evaluate(h, _p(c_x), _p(ev)), "pz_proof_evaluate")
@@ -137,7 +137,7 @@ def create_proof(key: NativeKey, d_cols: int, tr, seed: int = 0, blinding: Optio
         c_shy, c_shv = M(tr.squeeze("sh_y")), M(tr.squeeze("sh_v"))
         w1, w2 = z(1), z(1)
         eng._chk(L.pz_proof_open_begin(h, _p(c_shy), _p(c_shv), _p(w1)), "pz_proof_open_begin")
-        tr.absorb_scalars(w1)
+        tr.absorb_affine(w1)
         c_shu = M(tr.squeeze("sh_u"))
         ok = C.c_int(0)
         eng._chk(L.pz_proof_open_finish(h, _p(c_shu), _p(w2), C.byref(ok)), "pz_proof_open_finish")

@@ -10,6 +10,7 @@ import pytest
 
 from oracle import pyref as P
 from oracle import verifier as V
+from tests.util import challenges_replay
 
 pytestmark = pytest.mark.gpu
 
@@ -122,6 +123,7 @@ def test_c2_library_stepper_verifies(eng, cref, srs):
         tr = prover.HashTranscript(b"c2-stepper")
         pr = prover_native.create_proof(key, cols.data_ptr(), tr, seed=17)
         ch = tr.challenges()
+        assert challenges_replay(pr, ch)
         R = P.FR_R
 
         def ints(a):

@@ -17,6 +17,7 @@ import pytest
 from oracle import circuit as CQ
 from oracle import pyref as P
 from oracle import verifier as V
+from tests.util import challenges_replay
 
 pytestmark = pytest.mark.gpu
 
@@ -159,8 +160,8 @@ def test_connected_proof_satisfies_the_verifier(eng, cref, world):
 
 
 def test_connected_proof_with_a_hashing_transcript(eng, cref, world):
-    """the same flow with every challenge DERIVED from the commitments of the phase before it (a Blake2b stand-in for halo2's
-    transcript: a synchronising download per phase) -- what bench.py's with_next_rows times; verified with the challenges it drew"""
+    """the same flow with every challenge DERIVED from the commitments of the phase before it (prover.HashTranscript: halo2's
+    Blake2b transcript in its primitives, a synchronising download per phase) -- what bench.py's with_next_rows times; verified with the challenges it drew"""
     from paillier_halo2_amd import prover
 
     tr = prover.HashTranscript(b"test")
@@ -170,6 +171,11 @@ def test_connected_proof_with_a_hashing_transcript(eng, cref, world):
     w2["ch"] = tr.challenges()
     assert w2["ch"] != world["ch"] and set(tm) >= {"advice_commit", "quotient", "multiopen"}
     assert _verify(cref, w2, pr) == (True, True, True)
+    # ... and they are the challenges a verifier re-derives from the proof alone; a proof with one commitment changed replays to others
+    assert challenges_replay(pr, w2["ch"])
+    bad = prover.Proof(commitments={k_: v_.copy() for k_, v_ in pr.commitments.items()}, evals=pr.evals)
+    bad.commitments["perm_z"][0, 0] ^= np.uint64(1)
+    assert not challenges_replay(bad, w2["ch"])
     # a different witness (another randomness r is not available here, so: another blinding seed) changes every challenge
     tr2 = prover.HashTranscript(b"test")
     prover.create_proof(world["pk"], world["witness"](), tr2, seed=8, tile=16)
@@ -292,6 +298,7 @@ def test_c3_add_circuit_connected_proof_at_size(eng, cref):
     tr = prover.HashTranscript(b"c3")
     pr = prover.create_proof(pk, cols, tr, seed=11)
     ch = tr.challenges()
+    assert challenges_replay(pr, ch)
     ev = {k_: _ints(cref, v_) for k_, v_ in pr.evals.items()}
     want = V.expected_h(k, cs.blinding_factors, cs.n_adv, cs.n_lk, prover.CHUNK, ev, ch.beta, ch.gamma, ch.y, ch.x, prover.DELTA)
     assert pr.h_degree_ok and want == ev["h"][0][0]
@@ -502,7 +509,7 @@ def test_library_stepper_is_the_same_prover(eng, cref, world):
         pr2 = prover_native.create_proof(key, cols.data_ptr(), tr, blinding=words)
         w2 = dict(world)
         w2["ch"] = tr.challenges()
-        assert _verify(cref, w2, pr2) == (True, True, True)
+        assert _verify(cref, w2, pr2) == (True, True, True) and challenges_replay(pr2, w2["ch"])
         assert not np.array_equal(pr.commitments["advice"], pr2.commitments["advice"])          # other blinding rows
         # too few random words
         cols = world["witness"]()

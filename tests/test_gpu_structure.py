@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from oracle import pyref as P
+from tests.util import challenges_replay
 
 pytestmark = pytest.mark.gpu
 
@@ -132,6 +133,7 @@ def test_structure_to_key_to_proof_from_the_library_alone(eng, cref):
         tr = prover.HashTranscript(b"native-structure")
         pr = prover_native.create_proof(key, cols.data_ptr(), tr, seed=5)
         ch = tr.challenges()
+        assert challenges_replay(pr, ch)
 
         def ints(a):
             a = np.asarray(a, dtype=np.uint64)

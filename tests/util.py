@@ -77,3 +77,12 @@ def walk_dlog_sum(sc, s, t, r=0x30644E72E131A029B85045B68181585D2833E84879B97091
     c_sum = sum(int(v) << (16 * j) for j, v in enumerate(s0.tolist()))
     ic_sum = sum(int(v) << (16 * j) for j, v in enumerate(s1.tolist()))
     return (s * c_sum + t * ic_sum) % r
+
+
+def challenges_replay(pr, ch):
+    """the verifier's side of Fiat-Shamir (oracle/verifier.py::replay_challenges): True iff every challenge the prover's HashTranscript drew is
+    the one re-derived from the proof's own commitments and evaluations"""
+    from oracle import verifier as V
+
+    d = V.replay_challenges(ch.transcript_seed, pr.commitments, pr.evals)
+    return len(d) == 8 and all(getattr(ch, nm) == v for nm, v in d.items())
