@@ -71,7 +71,7 @@ def cpp_connected(cw, proofs=4, verify_with=None, log=lambda s: None, via_steppe
     return out
 
 
-def cpp_fresh_message(enc_bits, k, lookup_bits, seed, steps=4, minimum_rows=20, verify_with=None, log=lambda s: None, streamed_key=None):
+def cpp_fresh_message(enc_bits, k, lookup_bits, seed, steps=4, minimum_rows=20, verify_with=None, log=lambda s: None, streamed_key=None, arena_gb=None):
     """a NEW key pair and message per proof from the COMPILED prover alone (`prove_connected --fresh`): per step the circuit structure
     generated on the device by the library (pz_circuit_structure_dev), keygen on its device arrays, K3 + K4, create_proof -- the
     reference's per-message cost (paillier.rs:50-55 makes every message its own circuit; bench.rs:161-171) with no Python in the loop.
@@ -90,14 +90,19 @@ def cpp_fresh_message(enc_bits, k, lookup_bits, seed, steps=4, minimum_rows=20, 
         prover_job.write_fresh_params(params, enc_bits, k, lookup_bits if lookup_bits is not None else k - 1, inputs, s_tox, minimum_rows=minimum_rows,
                                       seed=13)
         t0 = time.perf_counter()
-        env = dict(os.environ, PZ_PROVE_STREAMED_KEY=str(streamed_key)) if streamed_key is not None else None
+        env = dict(os.environ)
+        if streamed_key is not None:
+            env["PZ_PROVE_STREAMED_KEY"] = str(streamed_key)
+        if arena_gb is not None:             # (default: one arena over nearly all free device memory; 0 = driver allocations + block cache)
+            env["PZ_PROVE_ARENA_GB"] = str(arena_gb)
         line = prover_job.run_fresh(params, proof, timeout=1100, env=env)
         wall = time.perf_counter() - t0
         out = {"value": 1e3 / line["mean_step_ms"], "unit": "proofs/s", "steps": steps, "s_per_step": line["mean_step_ms"] / 1e3, "of_which": line["of_which"],
                "connected": True, "binary_wall_s": wall, "quotient_degree_ok": line["quotient_degree_ok"], "per_step_log": line.get("stderr_tail"),
+               "device_memory": line.get("arena"),
                "note": "tests/cpp/prove_connected --fresh: every step a new key pair and message -> circuit structure on the device (pz_circuit_structure_dev) "
                        "-> keygen on its device arrays (host/create_proof.hpp) -> K3 + K4 -> create_proof, from plain C++ over the C ABI only; device "
-                       "blocks recycled from key to key; mean over the steps after the first"}
+                       "memory from one arena (pz_dev_arena; arena gib 0 = driver allocations recycled through the block cache); mean over the steps after the first"}
         if verify_with is not None:
             rec = prover_job.read_proofs(proof)
             last = "p%d/" % (steps - 1)

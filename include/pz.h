@@ -81,7 +81,7 @@ int pz_set_stream(pz_ctx* ctx, void* hip_stream);
 int pz_sync(pz_ctx* ctx);
 /* explicit ABI version, bumped whenever an entry point below is added, removed or changes meaning (measurement probes are
  * not part of this ABI: they live in libpz_probe.so).  A binding compares it with the PZ_ABI_VERSION it was built against. */
-#define PZ_ABI_VERSION 6
+#define PZ_ABI_VERSION 7
 int pz_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -97,6 +97,22 @@ int pz_dev_alloc(pz_ctx* ctx, size_t bytes, void** d_out);
  * through these functions, with column counts rounded up to 64 so that keys of nearly equal shape ask for identical sizes.  Lowering the
  * limit releases what exceeds it; the library releases the cache itself when one of its own allocations runs out of memory. */
 int pz_dev_cache_limit(pz_ctx* ctx, size_t max_bytes);
+/* the ARENA: one block of `bytes` reserved from the driver NOW, out of which this context's later allocations are carved -- pz_dev_alloc and
+ * every buffer the library allocates for itself on this context (workspaces, tables, pz_load_bases*, pz_circuit_structure_dev's arrays and
+ * temporaries, a proving key).  Freed blocks go back to the arena and coalesce; a request the arena cannot serve falls through to the
+ * driver (and the block cache above).  For the caller pz_dev_cache_limit was made for, at the sizes where the cache stops helping: at
+ * config c5 (3072-bit n, k = 19; bench.rs:161-171's keygen + proof per run) a step holds 250 GB, the cache has to be released between a
+ * key and the next structure's temporaries, and half of an 11-s step was driver allocation calls; from an arena the same step makes none.
+ * Blocks are 4 KiB-granular and NOT zeroed.  A block may be freed through any context.  bytes = 0 releases the arena (also pz_free does);
+ * one that still holds live blocks -- PZ_ERR_INVALID -- is detached from the context and stays reserved until the last of them is freed.
+ * Size it from pz_dev_mem_info (leave a few GiB to the runtime).  PZ_DEV_ARENA_POISON=1 in the environment fills the arena, and every
+ * block again when it is freed, with 0xA5 (tests). */
+int pz_dev_arena(pz_ctx* ctx, size_t bytes);
+/* out: arena bytes, bytes in live blocks, the peak of that, the largest free hole, requests served, requests it could not serve (all 0
+ * without an arena) */
+int pz_dev_arena_info(pz_ctx* ctx, uint64_t out[6]);
+/* the driver's free / total device memory (hipMemGetInfo; waits for the device's queued work on ROCm).  Either pointer may be NULL */
+int pz_dev_mem_info(pz_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 /* waits for the context's queued work, then frees */
 int pz_dev_free(pz_ctx* ctx, void* d);
 /* host -> device on the context's stream; returns when the host buffer may be reused */

@@ -30,6 +30,9 @@ SIGNATURES = {
     "pz_abi_version": (C.c_int, []),
     "pz_dev_alloc": (C.c_int, [VP, C.c_size_t, C.POINTER(VP)]),
     "pz_dev_cache_limit": (C.c_int, [VP, C.c_size_t]),
+    "pz_dev_arena": (C.c_int, [VP, C.c_size_t]),
+    "pz_dev_arena_info": (C.c_int, [VP, C.POINTER(C.c_uint64)]),
+    "pz_dev_mem_info": (C.c_int, [VP, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "pz_dev_free": (C.c_int, [VP, VP]),
     "pz_upload": (C.c_int, [VP, VP, VP, C.c_size_t]),
     "pz_download": (C.c_int, [VP, VP, VP, C.c_size_t]),

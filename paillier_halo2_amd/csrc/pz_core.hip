@@ -91,19 +91,20 @@ extern "C" int pz_init(int n_devices, const int* device_ids, pz_ctx** out) {
     return PZ_OK;
 }
 
+static int arena_release(pz_ctx* ctx);
 extern "C" int pz_free(pz_ctx* ctx) {
     if (!ctx) return PZ_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     pz_dev_cache_trim(ctx, 0);
     for (auto& w : ctx->ws)
-        if (w.d) (void)hipFree(w.d);
+        if (w.d) (void)pz_hip_free(w.d);
     for (auto& t : ctx->pow_tables) {
-        if (t.d) (void)hipFree(t.d);
-        if (t.d_raw) (void)hipFree(t.d_raw);
+        if (t.d) (void)pz_hip_free(t.d);
+        if (t.d_raw) (void)pz_hip_free(t.d_raw);
     }
     for (auto& t : ctx->ext_tables)
-        if (t.d) (void)hipFree(t.d);
+        if (t.d) (void)pz_hip_free(t.d);
     for (auto& v : ctx->ev)
         for (auto& p : v) {
             (void)hipEventDestroy(p.a);
@@ -119,6 +120,7 @@ extern "C" int pz_free(pz_ctx* ctx) {
     if (ctx->io_h2d) (void)hipStreamDestroy(ctx->io_h2d);
     if (ctx->io_d2h) (void)hipStreamDestroy(ctx->io_d2h);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    (void)arena_release(ctx);   // (an arena other objects still hold blocks of -- bases tables, a proving key -- stays reserved)
     delete ctx;
     return PZ_OK;
 }
@@ -142,6 +144,220 @@ extern "C" int pz_set_stream(pz_ctx* ctx, void* s) {
 }
 
 
+// ---- pz_dev_arena: a sub-allocator over ONE reserved block --------------------------------------------------------------------
+// Why: a caller that follows the reference's flow (src/paillier.rs:50-55 bakes the message into the circuit, so every message is a new key)
+// builds and drops 120-250 GB of key, workspace and witness per proof.  Through the driver that is seconds per step (measured at config c5,
+// prove_connected --fresh: 5.6 of 11.4 s per step in hipMalloc / hipFree once the block cache has to be released for the next phase's
+// temporaries); carved out of one block it is map operations.  Address-ordered hole list, coalescing on free; large requests take the best
+// fitting hole from its start, small ones (< 64 MiB: temporaries, tables) the highest hole from its end, so that short-lived small blocks
+// do not pin holes between the long-lived large ones.  Blocks are 4 KiB-granular.  Memory is NOT zeroed (hipMalloc does not promise it
+// either); PZ_DEV_ARENA_POISON=1 fills the block with 0xA5 at creation and every block again when it is freed -- the test suite runs
+// under it to prove that nothing in the library depends on fresh pages being zero.
+struct pz_arena {
+    char* base = nullptr;
+    size_t size = 0;
+    int device = 0;
+    bool poison = false;
+    bool orphan = false;   // detached from its context while blocks were live: released when the last of them is freed
+    std::mutex mu;
+    std::map<size_t, size_t> holes;   // offset -> length
+    std::map<size_t, size_t> live;    // offset -> length
+    size_t used = 0, peak = 0, served = 0, missed = 0;
+};
+static std::mutex g_arena_mu;
+static std::vector<pz_arena*> g_arenas;   // every live arena of the process: a block may be freed through another context than its own
+#define PZ_ARENA_GRAIN ((size_t)4096)
+#define PZ_ARENA_SMALL ((size_t)64 << 20)
+
+static void* arena_take(pz_arena* a, size_t bytes) {
+    const size_t need = (bytes + PZ_ARENA_GRAIN - 1) / PZ_ARENA_GRAIN * PZ_ARENA_GRAIN;
+    std::lock_guard<std::mutex> lk(a->mu);
+    size_t off = 0;
+    bool found = false;
+    if (need < PZ_ARENA_SMALL) {
+        for (auto it = a->holes.rbegin(); it != a->holes.rend(); ++it)
+            if (it->second >= need) {
+                const size_t h_off = it->first, h_len = it->second;
+                off = h_off + h_len - need;
+                a->holes.erase(h_off);
+                if (h_len > need) a->holes[h_off] = h_len - need;
+                found = true;
+                break;
+            }
+    } else {
+        size_t best_off = 0, best_len = ~(size_t)0;
+        for (auto& h : a->holes)
+            if (h.second >= need && h.second < best_len) { best_off = h.first; best_len = h.second; }
+        if (best_len != ~(size_t)0) {
+            a->holes.erase(best_off);
+            if (best_len > need) a->holes[best_off + need] = best_len - need;
+            off = best_off;
+            found = true;
+        }
+    }
+    if (!found) { ++a->missed; return nullptr; }
+    a->live[off] = need;
+    a->used += need;
+    if (a->used > a->peak) a->peak = a->used;
+    ++a->served;
+    return a->base + off;
+}
+// -> the arena `d` lies in (registered), or nullptr
+static pz_arena* arena_of(const void* d) {
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    for (pz_arena* a : g_arenas)
+        if ((const char*)d >= a->base && (const char*)d < a->base + a->size) return a;
+    return nullptr;
+}
+static hipError_t arena_give(pz_arena* a, void* d) {
+    size_t off = (size_t)((char*)d - a->base), len = 0;
+    {
+        std::lock_guard<std::mutex> lk(a->mu);
+        auto it = a->live.find(off);
+        if (it == a->live.end()) return hipErrorInvalidValue;   // not the start of a live block (double free)
+        len = it->second;
+    }
+    // hipFree's semantics, which the library's callers rely on: nothing queued on the device still uses the block afterwards
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (cur != a->device) (void)hipSetDevice(a->device);
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess && a->poison) {
+        e = hipMemset(d, 0xA5, len);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    if (cur != a->device) (void)hipSetDevice(cur);
+    if (e != hipSuccess) return e;
+    bool last = false;
+    {
+        std::lock_guard<std::mutex> lk(a->mu);
+        a->live.erase(off);
+        a->used -= len;
+        last = a->orphan && a->live.empty();
+        auto nx = a->holes.lower_bound(off);
+        if (nx != a->holes.end() && off + len == nx->first) {   // merge with the hole above
+            len += nx->second;
+            nx = a->holes.erase(nx);
+        }
+        bool merged = false;
+        if (nx != a->holes.begin()) {                            // ... and below
+            auto pv = std::prev(nx);
+            if (pv->first + pv->second == off) {
+                pv->second += len;
+                merged = true;
+            }
+        }
+        if (!merged) a->holes[off] = len;
+    }
+    if (last) {   // nobody can allocate from an orphan: this was its last user
+        {
+            std::lock_guard<std::mutex> lk(g_arena_mu);
+            for (size_t i = 0; i < g_arenas.size(); ++i)
+                if (g_arenas[i] == a) { g_arenas.erase(g_arenas.begin() + (long)i); break; }
+        }
+        (void)hipFree(a->base);
+        delete a;
+    }
+    return hipSuccess;
+}
+hipError_t pz_hip_free(void* d) {
+    if (!d) return hipSuccess;
+    if (pz_arena* a = arena_of(d)) return arena_give(a, d);
+    return hipFree(d);
+}
+size_t pz_mem_free_bytes(pz_ctx* ctx) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    if (ctx && ctx->arena) {
+        std::lock_guard<std::mutex> lk(ctx->arena->mu);
+        free_b += ctx->arena->size - ctx->arena->used;
+    }
+    return free_b;
+}
+// releases the context's arena if nothing lives in it; an arena with live blocks stays registered (their owners free them later through
+// pz_hip_free) and is only detached from the context
+static int arena_release(pz_ctx* ctx) {
+    pz_arena* a = ctx->arena;
+    if (!a) return PZ_OK;
+    ctx->arena = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(a->mu);
+        if (!a->live.empty()) {
+            a->orphan = true;
+            return PZ_ERR_INVALID;
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_arena_mu);
+        for (size_t i = 0; i < g_arenas.size(); ++i)
+            if (g_arenas[i] == a) { g_arenas.erase(g_arenas.begin() + (long)i); break; }
+    }
+    (void)hipFree(a->base);
+    delete a;
+    return PZ_OK;
+}
+extern "C" int pz_dev_arena(pz_ctx* ctx, size_t bytes) {
+    if (!ctx) return PZ_ERR_INVALID;
+    PZ_ENTER(ctx);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->arena) {
+        const int rc = arena_release(ctx);
+        if (rc != PZ_OK) {
+            snprintf(ctx->hip_err, sizeof ctx->hip_err, "pz_dev_arena: blocks of the previous arena are still live; it stays reserved until they are freed");
+            return rc;
+        }
+    }
+    if (!bytes) return PZ_OK;
+    pz_dev_cache_trim(ctx, 0);   // cached blocks are driver allocations the arena is about to replace
+    pz_arena* a = new pz_arena();
+    a->size = bytes / PZ_ARENA_GRAIN * PZ_ARENA_GRAIN;
+    a->device = ctx->device;
+    const char* po = getenv("PZ_DEV_ARENA_POISON");
+    a->poison = po && po[0] == '1';
+    void* base = nullptr;
+    hipError_t e = a->size ? hipMalloc(&base, a->size) : hipErrorInvalidValue;
+    if (e == hipSuccess && a->poison) {
+        e = hipMemset(base, 0xA5, a->size);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) (void)hipFree(base);
+    }
+    if (e != hipSuccess) {
+        delete a;
+        return pz_hip_fail(ctx, e, "pz_dev_arena: hipMalloc of the arena");
+    }
+    a->base = (char*)base;
+    a->holes[0] = a->size;
+    {
+        std::lock_guard<std::mutex> lk(g_arena_mu);
+        g_arenas.push_back(a);
+    }
+    ctx->arena = a;
+    ctx->mem_avail = 0;
+    return PZ_OK;
+}
+extern "C" int pz_dev_mem_info(pz_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
+    if (!ctx) return PZ_ERR_INVALID;
+    PZ_ENTER(ctx);
+    size_t f = 0, t = 0;
+    HIPCHK(ctx, hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return PZ_OK;
+}
+extern "C" int pz_dev_arena_info(pz_ctx* ctx, uint64_t out[6]) {
+    if (!ctx || !out) return PZ_ERR_INVALID;
+    PZ_ENTER(ctx);
+    memset(out, 0, 48);
+    if (!ctx->arena) return PZ_OK;
+    pz_arena* a = ctx->arena;
+    std::lock_guard<std::mutex> lk(a->mu);
+    size_t largest = 0;
+    for (auto& h : a->holes)
+        if (h.second > largest) largest = h.second;
+    out[0] = a->size; out[1] = a->used; out[2] = a->peak; out[3] = largest; out[4] = a->served; out[5] = a->missed;
+    return PZ_OK;
+}
+
 // ---- device memory for hosts that own no HIP runtime of their own (a Rust prover behind the FFI; tests/cpp) ------------
 // Plain hipMalloc'd buffers; the `_dev` entry points take them as they are.  Transfers are ordered on the context's stream:
 // pz_upload returns once the host buffer may be reused, pz_download once the data has arrived.
@@ -151,12 +367,18 @@ void pz_dev_cache_trim(pz_ctx* ctx, size_t keep_bytes) {   // largest blocks go 
         size_t big = 0;
         for (size_t i = 1; i < ctx->dev_cache.size(); ++i)
             if (ctx->dev_cache[i].second > ctx->dev_cache[big].second) big = i;
-        (void)hipFree(ctx->dev_cache[big].first);
+        (void)pz_hip_free(ctx->dev_cache[big].first);
         ctx->dev_cache_bytes -= ctx->dev_cache[big].second;
         ctx->dev_cache.erase(ctx->dev_cache.begin() + (long)big);
     }
 }
 hipError_t pz_hip_malloc(pz_ctx* ctx, void** d, size_t bytes) {
+    if (ctx && ctx->arena && bytes) {
+        if (void* p = arena_take(ctx->arena, bytes)) {
+            *d = p;
+            return hipSuccess;
+        }
+    }
     hipError_t e = hipMalloc(d, bytes);
     if (e == hipErrorOutOfMemory && ctx && !ctx->dev_cache.empty()) {
         (void)hipGetLastError();
@@ -180,6 +402,10 @@ extern "C" int pz_dev_alloc(pz_ctx* ctx, size_t bytes, void** d_out) {
     *d_out = nullptr;
     if (!bytes) return PZ_OK;
     PZ_ENTER(ctx);
+    if (ctx->arena) {   // from the arena, else from the driver; the block cache is for contexts without one
+        HIPCHK(ctx, pz_hip_malloc(ctx, d_out, bytes));
+        return PZ_OK;
+    }
     if (ctx->dev_cache_limit && bytes >= PZ_DEV_CACHE_MIN) {
         int best = -1;   // best fit: the smallest cached block that holds the request and is at most an eighth larger
         for (size_t i = 0; i < ctx->dev_cache.size(); ++i) {
@@ -200,7 +426,7 @@ extern "C" int pz_dev_alloc(pz_ctx* ctx, size_t bytes, void** d_out) {
         for (size_t i = 0; i < ctx->dev_cache.size();) {
             const size_t c = ctx->dev_cache[i].second;
             if (c < bytes && bytes - c <= bytes / 8) {
-                (void)hipFree(ctx->dev_cache[i].first);
+                (void)pz_hip_free(ctx->dev_cache[i].first);
                 ctx->dev_cache_bytes -= c;
                 ctx->dev_cache.erase(ctx->dev_cache.begin() + (long)i);
             } else {
@@ -217,6 +443,10 @@ extern "C" int pz_dev_free(pz_ctx* ctx, void* d) {
     if (!d) return PZ_OK;
     PZ_ENTER(ctx);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // kernels queued by this context may still use it
+    if (pz_arena* a = arena_of(d)) {
+        HIPCHK(ctx, arena_give(a, d));
+        return PZ_OK;
+    }
     auto it = ctx->dev_live.find(d);
     if (it != ctx->dev_live.end()) {
         const size_t bytes = it->second;
@@ -227,7 +457,7 @@ extern "C" int pz_dev_free(pz_ctx* ctx, void* d) {
             return PZ_OK;
         }
     }
-    HIPCHK(ctx, hipFree(d));
+    HIPCHK(ctx, pz_hip_free(d));
     return PZ_OK;
 }
 extern "C" int pz_upload(pz_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
@@ -352,7 +582,7 @@ int pz_ws_get(pz_ctx* ctx, int slot, size_t bytes, void** out) {
     if (w.cap < bytes) {
         // in-flight kernels may still use the old buffer
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        if (w.d) HIPCHK(ctx, hipFree(w.d));
+        if (w.d) HIPCHK(ctx, pz_hip_free(w.d));
         w.d = nullptr;
         w.cap = 0;
         size_t want = bytes + bytes / 8 + 256;
@@ -390,8 +620,8 @@ int pz_get_pow_table(pz_ctx* ctx, const uint64_t base[4], size_t n, void** d_out
             reuse_raw = ctx->pow_tables[lru].d_raw;   // same capacity: rebuilt on demand (in stream order)
         } else {
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            HIPCHK(ctx, hipFree(ctx->pow_tables[lru].d));
-            if (ctx->pow_tables[lru].d_raw) HIPCHK(ctx, hipFree(ctx->pow_tables[lru].d_raw));
+            HIPCHK(ctx, pz_hip_free(ctx->pow_tables[lru].d));
+            if (ctx->pow_tables[lru].d_raw) HIPCHK(ctx, pz_hip_free(ctx->pow_tables[lru].d_raw));
         }
         ctx->pow_tables.erase(ctx->pow_tables.begin() + lru);
     }

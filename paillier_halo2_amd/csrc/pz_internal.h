@@ -43,6 +43,7 @@ struct pz_event_pair {
 };
 
 #define PZ_IO_EVENTS 10
+struct pz_arena;
 struct pz_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -80,6 +81,9 @@ struct pz_ctx {
     size_t dev_cache_limit = 0, dev_cache_bytes = 0;
     std::vector<std::pair<void*, size_t>> dev_cache;
     std::map<void*, size_t> dev_live;   // sizes of the live pz_dev_alloc blocks (only tracked while the cache is on)
+    // pz_dev_arena: one reserved block of device memory this context's allocations (pz_dev_alloc and the library's own buffers)
+    // are carved from, so that a caller who builds and drops a proving key per message makes no driver allocation call after start-up
+    struct pz_arena* arena = nullptr;
     std::recursive_mutex mu;   // one context is serialised internally: entry points may be called from any thread
 };
 
@@ -117,6 +121,11 @@ static inline int pz_hip_fail(pz_ctx* ctx, hipError_t e, const char* what) {
 int pz_ws_get(pz_ctx* ctx, int slot, size_t bytes, void** out);
 // hipMalloc for the library's own buffers: on out-of-memory the pz_dev_alloc block cache is released and the request repeated once
 hipError_t pz_hip_malloc(pz_ctx* ctx, void** d, size_t bytes);
+// the counterpart: a block of ANY context's arena goes back to its arena (after a device synchronisation: hipFree's own semantics, the
+// callers rely on it), anything else to hipFree
+hipError_t pz_hip_free(void* d);
+// free device memory as the library should plan with it: the driver's figure plus what this context's arena has free
+size_t pz_mem_free_bytes(pz_ctx* ctx);
 void pz_dev_cache_trim(pz_ctx* ctx, size_t keep_bytes);
 // cached base^i table (device, Fr Montgomery)
 int pz_get_pow_table(pz_ctx* ctx, const uint64_t base[4], size_t n, void** d_out, const uint64_t* init = nullptr);

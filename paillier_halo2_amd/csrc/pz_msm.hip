@@ -1338,16 +1338,16 @@ extern "C" int pz_bases_load_g1(pz_ctx* ctx, const uint64_t* bases_affine, size_
     if (!on_device) {
         void* stage;
         int rc = pz_ws_get(ctx, WS_IO_A, n_points * 64, &stage);
-        if (rc != PZ_OK) { (void)hipFree(b->d_table); delete b; return rc; }
+        if (rc != PZ_OK) { (void)pz_hip_free(b->d_table); delete b; return rc; }
         e = hipMemcpyAsync(stage, bases_affine, n_points * 64, hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) { (void)hipFree(b->d_table); delete b; return pz_hip_fail(ctx, e, "memcpy bases"); }
+        if (e != hipSuccess) { (void)pz_hip_free(b->d_table); delete b; return pz_hip_fail(ctx, e, "memcpy bases"); }
         d_src = stage;
     }
     hipLaunchKernelGGL(k_build_table, dim3(pz_div_up(n_points, 128)), dim3(128), 0, ctx->stream,
                        (const G1Aff64*)d_src, (G1Aff64*)b->d_table, n_points, c, nwin);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { (void)hipFree(b->d_table); delete b; return pz_hip_fail(ctx, e, "k_build_table"); }
+    if (e != hipSuccess) { (void)pz_hip_free(b->d_table); delete b; return pz_hip_fail(ctx, e, "k_build_table"); }
     *out = b;
     return PZ_OK;
 }
@@ -1366,7 +1366,7 @@ extern "C" int pz_bases_free(pz_ctx* ctx, pz_bases* b) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
-    if (b->d_table) (void)hipFree(b->d_table);
+    if (b->d_table) (void)pz_hip_free(b->d_table);
     delete b;
     return PZ_OK;
 }
@@ -1609,8 +1609,8 @@ extern "C" int pz_msm_g1_dev(pz_ctx* ctx, const pz_bases* bases, const uint64_t*
         // never plan for more than half of what is free (plus what this context already holds).  The query is cached: between
         // two launch sequences it left the GPU idle for ~0.3 ms
         if (ctx->mem_avail == 0 || ++ctx->mem_avail_age >= 64) {
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t free_b = pz_mem_free_bytes(ctx);   // (the driver's figure + the free part of the context's arena)
+            if (free_b) {
                 size_t held = 0;
                 for (int i = 0; i < WS_COUNT; ++i) held += ctx->ws[i].cap;
                 ctx->mem_avail = (free_b + held) / 2;

@@ -790,7 +790,7 @@ __global__ __launch_bounds__(256) void k_struct_selectors(DStream D, const u32* 
 struct DevBufs {
     std::vector<void*> bufs;
     ~DevBufs() {
-        for (void* d : bufs) (void)hipFree(d);
+        for (void* d : bufs) (void)pz_hip_free(d);
     }
     template <class T> int get(pz_ctx* ctx, size_t count, T** out) {
         void* d = nullptr;
@@ -809,7 +809,7 @@ struct DevBufs {
     void drop(void* d) {
         auto it = std::find(bufs.begin(), bufs.end(), d);
         if (it != bufs.end()) {
-            (void)hipFree(d);
+            (void)pz_hip_free(d);
             bufs.erase(it);
         }
     }
@@ -834,7 +834,7 @@ extern "C" int pz_structure_free(pz_structure* st) {
         (void)hipSetDevice(st->ctx->device);
         (void)hipStreamSynchronize(st->ctx->stream);
         for (void* d : {(void*)st->d_selectors, (void*)st->d_map_col, (void*)st->d_map_row, (void*)st->d_starts})
-            if (d) (void)hipFree(d);
+            if (d) (void)pz_hip_free(d);
     }
     delete st;
     return PZ_OK;

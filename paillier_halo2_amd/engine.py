@@ -562,6 +562,22 @@ class Engine:
     def dev_free(self, d: int):
         self._chk(self.L.pz_dev_free(self.ctx, VP(d)), "pz_dev_free")
 
+    def dev_arena(self, nbytes: int):
+        """pz_dev_arena: reserve one block this context's later allocations (pz_dev_alloc and the library's own buffers) are carved from;
+        0 releases it"""
+        self._chk(self.L.pz_dev_arena(self.ctx, C.c_size_t(nbytes)), "pz_dev_arena")
+
+    def dev_arena_info(self) -> dict:
+        out = (C.c_uint64 * 6)()
+        self._chk(self.L.pz_dev_arena_info(self.ctx, out), "pz_dev_arena_info")
+        return dict(zip(("bytes", "used", "peak", "largest_hole", "served", "missed"), (int(v) for v in out)))
+
+    def dev_mem_info(self):
+        """-> (free, total) bytes as the driver reports them"""
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        self._chk(self.L.pz_dev_mem_info(self.ctx, C.byref(f), C.byref(t)), "pz_dev_mem_info")
+        return int(f.value), int(t.value)
+
     def upload(self, d_dst: int, arr):
         a = np.ascontiguousarray(arr)
         self._chk(self.L.pz_upload(self.ctx, VP(d_dst), VP(a.ctypes.data), a.nbytes), "pz_upload")

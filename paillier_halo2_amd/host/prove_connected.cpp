@@ -20,7 +20,7 @@
 //   writes the witness (K3 + K4 in the structure's break-point layout) and proves -- what bench.rs:161-171 pays per message.
 //   params file (u64 words): [0] magic 0x465a50  [1] enc_bits  [2] k  [3] lookup_bits  [4] minimum_rows  [5] blinding_factors  [6] seed
 //   [7] steps  [8] tile  then s_toxic (4, Montgomery), then per step n | g | m | r (Ln words each).
-//   Device blocks are recycled from key to key (pz_dev_cache_limit): re-allocating 116 GB per message would cost seconds.
+//   Device memory comes from one arena (pz_dev_arena; PZ_PROVE_ARENA_GB): re-allocating 116-250 GB per message through the driver costs seconds.
 //
 // PZ_PROVE_VIA_STEPPER=1 (job-file mode): the SAME proofs through the library's entry points instead of this file's own composition --
 //   pz_pk_create (the structure's host arrays, as halo2's Assembly would hand them over) and pz_proof_begin ... pz_proof_open_finish, one call
@@ -87,7 +87,24 @@ static int fresh_main(const char* params_path, const char* proof_path) {
     cx.round_cols = true;
     int dev = 0;
     PZP_CK(pz_init(1, &dev, &cx.c));
-    PZP_CK(pz_dev_cache_limit(cx.c, ~(size_t)0));     // a released key's blocks serve the next key (pz.h)
+    // device memory: by default ONE arena over (almost) all free memory, so that a step -- structure, key, workspace, witness: 120 GB at
+    // c2, 250 GB at c5, all dropped again at its end -- makes no driver allocation call (pz.h pz_dev_arena).  PZ_PROVE_ARENA_GB=<n> sizes
+    // it; PZ_PROVE_ARENA_GB=0 = the older plan: driver allocations recycled through the block cache
+    uint64_t arena_gb = 0;
+    {
+        size_t free_b = 0;
+        PZP_CK(pz_dev_mem_info(cx.c, &free_b, nullptr));
+        const char* e = getenv("PZ_PROVE_ARENA_GB");
+        const size_t reserve = (size_t)4 << 30;   // left to the runtime (code objects, scratch, the other context's small buffers)
+        size_t want = e ? (size_t)strtoull(e, nullptr, 10) << 30 : (free_b > reserve ? free_b - reserve : 0);
+        if (want && want + ((size_t)1 << 30) > free_b) want = free_b > ((size_t)1 << 30) ? free_b - ((size_t)1 << 30) : 0;
+        if (want) {
+            PZP_CK(pz_dev_arena(cx.c, want));
+            arena_gb = want >> 30;
+        } else {
+            PZP_CK(pz_dev_cache_limit(cx.c, ~(size_t)0));     // a released key's blocks serve the next key (pz.h)
+        }
+    }
     const Fr om = pzh::omega(k);
     void *d_g = nullptr, *d_gl = nullptr;
     PZP_CK(pz_dev_alloc(cx.c, n * 64, &d_g));
@@ -188,11 +205,13 @@ static int fresh_main(const char* params_path, const char* proof_path) {
     }
     fclose(out.f);
     const double d = steps > 1 ? (double)(steps - 1) : 1.0;
+    uint64_t ai[6] = {0, 0, 0, 0, 0, 0};
+    PZP_CK(pz_dev_arena_info(cx.c, ai));
     printf("{\"mode\": \"fresh_message\", \"steps\": %zu, \"k\": %u, \"enc_bits\": %llu, \"minimum_rows\": %zu, \"n_adv_last\": %zu, \"n_lk_last\": %zu, "
            "\"mean_step_ms\": %.1f, \"of_which\": {\"structure_ms\": %.1f, \"keygen_and_workspace_ms\": %.1f, \"witness_ms\": %.1f, \"proof_ms\": %.1f}, "
-           "\"quotient_degree_ok\": %s}\n",
+           "\"arena\": {\"gib\": %llu, \"peak_gb\": %.2f, \"requests_served\": %llu, \"requests_passed_to_the_driver\": %llu}, \"quotient_degree_ok\": %s}\n",
            steps, k, (unsigned long long)enc_bits, minimum_rows, last_adv, last_lk, sum_after_first / d, structure_ms / d, keygen_ms / d, witness_ms / d,
-           prove_ms / d, degree_ok ? "true" : "false");
+           prove_ms / d, (unsigned long long)arena_gb, (double)ai[2] / 1e9, (unsigned long long)ai[4], (unsigned long long)ai[5], degree_ok ? "true" : "false");
     pz_bases_free(cx.c, bl);
     pz_bases_free(cx.c, bm);
     pz_free(cx.c);

@@ -12,7 +12,7 @@ use std::collections::HashMap;
 use std::sync::Mutex;
 
 /// `PZ_ABI_VERSION` this crate was written against (include/pz.h)
-pub const ABI: c_int = 6;
+pub const ABI: c_int = 7;
 
 pub struct Ctx(pub *mut pz_ctx);
 unsafe impl Send for Ctx {}
@@ -37,6 +37,18 @@ pub fn ctx_on(dev: c_int) -> *mut pz_ctx {
 pub fn ctx() -> *mut pz_ctx {
     ctx_on(0)
 }
+/// Reserve one arena over the device memory that is free now (less `leave_bytes` for the runtime): from here on this context's keys,
+/// workspaces, structures and tables are carved out of it and a per-message `DeviceKey::for_message` / drop makes no driver allocation call
+/// (pz.h `pz_dev_arena`; at config c5 half of a keygen + proof step was `hipMalloc` / `hipFree` without it).  Call once, before the SRS is
+/// loaded.  -> the arena's size
+pub fn reserve_device_memory(leave_bytes: usize) -> usize {
+    let (mut free, mut total) = (0usize, 0usize);
+    check(unsafe { pz_dev_mem_info(ctx(), &mut free, &mut total) });
+    let bytes = free.saturating_sub(leave_bytes);
+    check(unsafe { pz_dev_arena(ctx(), bytes) });
+    bytes
+}
+
 /// a further context on device 0 (its own stream: the witness / commitment / transform contexts of INTEGRATION.md section 5a)
 pub fn new_ctx() -> *mut pz_ctx {
     let mut p: *mut pz_ctx = core::ptr::null_mut();

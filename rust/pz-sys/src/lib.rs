@@ -23,11 +23,14 @@ extern "C" {
     pub fn pz_last_hip_error(ctx: *const pz_ctx) -> *const c_char;
     pub fn pz_set_stream(ctx: *mut pz_ctx, hip_stream: *mut c_void) -> c_int;
     pub fn pz_sync(ctx: *mut pz_ctx) -> c_int;
-    pub fn pz_abi_version() -> c_int;       // == PZ_ABI_VERSION (6); checked once in pz_rt::ctx()
+    pub fn pz_abi_version() -> c_int;       // == PZ_ABI_VERSION (7); checked once in pz_rt::ctx()
 
     // device memory + context ordering: what lets the columns of a proof stay in HBM (patch points C / D, section 5a)
     pub fn pz_dev_alloc(ctx: *mut pz_ctx, bytes: usize, d_out: *mut *mut c_void) -> c_int;
     pub fn pz_dev_cache_limit(ctx: *mut pz_ctx, max_bytes: usize) -> c_int;
+    pub fn pz_dev_arena(ctx: *mut pz_ctx, bytes: usize) -> c_int;
+    pub fn pz_dev_arena_info(ctx: *mut pz_ctx, out: *mut u64) -> c_int;
+    pub fn pz_dev_mem_info(ctx: *mut pz_ctx, free_bytes: *mut usize, total_bytes: *mut usize) -> c_int;
     pub fn pz_dev_free(ctx: *mut pz_ctx, d: *mut c_void) -> c_int;
     pub fn pz_upload(ctx: *mut pz_ctx, d_dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
     pub fn pz_download(ctx: *mut pz_ctx, dst: *mut c_void, d_src: *const c_void, bytes: usize) -> c_int;

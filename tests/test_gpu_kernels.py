@@ -515,6 +515,67 @@ def test_dev_block_cache(cref):
         e.close()
 
 
+def test_dev_arena(cref):
+    """pz_dev_arena: allocations carved out of one reserved block -- address-ordered holes that coalesce, small blocks from the top, a
+    request the arena cannot hold passed to the driver, a block freed through ANOTHER context, an arena with live blocks not released; the
+    arena is poisoned (0xA5) at creation and on every free, and a kernel's result does not depend on it"""
+    import ctypes as C
+    import os
+
+    import paillier_halo2_amd as pz
+
+    MiB = 1 << 20
+    e, e2 = pz.Engine(0), pz.Engine(0)
+    os.environ["PZ_DEV_ARENA_POISON"] = "1"
+    try:
+        free0, total = e.dev_mem_info()
+        assert 0 < free0 <= total
+        assert e.dev_arena_info()["bytes"] == 0
+        e.dev_arena(1024 * MiB)
+        assert free0 - e.dev_mem_info()[0] >= 1000 * MiB
+        a = e.dev_alloc(256 * MiB)
+        b = e.dev_alloc(256 * MiB)
+        c = e.dev_alloc(256 * MiB)
+        assert (b - a, c - b) == (256 * MiB, 256 * MiB)                       # large blocks: from the bottom, in address order
+        assert e.download(a, (4,))[0] == 0xA5A5A5A5A5A5A5A5                     # poisoned, not zero
+        s1 = e.dev_alloc(5000)                                                  # small: from the top, 4-KiB granular
+        s2 = e.dev_alloc(4096)
+        assert s1 == a + 1024 * MiB - 8192 and s2 == s1 - 4096
+        info = e.dev_arena_info()
+        assert info["used"] == 768 * MiB + 8192 + 4096 and info["largest_hole"] == 256 * MiB - 12288 and info["served"] == 5 and info["missed"] == 0
+        e.dev_memset(b, 0x11, 256 * MiB)
+        e.dev_free(b)
+        assert e.dev_arena_info()["largest_hole"] == 256 * MiB
+        assert e.dev_alloc(256 * MiB) == b and e.download(b, (2,))[1] == 0xA5A5A5A5A5A5A5A5       # best fit; poisoned again when it was freed
+        e.dev_free(b)
+        e2.dev_free(c)                                                          # through another context
+        assert e.dev_arena_info()["largest_hole"] == 768 * MiB - 12288         # b + c + the rest below the small blocks: coalesced
+        e.dev_free(a)
+        assert e.dev_arena_info()["largest_hole"] == 1024 * MiB - 12288
+        big = e.dev_alloc(1500 * MiB)                                           # does not fit: the driver's
+        assert not (a <= big < a + 1024 * MiB) and e.dev_arena_info()["missed"] == 1
+        e.dev_free(big)
+        with pytest.raises(pz.PzError):                                         # a double free is an error, not a corruption
+            e.dev_free(a)
+        # the library's own buffers come from the arena too, and a kernel's result does not depend on what the memory held
+        rng = np.random.default_rng(3)
+        x = cref.fr_ints_to_mont([int(v) for v in rng.integers(0, 1 << 62, size=1 << 12)])
+        omega = cref.fr_ints_to_mont([P.fr_omega(12)])[0]
+        served = e.dev_arena_info()["served"]
+        assert np.array_equal(e.ntt(x, omega, 12), cref.ntt_fr(x, omega, 12))
+        assert e.dev_arena_info()["served"] > served
+        # live blocks (s1, s2, the library's workspaces): the arena is detached but not released
+        with pytest.raises(pz.PzError):
+            e.dev_arena(0)
+        assert e.dev_arena_info()["bytes"] == 0
+        e.dev_free(s1)                                                          # ... and its blocks can still be freed; the last one
+        e.dev_free(s2)                                                          # (here: a workspace, when the context closes) releases it
+    finally:
+        os.environ.pop("PZ_DEV_ARENA_POISON", None)
+        e2.close()
+        e.close()
+
+
 def test_dev_copy_2d(eng):
     """pz_dev_copy_2d: the strided device copy the compiled prover fills the blinding rows with (rows [u, n) of every column from one
     staged block); pitches below the width and null pointers are refused"""

@@ -154,3 +154,82 @@ def test_structure_to_key_to_proof_from_the_library_alone(eng, cref):
         key.free()
         bl.free()
         bm.free()
+
+
+def _library_proof(e, cref, s_tox, tile=8):
+    """structure -> key -> witness -> the stepper's proof on context `e`, every device array allocated by the LIBRARY (pz_dev_alloc) -- what a
+    compiled caller does.  Fixed challenges and seed: the result is a function of the inputs alone.  -> (commitments, evals, vk)"""
+    from paillier_halo2_amd import prover, prover_native
+
+    bits, W, lb, k = 128, 64, 13, 14
+    n = 1 << k
+    Ln = bits // W
+    R = P.FR_R
+    nn, g, m, r = P.synth_paillier_inputs(bits, 0x5043, standard_g=False)
+    res = P.paillier_enc_native(nn, g, m, r)
+    F = lambda v: cref.fr_ints_to_mont([v % R])[0]
+    arr = lambda v, l: cref.int_to_limbs(v, l)
+    d_g, d_gl = e.dev_alloc(n * 64), e.dev_alloc(n * 64)
+    e.srs_setup_g1_dev(k, F(s_tox), F(P.fr_omega(k)), d_g, d_gl)
+    e.sync()
+    bl, bm = e.load_bases_dev(d_gl, n), e.load_bases_dev(d_g, n)
+    e.dev_free(d_g)
+    e.dev_free(d_gl)
+    ns = prover_native.NativeStructure(e, "encrypt", bits, W, lb, k, exp_g=m, exp_r=nn)
+    key = ns.key(bl, bm, tile=tile)
+    cap = ns.n_steps_g + ns.n_steps_r + 1
+    d_steps, d_mod, cols = e.dev_alloc(cap * 4 * 2 * Ln * 8), e.dev_alloc(2 * Ln * 8), e.dev_alloc(ns.m * n * 32)
+    try:
+        c, g_, r_ = e.paillier_encrypt_dev(Ln, arr(nn, Ln), arr(g, Ln), arr(m, Ln), arr(r, Ln), d_steps, cap)
+        assert cref.limbs_to_int(c[0]) == res
+        e.upload(d_mod, arr(nn * nn, 2 * Ln))
+        e.dev_memset(cols, 0, ns.m * n * 32)
+        inputs = np.concatenate([arr(nn, Ln), arr(g, Ln), arr(m, Ln), arr(r, Ln), arr(res, 2 * Ln)])
+        e.circuit_expand_cols_dev(0, Ln, W, lb, inputs, d_steps, ns.n_steps_g, ns.n_steps_r, d_mod, cols, cols + ns.n_adv * n * 32, ns.d_starts, ns.n_adv,
+                                  ns.max_rows, ns.max_rows, n)
+        e.sync()
+        ns.free()
+        rng = random.Random(9)
+        ch = prover.Challenges(*(rng.randrange(2, R) for _ in range(8)))
+        pr = prover_native.create_proof(key, cols, ch, seed=5)
+        assert pr.h_degree_ok
+        return pr.commitments, pr.evals, key.vk_commitments()
+    finally:
+        for d in (d_steps, d_mod, cols):
+            e.dev_free(d)
+        key.free()
+        bl.free()
+        bm.free()
+
+
+def test_library_path_from_a_poisoned_arena_is_byte_identical(eng, cref):
+    """pz_dev_arena: the whole library path (structure generator, keygen, K3, K4, the stepper's six phases, every workspace and table)
+    with its memory carved out of ONE block that is filled with 0xA5 at creation and refilled on every free gives the same key and the same
+    proof, byte for byte, as the same path on driver allocations -- nothing depends on fresh memory being zero; a second proof from the
+    same arena leaves no more memory in use than the first (no leak), and nothing had to be passed to the driver"""
+    import os
+
+    import paillier_halo2_amd as pz
+
+    s_tox = random.Random(0x58).randrange(2, P.FR_R)
+    com0, ev0, vk0 = _library_proof(eng, cref, s_tox)
+    e = pz.Engine(0)
+    os.environ["PZ_DEV_ARENA_POISON"] = "1"
+    try:
+        e.dev_arena(6 << 30)
+        com1, ev1, vk1 = _library_proof(e, cref, s_tox)
+        used1 = e.dev_arena_info()
+        com2, ev2, vk2 = _library_proof(e, cref, s_tox)
+        used2 = e.dev_arena_info()
+        for got_c, got_e, got_vk in ((com1, ev1, vk1), (com2, ev2, vk2)):
+            assert set(got_c) == set(com0) and set(got_e) == set(ev0)
+            for nm in com0:
+                assert np.array_equal(got_c[nm], com0[nm]), nm
+            for nm in ev0:
+                assert np.array_equal(got_e[nm], ev0[nm]), nm
+            assert np.array_equal(got_vk["fixed"], vk0["fixed"]) and np.array_equal(got_vk["sigma"], vk0["sigma"])
+        assert used1["served"] > 50 and used1["missed"] == 0 and used2["missed"] == 0
+        assert used2["used"] == used1["used"]            # what stays in use is the context's grown workspaces and tables, not a key's arrays
+    finally:
+        os.environ.pop("PZ_DEV_ARENA_POISON", None)
+        e.close()
