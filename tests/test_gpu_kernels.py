@@ -576,6 +576,79 @@ def test_dev_arena(cref):
         e.close()
 
 
+def test_dev_arena_random_traffic():
+    """pz_dev_arena under 6000 random allocations and frees of mixed sizes, half of the frees from a second thread through a second
+    context: live blocks never overlap and stay inside the arena, the accounting matches, and once everything is freed the arena is one hole"""
+    import threading
+
+    import paillier_halo2_amd as pz
+
+    MiB = 1 << 20
+    e, e2 = pz.Engine(0), pz.Engine(0)
+    try:
+        size = 2048 * MiB
+        e.dev_arena(size)
+        probe = e.dev_alloc(4096)
+        base = probe
+        e.dev_free(probe)
+        base = base + 4096 - size                        # (a small block comes from the top end of the arena)
+        rng = random.Random(77)
+        live = {}                                        # ptr -> rounded bytes
+        handed = []                                      # blocks the second thread frees
+        lock = threading.Lock()
+        stop = threading.Event()
+        errors = []
+
+        def other():
+            while not stop.is_set() or handed:
+                with lock:
+                    d = handed.pop() if handed else None
+                if d is None:
+                    continue
+                try:
+                    e2.dev_free(d)
+                except Exception as ex:   # noqa: BLE001
+                    errors.append(ex)
+
+        th = threading.Thread(target=other)
+        th.start()
+        missed = 0
+        for it in range(6000):
+            if live and (rng.random() < 0.48 or len(live) > 300):
+                d = rng.choice(list(live))
+                del live[d]
+                if it & 1:
+                    with lock:
+                        handed.append(d)
+                else:
+                    e.dev_free(d)
+            else:
+                nbytes = rng.choice([1, 4096, 5000, 70_000, MiB, 3 * MiB + 17, 65 * MiB, 100 * MiB, 200 * MiB])
+                d = e.dev_alloc(nbytes)
+                need = -(-nbytes // 4096) * 4096
+                if not (base <= d and d + need <= base + size):     # the arena was full or too fragmented: a driver block
+                    missed += 1
+                    e.dev_free(d)
+                    continue
+                for o, ob in live.items():
+                    assert d + need <= o or o + ob <= d, "overlapping blocks"
+                live[d] = need
+        stop.set()
+        th.join()
+        assert not errors, errors[:2]
+        info = e.dev_arena_info()
+        assert info["used"] == sum(live.values()) and info["missed"] == missed
+        for d in list(live):
+            e.dev_free(d)
+        info = e.dev_arena_info()
+        assert info["used"] == 0 and info["largest_hole"] == size and info["peak"] <= size
+        e.dev_arena(0)                                   # empty: released
+        assert e.dev_arena_info()["bytes"] == 0
+    finally:
+        e2.close()
+        e.close()
+
+
 def test_dev_copy_2d(eng):
     """pz_dev_copy_2d: the strided device copy the compiled prover fills the blinding rows with (rows [u, n) of every column from one
     staged block); pitches below the width and null pointers are refused"""
