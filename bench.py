@@ -1706,6 +1706,23 @@ def connected_line(args, R):
                 out["comparable"] = False
         except Exception as ex:
             out["fresh_message_cpp"] = {"error": repr(ex)[:600]}
+    # ---- config c5: bench.rs:161-171's own flow (keygen + proof per run) from compiled code -- a step fills the GPU (250 GB of key, workspace and
+    # witness), so this process first gives back the library's workspaces; the binary carves its memory out of one arena (pz_dev_arena)
+    if extras and preset == "c5" and not args.no_dropin and not args.no_fresh_key:
+        try:
+            t_p = time.time()
+            eng.close()
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["fresh_message_cpp"] = bench_connected.cpp_fresh_message(args.enc_bits, args.k, args.lookup_bits, args.seed, steps=3, minimum_rows=args.minimum_rows,
+                                                                         verify_with=_cref if ver is not None else None, log=log, streamed_key=0)
+            log("fresh message, compiled prover %.1fs: %.2f s per step %s, verified %s, %s" % (
+                time.time() - t_p, out["fresh_message_cpp"]["s_per_step"], out["fresh_message_cpp"]["of_which"], out["fresh_message_cpp"].get("verified"),
+                out["fresh_message_cpp"].get("device_memory")))
+            if out["fresh_message_cpp"].get("verified") is False:
+                out["comparable"] = False
+        except Exception as ex:
+            out["fresh_message_cpp"] = {"error": repr(ex)[:600]}
     # ---- the same through the UNIFORM-shape circuit (row f4): ONE proving key for every message of a key -- the proofs of this loop are
     # of DISTINCT messages (the reference's circuit needs a new structure + keygen per message: `fresh_message`)
     if extras and headline_cfg and not args.no_c2u:

@@ -89,6 +89,8 @@ int pz_abi_version(void);
  * driver in paillier_halo2_amd/host/prove_c2.cpp).  The `_dev` entry points take these pointers as they are, so a proof's
  * columns can stay in HBM from K4 through K1 and K2 (patch points C / D of INTEGRATION.md: bench.rs:161-171's create_proof).
  * ------------------------------------------------------------------------------------------- */
+/* (a request that does not fit makes the library give back what it holds as caches -- cached blocks, then the grow-only sort / partial-sum
+ * workspaces of pz_msm_g1*, which the next MSM sizes anew for what is free then -- before it returns PZ_ERR_OOM) */
 int pz_dev_alloc(pz_ctx* ctx, size_t bytes, void** d_out);
 /* block cache of pz_dev_alloc / pz_dev_free (off by default: max_bytes = 0): freed blocks of 32 MiB and more are KEPT by the context, up
  * to max_bytes in all, and handed to the next pz_dev_alloc of that size (or up to an eighth smaller) instead of going back to the driver.

@@ -397,13 +397,38 @@ extern "C" int pz_dev_cache_limit(pz_ctx* ctx, size_t max_bytes) {
     }
     return PZ_OK;
 }
+// The MSM's grow-only workspaces (up to PZ_MSM_WS_GIB = 48 GiB, sized when memory was plentiful) are a CACHE: when a caller's allocation
+// does not fit beside them they go back, and the next pz_msm_g1* call sizes its column groups for what is free then.  Only the slots whose
+// contents no entry point expects to survive its own return (the sort / partial-sum / tree buffers; NOT the SHPLONK state's or K3's).
+static hipError_t ws_release_msm(pz_ctx* ctx) {
+    static const int slots[] = {WS_HIST, WS_OFFS, WS_CURSOR, WS_ITEMS, WS_ENTRIES, WS_PARTIALS, WS_NODES_A, WS_NODES_B, WS_TOTALS, WS_ORDER};
+    hipError_t e = hipStreamSynchronize(ctx->stream);   // queued kernels of this context may still use them
+    if (e != hipSuccess) return e;
+    for (int sl : slots) {
+        pz_wsbuf& w = ctx->ws[sl];
+        if (w.d) (void)pz_hip_free(w.d);
+        w.d = nullptr;
+        w.cap = 0;
+    }
+    ctx->mem_avail = 0;
+    return hipSuccess;
+}
+static bool ws_msm_held(const pz_ctx* ctx) {
+    return ctx->ws[WS_ENTRIES].cap || ctx->ws[WS_PARTIALS].cap || ctx->ws[WS_HIST].cap || ctx->ws[WS_ITEMS].cap;
+}
 extern "C" int pz_dev_alloc(pz_ctx* ctx, size_t bytes, void** d_out) {
     if (!ctx || !d_out) return PZ_ERR_INVALID;
     *d_out = nullptr;
     if (!bytes) return PZ_OK;
     PZ_ENTER(ctx);
     if (ctx->arena) {   // from the arena, else from the driver; the block cache is for contexts without one
-        HIPCHK(ctx, pz_hip_malloc(ctx, d_out, bytes));
+        hipError_t e = pz_hip_malloc(ctx, d_out, bytes);
+        if (e == hipErrorOutOfMemory && ws_msm_held(ctx)) {
+            (void)hipGetLastError();
+            HIPCHK(ctx, ws_release_msm(ctx));
+            e = pz_hip_malloc(ctx, d_out, bytes);
+        }
+        HIPCHK(ctx, e);
         return PZ_OK;
     }
     if (ctx->dev_cache_limit && bytes >= PZ_DEV_CACHE_MIN) {
@@ -434,7 +459,15 @@ extern "C" int pz_dev_alloc(pz_ctx* ctx, size_t bytes, void** d_out) {
             }
         }
     }
-    HIPCHK(ctx, pz_hip_malloc(ctx, d_out, bytes));
+    {
+        hipError_t e = pz_hip_malloc(ctx, d_out, bytes);
+        if (e == hipErrorOutOfMemory && ws_msm_held(ctx)) {
+            (void)hipGetLastError();
+            HIPCHK(ctx, ws_release_msm(ctx));
+            e = pz_hip_malloc(ctx, d_out, bytes);
+        }
+        HIPCHK(ctx, e);
+    }
     if (ctx->dev_cache_limit && bytes >= PZ_DEV_CACHE_MIN) ctx->dev_live[*d_out] = bytes;
     return PZ_OK;
 }

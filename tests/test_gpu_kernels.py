@@ -576,6 +576,47 @@ def test_dev_arena(cref):
         e.close()
 
 
+def test_caller_allocation_takes_the_msm_workspaces_back(cref):
+    """the MSM's grow-only workspaces are a cache: a pz_dev_alloc that fits neither beside them nor in what the driver has left makes the
+    library give them back and succeeds; the next MSM sizes its column groups for what is free then and gives the same points"""
+    import paillier_halo2_amd as pz
+
+    GiB = 1 << 30
+    e = pz.Engine(0)
+    try:
+        n, cols = 1 << 13, 96
+        free0, _ = e.dev_mem_info()
+        size = free0 - GiB - (GiB >> 1)                                    # the arena takes all but 1.5 GiB of the device
+        e.dev_arena(size)
+        bases = cref.walk_bases(n, 0xABC, 0x135)
+        tb = e.load_bases(bases)
+        rng = np.random.default_rng(8)
+        sc = rng.integers(0, 1 << 63, size=(cols, n, 4), dtype=np.uint64)
+        sc[:, :, 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
+        d_sc, d_out = e.dev_alloc(sc.nbytes), e.dev_alloc(cols * 96)
+        e.upload(d_sc, sc)
+        e.msm_dev(tb, d_sc, cols, n, 4 * n, d_out)
+        e.sync()
+        first = e.g1_normalize(e.download(d_out, (cols, 12)))
+        assert np.array_equal(first[0], cref.g1_normalize(cref.msm_g1(sc[0], bases)))
+        held = e.dev_arena_info()
+        assert held["used"] > 150 << 20                                    # the sort's and the tree's workspaces among it
+        want = held["largest_hole"] + (64 << 20)                           # fits neither beside them nor in the driver's 1.5 GiB ...
+        assert want > e.dev_mem_info()[0]
+        big = e.dev_alloc(want)                                            # ... but does once they are given back
+        after = e.dev_arena_info()
+        assert after["missed"] > held["missed"] and after["used"] >= want
+        e.dev_memset(d_out, 0, cols * 96)
+        e.msm_dev(tb, d_sc, cols, n, 4 * n, d_out)                         # smaller groups now; the same points
+        e.sync()
+        assert np.array_equal(e.g1_normalize(e.download(d_out, (cols, 12))), first)
+        for d in (big, d_sc, d_out):
+            e.dev_free(d)
+        tb.free()
+    finally:
+        e.close()
+
+
 def test_dev_arena_random_traffic():
     """pz_dev_arena under 6000 random allocations and frees of mixed sizes, half of the frees from a second thread through a second
     context: live blocks never overlap and stay inside the arena, the accounting matches, and once everything is freed the arena is one hole"""
