@@ -231,7 +231,7 @@ static hipError_t arena_give(pz_arena* a, void* d) {
     bool last = false;
     {
         std::lock_guard<std::mutex> lk(a->mu);
-        a->live.erase(off);
+        if (a->live.erase(off) != 1) return hipErrorInvalidValue;   // two threads freed the same block: the second one loses
         a->used -= len;
         last = a->orphan && a->live.empty();
         auto nx = a->holes.lower_bound(off);
