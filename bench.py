@@ -1575,8 +1575,9 @@ def connected_line(args, R):
         "config": {
             "workload": "%s: %d-bit n, ONE CONNECTED KZG proof per GPU per step at k=%d (K3 trace -> K4 break-point columns -> create_proof's phases in order, "
                         "a transcript round trip per phase)" % (shape_name, args.enc_bits, args.k),
-            "scope": "one connected proof (keygen once per key and message shape, outside: keygen_ms; the transcript is a hashing stand-in with halo2's "
-                     "round trips, not its byte format)",
+            "scope": "one connected proof (keygen once per key and message shape, outside: keygen_ms; the transcript is halo2's Blake2b transcript in its "
+                     "primitives and round trips -- BLAKE2b-512, its personalisation, domain bytes and wide-reduced challenges -- over Montgomery words, "
+                     "not its byte format; the checker re-derives every challenge from the proof)",
             "enc_bits": args.enc_bits, "k": args.k, "lookup_bits": cw.lb, "limb_bits": 64, "mul_mod_steps": cw.n_steps,
             "minimum_rows": cw.minimum_rows, "max_rows": cw.cs.max_rows, "advice_cols": cw.A, "advice_cols_filled": cw.cs.n_adv_used,
             "lookup_cols": cw.Lk, "permutation_cols": cw.m, "permutation_sets": cw.pk.n_sets,
